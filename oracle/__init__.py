@@ -1,0 +1,280 @@
+"""oracle -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+ctypes loaders for the two CPU checkers:
+
+* ``port``  -- ``liblsqr_oracle.so``: the plain-C restatement in ``lsqr_oracle.c``
+  (builds anywhere with gcc; pinned bit-for-bit by ``tests/test_oracle_golden.py``).
+* ``ref``   -- ``_ref/libref_lsqr.so``: the unmodified reference compiled from
+  ``/root/reference/src`` by ``oracle/Makefile`` (prebuilt; travels to the GPU box
+  as a binary only).  ``ref()`` returns ``None`` when it is not there.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of
+``bench.py`` may import this package.  Nothing under ``lsqr_amd/`` does.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from dataclasses import dataclass, field
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LOG_STRIDE = 12  # ORACLE_LOG_STRIDE
+
+_i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+_f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+
+
+def build(quiet: bool = True) -> None:
+    """Compile the checker libraries (``make -C oracle``)."""
+    subprocess.run(["make", "-C", _HERE], check=True,
+                   stdout=subprocess.DEVNULL if quiet else None)
+
+
+@dataclass
+class Result:
+    """Outputs of one ``solve`` (src/lsqr.f90:207-223)."""
+    x: np.ndarray
+    istop: int
+    itn: int
+    anorm: float
+    acond: float
+    rnorm: float
+    arnorm: float
+    xnorm: float
+    se: np.ndarray | None = None
+    log: np.ndarray | None = field(default=None, repr=False)
+
+
+def _coo(irow, icol, a):
+    irow = np.ascontiguousarray(irow, dtype=np.int32)
+    icol = np.ascontiguousarray(icol, dtype=np.int32)
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    assert irow.shape == icol.shape == a.shape
+    return irow, icol, a
+
+
+class _Port:
+    """The C restatement (lsqr_oracle.c)."""
+    kind = "port"
+
+    def __init__(self, path: str):
+        L = C.CDLL(path)
+        self.L = L
+        L.oracle_dnrm2.restype = C.c_double
+        L.oracle_dnrm2.argtypes = [C.c_int, _f64p, C.c_int]
+        L.oracle_ddot.restype = C.c_double
+        L.oracle_ddot.argtypes = [C.c_int, _f64p, C.c_int, _f64p, C.c_int]
+        L.oracle_dscal.restype = None
+        L.oracle_dscal.argtypes = [C.c_int, C.c_double, _f64p, C.c_int]
+        L.oracle_dcopy.restype = None
+        L.oracle_dcopy.argtypes = [C.c_int, _f64p, C.c_int, _f64p, C.c_int]
+        L.oracle_d2norm.restype = C.c_double
+        L.oracle_d2norm.argtypes = [C.c_double, C.c_double]
+        L.oracle_aprod.restype = C.c_int
+        L.oracle_aprod.argtypes = [C.c_int, C.c_int, C.c_int, C.c_longlong, _i32p, _i32p, _f64p,
+                                   _f64p, _f64p, _f64p]
+        L.oracle_validate.restype = C.c_int
+        L.oracle_validate.argtypes = [C.c_int, C.c_int, C.c_longlong, _i32p, _i32p]
+        L.oracle_lsqr_ez.restype = C.c_int
+        L.oracle_lsqr_ez.argtypes = [C.c_int, C.c_int, C.c_longlong, _i32p, _i32p, _f64p, _f64p,
+                                     C.c_double, C.c_double, C.c_double, C.c_double, C.c_int,
+                                     C.c_int, _f64p, _f64p] + [C.c_void_p] * 7 + [C.c_void_p, C.c_int]
+        L.oracle_acheck.restype = C.c_int
+        L.oracle_acheck.argtypes = [C.c_int, C.c_int, C.c_longlong, _i32p, _i32p, _f64p, C.c_double,
+                                    C.c_void_p]
+        L.oracle_xcheck.restype = C.c_int
+        L.oracle_xcheck.argtypes = [C.c_int, C.c_int, C.c_longlong, _i32p, _i32p, _f64p, C.c_double,
+                                    C.c_double, C.c_double, _f64p, _f64p, _f64p, _f64p, _f64p, _f64p]
+
+    # BLAS-1 -------------------------------------------------------------
+    def dnrm2(self, x, incx=1, n=None):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        n = (len(x) + incx - 1) // incx if n is None else n
+        return float(self.L.oracle_dnrm2(n, x, incx))
+
+    def ddot(self, x, y):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        return float(self.L.oracle_ddot(len(x), x, 1, y, 1))
+
+    def dscal(self, da, x):
+        x = np.array(x, dtype=np.float64)
+        self.L.oracle_dscal(len(x), float(da), x, 1)
+        return x
+
+    def dcopy(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y = np.empty_like(x)
+        self.L.oracle_dcopy(len(x), x, 1, y, 1)
+        return y
+
+    def d2norm(self, a, b):
+        return float(self.L.oracle_d2norm(float(a), float(b)))
+
+    # operator -----------------------------------------------------------
+    def validate(self, m, n, irow, icol):
+        irow = np.ascontiguousarray(irow, dtype=np.int32)
+        icol = np.ascontiguousarray(icol, dtype=np.int32)
+        return int(self.L.oracle_validate(m, n, len(irow), irow, icol))
+
+    def aprod(self, mode, m, n, irow, icol, a, x, y):
+        """Returns the updated (x, y) copies: mode 1 -> y += A x, mode 2 -> x += A' y."""
+        irow, icol, a = _coo(irow, icol, a)
+        x = np.array(x, dtype=np.float64)
+        y = np.array(y, dtype=np.float64)
+        scratch = np.empty(max(m, n, 1))
+        rc = self.L.oracle_aprod(mode, m, n, len(a), irow, icol, a, x, y, scratch)
+        if rc:
+            raise ValueError("invalid mode in aprod_ez")
+        return x, y
+
+    def solve(self, m, n, irow, icol, a, b, damp=0.0, atol=0.0, btol=0.0, conlim=0.0,
+              itnlim=100, wantse=False, want_log=False) -> Result:
+        irow, icol, a = _coo(irow, icol, a)
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        assert b.shape == (m,)
+        x = np.zeros(max(n, 1))
+        se = np.zeros(max(n, 1))
+        istop, itn = C.c_int(), C.c_int()
+        sc = [C.c_double() for _ in range(5)]
+        log = np.zeros((itnlim, LOG_STRIDE)) if want_log else None
+        rc = self.L.oracle_lsqr_ez(m, n, len(a), irow, icol, a, b, damp, atol, btol, conlim, itnlim,
+                                   int(wantse), x, se, C.addressof(istop), C.addressof(itn),
+                                   *[C.addressof(s) for s in sc],
+                                   log.ctypes.data if want_log else None, itnlim if want_log else 0)
+        if rc:
+            raise MemoryError("oracle_lsqr_ez")
+        return Result(x[:n], istop.value, itn.value, *[s.value for s in sc],
+                      se=se[:n] if wantse else None,
+                      log=log[:itn.value] if want_log else None)
+
+    def acheck(self, m, n, irow, icol, a, eps=np.finfo(np.float64).eps):
+        irow, icol, a = _coo(irow, icol, a)
+        err = C.c_double()
+        inform = self.L.oracle_acheck(m, n, len(a), irow, icol, a, eps, C.addressof(err))
+        return int(inform), err.value
+
+    def xcheck(self, m, n, irow, icol, a, anorm, damp, b, x, eps=np.finfo(np.float64).eps):
+        irow, icol, a = _coo(irow, icol, a)
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        u, v, w, tests = np.zeros(m), np.zeros(n), np.zeros(n), np.zeros(3)
+        inform = self.L.oracle_xcheck(m, n, len(a), irow, icol, a, anorm, damp, eps, b, x, u, v, w, tests)
+        return int(inform), tests, u, v, w
+
+
+class _Ref:
+    """The unmodified reference behind oracle/ref_shim.f90."""
+    kind = "reference"
+
+    def __init__(self, path: str):
+        L = C.CDLL(path)
+        self.L = L
+        L.ref_dnrm2.restype = C.c_double
+        L.ref_dnrm2.argtypes = [C.c_int, _f64p, C.c_int]
+        L.ref_ddot.restype = C.c_double
+        L.ref_ddot.argtypes = [C.c_int, _f64p, C.c_int, _f64p, C.c_int]
+        L.ref_dscal.restype = None
+        L.ref_dscal.argtypes = [C.c_int, C.c_double, _f64p, C.c_int]
+        L.ref_dcopy.restype = None
+        L.ref_dcopy.argtypes = [C.c_int, _f64p, C.c_int, _f64p, C.c_int]
+        L.ref_aprod.restype = None
+        L.ref_aprod.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, _i32p, _i32p, _f64p, _f64p, _f64p]
+        L.ref_lsqr_ez.restype = None
+        L.ref_lsqr_ez.argtypes = [C.c_int, C.c_int, C.c_int, _i32p, _i32p, _f64p, _f64p, C.c_double,
+                                  C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, _f64p, _f64p] + \
+                                 [C.c_void_p] * 7 + [C.c_char_p, C.c_int]
+        L.ref_acheck.restype = None
+        L.ref_acheck.argtypes = [C.c_int, C.c_int, C.c_int, _i32p, _i32p, _f64p, C.c_double, C.c_void_p]
+        L.ref_xcheck.restype = None
+        L.ref_xcheck.argtypes = [C.c_int, C.c_int, C.c_int, _i32p, _i32p, _f64p, C.c_double, C.c_double,
+                                 C.c_double, _f64p, _f64p, _f64p, _f64p, _f64p, C.c_void_p, _f64p]
+
+    def dnrm2(self, x, incx=1, n=None):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        n = (len(x) + incx - 1) // incx if n is None else n
+        return float(self.L.ref_dnrm2(n, x, incx))
+
+    def ddot(self, x, y):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        return float(self.L.ref_ddot(len(x), x, 1, y, 1))
+
+    def dscal(self, da, x):
+        x = np.array(x, dtype=np.float64)
+        self.L.ref_dscal(len(x), float(da), x, 1)
+        return x
+
+    def dcopy(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y = np.empty_like(x)
+        self.L.ref_dcopy(len(x), x, 1, y, 1)
+        return y
+
+    def aprod(self, mode, m, n, irow, icol, a, x, y):
+        irow, icol, a = _coo(irow, icol, a)
+        x = np.array(x, dtype=np.float64)
+        y = np.array(y, dtype=np.float64)
+        self.L.ref_aprod(mode, m, n, len(a), irow, icol, a, x, y)
+        return x, y
+
+    def solve(self, m, n, irow, icol, a, b, damp=0.0, atol=0.0, btol=0.0, conlim=0.0,
+              itnlim=100, wantse=False, logpath: str | None = None) -> Result:
+        irow, icol, a = _coo(irow, icol, a)
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        x = np.zeros(max(n, 1))
+        se = np.zeros(max(n, 1))
+        istop, itn = C.c_int(), C.c_int()
+        sc = [C.c_double() for _ in range(5)]
+        lp = logpath.encode() if logpath else b""
+        self.L.ref_lsqr_ez(m, n, len(a), irow, icol, a, b, damp, atol, btol, conlim, itnlim,
+                           int(wantse), x, se, C.addressof(istop), C.addressof(itn),
+                           *[C.addressof(s) for s in sc], lp, len(lp))
+        return Result(x[:n], istop.value, itn.value, *[s.value for s in sc],
+                      se=se[:n] if wantse else None)
+
+    def acheck(self, m, n, irow, icol, a, eps=np.finfo(np.float64).eps):
+        irow, icol, a = _coo(irow, icol, a)
+        inform = C.c_int()
+        self.L.ref_acheck(m, n, len(a), irow, icol, a, eps, C.addressof(inform))
+        return inform.value
+
+    def xcheck(self, m, n, irow, icol, a, anorm, damp, b, x, eps=np.finfo(np.float64).eps):
+        irow, icol, a = _coo(irow, icol, a)
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        u, v, w, tests = np.zeros(m), np.zeros(n), np.zeros(n), np.zeros(3)
+        inform = C.c_int()
+        self.L.ref_xcheck(m, n, len(a), irow, icol, a, anorm, damp, eps, b, x, u, v, w,
+                          C.addressof(inform), tests)
+        return inform.value, tests, u, v, w
+
+
+_port = None
+_ref = None
+
+
+def port() -> _Port:
+    """The C restatement; built on demand (gcc only)."""
+    global _port
+    if _port is None:
+        path = os.path.join(_HERE, "liblsqr_oracle.so")
+        src = os.path.join(_HERE, "lsqr_oracle.c")
+        if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
+            build()
+        _port = _Port(path)
+    return _port
+
+
+def ref() -> _Ref | None:
+    """The compiled reference, or None when oracle/_ref was not built/shipped."""
+    global _ref
+    if _ref is None:
+        path = os.path.join(_HERE, "_ref", "libref_lsqr.so")
+        if not os.path.exists(path):
+            return None
+        _ref = _Ref(path)
+    return _ref

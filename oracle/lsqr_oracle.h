@@ -1,0 +1,38 @@
+/* oracle/lsqr_oracle.h -- TEST INFRASTRUCTURE (see lsqr_oracle.c header). */
+#ifndef LSQR_ORACLE_H
+#define LSQR_ORACLE_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* doubles per per-iteration log record: itn, x(1), rnorm, test1, test2, anorm,
+ * acond, phi, dknorm, dxk, alfopt, istop(before the nconv rule) */
+#define ORACLE_LOG_STRIDE 12
+
+void oracle_dcopy(int n, const double *dx, int incx, double *dy, int incy);
+double oracle_ddot(int n, const double *dx, int incx, const double *dy, int incy);
+double oracle_dnrm2(int n, const double *x, int incx);
+void oracle_dscal(int n, double da, double *dx, int incx);
+double oracle_d2norm(double a, double b);
+
+int oracle_aprod(int mode, int m, int n, long long nnz, const int *irow, const int *icol,
+                 const double *a, double *x, double *y, double *scratch);
+int oracle_validate(int m, int n, long long nnz, const int *irow, const int *icol);
+
+int oracle_lsqr_ez(int m, int n, long long nnz, const int *irow, const int *icol, const double *a,
+                   const double *b, double damp, double atol, double btol, double conlim,
+                   int itnlim, int wantse, double *x, double *se, int *istop, int *itn,
+                   double *anorm, double *acond, double *rnorm, double *arnorm, double *xnorm,
+                   double *log, int logcap);
+
+int oracle_acheck(int m, int n, long long nnz, const int *irow, const int *icol, const double *a,
+                  double eps, double *err_out);
+int oracle_xcheck(int m, int n, long long nnz, const int *irow, const int *icol, const double *a,
+                  double anorm, double damp, double eps, const double *b, const double *x,
+                  double *u, double *v, double *w, double *tests);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
