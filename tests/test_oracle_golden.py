@@ -123,8 +123,8 @@ def test_d2norm_properties():
     # src/lsqr.f90:1164-1179 (private in the reference: pinned through anorm/rnorm above)
     po = oracle.port()
     assert po.d2norm(0.0, 0.0) == 0.0
-    assert po.d2norm(3.0, 4.0) == 5.0
-    assert po.d2norm(-3.0, 4.0) == 5.0
+    assert abs(po.d2norm(3.0, 4.0) - 5.0) <= 4 * np.finfo(float).eps * 5.0   # scaled form is not exact
+    assert po.d2norm(-3.0, 4.0) == po.d2norm(3.0, 4.0)
     assert np.isfinite(po.d2norm(1e300, 1e300))
     assert po.d2norm(1e-300, 1e-300) > 0.0
 
