@@ -1,0 +1,160 @@
+#!/usr/bin/env python3
+"""bench.py -- LSQR iterations/s + aprod SpMV GB/s on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is ONE LSQR iteration (mode-1 SpMV + mode-2 SpMV + x/w update + the scalar
+recurrences) over the whole system.  The timed region is one `solve` of exactly K
+iterations (atol = btol = conlim = 0, itnlim = K -> istop = 5) with the matrix, b and x
+already resident in HBM; W warm-up iterations run first as a separate solve.
+
+N = 1 workload: BASELINE.json configs[1] -- 1M x 1M 5-point Poisson (nnz 4 996 000),
+damp = 0.  N > 1: the row-block sharded solve (lsqr_amd/dist.py).
+
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel = mode-1 CSR SpMV, live HIP
+event timing) and `cpu_baseline` (the reference's own CPU path, 1 core, bounded sample).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=40)
+    ap.add_argument("--workload", default="auto",
+                    help="auto | poisson2d:NX:NY | random:M:N:PER_ROW | powerlaw:M:N:DMAX")
+    ap.add_argument("--cpu-iters", type=int, default=300, help="iterations of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def make_problem(spec: str):
+    from lsqr_amd import problems as P
+    kind, *a = spec.split(":")
+    if kind == "poisson2d":
+        return P.poisson2d(int(a[0]), int(a[1]))
+    if kind == "random":
+        return P.random_rows(int(a[0]), int(a[1]), int(a[2]), damp=1e-3)
+    if kind == "powerlaw":
+        return P.powerlaw_rows(int(a[0]), int(a[1]), dmax=int(a[2]))
+    raise SystemExit(f"unknown workload {spec}")
+
+
+def cpu_baseline(p, iters: int):
+    """The reference's CPU path on the same system, 1 core (it has no threading)."""
+    import oracle
+    rf = oracle.ref()
+    eng, kind = (rf, "reference") if rf is not None else (oracle.port(), "port")
+    t0 = time.perf_counter()
+    r = eng.solve(p.m, p.n, p.irow, p.icol, p.a, p.b, damp=p.damp, itnlim=iters)
+    dt = time.perf_counter() - t0
+    assert r.itn == iters, (r.itn, r.istop)
+    return {"value": r.itn / dt, "unit": "it/s", "cores": 1, "kind": kind,
+            "sample": f"{p.name}: same (irow,icol,a,b), {iters} iterations in {dt:.2f} s, "
+                      f"{'oracle/_ref (reference compiled with amdflang -O2)' if kind == 'reference' else 'oracle C port'}"}
+
+
+def run_single(args):
+    import torch
+    from lsqr_amd import capi
+    from lsqr_amd.solver import lsqr_solver_ez
+
+    if not torch.cuda.is_available() or capi.device_count() < 1:
+        raise SystemExit("bench.py: no MI355X visible; the HIP path has no CPU fallback")
+    spec = "poisson2d:1000:1000" if args.workload == "auto" else args.workload
+    p = make_problem(spec)
+    K, W = args.steps, args.warmup
+
+    s = lsqr_solver_ez().initialize(p.m, p.n, p.a, p.irow, p.icol, itnlim=K)
+    d_b = capi.DeviceBuffer.from_array(p.b)
+    d_x = capi.DeviceBuffer(8 * max(p.n, 1))
+    # graph batches that divide K exactly: no predicated-off tail iterations in the timed solve
+    gi = next(g for g in (20, 16, 10, 8, 5, 4, 2, 1) if K % g == 0)
+    s.set_option("graph_iters", gi)
+
+    if W > 0:
+        s.itnlim = W
+        s.solve_device(d_b.ptr.value, d_x.ptr.value, p.damp)
+    s.itnlim = K
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    r = s.solve_device(d_b.ptr.value, d_x.ptr.value, p.damp)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert r.itn == K and r.istop == 5, (r.itn, r.istop)
+    tm = s.last_timing()
+
+    out = {
+        "metric": "lsqr_iterations_per_sec", "value": K / dt, "unit": "it/s", "n_gpus": 1,
+        "steps": K, "warmup": W, "ms_per_step": 1e3 * dt / K, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"{p.name} m={p.m} n={p.n} nnz={p.nnz} damp={p.damp} "
+                               f"(BASELINE.json configs[1])" if spec == "poisson2d:1000:1000" else
+                               f"{p.name} m={p.m} n={p.n} nnz={p.nnz} damp={p.damp}",
+                   "graph_iters": gi, "device_loop_ms": tm.loop_ms},
+        "result": {"istop": r.istop, "itn": r.itn, "anorm": r.anorm, "rnorm": r.rnorm},
+        "iter_bytes": tm.spmv1_bytes + tm.spmv2_bytes + tm.vec_bytes,
+        "iter_gbps": (tm.spmv1_bytes + tm.spmv2_bytes + tm.vec_bytes) * K / dt / 1e9,
+    }
+
+    if not args.no_roofline:
+        # Same K iterations again, eager launches with HIP events around each hot kernel
+        # (recorded on the stream the kernels run on).
+        s.set_option("time_kernels", 1)
+        r2 = s.solve_device(d_b.ptr.value, d_x.ptr.value, p.damp)
+        t2 = s.last_timing()
+        s.set_option("time_kernels", 0)
+        assert r2.itn == K and r2.anorm == r.anorm
+        avg1 = t2.spmv1_ms / max(t2.spmv1_launches, 1)
+        avg2 = t2.spmv2_ms / max(t2.spmv2_launches, 1)
+        avg3 = t2.update_ms / max(t2.update_launches, 1)
+        ach = t2.spmv1_bytes / (avg1 * 1e-3) / 1e9
+        traffic = None
+        tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tp):
+            try:
+                traffic = json.load(open(tp)).get(spec, {}).get("spmv_mode1_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out["roofline"] = {"bound": "hbm", "kernel": "k_spmv_fused (aprod mode 1, CSR of A)",
+                           "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                           "traffic": traffic, "bytes_per_launch": t2.spmv1_bytes,
+                           "avg_launch_us": avg1 * 1e3, "launches": t2.spmv1_launches}
+        out["kernels"] = {
+            "spmv_mode2": {"avg_launch_us": avg2 * 1e3, "bytes_per_launch": t2.spmv2_bytes,
+                           "gbps": t2.spmv2_bytes / (avg2 * 1e-3) / 1e9},
+            "update_xw": {"avg_launch_us": avg3 * 1e3, "bytes_per_launch": t2.vec_bytes,
+                          "gbps": t2.vec_bytes / (avg3 * 1e-3) / 1e9},
+        }
+
+    if args.cpu_iters > 0:
+        out["cpu_baseline"] = cpu_baseline(p, args.cpu_iters)
+    print(json.dumps(out), flush=True)
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 or world > 1:
+        from lsqr_amd.dist_bench import run_distributed
+        run_distributed(args)
+    else:
+        run_single(args)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,176 @@
+/*
+ * lsqrhip.h -- C-ABI of the MI355X-native LSQR hot path (liblsqrhip.so).
+ *
+ * This is the drop-in boundary for the reference's `lsqr_solver_ez` path
+ * (jacobwilliams/LSQR).  Each entry point names the reference interface it
+ * replaces (paths relative to the reference root).  Plain pointers and sizes
+ * only; host code in any language binds these (Fortran ISO_C_BINDING shim:
+ * lsqr_amd/fortran/lsqr_module.f90; Python ctypes: lsqr_amd/capi.py; see
+ * INTEGRATION.md).
+ *
+ * Conventions
+ *   - every function returns an int status: 0 = ok, 1..5 = the reference's own
+ *     `error stop` conditions (same ordinal as listed below), >= 10 = runtime
+ *     failures (no device, HIP error, allocation).  There is NO CPU fallback:
+ *     without a usable gfx950 device every compute entry point fails with
+ *     LSQRHIP_ERR_NO_DEVICE.
+ *   - COO indices are 1-based (Fortran), vectors are dense fp64.
+ *   - pointers named d_* are device pointers; all others are host pointers.
+ *   - one handle = one matrix on one GPU with its own HIP stream; calls on one
+ *     handle are blocking and must not be issued concurrently (the reference
+ *     object carries scratch the same way, src/lsqr.f90:54-58).
+ */
+#ifndef LSQRHIP_H
+#define LSQRHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct lsqrhip_handle_s *lsqrhip_handle_t;
+
+/* status codes --------------------------------------------------------- */
+#define LSQRHIP_OK 0
+#define LSQRHIP_ERR_SIZES 1     /* 'invalid a,icol,irow sizes in initialize_ez'   src/lsqr.f90:109 */
+#define LSQRHIP_ERR_IROW 2      /* 'invalid irow or m in initialize_ez'           src/lsqr.f90:110 */
+#define LSQRHIP_ERR_ICOL 3      /* 'invalid icol or n in initialize_ez'           src/lsqr.f90:111 */
+#define LSQRHIP_ERR_NOT_INIT 4  /* 'lsqr_solver_ez class not properly initialized' src/lsqr.f90:152 */
+#define LSQRHIP_ERR_MODE 5      /* 'invalid mode in aprod_ez'                     src/lsqr.f90:197 */
+#define LSQRHIP_ERR_NO_DEVICE 10
+#define LSQRHIP_ERR_HIP 11
+#define LSQRHIP_ERR_ALLOC 12
+#define LSQRHIP_ERR_ARG 13
+#define LSQRHIP_ERR_TOO_LARGE 14
+
+/* The reference's message for codes 1..5 (verbatim `error stop` strings), a
+ * short description otherwise. */
+const char *lsqrhip_error_string(int code);
+/* Detail of the last failure on the calling thread (HIP error text etc.). */
+const char *lsqrhip_last_error(void);
+
+/* Number of usable gfx950 devices (0 when none; never initialises a context). */
+int lsqrhip_device_count(void);
+/* Select the device later handles are created on (default 0). */
+int lsqrhip_set_device(int device);
+
+/* ---------------------------------------------------------------------- */
+/* initialize_ez                     replaces src/lsqr.f90:91-127           */
+/* ---------------------------------------------------------------------- */
+/* Validates like the reference (irow > m -> 2, icol > n -> 3; additionally
+ * indices < 1, which the reference leaves unchecked and would read out of
+ * bounds on, are rejected with the same codes), deep-copies the COO triplets
+ * to the device and builds CSR(A) and CSR(A') there (stable: entries of a row
+ * keep their COO order, duplicates are kept and therefore summed exactly as
+ * src/lsqr.f90:168-172 sums them).  The caller may free its arrays afterwards. */
+int lsqrhip_create(int m, int n, int64_t nnz, const int *irow, const int *icol, const double *a,
+                   lsqrhip_handle_t *out);
+
+/* Same, from COO triplets that already live on the device (1-based). */
+int lsqrhip_create_from_device_coo(int m, int n, int64_t nnz, const int *d_irow, const int *d_icol,
+                                   const double *d_a, lsqrhip_handle_t *out);
+
+/* Releases every device resource of the handle (the reference has no finaliser;
+ * its allocatables auto-free, src/lsqr.f90:42-58). */
+int lsqrhip_destroy(lsqrhip_handle_t h);
+
+/* Matrix facts: dims[0..5] = m, n, nnz, bytes of CSR(A), bytes of CSR(A'),
+ * bytes per row pointer (4 or 8). */
+int lsqrhip_info(lsqrhip_handle_t h, int64_t *dims);
+
+/* ---------------------------------------------------------------------- */
+/* solve_ez + LSQR                   replaces src/lsqr.f90:207-259, 432-882 */
+/* ---------------------------------------------------------------------- */
+/* b[m] in, x[n] out, se[n] out iff wantse != 0 (else untouched, may be NULL).
+ * atol/btol/conlim/itnlim are the values `initialize` stored (:121-124).
+ * want_log != 0 keeps the per-iteration record the reference would print for
+ * nout /= 0 (:813-837); fetch it with lsqrhip_log_fetch.  Any scalar output
+ * pointer may be NULL (the Fortran `optional` outputs, :217-223).
+ * Deliberate fix: when no iteration runs (istop = 0) rnorm is returned as
+ * norm(b); the reference leaves it unassigned (:646-653). */
+int lsqrhip_solve(lsqrhip_handle_t h, const double *b, double damp, double atol, double btol,
+                  double conlim, int itnlim, int wantse, int want_log, double *x, double *se,
+                  int *istop, int *itn, double *anorm, double *acond, double *rnorm,
+                  double *arnorm, double *xnorm);
+
+/* Same with b, x, se resident in HBM (no PCIe in the call). */
+int lsqrhip_solve_device(lsqrhip_handle_t h, const double *d_b, double damp, double atol,
+                         double btol, double conlim, int itnlim, int wantse, int want_log,
+                         double *d_x, double *d_se, int *istop, int *itn, double *anorm,
+                         double *acond, double *rnorm, double *arnorm, double *xnorm);
+
+/* ---------------------------------------------------------------------- */
+/* aprod_ez                          replaces src/lsqr.f90:134-200          */
+/* ---------------------------------------------------------------------- */
+/* mode 1: y[m] += A x[n] (x unchanged); mode 2: x[n] += A' y[m] (y unchanged). */
+int lsqrhip_aprod(lsqrhip_handle_t h, int mode, double *x, double *y);
+int lsqrhip_aprod_device(lsqrhip_handle_t h, int mode, double *d_x, double *d_y);
+
+/* ---------------------------------------------------------------------- */
+/* acheck / xcheck on the device operator   replaces src/lsqr.f90:908-994, 1015-1154 */
+/* ---------------------------------------------------------------------- */
+int lsqrhip_acheck(lsqrhip_handle_t h, double eps, int *inform, double *relerr);
+/* u[m], v[n], w[n] receive r = b - Ax, A'r, A'r - damp^2 x (may be NULL). tests[3]. */
+int lsqrhip_xcheck(lsqrhip_handle_t h, double anorm, double damp, double eps, const double *b,
+                   const double *x, double *u, double *v, double *w, int *inform, double *tests);
+
+/* ---------------------------------------------------------------------- */
+/* iteration log (nout /= 0)         replaces src/lsqr.f90:813-837          */
+/* ---------------------------------------------------------------------- */
+/* One record per iteration, LSQRHIP_LOG_STRIDE doubles: itn, x(1), rnorm,
+ * test1, test2, anorm, acond, phi, dknorm, dxk, alfa_opt, istop (as decided in
+ * that iteration before the nconv rule), rtol, xnorm.  Host code applies the
+ * reference's print rule (:815-822) and format strings to them. */
+#define LSQRHIP_LOG_STRIDE 14
+int lsqrhip_log_count(lsqrhip_handle_t h);
+int lsqrhip_log_fetch(lsqrhip_handle_t h, int first, int count, double *records);
+/* Scalars of the last solve that only the log prints: out[0..5] = bnorm, dxmax,
+ * maxdx, alpha(first), beta(first), test2(itn 0) (src/lsqr.f90:663-669, 875-878). */
+int lsqrhip_log_extras(lsqrhip_handle_t h, double *out);
+
+/* ---------------------------------------------------------------------- */
+/* device BLAS-1 used inside the iteration   replaces src/lsqrblas.f90:25-201 */
+/* ---------------------------------------------------------------------- */
+/* Unit-stride, device vectors; results returned to the host. */
+int lsqrhip_dnrm2(lsqrhip_handle_t h, int64_t n, const double *d_x, double *result);
+int lsqrhip_ddot(lsqrhip_handle_t h, int64_t n, const double *d_x, const double *d_y, double *result);
+int lsqrhip_dscal(lsqrhip_handle_t h, int64_t n, double da, double *d_x);
+int lsqrhip_dcopy(lsqrhip_handle_t h, int64_t n, const double *d_x, double *d_y);
+
+/* ---------------------------------------------------------------------- */
+/* measurement                                                             */
+/* ---------------------------------------------------------------------- */
+typedef struct {
+    double solve_ms;      /* whole lsqrhip_solve* call, host clock                     */
+    double loop_ms;       /* device time of the iteration loop (HIP events)            */
+    double spmv1_ms;      /* summed device time of the mode-1 SpMV kernel launches     */
+    double spmv2_ms;      /* summed device time of the mode-2 SpMV kernel launches     */
+    double update_ms;     /* summed device time of the x/w update kernel launches      */
+    int64_t spmv1_launches, spmv2_launches, update_launches;
+    int64_t spmv1_bytes;  /* algorithmic bytes of ONE mode-1 launch (B1) */
+    int64_t spmv2_bytes;  /* algorithmic bytes of ONE mode-2 launch (B2)               */
+    int64_t vec_bytes;    /* algorithmic bytes of the fused vector work per iteration  */
+    int itn;
+} lsqrhip_timing_t;
+int lsqrhip_last_timing(lsqrhip_handle_t h, lsqrhip_timing_t *t);
+
+/* Options: "graph" (1 = hipGraph-captured iteration batches [default], 0 = eager
+ * launches), "graph_iters" (iterations per captured batch), "time_kernels"
+ * (1 = eager launches with HIP events around each hot kernel, fills *_ms above). */
+int lsqrhip_set_option(lsqrhip_handle_t h, const char *name, int64_t value);
+/* Run all work of this handle on an externally owned hipStream_t (e.g. the
+ * caller's torch stream); NULL restores the handle's own stream. */
+int lsqrhip_set_stream(lsqrhip_handle_t h, void *hip_stream);
+
+/* plain device-memory helpers for hosts without their own allocator */
+int lsqrhip_dev_alloc(void **d_ptr, int64_t bytes);
+int lsqrhip_dev_free(void *d_ptr);
+int lsqrhip_dev_upload(void *d_dst, const void *src, int64_t bytes);
+int lsqrhip_dev_download(void *dst, const void *d_src, int64_t bytes);
+int lsqrhip_dev_sync(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LSQRHIP_H */

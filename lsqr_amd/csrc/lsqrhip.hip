@@ -1,0 +1,897 @@
+// lsqrhip.hip -- liblsqrhip.so: host orchestration + C-ABI (include/lsqrhip.h).
+//
+// Drop-in for the reference's lsqr_solver_ez path:
+//   lsqrhip_create  <- initialize_ez   (src/lsqr.f90:91-127)
+//   lsqrhip_solve   <- solve_ez + LSQR (src/lsqr.f90:207-259, 432-882)
+//   lsqrhip_aprod   <- aprod_ez        (src/lsqr.f90:134-200)
+// The whole iteration runs device-resident: per iteration three HBM-bound vector
+// kernels (mode-1 SpMV, mode-2 SpMV, x/w update) and three one-workgroup scalar
+// kernels, captured in batches into a hipGraph; the host only polls the stop flag
+// between batches.  There is no CPU fallback anywhere in this file.
+#include "../../include/lsqrhip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "csr_build.h"
+#include "scalar.h"
+#include "spmv.h"
+#include "state.h"
+#include "vec.h"
+
+using namespace lsqrhip;
+
+// ---------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+static int g_device = 0;
+
+static int fail(int code, const std::string &msg)
+{
+    g_last_error = msg;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                          \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess) {                                                               \
+            const int _c = (_e == hipErrorNoDevice || _e == hipErrorInvalidDevice)            \
+                               ? LSQRHIP_ERR_NO_DEVICE                                        \
+                               : (_e == hipErrorOutOfMemory ? LSQRHIP_ERR_ALLOC : LSQRHIP_ERR_HIP); \
+            return fail(_c, std::string(#expr) + ": " + hipGetErrorString(_e));               \
+        }                                                                                     \
+    } while (0)
+
+#define RET(expr)                    \
+    do {                             \
+        int _rc = (expr);            \
+        if (_rc != LSQRHIP_OK) return _rc; \
+    } while (0)
+
+extern "C" const char *lsqrhip_error_string(int code)
+{
+    switch (code) {
+    case LSQRHIP_OK: return "ok";
+    case LSQRHIP_ERR_SIZES: return "invalid a,icol,irow sizes in initialize_ez";
+    case LSQRHIP_ERR_IROW: return "invalid irow or m in initialize_ez";
+    case LSQRHIP_ERR_ICOL: return "invalid icol or n in initialize_ez";
+    case LSQRHIP_ERR_NOT_INIT: return "lsqr_solver_ez class not properly initialized";
+    case LSQRHIP_ERR_MODE: return "invalid mode in aprod_ez";
+    case LSQRHIP_ERR_NO_DEVICE: return "no usable gfx950 (MI355X) device; the HIP path has no CPU fallback";
+    case LSQRHIP_ERR_HIP: return "HIP runtime error";
+    case LSQRHIP_ERR_ALLOC: return "device memory allocation failed";
+    case LSQRHIP_ERR_ARG: return "invalid argument";
+    case LSQRHIP_ERR_TOO_LARGE: return "problem too large for this build (nnz must be < 2^32)";
+    default: return "unknown lsqrhip status";
+    }
+}
+
+extern "C" const char *lsqrhip_last_error(void) { return g_last_error.c_str(); }
+
+extern "C" int lsqrhip_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    int ok = 0;
+    for (int i = 0; i < n; ++i) {
+        hipDeviceProp_t p;
+        if (hipGetDeviceProperties(&p, i) == hipSuccess && std::strncmp(p.gcnArchName, "gfx950", 6) == 0) ++ok;
+    }
+    return ok;
+}
+
+extern "C" int lsqrhip_set_device(int device)
+{
+    if (device < 0) return fail(LSQRHIP_ERR_ARG, "negative device");
+    g_device = device;
+    return LSQRHIP_OK;
+}
+
+static int use_device()
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(LSQRHIP_ERR_NO_DEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+    if (g_device >= n) return fail(LSQRHIP_ERR_NO_DEVICE, "selected device index out of range");
+    hipDeviceProp_t p;
+    HIPCHK(hipGetDeviceProperties(&p, g_device));
+    if (std::strncmp(p.gcnArchName, "gfx950", 6) != 0)
+        return fail(LSQRHIP_ERR_NO_DEVICE, std::string("device is ") + p.gcnArchName + ", kernels are built for gfx950 only");
+    HIPCHK(hipSetDevice(g_device));
+    return LSQRHIP_OK;
+}
+
+// ---------------------------------------------------------------------------
+// handle
+// ---------------------------------------------------------------------------
+struct Csr {
+    void *rowptr = nullptr;  // int32 or int64 [rows+1]
+    int *col = nullptr;
+    double *val = nullptr;
+    int *rb = nullptr;  // row-block boundaries [nblk+1]
+    int64_t nblk = 0;
+    int rows = 0, cols = 0;
+    int grid = 0;
+    int64_t bytes = 0;
+};
+
+struct lsqrhip_handle_s {
+    int device = 0;
+    int m = 0, n = 0;
+    int64_t nnz = 0;
+    bool off64 = false;
+    Csr A, AT;
+    double *U = nullptr, *V = nullptr, *W = nullptr, *X = nullptr, *SE = nullptr;
+    double *partials = nullptr;  // SPMV_MAX_GRID
+    int vgrid_m = 1, vgrid_n = 1;
+    LsqrState *d_state = nullptr;
+    LsqrState *h_state = nullptr;  // pinned
+    SpmvCoef *d_unit = nullptr;    // (1,1,1): plain y += A x
+    int *d_zero = nullptr;         // a stop flag that is never set
+    double *d_scalar = nullptr;    // 4 doubles scratch
+    double *d_log = nullptr;
+    int log_cap = 0;
+    std::vector<double> h_log;
+    int log_count = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    // options
+    int use_graph = 1, graph_iters = 16, time_kernels = 0;
+    hipGraphExec_t gexec = nullptr;
+    int gexec_iters = 0;
+    bool graph_dirty = true;
+    std::vector<hipEvent_t> ev;
+    hipEvent_t ev_loop0 = nullptr, ev_loop1 = nullptr;
+    lsqrhip_timing_t timing{};
+};
+typedef lsqrhip_handle_s H;
+
+static int vec_grid(int64_t n)
+{
+    int64_t g = (n / 2 + VEC_BLOCK - 1) / VEC_BLOCK;
+    if (g < 1) g = 1;
+    if (g > VEC_MAX_GRID) g = VEC_MAX_GRID;
+    return (int)g;
+}
+
+static void free_csr(Csr &c)
+{
+    if (c.rowptr) (void)hipFree(c.rowptr);
+    if (c.col) (void)hipFree(c.col);
+    if (c.val) (void)hipFree(c.val);
+    if (c.rb) (void)hipFree(c.rb);
+    c = Csr();
+}
+
+static void destroy_graph(H *h)
+{
+    if (h->gexec) {
+        (void)hipGraphExecDestroy(h->gexec);
+        h->gexec = nullptr;
+    }
+    h->graph_dirty = true;
+}
+
+extern "C" int lsqrhip_destroy(lsqrhip_handle_t h)
+{
+    if (!h) return LSQRHIP_OK;
+    (void)hipSetDevice(h->device);
+    if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
+    destroy_graph(h);
+    free_csr(h->A);
+    free_csr(h->AT);
+    for (double *p : {h->U, h->V, h->W, h->X, h->SE, h->partials, h->d_scalar, h->d_log})
+        if (p) (void)hipFree(p);
+    if (h->d_state) (void)hipFree(h->d_state);
+    if (h->h_state) (void)hipHostFree(h->h_state);
+    if (h->d_unit) (void)hipFree(h->d_unit);
+    if (h->d_zero) (void)hipFree(h->d_zero);
+    for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
+    if (h->ev_loop0) (void)hipEventDestroy(h->ev_loop0);
+    if (h->ev_loop1) (void)hipEventDestroy(h->ev_loop1);
+    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+    delete h;
+    return LSQRHIP_OK;
+}
+
+// ---------------------------------------------------------------------------
+// K0: build one CSR from device COO (keys = row index of the CSR being built)
+// ---------------------------------------------------------------------------
+static int bits_for(int limit)
+{
+    int b = 1;
+    while (b < 31 && (1ll << b) < (long long)limit) ++b;
+    return b;
+}
+
+template <typename OffT>
+static int build_csr_T(hipStream_t s, const int *d_keys, const int *d_other, const double *d_a, int64_t nnz,
+                       int rows, int cols, int bad_code, unsigned long long *bufA, unsigned long long *bufB,
+                       unsigned *hist, int *d_flags, Csr &out)
+{
+    out.rows = rows;
+    out.cols = cols;
+    HIPCHK(hipMalloc(&out.rowptr, sizeof(OffT) * ((size_t)rows + 1)));
+    HIPCHK(hipMalloc((void **)&out.col, sizeof(int) * (size_t)std::max<int64_t>(nnz, 1)));
+    HIPCHK(hipMalloc((void **)&out.val, sizeof(double) * (size_t)std::max<int64_t>(nnz, 1)));
+    out.bytes = (int64_t)sizeof(OffT) * (rows + 1) + 12 * nnz;
+
+    HIPCHK(hipMemsetAsync(d_flags, 0, 2 * sizeof(int), s));
+    const int g = (int)std::min<int64_t>(std::max<int64_t>((nnz + 255) / 256, 1), 4096);
+    int flags[2] = {0, 0};
+    unsigned long long *sorted = bufA;
+    if (nnz > 0) {
+        hipLaunchKernelGGL(k_pack_keys, dim3(g), dim3(256), 0, s, d_keys, nnz, rows, bufA, d_flags);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(flags, d_flags, sizeof(flags), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        if (flags[0]) return fail(bad_code, lsqrhip_error_string(bad_code));
+        if (flags[1]) {  // not sorted by key: stable LSD radix sort on the key bits
+            const int64_t nb = (nnz + RS_TILE - 1) / RS_TILE;
+            const int nbits = bits_for(rows);
+            unsigned long long *in = bufA, *outb = bufB;
+            for (int shift = 32; shift < 32 + nbits; shift += 8) {
+                hipLaunchKernelGGL(k_radix_hist, dim3((unsigned)nb), dim3(RS_BLOCK), 0, s, in, nnz, shift, nb, hist);
+                hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, s, hist, (int64_t)256 * nb);
+                hipLaunchKernelGGL(k_radix_scatter, dim3((unsigned)nb), dim3(RS_BLOCK), 0, s, in, outb, nnz, shift, nb, hist);
+                HIPCHK(hipGetLastError());
+                std::swap(in, outb);
+            }
+            sorted = in;
+        }
+        hipLaunchKernelGGL(k_csr_gather, dim3(g), dim3(256), 0, s, sorted, nnz, d_other, d_a, out.col, out.val);
+    }
+    hipLaunchKernelGGL(k_rowptr_from_sorted<OffT>, dim3(g), dim3(256), 0, s, sorted, nnz, rows, (OffT *)out.rowptr);
+    HIPCHK(hipGetLastError());
+
+    // row blocks ("row windows", spmv.h)
+    out.nblk = std::max<int64_t>((nnz + rows + SPMV_C - 1) / SPMV_C, 1);
+    HIPCHK(hipMalloc((void **)&out.rb, sizeof(int) * (size_t)(out.nblk + 1)));
+    out.bytes += (int64_t)sizeof(int) * (out.nblk + 1);
+    const int64_t nt = out.nblk + 1;
+    hipLaunchKernelGGL(k_row_blocks<OffT>, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, s,
+                       (const OffT *)out.rowptr, rows, out.nblk, out.rb);
+    HIPCHK(hipGetLastError());
+    int64_t grid = std::min<int64_t>(out.nblk, SPMV_MAX_GRID);
+    if (grid >= 8) grid &= ~(int64_t)7;  // multiple of 8: XCD-aware mapping (common.h)
+    out.grid = (int)std::max<int64_t>(grid, 1);
+    HIPCHK(hipStreamSynchronize(s));
+    return LSQRHIP_OK;
+}
+
+static int finish_create(H *h, const int *d_irow, const int *d_icol, const double *d_a)
+{
+    hipStream_t s = h->stream;
+    const int64_t nnz = h->nnz;
+    unsigned long long *bufA = nullptr, *bufB = nullptr;
+    unsigned *hist = nullptr;
+    int *d_flags = nullptr;
+    const int64_t nb = std::max<int64_t>((nnz + RS_TILE - 1) / RS_TILE, 1);
+    HIPCHK(hipMalloc((void **)&bufA, sizeof(unsigned long long) * (size_t)std::max<int64_t>(nnz, 1)));
+    HIPCHK(hipMalloc((void **)&bufB, sizeof(unsigned long long) * (size_t)std::max<int64_t>(nnz, 1)));
+    HIPCHK(hipMalloc((void **)&hist, sizeof(unsigned) * 256 * (size_t)nb));
+    HIPCHK(hipMalloc((void **)&d_flags, 2 * sizeof(int)));
+    int rc;
+    if (h->off64) {
+        rc = build_csr_T<long long>(s, d_irow, d_icol, d_a, nnz, h->m, h->n, LSQRHIP_ERR_IROW, bufA, bufB, hist, d_flags, h->A);
+        if (rc == LSQRHIP_OK)
+            rc = build_csr_T<long long>(s, d_icol, d_irow, d_a, nnz, h->n, h->m, LSQRHIP_ERR_ICOL, bufA, bufB, hist, d_flags, h->AT);
+    } else {
+        rc = build_csr_T<int>(s, d_irow, d_icol, d_a, nnz, h->m, h->n, LSQRHIP_ERR_IROW, bufA, bufB, hist, d_flags, h->A);
+        if (rc == LSQRHIP_OK)
+            rc = build_csr_T<int>(s, d_icol, d_irow, d_a, nnz, h->n, h->m, LSQRHIP_ERR_ICOL, bufA, bufB, hist, d_flags, h->AT);
+    }
+    (void)hipFree(bufA);
+    (void)hipFree(bufB);
+    (void)hipFree(hist);
+    (void)hipFree(d_flags);
+    RET(rc);
+
+    const size_t m1 = (size_t)std::max(h->m, 1), n1 = (size_t)std::max(h->n, 1);
+    HIPCHK(hipMalloc((void **)&h->U, sizeof(double) * m1));
+    HIPCHK(hipMalloc((void **)&h->V, sizeof(double) * n1));
+    HIPCHK(hipMalloc((void **)&h->W, sizeof(double) * n1));
+    HIPCHK(hipMalloc((void **)&h->X, sizeof(double) * n1));
+    HIPCHK(hipMalloc((void **)&h->SE, sizeof(double) * n1));
+    HIPCHK(hipMalloc((void **)&h->partials, sizeof(double) * SPMV_MAX_GRID));
+    HIPCHK(hipMalloc((void **)&h->d_scalar, sizeof(double) * 4));
+    HIPCHK(hipMalloc((void **)&h->d_state, sizeof(LsqrState)));
+    HIPCHK(hipHostMalloc((void **)&h->h_state, sizeof(LsqrState)));
+    HIPCHK(hipMalloc((void **)&h->d_unit, sizeof(SpmvCoef)));
+    HIPCHK(hipMalloc((void **)&h->d_zero, sizeof(int)));
+    SpmvCoef unit{1.0, 1.0, 1.0, 0, 0};
+    HIPCHK(hipMemcpyAsync(h->d_unit, &unit, sizeof(unit), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemsetAsync(h->d_zero, 0, sizeof(int), s));
+    HIPCHK(hipEventCreate(&h->ev_loop0));
+    HIPCHK(hipEventCreate(&h->ev_loop1));
+    h->vgrid_m = vec_grid(h->m);
+    h->vgrid_n = vec_grid(h->n);
+    HIPCHK(hipStreamSynchronize(s));
+    return LSQRHIP_OK;
+}
+
+static int new_handle(int m, int n, int64_t nnz, H **out)
+{
+    if (!out) return fail(LSQRHIP_ERR_ARG, "null handle pointer");
+    *out = nullptr;
+    if (m < 0 || n < 0 || nnz < 0) return fail(LSQRHIP_ERR_ARG, "negative dimension");
+    if (nnz >= (1ll << 32)) return fail(LSQRHIP_ERR_TOO_LARGE, lsqrhip_error_string(LSQRHIP_ERR_TOO_LARGE));
+    RET(use_device());
+    H *h = new H();
+    h->device = g_device;
+    h->m = m;
+    h->n = n;
+    h->nnz = nnz;
+    h->off64 = nnz >= (1ll << 31);
+    hipError_t e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete h;
+        return fail(LSQRHIP_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
+    }
+    h->stream = h->own_stream;
+    *out = h;
+    return LSQRHIP_OK;
+}
+
+extern "C" int lsqrhip_create_from_device_coo(int m, int n, int64_t nnz, const int *d_irow, const int *d_icol,
+                                              const double *d_a, lsqrhip_handle_t *out)
+{
+    H *h = nullptr;
+    RET(new_handle(m, n, nnz, &h));
+    int rc = finish_create(h, d_irow, d_icol, d_a);
+    if (rc != LSQRHIP_OK) {
+        std::string keep = g_last_error;
+        lsqrhip_destroy(h);
+        g_last_error = keep;
+        return rc;
+    }
+    *out = h;
+    return LSQRHIP_OK;
+}
+
+extern "C" int lsqrhip_create(int m, int n, int64_t nnz, const int *irow, const int *icol, const double *a,
+                              lsqrhip_handle_t *out)
+{
+    if (!out) return fail(LSQRHIP_ERR_ARG, "null handle pointer");
+    *out = nullptr;
+    if (nnz > 0 && (!irow || !icol || !a)) return fail(LSQRHIP_ERR_SIZES, lsqrhip_error_string(LSQRHIP_ERR_SIZES));
+    RET(use_device());
+    int *d_irow = nullptr, *d_icol = nullptr;
+    double *d_a = nullptr;
+    const size_t k = (size_t)std::max<int64_t>(nnz, 1);
+    HIPCHK(hipMalloc((void **)&d_irow, sizeof(int) * k));
+    HIPCHK(hipMalloc((void **)&d_icol, sizeof(int) * k));
+    HIPCHK(hipMalloc((void **)&d_a, sizeof(double) * k));
+    if (nnz > 0) {
+        HIPCHK(hipMemcpy(d_irow, irow, sizeof(int) * (size_t)nnz, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(d_icol, icol, sizeof(int) * (size_t)nnz, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(d_a, a, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice));
+    }
+    int rc = lsqrhip_create_from_device_coo(m, n, nnz, d_irow, d_icol, d_a, out);
+    (void)hipFree(d_irow);
+    (void)hipFree(d_icol);
+    (void)hipFree(d_a);
+    return rc;
+}
+
+extern "C" int lsqrhip_info(lsqrhip_handle_t h, int64_t *dims)
+{
+    if (!h || !dims) return fail(LSQRHIP_ERR_NOT_INIT, lsqrhip_error_string(LSQRHIP_ERR_NOT_INIT));
+    dims[0] = h->m;
+    dims[1] = h->n;
+    dims[2] = h->nnz;
+    dims[3] = h->A.bytes;
+    dims[4] = h->AT.bytes;
+    dims[5] = h->off64 ? 8 : 4;
+    return LSQRHIP_OK;
+}
+
+// ---------------------------------------------------------------------------
+// kernel launch helpers
+// ---------------------------------------------------------------------------
+static void launch_spmv(H *h, const Csr &c, const double *x, double *y, const SpmvCoef *coef, const int *stop)
+{
+    if (h->off64)
+        hipLaunchKernelGGL(k_spmv_fused<long long>, dim3(c.grid), dim3(SPMV_BLOCK), 0, h->stream,
+                           (const long long *)c.rowptr, c.col, c.val, c.rb, c.nblk, x, y, coef, stop, h->partials);
+    else
+        hipLaunchKernelGGL(k_spmv_fused<int>, dim3(c.grid), dim3(SPMV_BLOCK), 0, h->stream,
+                           (const int *)c.rowptr, c.col, c.val, c.rb, c.nblk, x, y, coef, stop, h->partials);
+}
+
+// one LSQR iteration = 6 launches; `ev` (optional) gets 6 events: before/after each vector kernel
+static void launch_iteration(H *h, hipEvent_t *ev)
+{
+    LsqrState *st = h->d_state;
+    hipStream_t s = h->stream;
+    if (ev) (void)hipEventRecord(ev[0], s);
+    launch_spmv(h, h->A, h->V, h->U, &st->c1, &st->stop);  // U <- (-alpha)(U su) + A (V sv)
+    if (ev) (void)hipEventRecord(ev[1], s);
+    hipLaunchKernelGGL(k_s1<true>, dim3(1), dim3(SC_BLOCK), 0, s, h->partials, h->A.grid, st);
+    if (ev) (void)hipEventRecord(ev[2], s);
+    launch_spmv(h, h->AT, h->U, h->V, &st->c2, &st->stop);  // V <- (-beta)(V sv) + A'(U su)
+    if (ev) (void)hipEventRecord(ev[3], s);
+    hipLaunchKernelGGL(k_s2<true>, dim3(1), dim3(SC_BLOCK), 0, s, h->partials, h->AT.grid, st);
+    if (ev) (void)hipEventRecord(ev[4], s);
+    hipLaunchKernelGGL(k_update, dim3(h->vgrid_n), dim3(VEC_BLOCK), 0, s, h->X, h->W, h->V, h->SE, (int64_t)h->n,
+                       (const LsqrState *)st, h->partials);
+    if (ev) (void)hipEventRecord(ev[5], s);
+    hipLaunchKernelGGL(k_s3<true>, dim3(1), dim3(SC_BLOCK), 0, s, h->partials, h->vgrid_n, st, h->X, h->d_log);
+}
+
+static int ensure_graph(H *h)
+{
+    if (h->gexec && !h->graph_dirty && h->gexec_iters == h->graph_iters) return LSQRHIP_OK;
+    destroy_graph(h);
+    hipGraph_t g = nullptr;
+    HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+    for (int i = 0; i < h->graph_iters; ++i) launch_iteration(h, nullptr);
+    HIPCHK(hipStreamEndCapture(h->stream, &g));
+    hipError_t e = hipGraphInstantiate(&h->gexec, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    if (e != hipSuccess) return fail(LSQRHIP_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
+    h->gexec_iters = h->graph_iters;
+    h->graph_dirty = false;
+    return LSQRHIP_OK;
+}
+
+// ---------------------------------------------------------------------------
+// solve
+// ---------------------------------------------------------------------------
+static int solve_core(H *h, const double *b, bool b_on_device, double damp, double atol, double btol, double conlim,
+                      int itnlim, int wantse, int want_log, double *x, double *se, bool out_on_device, int *istop,
+                      int *itn, double *anorm, double *acond, double *rnorm, double *arnorm, double *xnorm)
+{
+    if (!h) return fail(LSQRHIP_ERR_NOT_INIT, lsqrhip_error_string(LSQRHIP_ERR_NOT_INIT));
+    if (!istop || (!x && h->n > 0) || (!b && h->m > 0)) return fail(LSQRHIP_ERR_ARG, "null b, x or istop");
+    if (wantse && !se) return fail(LSQRHIP_ERR_ARG, "wantse set but se is null");
+    HIPCHK(hipSetDevice(h->device));
+    const auto t_host0 = std::chrono::steady_clock::now();
+    hipStream_t s = h->stream;
+    const int m = h->m, n = h->n;
+    LsqrState *st = h->d_state;
+
+    if (want_log) {
+        const int cap = std::max(itnlim, 1);
+        if (cap > h->log_cap) {
+            if (h->d_log) (void)hipFree(h->d_log);
+            h->d_log = nullptr;
+            HIPCHK(hipMalloc((void **)&h->d_log, sizeof(double) * LOG_STRIDE * (size_t)cap));
+            h->log_cap = cap;
+            h->graph_dirty = true;
+        }
+    }
+    h->log_count = 0;
+
+    // ---- initial state (src/lsqr.f90:597-617) -------------------------------
+    LsqrState init;
+    std::memset(&init, 0, sizeof(init));
+    init.itnlim = itnlim;
+    init.damped = damp > 0.0;
+    init.wantse = wantse != 0;
+    init.want_log = want_log != 0;
+    init.log_cap = h->log_cap;
+    init.m = m;
+    init.n = n;
+    init.damp = damp;
+    init.atol = atol;
+    init.btol = btol;
+    init.ctol = conlim > 0.0 ? 1.0 / conlim : 0.0;
+    init.cs2 = -1.0;
+    init.su = init.sv = 1.0;
+    init.c1.skip = 1;
+    init.c2.skip = 1;
+    *h->h_state = init;
+    HIPCHK(hipMemcpyAsync(st, h->h_state, sizeof(LsqrState), hipMemcpyHostToDevice, s));
+
+    // u = b (solve_ez :242); v = 0, x = 0, se = 0 (:621-630)
+    if (m > 0)
+        HIPCHK(hipMemcpyAsync(h->U, b, sizeof(double) * (size_t)m,
+                              b_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
+    if (n > 0) {
+        HIPCHK(hipMemsetAsync(h->V, 0, sizeof(double) * (size_t)n, s));
+        HIPCHK(hipMemsetAsync(h->X, 0, sizeof(double) * (size_t)n, s));
+        HIPCHK(hipMemsetAsync(h->W, 0, sizeof(double) * (size_t)n, s));
+        if (wantse) HIPCHK(hipMemsetAsync(h->SE, 0, sizeof(double) * (size_t)n, s));
+    }
+    // beta = norm(u); u /= beta; v = A'u; alpha = norm(v); v /= alpha; w = v  (:632-644)
+    hipLaunchKernelGGL(k_dot, dim3(h->vgrid_m), dim3(VEC_BLOCK), 0, s, h->U, h->U, (int64_t)m, h->partials);
+    hipLaunchKernelGGL(k_s_init1<true>, dim3(1), dim3(SC_BLOCK), 0, s, h->partials, h->vgrid_m, st);
+    launch_spmv(h, h->AT, h->U, h->V, &st->c2, h->d_zero);
+    hipLaunchKernelGGL(k_s_init2<true>, dim3(1), dim3(SC_BLOCK), 0, s, h->partials, h->AT.grid, st);
+    hipLaunchKernelGGL(k_copy_scale, dim3(h->vgrid_n), dim3(VEC_BLOCK), 0, s, h->W, h->V, (int64_t)n,
+                       (const LsqrState *)st);
+    HIPCHK(hipGetLastError());
+
+    // ---- the loop (src/lsqr.f90:673-852) ------------------------------------
+    lsqrhip_timing_t &tm = h->timing;
+    tm = lsqrhip_timing_t{};
+    const int P = h->off64 ? 8 : 4;
+    tm.spmv1_bytes = 12 * h->nnz + (int64_t)P * (m + 1) + 8ll * n + 16ll * m;
+    tm.spmv2_bytes = 12 * h->nnz + (int64_t)P * (n + 1) + 8ll * m + 16ll * n;
+    tm.vec_bytes = 40ll * n + (wantse ? 16ll * n : 0);
+
+    const int G = std::max(1, h->graph_iters);
+    const bool timed = h->time_kernels != 0;
+    const bool graph = h->use_graph != 0 && !timed;
+    if (graph) RET(ensure_graph(h));
+    if (timed && (int)h->ev.size() < 6 * G) {
+        const size_t old = h->ev.size();
+        h->ev.resize(6 * (size_t)G);
+        for (size_t i = old; i < h->ev.size(); ++i) HIPCHK(hipEventCreate(&h->ev[i]));
+    }
+    HIPCHK(hipEventRecord(h->ev_loop0, s));
+    // S3 raises `stop` at itn == itnlim at the latest; anything beyond this many batches
+    // means the device loop is not advancing (never spin on a dead stream).
+    const int64_t max_batches = (int64_t)std::max(itnlim, 0) / G + 2;
+    for (int64_t batch = 0;; ++batch) {
+        if (batch > max_batches) return fail(LSQRHIP_ERR_HIP, "iteration loop did not terminate (device state not advancing)");
+        if (graph) {
+            HIPCHK(hipGraphLaunch(h->gexec, s));
+        } else {
+            for (int i = 0; i < G; ++i) launch_iteration(h, timed ? &h->ev[6 * (size_t)i] : nullptr);
+            HIPCHK(hipGetLastError());
+        }
+        HIPCHK(hipMemcpyAsync(h->h_state, st, sizeof(LsqrState), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        if (timed) {
+            // iterations after the stop flag was raised are no-op launches: count only live ones
+            const int live = std::min(G, h->h_state->itn - (int)tm.spmv1_launches);
+            for (int i = 0; i < live; ++i) {
+                float a = 0, c = 0, d = 0;
+                (void)hipEventElapsedTime(&a, h->ev[6 * i + 0], h->ev[6 * i + 1]);
+                (void)hipEventElapsedTime(&c, h->ev[6 * i + 2], h->ev[6 * i + 3]);
+                (void)hipEventElapsedTime(&d, h->ev[6 * i + 4], h->ev[6 * i + 5]);
+                tm.spmv1_ms += a;
+                tm.spmv2_ms += c;
+                tm.update_ms += d;
+            }
+            tm.spmv1_launches += live;
+            tm.spmv2_launches += live;
+            tm.update_launches += live;
+        }
+        if (h->h_state->stop != 0) break;
+    }
+    HIPCHK(hipEventRecord(h->ev_loop1, s));
+
+    // ---- epilogue: se (:857-865), istop 2 -> 3 (:871), outputs --------------
+    if (wantse && n > 0)
+        hipLaunchKernelGGL(k_se_finish, dim3(h->vgrid_n), dim3(VEC_BLOCK), 0, s, h->SE, (int64_t)n,
+                           (const LsqrState *)st);
+    const hipMemcpyKind out_kind = out_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+    if (n > 0) HIPCHK(hipMemcpyAsync(x, h->X, sizeof(double) * (size_t)n, out_kind, s));
+    if (wantse && n > 0) HIPCHK(hipMemcpyAsync(se, h->SE, sizeof(double) * (size_t)n, out_kind, s));
+    const LsqrState &r = *h->h_state;
+    if (want_log && r.itn > 0) {
+        h->log_count = std::min(r.itn, h->log_cap);
+        h->h_log.resize((size_t)h->log_count * LOG_STRIDE);
+        HIPCHK(hipMemcpyAsync(h->h_log.data(), h->d_log, sizeof(double) * h->h_log.size(), hipMemcpyDeviceToHost, s));
+    }
+    HIPCHK(hipStreamSynchronize(s));
+    float loop_ms = 0;
+    (void)hipEventElapsedTime(&loop_ms, h->ev_loop0, h->ev_loop1);
+    tm.loop_ms = loop_ms;
+    tm.itn = r.itn;
+    if (!timed) {
+        tm.spmv1_launches = tm.spmv2_launches = tm.update_launches = r.itn;
+    }
+
+    int is = r.istop;
+    if (r.damped && is == 2) is = 3;
+    *istop = is;
+    if (itn) *itn = r.itn;
+    if (anorm) *anorm = r.anorm;
+    if (acond) *acond = r.acond;
+    if (rnorm) *rnorm = r.rnorm;
+    if (arnorm) *arnorm = r.arnorm;
+    if (xnorm) *xnorm = r.xnorm;
+    tm.solve_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_host0).count();
+    return LSQRHIP_OK;
+}
+
+extern "C" int lsqrhip_solve(lsqrhip_handle_t h, const double *b, double damp, double atol, double btol,
+                             double conlim, int itnlim, int wantse, int want_log, double *x, double *se, int *istop,
+                             int *itn, double *anorm, double *acond, double *rnorm, double *arnorm, double *xnorm)
+{
+    return solve_core(h, b, false, damp, atol, btol, conlim, itnlim, wantse, want_log, x, se, false, istop, itn,
+                      anorm, acond, rnorm, arnorm, xnorm);
+}
+
+extern "C" int lsqrhip_solve_device(lsqrhip_handle_t h, const double *d_b, double damp, double atol, double btol,
+                                    double conlim, int itnlim, int wantse, int want_log, double *d_x, double *d_se,
+                                    int *istop, int *itn, double *anorm, double *acond, double *rnorm,
+                                    double *arnorm, double *xnorm)
+{
+    return solve_core(h, d_b, true, damp, atol, btol, conlim, itnlim, wantse, want_log, d_x, d_se, true, istop, itn,
+                      anorm, acond, rnorm, arnorm, xnorm);
+}
+
+// ---------------------------------------------------------------------------
+// aprod
+// ---------------------------------------------------------------------------
+extern "C" int lsqrhip_aprod_device(lsqrhip_handle_t h, int mode, double *d_x, double *d_y)
+{
+    if (!h) return fail(LSQRHIP_ERR_NOT_INIT, lsqrhip_error_string(LSQRHIP_ERR_NOT_INIT));
+    if (mode != 1 && mode != 2) return fail(LSQRHIP_ERR_MODE, lsqrhip_error_string(LSQRHIP_ERR_MODE));
+    HIPCHK(hipSetDevice(h->device));
+    if (mode == 1) launch_spmv(h, h->A, d_x, d_y, h->d_unit, h->d_zero);   // y += A x
+    else launch_spmv(h, h->AT, d_y, d_x, h->d_unit, h->d_zero);            // x += A' y
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return LSQRHIP_OK;
+}
+
+extern "C" int lsqrhip_aprod(lsqrhip_handle_t h, int mode, double *x, double *y)
+{
+    if (!h) return fail(LSQRHIP_ERR_NOT_INIT, lsqrhip_error_string(LSQRHIP_ERR_NOT_INIT));
+    if (mode != 1 && mode != 2) return fail(LSQRHIP_ERR_MODE, lsqrhip_error_string(LSQRHIP_ERR_MODE));
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    // borrow the solver's work vectors: V (n) for x, U (m) for y
+    if (h->n > 0) HIPCHK(hipMemcpyAsync(h->V, x, sizeof(double) * (size_t)h->n, hipMemcpyHostToDevice, s));
+    if (h->m > 0) HIPCHK(hipMemcpyAsync(h->U, y, sizeof(double) * (size_t)h->m, hipMemcpyHostToDevice, s));
+    RET(lsqrhip_aprod_device(h, mode, h->V, h->U));
+    if (mode == 1 && h->m > 0) HIPCHK(hipMemcpyAsync(y, h->U, sizeof(double) * (size_t)h->m, hipMemcpyDeviceToHost, s));
+    if (mode == 2 && h->n > 0) HIPCHK(hipMemcpyAsync(x, h->V, sizeof(double) * (size_t)h->n, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return LSQRHIP_OK;
+}
+
+// ---------------------------------------------------------------------------
+// device BLAS-1 (unit stride)
+// ---------------------------------------------------------------------------
+static int dev_dot(H *h, int64_t n, const double *d_x, const double *d_y, double *result)
+{
+    *result = 0.0;
+    if (n <= 0) return LSQRHIP_OK;
+    const int g = vec_grid(n);
+    hipLaunchKernelGGL(k_dot, dim3(g), dim3(VEC_BLOCK), 0, h->stream, d_x, d_y, n, h->partials);
+    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(VEC_BLOCK), 0, h->stream, (const double *)h->partials, g,
+                       h->d_scalar);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(result, h->d_scalar, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return LSQRHIP_OK;
+}
+
+extern "C" int lsqrhip_dnrm2(lsqrhip_handle_t h, int64_t n, const double *d_x, double *result)
+{
+    if (!h || !result) return fail(LSQRHIP_ERR_NOT_INIT, lsqrhip_error_string(LSQRHIP_ERR_NOT_INIT));
+    HIPCHK(hipSetDevice(h->device));
+    double ss = 0.0;
+    RET(dev_dot(h, n, d_x, d_x, &ss));
+    *result = std::sqrt(ss);
+    return LSQRHIP_OK;
+}
+
+extern "C" int lsqrhip_ddot(lsqrhip_handle_t h, int64_t n, const double *d_x, const double *d_y, double *result)
+{
+    if (!h || !result) return fail(LSQRHIP_ERR_NOT_INIT, lsqrhip_error_string(LSQRHIP_ERR_NOT_INIT));
+    HIPCHK(hipSetDevice(h->device));
+    return dev_dot(h, n, d_x, d_y, result);
+}
+
+extern "C" int lsqrhip_dscal(lsqrhip_handle_t h, int64_t n, double da, double *d_x)
+{
+    if (!h) return fail(LSQRHIP_ERR_NOT_INIT, lsqrhip_error_string(LSQRHIP_ERR_NOT_INIT));
+    if (n <= 0) return LSQRHIP_OK;
+    HIPCHK(hipSetDevice(h->device));
+    hipLaunchKernelGGL(k_scale, dim3(vec_grid(n)), dim3(VEC_BLOCK), 0, h->stream, d_x, n, da);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return LSQRHIP_OK;
+}
+
+extern "C" int lsqrhip_dcopy(lsqrhip_handle_t h, int64_t n, const double *d_x, double *d_y)
+{
+    if (!h) return fail(LSQRHIP_ERR_NOT_INIT, lsqrhip_error_string(LSQRHIP_ERR_NOT_INIT));
+    if (n <= 0) return LSQRHIP_OK;
+    HIPCHK(hipSetDevice(h->device));
+    hipLaunchKernelGGL(k_copy, dim3(vec_grid(n)), dim3(VEC_BLOCK), 0, h->stream, d_x, d_y, n);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return LSQRHIP_OK;
+}
+
+// ---------------------------------------------------------------------------
+// acheck / xcheck on the device operator
+// ---------------------------------------------------------------------------
+struct DevVec {
+    double *p = nullptr;
+    ~DevVec()
+    {
+        if (p) (void)hipFree(p);
+    }
+    int alloc(int64_t n)
+    {
+        hipError_t e = hipMalloc((void **)&p, sizeof(double) * (size_t)std::max<int64_t>(n, 1));
+        return e == hipSuccess ? LSQRHIP_OK : fail(LSQRHIP_ERR_ALLOC, hipGetErrorString(e));
+    }
+};
+
+extern "C" int lsqrhip_acheck(lsqrhip_handle_t h, double eps, int *inform, double *relerr)
+{
+    if (!h || !inform) return fail(LSQRHIP_ERR_NOT_INIT, lsqrhip_error_string(LSQRHIP_ERR_NOT_INIT));
+    HIPCHK(hipSetDevice(h->device));
+    const int64_t m = h->m, n = h->n;
+    hipStream_t s = h->stream;
+    DevVec v, w, x, y;
+    RET(v.alloc(n)); RET(w.alloc(m)); RET(x.alloc(n)); RET(y.alloc(m));
+    const double tol = std::pow(eps, 0.5);                                      // src/lsqr.f90:939
+    hipLaunchKernelGGL(k_acheck_fill, dim3(vec_grid(n)), dim3(VEC_BLOCK), 0, s, x.p, n, 0);   // :946-950
+    hipLaunchKernelGGL(k_acheck_fill, dim3(vec_grid(m)), dim3(VEC_BLOCK), 0, s, y.p, m, 1);   // :952-956
+    double alfa = 0, beta = 0;
+    RET(lsqrhip_dnrm2(h, n, x.p, &alfa));                                       // :958-961
+    RET(lsqrhip_dnrm2(h, m, y.p, &beta));
+    RET(lsqrhip_dscal(h, n, 1.0 / alfa, x.p));
+    RET(lsqrhip_dscal(h, m, 1.0 / beta, y.p));
+    RET(lsqrhip_dcopy(h, m, y.p, w.p));                                         // :969-972
+    RET(lsqrhip_dcopy(h, n, x.p, v.p));
+    RET(lsqrhip_aprod_device(h, 1, x.p, w.p));
+    RET(lsqrhip_aprod_device(h, 2, v.p, y.p));
+    RET(lsqrhip_ddot(h, m, y.p, w.p, &alfa));                                   // :976-980
+    RET(lsqrhip_ddot(h, n, x.p, v.p, &beta));
+    const double test1 = std::fabs(alfa - beta);
+    const double test2 = 1.0 + std::fabs(alfa) + std::fabs(beta);
+    const double test3 = test1 / test2;
+    if (relerr) *relerr = test3;
+    *inform = test3 <= tol ? 0 : 1;                                             // :984-992
+    return LSQRHIP_OK;
+}
+
+extern "C" int lsqrhip_xcheck(lsqrhip_handle_t h, double anorm, double damp, double eps, const double *b,
+                              const double *x, double *u, double *v, double *w, int *inform, double *tests)
+{
+    if (!h || !inform || !tests) return fail(LSQRHIP_ERR_NOT_INIT, lsqrhip_error_string(LSQRHIP_ERR_NOT_INIT));
+    HIPCHK(hipSetDevice(h->device));
+    const int64_t m = h->m, n = h->n;
+    hipStream_t s = h->stream;
+    DevVec db, dx, du, dv, dw;
+    RET(db.alloc(m)); RET(dx.alloc(n)); RET(du.alloc(m)); RET(dv.alloc(n)); RET(dw.alloc(n));
+    if (m > 0) HIPCHK(hipMemcpyAsync(db.p, b, sizeof(double) * (size_t)m, hipMemcpyHostToDevice, s));
+    if (n > 0) HIPCHK(hipMemcpyAsync(dx.p, x, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, s));
+    const double dampsq = damp * damp, tol = std::pow(eps, 0.5);
+    RET(lsqrhip_dcopy(h, m, db.p, du.p));                                       // :1073-1076
+    RET(lsqrhip_dscal(h, m, -1.0, du.p));
+    RET(lsqrhip_aprod_device(h, 1, dx.p, du.p));
+    RET(lsqrhip_dscal(h, m, -1.0, du.p));
+    if (n > 0) HIPCHK(hipMemsetAsync(dv.p, 0, sizeof(double) * (size_t)n, s));  // :1080-1083
+    RET(lsqrhip_aprod_device(h, 2, dv.p, du.p));
+    RET(lsqrhip_dcopy(h, n, dv.p, dw.p));                                       // :1089-1094
+    if (damp != 0.0 && n > 0) {
+        hipLaunchKernelGGL(k_axpy, dim3(vec_grid(n)), dim3(VEC_BLOCK), 0, s, dw.p, (const double *)dx.p, n, -dampsq);
+        HIPCHK(hipGetLastError());
+    }
+    double bnorm, xnorm, rho1, sigma1, rho2, sigma2;
+    RET(lsqrhip_dnrm2(h, m, db.p, &bnorm));                                     // :1098-1101
+    RET(lsqrhip_dnrm2(h, n, dx.p, &xnorm));
+    RET(lsqrhip_dnrm2(h, m, du.p, &rho1));
+    RET(lsqrhip_dnrm2(h, n, dv.p, &sigma1));
+    if (damp == 0.0) {                                                          // :1110-1124
+        rho2 = rho1;
+        sigma2 = sigma1;
+    } else {
+        rho2 = std::sqrt(rho1 * rho1 + dampsq * (xnorm * xnorm));
+        RET(lsqrhip_dnrm2(h, n, dw.p, &sigma2));
+    }
+    double test1, test2, test3;
+    if (bnorm == 0.0 && xnorm == 0.0) {                                         // :1129-1144
+        *inform = 0;
+        test1 = test2 = test3 = 0.0;
+    } else {
+        *inform = 4;
+        test1 = rho1 / (bnorm + anorm * xnorm);
+        test2 = 0.0;
+        if (rho1 > 0.0) test2 = sigma1 / (anorm * rho1);
+        test3 = test2;
+        if (rho2 > 0.0) test3 = sigma2 / (anorm * rho2);
+        if (test3 <= tol) *inform = 3;
+        if (test2 <= tol) *inform = 2;
+        if (test1 <= tol) *inform = 1;
+    }
+    tests[0] = test1;
+    tests[1] = test2;
+    tests[2] = test3;
+    if (u && m > 0) HIPCHK(hipMemcpyAsync(u, du.p, sizeof(double) * (size_t)m, hipMemcpyDeviceToHost, s));
+    if (v && n > 0) HIPCHK(hipMemcpyAsync(v, dv.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, s));
+    if (w && n > 0) HIPCHK(hipMemcpyAsync(w, dw.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return LSQRHIP_OK;
+}
+
+// ---------------------------------------------------------------------------
+// log, timing, options, memory helpers
+// ---------------------------------------------------------------------------
+extern "C" int lsqrhip_log_count(lsqrhip_handle_t h) { return h ? h->log_count : 0; }
+
+extern "C" int lsqrhip_log_fetch(lsqrhip_handle_t h, int first, int count, double *records)
+{
+    if (!h || !records) return fail(LSQRHIP_ERR_ARG, "null handle or buffer");
+    if (first < 0 || count < 0 || first + count > h->log_count) return fail(LSQRHIP_ERR_ARG, "log range out of bounds");
+    std::memcpy(records, h->h_log.data() + (size_t)first * LOG_STRIDE, sizeof(double) * LOG_STRIDE * (size_t)count);
+    return LSQRHIP_OK;
+}
+
+extern "C" int lsqrhip_log_extras(lsqrhip_handle_t h, double *out)
+{
+    if (!h || !out || !h->h_state) return fail(LSQRHIP_ERR_ARG, "null handle or buffer");
+    const LsqrState &r = *h->h_state;
+    out[0] = r.bnorm;
+    out[1] = r.dxmax;
+    out[2] = (double)r.maxdx;
+    out[3] = r.alpha0;
+    out[4] = r.beta0;
+    out[5] = r.test2_0;
+    return LSQRHIP_OK;
+}
+
+extern "C" int lsqrhip_last_timing(lsqrhip_handle_t h, lsqrhip_timing_t *t)
+{
+    if (!h || !t) return fail(LSQRHIP_ERR_ARG, "null handle or buffer");
+    *t = h->timing;
+    return LSQRHIP_OK;
+}
+
+extern "C" int lsqrhip_set_option(lsqrhip_handle_t h, const char *name, int64_t value)
+{
+    if (!h || !name) return fail(LSQRHIP_ERR_ARG, "null handle or option name");
+    const std::string k(name);
+    if (k == "graph") h->use_graph = value != 0;
+    else if (k == "graph_iters") {
+        if (value < 1 || value > 1024) return fail(LSQRHIP_ERR_ARG, "graph_iters must be in [1,1024]");
+        h->graph_iters = (int)value;
+    } else if (k == "time_kernels") h->time_kernels = value != 0;
+    else return fail(LSQRHIP_ERR_ARG, "unknown option: " + k);
+    return LSQRHIP_OK;
+}
+
+extern "C" int lsqrhip_set_stream(lsqrhip_handle_t h, void *hip_stream)
+{
+    if (!h) return fail(LSQRHIP_ERR_ARG, "null handle");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+    destroy_graph(h);
+    return LSQRHIP_OK;
+}
+
+extern "C" int lsqrhip_dev_alloc(void **d_ptr, int64_t bytes)
+{
+    if (!d_ptr || bytes < 0) return fail(LSQRHIP_ERR_ARG, "bad alloc request");
+    RET(use_device());
+    HIPCHK(hipMalloc(d_ptr, (size_t)std::max<int64_t>(bytes, 8)));
+    return LSQRHIP_OK;
+}
+
+extern "C" int lsqrhip_dev_free(void *d_ptr)
+{
+    if (d_ptr) HIPCHK(hipFree(d_ptr));
+    return LSQRHIP_OK;
+}
+
+extern "C" int lsqrhip_dev_upload(void *d_dst, const void *src, int64_t bytes)
+{
+    if (bytes > 0) HIPCHK(hipMemcpy(d_dst, src, (size_t)bytes, hipMemcpyHostToDevice));
+    return LSQRHIP_OK;
+}
+
+extern "C" int lsqrhip_dev_download(void *dst, const void *d_src, int64_t bytes)
+{
+    if (bytes > 0) HIPCHK(hipMemcpy(dst, d_src, (size_t)bytes, hipMemcpyDeviceToHost));
+    return LSQRHIP_OK;
+}
+
+extern "C" int lsqrhip_dev_sync(void)
+{
+    HIPCHK(hipDeviceSynchronize());
+    return LSQRHIP_OK;
+}

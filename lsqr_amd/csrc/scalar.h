@@ -1,0 +1,242 @@
+// scalar.h -- the scalar recurrences of LSQR as one-workgroup kernels.
+//
+// Replaces reference src/lsqr.f90:597-617, 632-653 (initialisation), :687-689
+// (anorm), :703-721 (damping + QR rotation), :751-810 (estimates, stopping tests),
+// :843-850 (nconv rule), :871 (istop 2 -> 3) and d2norm (:1164-1179).
+//
+// Each kernel first reduces the per-workgroup partials of the preceding vector
+// kernel in a fixed order (template REDUCE = true), or takes an already reduced /
+// all-reduced sum from the state (REDUCE = false, multi-GPU), then thread 0 runs
+// the ~60 flops of scalar work and publishes the coefficients the next vector
+// kernel needs.  Nothing here ever leaves the device during the loop.
+#pragma once
+
+#include "common.h"
+#include "state.h"
+
+namespace lsqrhip {
+
+constexpr int SC_BLOCK = 256;
+
+__device__ __forceinline__ double d2norm(double a, double b)  // src/lsqr.f90:1164-1179
+{
+    const double scale = fabs(a) + fabs(b);
+    if (scale == 0.0) return 0.0;
+    const double p = a / scale, q = b / scale;
+    return scale * sqrt(p * p + q * q);
+}
+
+template <bool REDUCE>
+__device__ __forceinline__ double take_sum(const double *partials, int np, const double *pre)
+{
+    __shared__ double red[SC_BLOCK / WAVE];
+    if (!REDUCE) return *pre;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < np; i += SC_BLOCK) s += partials[i];
+    return block_sum<SC_BLOCK>(s, red);  // valid in thread 0
+}
+
+// after sum(b^2): beta = norm(b); u = b/beta     (src/lsqr.f90:597-617, 632-637)
+template <bool REDUCE>
+__global__ __launch_bounds__(SC_BLOCK) void k_s_init1(const double *partials, int np, LsqrState *st)
+{
+    const double sum = take_sum<REDUCE>(partials, np, &st->sum_u);
+    if (threadIdx.x != 0) return;
+    const double beta = sqrt(sum);
+    st->beta = beta;
+    st->alpha = 0.0;
+    st->sv = 1.0;
+    if (beta > 0.0) {
+        st->su = 1.0 / beta;
+        st->c2.sx = st->su;  // V <- 0*(V*1) + A'(U*su), V pre-zeroed
+        st->c2.sy = 1.0;
+        st->c2.cy = 0.0;
+        st->c2.skip = 0;
+    } else {
+        st->su = 1.0;
+        st->c2.skip = 1;
+    }
+}
+
+// after sum(V^2): alpha = norm(A'u); v = V/alpha; arnorm; loop entry     (:638-653)
+template <bool REDUCE>
+__global__ __launch_bounds__(SC_BLOCK) void k_s_init2(const double *partials, int np, LsqrState *st)
+{
+    const bool skipped = st->c2.skip != 0;
+    const double sum = take_sum<REDUCE>(partials, np, &st->sum_v);
+    if (threadIdx.x != 0) return;
+    const double beta = st->beta;
+    const double alpha = skipped ? 0.0 : sqrt(sum);
+    st->alpha = alpha;
+    st->sv = alpha > 0.0 ? 1.0 / alpha : 1.0;
+    st->arnorm = alpha * beta;
+    // the reference leaves these unassigned when the loop is skipped; define them
+    st->bnorm = beta;
+    st->rnorm = beta;
+    st->alpha0 = alpha;
+    st->beta0 = beta;
+    st->test2_0 = beta > 0.0 ? alpha / beta : 0.0;
+    if (st->arnorm == 0.0) {
+        st->stop = 1;  // istop stays 0: x = 0 is the exact solution
+        return;
+    }
+    st->rhobar = alpha;
+    st->phibar = beta;
+    st->c1.sx = st->sv;
+    st->c1.sy = st->su;
+    st->c1.cy = -alpha;
+    st->c1.skip = 0;
+}
+
+// after mode 1: beta = norm(A v - alpha u); anorm     (:675, :683-693)
+template <bool REDUCE>
+__global__ __launch_bounds__(SC_BLOCK) void k_s1(const double *partials, int np, LsqrState *st)
+{
+    if (st->stop != 0) return;
+    const double sum = take_sum<REDUCE>(partials, np, &st->sum_u);
+    if (threadIdx.x != 0) return;
+    st->itn = st->itn + 1;
+    const double alpha = st->alpha;
+    const double beta = sqrt(sum);
+    st->beta = beta;
+    double temp = d2norm(alpha, beta);
+    temp = d2norm(temp, st->damp);
+    st->anorm = d2norm(st->anorm, temp);
+    if (beta > 0.0) {
+        st->su = 1.0 / beta;
+        st->c2.sx = st->su;
+        st->c2.sy = st->sv;
+        st->c2.cy = -beta;
+        st->c2.skip = 0;
+    } else {
+        st->su = 1.0;
+        st->c2.skip = 1;
+    }
+}
+
+// after mode 2: alpha = norm(A'u - beta v); plane rotations; update coefficients   (:695-726)
+template <bool REDUCE>
+__global__ __launch_bounds__(SC_BLOCK) void k_s2(const double *partials, int np, LsqrState *st)
+{
+    if (st->stop != 0) return;
+    const bool skipped = st->c2.skip != 0;
+    const double sum = take_sum<REDUCE>(partials, np, &st->sum_v);
+    if (threadIdx.x != 0) return;
+    double alpha = st->alpha;
+    const double beta = st->beta;
+    if (!skipped) {
+        alpha = sqrt(sum);
+        st->alpha = alpha;
+        st->sv = alpha > 0.0 ? 1.0 / alpha : 1.0;
+    }
+    const double damp = st->damp;
+    double phibar = st->phibar;
+    double rhbar1 = st->rhobar;
+    if (st->damped) {
+        rhbar1 = d2norm(st->rhobar, damp);
+        const double cs1 = st->rhobar / rhbar1;
+        const double sn1 = damp / rhbar1;
+        st->psi = sn1 * phibar;
+        phibar = cs1 * phibar;
+    }
+    const double rho = d2norm(rhbar1, beta);
+    const double cs = rhbar1 / rho;
+    const double sn = beta / rho;
+    const double theta = sn * alpha;
+    st->rhobar = -cs * alpha;
+    const double phi = cs * phibar;
+    st->phibar = sn * phibar;
+    st->tau = sn * phi;
+    st->rho = rho;
+    st->phi = phi;
+    st->theta = theta;
+    st->t1 = phi / rho;
+    st->t2 = -theta / rho;
+    st->t3 = 1.0 / rho;
+    st->c1.sx = st->sv;
+    st->c1.sy = st->su;
+    st->c1.cy = -alpha;
+    st->c1.skip = 0;
+}
+
+// after the x/w update: dknorm, norm estimates, stopping tests, istop   (:751-810, 843-850)
+template <bool REDUCE>
+__global__ __launch_bounds__(SC_BLOCK) void k_s3(const double *partials, int np, LsqrState *st,
+                                                 const double *x, double *log)
+{
+    if (st->stop != 0) return;
+    const double sum = take_sum<REDUCE>(partials, np, &st->sum_d);
+    if (threadIdx.x != 0) return;
+    const int itn = st->itn;
+    const double rho = st->rho, phi = st->phi, theta = st->theta, tau = st->tau;
+    const double alpha = st->alpha;
+
+    const double dknorm = sqrt(sum);
+    const double dnorm = d2norm(st->dnorm, dknorm);
+    st->dnorm = dnorm;
+    const double dxk = fabs(phi * dknorm);
+    if (st->dxmax < dxk) {
+        st->dxmax = dxk;
+        st->maxdx = itn;
+    }
+
+    const double delta = st->sn2 * rho;
+    const double gambar = -st->cs2 * rho;
+    const double rhs = phi - delta * st->z;
+    const double zbar = rhs / gambar;
+    const double xnorm = d2norm(st->xnorm1, zbar);
+    const double gamma = d2norm(gambar, theta);
+    st->cs2 = gambar / gamma;
+    st->sn2 = theta / gamma;
+    st->z = rhs / gamma;
+    st->xnorm1 = d2norm(st->xnorm1, st->z);
+    st->xnorm = xnorm;
+
+    const double anorm = st->anorm, bnorm = st->bnorm;
+    const double acond = anorm * dnorm;
+    st->acond = acond;
+    st->res2 = d2norm(st->res2, st->psi);
+    const double rnorm = d2norm(st->res2, st->phibar);
+    st->rnorm = rnorm;
+    const double arnorm = alpha * fabs(tau);
+    st->arnorm = arnorm;
+
+    const double alfopt = sqrt(rnorm / (dnorm * xnorm));
+    const double test1 = rnorm / bnorm;
+    double test2 = 0.0;
+    if (rnorm > 0.0) test2 = arnorm / (anorm * rnorm);
+    const double test3 = 1.0 / acond;
+    double t1 = test1 / (1.0 + anorm * xnorm / bnorm);
+    const double rtol = st->btol + st->atol * anorm * xnorm / bnorm;
+
+    const double t3 = 1.0 + test3;
+    const double t2 = 1.0 + test2;
+    t1 = 1.0 + t1;
+    int istop = st->istop;
+    if (itn >= st->itnlim) istop = 5;
+    if (t3 <= 1.0) istop = 4;
+    if (t2 <= 1.0) istop = 2;
+    if (t1 <= 1.0) istop = 1;
+    if (test3 <= st->ctol) istop = 4;
+    if (test2 <= st->atol) istop = 2;
+    if (test1 <= rtol) istop = 1;
+
+    if (st->want_log && itn <= st->log_cap) {
+        double *r = log + (size_t)(itn - 1) * LOG_STRIDE;
+        r[0] = (double)itn; r[1] = x[0]; r[2] = rnorm; r[3] = test1; r[4] = test2; r[5] = anorm;
+        r[6] = acond; r[7] = phi; r[8] = dknorm; r[9] = dxk; r[10] = alfopt; r[11] = (double)istop;
+        r[12] = rtol; r[13] = xnorm;
+    }
+
+    if (istop == 0) {
+        st->nstop = 0;
+    } else {
+        const int nconv = 1;
+        st->nstop = st->nstop + 1;
+        if (st->nstop < nconv && itn < st->itnlim) istop = 0;
+    }
+    st->istop = istop;
+    if (istop != 0) st->stop = 1;
+}
+
+}  // namespace lsqrhip

@@ -1,0 +1,54 @@
+// state.h -- device-resident scalar state of one LSQR solve.
+//
+// All ~35 scalars of the reference's iteration (src/lsqr.f90:565-574) live in
+// one struct in HBM.  The vector kernels read their coefficients from it and
+// the one-workgroup scalar kernels advance it, so an iteration needs no host
+// round trip; the host only polls `stop` between captured batches.
+#pragma once
+
+#include <stdint.h>
+
+namespace lsqrhip {
+
+// y_new = cy * (y * sy) + sum_j A_ij * (x_j * sx)      (see spmv.h)
+struct SpmvCoef {
+    double sx, sy, cy;
+    int skip;  // launch is a no-op (mode 2 when beta == 0, src/lsqr.f90:691)
+    int pad;
+};
+
+struct LsqrState {
+    // control ------------------------------------------------------------
+    int stop;      // != 0: every kernel of the loop returns at once
+    int istop;     // src/lsqr.f90:520-538
+    int itn;
+    int nstop;
+    int itnlim;
+    int maxdx;
+    int damped;
+    int wantse;
+    int want_log;
+    int log_cap;
+    int m, n;
+    // user tolerances ------------------------------------------------------
+    double damp, atol, btol, ctol;
+    // Golub-Kahan scalars ----------------------------------------------------
+    double alpha, beta;
+    double su;  // pending scale of U: u = U * su   (1/beta, or 1 when beta == 0)
+    double sv;  // pending scale of V: v = V * sv   (1/alpha, or 1 when alpha == 0)
+    SpmvCoef c1;    // mode-1 launch of the next iteration: U <- (-alpha)*(U*su) + A (V*sv)
+    SpmvCoef c2;    // mode-2 launch of this iteration:     V <- (-beta)*(V*sv) + A'(U*su)
+    // rotations / estimates (names as in the reference) ------------------------
+    double rhobar, phibar, anorm, acond, dnorm, dxmax, res2, psi;
+    double xnorm, xnorm1, cs2, sn2, z, bnorm, rnorm, arnorm;
+    double rho, phi, theta, tau;  // S2 -> S3
+    double t1, t2, t3;            // coefficients of the x/w update kernel
+    // log-only extras ----------------------------------------------------------
+    double alpha0, beta0, test2_0;
+    // reduced sums handed between kernels (and, multi-GPU, through the all-reduce)
+    double sum_u, sum_v, sum_d;
+};
+
+constexpr int LOG_STRIDE = 14;  // == LSQRHIP_LOG_STRIDE
+
+}  // namespace lsqrhip

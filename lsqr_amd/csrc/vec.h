@@ -1,0 +1,175 @@
+// vec.h -- the Golub-Kahan vector kernels (BLAS-1 shaped, HBM-bound).
+//
+//   k_update      x += t1 w ; w = t2 w + v ; dk += (t3 w)^2 ; [se += (t3 w)^2]
+//                 replaces the inline loops at reference src/lsqr.f90:729-745, with the
+//                 `dscal(n, 1/alpha, v)` of :697 folded in (v = V * sv).
+//   k_sumsq       partial sums of x^2      (dnrm2, src/lsqrblas.f90:123-159; see note)
+//   k_dot         partial sums of x*y      (ddot,  src/lsqrblas.f90:74-116)
+//   k_scale       x <- a x                 (dscal, src/lsqrblas.f90:166-201)
+//   k_copy        y <- x                   (dcopy, src/lsqrblas.f90:25-67)
+//   k_copy_scale  w <- V * sv              (dscal + dcopy at src/lsqr.f90:642-643)
+//   k_se_finish   se <- t * sqrt(se)       (src/lsqr.f90:857-865)
+//
+// Note on dnrm2: the reference's dlassq recurrence is a serial dependent chain
+// with a divide per element; here the norm is sqrt(sum x^2) accumulated in a fixed
+// tree.  Same value to a few ulp for |x| in ~[1e-150, 1e150] (LSQR's u, v are
+// re-normalised every iteration, so they live at the scale of the matrix entries).
+//
+// All kernels: 256 threads, 16-byte (double2) accesses, capped grid-stride grid,
+// one partial per workgroup reduced later in fixed order.
+#pragma once
+
+#include "common.h"
+#include "state.h"
+
+namespace lsqrhip {
+
+constexpr int VEC_BLOCK = 256;
+constexpr int VEC_MAX_GRID = 2048;
+
+__global__ __launch_bounds__(VEC_BLOCK) void k_update(
+    double *__restrict__ x, double *__restrict__ w, const double *__restrict__ V,
+    double *__restrict__ se, int64_t n, const LsqrState *__restrict__ st,
+    double *__restrict__ partials)
+{
+    if (st->stop != 0) return;
+    const double t1 = st->t1, t2 = st->t2, t3 = st->t3, sv = st->sv;
+    const bool wantse = st->wantse != 0;
+    __shared__ double red[VEC_BLOCK / WAVE];
+    double dk = 0.0;
+    const int64_t n2 = n >> 1;
+    const int64_t stride = (int64_t)gridDim.x * VEC_BLOCK;
+    double2 *x2 = reinterpret_cast<double2 *>(x);
+    double2 *w2 = reinterpret_cast<double2 *>(w);
+    const double2 *V2 = reinterpret_cast<const double2 *>(V);
+    double2 *se2 = reinterpret_cast<double2 *>(se);
+    for (int64_t i = (int64_t)blockIdx.x * VEC_BLOCK + threadIdx.x; i < n2; i += stride) {
+        const double2 t = w2[i];
+        double2 xv = x2[i];
+        const double2 vv = V2[i];
+        xv.x = t1 * t.x + xv.x;
+        xv.y = t1 * t.y + xv.y;
+        double2 wn;
+        wn.x = t2 * t.x + vv.x * sv;
+        wn.y = t2 * t.y + vv.y * sv;
+        const double d0 = (t3 * t.x) * (t3 * t.x), d1 = (t3 * t.y) * (t3 * t.y);
+        x2[i] = xv;
+        w2[i] = wn;
+        if (wantse) {
+            double2 s = se2[i];
+            s.x = d0 + s.x;
+            s.y = d1 + s.y;
+            se2[i] = s;
+        }
+        dk += d0;
+        dk += d1;
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        const int64_t i = n - 1;
+        const double t = w[i];
+        x[i] = t1 * t + x[i];
+        w[i] = t2 * t + V[i] * sv;
+        const double d = (t3 * t) * (t3 * t);
+        if (wantse) se[i] = d + se[i];
+        dk += d;
+    }
+    const double tot = block_sum<VEC_BLOCK>(dk, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = tot;
+}
+
+// partials[b] = sum over this workgroup's share of x[i]*y[i]  (y == x: sum of squares)
+__global__ __launch_bounds__(VEC_BLOCK) void k_dot(const double *__restrict__ x,
+                                                   const double *__restrict__ y, int64_t n,
+                                                   double *__restrict__ partials)
+{
+    __shared__ double red[VEC_BLOCK / WAVE];
+    double s = 0.0;
+    const int64_t n2 = n >> 1;
+    const int64_t stride = (int64_t)gridDim.x * VEC_BLOCK;
+    const double2 *x2 = reinterpret_cast<const double2 *>(x);
+    const double2 *y2 = reinterpret_cast<const double2 *>(y);
+    for (int64_t i = (int64_t)blockIdx.x * VEC_BLOCK + threadIdx.x; i < n2; i += stride) {
+        const double2 a = x2[i], b = y2[i];
+        s += a.x * b.x;
+        s += a.y * b.y;
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) s += x[n - 1] * y[n - 1];
+    const double tot = block_sum<VEC_BLOCK>(s, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(VEC_BLOCK) void k_scale(double *__restrict__ x, int64_t n, double a)
+{
+    const int64_t stride = (int64_t)gridDim.x * VEC_BLOCK;
+    for (int64_t i = (int64_t)blockIdx.x * VEC_BLOCK + threadIdx.x; i < n; i += stride) x[i] = a * x[i];
+}
+
+__global__ __launch_bounds__(VEC_BLOCK) void k_copy(const double *__restrict__ x,
+                                                    double *__restrict__ y, int64_t n)
+{
+    const int64_t stride = (int64_t)gridDim.x * VEC_BLOCK;
+    for (int64_t i = (int64_t)blockIdx.x * VEC_BLOCK + threadIdx.x; i < n; i += stride) y[i] = x[i];
+}
+
+__global__ __launch_bounds__(VEC_BLOCK) void k_fill(double *__restrict__ x, int64_t n, double a)
+{
+    const int64_t stride = (int64_t)gridDim.x * VEC_BLOCK;
+    for (int64_t i = (int64_t)blockIdx.x * VEC_BLOCK + threadIdx.x; i < n; i += stride) x[i] = a;
+}
+
+// w <- V * sv  (first w of the recurrence, src/lsqr.f90:641-644)
+__global__ __launch_bounds__(VEC_BLOCK) void k_copy_scale(double *__restrict__ w,
+                                                          const double *__restrict__ V, int64_t n,
+                                                          const LsqrState *__restrict__ st)
+{
+    if (st->stop != 0) return;
+    const double sv = st->sv;
+    const int64_t stride = (int64_t)gridDim.x * VEC_BLOCK;
+    for (int64_t i = (int64_t)blockIdx.x * VEC_BLOCK + threadIdx.x; i < n; i += stride) w[i] = V[i] * sv;
+}
+
+// y <- y + a*x   (xcheck's w = w - damp^2 x, src/lsqr.f90:1090-1094)
+__global__ __launch_bounds__(VEC_BLOCK) void k_axpy(double *__restrict__ y,
+                                                    const double *__restrict__ x, int64_t n, double a)
+{
+    const int64_t stride = (int64_t)gridDim.x * VEC_BLOCK;
+    for (int64_t i = (int64_t)blockIdx.x * VEC_BLOCK + threadIdx.x; i < n; i += stride)
+        y[i] = y[i] + a * x[i];
+}
+
+// acheck's "unlikely" vectors (src/lsqr.f90:946-956): x_j = sqrt(j+1), y_i = 1/sqrt(i+1), 1-based j,i
+__global__ __launch_bounds__(VEC_BLOCK) void k_acheck_fill(double *__restrict__ x, int64_t n, int inverse)
+{
+    const int64_t stride = (int64_t)gridDim.x * VEC_BLOCK;
+    for (int64_t i = (int64_t)blockIdx.x * VEC_BLOCK + threadIdx.x; i < n; i += stride) {
+        const double s = sqrt((double)(i + 2));
+        x[i] = inverse ? 1.0 / s : s;
+    }
+}
+
+// se <- t * sqrt(se), t = rnorm / sqrt(1 | m-n | m)   (src/lsqr.f90:857-865)
+__global__ __launch_bounds__(VEC_BLOCK) void k_se_finish(double *__restrict__ se, int64_t n,
+                                                         const LsqrState *__restrict__ st)
+{
+    if (st->wantse == 0 || st->itn == 0) return;
+    double t = 1.0;
+    if (st->m > st->n) t = (double)(st->m - st->n);
+    if (st->damped) t = (double)st->m;
+    t = st->rnorm / sqrt(t);
+    const int64_t stride = (int64_t)gridDim.x * VEC_BLOCK;
+    for (int64_t i = (int64_t)blockIdx.x * VEC_BLOCK + threadIdx.x; i < n; i += stride)
+        se[i] = t * sqrt(se[i]);
+}
+
+// out[0] = sum of partials[0..np) in fixed order (one workgroup).
+__global__ __launch_bounds__(VEC_BLOCK) void k_reduce_partials(const double *__restrict__ partials,
+                                                               int np, double *__restrict__ out)
+{
+    __shared__ double red[VEC_BLOCK / WAVE];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < np; i += VEC_BLOCK) s += partials[i];
+    const double tot = block_sum<VEC_BLOCK>(s, red);
+    if (threadIdx.x == 0) out[0] = tot;
+}
+
+}  // namespace lsqrhip

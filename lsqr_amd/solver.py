@@ -1,0 +1,202 @@
+"""Host-side mirror of the reference's `lsqr_solver_ez` type over the C-ABI.
+
+Same names, argument meaning and error behaviour as reference src/lsqr.f90:32-65:
+
+    solver = lsqr_solver_ez()
+    solver.initialize(m, n, a, irow, icol, atol=..., btol=..., conlim=..., itnlim=..., nout=...)
+    r = solver.solve(b, damp)            # r.x, r.istop, r.itn, r.anorm, ...
+    solver.aprod(mode, m, n, x, y)       # in place, like the reference
+
+Where the reference `error stop`s with a fixed string, this raises
+`LsqrHipError` carrying that exact string (`.message`).  All arithmetic happens
+in liblsqrhip.so on the GPU; this file only marshals arguments.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import io
+import sys
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import capi
+from .capi import LsqrHipError, Timing, check, lib
+from .logfmt import format_log
+
+_EPS = float(np.finfo(np.float64).eps)
+
+
+@dataclass
+class SolveResult:
+    """Outputs of `solve` (reference src/lsqr.f90:215-223)."""
+    x: np.ndarray
+    istop: int
+    itn: int
+    anorm: float
+    acond: float
+    rnorm: float
+    arnorm: float
+    xnorm: float
+    se: np.ndarray | None = None
+
+
+class lsqr_solver_ez:  # noqa: N801  (name kept from the reference)
+    """GPU-resident twin of the reference's `lsqr_solver_ez` (src/lsqr.f90:32-65)."""
+
+    def __init__(self):
+        self._h = C.c_void_p()
+        self._reset()
+
+    # -- reference component defaults, src/lsqr.f90:39-51 ---------------------
+    def _reset(self):
+        self.m = 0
+        self.n = 0
+        self.num_nonzero_elements = 0
+        self.atol = 0.0
+        self.btol = 0.0
+        self.conlim = 0.0
+        self.itnlim = 100
+        self.nout = 0
+
+    def _free(self):
+        if getattr(self, "_h", None):
+            lib().lsqrhip_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self._free()
+        except Exception:
+            pass
+
+    # -- initialize_ez, src/lsqr.f90:91-127 ------------------------------------
+    def initialize(self, m, n, a, irow, icol, atol=None, btol=None, conlim=None, itnlim=None, nout=None):
+        """`me` is intent(out) in the reference (:95): every call starts from the defaults."""
+        self._free()
+        self._reset()
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        irow = np.ascontiguousarray(irow, dtype=np.int32)
+        icol = np.ascontiguousarray(icol, dtype=np.int32)
+        if not (a.size == irow.size == icol.size):                      # :109
+            raise LsqrHipError(capi.ERR_SIZES, lib().lsqrhip_error_string(capi.ERR_SIZES).decode())
+        h = C.c_void_p()
+        check(lib().lsqrhip_create(int(m), int(n), a.size, irow.ctypes.data, icol.ctypes.data,
+                                   a.ctypes.data, C.byref(h)))         # :110-118
+        self._h = h
+        self.m, self.n, self.num_nonzero_elements = int(m), int(n), int(a.size)
+        if atol is not None:
+            self.atol = float(atol)                                     # :121-125
+        if btol is not None:
+            self.btol = float(btol)
+        if conlim is not None:
+            self.conlim = float(conlim)
+        if itnlim is not None:
+            self.itnlim = int(itnlim)
+        if nout is not None:
+            self.nout = nout
+        return self
+
+    def _need(self):
+        if not self._h:
+            raise LsqrHipError(capi.ERR_NOT_INIT, lib().lsqrhip_error_string(capi.ERR_NOT_INIT).decode())
+
+    # -- solve_ez, src/lsqr.f90:207-259 ----------------------------------------
+    def solve(self, b, damp=0.0, wantse=False) -> SolveResult:
+        self._need()
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        if b.shape != (self.m,):
+            raise ValueError(f"b must have shape ({self.m},)")          # explicit-shape dummy b(me%m), :213
+        x = np.zeros(max(self.n, 1))
+        se = np.zeros(max(self.n, 1)) if wantse else None
+        istop, itn = C.c_int(), C.c_int()
+        sc = [C.c_double() for _ in range(5)]
+        want_log = 1 if self.nout else 0
+        check(lib().lsqrhip_solve(self._h, b.ctypes.data, float(damp), self.atol, self.btol, self.conlim,
+                                  self.itnlim, int(bool(wantse)), want_log, x.ctypes.data,
+                                  se.ctypes.data if wantse else None, C.addressof(istop), C.addressof(itn),
+                                  *[C.addressof(s) for s in sc]))
+        r = SolveResult(x[:self.n], istop.value, itn.value, *[s.value for s in sc],
+                        se=se[:self.n] if wantse else None)
+        if self.nout:
+            self._write_log(r, float(damp), bool(wantse))
+        return r
+
+    def solve_device(self, d_b: int, d_x: int, damp=0.0, d_se: int | None = None) -> SolveResult:
+        """b, x (and se) already resident in HBM: raw device addresses (no PCIe in the call)."""
+        self._need()
+        istop, itn = C.c_int(), C.c_int()
+        sc = [C.c_double() for _ in range(5)]
+        check(lib().lsqrhip_solve_device(self._h, d_b, float(damp), self.atol, self.btol, self.conlim,
+                                         self.itnlim, 1 if d_se else 0, 0, d_x, d_se,
+                                         C.addressof(istop), C.addressof(itn), *[C.addressof(s) for s in sc]))
+        return SolveResult(np.zeros(0), istop.value, itn.value, *[s.value for s in sc])
+
+    # -- aprod_ez, src/lsqr.f90:134-200 ----------------------------------------
+    def aprod(self, mode, m, n, x, y):
+        """mode 1: y += A x ; mode 2: x += A' y.  x, y are float64 numpy arrays updated in place."""
+        self._need()
+        if m != self.m or n != self.n:                                  # :152
+            raise LsqrHipError(capi.ERR_NOT_INIT, lib().lsqrhip_error_string(capi.ERR_NOT_INIT).decode())
+        for v, k in ((x, self.n), (y, self.m)):
+            if not (isinstance(v, np.ndarray) and v.dtype == np.float64 and v.flags.c_contiguous and v.size == k):
+                raise ValueError("x, y must be contiguous float64 arrays of length n, m")
+        check(lib().lsqrhip_aprod(self._h, int(mode), x.ctypes.data, y.ctypes.data))  # :197 -> ERR_MODE
+
+    # -- acheck / xcheck, src/lsqr.f90:908-994, 1015-1154 ------------------------
+    def acheck(self, eps=_EPS):
+        self._need()
+        inform, err = C.c_int(), C.c_double()
+        check(lib().lsqrhip_acheck(self._h, float(eps), C.addressof(inform), C.addressof(err)))
+        return inform.value, err.value
+
+    def xcheck(self, anorm, damp, b, x, eps=_EPS):
+        self._need()
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        u, v, w, tests = np.zeros(max(self.m, 1)), np.zeros(max(self.n, 1)), np.zeros(max(self.n, 1)), np.zeros(3)
+        inform = C.c_int()
+        check(lib().lsqrhip_xcheck(self._h, float(anorm), float(damp), float(eps), b.ctypes.data, x.ctypes.data,
+                                   u.ctypes.data, v.ctypes.data, w.ctypes.data, C.addressof(inform),
+                                   tests.ctypes.data))
+        return inform.value, tests, u[:self.m], v[:self.n], w[:self.n]
+
+    # -- measurement / options --------------------------------------------------
+    def set_option(self, name: str, value: int):
+        self._need()
+        check(lib().lsqrhip_set_option(self._h, name.encode(), int(value)))
+
+    def last_timing(self) -> Timing:
+        self._need()
+        t = Timing()
+        check(lib().lsqrhip_last_timing(self._h, C.byref(t)))
+        return t
+
+    def info(self) -> dict:
+        self._need()
+        d = (C.c_int64 * 6)()
+        check(lib().lsqrhip_info(self._h, d))
+        return dict(m=d[0], n=d[1], nnz=d[2], csr_bytes=d[3], csrt_bytes=d[4], rowptr_bytes=d[5])
+
+    def log_records(self) -> np.ndarray:
+        self._need()
+        k = lib().lsqrhip_log_count(self._h)
+        rec = np.zeros((k, capi.LOG_STRIDE))
+        if k:
+            check(lib().lsqrhip_log_fetch(self._h, 0, k, rec.ctypes.data))
+        return rec
+
+    def _write_log(self, r: SolveResult, damp: float, wantse: bool):
+        ex = np.zeros(6)
+        check(lib().lsqrhip_log_extras(self._h, ex.ctypes.data))
+        text = format_log(self.m, self.n, damp, wantse, self.atol, self.btol, self.conlim, self.itnlim,
+                          self.log_records(), r, bnorm=ex[0], dxmax=ex[1], maxdx=int(ex[2]), test2_0=ex[5],
+                          beta0=ex[4])
+        out = self.nout
+        if isinstance(out, (io.IOBase,)) or hasattr(out, "write"):
+            out.write(text)
+        elif isinstance(out, str):
+            with open(out, "w") as f:
+                f.write(text)
+        else:  # any non-zero unit number: standard output, like output_unit
+            sys.stdout.write(text)

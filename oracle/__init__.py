@@ -21,7 +21,7 @@ from dataclasses import dataclass, field
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LOG_STRIDE = 12  # ORACLE_LOG_STRIDE
+LOG_STRIDE = 14  # ORACLE_LOG_STRIDE
 
 _i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
 _f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")

@@ -331,7 +331,7 @@ int oracle_lsqr_ez(int m, int n, long long nnz, const int *irow, const int *icol
                 double *r = log + (size_t)(itn - 1) * ORACLE_LOG_STRIDE;
                 r[0] = (double)itn; r[1] = n > 0 ? x[0] : 0.0; r[2] = rnorm; r[3] = test1;
                 r[4] = test2; r[5] = anorm; r[6] = acond; r[7] = phi; r[8] = dknorm;
-                r[9] = dxk; r[10] = alfopt; r[11] = (double)istop;
+                r[9] = dxk; r[10] = alfopt; r[11] = (double)istop; r[12] = rtol; r[13] = xnorm;
             }
 
             /* :843-850 */

@@ -7,8 +7,8 @@ extern "C" {
 #endif
 
 /* doubles per per-iteration log record: itn, x(1), rnorm, test1, test2, anorm,
- * acond, phi, dknorm, dxk, alfopt, istop(before the nconv rule) */
-#define ORACLE_LOG_STRIDE 12
+ * acond, phi, dknorm, dxk, alfopt, istop(before the nconv rule), rtol, xnorm */
+#define ORACLE_LOG_STRIDE 14
 
 void oracle_dcopy(int n, const double *dx, int incx, double *dy, int incy);
 double oracle_ddot(int n, const double *dx, int incx, const double *dy, int incy);

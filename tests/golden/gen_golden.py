@@ -71,6 +71,23 @@ def main():
         rec["rnorm"] = hx(r.rnorm) if r.istop != 0 else None
         if o["wantse"]:
             rec["se"] = hx(r.se)
+        # The reference's OWN sensitivity to summation order: rerun it on the same
+        # matrix with the COO triplets permuted (legal input, src/lsqr.f90:168-172 sums
+        # in COO order).  Long / ill-conditioned runs drift far above 1e-10 by
+        # themselves; parity tests use tol = max(1e-10, 10 * this band).
+        if p.nnz > 1:
+            sx = sa = sr = 0.0
+            itns, istops = {r.itn}, {r.istop}
+            for seed in (1, 2, 3):
+                q = P.shuffled(p, seed)
+                rq = rf.solve(q.m, q.n, q.irow, q.icol, q.a, q.b, **o)
+                nx = float(np.linalg.norm(r.x))
+                sx = max(sx, float(np.linalg.norm(rq.x - r.x)) / nx if nx > 0 else 0.0)
+                sa = max(sa, abs(rq.anorm - r.anorm) / r.anorm if r.anorm > 0 else 0.0)
+                sr = max(sr, abs(rq.rnorm - r.rnorm) / r.rnorm if r.rnorm > 0 and r.istop != 0 else 0.0)
+                itns.add(rq.itn)
+                istops.add(rq.istop)
+            rec["sens"] = dict(x=sx, anorm=sa, rnorm=sr, itn=sorted(itns), istop=sorted(istops))
         # aprod mode 1 / 2 on this matrix with fixed probe vectors (src/lsqr.f90:134-200)
         if p.nnz > 0:
             xp = P.u64_to_unit(P.rng_u64(101, 9, np.arange(p.n, dtype=np.uint64)))
