@@ -115,8 +115,12 @@ __global__ __launch_bounds__(SPMV_BLOCK) void k_spmv_fused(
         // ---- phase 2: reduce the short rows out of LDS ---------------------
         const int nr = r1s - r0;
         if (nr > 0) {
+            // lanes per row from the block's mean row length: <= 16 nonzeros -> one lane,
+            // plain left-to-right sum (bit-identical to the reference's COO-order row
+            // sums); longer rows get 2..64 lanes and a shuffle tree.
+            const int avg = cnt / nr;
             int G = 1;
-            while (G < WAVE && nr * (G * 2) <= SPMV_BLOCK) G <<= 1;  // uniform
+            while (G < WAVE && avg > 16 * G) G <<= 1;  // uniform
             const int gl = tid & (G - 1), gid = tid / G, ngroups = SPMV_BLOCK / G;
             for (int r = r0 + gid; r < r1s; r += ngroups) {
                 const int s0 = (int)(rowptr[r] - p0), s1 = (int)(rowptr[r + 1] - p0);
