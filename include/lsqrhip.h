@@ -75,6 +75,11 @@ int lsqrhip_create_from_device_coo(int m, int n, int64_t nnz, const int *d_irow,
  * its allocatables auto-free, src/lsqr.f90:42-58). */
 int lsqrhip_destroy(lsqrhip_handle_t h);
 
+/* Add one owner: the handle is freed by the LAST lsqrhip_destroy.  Lets host languages
+ * with value semantics (Fortran intrinsic assignment of a solver object, which in the
+ * reference deep-copies its allocatable components) share one device matrix safely. */
+int lsqrhip_retain(lsqrhip_handle_t h);
+
 /* Matrix facts: dims[0..5] = m, n, nnz, bytes of CSR(A), bytes of CSR(A'),
  * bytes per row pointer (4 or 8). */
 int lsqrhip_info(lsqrhip_handle_t h, int64_t *dims);
@@ -154,6 +159,14 @@ typedef struct {
     int itn;
 } lsqrhip_timing_t;
 int lsqrhip_last_timing(lsqrhip_handle_t h, lsqrhip_timing_t *t);
+
+/* Average device time (ms) of `reps` back-to-back launches of one hot kernel on the
+ * handle's stream, bracketed by ONE pair of HIP events (so the per-launch figure is what
+ * rocprofv3's kernel trace reports as the kernel's average duration).  which: 1 = mode-1
+ * SpMV on CSR(A), 2 = mode-2 SpMV on CSR(A'), 3 = x/w update.  Runs on scratch
+ * copies of the coefficients with the solver's work vectors as operands; their contents
+ * are unspecified afterwards. */
+int lsqrhip_bench_kernel(lsqrhip_handle_t h, int which, int reps, double *avg_ms);
 
 /* Options: "graph" (1 = hipGraph-captured iteration batches [default], 0 = eager
  * launches), "graph_iters" (iterations per captured batch), "time_kernels"

@@ -23,11 +23,11 @@ ERR_NO_DEVICE, ERR_HIP, ERR_ALLOC, ERR_ARG, ERR_TOO_LARGE = 10, 11, 12, 13, 14
 
 EXPORTS = [
     "lsqrhip_error_string", "lsqrhip_last_error", "lsqrhip_device_count", "lsqrhip_set_device",
-    "lsqrhip_create", "lsqrhip_create_from_device_coo", "lsqrhip_destroy", "lsqrhip_info",
+    "lsqrhip_create", "lsqrhip_create_from_device_coo", "lsqrhip_destroy", "lsqrhip_retain", "lsqrhip_info",
     "lsqrhip_solve", "lsqrhip_solve_device", "lsqrhip_aprod", "lsqrhip_aprod_device",
     "lsqrhip_acheck", "lsqrhip_xcheck", "lsqrhip_log_count", "lsqrhip_log_fetch",
     "lsqrhip_log_extras", "lsqrhip_dnrm2", "lsqrhip_ddot", "lsqrhip_dscal", "lsqrhip_dcopy",
-    "lsqrhip_last_timing", "lsqrhip_set_option", "lsqrhip_set_stream", "lsqrhip_dev_alloc",
+    "lsqrhip_last_timing", "lsqrhip_bench_kernel", "lsqrhip_set_option", "lsqrhip_set_stream", "lsqrhip_dev_alloc",
     "lsqrhip_dev_free", "lsqrhip_dev_upload", "lsqrhip_dev_download", "lsqrhip_dev_sync",
 ]
 
@@ -69,6 +69,7 @@ def lib() -> C.CDLL:
     L.lsqrhip_create.argtypes = [i32, i32, i64, vp, vp, vp, C.POINTER(vp)]
     L.lsqrhip_create_from_device_coo.argtypes = [i32, i32, i64, vp, vp, vp, C.POINTER(vp)]
     L.lsqrhip_destroy.argtypes = [vp]
+    L.lsqrhip_retain.argtypes = [vp]
     L.lsqrhip_info.argtypes = [vp, C.POINTER(i64)]
     solve_args = [vp, vp, f64, f64, f64, f64, i32, i32, i32, vp, vp] + [vp] * 7
     L.lsqrhip_solve.argtypes = solve_args
@@ -85,6 +86,7 @@ def lib() -> C.CDLL:
     L.lsqrhip_dscal.argtypes = [vp, i64, f64, vp]
     L.lsqrhip_dcopy.argtypes = [vp, i64, vp, vp]
     L.lsqrhip_last_timing.argtypes = [vp, C.POINTER(Timing)]
+    L.lsqrhip_bench_kernel.argtypes = [vp, i32, i32, vp]
     L.lsqrhip_set_option.argtypes = [vp, C.c_char_p, i64]
     L.lsqrhip_set_stream.argtypes = [vp, vp]
     L.lsqrhip_dev_alloc.argtypes = [C.POINTER(vp), i64]

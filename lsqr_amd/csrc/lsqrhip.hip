@@ -10,6 +10,7 @@
 // between batches.  There is no CPU fallback anywhere in this file.
 #include "../../include/lsqrhip.h"
 
+#include <hip/hip_ext.h>
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -126,6 +127,7 @@ struct Csr {
 };
 
 struct lsqrhip_handle_s {
+    int refs = 1;  // lsqrhip_retain / lsqrhip_destroy
     int device = 0;
     int m = 0, n = 0;
     int64_t nnz = 0;
@@ -181,9 +183,17 @@ static void destroy_graph(H *h)
     h->graph_dirty = true;
 }
 
+extern "C" int lsqrhip_retain(lsqrhip_handle_t h)
+{
+    if (!h) return fail(LSQRHIP_ERR_ARG, "null handle");
+    ++h->refs;
+    return LSQRHIP_OK;
+}
+
 extern "C" int lsqrhip_destroy(lsqrhip_handle_t h)
 {
     if (!h) return LSQRHIP_OK;
+    if (--h->refs > 0) return LSQRHIP_OK;
     (void)hipSetDevice(h->device);
     if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
     destroy_graph(h);
@@ -398,33 +408,46 @@ extern "C" int lsqrhip_info(lsqrhip_handle_t h, int64_t *dims)
 // ---------------------------------------------------------------------------
 // kernel launch helpers
 // ---------------------------------------------------------------------------
-static void launch_spmv(H *h, const Csr &c, const double *x, double *y, const SpmvCoef *coef, const int *stop)
+// e0/e1 (optional): HIP events that receive the kernel's own begin / end timestamps
+// (hipExtLaunchKernelGGL), i.e. the same interval rocprofv3's kernel trace reports.
+static void launch_spmv(H *h, const Csr &c, const double *x, double *y, const SpmvCoef *coef, const int *stop,
+                        hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr)
 {
+    if (e0 == nullptr) {  // plain launch (also the only form used under stream capture)
+        if (h->off64)
+            hipLaunchKernelGGL(k_spmv_fused<long long>, dim3(c.grid), dim3(SPMV_BLOCK), 0, h->stream,
+                               (const long long *)c.rowptr, c.col, c.val, c.rb, c.nblk, x, y, coef, stop, h->partials);
+        else
+            hipLaunchKernelGGL(k_spmv_fused<int>, dim3(c.grid), dim3(SPMV_BLOCK), 0, h->stream,
+                               (const int *)c.rowptr, c.col, c.val, c.rb, c.nblk, x, y, coef, stop, h->partials);
+        return;
+    }
     if (h->off64)
-        hipLaunchKernelGGL(k_spmv_fused<long long>, dim3(c.grid), dim3(SPMV_BLOCK), 0, h->stream,
-                           (const long long *)c.rowptr, c.col, c.val, c.rb, c.nblk, x, y, coef, stop, h->partials);
+        hipExtLaunchKernelGGL(k_spmv_fused<long long>, dim3(c.grid), dim3(SPMV_BLOCK), 0, h->stream, e0, e1, 0,
+                              (const long long *)c.rowptr, (const int *)c.col, (const double *)c.val,
+                              (const int *)c.rb, c.nblk, x, y, coef, stop, h->partials);
     else
-        hipLaunchKernelGGL(k_spmv_fused<int>, dim3(c.grid), dim3(SPMV_BLOCK), 0, h->stream,
-                           (const int *)c.rowptr, c.col, c.val, c.rb, c.nblk, x, y, coef, stop, h->partials);
+        hipExtLaunchKernelGGL(k_spmv_fused<int>, dim3(c.grid), dim3(SPMV_BLOCK), 0, h->stream, e0, e1, 0,
+                              (const int *)c.rowptr, (const int *)c.col, (const double *)c.val, (const int *)c.rb,
+                              c.nblk, x, y, coef, stop, h->partials);
 }
 
-// one LSQR iteration = 6 launches; `ev` (optional) gets 6 events: before/after each vector kernel
+// one LSQR iteration = 6 launches; `ev` (optional) gets 3 (start, stop) event pairs, one per
+// vector kernel
 static void launch_iteration(H *h, hipEvent_t *ev)
 {
     LsqrState *st = h->d_state;
     hipStream_t s = h->stream;
-    if (ev) (void)hipEventRecord(ev[0], s);
-    launch_spmv(h, h->A, h->V, h->U, &st->c1, &st->stop);  // U <- (-alpha)(U su) + A (V sv)
-    if (ev) (void)hipEventRecord(ev[1], s);
+    launch_spmv(h, h->A, h->V, h->U, &st->c1, &st->stop, ev ? ev[0] : nullptr, ev ? ev[1] : nullptr);   // U <- (-alpha)(U su) + A (V sv)
     hipLaunchKernelGGL(k_s1<true>, dim3(1), dim3(SC_BLOCK), 0, s, h->partials, h->A.grid, st);
-    if (ev) (void)hipEventRecord(ev[2], s);
-    launch_spmv(h, h->AT, h->U, h->V, &st->c2, &st->stop);  // V <- (-beta)(V sv) + A'(U su)
-    if (ev) (void)hipEventRecord(ev[3], s);
+    launch_spmv(h, h->AT, h->U, h->V, &st->c2, &st->stop, ev ? ev[2] : nullptr, ev ? ev[3] : nullptr);  // V <- (-beta)(V sv) + A'(U su)
     hipLaunchKernelGGL(k_s2<true>, dim3(1), dim3(SC_BLOCK), 0, s, h->partials, h->AT.grid, st);
-    if (ev) (void)hipEventRecord(ev[4], s);
-    hipLaunchKernelGGL(k_update, dim3(h->vgrid_n), dim3(VEC_BLOCK), 0, s, h->X, h->W, h->V, h->SE, (int64_t)h->n,
-                       (const LsqrState *)st, h->partials);
-    if (ev) (void)hipEventRecord(ev[5], s);
+    if (ev)
+        hipExtLaunchKernelGGL(k_update, dim3(h->vgrid_n), dim3(VEC_BLOCK), 0, s, ev[4], ev[5], 0, h->X, h->W,
+                              (const double *)h->V, h->SE, (int64_t)h->n, (const LsqrState *)st, h->partials);
+    else
+        hipLaunchKernelGGL(k_update, dim3(h->vgrid_n), dim3(VEC_BLOCK), 0, s, h->X, h->W, h->V, h->SE,
+                           (int64_t)h->n, (const LsqrState *)st, h->partials);
     hipLaunchKernelGGL(k_s3<true>, dim3(1), dim3(SC_BLOCK), 0, s, h->partials, h->vgrid_n, st, h->X, h->d_log);
 }
 
@@ -805,6 +828,46 @@ extern "C" int lsqrhip_xcheck(lsqrhip_handle_t h, double anorm, double damp, dou
     if (v && n > 0) HIPCHK(hipMemcpyAsync(v, dv.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, s));
     if (w && n > 0) HIPCHK(hipMemcpyAsync(w, dw.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
+    return LSQRHIP_OK;
+}
+
+// ---------------------------------------------------------------------------
+// kernel micro-timing (bench.py roofline leg)
+// ---------------------------------------------------------------------------
+extern "C" int lsqrhip_bench_kernel(lsqrhip_handle_t h, int which, int reps, double *avg_ms)
+{
+    if (!h || !avg_ms || reps < 1 || which < 1 || which > 3) return fail(LSQRHIP_ERR_ARG, "bad bench_kernel arguments");
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    // operands: finite, small; coefficients that keep them bounded over `reps` launches
+    hipLaunchKernelGGL(k_fill, dim3(h->vgrid_m), dim3(VEC_BLOCK), 0, s, h->U, (int64_t)h->m, 1.0e-3);
+    hipLaunchKernelGGL(k_fill, dim3(h->vgrid_n), dim3(VEC_BLOCK), 0, s, h->V, (int64_t)h->n, 1.0e-3);
+    hipLaunchKernelGGL(k_fill, dim3(h->vgrid_n), dim3(VEC_BLOCK), 0, s, h->W, (int64_t)h->n, 1.0e-3);
+    hipLaunchKernelGGL(k_fill, dim3(h->vgrid_n), dim3(VEC_BLOCK), 0, s, h->X, (int64_t)h->n, 0.0);
+    LsqrState tmp;
+    std::memset(&tmp, 0, sizeof(tmp));
+    tmp.t1 = 1.0e-3; tmp.t2 = -0.5; tmp.t3 = 1.0e-3; tmp.sv = 1.0; tmp.su = 1.0;
+    tmp.c1.sx = 1.0; tmp.c1.sy = 0.5; tmp.c1.cy = -0.5;   // y <- -0.25 y + A x : bounded
+    tmp.c2 = tmp.c1;
+    LsqrState *d_tmp = nullptr;
+    HIPCHK(hipMalloc((void **)&d_tmp, sizeof(LsqrState)));
+    HIPCHK(hipMemcpyAsync(d_tmp, &tmp, sizeof(tmp), hipMemcpyHostToDevice, s));
+    auto one = [&]() {
+        if (which == 1) launch_spmv(h, h->A, h->V, h->U, &d_tmp->c1, &d_tmp->stop);
+        else if (which == 2) launch_spmv(h, h->AT, h->U, h->V, &d_tmp->c2, &d_tmp->stop);
+        else hipLaunchKernelGGL(k_update, dim3(h->vgrid_n), dim3(VEC_BLOCK), 0, s, h->X, h->W, h->V, h->SE,
+                                (int64_t)h->n, (const LsqrState *)d_tmp, h->partials);
+    };
+    for (int i = 0; i < 3; ++i) one();  // warm
+    HIPCHK(hipEventRecord(h->ev_loop0, s));
+    for (int i = 0; i < reps; ++i) one();
+    HIPCHK(hipEventRecord(h->ev_loop1, s));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(s));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, h->ev_loop0, h->ev_loop1));
+    (void)hipFree(d_tmp);
+    *avg_ms = (double)ms / reps;
     return LSQRHIP_OK;
 }
 

@@ -166,6 +166,14 @@ class lsqr_solver_ez:  # noqa: N801  (name kept from the reference)
         self._need()
         check(lib().lsqrhip_set_option(self._h, name.encode(), int(value)))
 
+    def bench_kernel(self, which: int, reps: int) -> float:
+        """Average ms of `reps` back-to-back launches of hot kernel 1 (mode-1 SpMV), 2 (mode-2 SpMV)
+        or 3 (x/w update), one HIP event pair around the whole run."""
+        self._need()
+        ms = C.c_double()
+        check(lib().lsqrhip_bench_kernel(self._h, int(which), int(reps), C.addressof(ms)))
+        return ms.value
+
     def last_timing(self) -> Timing:
         self._need()
         t = Timing()

@@ -1,0 +1,103 @@
+"""The Fortran host layer (lsqr_amd/fortran: modules lsqr_kinds, lsqpblas_module,
+lsqr_module with the reference's names and signatures).
+
+* CPU: a user type extending `lsqr_solver` with its own aprod (host path) against the
+  reference run on the same matrix; the EZ driver must fail loudly without a GPU.
+* GPU: Fortran -> ISO_C_BINDING -> liblsqrhip.so -> HIP kernels against the oracle.
+"""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle
+from lsqr_amd import problems as P
+
+LIB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lsqr_amd", "lib")
+NUM = r"[-+]?\d\.\d+E[-+]\d+"
+
+
+def run(exe, check=True):
+    path = os.path.join(LIB, exe)
+    assert os.path.exists(path), f"{path} missing: run __graft_entry__.build()"
+    return subprocess.run([path], capture_output=True, text=True, timeout=300, check=check)
+
+
+def numbers(line):
+    return np.array([float(t) for t in re.findall(NUM, line)])
+
+
+def has_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+def test_user_aprod_host_path_matches_reference():
+    """lsqr / acheck / xcheck of the abstract class (own Fortran code) on a dense user operator,
+    compared with the reference algorithm on the same matrix given as COO."""
+    out = run("test_user_aprod").stdout
+    assert "USER APROD TESTS PASSED" in out and "ACHECK inform= 0" in out
+    lines = {l.split("=")[0].strip(): l for l in out.splitlines() if "=" in l}
+    m, n, damp = 40, 25, 0.125
+    i, j = np.meshgrid(np.arange(1, m + 1), np.arange(1, n + 1), indexing="ij")
+    A = 1.0 / (i + 2 * j + 1) + 2.0 * (i == j)
+    b = 1.0 / np.arange(1, m + 1) - 0.25
+    irow = i.T.reshape(-1).astype(np.int32)   # column-major triplets
+    icol = j.T.reshape(-1).astype(np.int32)
+    a = A.T.reshape(-1)
+    eng = oracle.ref() or oracle.port()
+    r = eng.solve(m, n, irow, icol, a, b, damp=damp, atol=1e-12, btol=1e-12, conlim=1e8, itnlim=200, wantse=True)
+    istop, itn = [int(t) for t in re.findall(r"=\s*(\d+)", lines["LSQR istop"])]
+    assert (istop, itn) == (r.istop, r.itn)
+    x = numbers(lines["LSQR x"])
+    se = numbers(lines["LSQR se"])
+    norms = numbers(lines["LSQR norms"])
+    assert np.linalg.norm(x - r.x) <= 1e-10 * np.linalg.norm(r.x)
+    assert np.linalg.norm(se - r.se) <= 1e-9 * np.linalg.norm(r.se)
+    assert abs(norms[0] - r.anorm) <= 1e-10 * r.anorm
+    assert abs(norms[2] - r.rnorm) <= 1e-10 * r.rnorm
+    assert abs(norms[4] - r.xnorm) <= 1e-10 * r.xnorm
+    assert int(re.findall(r"tests=\s*(\d)", out)[0]) == 3      # damped least-squares solution
+
+
+@pytest.mark.skipif(has_gpu(), reason="only meaningful on a box without a GPU")
+def test_ez_driver_fails_loudly_without_a_device():
+    p = run("test_ez", check=False)
+    assert p.returncode != 0
+    assert "no usable MI355X" in (p.stdout + p.stderr)
+    assert "EZ TESTS PASSED" not in p.stdout
+
+
+@pytest.mark.gpu
+def test_ez_driver_on_gpu_matches_oracle():
+    p = run("test_ez", check=False)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    out = p.stdout
+    assert "EZ TESTS PASSED" in out and "OPTIONS OK" in out
+    # the reference's iteration log is printed for the toy systems (nout = output_unit)
+    assert " Enter LSQR.       Least-squares solution of  Ax = b" in out
+    assert "A solution to Ax = b was found, given atol, btol" in out
+    toy = [l for l in out.splitlines() if l.startswith("TOY readme_3x3")][0]
+    assert "istop= 1" in toy
+    assert np.allclose(numbers(toy), [1.2424242424242424, -6.0606060606060594e-02, -4.0404040404040407e-02],
+                       rtol=1e-10, atol=0)
+    damped = [l for l in out.splitlines() if l.startswith("DAMPED istop")][0]
+    assert np.allclose(numbers(damped), [8.10640473795055549e-01, -2.86387641921484436e-02, -1.64648479828245174e-02],
+                       rtol=1e-10, atol=0)        # SURVEY.md 8c 'T1 damped' golden
+    # generated Poisson system: Fortran host -> C-ABI -> HIP against the CPU oracle
+    prob = P.poisson2d(64, 64)
+    head = [l for l in out.splitlines() if l.startswith("POISSON nx=")][0]
+    assert f"nnz={prob.nnz}" in head and "istop=5" in head and "itn=60" in head
+    o = oracle.port().solve(prob.m, prob.n, prob.irow, prob.icol, prob.a, prob.b, itnlim=60)
+    nrm = numbers([l for l in out.splitlines() if l.startswith("POISSON anorm")][0])
+    xs = numbers([l for l in out.splitlines() if l.startswith("POISSON x(1)")][0])
+    assert abs(nrm[0] - o.anorm) <= 1e-10 * o.anorm
+    assert abs(nrm[1] - o.rnorm) <= 1e-10 * o.rnorm
+    assert abs(nrm[2] - o.xnorm) <= 1e-10 * o.xnorm
+    want = np.array([o.x[0], o.x[prob.n // 2 - 1], o.x[-1]])
+    assert np.max(np.abs(xs - want)) <= 1e-10 * np.linalg.norm(o.x, np.inf)
