@@ -183,6 +183,51 @@ int lsqrhip_dev_upload(void *d_dst, const void *src, int64_t bytes);
 int lsqrhip_dev_download(void *dst, const void *d_src, int64_t bytes);
 int lsqrhip_dev_sync(void);
 
+/* ---------------------------------------------------------------------- */
+/* row-block sharded solve (one process per GPU)                            */
+/* ---------------------------------------------------------------------- */
+/* The reference is serial; this is the multi-GPU form of the same iteration.
+ * Rank p creates its handle from its own row block A_p (rows renumbered from 1, all n columns).
+ * u, b are sharded with the rows; v, w, x are replicated.  The library only launches LOCAL
+ * kernels; the host issues the two collectives per iteration on buffers it owns
+ * (torch.distributed / RCCL in lsqr_amd/dist.py):
+ *
+ *   begin(b_p, T, sums)
+ *   stage 0                      -> all-reduce(sums[0])          |b|^2
+ *   stage 1                      -> all-reduce(T[0..n))          A'u
+ *   stage 2
+ *   repeat:  stage 3             -> all-reduce(sums[0])          |u|^2
+ *            stage 4             -> all-reduce(T[0..n))          A'u
+ *            stage 5
+ *            every k iterations: poll (all ranks see the same stop flag: the scalar
+ *            recurrences run replicated on identical all-reduced inputs)
+ *   end(x)
+ *
+ * d_T: n doubles, d_sums: >= 2 doubles, both device memory owned by the caller. */
+int lsqrhip_shard_begin(lsqrhip_handle_t h, const double *d_b_local, int64_t m_global, double damp,
+                        double atol, double btol, double conlim, int itnlim, int wantse, double *d_T,
+                        double *d_sums);
+int lsqrhip_shard_stage(lsqrhip_handle_t h, int stage);
+/* out[0..2] = stop, itn, istop (synchronises the handle's stream). */
+int lsqrhip_shard_poll(lsqrhip_handle_t h, int *out);
+int lsqrhip_shard_end(lsqrhip_handle_t h, double *d_x, double *d_se, int *istop, int *itn, double *anorm,
+                      double *acond, double *rnorm, double *arnorm, double *xnorm);
+
+/* ---------------------------------------------------------------------- */
+/* synthetic systems generated in HBM (bench / scale tests)                 */
+/* ---------------------------------------------------------------------- */
+/* Bit-identical to the host generators in lsqr_amd/problems.py (same counter-based hash).
+ * kind 0: random rows (p0 = nnz per row); kind 1: 5-point Poisson (p0 = nx, p1 = ny; b is
+ * not generated, d_b may be NULL); kind 2: rows with prescribed degrees (power law):
+ * d_rowptr_local = exclusive prefix of the local row degrees, nrows+1 entries, built by the
+ * host from the integer CDF table (problems.powerlaw_degrees).
+ * Generates rows [row0, row0+nrows) of the global m-by-n system as LOCAL 1-based COO
+ * (irow in 1..nrows) plus b for those rows.  *nnz_out = triplets written. */
+int64_t lsqrhip_gen_count(int kind, int64_t m, int64_t n, int64_t p0, int64_t p1, int64_t row0, int64_t nrows);
+int lsqrhip_gen_coo(int kind, uint64_t seed, int64_t m, int64_t n, int64_t p0, int64_t p1, int64_t row0,
+                    int64_t nrows, const int64_t *d_rowptr_local, int *d_irow, int *d_icol, double *d_a,
+                    double *d_b, int64_t *nnz_out);
+
 #ifdef __cplusplus
 }
 #endif

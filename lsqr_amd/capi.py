@@ -29,6 +29,8 @@ EXPORTS = [
     "lsqrhip_log_extras", "lsqrhip_dnrm2", "lsqrhip_ddot", "lsqrhip_dscal", "lsqrhip_dcopy",
     "lsqrhip_last_timing", "lsqrhip_bench_kernel", "lsqrhip_set_option", "lsqrhip_set_stream", "lsqrhip_dev_alloc",
     "lsqrhip_dev_free", "lsqrhip_dev_upload", "lsqrhip_dev_download", "lsqrhip_dev_sync",
+    "lsqrhip_shard_begin", "lsqrhip_shard_stage", "lsqrhip_shard_poll", "lsqrhip_shard_end",
+    "lsqrhip_gen_count", "lsqrhip_gen_coo",
 ]
 
 
@@ -93,6 +95,13 @@ def lib() -> C.CDLL:
     L.lsqrhip_dev_free.argtypes = [vp]
     L.lsqrhip_dev_upload.argtypes = [vp, vp, i64]
     L.lsqrhip_dev_download.argtypes = [vp, vp, i64]
+    L.lsqrhip_shard_begin.argtypes = [vp, vp, i64, f64, f64, f64, f64, i32, i32, vp, vp]
+    L.lsqrhip_shard_stage.argtypes = [vp, i32]
+    L.lsqrhip_shard_poll.argtypes = [vp, vp]
+    L.lsqrhip_shard_end.argtypes = [vp, vp, vp] + [vp] * 7
+    L.lsqrhip_gen_count.restype = i64
+    L.lsqrhip_gen_count.argtypes = [i32, i64, i64, i64, i64, i64, i64]
+    L.lsqrhip_gen_coo.argtypes = [i32, C.c_uint64, i64, i64, i64, i64, i64, i64, vp, vp, vp, vp, vp, vp]
     for name in EXPORTS:
         getattr(L, name)  # every declared symbol must be exported
     _lib = L

@@ -154,6 +154,9 @@ struct lsqrhip_handle_s {
     std::vector<hipEvent_t> ev;
     hipEvent_t ev_loop0 = nullptr, ev_loop1 = nullptr;
     lsqrhip_timing_t timing{};
+    // row-sharded solve (shard_api.h): caller-owned exchange buffers
+    double *shard_T = nullptr, *shard_sums = nullptr;
+    int shard_wantse = 0;
 };
 typedef lsqrhip_handle_s H;
 
@@ -439,16 +442,16 @@ static void launch_iteration(H *h, hipEvent_t *ev)
     LsqrState *st = h->d_state;
     hipStream_t s = h->stream;
     launch_spmv(h, h->A, h->V, h->U, &st->c1, &st->stop, ev ? ev[0] : nullptr, ev ? ev[1] : nullptr);   // U <- (-alpha)(U su) + A (V sv)
-    hipLaunchKernelGGL(k_s1<true>, dim3(1), dim3(SC_BLOCK), 0, s, h->partials, h->A.grid, st);
+    hipLaunchKernelGGL(k_s1<true>, dim3(1), dim3(SC_BLOCK), 0, s, h->partials, h->A.grid, (const double *)nullptr, st);
     launch_spmv(h, h->AT, h->U, h->V, &st->c2, &st->stop, ev ? ev[2] : nullptr, ev ? ev[3] : nullptr);  // V <- (-beta)(V sv) + A'(U su)
-    hipLaunchKernelGGL(k_s2<true>, dim3(1), dim3(SC_BLOCK), 0, s, h->partials, h->AT.grid, st);
+    hipLaunchKernelGGL(k_s2<true>, dim3(1), dim3(SC_BLOCK), 0, s, h->partials, h->AT.grid, (const double *)nullptr, st);
     if (ev)
         hipExtLaunchKernelGGL(k_update, dim3(h->vgrid_n), dim3(VEC_BLOCK), 0, s, ev[4], ev[5], 0, h->X, h->W,
                               (const double *)h->V, h->SE, (int64_t)h->n, (const LsqrState *)st, h->partials);
     else
         hipLaunchKernelGGL(k_update, dim3(h->vgrid_n), dim3(VEC_BLOCK), 0, s, h->X, h->W, h->V, h->SE,
                            (int64_t)h->n, (const LsqrState *)st, h->partials);
-    hipLaunchKernelGGL(k_s3<true>, dim3(1), dim3(SC_BLOCK), 0, s, h->partials, h->vgrid_n, st, h->X, h->d_log);
+    hipLaunchKernelGGL(k_s3<true>, dim3(1), dim3(SC_BLOCK), 0, s, h->partials, h->vgrid_n, (const double *)nullptr, st, h->X, h->d_log);
 }
 
 static int ensure_graph(H *h)
@@ -528,9 +531,9 @@ static int solve_core(H *h, const double *b, bool b_on_device, double damp, doub
     }
     // beta = norm(u); u /= beta; v = A'u; alpha = norm(v); v /= alpha; w = v  (:632-644)
     hipLaunchKernelGGL(k_dot, dim3(h->vgrid_m), dim3(VEC_BLOCK), 0, s, h->U, h->U, (int64_t)m, h->partials);
-    hipLaunchKernelGGL(k_s_init1<true>, dim3(1), dim3(SC_BLOCK), 0, s, h->partials, h->vgrid_m, st);
+    hipLaunchKernelGGL(k_s_init1<true>, dim3(1), dim3(SC_BLOCK), 0, s, h->partials, h->vgrid_m, (const double *)nullptr, st);
     launch_spmv(h, h->AT, h->U, h->V, &st->c2, h->d_zero);
-    hipLaunchKernelGGL(k_s_init2<true>, dim3(1), dim3(SC_BLOCK), 0, s, h->partials, h->AT.grid, st);
+    hipLaunchKernelGGL(k_s_init2<true>, dim3(1), dim3(SC_BLOCK), 0, s, h->partials, h->AT.grid, (const double *)nullptr, st);
     hipLaunchKernelGGL(k_copy_scale, dim3(h->vgrid_n), dim3(VEC_BLOCK), 0, s, h->W, h->V, (int64_t)n,
                        (const LsqrState *)st);
     HIPCHK(hipGetLastError());
@@ -958,3 +961,7 @@ extern "C" int lsqrhip_dev_sync(void)
     HIPCHK(hipDeviceSynchronize());
     return LSQRHIP_OK;
 }
+
+// row-block sharded solve (multi-GPU) and on-device problem generators
+#include "shard_api.h"
+#include "gen_api.h"

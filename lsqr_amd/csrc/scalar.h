@@ -38,9 +38,9 @@ __device__ __forceinline__ double take_sum(const double *partials, int np, const
 
 // after sum(b^2): beta = norm(b); u = b/beta     (src/lsqr.f90:597-617, 632-637)
 template <bool REDUCE>
-__global__ __launch_bounds__(SC_BLOCK) void k_s_init1(const double *partials, int np, LsqrState *st)
+__global__ __launch_bounds__(SC_BLOCK) void k_s_init1(const double *partials, int np, const double *pre, LsqrState *st)
 {
-    const double sum = take_sum<REDUCE>(partials, np, &st->sum_u);
+    const double sum = take_sum<REDUCE>(partials, np, pre);
     if (threadIdx.x != 0) return;
     const double beta = sqrt(sum);
     st->beta = beta;
@@ -56,14 +56,15 @@ __global__ __launch_bounds__(SC_BLOCK) void k_s_init1(const double *partials, in
         st->su = 1.0;
         st->c2.skip = 1;
     }
+    st->c2p = st->c2;  // sharded: T <- 0*(T*1) + A_p'(U su)
 }
 
 // after sum(V^2): alpha = norm(A'u); v = V/alpha; arnorm; loop entry     (:638-653)
 template <bool REDUCE>
-__global__ __launch_bounds__(SC_BLOCK) void k_s_init2(const double *partials, int np, LsqrState *st)
+__global__ __launch_bounds__(SC_BLOCK) void k_s_init2(const double *partials, int np, const double *pre, LsqrState *st)
 {
     const bool skipped = st->c2.skip != 0;
-    const double sum = take_sum<REDUCE>(partials, np, &st->sum_v);
+    const double sum = take_sum<REDUCE>(partials, np, pre);
     if (threadIdx.x != 0) return;
     const double beta = st->beta;
     const double alpha = skipped ? 0.0 : sqrt(sum);
@@ -90,10 +91,10 @@ __global__ __launch_bounds__(SC_BLOCK) void k_s_init2(const double *partials, in
 
 // after mode 1: beta = norm(A v - alpha u); anorm     (:675, :683-693)
 template <bool REDUCE>
-__global__ __launch_bounds__(SC_BLOCK) void k_s1(const double *partials, int np, LsqrState *st)
+__global__ __launch_bounds__(SC_BLOCK) void k_s1(const double *partials, int np, const double *pre, LsqrState *st)
 {
     if (st->stop != 0) return;
-    const double sum = take_sum<REDUCE>(partials, np, &st->sum_u);
+    const double sum = take_sum<REDUCE>(partials, np, pre);
     if (threadIdx.x != 0) return;
     st->itn = st->itn + 1;
     const double alpha = st->alpha;
@@ -112,15 +113,19 @@ __global__ __launch_bounds__(SC_BLOCK) void k_s1(const double *partials, int np,
         st->su = 1.0;
         st->c2.skip = 1;
     }
+    st->c2p.sx = st->su;  // sharded: T <- 0*(T*1) + A_p'(U su); V <- c2.cy (V c2.sy) + sum_p T_p
+    st->c2p.sy = 1.0;
+    st->c2p.cy = 0.0;
+    st->c2p.skip = st->c2.skip;
 }
 
 // after mode 2: alpha = norm(A'u - beta v); plane rotations; update coefficients   (:695-726)
 template <bool REDUCE>
-__global__ __launch_bounds__(SC_BLOCK) void k_s2(const double *partials, int np, LsqrState *st)
+__global__ __launch_bounds__(SC_BLOCK) void k_s2(const double *partials, int np, const double *pre, LsqrState *st)
 {
     if (st->stop != 0) return;
     const bool skipped = st->c2.skip != 0;
-    const double sum = take_sum<REDUCE>(partials, np, &st->sum_v);
+    const double sum = take_sum<REDUCE>(partials, np, pre);
     if (threadIdx.x != 0) return;
     double alpha = st->alpha;
     const double beta = st->beta;
@@ -161,11 +166,11 @@ __global__ __launch_bounds__(SC_BLOCK) void k_s2(const double *partials, int np,
 
 // after the x/w update: dknorm, norm estimates, stopping tests, istop   (:751-810, 843-850)
 template <bool REDUCE>
-__global__ __launch_bounds__(SC_BLOCK) void k_s3(const double *partials, int np, LsqrState *st,
-                                                 const double *x, double *log)
+__global__ __launch_bounds__(SC_BLOCK) void k_s3(const double *partials, int np, const double *pre,
+                                                 LsqrState *st, const double *x, double *log)
 {
     if (st->stop != 0) return;
-    const double sum = take_sum<REDUCE>(partials, np, &st->sum_d);
+    const double sum = take_sum<REDUCE>(partials, np, pre);
     if (threadIdx.x != 0) return;
     const int itn = st->itn;
     const double rho = st->rho, phi = st->phi, theta = st->theta, tau = st->tau;

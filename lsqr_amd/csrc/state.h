@@ -38,6 +38,7 @@ struct LsqrState {
     double sv;  // pending scale of V: v = V * sv   (1/alpha, or 1 when alpha == 0)
     SpmvCoef c1;    // mode-1 launch of the next iteration: U <- (-alpha)*(U*su) + A (V*sv)
     SpmvCoef c2;    // mode-2 launch of this iteration:     V <- (-beta)*(V*sv) + A'(U*su)
+    SpmvCoef c2p;   // row-sharded mode 2: T_p <- A_p'(U_p*su) (then V <- c2.cy*(V*c2.sy) + sum_p T_p)
     // rotations / estimates (names as in the reference) ------------------------
     double rhobar, phibar, anorm, acond, dnorm, dxmax, res2, psi;
     double xnorm, xnorm1, cs2, sn2, z, bnorm, rnorm, arnorm;
@@ -45,8 +46,6 @@ struct LsqrState {
     double t1, t2, t3;            // coefficients of the x/w update kernel
     // log-only extras ----------------------------------------------------------
     double alpha0, beta0, test2_0;
-    // reduced sums handed between kernels (and, multi-GPU, through the all-reduce)
-    double sum_u, sum_v, sum_d;
 };
 
 constexpr int LOG_STRIDE = 14;  // == LSQRHIP_LOG_STRIDE

@@ -1,0 +1,91 @@
+"""bench.py's N > 1 leg: the row-block sharded solve, one rank per GPU over RCCL.
+
+Default workload: BASELINE.json configs[3] made concrete per SURVEY.md section 8d --
+m = n = 10^7 random sparse least squares with 100 nonzeros per row (10^9 nonzeros, density
+1e-5; the literal "~1 %" is 10^12 nonzeros = 12 TB and cannot exist on 8 x 288 GB), damp = 1e-3.
+Total work is fixed as N grows: "scaling": "strong".  The matrix is generated in HBM, each
+rank only its own row block.
+"""
+from __future__ import annotations
+
+import json
+import os
+import time
+
+DEFAULT_SPEC = "random:10000000:10000000:100"
+
+
+def run_distributed(args):
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from . import capi, devgen
+    from .dist import HipShardBackend, ShardedLSQR, TorchComm, partition_rows
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py: no MI355X visible; the HIP path has no CPU fallback")
+    torch.cuda.set_device(local)
+    capi.check(capi.lib().lsqrhip_set_device(local))
+    dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+    comm = TorchComm()
+
+    spec = DEFAULT_SPEC if args.workload == "auto" else args.workload
+    cfg = devgen.parse_spec(spec)
+    K, W = args.steps, args.warmup
+    blocks = partition_rows(cfg["m"], world, devgen.row_weights(cfg))
+    row0, nrows = blocks[rank]
+    prob = devgen.generate(spec, row0, nrows)
+    be = HipShardBackend(prob.solver, cfg["m"])
+    drv = ShardedLSQR(be, comm, poll_every=min(16, max(1, K)))
+    kw = dict(damp=cfg["damp"], atol=0.0, btol=0.0, conlim=0.0)
+
+    if W > 0:
+        drv.solve(prob.d_b.ptr.value, itnlim=W, **kw)
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    r = drv.solve(prob.d_b.ptr.value, itnlim=K, **kw)
+    torch.cuda.synchronize()
+    dist.barrier()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    assert r.itn == K and r.istop == 5, (r.itn, r.istop)
+
+    nnz_all = torch.tensor([prob.nnz], dtype=torch.int64, device="cuda")
+    dist.all_reduce(nnz_all)
+    nnz_total = int(nnz_all.item())
+
+    # local SpMV rate of this rank's block (roofline of the dominant kernel)
+    be.close()
+    s = prob.solver
+    reps = max(20, min(K, 200))
+    avg1 = s.bench_kernel(1, reps)
+    tm = s.last_timing()
+    p = 8 if nnz_total >= 2 ** 31 and prob.nnz >= 2 ** 31 else 4
+    b1 = 12 * prob.nnz + p * (nrows + 1) + 8 * cfg["n"] + 16 * nrows
+    ach = b1 / (avg1 * 1e-3) / 1e9
+
+    if rank == 0:
+        out = {
+            "metric": "lsqr_iterations_per_sec", "value": K / dt, "unit": "it/s", "n_gpus": world, "steps": K,
+            "warmup": W, "ms_per_step": 1e3 * dt / K, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{spec} m={cfg['m']} n={cfg['n']} nnz={nnz_total} damp={cfg['damp']} "
+                                   f"(BASELINE.json configs[3]: 10M x 10M random, row-block sharded)",
+                       "rows_per_rank": [b[1] for b in blocks], "collectives_per_iteration":
+                           {"allreduce_scalar_f64": 1, "allreduce_vector_bytes": 8 * cfg["n"]},
+                       "backend": "nccl (RCCL over xGMI)"},
+            "result": {"istop": r.istop, "itn": r.itn, "anorm": r.anorm, "rnorm": r.rnorm},
+            "roofline": {"bound": "hbm", "kernel": "k_spmv_fused (aprod mode 1, local row block, rank 0)",
+                         "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": None,
+                         "bytes_per_launch": b1, "avg_launch_us": avg1 * 1e3, "launches": reps},
+        }
+        print(json.dumps(out), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()

@@ -97,6 +97,24 @@ class lsqr_solver_ez:  # noqa: N801  (name kept from the reference)
             self.nout = nout
         return self
 
+    def initialize_from_device_coo(self, m, n, nnz, d_irow, d_icol, d_a, atol=None, btol=None, conlim=None,
+                                   itnlim=None, nout=None):
+        """`initialize` for triplets that already live in HBM (1-based; raw device addresses)."""
+        self._free()
+        self._reset()
+        h = C.c_void_p()
+        check(lib().lsqrhip_create_from_device_coo(int(m), int(n), int(nnz), d_irow, d_icol, d_a, C.byref(h)))
+        self._h = h
+        self.m, self.n, self.num_nonzero_elements = int(m), int(n), int(nnz)
+        for k, v in (("atol", atol), ("btol", btol), ("conlim", conlim)):
+            if v is not None:
+                setattr(self, k, float(v))
+        if itnlim is not None:
+            self.itnlim = int(itnlim)
+        if nout is not None:
+            self.nout = nout
+        return self
+
     def _need(self):
         if not self._h:
             raise LsqrHipError(capi.ERR_NOT_INIT, lib().lsqrhip_error_string(capi.ERR_NOT_INIT).decode())

@@ -1,0 +1,111 @@
+"""Multi-GPU path: partitioner (host logic) + the sharded driver under gloo, world_size 2/3.
+
+CPU: the stage kernels are replaced by tests/np_shard_backend.py (oracle-backed), which
+exercises lsqr_amd.dist -- stage order, the scalar and the n-vector all-reduce, stop
+agreement -- across real processes.  GPU (-m gpu): the same driver over the C-ABI stage
+entry points, two ranks sharing cuda:0 with gloo carrying the collectives."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import oracle
+from cases import build_cases
+from lsqr_amd.dist import local_block, partition_rows
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CASES = build_cases()
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def run_world(case, world, backend, tmp_path):
+    port = free_port()
+    outs = [str(tmp_path / f"r{r}.npz") for r in range(world)]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dist_worker.py"), str(r), str(world), str(port),
+                               case, backend, outs[r]], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                              text=True) for r in range(world)]
+    logs = []
+    for p in procs:
+        try:
+            logs.append(p.communicate(timeout=240)[0])
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+    for p, log in zip(procs, logs):
+        assert p.returncode == 0, log[-3000:]
+    return [np.load(o) for o in outs]
+
+
+def test_partition_rows_properties():
+    for m, parts in ((10, 3), (7, 7), (100, 8), (5, 1)):
+        blocks = partition_rows(m, parts)
+        assert blocks[0][0] == 0 and sum(b[1] for b in blocks) == m
+        assert all(blocks[i][0] + blocks[i][1] == blocks[i + 1][0] for i in range(parts - 1))
+        assert all(b[1] >= 1 for b in blocks)
+    # balanced by nonzeros, not by rows: one heavy row gets a block (almost) to itself
+    w = np.ones(1000)
+    w[10] = 5000.0
+    blocks = partition_rows(1000, 4, w)
+    loads = [float(np.sum(w[r0:r0 + nr])) for r0, nr in blocks]
+    assert max(loads) <= 5200 and sum(b[1] for b in blocks) == 1000 and all(b[1] >= 1 for b in blocks)
+    # uniform weights -> near-equal row counts
+    blocks = partition_rows(1000, 8, np.full(1000, 7.0))
+    assert max(b[1] for b in blocks) - min(b[1] for b in blocks) <= 1
+    # fewer rows than ranks: trailing blocks may be empty, still a partition
+    blocks = partition_rows(2, 4)
+    assert sum(b[1] for b in blocks) == 2
+
+
+def test_local_block_renumbers_and_keeps_order():
+    p, _ = CASES["shuffled_dups"]
+    blocks = partition_rows(p.m, 3, np.bincount(p.irow - 1, minlength=p.m))
+    total = 0
+    for r0, nr in blocks:
+        ir, ic, a, b = local_block(p.irow, p.icol, p.a, p.b, r0, nr)
+        assert ir.min() >= 1 and ir.max() <= nr and len(b) == nr
+        sel = (p.irow > r0) & (p.irow <= r0 + nr)
+        assert np.array_equal(a, p.a[sel]) and np.array_equal(ic, p.icol[sel])
+        total += len(a)
+    assert total == p.nnz
+
+
+def check_against_oracle(case, res):
+    p, o = CASES[case]
+    ref = oracle.port().solve(p.m, p.n, p.irow, p.icol, p.a, p.b, **o)
+    for r in res:                          # every rank holds the replicated solution
+        assert int(r["istop"]) == ref.istop and int(r["itn"]) == ref.itn
+        assert np.linalg.norm(r["x"] - ref.x) <= 1e-10 * np.linalg.norm(ref.x)
+        assert abs(float(r["anorm"]) - ref.anorm) <= 1e-10 * ref.anorm
+        assert abs(float(r["rnorm"]) - ref.rnorm) <= 1e-10 * ref.rnorm
+        if o["wantse"]:
+            assert np.linalg.norm(r["se"] - ref.se) <= 1e-9 * np.linalg.norm(ref.se)
+    for r in res[1:]:                      # replicated state is bit-identical across ranks
+        assert np.array_equal(r["x"], res[0]["x"]) and float(r["anorm"]) == float(res[0]["anorm"])
+
+
+@pytest.mark.parametrize("case,world", [("random_over_damped", 2), ("poisson_20x20_it50", 2),
+                                        ("random_over_se", 3), ("b_zero", 2)])
+def test_sharded_driver_gloo_cpu(case, world, tmp_path):
+    res = run_world(case, world, "numpy", tmp_path)
+    if case == "b_zero":
+        assert all(int(r["istop"]) == 0 and int(r["itn"]) == 0 and not r["x"].any() for r in res)
+    else:
+        check_against_oracle(case, res)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["random_over_damped", "poisson_20x20_it50", "random_over_se"])
+def test_sharded_hip_stages_two_ranks_one_gpu(case, tmp_path):
+    check_against_oracle(case, run_world(case, 2, "hip", tmp_path))
