@@ -86,6 +86,12 @@ class TorchComm:
         self.rank = dist.get_rank(group)
 
     def all_reduce_sum(self, t):
+        if getattr(t, "is_cuda", False) and self.dist.get_backend(self.group) != "nccl":
+            # gloo (tests): stage through host memory on the CURRENT stream, explicitly
+            tmp = t.cpu()
+            self.dist.all_reduce(tmp, op=self.dist.ReduceOp.SUM, group=self.group)
+            t.copy_(tmp)
+            return
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
 
     def agree_max(self, value: int) -> int:

@@ -38,7 +38,7 @@ def run_world(case, world, backend, tmp_path):
     logs = []
     for p in procs:
         try:
-            logs.append(p.communicate(timeout=240)[0])
+            logs.append(p.communicate(timeout=150)[0])
         except subprocess.TimeoutExpired:
             for q in procs:
                 q.kill()
