@@ -35,6 +35,45 @@ __device__ __forceinline__ double block_sum(double v, double *lds)
     return r;
 }
 
+// This thread's share of a fixed-order sum of np partials: p[tid] + p[tid+BLOCK] + ... in that
+// order.  The first 8 loads are issued together (np <= 2048 = every grid cap in this library),
+// because a plain `for (...) s += p[i]` waits for each load in turn: 8 dependent L2 round
+// trips, ~4 us of every scalar kernel and every lazy SpMV prologue before this was unrolled.
+template <int BLOCK>
+__device__ __forceinline__ double strided_sum(const double *__restrict__ p, int np)
+{
+    const int t = threadIdx.x;
+    const int last = np > 0 ? np - 1 : 0;
+    double v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int i = t + k * BLOCK;
+        v[k] = p[i < last ? i : last];
+    }
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+        if (t + k * BLOCK < np) s += v[k];
+    for (int i = t + 8 * BLOCK; i < np; i += BLOCK) s += p[i];
+    return s;
+}
+
+// Fixed-order sum of np doubles by the whole workgroup, result returned to EVERY thread.
+// Same per-thread stride, shuffle tree and cross-wave order as the scalar kernels use
+// (scalar.h take_sum), so any kernel reducing the same partials obtains the same bits.
+// `lds` holds BLOCK/64 + 1 doubles.
+template <int BLOCK>
+__device__ __forceinline__ double block_sum_all(const double *__restrict__ p, int np, double *lds)
+{
+    const double s = np > 0 ? strided_sum<BLOCK>(p, np) : 0.0;
+    const double r = block_sum<BLOCK>(s, lds);
+    if (threadIdx.x == 0) lds[BLOCK / WAVE] = r;
+    __syncthreads();
+    const double out = lds[BLOCK / WAVE];
+    __syncthreads();  // lds may be reused right away by the caller
+    return out;
+}
+
 // Blocks b and b+8 share an XCD (and its 4 MiB L2) under the observed round-robin
 // placement.  Give each XCD label one contiguous eighth of the work items so that
 // neighbouring row blocks -- which gather neighbouring parts of x -- share an L2.
@@ -42,17 +81,16 @@ __device__ __forceinline__ double block_sum(double v, double *lds)
 struct XcdRange {
     int64_t first, end, stride;
 };
-__device__ __forceinline__ XcdRange xcd_range(int64_t nitems)
+__device__ __forceinline__ XcdRange xcd_range(int64_t nitems, int g, int wg)
 {
-    const int g = gridDim.x;
     XcdRange r;
     if ((g & 7) != 0 || g < 8) {
-        r.first = blockIdx.x;
+        r.first = wg;
         r.end = nitems;
         r.stride = g;
         return r;
     }
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int xcd = wg & 7, slot = wg >> 3;
     const int64_t per = (nitems + 7) >> 3;
     r.first = (int64_t)xcd * per + slot;
     r.end = (int64_t)(xcd + 1) * per;

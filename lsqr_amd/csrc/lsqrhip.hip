@@ -120,6 +120,7 @@ struct Csr {
     int *col = nullptr;
     double *val = nullptr;
     int *rb = nullptr;  // row-block boundaries [nblk+1]
+    RowBlock *blk = nullptr;  // one descriptor per row block (spmv.h)
     int64_t nblk = 0;
     int rows = 0, cols = 0;
     int grid = 0;
@@ -154,6 +155,16 @@ struct lsqrhip_handle_s {
     std::vector<hipEvent_t> ev;
     hipEvent_t ev_loop0 = nullptr, ev_loop1 = nullptr;
     lsqrhip_timing_t timing{};
+    // pipelined schedule (solve_loop.h)
+    int pipeline = 1;
+    int gexec_pipeline = -1;
+    hipStream_t stream_b = nullptr;      // side stream: scalar machine + x/w update
+    hipEvent_t ev_join = nullptr;
+    std::vector<hipEvent_t> ev_k2, ev_k4;  // per iteration of a batch
+    double *P1[2] = {nullptr, nullptr};  // mode-1 partials by iteration parity
+    double *P2[2] = {nullptr, nullptr};  // mode-2 partials by iteration parity
+    double *P3 = nullptr;                // x/w update partials
+    NormSlot *slots = nullptr;           // [0..1] alpha side (from mode 1), [2..3] beta side (from mode 2)
     // row-sharded solve (shard_api.h): caller-owned exchange buffers
     double *shard_T = nullptr, *shard_sums = nullptr;
     int shard_wantse = 0;
@@ -174,6 +185,7 @@ static void free_csr(Csr &c)
     if (c.col) (void)hipFree(c.col);
     if (c.val) (void)hipFree(c.val);
     if (c.rb) (void)hipFree(c.rb);
+    if (c.blk) (void)hipFree(c.blk);
     c = Csr();
 }
 
@@ -209,6 +221,13 @@ extern "C" int lsqrhip_destroy(lsqrhip_handle_t h)
     if (h->d_unit) (void)hipFree(h->d_unit);
     if (h->d_zero) (void)hipFree(h->d_zero);
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
+    for (hipEvent_t e : h->ev_k2) (void)hipEventDestroy(e);
+    for (hipEvent_t e : h->ev_k4) (void)hipEventDestroy(e);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+    for (double *p : {h->P1[0], h->P1[1], h->P2[0], h->P2[1], h->P3})
+        if (p) (void)hipFree(p);
+    if (h->slots) (void)hipFree(h->slots);
+    if (h->stream_b) (void)hipStreamDestroy(h->stream_b);
     if (h->ev_loop0) (void)hipEventDestroy(h->ev_loop0);
     if (h->ev_loop1) (void)hipEventDestroy(h->ev_loop1);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -273,6 +292,10 @@ static int build_csr_T(hipStream_t s, const int *d_keys, const int *d_other, con
     const int64_t nt = out.nblk + 1;
     hipLaunchKernelGGL(k_row_blocks<OffT>, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, s,
                        (const OffT *)out.rowptr, rows, out.nblk, out.rb);
+    HIPCHK(hipMalloc((void **)&out.blk, sizeof(RowBlock) * (size_t)out.nblk));
+    out.bytes += (int64_t)sizeof(RowBlock) * out.nblk;
+    hipLaunchKernelGGL(k_block_desc<OffT>, dim3((unsigned)((out.nblk + 255) / 256)), dim3(256), 0, s,
+                       (const OffT *)out.rowptr, (const int *)out.rb, out.nblk, out.blk);
     HIPCHK(hipGetLastError());
     int64_t grid = std::min<int64_t>(out.nblk, SPMV_MAX_GRID);
     if (grid >= 8) grid &= ~(int64_t)7;  // multiple of 8: XCD-aware mapping (common.h)
@@ -317,6 +340,14 @@ static int finish_create(H *h, const int *d_irow, const int *d_icol, const doubl
     HIPCHK(hipMalloc((void **)&h->SE, sizeof(double) * n1));
     HIPCHK(hipMalloc((void **)&h->partials, sizeof(double) * SPMV_MAX_GRID));
     HIPCHK(hipMalloc((void **)&h->d_scalar, sizeof(double) * 4));
+    for (double **pp : {&h->P1[0], &h->P1[1], &h->P2[0], &h->P2[1], &h->P3}) {
+        HIPCHK(hipMalloc((void **)pp, sizeof(double) * SPMV_MAX_GRID));
+        HIPCHK(hipMemsetAsync(*pp, 0, sizeof(double) * SPMV_MAX_GRID, s));
+    }
+    HIPCHK(hipMalloc((void **)&h->slots, sizeof(NormSlot) * 4));
+    HIPCHK(hipMemsetAsync(h->slots, 0, sizeof(NormSlot) * 4, s));
+    HIPCHK(hipStreamCreateWithFlags(&h->stream_b, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
     HIPCHK(hipMalloc((void **)&h->d_state, sizeof(LsqrState)));
     HIPCHK(hipHostMalloc((void **)&h->h_state, sizeof(LsqrState)));
     HIPCHK(hipMalloc((void **)&h->d_unit, sizeof(SpmvCoef)));
@@ -409,220 +440,9 @@ extern "C" int lsqrhip_info(lsqrhip_handle_t h, int64_t *dims)
 }
 
 // ---------------------------------------------------------------------------
-// kernel launch helpers
+// launch helpers, iteration schedules, solve_core
 // ---------------------------------------------------------------------------
-// e0/e1 (optional): HIP events that receive the kernel's own begin / end timestamps
-// (hipExtLaunchKernelGGL), i.e. the same interval rocprofv3's kernel trace reports.
-static void launch_spmv(H *h, const Csr &c, const double *x, double *y, const SpmvCoef *coef, const int *stop,
-                        hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr)
-{
-    if (e0 == nullptr) {  // plain launch (also the only form used under stream capture)
-        if (h->off64)
-            hipLaunchKernelGGL(k_spmv_fused<long long>, dim3(c.grid), dim3(SPMV_BLOCK), 0, h->stream,
-                               (const long long *)c.rowptr, c.col, c.val, c.rb, c.nblk, x, y, coef, stop, h->partials);
-        else
-            hipLaunchKernelGGL(k_spmv_fused<int>, dim3(c.grid), dim3(SPMV_BLOCK), 0, h->stream,
-                               (const int *)c.rowptr, c.col, c.val, c.rb, c.nblk, x, y, coef, stop, h->partials);
-        return;
-    }
-    if (h->off64)
-        hipExtLaunchKernelGGL(k_spmv_fused<long long>, dim3(c.grid), dim3(SPMV_BLOCK), 0, h->stream, e0, e1, 0,
-                              (const long long *)c.rowptr, (const int *)c.col, (const double *)c.val,
-                              (const int *)c.rb, c.nblk, x, y, coef, stop, h->partials);
-    else
-        hipExtLaunchKernelGGL(k_spmv_fused<int>, dim3(c.grid), dim3(SPMV_BLOCK), 0, h->stream, e0, e1, 0,
-                              (const int *)c.rowptr, (const int *)c.col, (const double *)c.val, (const int *)c.rb,
-                              c.nblk, x, y, coef, stop, h->partials);
-}
-
-// one LSQR iteration = 6 launches; `ev` (optional) gets 3 (start, stop) event pairs, one per
-// vector kernel
-static void launch_iteration(H *h, hipEvent_t *ev)
-{
-    LsqrState *st = h->d_state;
-    hipStream_t s = h->stream;
-    launch_spmv(h, h->A, h->V, h->U, &st->c1, &st->stop, ev ? ev[0] : nullptr, ev ? ev[1] : nullptr);   // U <- (-alpha)(U su) + A (V sv)
-    hipLaunchKernelGGL(k_s1<true>, dim3(1), dim3(SC_BLOCK), 0, s, h->partials, h->A.grid, (const double *)nullptr, st);
-    launch_spmv(h, h->AT, h->U, h->V, &st->c2, &st->stop, ev ? ev[2] : nullptr, ev ? ev[3] : nullptr);  // V <- (-beta)(V sv) + A'(U su)
-    hipLaunchKernelGGL(k_s2<true>, dim3(1), dim3(SC_BLOCK), 0, s, h->partials, h->AT.grid, (const double *)nullptr, st);
-    if (ev)
-        hipExtLaunchKernelGGL(k_update, dim3(h->vgrid_n), dim3(VEC_BLOCK), 0, s, ev[4], ev[5], 0, h->X, h->W,
-                              (const double *)h->V, h->SE, (int64_t)h->n, (const LsqrState *)st, h->partials);
-    else
-        hipLaunchKernelGGL(k_update, dim3(h->vgrid_n), dim3(VEC_BLOCK), 0, s, h->X, h->W, h->V, h->SE,
-                           (int64_t)h->n, (const LsqrState *)st, h->partials);
-    hipLaunchKernelGGL(k_s3<true>, dim3(1), dim3(SC_BLOCK), 0, s, h->partials, h->vgrid_n, (const double *)nullptr, st, h->X, h->d_log);
-}
-
-static int ensure_graph(H *h)
-{
-    if (h->gexec && !h->graph_dirty && h->gexec_iters == h->graph_iters) return LSQRHIP_OK;
-    destroy_graph(h);
-    hipGraph_t g = nullptr;
-    HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-    for (int i = 0; i < h->graph_iters; ++i) launch_iteration(h, nullptr);
-    HIPCHK(hipStreamEndCapture(h->stream, &g));
-    hipError_t e = hipGraphInstantiate(&h->gexec, g, nullptr, nullptr, 0);
-    (void)hipGraphDestroy(g);
-    if (e != hipSuccess) return fail(LSQRHIP_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
-    h->gexec_iters = h->graph_iters;
-    h->graph_dirty = false;
-    return LSQRHIP_OK;
-}
-
-// ---------------------------------------------------------------------------
-// solve
-// ---------------------------------------------------------------------------
-static int solve_core(H *h, const double *b, bool b_on_device, double damp, double atol, double btol, double conlim,
-                      int itnlim, int wantse, int want_log, double *x, double *se, bool out_on_device, int *istop,
-                      int *itn, double *anorm, double *acond, double *rnorm, double *arnorm, double *xnorm)
-{
-    if (!h) return fail(LSQRHIP_ERR_NOT_INIT, lsqrhip_error_string(LSQRHIP_ERR_NOT_INIT));
-    if (!istop || (!x && h->n > 0) || (!b && h->m > 0)) return fail(LSQRHIP_ERR_ARG, "null b, x or istop");
-    if (wantse && !se) return fail(LSQRHIP_ERR_ARG, "wantse set but se is null");
-    HIPCHK(hipSetDevice(h->device));
-    const auto t_host0 = std::chrono::steady_clock::now();
-    hipStream_t s = h->stream;
-    const int m = h->m, n = h->n;
-    LsqrState *st = h->d_state;
-
-    if (want_log) {
-        const int cap = std::max(itnlim, 1);
-        if (cap > h->log_cap) {
-            if (h->d_log) (void)hipFree(h->d_log);
-            h->d_log = nullptr;
-            HIPCHK(hipMalloc((void **)&h->d_log, sizeof(double) * LOG_STRIDE * (size_t)cap));
-            h->log_cap = cap;
-            h->graph_dirty = true;
-        }
-    }
-    h->log_count = 0;
-
-    // ---- initial state (src/lsqr.f90:597-617) -------------------------------
-    LsqrState init;
-    std::memset(&init, 0, sizeof(init));
-    init.itnlim = itnlim;
-    init.damped = damp > 0.0;
-    init.wantse = wantse != 0;
-    init.want_log = want_log != 0;
-    init.log_cap = h->log_cap;
-    init.m = m;
-    init.n = n;
-    init.damp = damp;
-    init.atol = atol;
-    init.btol = btol;
-    init.ctol = conlim > 0.0 ? 1.0 / conlim : 0.0;
-    init.cs2 = -1.0;
-    init.su = init.sv = 1.0;
-    init.c1.skip = 1;
-    init.c2.skip = 1;
-    *h->h_state = init;
-    HIPCHK(hipMemcpyAsync(st, h->h_state, sizeof(LsqrState), hipMemcpyHostToDevice, s));
-
-    // u = b (solve_ez :242); v = 0, x = 0, se = 0 (:621-630)
-    if (m > 0)
-        HIPCHK(hipMemcpyAsync(h->U, b, sizeof(double) * (size_t)m,
-                              b_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
-    if (n > 0) {
-        HIPCHK(hipMemsetAsync(h->V, 0, sizeof(double) * (size_t)n, s));
-        HIPCHK(hipMemsetAsync(h->X, 0, sizeof(double) * (size_t)n, s));
-        HIPCHK(hipMemsetAsync(h->W, 0, sizeof(double) * (size_t)n, s));
-        if (wantse) HIPCHK(hipMemsetAsync(h->SE, 0, sizeof(double) * (size_t)n, s));
-    }
-    // beta = norm(u); u /= beta; v = A'u; alpha = norm(v); v /= alpha; w = v  (:632-644)
-    hipLaunchKernelGGL(k_dot, dim3(h->vgrid_m), dim3(VEC_BLOCK), 0, s, h->U, h->U, (int64_t)m, h->partials);
-    hipLaunchKernelGGL(k_s_init1<true>, dim3(1), dim3(SC_BLOCK), 0, s, h->partials, h->vgrid_m, (const double *)nullptr, st);
-    launch_spmv(h, h->AT, h->U, h->V, &st->c2, h->d_zero);
-    hipLaunchKernelGGL(k_s_init2<true>, dim3(1), dim3(SC_BLOCK), 0, s, h->partials, h->AT.grid, (const double *)nullptr, st);
-    hipLaunchKernelGGL(k_copy_scale, dim3(h->vgrid_n), dim3(VEC_BLOCK), 0, s, h->W, h->V, (int64_t)n,
-                       (const LsqrState *)st);
-    HIPCHK(hipGetLastError());
-
-    // ---- the loop (src/lsqr.f90:673-852) ------------------------------------
-    lsqrhip_timing_t &tm = h->timing;
-    tm = lsqrhip_timing_t{};
-    const int P = h->off64 ? 8 : 4;
-    tm.spmv1_bytes = 12 * h->nnz + (int64_t)P * (m + 1) + 8ll * n + 16ll * m;
-    tm.spmv2_bytes = 12 * h->nnz + (int64_t)P * (n + 1) + 8ll * m + 16ll * n;
-    tm.vec_bytes = 40ll * n + (wantse ? 16ll * n : 0);
-
-    const int G = std::max(1, h->graph_iters);
-    const bool timed = h->time_kernels != 0;
-    const bool graph = h->use_graph != 0 && !timed;
-    if (graph) RET(ensure_graph(h));
-    if (timed && (int)h->ev.size() < 6 * G) {
-        const size_t old = h->ev.size();
-        h->ev.resize(6 * (size_t)G);
-        for (size_t i = old; i < h->ev.size(); ++i) HIPCHK(hipEventCreate(&h->ev[i]));
-    }
-    HIPCHK(hipEventRecord(h->ev_loop0, s));
-    // S3 raises `stop` at itn == itnlim at the latest; anything beyond this many batches
-    // means the device loop is not advancing (never spin on a dead stream).
-    const int64_t max_batches = (int64_t)std::max(itnlim, 0) / G + 2;
-    for (int64_t batch = 0;; ++batch) {
-        if (batch > max_batches) return fail(LSQRHIP_ERR_HIP, "iteration loop did not terminate (device state not advancing)");
-        if (graph) {
-            HIPCHK(hipGraphLaunch(h->gexec, s));
-        } else {
-            for (int i = 0; i < G; ++i) launch_iteration(h, timed ? &h->ev[6 * (size_t)i] : nullptr);
-            HIPCHK(hipGetLastError());
-        }
-        HIPCHK(hipMemcpyAsync(h->h_state, st, sizeof(LsqrState), hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));
-        if (timed) {
-            // iterations after the stop flag was raised are no-op launches: count only live ones
-            const int live = std::min(G, h->h_state->itn - (int)tm.spmv1_launches);
-            for (int i = 0; i < live; ++i) {
-                float a = 0, c = 0, d = 0;
-                (void)hipEventElapsedTime(&a, h->ev[6 * i + 0], h->ev[6 * i + 1]);
-                (void)hipEventElapsedTime(&c, h->ev[6 * i + 2], h->ev[6 * i + 3]);
-                (void)hipEventElapsedTime(&d, h->ev[6 * i + 4], h->ev[6 * i + 5]);
-                tm.spmv1_ms += a;
-                tm.spmv2_ms += c;
-                tm.update_ms += d;
-            }
-            tm.spmv1_launches += live;
-            tm.spmv2_launches += live;
-            tm.update_launches += live;
-        }
-        if (h->h_state->stop != 0) break;
-    }
-    HIPCHK(hipEventRecord(h->ev_loop1, s));
-
-    // ---- epilogue: se (:857-865), istop 2 -> 3 (:871), outputs --------------
-    if (wantse && n > 0)
-        hipLaunchKernelGGL(k_se_finish, dim3(h->vgrid_n), dim3(VEC_BLOCK), 0, s, h->SE, (int64_t)n,
-                           (const LsqrState *)st);
-    const hipMemcpyKind out_kind = out_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
-    if (n > 0) HIPCHK(hipMemcpyAsync(x, h->X, sizeof(double) * (size_t)n, out_kind, s));
-    if (wantse && n > 0) HIPCHK(hipMemcpyAsync(se, h->SE, sizeof(double) * (size_t)n, out_kind, s));
-    const LsqrState &r = *h->h_state;
-    if (want_log && r.itn > 0) {
-        h->log_count = std::min(r.itn, h->log_cap);
-        h->h_log.resize((size_t)h->log_count * LOG_STRIDE);
-        HIPCHK(hipMemcpyAsync(h->h_log.data(), h->d_log, sizeof(double) * h->h_log.size(), hipMemcpyDeviceToHost, s));
-    }
-    HIPCHK(hipStreamSynchronize(s));
-    float loop_ms = 0;
-    (void)hipEventElapsedTime(&loop_ms, h->ev_loop0, h->ev_loop1);
-    tm.loop_ms = loop_ms;
-    tm.itn = r.itn;
-    if (!timed) {
-        tm.spmv1_launches = tm.spmv2_launches = tm.update_launches = r.itn;
-    }
-
-    int is = r.istop;
-    if (r.damped && is == 2) is = 3;
-    *istop = is;
-    if (itn) *itn = r.itn;
-    if (anorm) *anorm = r.anorm;
-    if (acond) *acond = r.acond;
-    if (rnorm) *rnorm = r.rnorm;
-    if (arnorm) *arnorm = r.arnorm;
-    if (xnorm) *xnorm = r.xnorm;
-    tm.solve_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_host0).count();
-    return LSQRHIP_OK;
-}
+#include "solve_loop.h"
 
 extern "C" int lsqrhip_solve(lsqrhip_handle_t h, const double *b, double damp, double atol, double btol,
                              double conlim, int itnlim, int wantse, int want_log, double *x, double *se, int *istop,
@@ -916,6 +736,7 @@ extern "C" int lsqrhip_set_option(lsqrhip_handle_t h, const char *name, int64_t 
         if (value < 1 || value > 1024) return fail(LSQRHIP_ERR_ARG, "graph_iters must be in [1,1024]");
         h->graph_iters = (int)value;
     } else if (k == "time_kernels") h->time_kernels = value != 0;
+    else if (k == "pipeline") h->pipeline = value != 0;
     else return fail(LSQRHIP_ERR_ARG, "unknown option: " + k);
     return LSQRHIP_OK;
 }

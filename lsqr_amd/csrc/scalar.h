@@ -4,11 +4,14 @@
 // (anorm), :703-721 (damping + QR rotation), :751-810 (estimates, stopping tests),
 // :843-850 (nconv rule), :871 (istop 2 -> 3) and d2norm (:1164-1179).
 //
-// Each kernel first reduces the per-workgroup partials of the preceding vector
-// kernel in a fixed order (template REDUCE = true), or takes an already reduced /
-// all-reduced sum from the state (REDUCE = false, multi-GPU), then thread 0 runs
-// the ~60 flops of scalar work and publishes the coefficients the next vector
-// kernel needs.  Nothing here ever leaves the device during the loop.
+// Each kernel first reduces the per-workgroup partials of a vector kernel in a fixed
+// order (template REDUCE = true), or takes an already reduced / all-reduced sum
+// (REDUCE = false, multi-GPU), then thread 0 runs the scalar work and publishes the
+// coefficients the next vector kernel needs.  Nothing leaves the device during the loop.
+//
+// In the pipelined single-GPU schedule (solve_loop.h) these kernels are OFF the critical
+// path: k_s12 (steps 1+2 merged) and k_s3 run on a side stream next to the following SpMV,
+// which derives the one norm it needs by itself (spmv.h, lazy coefficients).
 #pragma once
 
 #include "common.h"
@@ -27,75 +30,16 @@ __device__ __forceinline__ double d2norm(double a, double b)  // src/lsqr.f90:11
 }
 
 template <bool REDUCE>
-__device__ __forceinline__ double take_sum(const double *partials, int np, const double *pre)
+__device__ __forceinline__ double take_sum(const double *partials, int np, const double *pre, double *red)
 {
-    __shared__ double red[SC_BLOCK / WAVE];
     if (!REDUCE) return *pre;
-    double s = 0.0;
-    for (int i = threadIdx.x; i < np; i += SC_BLOCK) s += partials[i];
+    const double s = np > 0 ? strided_sum<SC_BLOCK>(partials, np) : 0.0;
     return block_sum<SC_BLOCK>(s, red);  // valid in thread 0
 }
 
-// after sum(b^2): beta = norm(b); u = b/beta     (src/lsqr.f90:597-617, 632-637)
-template <bool REDUCE>
-__global__ __launch_bounds__(SC_BLOCK) void k_s_init1(const double *partials, int np, const double *pre, LsqrState *st)
+// ---- step 1: after mode 1.  beta = norm(A v - alpha u); anorm        (:675, :683-693) ----
+__device__ __forceinline__ void s1_step(LsqrState *st, double sum)
 {
-    const double sum = take_sum<REDUCE>(partials, np, pre);
-    if (threadIdx.x != 0) return;
-    const double beta = sqrt(sum);
-    st->beta = beta;
-    st->alpha = 0.0;
-    st->sv = 1.0;
-    if (beta > 0.0) {
-        st->su = 1.0 / beta;
-        st->c2.sx = st->su;  // V <- 0*(V*1) + A'(U*su), V pre-zeroed
-        st->c2.sy = 1.0;
-        st->c2.cy = 0.0;
-        st->c2.skip = 0;
-    } else {
-        st->su = 1.0;
-        st->c2.skip = 1;
-    }
-    st->c2p = st->c2;  // sharded: T <- 0*(T*1) + A_p'(U su)
-}
-
-// after sum(V^2): alpha = norm(A'u); v = V/alpha; arnorm; loop entry     (:638-653)
-template <bool REDUCE>
-__global__ __launch_bounds__(SC_BLOCK) void k_s_init2(const double *partials, int np, const double *pre, LsqrState *st)
-{
-    const bool skipped = st->c2.skip != 0;
-    const double sum = take_sum<REDUCE>(partials, np, pre);
-    if (threadIdx.x != 0) return;
-    const double beta = st->beta;
-    const double alpha = skipped ? 0.0 : sqrt(sum);
-    st->alpha = alpha;
-    st->sv = alpha > 0.0 ? 1.0 / alpha : 1.0;
-    st->arnorm = alpha * beta;
-    // the reference leaves these unassigned when the loop is skipped; define them
-    st->bnorm = beta;
-    st->rnorm = beta;
-    st->alpha0 = alpha;
-    st->beta0 = beta;
-    st->test2_0 = beta > 0.0 ? alpha / beta : 0.0;
-    if (st->arnorm == 0.0) {
-        st->stop = 1;  // istop stays 0: x = 0 is the exact solution
-        return;
-    }
-    st->rhobar = alpha;
-    st->phibar = beta;
-    st->c1.sx = st->sv;
-    st->c1.sy = st->su;
-    st->c1.cy = -alpha;
-    st->c1.skip = 0;
-}
-
-// after mode 1: beta = norm(A v - alpha u); anorm     (:675, :683-693)
-template <bool REDUCE>
-__global__ __launch_bounds__(SC_BLOCK) void k_s1(const double *partials, int np, const double *pre, LsqrState *st)
-{
-    if (st->stop != 0) return;
-    const double sum = take_sum<REDUCE>(partials, np, pre);
-    if (threadIdx.x != 0) return;
     st->itn = st->itn + 1;
     const double alpha = st->alpha;
     const double beta = sqrt(sum);
@@ -119,14 +63,9 @@ __global__ __launch_bounds__(SC_BLOCK) void k_s1(const double *partials, int np,
     st->c2p.skip = st->c2.skip;
 }
 
-// after mode 2: alpha = norm(A'u - beta v); plane rotations; update coefficients   (:695-726)
-template <bool REDUCE>
-__global__ __launch_bounds__(SC_BLOCK) void k_s2(const double *partials, int np, const double *pre, LsqrState *st)
+// ---- step 2: after mode 2.  alpha = norm(A'u - beta v); rotations; update coefficients (:695-726)
+__device__ __forceinline__ void s2_step(LsqrState *st, double sum, bool skipped)
 {
-    if (st->stop != 0) return;
-    const bool skipped = st->c2.skip != 0;
-    const double sum = take_sum<REDUCE>(partials, np, pre);
-    if (threadIdx.x != 0) return;
     double alpha = st->alpha;
     const double beta = st->beta;
     if (!skipped) {
@@ -164,14 +103,106 @@ __global__ __launch_bounds__(SC_BLOCK) void k_s2(const double *partials, int np,
     st->c1.skip = 0;
 }
 
-// after the x/w update: dknorm, norm estimates, stopping tests, istop   (:751-810, 843-850)
+// after sum(b^2): beta = norm(b); u = b/beta     (src/lsqr.f90:597-617, 632-637)
+// `slot` (optional) receives (beta, 1/beta) for the first pipelined mode-1 launch.
 template <bool REDUCE>
-__global__ __launch_bounds__(SC_BLOCK) void k_s3(const double *partials, int np, const double *pre,
-                                                 LsqrState *st, const double *x, double *log)
+__global__ __launch_bounds__(SC_BLOCK) void k_s_init1(const double *partials, int np, const double *pre,
+                                                      LsqrState *st, NormSlot *slot)
+{
+    __shared__ double red[SC_BLOCK / WAVE];
+    const double sum = take_sum<REDUCE>(partials, np, pre, red);
+    if (threadIdx.x != 0) return;
+    const double beta = sqrt(sum);
+    st->beta = beta;
+    st->alpha = 0.0;
+    st->sv = 1.0;
+    if (beta > 0.0) {
+        st->su = 1.0 / beta;
+        st->c2.sx = st->su;  // V <- 0*(V*1) + A'(U*su), V pre-zeroed
+        st->c2.sy = 1.0;
+        st->c2.cy = 0.0;
+        st->c2.skip = 0;
+    } else {
+        st->su = 1.0;
+        st->c2.skip = 1;
+    }
+    st->c2p = st->c2;  // sharded: T <- 0*(T*1) + A_p'(U su)
+    if (slot) {
+        slot->nrm = beta;
+        slot->scale = st->su;
+    }
+}
+
+// after sum(V^2): alpha = norm(A'u); v = V/alpha; arnorm; loop entry     (:638-653)
+template <bool REDUCE>
+__global__ __launch_bounds__(SC_BLOCK) void k_s_init2(const double *partials, int np, const double *pre,
+                                                      LsqrState *st)
+{
+    __shared__ double red[SC_BLOCK / WAVE];
+    const bool skipped = st->c2.skip != 0;
+    const double sum = take_sum<REDUCE>(partials, np, pre, red);
+    if (threadIdx.x != 0) return;
+    const double beta = st->beta;
+    const double alpha = skipped ? 0.0 : sqrt(sum);
+    st->alpha = alpha;
+    st->sv = alpha > 0.0 ? 1.0 / alpha : 1.0;
+    st->arnorm = alpha * beta;
+    // the reference leaves these unassigned when the loop is skipped; define them
+    st->bnorm = beta;
+    st->rnorm = beta;
+    st->alpha0 = alpha;
+    st->beta0 = beta;
+    st->test2_0 = beta > 0.0 ? alpha / beta : 0.0;
+    if (st->arnorm == 0.0) {
+        st->stop = 1;  // istop stays 0: x = 0 is the exact solution
+        return;
+    }
+    st->rhobar = alpha;
+    st->phibar = beta;
+    st->c1.sx = st->sv;
+    st->c1.sy = st->su;
+    st->c1.cy = -alpha;
+    st->c1.skip = 0;
+}
+
+template <bool REDUCE>
+__global__ __launch_bounds__(SC_BLOCK) void k_s1(const double *partials, int np, const double *pre, LsqrState *st)
 {
     if (st->stop != 0) return;
-    const double sum = take_sum<REDUCE>(partials, np, pre);
+    __shared__ double red[SC_BLOCK / WAVE];
+    const double sum = take_sum<REDUCE>(partials, np, pre, red);
     if (threadIdx.x != 0) return;
+    s1_step(st, sum);
+}
+
+template <bool REDUCE>
+__global__ __launch_bounds__(SC_BLOCK) void k_s2(const double *partials, int np, const double *pre, LsqrState *st)
+{
+    if (st->stop != 0) return;
+    __shared__ double red[SC_BLOCK / WAVE];
+    const bool skipped = st->c2.skip != 0;
+    const double sum = take_sum<REDUCE>(partials, np, pre, red);
+    if (threadIdx.x != 0) return;
+    s2_step(st, sum, skipped);
+}
+
+// steps 1 and 2 in one launch: p1 = partials of the mode-1 SpMV, p2 = partials of the
+// mode-2 SpMV of the same iteration (pipelined schedule; both products have already run).
+__global__ __launch_bounds__(SC_BLOCK) void k_s12(const double *p1, int np1, const double *p2, int np2,
+                                                  LsqrState *st)
+{
+    if (st->stop != 0) return;
+    __shared__ double red[SC_BLOCK / WAVE];
+    const double sum1 = take_sum<true>(p1, np1, nullptr, red);
+    const double sum2 = take_sum<true>(p2, np2, nullptr, red);
+    if (threadIdx.x != 0) return;
+    s1_step(st, sum1);
+    s2_step(st, sum2, st->c2.skip != 0);
+}
+
+// ---- step 3: after the x/w update.  dknorm, norm estimates, stopping tests, istop (:751-810, 843-850)
+__device__ __forceinline__ void s3_step(LsqrState *st, double sum, const double *x, double *log)
+{
     const int itn = st->itn;
     const double rho = st->rho, phi = st->phi, theta = st->theta, tau = st->tau;
     const double alpha = st->alpha;
@@ -242,6 +273,47 @@ __global__ __launch_bounds__(SC_BLOCK) void k_s3(const double *partials, int np,
     }
     st->istop = istop;
     if (istop != 0) st->stop = 1;
+}
+
+template <bool REDUCE>
+__global__ __launch_bounds__(SC_BLOCK) void k_s3(const double *partials, int np, const double *pre,
+                                                 LsqrState *st, const double *x, double *log)
+{
+    if (st->stop != 0) return;
+    __shared__ double red[SC_BLOCK / WAVE];
+    const double sum = take_sum<REDUCE>(partials, np, pre, red);
+    if (threadIdx.x != 0) return;
+    s3_step(st, sum, x, log);
+}
+
+// ---- riders -----------------------------------------------------------------------------
+// The same scalar steps executed by ONE spare workgroup of a long vector kernel (spmv.h):
+// the rider's inputs are complete when its host kernel starts and its outputs are first read
+// by a LATER kernel, so kernel-boundary ordering is all the synchronisation there is.
+struct Rider {
+    int kind;            // 0 none, 1 = steps 1+2 (pa = mode-1 partials, pb = mode-2 partials), 2 = step 3 (pa)
+    int na, nb;
+    const double *pa, *pb;
+    LsqrState *st;
+    const double *x;     // step 3: x(1) for the log
+    double *log;
+};
+
+__device__ __forceinline__ void run_rider(const Rider &r, double *red)
+{
+    LsqrState *st = r.st;
+    if (st->stop != 0) return;
+    if (r.kind == 1) {
+        const double sum1 = take_sum<true>(r.pa, r.na, nullptr, red);
+        const double sum2 = take_sum<true>(r.pb, r.nb, nullptr, red);
+        if (threadIdx.x != 0) return;
+        s1_step(st, sum1);
+        s2_step(st, sum2, st->c2.skip != 0);
+    } else if (r.kind == 2) {
+        const double sum = take_sum<true>(r.pa, r.na, nullptr, red);
+        if (threadIdx.x != 0) return;
+        s3_step(st, sum, r.x, r.log);
+    }
 }
 
 }  // namespace lsqrhip

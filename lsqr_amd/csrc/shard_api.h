@@ -97,7 +97,7 @@ extern "C" int lsqrhip_shard_stage(lsqrhip_handle_t h, int stage)
         break;
     case ST_INIT_BETA_ATU:  // beta from the all-reduced sums[0]; T_p = A_p'(U_p/beta)
         hipLaunchKernelGGL(k_s_init1<false>, dim3(1), dim3(SC_BLOCK), 0, s, (const double *)h->partials, 0,
-                           (const double *)sums, st);
+                           (const double *)sums, st, (NormSlot *)nullptr);
         launch_spmv(h, h->AT, h->U, T, &st->c2p, h->d_zero);
         break;
     case ST_INIT_V:  // V = sum_p T_p (all-reduced); alpha, v, w

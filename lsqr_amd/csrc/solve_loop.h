@@ -1,0 +1,362 @@
+// solve_loop.h -- the device-resident LSQR loop (included by lsqrhip.hip).
+//
+// Two schedules over the same kernels (results are bit-identical; tests compare them):
+//
+//  sequential ("pipeline" = 0)      K1 -> S1 -> K2 -> S2 -> K4 -> S3            6 launches / iteration
+//
+//  riders     ("pipeline" = 1, default)                                          3 launches / iteration
+//      K1(i+1) (+) S12(i)  ->  K4(i)  ->  K2(i+1) (+) S3(i)  ->  K1(i+2) (+) S12(i+1)  -> ...
+//
+//      K1 = mode-1 SpMV, K2 = mode-2 SpMV, K4 = x/w update, S* = the scalar steps (scalar.h).
+//      At config 2 each scalar kernel is ~4.7 us (a chain of fp64 divides and square roots
+//      behind a kernel boundary) during which HBM idles: 14 us of a 58 us iteration.  Here:
+//        * K2 derives beta from K1's partials and K1 derives alpha from K2's partials in a
+//          short prologue (spmv.h, lazy coefficients), so nothing sits between the SpMVs;
+//        * the authoritative scalar machine (anorm, rotations, norm estimates, stopping
+//          tests) runs as a RIDER: one extra workgroup of the next SpMV launch.  A rider's
+//          inputs are complete when its host kernel starts and its outputs are first read by
+//          a later kernel, so stream order is the only synchronisation -- no flags, no
+//          fences, one stream, one queue.
+//      K1/K2 launched past the stopping iteration are speculative: they only touch U, V and
+//      partials; K4 and the riders check `stop` (written by the S3 rider two launches
+//      earlier), so x, w, se and the scalar state are exactly those of the stopping iteration.
+//      Partials and hand-over slots are double-buffered by iteration parity; batches hold an
+//      even number of iterations so a captured graph replays with the right parity.  Each
+//      batch ends with the last iteration's S12 -> K4 -> S3 as plain kernels so that the host
+//      polls a settled state.
+//
+//      (A two-stream variant -- scalar machine and K4 on a side stream beside the next
+//      SpMV -- was measured first: 73 us/iteration device time against 60 sequential.
+//      Cross-queue dependencies inside a hipGraph cost more than the bubbles they hide.)
+#pragma once
+
+// ---------------------------------------------------------------------------
+// kernel launch helpers
+// ---------------------------------------------------------------------------
+struct SpmvArgs {
+    const Csr *c = nullptr;
+    const double *x = nullptr;
+    double *y = nullptr;
+    const SpmvCoef *coef = nullptr;  // explicit coefficients ...
+    const double *pin = nullptr;     // ... or lazy: partials to derive the norm from
+    int npin = 0;
+    const NormSlot *slot_in = nullptr;
+    NormSlot *slot_out = nullptr;
+    int skip_if_zero = 0;
+    const int *stop = nullptr;
+    double *pout = nullptr;
+    Rider rider{};                   // scalar work carried by one extra workgroup (kind 0 = none)
+    hipStream_t stream = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;  // kernel begin/end timestamps (hipExtLaunchKernelGGL)
+};
+
+template <typename OffT>
+static void launch_spmv_T(const SpmvArgs &a)
+{
+    const Csr &c = *a.c;
+    const dim3 grid(c.grid + (a.rider.kind != 0 ? 1 : 0));
+    if (a.e0 == nullptr)  // plain launch (the only form used under stream capture)
+        hipLaunchKernelGGL(k_spmv_fused<OffT>, grid, dim3(SPMV_BLOCK), 0, a.stream, (const OffT *)c.rowptr,
+                           (const int *)c.col, (const double *)c.val, (const RowBlock *)c.blk, c.nblk, a.x, a.y,
+                           a.coef, a.stop, a.pout, a.pin, a.npin, a.slot_in, a.slot_out, a.skip_if_zero, a.rider);
+    else
+        hipExtLaunchKernelGGL(k_spmv_fused<OffT>, grid, dim3(SPMV_BLOCK), 0, a.stream, a.e0, a.e1, 0,
+                              (const OffT *)c.rowptr, (const int *)c.col, (const double *)c.val,
+                              (const RowBlock *)c.blk, c.nblk, a.x, a.y, a.coef, a.stop, a.pout, a.pin, a.npin,
+                              a.slot_in, a.slot_out, a.skip_if_zero, a.rider);
+}
+
+static void launch_spmv_args(H *h, const SpmvArgs &a)
+{
+    if (h->off64) launch_spmv_T<long long>(a);
+    else launch_spmv_T<int>(a);
+}
+
+// explicit-coefficient form on the handle's stream, partials into h->partials
+static void launch_spmv(H *h, const Csr &c, const double *x, double *y, const SpmvCoef *coef, const int *stop,
+                        hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr)
+{
+    SpmvArgs a;
+    a.c = &c; a.x = x; a.y = y; a.coef = coef; a.stop = stop; a.pout = h->partials; a.stream = h->stream;
+    a.e0 = e0; a.e1 = e1;
+    launch_spmv_args(h, a);
+}
+
+static void launch_update(H *h, double *pout, hipEvent_t e0, hipEvent_t e1)
+{
+    hipStream_t s = h->stream;
+    if (e0)
+        hipExtLaunchKernelGGL(k_update, dim3(h->vgrid_n), dim3(VEC_BLOCK), 0, s, e0, e1, 0, h->X, h->W,
+                              (const double *)h->V, h->SE, (int64_t)h->n, (const LsqrState *)h->d_state, pout);
+    else
+        hipLaunchKernelGGL(k_update, dim3(h->vgrid_n), dim3(VEC_BLOCK), 0, s, h->X, h->W, (const double *)h->V, h->SE,
+                           (int64_t)h->n, (const LsqrState *)h->d_state, pout);
+}
+
+// ---- sequential schedule: 6 launches ----------------------------------------------------------
+static void launch_iteration_seq(H *h, hipEvent_t *ev)
+{
+    LsqrState *st = h->d_state;
+    hipStream_t s = h->stream;
+    launch_spmv(h, h->A, h->V, h->U, &st->c1, &st->stop, ev ? ev[0] : nullptr, ev ? ev[1] : nullptr);
+    hipLaunchKernelGGL(k_s1<true>, dim3(1), dim3(SC_BLOCK), 0, s, (const double *)h->partials, h->A.grid,
+                       (const double *)nullptr, st);
+    launch_spmv(h, h->AT, h->U, h->V, &st->c2, &st->stop, ev ? ev[2] : nullptr, ev ? ev[3] : nullptr);
+    hipLaunchKernelGGL(k_s2<true>, dim3(1), dim3(SC_BLOCK), 0, s, (const double *)h->partials, h->AT.grid,
+                       (const double *)nullptr, st);
+    launch_update(h, h->partials, ev ? ev[4] : nullptr, ev ? ev[5] : nullptr);
+    hipLaunchKernelGGL(k_s3<true>, dim3(1), dim3(SC_BLOCK), 0, s, (const double *)h->partials, h->vgrid_n,
+                       (const double *)nullptr, st, (const double *)h->X, h->d_log);
+}
+
+// ---- rider schedule -------------------------------------------------------------------------
+static Rider rider_s12(H *h, int i)  // steps 1+2 of iteration i
+{
+    Rider r{};
+    r.kind = 1;
+    r.pa = h->P1[i & 1]; r.na = h->A.grid;
+    r.pb = h->P2[i & 1]; r.nb = h->AT.grid;
+    r.st = h->d_state;
+    return r;
+}
+static Rider rider_s3(H *h)  // step 3 of the iteration whose K4 ran last
+{
+    Rider r{};
+    r.kind = 2;
+    r.pa = h->P3; r.na = h->vgrid_n;
+    r.st = h->d_state; r.x = h->X; r.log = h->d_log;
+    return r;
+}
+
+// mode-1 SpMV of iteration i: alpha from the mode-2 partials of iteration i-1
+static void launch_k1(H *h, int i, const Rider &rider, hipEvent_t e0, hipEvent_t e1)
+{
+    const int par = i & 1, prev = par ^ 1;
+    NormSlot *slotA = h->slots, *slotB = h->slots + 2;
+    SpmvArgs a;
+    a.c = &h->A; a.x = h->V; a.y = h->U; a.pin = h->P2[prev]; a.npin = h->AT.grid;
+    a.slot_in = &slotB[prev]; a.slot_out = &slotA[par]; a.skip_if_zero = 0; a.stop = &h->d_state->stop;
+    a.pout = h->P1[par]; a.rider = rider; a.stream = h->stream; a.e0 = e0; a.e1 = e1;
+    launch_spmv_args(h, a);
+}
+// mode-2 SpMV of iteration i: beta from the mode-1 partials of the same iteration
+static void launch_k2(H *h, int i, const Rider &rider, hipEvent_t e0, hipEvent_t e1)
+{
+    const int par = i & 1;
+    NormSlot *slotA = h->slots, *slotB = h->slots + 2;
+    SpmvArgs a;
+    a.c = &h->AT; a.x = h->U; a.y = h->V; a.pin = h->P1[par]; a.npin = h->A.grid;
+    a.slot_in = &slotA[par]; a.slot_out = &slotB[par]; a.skip_if_zero = 1; a.stop = &h->d_state->stop;
+    a.pout = h->P2[par]; a.rider = rider; a.stream = h->stream; a.e0 = e0; a.e1 = e1;
+    launch_spmv_args(h, a);
+}
+
+// G iterations starting at global iteration i0 (1-based).  `ev`: 6 events per iteration
+// (begin/end of K1, K2, K4) or nullptr.
+static int launch_batch(H *h, int i0, int G, hipEvent_t *ev)
+{
+    if (!h->pipeline) {
+        for (int j = 0; j < G; ++j) launch_iteration_seq(h, ev ? ev + 6 * j : nullptr);
+        return LSQRHIP_OK;
+    }
+    LsqrState *st = h->d_state;
+    hipStream_t s = h->stream;
+    auto E = [&](int j, int k) -> hipEvent_t { return ev ? ev[6 * j + k] : nullptr; };
+    const Rider none{};
+    launch_k1(h, i0, none, E(0, 0), E(0, 1));
+    launch_k2(h, i0, none, E(0, 2), E(0, 3));
+    for (int j = 1; j < G; ++j) {
+        const int i = i0 + j;
+        launch_k1(h, i, rider_s12(h, i - 1), E(j, 0), E(j, 1));   // K1(i)  (+) S12(i-1)
+        launch_update(h, h->P3, E(j - 1, 4), E(j - 1, 5));         // K4(i-1)
+        launch_k2(h, i, rider_s3(h), E(j, 2), E(j, 3));            // K2(i)  (+) S3(i-1)
+    }
+    const int il = i0 + G - 1;  // settle the last iteration of the batch with plain kernels
+    hipLaunchKernelGGL(k_s12, dim3(1), dim3(SC_BLOCK), 0, s, (const double *)h->P1[il & 1], h->A.grid,
+                       (const double *)h->P2[il & 1], h->AT.grid, st);
+    launch_update(h, h->P3, E(G - 1, 4), E(G - 1, 5));
+    hipLaunchKernelGGL(k_s3<true>, dim3(1), dim3(SC_BLOCK), 0, s, (const double *)h->P3, h->vgrid_n,
+                       (const double *)nullptr, st, (const double *)h->X, h->d_log);
+    return LSQRHIP_OK;
+}
+
+static int ensure_graph(H *h, int G)
+{
+    if (h->gexec && !h->graph_dirty && h->gexec_iters == G && h->gexec_pipeline == h->pipeline) return LSQRHIP_OK;
+    destroy_graph(h);
+    hipGraph_t g = nullptr;
+    HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+    int rc = launch_batch(h, 1, G, nullptr);  // parity of iteration 1; G is even when riders are on
+    hipError_t e = hipStreamEndCapture(h->stream, &g);
+    RET(rc);
+    if (e != hipSuccess) return fail(LSQRHIP_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+    e = hipGraphInstantiate(&h->gexec, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    if (e != hipSuccess) return fail(LSQRHIP_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
+    h->gexec_iters = G;
+    h->gexec_pipeline = h->pipeline;
+    h->graph_dirty = false;
+    return LSQRHIP_OK;
+}
+
+// ---------------------------------------------------------------------------
+// solve
+// ---------------------------------------------------------------------------
+static int solve_core(H *h, const double *b, bool b_on_device, double damp, double atol, double btol, double conlim,
+                      int itnlim, int wantse, int want_log, double *x, double *se, bool out_on_device, int *istop,
+                      int *itn, double *anorm, double *acond, double *rnorm, double *arnorm, double *xnorm)
+{
+    if (!h) return fail(LSQRHIP_ERR_NOT_INIT, lsqrhip_error_string(LSQRHIP_ERR_NOT_INIT));
+    if (!istop || (!x && h->n > 0) || (!b && h->m > 0)) return fail(LSQRHIP_ERR_ARG, "null b, x or istop");
+    if (wantse && !se) return fail(LSQRHIP_ERR_ARG, "wantse set but se is null");
+    HIPCHK(hipSetDevice(h->device));
+    const auto t_host0 = std::chrono::steady_clock::now();
+    hipStream_t s = h->stream;
+    const int m = h->m, n = h->n;
+    LsqrState *st = h->d_state;
+
+    if (want_log) {
+        const int cap = std::max(itnlim, 1);
+        if (cap > h->log_cap) {
+            if (h->d_log) (void)hipFree(h->d_log);
+            h->d_log = nullptr;
+            HIPCHK(hipMalloc((void **)&h->d_log, sizeof(double) * LOG_STRIDE * (size_t)cap));
+            h->log_cap = cap;
+            h->graph_dirty = true;
+        }
+    }
+    h->log_count = 0;
+
+    // ---- initial state (src/lsqr.f90:597-617) -------------------------------
+    LsqrState init;
+    std::memset(&init, 0, sizeof(init));
+    init.itnlim = itnlim;
+    init.damped = damp > 0.0;
+    init.wantse = wantse != 0;
+    init.want_log = want_log != 0;
+    init.log_cap = h->log_cap;
+    init.m = m;
+    init.n = n;
+    init.damp = damp;
+    init.atol = atol;
+    init.btol = btol;
+    init.ctol = conlim > 0.0 ? 1.0 / conlim : 0.0;
+    init.cs2 = -1.0;
+    init.su = init.sv = 1.0;
+    init.c1.skip = init.c2.skip = init.c2p.skip = 1;
+    *h->h_state = init;
+    HIPCHK(hipMemcpyAsync(st, h->h_state, sizeof(LsqrState), hipMemcpyHostToDevice, s));
+
+    // u = b (solve_ez :242); v = 0, x = 0, se = 0 (:621-630)
+    if (m > 0)
+        HIPCHK(hipMemcpyAsync(h->U, b, sizeof(double) * (size_t)m,
+                              b_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
+    if (n > 0) {
+        HIPCHK(hipMemsetAsync(h->V, 0, sizeof(double) * (size_t)n, s));
+        HIPCHK(hipMemsetAsync(h->X, 0, sizeof(double) * (size_t)n, s));
+        HIPCHK(hipMemsetAsync(h->W, 0, sizeof(double) * (size_t)n, s));
+        if (wantse) HIPCHK(hipMemsetAsync(h->SE, 0, sizeof(double) * (size_t)n, s));
+    }
+    // beta = norm(u); u /= beta; v = A'u; alpha = norm(v); v /= alpha; w = v  (:632-644)
+    // The mode-2 partials land in P2[0] and (beta, 1/beta) in slot B[0]: exactly what the
+    // first lazy mode-1 launch (iteration 1: parity 1, previous parity 0) consumes.
+    hipLaunchKernelGGL(k_dot, dim3(h->vgrid_m), dim3(VEC_BLOCK), 0, s, (const double *)h->U, (const double *)h->U,
+                       (int64_t)m, h->partials);
+    hipLaunchKernelGGL(k_s_init1<true>, dim3(1), dim3(SC_BLOCK), 0, s, (const double *)h->partials, h->vgrid_m,
+                       (const double *)nullptr, st, h->slots + 2);
+    {
+        SpmvArgs a;
+        a.c = &h->AT; a.x = h->U; a.y = h->V; a.coef = &st->c2; a.stop = h->d_zero; a.pout = h->P2[0]; a.stream = s;
+        launch_spmv_args(h, a);
+    }
+    hipLaunchKernelGGL(k_s_init2<true>, dim3(1), dim3(SC_BLOCK), 0, s, (const double *)h->P2[0], h->AT.grid,
+                       (const double *)nullptr, st);
+    hipLaunchKernelGGL(k_copy_scale, dim3(h->vgrid_n), dim3(VEC_BLOCK), 0, s, h->W, (const double *)h->V, (int64_t)n,
+                       (const LsqrState *)st);
+    HIPCHK(hipGetLastError());
+
+    // ---- the loop (src/lsqr.f90:673-852) ------------------------------------
+    lsqrhip_timing_t &tm = h->timing;
+    tm = lsqrhip_timing_t{};
+    const int P = h->off64 ? 8 : 4;
+    tm.spmv1_bytes = 12 * h->nnz + (int64_t)P * (m + 1) + 8ll * n + 16ll * m;
+    tm.spmv2_bytes = 12 * h->nnz + (int64_t)P * (n + 1) + 8ll * m + 16ll * n;
+    tm.vec_bytes = 40ll * n + (wantse ? 16ll * n : 0);
+
+    int G = std::max(1, h->graph_iters);
+    if (h->pipeline) G = (G + 1) & ~1;  // even: parity-consistent batches
+    const bool timed = h->time_kernels != 0;
+    const bool graph = h->use_graph != 0 && !timed;
+    if (graph) RET(ensure_graph(h, G));
+    if (timed && (int)h->ev.size() < 6 * G) {
+        const size_t old = h->ev.size();
+        h->ev.resize(6 * (size_t)G);
+        for (size_t k = old; k < h->ev.size(); ++k) HIPCHK(hipEventCreate(&h->ev[k]));
+    }
+    HIPCHK(hipEventRecord(h->ev_loop0, s));
+    // S3 raises `stop` at itn == itnlim at the latest; anything beyond this many batches
+    // means the device loop is not advancing (never spin on a dead stream).
+    const int64_t max_batches = (int64_t)std::max(itnlim, 0) / G + 2;
+    for (int64_t batch = 0;; ++batch) {
+        if (batch > max_batches)
+            return fail(LSQRHIP_ERR_HIP, "iteration loop did not terminate (device state not advancing)");
+        if (graph) {
+            HIPCHK(hipGraphLaunch(h->gexec, s));
+        } else {
+            RET(launch_batch(h, 1 + (int)(batch * G), G, timed ? h->ev.data() : nullptr));
+            HIPCHK(hipGetLastError());
+        }
+        HIPCHK(hipMemcpyAsync(h->h_state, st, sizeof(LsqrState), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        if (timed) {
+            // launches after the stop flag was raised are no-ops: count only live ones
+            const int live = std::min(G, h->h_state->itn - (int)tm.spmv1_launches);
+            for (int k = 0; k < live; ++k) {
+                float a = 0, c = 0, d = 0;
+                (void)hipEventElapsedTime(&a, h->ev[6 * k + 0], h->ev[6 * k + 1]);
+                (void)hipEventElapsedTime(&c, h->ev[6 * k + 2], h->ev[6 * k + 3]);
+                (void)hipEventElapsedTime(&d, h->ev[6 * k + 4], h->ev[6 * k + 5]);
+                tm.spmv1_ms += a;
+                tm.spmv2_ms += c;
+                tm.update_ms += d;
+            }
+            tm.spmv1_launches += live;
+            tm.spmv2_launches += live;
+            tm.update_launches += live;
+        }
+        if (h->h_state->stop != 0) break;
+    }
+    HIPCHK(hipEventRecord(h->ev_loop1, s));
+
+    // ---- epilogue: se (:857-865), istop 2 -> 3 (:871), outputs --------------
+    if (wantse && n > 0)
+        hipLaunchKernelGGL(k_se_finish, dim3(h->vgrid_n), dim3(VEC_BLOCK), 0, s, h->SE, (int64_t)n,
+                           (const LsqrState *)st);
+    const hipMemcpyKind out_kind = out_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+    if (n > 0) HIPCHK(hipMemcpyAsync(x, h->X, sizeof(double) * (size_t)n, out_kind, s));
+    if (wantse && n > 0) HIPCHK(hipMemcpyAsync(se, h->SE, sizeof(double) * (size_t)n, out_kind, s));
+    const LsqrState &r = *h->h_state;
+    if (want_log && r.itn > 0) {
+        h->log_count = std::min(r.itn, h->log_cap);
+        h->h_log.resize((size_t)h->log_count * LOG_STRIDE);
+        HIPCHK(hipMemcpyAsync(h->h_log.data(), h->d_log, sizeof(double) * h->h_log.size(), hipMemcpyDeviceToHost, s));
+    }
+    HIPCHK(hipStreamSynchronize(s));
+    float loop_ms = 0;
+    (void)hipEventElapsedTime(&loop_ms, h->ev_loop0, h->ev_loop1);
+    tm.loop_ms = loop_ms;
+    tm.itn = r.itn;
+    if (!timed) tm.spmv1_launches = tm.spmv2_launches = tm.update_launches = r.itn;
+
+    int is = r.istop;
+    if (r.damped && is == 2) is = 3;
+    *istop = is;
+    if (itn) *itn = r.itn;
+    if (anorm) *anorm = r.anorm;
+    if (acond) *acond = r.acond;
+    if (rnorm) *rnorm = r.rnorm;
+    if (arnorm) *arnorm = r.arnorm;
+    if (xnorm) *xnorm = r.xnorm;
+    tm.solve_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_host0).count();
+    return LSQRHIP_OK;
+}

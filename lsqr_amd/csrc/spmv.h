@@ -22,12 +22,29 @@
 //   phase 3  a long last row is split across the whole workgroup (strided
 //            partial sums, wave shuffle + LDS reduce).
 // The grid is capped and XCD-aware (common.h); every workgroup writes exactly one
-// partial of sum(y^2), reduced in fixed order by the scalar kernel => deterministic.
+// partial of sum(y^2), reduced in fixed order by its consumers => deterministic.
+//
+// Coefficients come in one of two ways:
+//   explicit  `coef` points at an SpmvCoef (aprod, initialisation, sharded stages);
+//   lazy      `pin` points at the partials of the PREVIOUS SpMV of the iteration: every
+//             workgroup reduces them itself (fixed order, so all workgroups and the scalar
+//             kernels get identical bits), takes nrm = sqrt(sum) and uses
+//                 sx = 1/nrm (1 if nrm = 0),  cy = -nrm,  sy = slot_in->scale,
+//             i.e. mode 1 derives alpha from the mode-2 partials and mode 2 derives beta from
+//             the mode-1 partials, with no scalar kernel on the critical path between them.
+//             Workgroup 0 publishes (nrm, 1/nrm) in slot_out for the next kernel's sy.
+//
+// Measured at config 2 (88 MB per launch): ~17 us = 5.2 TB/s.  Ablation (gather, LDS
+// reduce and y traffic removed) still needs 15.6 us for the (val, col) stream alone: the
+// kernel is bound by the memory system, not by its own phases.  Sweeps: window 512 / 1024 /
+// 2048 / 4096 -> 23 / 17 / 21 / 31 us; one workgroup per row block instead of a persistent
+// grid: +-2 % on banded, +13 % on power-law rows.
 //
 // Algorithmic HBM bytes per launch:  12*nnz + P*(rows+1) + 8*cols + 16*rows.
 #pragma once
 
 #include "common.h"
+#include "scalar.h"
 #include "state.h"
 
 namespace lsqrhip {
@@ -57,39 +74,147 @@ __global__ void k_row_blocks(const OffT *__restrict__ rowptr, int m, int64_t nbl
     rb[k] = lo;
 }
 
-template <typename OffT>
-__global__ __launch_bounds__(SPMV_BLOCK) void k_spmv_fused(
-    const OffT *__restrict__ rowptr, const int *__restrict__ col, const double *__restrict__ val,
-    const int *__restrict__ rb, int64_t nblk, const double *__restrict__ x, double *__restrict__ y,
-    const SpmvCoef *__restrict__ coef, const int *__restrict__ stop, double *__restrict__ partials)
-{
-    if (*stop != 0 || coef->skip != 0) return;
-    const double sx = coef->sx, sy = coef->sy, cy = coef->cy;
+// One descriptor per row block, built once (k_block_desc): everything the kernel needs to
+// start streaming, fetched with ONE scalar load instead of the dependent chain
+// rb[b] -> rowptr[r0], rowptr[r1-1], rowptr[r1].
+struct alignas(32) RowBlock {
+    long long p0;     // first nonzero of the block
+    long long plast;  // first nonzero of the last row
+    long long pend;   // one past the last nonzero
+    int r0, r1;       // rows [r0, r1)
+};
 
+template <typename OffT>
+__global__ void k_block_desc(const OffT *__restrict__ rowptr, const int *__restrict__ rb, int64_t nblk,
+                             RowBlock *__restrict__ blk)
+{
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nblk) return;
+    RowBlock d;
+    d.r0 = rb[b];
+    d.r1 = rb[b + 1];
+    if (d.r0 < d.r1) {
+        d.p0 = (long long)rowptr[d.r0];
+        d.plast = (long long)rowptr[d.r1 - 1];
+        d.pend = (long long)rowptr[d.r1];
+    } else {
+        d.p0 = d.plast = d.pend = 0;
+    }
+    blk[b] = d;
+}
+
+// launch bound 8 waves/SIMD: the kernel must stay within 64 VGPRs (66 cost a whole
+// workgroup per CU: 18.9 us instead of 17.2 at config 2)
+template <typename OffT>
+__global__ __launch_bounds__(SPMV_BLOCK, 8) void k_spmv_fused(
+    const OffT *__restrict__ rowptr, const int *__restrict__ col, const double *__restrict__ val,
+    const RowBlock *__restrict__ blk, int64_t nblk, const double *__restrict__ x, double *__restrict__ y,
+    const SpmvCoef *__restrict__ coef, const int *__restrict__ stop, double *__restrict__ partials,
+    const double *__restrict__ pin, int npin, const NormSlot *__restrict__ slot_in,
+    NormSlot *__restrict__ slot_out, int skip_if_zero, Rider rider)
+{
     __shared__ double prod[SPMV_LDS];
-    __shared__ double red[SPMV_BLOCK / WAVE];
+    __shared__ double red[SPMV_BLOCK / WAVE + 1];
+    // One extra workgroup carries scalar work (scalar.h "riders").  It is block 0, the first
+    // one dispatched, so it runs beside the SpMV from the start (as the LAST block of a grid
+    // that exceeds the resident slots it would only start when the first SpMV block retires).
+    const int shift = rider.kind != 0 ? 1 : 0;
+    const int nwg = (int)gridDim.x - shift;     // SpMV workgroups
+    const int wg = (int)blockIdx.x - shift;     // this workgroup's index among them
+    if (wg < 0) {
+        run_rider(rider, red);
+        return;
+    }
+    if (*stop != 0) return;
     const int tid = threadIdx.x;
+
+    double sx, sy, cy;
+    if (pin != nullptr) {  // lazy coefficients (uniform branch)
+        const double nrm = sqrt(block_sum_all<SPMV_BLOCK>(pin, npin, red));
+        if (skip_if_zero && !(nrm > 0.0)) return;  // mode 2 is skipped when beta == 0 (:691)
+        sx = nrm > 0.0 ? 1.0 / nrm : 1.0;
+        cy = -nrm;
+        sy = slot_in->scale;
+        if (wg == 0 && tid == 0) {
+            slot_out->nrm = nrm;
+            slot_out->scale = sx;
+        }
+    } else {
+        if (coef->skip != 0) return;
+        sx = coef->sx;
+        sy = coef->sy;
+        cy = coef->cy;
+    }
+
     double sq = 0.0;  // this thread's share of sum(y_new^2)
 
-    const XcdRange xr = xcd_range(nblk);
-    for (int64_t b = xr.first; b < xr.end; b += xr.stride) {
-        const int r0 = rb[b], r1 = rb[b + 1];
+    // Independent loads are issued up front: the descriptor of the NEXT block, this block's
+    // (val, col), and the row pointers + y of the row this lane will reduce.
+    const XcdRange xr = xcd_range(nblk, nwg, wg);
+    int64_t b = xr.first;
+    RowBlock d;
+    if (b < xr.end) d = blk[b];
+    for (; b < xr.end; b += xr.stride) {
+        const RowBlock cur = d;
+        if (b + xr.stride < xr.end) d = blk[b + xr.stride];  // prefetch (uniform index)
+        const int r0 = cur.r0, r1 = cur.r1;
         if (r0 >= r1) continue;  // uniform
-        const OffT p0 = rowptr[r0];
-        const OffT plast = rowptr[r1 - 1], pend = rowptr[r1];
+        const OffT p0 = (OffT)cur.p0, plast = (OffT)cur.plast, pend = (OffT)cur.pend;
         const bool has_long = (pend - plast) >= (OffT)SPMV_C;
         const int r1s = has_long ? r1 - 1 : r1;
         const int cnt = (int)((has_long ? plast : pend) - p0);  // < 2C by construction
+        const int nr = r1s - r0;
 
-        // ---- phase 1: stream (val, col), gather x, stage products ----------
-        // Indices are clamped instead of predicated so the loads of one round
-        // issue back to back (no per-element branch + wait).
+        // lanes per row from the block's mean row length: <= 16 nonzeros -> one lane, plain
+        // left-to-right sum (bit-identical to the reference's COO-order row sums); longer
+        // rows get 2..64 lanes and a shuffle tree.
+        int G = 1;
+        if (nr > 0) {
+            const int avg = cnt / nr;
+            while (G < WAVE && avg > 16 * G) G <<= 1;  // uniform
+        }
+        const int gl = tid & (G - 1), gid = tid / G, ngroups = SPMV_BLOCK / G;
+
+        // ---- phase 1 loads: (val, col) of the block; indices clamped, not predicated, so
+        // the loads of a round issue back to back (no per-element branch + wait) ----------
+        const int last = cnt > 0 ? cnt - 1 : 0;
+        int kk[4];
+        double a[4];
+        int c[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int t = tid + j * SPMV_BLOCK;
+            kk[j] = t < last ? t : last;
+        }
         if (cnt > 0) {
-            const int last = cnt - 1;
-            for (int k = tid; k < cnt; k += 4 * SPMV_BLOCK) {
-                int kk[4];
-                double a[4];
-                int c[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                a[j] = val[p0 + kk[j]];
+                c[j] = col[p0 + kk[j]];
+            }
+        }
+        // ---- early loads for phase 2: this lane's first row ---------------------------
+        const int rfirst = r0 + gid;
+        const bool have_row = rfirst < r1s;
+        const int rclamp = have_row ? rfirst : r0;
+        OffT q0 = 0, q1 = 0;
+        double y0 = 0.0;
+        if (nr > 0) {
+            q0 = rowptr[rclamp];
+            q1 = rowptr[rclamp + 1];
+            y0 = y[rclamp];
+        }
+        // ---- gather x, stage products ---------------------------------------------------
+        if (cnt > 0) {
+            double xv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xv[j] = x[c[j]];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int t = tid + j * SPMV_BLOCK;
+                if (t < cnt) prod[t] = a[j] * (xv[j] * sx);
+            }
+            for (int k = tid + 4 * SPMV_BLOCK; k < cnt; k += 4 * SPMV_BLOCK) {  // cnt in (1024, 2C)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int t = k + j * SPMV_BLOCK;
@@ -100,7 +225,6 @@ __global__ __launch_bounds__(SPMV_BLOCK) void k_spmv_fused(
                     a[j] = val[p0 + kk[j]];
                     c[j] = col[p0 + kk[j]];
                 }
-                double xv[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) xv[j] = x[c[j]];
 #pragma unroll
@@ -112,55 +236,53 @@ __global__ __launch_bounds__(SPMV_BLOCK) void k_spmv_fused(
         }
         __syncthreads();
 
-        // ---- phase 2: reduce the short rows out of LDS ---------------------
-        const int nr = r1s - r0;
-        if (nr > 0) {
-            // lanes per row from the block's mean row length: <= 16 nonzeros -> one lane,
-            // plain left-to-right sum (bit-identical to the reference's COO-order row
-            // sums); longer rows get 2..64 lanes and a shuffle tree.
-            const int avg = cnt / nr;
-            int G = 1;
-            while (G < WAVE && avg > 16 * G) G <<= 1;  // uniform
-            const int gl = tid & (G - 1), gid = tid / G, ngroups = SPMV_BLOCK / G;
-            for (int r = r0 + gid; r < r1s; r += ngroups) {
-                const int s0 = (int)(rowptr[r] - p0), s1 = (int)(rowptr[r + 1] - p0);
+        // ---- phase 2: reduce the short rows out of LDS ---------------------------------
+        if (have_row) {
+            int r = rfirst;
+            for (;;) {
+                const int s0 = (int)(q0 - p0), s1 = (int)(q1 - p0);
                 double s = 0.0;
                 for (int k = s0 + gl; k < s1; k += G) s = s + prod[k];
                 for (int off = G >> 1; off > 0; off >>= 1) s += __shfl_xor(s, off, WAVE);
                 if (gl == 0) {
-                    const double yn = cy * (y[r] * sy) + s;
+                    const double yn = cy * (y0 * sy) + s;
                     y[r] = yn;
                     sq += yn * yn;
                 }
+                r += ngroups;
+                if (r >= r1s) break;
+                q0 = rowptr[r];
+                q1 = rowptr[r + 1];
+                y0 = y[r];
             }
         }
 
-        // ---- phase 3: a long last row, split across the workgroup ----------
+        // ---- phase 3: a long last row, split across the workgroup ----------------------
         if (has_long) {
             const OffT len = pend - plast;
             const OffT lastk = len - 1;
             double s = 0.0;
             for (OffT k = tid; k < len; k += 4 * SPMV_BLOCK) {
-                OffT kk[4];
-                double a[4];
-                int c[4];
+                OffT kl[4];
+                double al[4];
+                int cl[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const OffT t = k + j * SPMV_BLOCK;
-                    kk[j] = t < lastk ? t : lastk;
+                    kl[j] = t < lastk ? t : lastk;
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    a[j] = val[plast + kk[j]];
-                    c[j] = col[plast + kk[j]];
+                    al[j] = val[plast + kl[j]];
+                    cl[j] = col[plast + kl[j]];
                 }
-                double xv[4];
+                double xl[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) xv[j] = x[c[j]];
+                for (int j = 0; j < 4; ++j) xl[j] = x[cl[j]];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const OffT t = k + j * SPMV_BLOCK;
-                    if (t < len) s = s + a[j] * (xv[j] * sx);
+                    if (t < len) s = s + al[j] * (xl[j] * sx);
                 }
             }
             const double tot = block_sum<SPMV_BLOCK>(s, red);
@@ -175,7 +297,7 @@ __global__ __launch_bounds__(SPMV_BLOCK) void k_spmv_fused(
     }
 
     const double tot = block_sum<SPMV_BLOCK>(sq, red);
-    if (tid == 0) partials[blockIdx.x] = tot;
+    if (tid == 0) partials[wg] = tot;
 }
 
 }  // namespace lsqrhip

@@ -17,6 +17,13 @@ struct SpmvCoef {
     int pad;
 };
 
+// What one SpMV hands to the next in the pipelined schedule (spmv.h, solve_loop.h): the
+// norm it derived from the previous kernel's partials and the matching scale.
+struct NormSlot {
+    double nrm;    // beta (published by mode 2) or alpha (published by mode 1)
+    double scale;  // 1/nrm, or 1 when nrm == 0  (the guards at src/lsqr.f90:635, 641, 691, 696)
+};
+
 struct LsqrState {
     // control ------------------------------------------------------------
     int stop;      // != 0: every kernel of the loop returns at once

@@ -166,8 +166,7 @@ __global__ __launch_bounds__(VEC_BLOCK) void k_reduce_partials(const double *__r
                                                                int np, double *__restrict__ out)
 {
     __shared__ double red[VEC_BLOCK / WAVE];
-    double s = 0.0;
-    for (int i = threadIdx.x; i < np; i += VEC_BLOCK) s += partials[i];
+    const double s = np > 0 ? strided_sum<VEC_BLOCK>(partials, np) : 0.0;
     const double tot = block_sum<VEC_BLOCK>(s, red);
     if (threadIdx.x == 0) out[0] = tot;
 }

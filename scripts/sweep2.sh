@@ -1,0 +1,7 @@
+#!/bin/bash
+cd "$(dirname "$0")/.."
+for spec in poisson2d:1000:1000 random:1000000:1000000:20 random:400000:100000:100 powerlaw:500000:200000:10000; do
+  for C in 512 1024 2048; do
+    LSQRHIP_SPMV_C=$C LSQRHIP_SPMV_EVEN=0 timeout 120 python scripts/kernel_times.py $spec 200 2>/dev/null
+  done
+done

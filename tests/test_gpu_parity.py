@@ -220,6 +220,30 @@ def test_graph_and_eager_launch_modes_agree_bitwise():
     assert np.array_equal(r7.x, r_graph.x) and r7.itn == r_graph.itn
 
 
+@pytest.mark.parametrize("name", ["poisson_20x20_it50", "random_over_se", "powerlaw_small", "illcond_conlim",
+                                  "empty_rows_cols", "t1_readme_damped", "b_zero"])
+def test_pipelined_and_sequential_schedules_agree_bitwise(name):
+    """solve_loop.h: the two-stream pipelined schedule (SpMVs derive their own norm, scalar
+    machine + x/w update beside the next SpMV) must reproduce the plain sequential schedule
+    bit for bit -- same x, se, scalars, istop, itn -- in graph and in eager mode."""
+    p, o = CASES[name]
+    s = make(p, o)
+    ref = None
+    for pipeline in (0, 1):
+        for graph in (1, 0):
+            s.set_option("pipeline", pipeline)
+            s.set_option("graph", graph)
+            r = s.solve(p.b, o["damp"], wantse=o["wantse"])
+            key = (r.istop, r.itn, r.anorm, r.acond, r.rnorm, r.arnorm, r.xnorm)
+            if ref is None:
+                ref = (r, key)
+            else:
+                assert key == ref[1], (pipeline, graph)
+                assert np.array_equal(r.x, ref[0].x)
+                if o["wantse"]:
+                    assert np.array_equal(r.se, ref[0].se)
+
+
 @pytest.mark.parametrize("name", sorted(BLAS))
 def test_device_blas1_vs_reference_golden(name):
     x = blas_vectors()[name]
