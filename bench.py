@@ -83,7 +83,7 @@ def run_single(args):
     d_b = capi.DeviceBuffer.from_array(p.b)
     d_x = capi.DeviceBuffer(8 * max(p.n, 1))
     # graph batches that divide K exactly: no predicated-off tail iterations in the timed solve
-    gi = next(g for g in (20, 16, 10, 8, 5, 4, 2, 1) if K % g == 0)
+    gi = next(g for g in (50, 40, 32, 20, 16, 10, 8, 4, 2, 1) if K % g == 0)
     s.set_option("graph_iters", gi)
 
     if W > 0:
@@ -153,7 +153,7 @@ def run_single(args):
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 or world > 1:
+    if args.gpus > 1 or world > 1 or os.environ.get("LSQR_BENCH_FORCE_DIST") == "1":
         from lsqr_amd.dist_bench import run_distributed
         run_distributed(args)
     else:

@@ -148,19 +148,16 @@ struct lsqrhip_handle_s {
     int log_count = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
     // options
-    int use_graph = 1, graph_iters = 16, time_kernels = 0;
+    int use_graph = 1, graph_iters = 32, time_kernels = 0;
     hipGraphExec_t gexec = nullptr;
     int gexec_iters = 0;
     bool graph_dirty = true;
     std::vector<hipEvent_t> ev;
     hipEvent_t ev_loop0 = nullptr, ev_loop1 = nullptr;
     lsqrhip_timing_t timing{};
-    // pipelined schedule (solve_loop.h)
+    // rider schedule (solve_loop.h)
     int pipeline = 1;
     int gexec_pipeline = -1;
-    hipStream_t stream_b = nullptr;      // side stream: scalar machine + x/w update
-    hipEvent_t ev_join = nullptr;
-    std::vector<hipEvent_t> ev_k2, ev_k4;  // per iteration of a batch
     double *P1[2] = {nullptr, nullptr};  // mode-1 partials by iteration parity
     double *P2[2] = {nullptr, nullptr};  // mode-2 partials by iteration parity
     double *P3 = nullptr;                // x/w update partials
@@ -221,13 +218,9 @@ extern "C" int lsqrhip_destroy(lsqrhip_handle_t h)
     if (h->d_unit) (void)hipFree(h->d_unit);
     if (h->d_zero) (void)hipFree(h->d_zero);
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
-    for (hipEvent_t e : h->ev_k2) (void)hipEventDestroy(e);
-    for (hipEvent_t e : h->ev_k4) (void)hipEventDestroy(e);
-    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     for (double *p : {h->P1[0], h->P1[1], h->P2[0], h->P2[1], h->P3})
         if (p) (void)hipFree(p);
     if (h->slots) (void)hipFree(h->slots);
-    if (h->stream_b) (void)hipStreamDestroy(h->stream_b);
     if (h->ev_loop0) (void)hipEventDestroy(h->ev_loop0);
     if (h->ev_loop1) (void)hipEventDestroy(h->ev_loop1);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -346,8 +339,6 @@ static int finish_create(H *h, const int *d_irow, const int *d_icol, const doubl
     }
     HIPCHK(hipMalloc((void **)&h->slots, sizeof(NormSlot) * 4));
     HIPCHK(hipMemsetAsync(h->slots, 0, sizeof(NormSlot) * 4, s));
-    HIPCHK(hipStreamCreateWithFlags(&h->stream_b, hipStreamNonBlocking));
-    HIPCHK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
     HIPCHK(hipMalloc((void **)&h->d_state, sizeof(LsqrState)));
     HIPCHK(hipHostMalloc((void **)&h->h_state, sizeof(LsqrState)));
     HIPCHK(hipMalloc((void **)&h->d_unit, sizeof(SpmvCoef)));

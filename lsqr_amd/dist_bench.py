@@ -71,6 +71,32 @@ def run_distributed(args):
     b1 = 12 * prob.nnz + p * (nrows + 1) + 8 * cfg["n"] + 16 * nrows
     ach = b1 / (avg1 * 1e-3) / 1e9
 
+    # Same workload on ONE GPU (rank 0), outside the timed region: N = 1 of bench.py runs a
+    # different configuration (BASELINE configs[1]), so the strong-scaling speedup of THIS
+    # problem is made self-contained here.
+    ref = None
+    sref = os.environ.get("LSQR_BENCH_STRONG_REF", "1")
+    if rank == 0 and ((sref == "1" and world > 1) or sref == "force"):
+        try:
+            import ctypes as C
+            full = devgen.generate(spec)
+            d_x = capi.DeviceBuffer(8 * max(cfg["n"], 1))
+            full.solver.atol = full.solver.btol = full.solver.conlim = 0.0
+            kr = max(2, min(K, 50))
+            full.solver.itnlim = max(2, min(W, 4))
+            full.solver.solve_device(full.d_b.ptr.value, d_x.ptr.value, cfg["damp"])
+            full.solver.itnlim = kr
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            rr = full.solver.solve_device(full.d_b.ptr.value, d_x.ptr.value, cfg["damp"])
+            torch.cuda.synchronize()
+            dt1 = time.perf_counter() - t1
+            ref = {"n_gpus": 1, "steps": kr, "value": rr.itn / dt1, "unit": "it/s", "ms_per_step": 1e3 * dt1 / rr.itn,
+                   "note": "same matrix, whole on rank 0's GPU, measured after the timed sharded solve"}
+            del full, d_x
+        except Exception as e:  # e.g. not enough HBM for the whole matrix: report, do not fail the run
+            ref = {"error": repr(e)}
+
     if rank == 0:
         out = {
             "metric": "lsqr_iterations_per_sec", "value": K / dt, "unit": "it/s", "n_gpus": world, "steps": K,
@@ -86,6 +112,10 @@ def run_distributed(args):
                          "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": None,
                          "bytes_per_launch": b1, "avg_launch_us": avg1 * 1e3, "launches": reps},
         }
+        if ref is not None:
+            out["strong_scaling_ref"] = ref
+            if "value" in ref:
+                out["speedup_vs_1gpu_same_workload"] = (K / dt) / ref["value"]
         print(json.dumps(out), flush=True)
     dist.barrier()
     dist.destroy_process_group()
