@@ -40,6 +40,48 @@ __global__ __launch_bounds__(256) void k_pack_keys(const int *__restrict__ keys,
     if (unsorted) atomicOr(&flags[1], 1);
 }
 
+// Column-panel layout (spmv.h "panels"): the sort key is the VIRTUAL row
+// panel(col) * rows + (row - 1), so the CSR that comes out is that of the panel-stacked matrix
+// [A_panel0; A_panel1; ...] with every virtual row still in COO order.
+// flags[0] |= 1 for a bad row index, flags[2] |= 1 for a bad column index.
+__global__ __launch_bounds__(256) void k_pack_keys_panel(const int *__restrict__ rowk,
+                                                         const int *__restrict__ colk, int64_t nnz, int rows,
+                                                         int cols, int pw,
+                                                         unsigned long long *__restrict__ packed,
+                                                         int *__restrict__ flags)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int badr = 0, badc = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nnz; i += stride) {
+        int r = rowk[i], c = colk[i];
+        if (r < 1 || r > rows) { badr = 1; r = 1; }
+        if (c < 1 || c > cols) { badc = 1; c = 1; }
+        const unsigned long long key = (unsigned long long)((c - 1) / pw) * (unsigned long long)rows +
+                                       (unsigned long long)(r - 1);
+        packed[i] = (key << 32) | (unsigned long long)(unsigned)i;
+    }
+    if (badr) atomicOr(&flags[0], 1);
+    if (badc) atomicOr(&flags[2], 1);
+}
+
+// How far the entries sit from the (scaled) diagonal: sum |col - row * cols / rows| in integer
+// arithmetic (order-independent, so deterministic).  Banded / local matrices score small and
+// keep the plain CSR; random column patterns score ~cols/3 and get column panels.
+__global__ __launch_bounds__(256) void k_col_deviation(const int *__restrict__ rowk,
+                                                       const int *__restrict__ colk, int64_t nnz, int rows,
+                                                       int cols, unsigned long long *__restrict__ out)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    unsigned long long acc = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nnz; i += stride) {
+        const long long r = rowk[i] - 1, c = colk[i] - 1;
+        const long long d = c - (r * (long long)cols) / (rows > 0 ? rows : 1);
+        acc += (unsigned long long)(d < 0 ? -d : d);
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, WAVE);
+    if ((threadIdx.x & (WAVE - 1)) == 0 && acc) atomicAdd(out, acc);
+}
+
 __global__ __launch_bounds__(RS_BLOCK) void k_radix_hist(const unsigned long long *__restrict__ in,
                                                          int64_t nnz, int shift, int64_t nblocks,
                                                          unsigned *__restrict__ hist_g)

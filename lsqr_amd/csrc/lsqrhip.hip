@@ -17,6 +17,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -123,7 +124,11 @@ struct Csr {
     RowBlock *blk = nullptr;  // one descriptor per row block (spmv.h)
     int64_t nblk = 0;
     int rows = 0, cols = 0;
-    int grid = 0;
+    int grid = 0;      // workgroups of the SpMV launch
+    int out_grid = 0;  // partials one product leaves behind (== grid, or the combine kernel's grid)
+    int P = 1;         // column panels (1 = plain CSR)
+    int pw = 0;        // panel width in columns
+    int64_t rows_v = 0;  // virtual rows = P * rows (what rowptr / rb / blk index)
     int64_t bytes = 0;
 };
 
@@ -135,6 +140,7 @@ struct lsqrhip_handle_s {
     bool off64 = false;
     Csr A, AT;
     double *U = nullptr, *V = nullptr, *W = nullptr, *X = nullptr, *SE = nullptr;
+    double *Z = nullptr;         // per-panel row sums of a panelled product (max over A, A')
     double *partials = nullptr;  // SPMV_MAX_GRID
     int vgrid_m = 1, vgrid_n = 1;
     LsqrState *d_state = nullptr;
@@ -167,6 +173,12 @@ struct lsqrhip_handle_s {
     int shard_wantse = 0;
 };
 typedef lsqrhip_handle_s H;
+
+static int env_int(const char *name, int dflt)
+{
+    const char *v = std::getenv(name);
+    return (v && *v) ? std::atoi(v) : dflt;
+}
 
 static int vec_grid(int64_t n)
 {
@@ -211,7 +223,7 @@ extern "C" int lsqrhip_destroy(lsqrhip_handle_t h)
     destroy_graph(h);
     free_csr(h->A);
     free_csr(h->AT);
-    for (double *p : {h->U, h->V, h->W, h->X, h->SE, h->partials, h->d_scalar, h->d_log})
+    for (double *p : {h->U, h->V, h->W, h->X, h->SE, h->Z, h->partials, h->d_scalar, h->d_log})
         if (p) (void)hipFree(p);
     if (h->d_state) (void)hipFree(h->d_state);
     if (h->h_state) (void)hipHostFree(h->h_state);
@@ -240,29 +252,42 @@ static int bits_for(int limit)
 
 template <typename OffT>
 static int build_csr_T(hipStream_t s, const int *d_keys, const int *d_other, const double *d_a, int64_t nnz,
-                       int rows, int cols, int bad_code, unsigned long long *bufA, unsigned long long *bufB,
-                       unsigned *hist, int *d_flags, Csr &out)
+                       int rows, int cols, int bad_code, int bad_code_other, int panels, int pw,
+                       unsigned long long *bufA, unsigned long long *bufB, unsigned *hist, int *d_flags, Csr &out)
 {
     out.rows = rows;
     out.cols = cols;
-    HIPCHK(hipMalloc(&out.rowptr, sizeof(OffT) * ((size_t)rows + 1)));
+    out.P = panels > 1 ? panels : 1;
+    out.pw = out.P > 1 ? pw : cols;
+    out.rows_v = (int64_t)out.P * rows;
+    const int rows_v = (int)out.rows_v;  // < 2^31, checked by the caller
+    HIPCHK(hipMalloc(&out.rowptr, sizeof(OffT) * ((size_t)rows_v + 1)));
     HIPCHK(hipMalloc((void **)&out.col, sizeof(int) * (size_t)std::max<int64_t>(nnz, 1)));
     HIPCHK(hipMalloc((void **)&out.val, sizeof(double) * (size_t)std::max<int64_t>(nnz, 1)));
-    out.bytes = (int64_t)sizeof(OffT) * (rows + 1) + 12 * nnz;
+    out.bytes = (int64_t)sizeof(OffT) * (rows_v + 1) + 12 * nnz;
 
-    HIPCHK(hipMemsetAsync(d_flags, 0, 2 * sizeof(int), s));
+    HIPCHK(hipMemsetAsync(d_flags, 0, 4 * sizeof(int), s));
     const int g = (int)std::min<int64_t>(std::max<int64_t>((nnz + 255) / 256, 1), 4096);
-    int flags[2] = {0, 0};
+    int flags[4] = {0, 0, 0, 0};
     unsigned long long *sorted = bufA;
     if (nnz > 0) {
-        hipLaunchKernelGGL(k_pack_keys, dim3(g), dim3(256), 0, s, d_keys, nnz, rows, bufA, d_flags);
+        if (out.P > 1) {  // key = panel(col) * rows + row: never pre-sorted
+            hipLaunchKernelGGL(k_pack_keys_panel, dim3(g), dim3(256), 0, s, d_keys, d_other, nnz, rows, cols, out.pw,
+                               bufA, d_flags);
+            flags[1] = 1;
+        } else {
+            hipLaunchKernelGGL(k_pack_keys, dim3(g), dim3(256), 0, s, d_keys, nnz, rows, bufA, d_flags);
+        }
         HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(flags, d_flags, sizeof(flags), hipMemcpyDeviceToHost, s));
+        int got[4];
+        HIPCHK(hipMemcpyAsync(got, d_flags, sizeof(got), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
-        if (flags[0]) return fail(bad_code, lsqrhip_error_string(bad_code));
+        if (got[0]) return fail(bad_code, lsqrhip_error_string(bad_code));
+        if (got[2]) return fail(bad_code_other, lsqrhip_error_string(bad_code_other));
+        flags[1] |= got[1];
         if (flags[1]) {  // not sorted by key: stable LSD radix sort on the key bits
             const int64_t nb = (nnz + RS_TILE - 1) / RS_TILE;
-            const int nbits = bits_for(rows);
+            const int nbits = bits_for(rows_v);
             unsigned long long *in = bufA, *outb = bufB;
             for (int shift = 32; shift < 32 + nbits; shift += 8) {
                 hipLaunchKernelGGL(k_radix_hist, dim3((unsigned)nb), dim3(RS_BLOCK), 0, s, in, nnz, shift, nb, hist);
@@ -275,16 +300,16 @@ static int build_csr_T(hipStream_t s, const int *d_keys, const int *d_other, con
         }
         hipLaunchKernelGGL(k_csr_gather, dim3(g), dim3(256), 0, s, sorted, nnz, d_other, d_a, out.col, out.val);
     }
-    hipLaunchKernelGGL(k_rowptr_from_sorted<OffT>, dim3(g), dim3(256), 0, s, sorted, nnz, rows, (OffT *)out.rowptr);
+    hipLaunchKernelGGL(k_rowptr_from_sorted<OffT>, dim3(g), dim3(256), 0, s, sorted, nnz, rows_v, (OffT *)out.rowptr);
     HIPCHK(hipGetLastError());
 
-    // row blocks ("row windows", spmv.h)
-    out.nblk = std::max<int64_t>((nnz + rows + SPMV_C - 1) / SPMV_C, 1);
+    // row blocks ("row windows", spmv.h) over the (virtual) rows
+    out.nblk = std::max<int64_t>((nnz + rows_v + SPMV_C - 1) / SPMV_C, 1);
     HIPCHK(hipMalloc((void **)&out.rb, sizeof(int) * (size_t)(out.nblk + 1)));
     out.bytes += (int64_t)sizeof(int) * (out.nblk + 1);
     const int64_t nt = out.nblk + 1;
     hipLaunchKernelGGL(k_row_blocks<OffT>, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, s,
-                       (const OffT *)out.rowptr, rows, out.nblk, out.rb);
+                       (const OffT *)out.rowptr, rows_v, out.nblk, out.rb);
     HIPCHK(hipMalloc((void **)&out.blk, sizeof(RowBlock) * (size_t)out.nblk));
     out.bytes += (int64_t)sizeof(RowBlock) * out.nblk;
     hipLaunchKernelGGL(k_block_desc<OffT>, dim3((unsigned)((out.nblk + 255) / 256)), dim3(256), 0, s,
@@ -293,8 +318,29 @@ static int build_csr_T(hipStream_t s, const int *d_keys, const int *d_other, con
     int64_t grid = std::min<int64_t>(out.nblk, SPMV_MAX_GRID);
     if (grid >= 8) grid &= ~(int64_t)7;  // multiple of 8: XCD-aware mapping (common.h)
     out.grid = (int)std::max<int64_t>(grid, 1);
+    out.out_grid = out.P > 1 ? vec_grid(2 * (int64_t)rows) : out.grid;
     HIPCHK(hipStreamSynchronize(s));
     return LSQRHIP_OK;
+}
+
+// Column panels for a product whose x vector has `cols` entries?  (spmv.h "Column panels")
+//   LSQRHIP_PANELS    0 never | 1 whenever x exceeds one panel | unset: only if the columns are not local
+//   LSQRHIP_PANEL_KB  panel size in KiB of x (default 2048: half an XCD's 4 MiB L2, the rest streams;
+//                     swept 1024 / 2560 / 3584: profiles/r01/sweep_panels.txt)
+static void choose_panels(int rows, int cols, double mean_dev, int *panels, int *pw)
+{
+    *panels = 1;
+    *pw = cols;
+    const int mode = env_int("LSQRHIP_PANELS", -1);
+    if (mode == 0) return;
+    const int64_t kb = std::max(64, env_int("LSQRHIP_PANEL_KB", 2048));
+    const int64_t width = (kb * 1024 / 8 + 1023) & ~(int64_t)1023;
+    if ((int64_t)cols <= 2 * width) return;                  // x (nearly) fits L2 as it is
+    if (mode != 1 && mean_dev < 0.25 * (double)width) return;  // banded / local: plain CSR is better
+    const int64_t P = ((int64_t)cols + width - 1) / width;
+    if (P * (int64_t)rows >= (1ll << 31)) return;            // virtual rows must fit int32
+    *panels = (int)P;
+    *pw = (int)width;
 }
 
 static int finish_create(H *h, const int *d_irow, const int *d_icol, const double *d_a)
@@ -308,16 +354,31 @@ static int finish_create(H *h, const int *d_irow, const int *d_icol, const doubl
     HIPCHK(hipMalloc((void **)&bufA, sizeof(unsigned long long) * (size_t)std::max<int64_t>(nnz, 1)));
     HIPCHK(hipMalloc((void **)&bufB, sizeof(unsigned long long) * (size_t)std::max<int64_t>(nnz, 1)));
     HIPCHK(hipMalloc((void **)&hist, sizeof(unsigned) * 256 * (size_t)nb));
-    HIPCHK(hipMalloc((void **)&d_flags, 2 * sizeof(int)));
+    HIPCHK(hipMalloc((void **)&d_flags, 4 * sizeof(int)));
+    // locality of the column pattern (only looked at when a vector exceeds L2; indices that are
+    // out of range are caught by the build below, the measure merely becomes meaningless)
+    double mean_dev = 0.0;
+    if (nnz > 0 && env_int("LSQRHIP_PANELS", -1) != 0 && std::max(h->m, h->n) > 600000) {
+        unsigned long long *d_dev = (unsigned long long *)hist, dev = 0;
+        HIPCHK(hipMemsetAsync(d_dev, 0, sizeof(dev), s));
+        const int g = (int)std::min<int64_t>(std::max<int64_t>((nnz + 255) / 256, 1), 4096);
+        hipLaunchKernelGGL(k_col_deviation, dim3(g), dim3(256), 0, s, d_irow, d_icol, nnz, h->m, h->n, d_dev);
+        HIPCHK(hipMemcpyAsync(&dev, d_dev, sizeof(dev), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        mean_dev = (double)dev / (double)nnz;
+    }
+    int pa = 1, pwa = h->n, pt = 1, pwt = h->m;
+    choose_panels(h->m, h->n, mean_dev, &pa, &pwa);                                   // mode 1 gathers V (n)
+    choose_panels(h->n, h->m, mean_dev * (double)std::max(h->m, 1) / (double)std::max(h->n, 1), &pt, &pwt);  // mode 2 gathers U (m)
     int rc;
     if (h->off64) {
-        rc = build_csr_T<long long>(s, d_irow, d_icol, d_a, nnz, h->m, h->n, LSQRHIP_ERR_IROW, bufA, bufB, hist, d_flags, h->A);
+        rc = build_csr_T<long long>(s, d_irow, d_icol, d_a, nnz, h->m, h->n, LSQRHIP_ERR_IROW, LSQRHIP_ERR_ICOL, pa, pwa, bufA, bufB, hist, d_flags, h->A);
         if (rc == LSQRHIP_OK)
-            rc = build_csr_T<long long>(s, d_icol, d_irow, d_a, nnz, h->n, h->m, LSQRHIP_ERR_ICOL, bufA, bufB, hist, d_flags, h->AT);
+            rc = build_csr_T<long long>(s, d_icol, d_irow, d_a, nnz, h->n, h->m, LSQRHIP_ERR_ICOL, LSQRHIP_ERR_IROW, pt, pwt, bufA, bufB, hist, d_flags, h->AT);
     } else {
-        rc = build_csr_T<int>(s, d_irow, d_icol, d_a, nnz, h->m, h->n, LSQRHIP_ERR_IROW, bufA, bufB, hist, d_flags, h->A);
+        rc = build_csr_T<int>(s, d_irow, d_icol, d_a, nnz, h->m, h->n, LSQRHIP_ERR_IROW, LSQRHIP_ERR_ICOL, pa, pwa, bufA, bufB, hist, d_flags, h->A);
         if (rc == LSQRHIP_OK)
-            rc = build_csr_T<int>(s, d_icol, d_irow, d_a, nnz, h->n, h->m, LSQRHIP_ERR_ICOL, bufA, bufB, hist, d_flags, h->AT);
+            rc = build_csr_T<int>(s, d_icol, d_irow, d_a, nnz, h->n, h->m, LSQRHIP_ERR_ICOL, LSQRHIP_ERR_IROW, pt, pwt, bufA, bufB, hist, d_flags, h->AT);
     }
     (void)hipFree(bufA);
     (void)hipFree(bufB);
@@ -332,6 +393,10 @@ static int finish_create(H *h, const int *d_irow, const int *d_icol, const doubl
     HIPCHK(hipMalloc((void **)&h->X, sizeof(double) * n1));
     HIPCHK(hipMalloc((void **)&h->SE, sizeof(double) * n1));
     HIPCHK(hipMalloc((void **)&h->partials, sizeof(double) * SPMV_MAX_GRID));
+    {
+        const int64_t zn = std::max<int64_t>(h->A.P > 1 ? h->A.rows_v : 0, h->AT.P > 1 ? h->AT.rows_v : 0);
+        if (zn > 0) HIPCHK(hipMalloc((void **)&h->Z, sizeof(double) * (size_t)zn));
+    }
     HIPCHK(hipMalloc((void **)&h->d_scalar, sizeof(double) * 4));
     for (double **pp : {&h->P1[0], &h->P1[1], &h->P2[0], &h->P2[1], &h->P3}) {
         HIPCHK(hipMalloc((void **)pp, sizeof(double) * SPMV_MAX_GRID));

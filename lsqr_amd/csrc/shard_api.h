@@ -111,7 +111,7 @@ extern "C" int lsqrhip_shard_stage(lsqrhip_handle_t h, int stage)
     case ST_MODE1:  // U_p <- (-alpha)(U_p su) + A_p (V sv); sums[0] = |U_p|^2
         launch_spmv(h, h->A, h->V, h->U, &st->c1, &st->stop);
         hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(VEC_BLOCK), 0, s, (const double *)h->partials,
-                           h->A.grid, sums);
+                           h->A.out_grid, sums);
         break;
     case ST_S1_ATU:  // beta, anorm from the all-reduced sums[0]; T_p = A_p'(U_p su)
         hipLaunchKernelGGL(k_s1<false>, dim3(1), dim3(SC_BLOCK), 0, s, (const double *)h->partials, 0,

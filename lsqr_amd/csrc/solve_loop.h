@@ -50,26 +50,41 @@ struct SpmvArgs {
     hipEvent_t e0 = nullptr, e1 = nullptr;  // kernel begin/end timestamps (hipExtLaunchKernelGGL)
 };
 
-template <typename OffT>
-static void launch_spmv_T(const SpmvArgs &a)
+template <typename OffT, bool PANEL>
+static void launch_spmv_T(const SpmvArgs &a, double *y, hipEvent_t e0, hipEvent_t e1)
 {
     const Csr &c = *a.c;
     const dim3 grid(c.grid + (a.rider.kind != 0 ? 1 : 0));
-    if (a.e0 == nullptr)  // plain launch (the only form used under stream capture)
-        hipLaunchKernelGGL(k_spmv_fused<OffT>, grid, dim3(SPMV_BLOCK), 0, a.stream, (const OffT *)c.rowptr,
-                           (const int *)c.col, (const double *)c.val, (const RowBlock *)c.blk, c.nblk, a.x, a.y,
+    if (e0 == nullptr && e1 == nullptr)  // plain launch (the only form used under stream capture)
+        hipLaunchKernelGGL((k_spmv_fused<OffT, PANEL>), grid, dim3(SPMV_BLOCK), 0, a.stream, (const OffT *)c.rowptr,
+                           (const int *)c.col, (const double *)c.val, (const RowBlock *)c.blk, c.nblk, a.x, y,
                            a.coef, a.stop, a.pout, a.pin, a.npin, a.slot_in, a.slot_out, a.skip_if_zero, a.rider);
     else
-        hipExtLaunchKernelGGL(k_spmv_fused<OffT>, grid, dim3(SPMV_BLOCK), 0, a.stream, a.e0, a.e1, 0,
+        hipExtLaunchKernelGGL((k_spmv_fused<OffT, PANEL>), grid, dim3(SPMV_BLOCK), 0, a.stream, e0, e1, 0,
                               (const OffT *)c.rowptr, (const int *)c.col, (const double *)c.val,
-                              (const RowBlock *)c.blk, c.nblk, a.x, a.y, a.coef, a.stop, a.pout, a.pin, a.npin,
+                              (const RowBlock *)c.blk, c.nblk, a.x, y, a.coef, a.stop, a.pout, a.pin, a.npin,
                               a.slot_in, a.slot_out, a.skip_if_zero, a.rider);
 }
 
 static void launch_spmv_args(H *h, const SpmvArgs &a)
 {
-    if (h->off64) launch_spmv_T<long long>(a);
-    else launch_spmv_T<int>(a);
+    const Csr &c = *a.c;
+    if (c.P <= 1) {
+        if (h->off64) launch_spmv_T<long long, false>(a, a.y, a.e0, a.e1);
+        else launch_spmv_T<int, false>(a, a.y, a.e0, a.e1);
+        return;
+    }
+    // panelled product: per-panel row sums into Z, then the combine (spmv.h "Column panels");
+    // a timed launch brackets both kernels (begin of the first, end of the second)
+    if (h->off64) launch_spmv_T<long long, true>(a, h->Z, a.e0, nullptr);
+    else launch_spmv_T<int, true>(a, h->Z, a.e0, nullptr);
+    if (a.e1 == nullptr)
+        hipLaunchKernelGGL(k_panel_combine, dim3(c.out_grid), dim3(SPMV_BLOCK), 0, a.stream, a.y, (const double *)h->Z,
+                           c.rows, c.P, a.coef, a.stop, a.pout, a.pin, a.npin, a.slot_in, a.skip_if_zero);
+    else
+        hipExtLaunchKernelGGL(k_panel_combine, dim3(c.out_grid), dim3(SPMV_BLOCK), 0, a.stream, nullptr, a.e1, 0, a.y,
+                              (const double *)h->Z, c.rows, c.P, a.coef, a.stop, a.pout, a.pin, a.npin, a.slot_in,
+                              a.skip_if_zero);
 }
 
 // explicit-coefficient form on the handle's stream, partials into h->partials
@@ -99,10 +114,10 @@ static void launch_iteration_seq(H *h, hipEvent_t *ev)
     LsqrState *st = h->d_state;
     hipStream_t s = h->stream;
     launch_spmv(h, h->A, h->V, h->U, &st->c1, &st->stop, ev ? ev[0] : nullptr, ev ? ev[1] : nullptr);
-    hipLaunchKernelGGL(k_s1<true>, dim3(1), dim3(SC_BLOCK), 0, s, (const double *)h->partials, h->A.grid,
+    hipLaunchKernelGGL(k_s1<true>, dim3(1), dim3(SC_BLOCK), 0, s, (const double *)h->partials, h->A.out_grid,
                        (const double *)nullptr, st);
     launch_spmv(h, h->AT, h->U, h->V, &st->c2, &st->stop, ev ? ev[2] : nullptr, ev ? ev[3] : nullptr);
-    hipLaunchKernelGGL(k_s2<true>, dim3(1), dim3(SC_BLOCK), 0, s, (const double *)h->partials, h->AT.grid,
+    hipLaunchKernelGGL(k_s2<true>, dim3(1), dim3(SC_BLOCK), 0, s, (const double *)h->partials, h->AT.out_grid,
                        (const double *)nullptr, st);
     launch_update(h, h->partials, ev ? ev[4] : nullptr, ev ? ev[5] : nullptr);
     hipLaunchKernelGGL(k_s3<true>, dim3(1), dim3(SC_BLOCK), 0, s, (const double *)h->partials, h->vgrid_n,
@@ -114,8 +129,8 @@ static Rider rider_s12(H *h, int i)  // steps 1+2 of iteration i
 {
     Rider r{};
     r.kind = 1;
-    r.pa = h->P1[i & 1]; r.na = h->A.grid;
-    r.pb = h->P2[i & 1]; r.nb = h->AT.grid;
+    r.pa = h->P1[i & 1]; r.na = h->A.out_grid;
+    r.pb = h->P2[i & 1]; r.nb = h->AT.out_grid;
     r.st = h->d_state;
     return r;
 }
@@ -134,7 +149,7 @@ static void launch_k1(H *h, int i, const Rider &rider, hipEvent_t e0, hipEvent_t
     const int par = i & 1, prev = par ^ 1;
     NormSlot *slotA = h->slots, *slotB = h->slots + 2;
     SpmvArgs a;
-    a.c = &h->A; a.x = h->V; a.y = h->U; a.pin = h->P2[prev]; a.npin = h->AT.grid;
+    a.c = &h->A; a.x = h->V; a.y = h->U; a.pin = h->P2[prev]; a.npin = h->AT.out_grid;
     a.slot_in = &slotB[prev]; a.slot_out = &slotA[par]; a.skip_if_zero = 0; a.stop = &h->d_state->stop;
     a.pout = h->P1[par]; a.rider = rider; a.stream = h->stream; a.e0 = e0; a.e1 = e1;
     launch_spmv_args(h, a);
@@ -145,7 +160,7 @@ static void launch_k2(H *h, int i, const Rider &rider, hipEvent_t e0, hipEvent_t
     const int par = i & 1;
     NormSlot *slotA = h->slots, *slotB = h->slots + 2;
     SpmvArgs a;
-    a.c = &h->AT; a.x = h->U; a.y = h->V; a.pin = h->P1[par]; a.npin = h->A.grid;
+    a.c = &h->AT; a.x = h->U; a.y = h->V; a.pin = h->P1[par]; a.npin = h->A.out_grid;
     a.slot_in = &slotA[par]; a.slot_out = &slotB[par]; a.skip_if_zero = 1; a.stop = &h->d_state->stop;
     a.pout = h->P2[par]; a.rider = rider; a.stream = h->stream; a.e0 = e0; a.e1 = e1;
     launch_spmv_args(h, a);
@@ -172,8 +187,8 @@ static int launch_batch(H *h, int i0, int G, hipEvent_t *ev)
         launch_k2(h, i, rider_s3(h), E(j, 2), E(j, 3));            // K2(i)  (+) S3(i-1)
     }
     const int il = i0 + G - 1;  // settle the last iteration of the batch with plain kernels
-    hipLaunchKernelGGL(k_s12, dim3(1), dim3(SC_BLOCK), 0, s, (const double *)h->P1[il & 1], h->A.grid,
-                       (const double *)h->P2[il & 1], h->AT.grid, st);
+    hipLaunchKernelGGL(k_s12, dim3(1), dim3(SC_BLOCK), 0, s, (const double *)h->P1[il & 1], h->A.out_grid,
+                       (const double *)h->P2[il & 1], h->AT.out_grid, st);
     launch_update(h, h->P3, E(G - 1, 4), E(G - 1, 5));
     hipLaunchKernelGGL(k_s3<true>, dim3(1), dim3(SC_BLOCK), 0, s, (const double *)h->P3, h->vgrid_n,
                        (const double *)nullptr, st, (const double *)h->X, h->d_log);
@@ -269,7 +284,7 @@ static int solve_core(H *h, const double *b, bool b_on_device, double damp, doub
         a.c = &h->AT; a.x = h->U; a.y = h->V; a.coef = &st->c2; a.stop = h->d_zero; a.pout = h->P2[0]; a.stream = s;
         launch_spmv_args(h, a);
     }
-    hipLaunchKernelGGL(k_s_init2<true>, dim3(1), dim3(SC_BLOCK), 0, s, (const double *)h->P2[0], h->AT.grid,
+    hipLaunchKernelGGL(k_s_init2<true>, dim3(1), dim3(SC_BLOCK), 0, s, (const double *)h->P2[0], h->AT.out_grid,
                        (const double *)nullptr, st);
     hipLaunchKernelGGL(k_copy_scale, dim3(h->vgrid_n), dim3(VEC_BLOCK), 0, s, h->W, (const double *)h->V, (int64_t)n,
                        (const LsqrState *)st);

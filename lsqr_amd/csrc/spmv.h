@@ -103,9 +103,20 @@ __global__ void k_block_desc(const OffT *__restrict__ rowptr, const int *__restr
     blk[b] = d;
 }
 
+// Column panels (PANEL = true).  When x does not fit an XCD's 4 MB L2 and the columns are not
+// local (random / power-law matrices), every 8-byte gather of x pulls a whole sector from
+// beyond L2: measured 1.2 / 0.88 / 0.65 TB/s of algorithmic bytes at n = 1e6 / 2e6 / 1e7.
+// The build then stores the CSR of the PANEL-STACKED matrix [A_0; A_1; ...; A_{P-1}], A_p =
+// the columns of panel p (a slice of x of ~2.5 MB): virtual row v = p * rows + r.  The same
+// kernel sweeps the virtual rows; because the work list is panel-major and each XCD owns one
+// contiguous eighth of it (common.h), an XCD gathers from one x slice at a time and that
+// slice lives in its L2.  The kernel writes the per-panel row sums z[v]; k_panel_combine
+// then forms y_r <- cy (y_r sy) + sum_p z[p*rows + r] in fixed panel order (deterministic)
+// and produces the partials of sum(y^2).
+//
 // launch bound 8 waves/SIMD: the kernel must stay within 64 VGPRs (66 cost a whole
 // workgroup per CU: 18.9 us instead of 17.2 at config 2)
-template <typename OffT>
+template <typename OffT, bool PANEL>
 __global__ __launch_bounds__(SPMV_BLOCK, 8) void k_spmv_fused(
     const OffT *__restrict__ rowptr, const int *__restrict__ col, const double *__restrict__ val,
     const RowBlock *__restrict__ blk, int64_t nblk, const double *__restrict__ x, double *__restrict__ y,
@@ -202,7 +213,7 @@ __global__ __launch_bounds__(SPMV_BLOCK, 8) void k_spmv_fused(
         if (nr > 0) {
             q0 = rowptr[rclamp];
             q1 = rowptr[rclamp + 1];
-            y0 = y[rclamp];
+            if (!PANEL) y0 = y[rclamp];
         }
         // ---- gather x, stage products ---------------------------------------------------
         if (cnt > 0) {
@@ -245,15 +256,19 @@ __global__ __launch_bounds__(SPMV_BLOCK, 8) void k_spmv_fused(
                 for (int k = s0 + gl; k < s1; k += G) s = s + prod[k];
                 for (int off = G >> 1; off > 0; off >>= 1) s += __shfl_xor(s, off, WAVE);
                 if (gl == 0) {
-                    const double yn = cy * (y0 * sy) + s;
-                    y[r] = yn;
-                    sq += yn * yn;
+                    if (PANEL) {
+                        y[r] = s;  // z[v]: raw sum of this (panel, row) segment
+                    } else {
+                        const double yn = cy * (y0 * sy) + s;
+                        y[r] = yn;
+                        sq += yn * yn;
+                    }
                 }
                 r += ngroups;
                 if (r >= r1s) break;
                 q0 = rowptr[r];
                 q1 = rowptr[r + 1];
-                y0 = y[r];
+                if (!PANEL) y0 = y[r];
             }
         }
 
@@ -288,16 +303,62 @@ __global__ __launch_bounds__(SPMV_BLOCK, 8) void k_spmv_fused(
             const double tot = block_sum<SPMV_BLOCK>(s, red);
             if (tid == 0) {
                 const int r = r1 - 1;
-                const double yn = cy * (y[r] * sy) + tot;
-                y[r] = yn;
-                sq += yn * yn;
+                if (PANEL) {
+                    y[r] = tot;
+                } else {
+                    const double yn = cy * (y[r] * sy) + tot;
+                    y[r] = yn;
+                    sq += yn * yn;
+                }
             }
         }
         __syncthreads();  // prod[] is rewritten by the next row block
     }
 
+    if (!PANEL) {
+        const double tot = block_sum<SPMV_BLOCK>(sq, red);
+        if (tid == 0) partials[wg] = tot;
+    }
+}
+
+// y_r <- cy (y_r sy) + sum_{p < P} z[p*rows + r]   (fixed panel order); partials of sum(y^2).
+// Coefficients as in k_spmv_fused: explicit (coef) or lazy (pin/slot_in); only cy, sy are used.
+__global__ __launch_bounds__(SPMV_BLOCK) void k_panel_combine(
+    double *__restrict__ y, const double *__restrict__ z, int rows, int P,
+    const SpmvCoef *__restrict__ coef, const int *__restrict__ stop, double *__restrict__ partials,
+    const double *__restrict__ pin, int npin, const NormSlot *__restrict__ slot_in, int skip_if_zero)
+{
+    if (*stop != 0) return;
+    __shared__ double red[SPMV_BLOCK / WAVE + 1];
+    double sy, cy;
+    if (pin != nullptr) {
+        const double nrm = sqrt(block_sum_all<SPMV_BLOCK>(pin, npin, red));
+        if (skip_if_zero && !(nrm > 0.0)) return;
+        cy = -nrm;
+        sy = slot_in->scale;
+    } else {
+        if (coef->skip != 0) return;
+        sy = coef->sy;
+        cy = coef->cy;
+    }
+    double sq = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * SPMV_BLOCK;
+    for (int64_t r = (int64_t)blockIdx.x * SPMV_BLOCK + threadIdx.x; r < rows; r += stride) {
+        const double yold = y[r];
+        double s = 0.0;
+        int p = 0;
+        for (; p + 4 <= P; p += 4) {  // 4 independent loads in flight, added in panel order
+            const double v0 = z[(int64_t)p * rows + r], v1 = z[(int64_t)(p + 1) * rows + r];
+            const double v2 = z[(int64_t)(p + 2) * rows + r], v3 = z[(int64_t)(p + 3) * rows + r];
+            s = (((s + v0) + v1) + v2) + v3;
+        }
+        for (; p < P; ++p) s = s + z[(int64_t)p * rows + r];
+        const double yn = cy * (yold * sy) + s;
+        y[r] = yn;
+        sq += yn * yn;
+    }
     const double tot = block_sum<SPMV_BLOCK>(sq, red);
-    if (tid == 0) partials[wg] = tot;
+    if (threadIdx.x == 0) partials[blockIdx.x] = tot;
 }
 
 }  // namespace lsqrhip

@@ -1,0 +1,71 @@
+"""Column-panel SpMV layout (spmv.h "Column panels"): forced on at test scale with a small
+panel size, checked against the oracle for both aprod modes, a full solve, the sharded-stage
+form, and run-to-run determinism."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from lsqr_amd import problems as P
+from lsqr_amd.solver import lsqr_solver_ez
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def forced_panels():
+    old = {k: os.environ.get(k) for k in ("LSQRHIP_PANELS", "LSQRHIP_PANEL_KB")}
+    os.environ["LSQRHIP_PANELS"] = "1"
+    os.environ["LSQRHIP_PANEL_KB"] = "64"      # 8192 columns per panel
+    yield
+    for k, v in old.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
+
+
+@pytest.mark.parametrize("shape", [(30000, 40000, 6), (50000, 20000, 9), (20000, 60000, 30)])
+def test_panelled_aprod_and_solve_match_oracle(forced_panels, shape):
+    m, n, per = shape
+    p = P.random_rows(m, n, per, seed=5, damp=1e-3)
+    # 12 iterations: panel mode changes the order of the row sums (per-panel segments), and LSQR
+    # amplifies such ulp-level differences with the iteration count -- the
+    # reference drifts the same way under a permutation of its COO input
+    s = lsqr_solver_ez().initialize(p.m, p.n, p.a, p.irow, p.icol, itnlim=12)
+    po = oracle.port()
+    xp = P.u64_to_unit(P.rng_u64(101, 9, np.arange(p.n, dtype=np.uint64)))
+    yp = P.u64_to_unit(P.rng_u64(102, 9, np.arange(p.m, dtype=np.uint64)))
+    x, y = xp.copy(), yp.copy()
+    s.aprod(1, p.m, p.n, x, y)
+    _, y_ref = po.aprod(1, p.m, p.n, p.irow, p.icol, p.a, xp, yp)
+    assert np.max(np.abs(y - y_ref)) <= 1e-13 * max(np.max(np.abs(y_ref)), 1.0)
+    x, y = xp.copy(), yp.copy()
+    s.aprod(2, p.m, p.n, x, y)
+    x_ref, _ = po.aprod(2, p.m, p.n, p.irow, p.icol, p.a, xp, yp)
+    assert np.max(np.abs(x - x_ref)) <= 1e-13 * max(np.max(np.abs(x_ref)), 1.0)
+    r = s.solve(p.b, 1e-3)
+    o = po.solve(p.m, p.n, p.irow, p.icol, p.a, p.b, damp=1e-3, itnlim=12)
+    assert (r.istop, r.itn) == (o.istop, o.itn)
+    assert np.linalg.norm(r.x - o.x) <= 1e-10 * np.linalg.norm(o.x)
+    assert abs(r.anorm - o.anorm) <= 1e-10 * o.anorm and abs(r.rnorm - o.rnorm) <= 1e-10 * o.rnorm
+    r2 = s.solve(p.b, 1e-3)
+    assert np.array_equal(r.x, r2.x) and r.anorm == r2.anorm          # deterministic
+    s.set_option("pipeline", 0)
+    r3 = s.solve(p.b, 1e-3)
+    assert np.array_equal(r.x, r3.x) and r.anorm == r3.anorm          # both schedules, same bits
+
+
+def test_panels_are_not_used_for_banded_matrices():
+    """Auto mode keeps the plain CSR for a banded system even when x exceeds L2: the aprod
+    result stays bit-identical to the reference's row sums (only the plain path is)."""
+    for k in ("LSQRHIP_PANELS", "LSQRHIP_PANEL_KB"):
+        os.environ.pop(k, None)
+    p = P.poisson2d(1200, 1000)        # n = 1.2e6: 9.6 MB of x
+    s = lsqr_solver_ez().initialize(p.m, p.n, p.a, p.irow, p.icol)
+    xp = P.u64_to_unit(P.rng_u64(101, 9, np.arange(p.n, dtype=np.uint64)))
+    y = np.zeros(p.m)
+    s.aprod(1, p.m, p.n, xp, y)
+    _, y_ref = oracle.port().aprod(1, p.m, p.n, p.irow, p.icol, p.a, xp, np.zeros(p.m))
+    assert np.array_equal(y, y_ref)
