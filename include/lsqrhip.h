@@ -123,7 +123,8 @@ int lsqrhip_xcheck(lsqrhip_handle_t h, double anorm, double damp, double eps, co
 /* ---------------------------------------------------------------------- */
 /* iteration log (nout /= 0)         replaces src/lsqr.f90:813-837          */
 /* ---------------------------------------------------------------------- */
-/* One record per iteration, LSQRHIP_LOG_STRIDE doubles: itn, x(1), rnorm,
+/* One record per PRINTED iteration (the device applies the reference's selective print rule,
+ * :815-822, so the buffer stays small for huge itnlim), LSQRHIP_LOG_STRIDE doubles: itn, x(1), rnorm,
  * test1, test2, anorm, acond, phi, dknorm, dxk, alfa_opt, istop (as decided in
  * that iteration before the nconv rule), rtol, xnorm.  Host code applies the
  * reference's print rule (:815-822) and format strings to them. */

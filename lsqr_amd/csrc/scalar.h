@@ -257,8 +257,14 @@ __device__ __forceinline__ void s3_step(LsqrState *st, double sum, const double 
     if (test2 <= st->atol) istop = 2;
     if (test1 <= rtol) istop = 1;
 
-    if (st->want_log && itn <= st->log_cap) {
-        double *r = log + (size_t)(itn - 1) * LOG_STRIDE;
+    // Keep a record only for the iterations the reference prints (src/lsqr.f90:815-822), so the
+    // buffer stays small even for itnlim = 4(m+n+50).
+    const bool show = (st->n <= 40) || (itn <= 10) || (itn >= st->itnlim - 10) || (itn % 10 == 0) ||
+                      (test3 <= 2.0 * st->ctol) || (test2 <= 10.0 * st->atol) || (test1 <= 10.0 * rtol) ||
+                      (istop != 0);
+    if (st->want_log && show && st->log_count < st->log_cap) {
+        double *r = log + (size_t)st->log_count * LOG_STRIDE;
+        st->log_count = st->log_count + 1;
         r[0] = (double)itn; r[1] = x[0]; r[2] = rnorm; r[3] = test1; r[4] = test2; r[5] = anorm;
         r[6] = acond; r[7] = phi; r[8] = dknorm; r[9] = dxk; r[10] = alfopt; r[11] = (double)istop;
         r[12] = rtol; r[13] = xnorm;

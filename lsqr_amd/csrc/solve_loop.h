@@ -231,7 +231,10 @@ static int solve_core(H *h, const double *b, bool b_on_device, double damp, doub
     LsqrState *st = h->d_state;
 
     if (want_log) {
-        const int cap = std::max(itnlim, 1);
+        // printable iterations: the first/last 10, every 10th, near convergence -- or all of
+        // them when n <= 40 (src/lsqr.f90:815-822); bounded at 2^20 records (112 MB)
+        const int64_t want = (n <= 40) ? (int64_t)itnlim : (int64_t)itnlim / 10 + 64;
+        const int cap = (int)std::min<int64_t>(std::max<int64_t>(want, 64), 1 << 20);
         if (cap > h->log_cap) {
             if (h->d_log) (void)hipFree(h->d_log);
             h->d_log = nullptr;
@@ -352,7 +355,7 @@ static int solve_core(H *h, const double *b, bool b_on_device, double damp, doub
     if (wantse && n > 0) HIPCHK(hipMemcpyAsync(se, h->SE, sizeof(double) * (size_t)n, out_kind, s));
     const LsqrState &r = *h->h_state;
     if (want_log && r.itn > 0) {
-        h->log_count = std::min(r.itn, h->log_cap);
+        h->log_count = std::min(r.log_count, h->log_cap);
         h->h_log.resize((size_t)h->log_count * LOG_STRIDE);
         HIPCHK(hipMemcpyAsync(h->h_log.data(), h->d_log, sizeof(double) * h->h_log.size(), hipMemcpyDeviceToHost, s));
     }

@@ -35,7 +35,8 @@ struct LsqrState {
     int damped;
     int wantse;
     int want_log;
-    int log_cap;
+    int log_cap;    // records the log buffer can hold
+    int log_count;  // records written so far (only iterations the reference would print)
     int m, n;
     // user tolerances ------------------------------------------------------
     double damp, atol, btol, ctol;
