@@ -101,3 +101,43 @@ def test_ez_driver_on_gpu_matches_oracle():
     assert abs(nrm[2] - o.xnorm) <= 1e-10 * o.xnorm
     want = np.array([o.x[0], o.x[prob.n // 2 - 1], o.x[-1]])
     assert np.max(np.abs(xs - want)) <= 1e-10 * np.linalg.norm(o.x, np.inf)
+
+
+REF_MESSAGES = {   # the reference's `error stop` strings, src/lsqr.f90:109-111, 152, 197
+    "sizes": "invalid a,icol,irow sizes in initialize_ez",
+    "irow": "invalid irow or m in initialize_ez",
+    "icol": "invalid icol or n in initialize_ez",
+    "notinit": "lsqr_solver_ez class not properly initialized",
+    "dims": "lsqr_solver_ez class not properly initialized",
+    "mode": "invalid mode in aprod_ez",
+}
+
+
+def run_err(which):
+    path = os.path.join(LIB, "test_errors")
+    assert os.path.exists(path), f"{path} missing: run __graft_entry__.build()"
+    return subprocess.run([path, which], capture_output=True, text=True, timeout=120)
+
+
+@pytest.mark.parametrize("which", ["sizes", "notinit"])
+def test_fortran_error_stops_that_need_no_device(which):
+    """Checked before any device work, exactly like the reference checks them first."""
+    p = run_err(which)
+    assert p.returncode != 0
+    assert REF_MESSAGES[which] in (p.stdout + p.stderr)
+    assert "NO ERROR RAISED" not in p.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", ["irow", "icol", "dims", "mode"])
+def test_fortran_error_stops_on_gpu(which):
+    p = run_err(which)
+    assert p.returncode != 0
+    assert REF_MESSAGES[which] in (p.stdout + p.stderr)
+    assert "NO ERROR RAISED" not in p.stdout
+
+
+@pytest.mark.gpu
+def test_fortran_error_driver_ok_case():
+    p = run_err("ok")
+    assert p.returncode == 0 and "OK istop= 1" in p.stdout
