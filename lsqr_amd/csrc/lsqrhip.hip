@@ -118,7 +118,9 @@ static int use_device()
 // ---------------------------------------------------------------------------
 struct Csr {
     void *rowptr = nullptr;  // int32 or int64 [rows+1]
-    int *col = nullptr;
+    int *col = nullptr;              // 32-bit column indices (freed when col16 is in use)
+    unsigned short *col16 = nullptr;  // 16-bit block-relative column indices (spmv.h C16) ...
+    int *cbase = nullptr;            // ... and each row block's smallest column
     double *val = nullptr;
     int *rb = nullptr;  // row-block boundaries [nblk+1]
     RowBlock *blk = nullptr;  // one descriptor per row block (spmv.h)
@@ -192,6 +194,8 @@ static void free_csr(Csr &c)
 {
     if (c.rowptr) (void)hipFree(c.rowptr);
     if (c.col) (void)hipFree(c.col);
+    if (c.col16) (void)hipFree(c.col16);
+    if (c.cbase) (void)hipFree(c.cbase);
     if (c.val) (void)hipFree(c.val);
     if (c.rb) (void)hipFree(c.rb);
     if (c.blk) (void)hipFree(c.blk);
@@ -315,6 +319,31 @@ static int build_csr_T(hipStream_t s, const int *d_keys, const int *d_other, con
     hipLaunchKernelGGL(k_block_desc<OffT>, dim3((unsigned)((out.nblk + 255) / 256)), dim3(256), 0, s,
                        (const OffT *)out.rowptr, (const int *)out.rb, out.nblk, out.blk);
     HIPCHK(hipGetLastError());
+    // 16-bit block-relative columns when every row block is narrower than 65536 columns
+    // (LSQRHIP_COL16=0 keeps 32-bit indices)
+    if (out.P <= 1 && nnz > 0 && env_int("LSQRHIP_COL16", 1) != 0) {
+        HIPCHK(hipMalloc((void **)&out.cbase, sizeof(int) * (size_t)out.nblk));
+        HIPCHK(hipMemsetAsync(d_flags, 0, sizeof(int), s));
+        const unsigned gb = (unsigned)std::min<int64_t>(out.nblk, 65535);
+        hipLaunchKernelGGL(k_block_colspan, dim3(gb), dim3(256), 0, s, (const RowBlock *)out.blk, out.nblk,
+                           (const int *)out.col, out.cbase, d_flags);
+        int wide = 0;
+        HIPCHK(hipMemcpyAsync(&wide, d_flags, sizeof(int), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        if (!wide) {
+            HIPCHK(hipMalloc((void **)&out.col16, sizeof(unsigned short) * (size_t)nnz));
+            hipLaunchKernelGGL(k_col_to16, dim3(gb), dim3(256), 0, s, (const RowBlock *)out.blk, out.nblk,
+                               (const int *)out.col, (const int *)out.cbase, out.col16);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipStreamSynchronize(s));
+            (void)hipFree(out.col);
+            out.col = nullptr;
+            out.bytes += (int64_t)sizeof(int) * out.nblk - 2 * nnz;
+        } else {
+            (void)hipFree(out.cbase);
+            out.cbase = nullptr;
+        }
+    }
     int64_t grid = std::min<int64_t>(out.nblk, SPMV_MAX_GRID);
     if (grid >= 8) grid &= ~(int64_t)7;  // multiple of 8: XCD-aware mapping (common.h)
     out.grid = (int)std::max<int64_t>(grid, 1);

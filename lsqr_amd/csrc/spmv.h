@@ -84,6 +84,54 @@ struct alignas(32) RowBlock {
     int r0, r1;       // rows [r0, r1)
 };
 
+// Column span of every row block: cbase[b] = smallest column; *too_wide |= 1 if a block spans
+// 65536 columns or more.  One workgroup per row block.
+__global__ __launch_bounds__(256) void k_block_colspan(const RowBlock *__restrict__ blk, int64_t nblk,
+                                                       const int *__restrict__ col, int *__restrict__ cbase,
+                                                       int *__restrict__ too_wide)
+{
+    __shared__ int smin[256], smax[256];
+    for (int64_t b = blockIdx.x; b < nblk; b += gridDim.x) {
+        const RowBlock d = blk[b];
+        int lo = 0x7fffffff, hi = -1;
+        if (d.r0 < d.r1)
+            for (long long k = d.p0 + threadIdx.x; k < d.pend; k += 256) {
+                const int c = col[k];
+                lo = c < lo ? c : lo;
+                hi = c > hi ? c : hi;
+            }
+        smin[threadIdx.x] = lo;
+        smax[threadIdx.x] = hi;
+        __syncthreads();
+        for (int off = 128; off > 0; off >>= 1) {
+            if ((int)threadIdx.x < off) {
+                smin[threadIdx.x] = min(smin[threadIdx.x], smin[threadIdx.x + off]);
+                smax[threadIdx.x] = max(smax[threadIdx.x], smax[threadIdx.x + off]);
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            const int mn = smax[0] >= 0 ? smin[0] : 0;
+            cbase[b] = mn;
+            if (smax[0] >= 0 && smax[0] - mn >= 65536) atomicOr(too_wide, 1);
+        }
+        __syncthreads();
+    }
+}
+
+// col16[k] = col[k] - cbase[block of k]
+__global__ __launch_bounds__(256) void k_col_to16(const RowBlock *__restrict__ blk, int64_t nblk,
+                                                  const int *__restrict__ col, const int *__restrict__ cbase,
+                                                  unsigned short *__restrict__ col16)
+{
+    for (int64_t b = blockIdx.x; b < nblk; b += gridDim.x) {
+        const RowBlock d = blk[b];
+        if (d.r0 >= d.r1) continue;
+        const int cb = cbase[b];
+        for (long long k = d.p0 + threadIdx.x; k < d.pend; k += 256) col16[k] = (unsigned short)(col[k] - cb);
+    }
+}
+
 template <typename OffT>
 __global__ void k_block_desc(const OffT *__restrict__ rowptr, const int *__restrict__ rb, int64_t nblk,
                              RowBlock *__restrict__ blk)
@@ -116,10 +164,14 @@ __global__ void k_block_desc(const OffT *__restrict__ rowptr, const int *__restr
 //
 // launch bound 8 waves/SIMD: the kernel must stay within 64 VGPRs (66 cost a whole
 // workgroup per CU: 18.9 us instead of 17.2 at config 2)
-template <typename OffT, bool PANEL>
+//
+// C16 = true: 16-bit column indices relative to the row block's smallest column (cbase[b]).
+// Chosen at build time when EVERY row block spans fewer than 65536 columns (banded / local
+// matrices): 2 instead of 4 bytes per nonzero on a kernel that is bound by bytes.
+template <typename OffT, bool PANEL, bool C16>
 __global__ __launch_bounds__(SPMV_BLOCK, 8) void k_spmv_fused(
-    const OffT *__restrict__ rowptr, const int *__restrict__ col, const double *__restrict__ val,
-    const RowBlock *__restrict__ blk, int64_t nblk, const double *__restrict__ x, double *__restrict__ y,
+    const OffT *__restrict__ rowptr, const void *__restrict__ colv, const int *__restrict__ cbase,
+    const double *__restrict__ val, const RowBlock *__restrict__ blk, int64_t nblk, const double *__restrict__ x, double *__restrict__ y,
     const SpmvCoef *__restrict__ coef, const int *__restrict__ stop, double *__restrict__ partials,
     const double *__restrict__ pin, int npin, const NormSlot *__restrict__ slot_in,
     NormSlot *__restrict__ slot_out, int skip_if_zero, Rider rider)
@@ -138,6 +190,8 @@ __global__ __launch_bounds__(SPMV_BLOCK, 8) void k_spmv_fused(
     }
     if (*stop != 0) return;
     const int tid = threadIdx.x;
+    const int *__restrict__ col = static_cast<const int *>(colv);
+    const unsigned short *__restrict__ col16 = static_cast<const unsigned short *>(colv);
 
     double sx, sy, cy;
     if (pin != nullptr) {  // lazy coefficients (uniform branch)
@@ -164,10 +218,18 @@ __global__ __launch_bounds__(SPMV_BLOCK, 8) void k_spmv_fused(
     const XcdRange xr = xcd_range(nblk, nwg, wg);
     int64_t b = xr.first;
     RowBlock d;
-    if (b < xr.end) d = blk[b];
+    int cbn = 0;
+    if (b < xr.end) {
+        d = blk[b];
+        if (C16) cbn = cbase[b];
+    }
     for (; b < xr.end; b += xr.stride) {
         const RowBlock cur = d;
-        if (b + xr.stride < xr.end) d = blk[b + xr.stride];  // prefetch (uniform index)
+        const int cb = cbn;
+        if (b + xr.stride < xr.end) {  // prefetch (uniform index)
+            d = blk[b + xr.stride];
+            if (C16) cbn = cbase[b + xr.stride];
+        }
         const int r0 = cur.r0, r1 = cur.r1;
         if (r0 >= r1) continue;  // uniform
         const OffT p0 = (OffT)cur.p0, plast = (OffT)cur.plast, pend = (OffT)cur.pend;
@@ -201,7 +263,7 @@ __global__ __launch_bounds__(SPMV_BLOCK, 8) void k_spmv_fused(
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 a[j] = val[p0 + kk[j]];
-                c[j] = col[p0 + kk[j]];
+                c[j] = C16 ? cb + (int)col16[p0 + kk[j]] : col[p0 + kk[j]];
             }
         }
         // ---- early loads for phase 2: this lane's first row ---------------------------
@@ -234,7 +296,7 @@ __global__ __launch_bounds__(SPMV_BLOCK, 8) void k_spmv_fused(
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     a[j] = val[p0 + kk[j]];
-                    c[j] = col[p0 + kk[j]];
+                    c[j] = C16 ? cb + (int)col16[p0 + kk[j]] : col[p0 + kk[j]];
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) xv[j] = x[c[j]];
@@ -289,7 +351,7 @@ __global__ __launch_bounds__(SPMV_BLOCK, 8) void k_spmv_fused(
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     al[j] = val[plast + kl[j]];
-                    cl[j] = col[plast + kl[j]];
+                    cl[j] = C16 ? cb + (int)col16[plast + kl[j]] : col[plast + kl[j]];
                 }
                 double xl[4];
 #pragma unroll

@@ -69,3 +69,34 @@ def test_panels_are_not_used_for_banded_matrices():
     s.aprod(1, p.m, p.n, xp, y)
     _, y_ref = oracle.port().aprod(1, p.m, p.n, p.irow, p.icol, p.a, xp, np.zeros(p.m))
     assert np.array_equal(y, y_ref)
+
+
+def test_wide_rows_keep_32bit_columns_and_match_oracle():
+    """Row blocks spanning >= 65536 columns cannot use the 16-bit block-relative column
+    indices (spmv.h C16): the 32-bit plain-CSR path must give the same answers."""
+    for k in ("LSQRHIP_PANELS", "LSQRHIP_PANEL_KB", "LSQRHIP_COL16"):
+        os.environ.pop(k, None)
+    p = P.random_rows(3000, 200000, 12, seed=9, damp=1e-3)
+    s = lsqr_solver_ez().initialize(p.m, p.n, p.a, p.irow, p.icol, itnlim=15)
+    po = oracle.port()
+    xp = P.u64_to_unit(P.rng_u64(101, 9, np.arange(p.n, dtype=np.uint64)))
+    y = np.zeros(p.m)
+    s.aprod(1, p.m, p.n, xp, y)
+    _, y_ref = po.aprod(1, p.m, p.n, p.irow, p.icol, p.a, xp, np.zeros(p.m))
+    assert np.array_equal(y, y_ref)             # plain path: bit-identical row sums
+    r = s.solve(p.b, 1e-3)
+    o = po.solve(p.m, p.n, p.irow, p.icol, p.a, p.b, damp=1e-3, itnlim=15)
+    assert (r.istop, r.itn) == (o.istop, o.itn)
+    assert np.linalg.norm(r.x - o.x) <= 1e-10 * np.linalg.norm(o.x)
+
+
+def test_col16_and_col32_paths_agree_bitwise():
+    p = P.poisson2d(300, 200)
+    res = []
+    for flag in ("1", "0"):
+        os.environ["LSQRHIP_COL16"] = flag
+        s = lsqr_solver_ez().initialize(p.m, p.n, p.a, p.irow, p.icol, itnlim=40)
+        r = s.solve(p.b, 0.0)
+        res.append((r.x.copy(), r.anorm, r.rnorm, r.itn))
+    os.environ.pop("LSQRHIP_COL16", None)
+    assert np.array_equal(res[0][0], res[1][0]) and res[0][1:] == res[1][1:]
