@@ -93,8 +93,9 @@ def run_single(args):
             name, m, n, nnz, damp = spec, dp.m, dp.n, dp.nnz, dp.damp
         p = _P
     d_x = capi.DeviceBuffer(8 * max(p.n, 1))
-    # graph batches that divide K exactly: no predicated-off tail iterations in the timed solve
-    gi = next(g for g in (50, 40, 32, 20, 16, 10, 8, 4, 2, 1) if K % g == 0)
+    # graph batch: a divisor of K when there is a good one (no predicated-off tail iterations in
+    # the timed solve), else up to 50 iterations (launches past the stop are ~us-scale no-ops)
+    gi = next((g for g in (50, 40, 32, 26, 20, 16) if K % g == 0), min(50, K + (K & 1)))
     s.set_option("graph_iters", gi)
 
     if W > 0:

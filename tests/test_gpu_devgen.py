@@ -42,3 +42,33 @@ def test_solve_on_device_generated_system_matches_oracle():
     assert (r.istop, r.itn) == (o.istop, o.itn)
     assert np.linalg.norm(x - o.x) <= 1e-10 * np.linalg.norm(o.x)
     assert abs(r.anorm - o.anorm) <= 1e-10 * o.anorm and abs(r.rnorm - o.rnorm) <= 1e-10 * o.rnorm
+
+
+def test_scale_properties_on_100M_nonzero_random_system():
+    """config 3 shape at 1e8 nonzeros (4M x 1M, 25 per row, generated in HBM; column panels
+    are chosen automatically).  No CPU oracle fits this size in test time, so the checks are
+    the size-independent ones: the reference's own acheck (mode 1 vs mode 2 consistency) and
+    xcheck (does x solve the damped problem?) on the device operator, linearity, determinism."""
+    from lsqr_amd.capi import DeviceBuffer
+    spec = "random:4000000:1000000:25"
+    dp = devgen.generate(spec, atol=1e-10, btol=1e-10, itnlim=400)
+    s = dp.solver
+    assert dp.nnz == 100_000_000
+    inform, err = s.acheck()
+    assert inform == 0 and err < 1e-12
+    d_x = DeviceBuffer(8 * dp.n)
+    r = s.solve_device(dp.d_b.ptr.value, d_x.ptr.value, 1e-3)
+    x = d_x.to_array(np.float64, dp.n)
+    b = dp.d_b.to_array(np.float64, dp.m)
+    assert r.istop == 3 and 10 < r.itn < 400               # damped least squares, converged on atol
+    inform, tests, u, v, w = s.xcheck(r.anorm, 1e-3, b, x)
+    assert inform in (1, 2, 3) and tests[2] < 1e-7          # A'r - damp^2 x ~ 0
+    r2 = s.solve_device(dp.d_b.ptr.value, d_x.ptr.value, 1e-3)
+    assert (r2.itn, r2.anorm, r2.rnorm) == (r.itn, r.anorm, r.rnorm)
+    assert np.array_equal(d_x.to_array(np.float64, dp.n), x)
+    # linearity of aprod on the panelled operator
+    xa = P.u64_to_unit(P.rng_u64(1, 9, np.arange(dp.n, dtype=np.uint64)))
+    ya, y2 = np.zeros(dp.m), np.zeros(dp.m)
+    s.aprod(1, dp.m, dp.n, xa, ya)
+    s.aprod(1, dp.m, dp.n, 3.0 * xa, y2)
+    assert np.max(np.abs(y2 - 3.0 * ya)) <= 1e-13 * np.max(np.abs(y2))

@@ -297,14 +297,14 @@ def test_iteration_log_text_matches_reference(name, tmp_path):
 
 
 def test_full_size_config2_poisson_vs_oracle():
-    """BASELINE.json configs[1]: 1M x 1M 5-point Poisson, damp = 0.  50 iterations against the
-    CPU checker (~2 s), plus the size-independent checks acheck / xcheck / linearity."""
+    """BASELINE.json configs[1]: 1M x 1M 5-point Poisson, damp = 0.  200 iterations against the
+    CPU checker (~3 s), plus the size-independent checks acheck / linearity."""
     p = P.poisson2d(1000, 1000)
     assert p.nnz == 4_996_000
-    s = lsqr_solver_ez().initialize(p.m, p.n, p.a, p.irow, p.icol, itnlim=50)
+    s = lsqr_solver_ez().initialize(p.m, p.n, p.a, p.irow, p.icol, itnlim=200)
     r = s.solve(p.b, 0.0)
-    o = oracle.port().solve(p.m, p.n, p.irow, p.icol, p.a, p.b, itnlim=50)
-    assert (r.istop, r.itn) == (o.istop, o.itn) == (5, 50)
+    o = oracle.port().solve(p.m, p.n, p.irow, p.icol, p.a, p.b, itnlim=200)
+    assert (r.istop, r.itn) == (o.istop, o.itn) == (5, 200)
     assert np.linalg.norm(r.x - o.x) <= TOL * np.linalg.norm(o.x)
     assert rel(r.anorm, o.anorm) <= TOL and rel(r.rnorm, o.rnorm) <= TOL
     inform, err = s.acheck()
