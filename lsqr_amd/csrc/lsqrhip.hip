@@ -598,9 +598,36 @@ extern "C" int lsqrhip_dnrm2(lsqrhip_handle_t h, int64_t n, const double *d_x, d
 {
     if (!h || !result) return fail(LSQRHIP_ERR_NOT_INIT, lsqrhip_error_string(LSQRHIP_ERR_NOT_INIT));
     HIPCHK(hipSetDevice(h->device));
+    // Stand-alone dnrm2 (src/lsqrblas.f90:123-159 is a scaled sum of squares): two passes, the
+    // largest magnitude and then the sum of (x * 2^-e)^2 with 2^e ~ max|x|, so that neither
+    // x^2 overflow nor underflow is possible -- same range as the reference's dlassq form.
+    // (Inside the iteration the norms are fused, unscaled sums: u, v are renormalised every step.)
+    *result = 0.0;
+    if (n < 1) return LSQRHIP_OK;
+    const int g = vec_grid(2 * n);
+    std::vector<double> part((size_t)g);
+    hipLaunchKernelGGL(k_amax, dim3(g), dim3(VEC_BLOCK), 0, h->stream, d_x, n, h->partials);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(part.data(), h->partials, sizeof(double) * (size_t)g, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    double amax = 0.0;
+    for (double v : part) amax = std::max(amax, v);      // NaN-free inputs assumed, like the reference
+    if (!(amax > 0.0)) return LSQRHIP_OK;
+    if (std::isinf(amax)) {
+        *result = amax;
+        return LSQRHIP_OK;
+    }
+    int e = 0;
+    (void)std::frexp(amax, &e);                           // amax = f * 2^e, f in [0.5, 1)
+    const double sc = std::ldexp(1.0, -e);
+    hipLaunchKernelGGL(k_sumsq_scaled, dim3(g), dim3(VEC_BLOCK), 0, h->stream, d_x, n, sc, h->partials);
+    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(VEC_BLOCK), 0, h->stream, (const double *)h->partials, g,
+                       h->d_scalar);
+    HIPCHK(hipGetLastError());
     double ss = 0.0;
-    RET(dev_dot(h, n, d_x, d_x, &ss));
-    *result = std::sqrt(ss);
+    HIPCHK(hipMemcpyAsync(&ss, h->d_scalar, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    *result = std::ldexp(std::sqrt(ss), e);
     return LSQRHIP_OK;
 }
 

@@ -161,6 +161,38 @@ __global__ __launch_bounds__(VEC_BLOCK) void k_se_finish(double *__restrict__ se
         se[i] = t * sqrt(se[i]);
 }
 
+// partials[b] = max |x[i]| over this workgroup's share (first pass of the scaled norm)
+__global__ __launch_bounds__(VEC_BLOCK) void k_amax(const double *__restrict__ x, int64_t n,
+                                                    double *__restrict__ partials)
+{
+    __shared__ double red[VEC_BLOCK];
+    double m = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * VEC_BLOCK;
+    for (int64_t i = (int64_t)blockIdx.x * VEC_BLOCK + threadIdx.x; i < n; i += stride) m = fmax(m, fabs(x[i]));
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int off = VEC_BLOCK / 2; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + off]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partials[blockIdx.x] = red[0];
+}
+
+// partials[b] = sum over this workgroup's share of (x[i] * sc)^2   (sc a power of two: exact)
+__global__ __launch_bounds__(VEC_BLOCK) void k_sumsq_scaled(const double *__restrict__ x, int64_t n, double sc,
+                                                            double *__restrict__ partials)
+{
+    __shared__ double red[VEC_BLOCK / WAVE];
+    double s = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * VEC_BLOCK;
+    for (int64_t i = (int64_t)blockIdx.x * VEC_BLOCK + threadIdx.x; i < n; i += stride) {
+        const double t = x[i] * sc;
+        s += t * t;
+    }
+    const double tot = block_sum<VEC_BLOCK>(s, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = tot;
+}
+
 // out[0] = sum of partials[0..np) in fixed order (one workgroup).
 __global__ __launch_bounds__(VEC_BLOCK) void k_reduce_partials(const double *__restrict__ partials,
                                                                int np, double *__restrict__ out)
