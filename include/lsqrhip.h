@@ -209,6 +209,12 @@ int lsqrhip_shard_begin(lsqrhip_handle_t h, const double *d_b_local, int64_t m_g
                         double atol, double btol, double conlim, int itnlim, int wantse, double *d_T,
                         double *d_sums);
 int lsqrhip_shard_stage(lsqrhip_handle_t h, int stage);
+/* d_out[0..chunk) = sum_{r < nchunks} d_in[r*chunk + i], in rank order (asynchronous on the
+ * handle's stream): the local step of a DIRECT reduce-scatter -- every rank sends slice j of its
+ * partial n-vector to rank j over all xGMI links at once (all-to-all), sums what it received in
+ * a fixed order, and the reduced slices are all-gathered.  xGMI is point-to-point, so this
+ * shape is not per-link bound the way a ring all-reduce of the same 8n bytes is. */
+int lsqrhip_sum_chunks(lsqrhip_handle_t h, const double *d_in, int nchunks, int64_t chunk, double *d_out);
 /* out[0..2] = stop, itn, istop (synchronises the handle's stream). */
 int lsqrhip_shard_poll(lsqrhip_handle_t h, int *out);
 int lsqrhip_shard_end(lsqrhip_handle_t h, double *d_x, double *d_se, int *istop, int *itn, double *anorm,

@@ -29,7 +29,7 @@ EXPORTS = [
     "lsqrhip_log_extras", "lsqrhip_dnrm2", "lsqrhip_ddot", "lsqrhip_dscal", "lsqrhip_dcopy",
     "lsqrhip_last_timing", "lsqrhip_bench_kernel", "lsqrhip_set_option", "lsqrhip_set_stream", "lsqrhip_dev_alloc",
     "lsqrhip_dev_free", "lsqrhip_dev_upload", "lsqrhip_dev_download", "lsqrhip_dev_sync",
-    "lsqrhip_shard_begin", "lsqrhip_shard_stage", "lsqrhip_shard_poll", "lsqrhip_shard_end",
+    "lsqrhip_shard_begin", "lsqrhip_shard_stage", "lsqrhip_shard_poll", "lsqrhip_shard_end", "lsqrhip_sum_chunks",
     "lsqrhip_gen_count", "lsqrhip_gen_coo",
 ]
 
@@ -97,6 +97,7 @@ def lib() -> C.CDLL:
     L.lsqrhip_dev_download.argtypes = [vp, vp, i64]
     L.lsqrhip_shard_begin.argtypes = [vp, vp, i64, f64, f64, f64, f64, i32, i32, vp, vp]
     L.lsqrhip_shard_stage.argtypes = [vp, i32]
+    L.lsqrhip_sum_chunks.argtypes = [vp, vp, i32, i64, vp]
     L.lsqrhip_shard_poll.argtypes = [vp, vp]
     L.lsqrhip_shard_end.argtypes = [vp, vp, vp] + [vp] * 7
     L.lsqrhip_gen_count.restype = i64

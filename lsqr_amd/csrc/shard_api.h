@@ -34,6 +34,19 @@ __global__ __launch_bounds__(VEC_BLOCK) void k_vcombine(double *__restrict__ V, 
     if (threadIdx.x == 0) partials[blockIdx.x] = tot;
 }
 
+// out[i] = in[0*chunk + i] + in[1*chunk + i] + ... in rank order (the local sum of a direct
+// reduce-scatter: every element is summed once, by its owner, in a fixed order)
+__global__ __launch_bounds__(VEC_BLOCK) void k_sum_chunks(double *__restrict__ out, const double *__restrict__ in,
+                                                          int nchunks, int64_t chunk)
+{
+    const int64_t stride = (int64_t)gridDim.x * VEC_BLOCK;
+    for (int64_t i = (int64_t)blockIdx.x * VEC_BLOCK + threadIdx.x; i < chunk; i += stride) {
+        double s = in[i];
+        for (int r = 1; r < nchunks; ++r) s = s + in[(int64_t)r * chunk + i];
+        out[i] = s;
+    }
+}
+
 }  // namespace lsqrhip
 
 // stage ids (keep in sync with lsqr_amd/dist.py)
@@ -131,6 +144,19 @@ extern "C" int lsqrhip_shard_stage(lsqrhip_handle_t h, int stage)
     default:
         return fail(LSQRHIP_ERR_ARG, "unknown shard stage");
     }
+    HIPCHK(hipGetLastError());
+    return LSQRHIP_OK;
+}
+
+// d_out[0..chunk) = sum over r < nchunks of d_in[r*chunk .. (r+1)*chunk), in rank order; asynchronous
+// on the handle's stream.  The local step of the direct reduce-scatter in lsqr_amd/dist.py.
+extern "C" int lsqrhip_sum_chunks(lsqrhip_handle_t h, const double *d_in, int nchunks, int64_t chunk, double *d_out)
+{
+    if (!h || !d_in || !d_out || nchunks < 1 || chunk < 0) return fail(LSQRHIP_ERR_ARG, "bad sum_chunks arguments");
+    HIPCHK(hipSetDevice(h->device));
+    if (chunk > 0)
+        hipLaunchKernelGGL(k_sum_chunks, dim3(vec_grid(2 * chunk)), dim3(VEC_BLOCK), 0, h->stream, d_out, d_in, nchunks,
+                           chunk);
     HIPCHK(hipGetLastError());
     return LSQRHIP_OK;
 }

@@ -76,14 +76,29 @@ class ShardResult:
 
 
 class TorchComm:
-    """Sum all-reduce of float64 tensors + an agreement check, over torch.distributed."""
+    """The two exchanges of the sharded iteration + an agreement check, over torch.distributed.
 
-    def __init__(self, group=None):
+    The n-vector sum has two shapes:
+      * "direct" (default): reduce-scatter as an all-to-all of n/P slices (all 7 xGMI links of a
+        GPU carry one slice each, at once), a local sum of the P received slices in RANK ORDER
+        (`sum_chunks`: deterministic, every element is summed once by its owner), then an
+        all-gather of the reduced slices.  xGMI is point-to-point: a ring all-reduce of the same
+        8n bytes is per-link bound.
+      * "ring": one `all_reduce` (RCCL's choice of algorithm) -- LSQR_DIST_ALLREDUCE=ring.
+    With gloo (CPU tests, no all-to-all) the direct shape is emulated by an all-gather of the
+    whole vector and the same rank-ordered sum, so results are bit-identical to the RCCL path.
+    """
+
+    def __init__(self, group=None, vector_sum: str | None = None):
+        import os
         import torch.distributed as dist
         self.dist = dist
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
+        self.backend = dist.get_backend(group)
+        self.vector_sum = vector_sum or os.environ.get("LSQR_DIST_ALLREDUCE", "direct")
+        self._scratch = {}
 
     def all_reduce_sum(self, t):
         if getattr(t, "is_cuda", False) and self.dist.get_backend(self.group) != "nccl":
@@ -93,6 +108,53 @@ class TorchComm:
             t.copy_(tmp)
             return
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+
+    def _buffers(self, t, chunk):
+        key = (t.device, chunk)
+        if key not in self._scratch:
+            import torch
+            P = self.world
+            self._scratch[key] = (torch.zeros(P * chunk, dtype=t.dtype, device=t.device),   # send (padded T)
+                                  torch.zeros(P * chunk, dtype=t.dtype, device=t.device),   # recv (P slices)
+                                  torch.zeros(chunk, dtype=t.dtype, device=t.device))       # my reduced slice
+        return self._scratch[key]
+
+    def all_reduce_vector(self, t, sum_chunks=None):
+        """t <- sum over ranks of t (n doubles).  `sum_chunks(recv, P, chunk, out)` is the backend's
+        rank-ordered local sum (HIP kernel on the GPU path); None = do it with torch ops."""
+        import torch
+        import os
+        P = self.world
+        forced = os.environ.get("LSQR_DIST_ALLREDUCE") == "direct!"   # exercise the direct path even at P = 1
+        if (P == 1 and not forced) or self.vector_sum == "ring":
+            return self.all_reduce_sum(t)
+        n = t.numel()
+        chunk = (n + P - 1) // P
+        if self.backend == "nccl":
+            send, recv, mine = self._buffers(t, chunk)
+            exact = n == P * chunk                 # no padding needed: exchange t in place
+            src = t if exact else send
+            if not exact:
+                send[:n].copy_(t)
+            self.dist.all_to_all_single(recv, src, group=self.group)        # slice j of every rank -> rank j
+            if sum_chunks is not None:
+                sum_chunks(recv, P, chunk, mine)
+            else:
+                mine.copy_(recv[:chunk])
+                for r in range(1, P):
+                    mine.add_(recv[r * chunk:(r + 1) * chunk])
+            self.dist.all_gather_into_tensor(src, mine, group=self.group)    # reduced slices -> everyone
+            if not exact:
+                t.copy_(send[:n])
+            return
+        # gloo (tests): same arithmetic -- every element summed in rank order -- via an all-gather
+        src = t.cpu() if getattr(t, "is_cuda", False) else t
+        parts = [torch.empty_like(src) for _ in range(P)]
+        self.dist.all_gather(parts, src.contiguous(), group=self.group)
+        acc = parts[0].clone()
+        for r in range(1, P):
+            acc.add_(parts[r])
+        t.copy_(acc)
 
     def agree_max(self, value: int) -> int:
         import torch
@@ -148,6 +210,11 @@ class HipShardBackend:
     def stage(self, k: int):
         self.capi.check(self.capi.lib().lsqrhip_shard_stage(self.h, int(k)))
 
+    def sum_chunks(self, recv, nchunks: int, chunk: int, out):
+        """Rank-ordered sum of the slices received in the direct reduce-scatter (HIP kernel)."""
+        self.capi.check(self.capi.lib().lsqrhip_sum_chunks(self.h, recv.data_ptr(), int(nchunks), int(chunk),
+                                                           out.data_ptr()))
+
     def poll(self):
         out = (C.c_int * 3)()
         self.capi.check(self.capi.lib().lsqrhip_shard_poll(self.h, out))
@@ -178,7 +245,11 @@ class ShardedLSQR:
         self.comm.all_reduce_sum(self.be.sums[:1])
 
     def _ar_vector(self):
-        self.comm.all_reduce_sum(self.be.T)
+        arv = getattr(self.comm, "all_reduce_vector", None)
+        if arv is None:
+            self.comm.all_reduce_sum(self.be.T)
+        else:
+            arv(self.be.T, getattr(self.be, "sum_chunks", None))
 
     def solve(self, b_local, damp=0.0, atol=0.0, btol=0.0, conlim=0.0, itnlim=100, wantse=False) -> ShardResult:
         be = self.be
