@@ -121,7 +121,9 @@ struct Csr {
     int *col = nullptr;              // 32-bit column indices (freed when col16 is in use)
     unsigned short *col16 = nullptr;  // 16-bit block-relative column indices (spmv.h C16) ...
     int *cbase = nullptr;            // ... and each row block's smallest column
-    double *val = nullptr;
+    double *val = nullptr;           // 8-byte values (freed when val8 is in use)
+    unsigned char *val8 = nullptr;   // one-byte codes into dict (valdict.h) ...
+    const double *dict = nullptr;    // ... the handle's dictionary (not owned)
     int *rb = nullptr;  // row-block boundaries [nblk+1]
     RowBlock *blk = nullptr;  // one descriptor per row block (spmv.h)
     int64_t nblk = 0;
@@ -141,6 +143,8 @@ struct lsqrhip_handle_s {
     int64_t nnz = 0;
     bool off64 = false;
     Csr A, AT;
+    double *dict = nullptr;  // <= 256 distinct values of the matrix, ascending bit patterns (valdict.h)
+    int ndict = 0;           // 0 = no dictionary
     double *U = nullptr, *V = nullptr, *W = nullptr, *X = nullptr, *SE = nullptr;
     double *Z = nullptr;         // per-panel row sums of a panelled product (max over A, A')
     double *partials = nullptr;  // SPMV_MAX_GRID
@@ -197,6 +201,7 @@ static void free_csr(Csr &c)
     if (c.col16) (void)hipFree(c.col16);
     if (c.cbase) (void)hipFree(c.cbase);
     if (c.val) (void)hipFree(c.val);
+    if (c.val8) (void)hipFree(c.val8);
     if (c.rb) (void)hipFree(c.rb);
     if (c.blk) (void)hipFree(c.blk);
     c = Csr();
@@ -227,7 +232,7 @@ extern "C" int lsqrhip_destroy(lsqrhip_handle_t h)
     destroy_graph(h);
     free_csr(h->A);
     free_csr(h->AT);
-    for (double *p : {h->U, h->V, h->W, h->X, h->SE, h->Z, h->partials, h->d_scalar, h->d_log})
+    for (double *p : {h->U, h->V, h->W, h->X, h->SE, h->Z, h->partials, h->d_scalar, h->d_log, h->dict})
         if (p) (void)hipFree(p);
     if (h->d_state) (void)hipFree(h->d_state);
     if (h->h_state) (void)hipHostFree(h->h_state);
@@ -257,7 +262,8 @@ static int bits_for(int limit)
 template <typename OffT>
 static int build_csr_T(hipStream_t s, const int *d_keys, const int *d_other, const double *d_a, int64_t nnz,
                        int rows, int cols, int bad_code, int bad_code_other, int panels, int pw,
-                       unsigned long long *bufA, unsigned long long *bufB, unsigned *hist, int *d_flags, Csr &out)
+                       unsigned long long *bufA, unsigned long long *bufB, unsigned *hist, int *d_flags,
+                       const double *dict, int ndict, Csr &out)
 {
     out.rows = rows;
     out.cols = cols;
@@ -344,6 +350,18 @@ static int build_csr_T(hipStream_t s, const int *d_keys, const int *d_other, con
             out.cbase = nullptr;
         }
     }
+    // one-byte value codes when the matrix has a dictionary (valdict.h)
+    if (ndict > 0 && nnz > 0) {
+        HIPCHK(hipMalloc((void **)&out.val8, (size_t)nnz));
+        hipLaunchKernelGGL(k_dict_encode, dim3(g), dim3(256), 0, s, (const double *)out.val, nnz,
+                           (const unsigned long long *)dict, ndict, out.val8);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(s));
+        (void)hipFree(out.val);
+        out.val = nullptr;
+        out.dict = dict;
+        out.bytes -= 7 * nnz;
+    }
     int64_t grid = std::min<int64_t>(out.nblk, SPMV_MAX_GRID);
     if (grid >= 8) grid &= ~(int64_t)7;  // multiple of 8: XCD-aware mapping (common.h)
     out.grid = (int)std::max<int64_t>(grid, 1);
@@ -372,6 +390,36 @@ static void choose_panels(int rows, int cols, double mean_dev, int *panels, int 
     *pw = (int)width;
 }
 
+// Value dictionary (valdict.h): h->dict / h->ndict when the matrix has <= 256 distinct values.
+// LSQRHIP_VAL8=0 keeps 8-byte values.  `table` is scratch of >= VD_SLOTS words, `ctl` of 4 ints.
+static int build_dictionary(H *h, const double *d_a, unsigned long long *table, int *ctl)
+{
+    h->ndict = 0;
+    const int64_t nnz = h->nnz;
+    if (nnz < VD_SLOTS || env_int("LSQRHIP_VAL8", 1) == 0) return LSQRHIP_OK;  // (scratch is nnz words)
+    hipStream_t s = h->stream;
+    HIPCHK(hipMemsetAsync(table, 0xFF, sizeof(unsigned long long) * VD_SLOTS, s));
+    HIPCHK(hipMemsetAsync(ctl, 0, 4 * sizeof(int), s));
+    const int g = (int)std::min<int64_t>((nnz + 255) / 256, 2048);
+    hipLaunchKernelGGL(k_dict_collect, dim3(g), dim3(256), 0, s, d_a, nnz, table, ctl);
+    HIPCHK(hipGetLastError());
+    int got[4];
+    HIPCHK(hipMemcpyAsync(got, ctl, sizeof(got), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (got[1] != 0 || got[0] < 1 || got[0] > VD_MAX) return LSQRHIP_OK;
+    std::vector<unsigned long long> slots(VD_SLOTS), keys;
+    HIPCHK(hipMemcpy(slots.data(), table, sizeof(unsigned long long) * VD_SLOTS, hipMemcpyDeviceToHost));
+    for (unsigned long long v : slots)
+        if (v != VD_EMPTY) keys.push_back(v);
+    if ((int)keys.size() != got[0]) return LSQRHIP_OK;
+    std::sort(keys.begin(), keys.end());
+    keys.resize(VD_MAX, keys.back());  // padded: the SpMV loads all 256 entries
+    HIPCHK(hipMalloc((void **)&h->dict, sizeof(double) * VD_MAX));
+    HIPCHK(hipMemcpy(h->dict, keys.data(), sizeof(double) * VD_MAX, hipMemcpyHostToDevice));
+    h->ndict = got[0];
+    return LSQRHIP_OK;
+}
+
 static int finish_create(H *h, const int *d_irow, const int *d_icol, const double *d_a)
 {
     hipStream_t s = h->stream;
@@ -396,18 +444,25 @@ static int finish_create(H *h, const int *d_irow, const int *d_icol, const doubl
         HIPCHK(hipStreamSynchronize(s));
         mean_dev = (double)dev / (double)nnz;
     }
+    if (int rcd = build_dictionary(h, d_a, bufA, d_flags)) {
+        (void)hipFree(bufA);
+        (void)hipFree(bufB);
+        (void)hipFree(hist);
+        (void)hipFree(d_flags);
+        return rcd;
+    }
     int pa = 1, pwa = h->n, pt = 1, pwt = h->m;
     choose_panels(h->m, h->n, mean_dev, &pa, &pwa);                                   // mode 1 gathers V (n)
     choose_panels(h->n, h->m, mean_dev * (double)std::max(h->m, 1) / (double)std::max(h->n, 1), &pt, &pwt);  // mode 2 gathers U (m)
     int rc;
     if (h->off64) {
-        rc = build_csr_T<long long>(s, d_irow, d_icol, d_a, nnz, h->m, h->n, LSQRHIP_ERR_IROW, LSQRHIP_ERR_ICOL, pa, pwa, bufA, bufB, hist, d_flags, h->A);
+        rc = build_csr_T<long long>(s, d_irow, d_icol, d_a, nnz, h->m, h->n, LSQRHIP_ERR_IROW, LSQRHIP_ERR_ICOL, pa, pwa, bufA, bufB, hist, d_flags, h->dict, h->ndict, h->A);
         if (rc == LSQRHIP_OK)
-            rc = build_csr_T<long long>(s, d_icol, d_irow, d_a, nnz, h->n, h->m, LSQRHIP_ERR_ICOL, LSQRHIP_ERR_IROW, pt, pwt, bufA, bufB, hist, d_flags, h->AT);
+            rc = build_csr_T<long long>(s, d_icol, d_irow, d_a, nnz, h->n, h->m, LSQRHIP_ERR_ICOL, LSQRHIP_ERR_IROW, pt, pwt, bufA, bufB, hist, d_flags, h->dict, h->ndict, h->AT);
     } else {
-        rc = build_csr_T<int>(s, d_irow, d_icol, d_a, nnz, h->m, h->n, LSQRHIP_ERR_IROW, LSQRHIP_ERR_ICOL, pa, pwa, bufA, bufB, hist, d_flags, h->A);
+        rc = build_csr_T<int>(s, d_irow, d_icol, d_a, nnz, h->m, h->n, LSQRHIP_ERR_IROW, LSQRHIP_ERR_ICOL, pa, pwa, bufA, bufB, hist, d_flags, h->dict, h->ndict, h->A);
         if (rc == LSQRHIP_OK)
-            rc = build_csr_T<int>(s, d_icol, d_irow, d_a, nnz, h->n, h->m, LSQRHIP_ERR_ICOL, LSQRHIP_ERR_IROW, pt, pwt, bufA, bufB, hist, d_flags, h->AT);
+            rc = build_csr_T<int>(s, d_icol, d_irow, d_a, nnz, h->n, h->m, LSQRHIP_ERR_ICOL, LSQRHIP_ERR_IROW, pt, pwt, bufA, bufB, hist, d_flags, h->dict, h->ndict, h->AT);
     }
     (void)hipFree(bufA);
     (void)hipFree(bufB);
@@ -521,6 +576,12 @@ extern "C" int lsqrhip_info(lsqrhip_handle_t h, int64_t *dims)
     dims[3] = h->A.bytes;
     dims[4] = h->AT.bytes;
     dims[5] = h->off64 ? 8 : 4;
+    dims[6] = h->ndict;                          // value dictionary entries (0 = 8-byte values)
+    dims[7] = h->A.val8 ? 1 : 8;                 // bytes per stored value
+    dims[8] = h->A.col16 ? 2 : 4;                // bytes per column index, CSR(A)
+    dims[9] = h->AT.col16 ? 2 : 4;               //                        CSR(A')
+    dims[10] = h->A.P;                           // column panels of CSR(A)
+    dims[11] = h->AT.P;                          //                  CSR(A')
     return LSQRHIP_OK;
 }
 

@@ -50,20 +50,21 @@ struct SpmvArgs {
     hipEvent_t e0 = nullptr, e1 = nullptr;  // kernel begin/end timestamps (hipExtLaunchKernelGGL)
 };
 
-template <typename OffT, bool PANEL, bool C16>
+template <typename OffT, bool PANEL, bool C16, bool V8>
 static void launch_spmv_C(const SpmvArgs &a, double *y, hipEvent_t e0, hipEvent_t e1)
 {
     const Csr &c = *a.c;
     const dim3 grid(c.grid + (a.rider.kind != 0 ? 1 : 0));
     const void *colv = C16 ? (const void *)c.col16 : (const void *)c.col;
+    const void *valv = V8 ? (const void *)c.val8 : (const void *)c.val;
     if (e0 == nullptr && e1 == nullptr)  // plain launch (the only form used under stream capture)
-        hipLaunchKernelGGL((k_spmv_fused<OffT, PANEL, C16>), grid, dim3(SPMV_BLOCK), 0, a.stream,
-                           (const OffT *)c.rowptr, colv, (const int *)c.cbase, (const double *)c.val,
+        hipLaunchKernelGGL((k_spmv_fused<OffT, PANEL, C16, V8>), grid, dim3(SPMV_BLOCK), 0, a.stream,
+                           (const OffT *)c.rowptr, colv, (const int *)c.cbase, valv, (const double *)c.dict,
                            (const RowBlock *)c.blk, c.nblk, a.x, y, a.coef, a.stop, a.pout, a.pin, a.npin, a.slot_in,
                            a.slot_out, a.skip_if_zero, a.rider);
     else
-        hipExtLaunchKernelGGL((k_spmv_fused<OffT, PANEL, C16>), grid, dim3(SPMV_BLOCK), 0, a.stream, e0, e1, 0,
-                              (const OffT *)c.rowptr, colv, (const int *)c.cbase, (const double *)c.val,
+        hipExtLaunchKernelGGL((k_spmv_fused<OffT, PANEL, C16, V8>), grid, dim3(SPMV_BLOCK), 0, a.stream, e0, e1, 0,
+                              (const OffT *)c.rowptr, colv, (const int *)c.cbase, valv, (const double *)c.dict,
                               (const RowBlock *)c.blk, c.nblk, a.x, y, a.coef, a.stop, a.pout, a.pin, a.npin,
                               a.slot_in, a.slot_out, a.skip_if_zero, a.rider);
 }
@@ -71,8 +72,14 @@ static void launch_spmv_C(const SpmvArgs &a, double *y, hipEvent_t e0, hipEvent_
 template <typename OffT, bool PANEL>
 static void launch_spmv_T(const SpmvArgs &a, double *y, hipEvent_t e0, hipEvent_t e1)
 {
-    if (!PANEL && a.c->col16 != nullptr) launch_spmv_C<OffT, false, true>(a, y, e0, e1);
-    else launch_spmv_C<OffT, PANEL, false>(a, y, e0, e1);
+    const bool v8 = a.c->val8 != nullptr;
+    if (!PANEL && a.c->col16 != nullptr) {
+        if (v8) launch_spmv_C<OffT, false, true, true>(a, y, e0, e1);
+        else launch_spmv_C<OffT, false, true, false>(a, y, e0, e1);
+    } else {
+        if (v8) launch_spmv_C<OffT, PANEL, false, true>(a, y, e0, e1);
+        else launch_spmv_C<OffT, PANEL, false, false>(a, y, e0, e1);
+    }
 }
 
 static void launch_spmv_args(H *h, const SpmvArgs &a)

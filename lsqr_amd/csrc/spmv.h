@@ -46,6 +46,7 @@
 #include "common.h"
 #include "scalar.h"
 #include "state.h"
+#include "valdict.h"
 
 namespace lsqrhip {
 
@@ -168,16 +169,20 @@ __global__ void k_block_desc(const OffT *__restrict__ rowptr, const int *__restr
 // C16 = true: 16-bit column indices relative to the row block's smallest column (cbase[b]).
 // Chosen at build time when EVERY row block spans fewer than 65536 columns (banded / local
 // matrices): 2 instead of 4 bytes per nonzero on a kernel that is bound by bytes.
-template <typename OffT, bool PANEL, bool C16>
+//
+// V8 = true: one-byte value codes into the matrix-wide dictionary dict[256] (valdict.h), held in
+// LDS: 1 instead of 8 bytes per nonzero when the matrix has <= 256 distinct values.
+template <typename OffT, bool PANEL, bool C16, bool V8>
 __global__ __launch_bounds__(SPMV_BLOCK, 8) void k_spmv_fused(
     const OffT *__restrict__ rowptr, const void *__restrict__ colv, const int *__restrict__ cbase,
-    const double *__restrict__ val, const RowBlock *__restrict__ blk, int64_t nblk, const double *__restrict__ x, double *__restrict__ y,
+    const void *__restrict__ valv, const double *__restrict__ dict, const RowBlock *__restrict__ blk, int64_t nblk, const double *__restrict__ x, double *__restrict__ y,
     const SpmvCoef *__restrict__ coef, const int *__restrict__ stop, double *__restrict__ partials,
     const double *__restrict__ pin, int npin, const NormSlot *__restrict__ slot_in,
     NormSlot *__restrict__ slot_out, int skip_if_zero, Rider rider)
 {
     __shared__ double prod[SPMV_LDS];
     __shared__ double red[SPMV_BLOCK / WAVE + 1];
+    __shared__ double sdict[V8 ? VD_MAX : 1];
     // One extra workgroup carries scalar work (scalar.h "riders").  It is block 0, the first
     // one dispatched, so it runs beside the SpMV from the start (as the LAST block of a grid
     // that exceeds the resident slots it would only start when the first SpMV block retires).
@@ -192,6 +197,9 @@ __global__ __launch_bounds__(SPMV_BLOCK, 8) void k_spmv_fused(
     const int tid = threadIdx.x;
     const int *__restrict__ col = static_cast<const int *>(colv);
     const unsigned short *__restrict__ col16 = static_cast<const unsigned short *>(colv);
+    const double *__restrict__ val = static_cast<const double *>(valv);
+    const unsigned char *__restrict__ val8 = static_cast<const unsigned char *>(valv);
+    if (V8) sdict[tid] = dict[tid];  // visible after the first barrier below
 
     double sx, sy, cy;
     if (pin != nullptr) {  // lazy coefficients (uniform branch)
@@ -210,6 +218,7 @@ __global__ __launch_bounds__(SPMV_BLOCK, 8) void k_spmv_fused(
         sy = coef->sy;
         cy = coef->cy;
     }
+    if (V8) __syncthreads();
 
     double sq = 0.0;  // this thread's share of sum(y_new^2)
 
@@ -262,7 +271,7 @@ __global__ __launch_bounds__(SPMV_BLOCK, 8) void k_spmv_fused(
         if (cnt > 0) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                a[j] = val[p0 + kk[j]];
+                a[j] = V8 ? sdict[val8[p0 + kk[j]]] : val[p0 + kk[j]];
                 c[j] = C16 ? cb + (int)col16[p0 + kk[j]] : col[p0 + kk[j]];
             }
         }
@@ -295,7 +304,7 @@ __global__ __launch_bounds__(SPMV_BLOCK, 8) void k_spmv_fused(
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    a[j] = val[p0 + kk[j]];
+                    a[j] = V8 ? sdict[val8[p0 + kk[j]]] : val[p0 + kk[j]];
                     c[j] = C16 ? cb + (int)col16[p0 + kk[j]] : col[p0 + kk[j]];
                 }
 #pragma unroll
@@ -350,7 +359,7 @@ __global__ __launch_bounds__(SPMV_BLOCK, 8) void k_spmv_fused(
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    al[j] = val[plast + kl[j]];
+                    al[j] = V8 ? sdict[val8[plast + kl[j]]] : val[plast + kl[j]];
                     cl[j] = C16 ? cb + (int)col16[plast + kl[j]] : col[plast + kl[j]];
                 }
                 double xl[4];
