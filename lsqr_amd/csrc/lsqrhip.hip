@@ -20,10 +20,12 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "csr_build.h"
 #include "scalar.h"
+#include "sell.h"
 #include "spmv.h"
 #include "state.h"
 #include "vec.h"
@@ -124,6 +126,15 @@ struct Csr {
     double *val = nullptr;           // 8-byte values (freed when val8 is in use)
     unsigned char *val8 = nullptr;   // one-byte codes into dict (valdict.h) ...
     const double *dict = nullptr;    // ... the handle's dictionary (not owned)
+    // sliced-ELL layout (sell.h), used instead of the arrays above when `sell` is set
+    int sell = 0;
+    unsigned *soff = nullptr;        // [nslices+1] first element of each 64-row slice
+    void *scol = nullptr;            // column-major columns (u16 relative to cbaseS, or i32)
+    void *sval = nullptr;            // column-major values (u8 dictionary codes, or f64)
+    int *cbaseS = nullptr;           // [nslices] smallest column of each slice
+    unsigned char *rlen = nullptr;   // [rows] row lengths
+    int nslices = 0;
+    bool sell_c16 = false, sell_v8 = false;
     int *rb = nullptr;  // row-block boundaries [nblk+1]
     RowBlock *blk = nullptr;  // one descriptor per row block (spmv.h)
     int64_t nblk = 0;
@@ -202,6 +213,11 @@ static void free_csr(Csr &c)
     if (c.cbase) (void)hipFree(c.cbase);
     if (c.val) (void)hipFree(c.val);
     if (c.val8) (void)hipFree(c.val8);
+    if (c.soff) (void)hipFree(c.soff);
+    if (c.scol) (void)hipFree(c.scol);
+    if (c.sval) (void)hipFree(c.sval);
+    if (c.cbaseS) (void)hipFree(c.cbaseS);
+    if (c.rlen) (void)hipFree(c.rlen);
     if (c.rb) (void)hipFree(c.rb);
     if (c.blk) (void)hipFree(c.blk);
     c = Csr();
@@ -259,6 +275,87 @@ static int bits_for(int limit)
     return b;
 }
 
+// Sliced-ELL layout for short, even rows (sell.h).  On success out.sell = 1 and the CSR arrays
+// col / val are released; otherwise `out` is left as it was.  `stats` is scratch of >= 4 words.
+static int try_sell(hipStream_t s, Csr &out, int64_t nnz, const double *dict, int ndict, unsigned long long *stats)
+{
+    const int rows = out.rows;
+    // LSQRHIP_SELL: 0 never | 1 whenever the row shape qualifies | unset: also require local
+    // columns (every slice spans < 65536 columns) -- with scattered columns the layout buys
+    // nothing (x gathers dominate; measured 5-10 % slower than row windows)
+    const int mode = env_int("LSQRHIP_SELL", -1);
+    if (out.P > 1 || nnz <= 0 || rows <= 0 || mode == 0) return LSQRHIP_OK;
+    if (nnz > 24 * (int64_t)rows) return LSQRHIP_OK;
+    const int nslices = (rows + 63) / 64;
+    const unsigned gr = (unsigned)(((int64_t)nslices * 64 + 255) / 256);
+    unsigned *soff = nullptr;
+    HIPCHK(hipMalloc((void **)&soff, sizeof(unsigned) * ((size_t)nslices + 1)));
+    HIPCHK(hipMemsetAsync(stats, 0, 4 * sizeof(unsigned long long), s));
+    HIPCHK(hipMemsetAsync(soff + nslices, 0, sizeof(unsigned), s));
+    hipLaunchKernelGGL(k_sell_width, dim3(gr), dim3(256), 0, s, (const int *)out.rowptr, rows, nslices, soff, stats);
+    HIPCHK(hipGetLastError());
+    unsigned long long st[4];
+    HIPCHK(hipMemcpyAsync(st, stats, sizeof(st), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    const unsigned long long padded = st[0];
+    if (st[1] > (unsigned long long)SELL_MAX_W || padded > (unsigned long long)(nnz + nnz / 8 + 4096) ||
+        padded >= (1ull << 31)) {
+        (void)hipFree(soff);
+        return LSQRHIP_OK;
+    }
+    int *cbaseS = nullptr;
+    HIPCHK(hipMalloc((void **)&cbaseS, sizeof(int) * (size_t)nslices));
+    hipLaunchKernelGGL(k_sell_colspan, dim3(gr), dim3(256), 0, s, (const int *)out.rowptr, (const int *)out.col, rows,
+                       nslices, cbaseS, stats);
+    hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, s, soff, (int64_t)nslices + 1);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(st, stats, sizeof(st), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (st[2] != 0 && mode != 1) {
+        (void)hipFree(soff);
+        (void)hipFree(cbaseS);
+        return LSQRHIP_OK;
+    }
+    const bool c16 = st[2] == 0 && env_int("LSQRHIP_COL16", 1) != 0;
+    const bool v8 = ndict > 0;
+    const size_t np = (size_t)std::max<unsigned long long>(padded, 1);
+    void *scol = nullptr, *sval = nullptr;
+    unsigned char *rlen = nullptr;
+    HIPCHK(hipMalloc(&scol, np * (c16 ? 2 : 4)));
+    HIPCHK(hipMalloc(&sval, np * (v8 ? 1 : 8)));
+    HIPCHK(hipMalloc((void **)&rlen, (size_t)rows));
+    const unsigned long long *db = (const unsigned long long *)dict;
+#define SELL_FILL(C16, V8)                                                                                          \
+    hipLaunchKernelGGL((k_sell_fill<C16, V8>), dim3(gr), dim3(256), 0, s, (const int *)out.rowptr,                  \
+                       (const int *)out.col, (const double *)out.val, (const unsigned *)soff, (const int *)cbaseS, \
+                       db, ndict, rows, nslices, scol, sval, rlen)
+    if (c16 && v8) SELL_FILL(true, true);
+    else if (c16) SELL_FILL(true, false);
+    else if (v8) SELL_FILL(false, true);
+    else SELL_FILL(false, false);
+#undef SELL_FILL
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(s));
+    (void)hipFree(out.col);
+    (void)hipFree(out.val);
+    out.col = nullptr;
+    out.val = nullptr;
+    out.sell = 1;
+    out.soff = soff;
+    out.scol = scol;
+    out.sval = sval;
+    out.cbaseS = cbaseS;
+    out.rlen = rlen;
+    out.nslices = nslices;
+    out.sell_c16 = c16;
+    out.sell_v8 = v8;
+    out.dict = dict;
+    out.nblk = (nslices + SELL_SLICES - 1) / SELL_SLICES;
+    out.bytes = (int64_t)sizeof(int) * (rows + 1) + (int64_t)padded * ((c16 ? 2 : 4) + (v8 ? 1 : 8)) +
+                (int64_t)nslices * 8 + rows;
+    return LSQRHIP_OK;
+}
+
 template <typename OffT>
 static int build_csr_T(hipStream_t s, const int *d_keys, const int *d_other, const double *d_a, int64_t nnz,
                        int rows, int cols, int bad_code, int bad_code_other, int panels, int pw,
@@ -312,6 +409,19 @@ static int build_csr_T(hipStream_t s, const int *d_keys, const int *d_other, con
     }
     hipLaunchKernelGGL(k_rowptr_from_sorted<OffT>, dim3(g), dim3(256), 0, s, sorted, nnz, rows_v, (OffT *)out.rowptr);
     HIPCHK(hipGetLastError());
+
+    // short, even rows: sliced-ELL layout instead of row windows (sell.h)
+    if (std::is_same<OffT, int>::value) {
+        const int rcs = try_sell(s, out, nnz, dict, ndict, (unsigned long long *)hist);
+        if (rcs != LSQRHIP_OK) return rcs;
+    }
+    if (out.sell) {
+        int64_t grid = std::min<int64_t>(out.nblk, SPMV_MAX_GRID);
+        if (grid >= 8) grid &= ~(int64_t)7;
+        out.grid = (int)std::max<int64_t>(grid, 1);
+        out.out_grid = out.grid;
+        return LSQRHIP_OK;
+    }
 
     // row blocks ("row windows", spmv.h) over the (virtual) rows
     out.nblk = std::max<int64_t>((nnz + rows_v + SPMV_C - 1) / SPMV_C, 1);
@@ -577,11 +687,13 @@ extern "C" int lsqrhip_info(lsqrhip_handle_t h, int64_t *dims)
     dims[4] = h->AT.bytes;
     dims[5] = h->off64 ? 8 : 4;
     dims[6] = h->ndict;                          // value dictionary entries (0 = 8-byte values)
-    dims[7] = h->A.val8 ? 1 : 8;                 // bytes per stored value
-    dims[8] = h->A.col16 ? 2 : 4;                // bytes per column index, CSR(A)
-    dims[9] = h->AT.col16 ? 2 : 4;               //                        CSR(A')
+    dims[7] = (h->A.val8 || h->A.sell_v8) ? 1 : 8;                 // bytes per stored value
+    dims[8] = (h->A.col16 || h->A.sell_c16) ? 2 : 4;                // bytes per column index, CSR(A)
+    dims[9] = (h->AT.col16 || h->AT.sell_c16) ? 2 : 4;               //                        CSR(A')
     dims[10] = h->A.P;                           // column panels of CSR(A)
     dims[11] = h->AT.P;                          //                  CSR(A')
+    dims[12] = h->A.sell;                        // sliced-ELL layout in use for A
+    dims[13] = h->AT.sell;                       //                          for A'
     return LSQRHIP_OK;
 }
 

@@ -1,0 +1,266 @@
+// sell.h -- sliced-ELL SpMV for matrices with short, even rows (aprod mode 1 / mode 2).
+//
+// Same contract as spmv.h's k_spmv_fused (reference src/lsqr.f90:166-174 / :186-194 fused with
+// the dscal before and the dnrm2 after, :681-683 / :692-695):
+//
+//     y_i  <-  cy * (y_i * sy)  +  sum_j A_ij * (x_j * sx)        partial += y_i^2
+//
+// Why a second layout.  The row-window kernel (spmv.h) handles any degree distribution, but a
+// trip through one window is a chain of dependent steps (descriptor -> (val, col) -> x gather
+// -> LDS -> barrier -> row sums -> barrier): ~4 us per resident round of windows whatever the
+// bytes (profiles/r01/sweep_prefetch_negative.txt).  When every row is short and the rows of a
+// 64-row slice have about the same length -- stencils, meshes, BASELINE.json configs[1] -- a
+// slice stored COLUMN-major needs none of that: lane i of a wave owns row i of the slice, the
+// k-th load of the wave reads the k-th nonzero of 64 consecutive rows (one contiguous
+// segment), each lane adds its own products left to right in registers.  No LDS staging, no
+// barriers, no row pointers; all W loads of a slice are issued before the first use.
+//
+// Layout (built by k_sell_* below from the CSR of csr_build.h):
+//   slice s = rows [64 s, 64 s + 64);  W_s = longest row of the slice;
+//   soff[s] = first element of slice s (in elements, 64 W_s per slice), soff[nslices] = total;
+//   element (row i of slice, k)  at  soff[s] + 64 k + i;   rlen[r] = length of row r (<= 64);
+//   padding slots (k >= rlen) hold the slice's smallest column and value 0 -- they are loaded
+//   but never added (the add is predicated on k < rlen, so no 0*inf, no -0 + 0 differences).
+// Every row sum is the plain left-to-right sum in COO order starting from 0, i.e. bit-identical
+// to the reference's and to the window kernel's one-lane-per-row path.
+//
+// Chosen at build time when mean row length <= 24, no row is longer than 64, padding costs
+// <= 12.5 % and the columns are local (every slice spans < 65536 columns; with scattered
+// columns the x gathers dominate and the layout buys nothing).  LSQRHIP_SELL=0 disables,
+// =1 drops the locality requirement.  Columns are 16-bit relative to the slice's
+// smallest column when every slice spans < 65536 columns; values are one-byte dictionary
+// codes when the matrix has a dictionary (valdict.h).
+#pragma once
+
+#include "common.h"
+#include "scalar.h"
+#include "state.h"
+#include "valdict.h"
+
+namespace lsqrhip {
+
+constexpr int SELL_BLOCK = 256;                 // 4 slices per workgroup trip
+constexpr int SELL_SLICES = SELL_BLOCK / WAVE;
+constexpr int SELL_MAX_W = 64;
+
+// width64[s] = 64 * W_s (elements of slice s); stats[0] += 64 W_s, stats[1] = max W.
+__global__ __launch_bounds__(256) void k_sell_width(const int *__restrict__ rowptr, int rows, int nslices,
+                                                    unsigned *__restrict__ width64,
+                                                    unsigned long long *__restrict__ stats)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int s = (int)(r >> 6);
+    int len = 0;
+    if (r < rows) len = rowptr[r + 1] - rowptr[r];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) len = max(len, __shfl_xor(len, off, WAVE));
+    if ((threadIdx.x & (WAVE - 1)) == 0 && s < nslices) {
+        width64[s] = (unsigned)len * 64u;
+        atomicAdd(&stats[0], (unsigned long long)len * 64ull);
+        atomicMax(&stats[1], (unsigned long long)len);
+    }
+}
+
+// cbaseS[s] = smallest column of slice s (0 if empty); stats[2] |= 1 if a slice spans >= 65536 columns.
+__global__ __launch_bounds__(256) void k_sell_colspan(const int *__restrict__ rowptr, const int *__restrict__ col,
+                                                      int rows, int nslices, int *__restrict__ cbaseS,
+                                                      unsigned long long *__restrict__ stats)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int s = (int)(r >> 6);
+    int lo = 0x7fffffff, hi = -1;
+    if (r < rows) {
+        const int q0 = rowptr[r], q1 = rowptr[r + 1];
+        for (int k = q0; k < q1; ++k) {
+            const int c = col[k];
+            lo = min(lo, c);
+            hi = max(hi, c);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        lo = min(lo, __shfl_xor(lo, off, WAVE));
+        hi = max(hi, __shfl_xor(hi, off, WAVE));
+    }
+    if ((threadIdx.x & (WAVE - 1)) == 0 && s < nslices) {
+        cbaseS[s] = hi >= 0 ? lo : 0;
+        if (hi >= 0 && hi - lo >= 65536) atomicOr(&stats[2], 1ull);
+    }
+}
+
+// CSR rows -> column-major slices.  One thread per (padded) row.
+template <bool C16, bool V8>
+__global__ __launch_bounds__(256) void k_sell_fill(const int *__restrict__ rowptr, const int *__restrict__ col,
+                                                   const double *__restrict__ val,
+                                                   const unsigned *__restrict__ soff, const int *__restrict__ cbaseS,
+                                                   const unsigned long long *__restrict__ dict_bits, int nd, int rows,
+                                                   int nslices, void *__restrict__ scolv, void *__restrict__ svalv,
+                                                   unsigned char *__restrict__ rlen)
+{
+    __shared__ unsigned long long tab[VD_MAX];
+    if (V8) {
+        if ((int)threadIdx.x < nd) tab[threadIdx.x] = dict_bits[threadIdx.x];
+        __syncthreads();
+    }
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int s = (int)(r >> 6), lane = (int)(r & 63);
+    if (s >= nslices) return;
+    const unsigned o0 = soff[s];
+    const int W = (int)((soff[s + 1] - o0) >> 6);
+    const int cb = cbaseS[s];
+    int q0 = 0, len = 0;
+    if (r < rows) {
+        q0 = rowptr[r];
+        len = rowptr[r + 1] - q0;
+        rlen[r] = (unsigned char)len;
+    }
+    unsigned short *sc16 = static_cast<unsigned short *>(scolv);
+    int *sc32 = static_cast<int *>(scolv);
+    unsigned char *sv8 = static_cast<unsigned char *>(svalv);
+    double *sv = static_cast<double *>(svalv);
+    for (int k = 0; k < W; ++k) {
+        const size_t idx = (size_t)o0 + (size_t)k * 64 + lane;
+        int c = cb;
+        double v = 0.0;
+        if (k < len) {
+            c = col[q0 + k];
+            v = val[q0 + k];
+        }
+        if (C16) sc16[idx] = (unsigned short)(c - cb);
+        else sc32[idx] = c;
+        if (V8) {
+            unsigned char code = 0;
+            if (k < len) {
+                const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+                int lo = 0, hi = nd - 1;
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (tab[mid] < bits) lo = mid + 1;
+                    else hi = mid;
+                }
+                code = (unsigned char)lo;
+            }
+            sv8[idx] = code;
+        } else {
+            sv[idx] = v;
+        }
+    }
+}
+
+// U columns of one slice, starting at element `e` (= soff + 64 k0 + lane): all loads first,
+// then the predicated left-to-right adds.
+template <int U, bool C16, bool V8>
+__device__ __forceinline__ double sell_chunk(double sum, size_t e, int k0, int len, int cb,
+                                             const int *__restrict__ sc32, const unsigned short *__restrict__ sc16,
+                                             const double *__restrict__ sv, const unsigned char *__restrict__ sv8,
+                                             const double *sdict, const double *__restrict__ x, double sx)
+{
+    int c[U];
+    double a[U], xv[U];
+    int code[U];
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+        const size_t idx = e + (size_t)j * 64;
+        c[j] = C16 ? cb + (int)sc16[idx] : sc32[idx];
+        if (V8) code[j] = (int)sv8[idx];
+        else a[j] = sv[idx];
+    }
+#pragma unroll
+    for (int j = 0; j < U; ++j) xv[j] = x[c[j]];
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+        const double av = V8 ? sdict[code[j]] : a[j];
+        const double p = av * (xv[j] * sx);
+        if (k0 + j < len) sum = sum + p;
+    }
+    return sum;
+}
+
+template <bool C16, bool V8>
+__global__ __launch_bounds__(SELL_BLOCK, 8) void k_spmv_sell(
+    const unsigned *__restrict__ soff, const void *__restrict__ scolv, const int *__restrict__ cbaseS,
+    const void *__restrict__ svalv, const double *__restrict__ dict, const unsigned char *__restrict__ rlen,
+    int rows, int nslices, int64_t nblk, const double *__restrict__ x, double *__restrict__ y,
+    const SpmvCoef *__restrict__ coef, const int *__restrict__ stop, double *__restrict__ partials,
+    const double *__restrict__ pin, int npin, const NormSlot *__restrict__ slot_in,
+    NormSlot *__restrict__ slot_out, int skip_if_zero, Rider rider)
+{
+    __shared__ double red[SELL_BLOCK / WAVE + 1];
+    __shared__ double sdict[V8 ? VD_MAX : 1];
+    // block 0 carries the scalar rider (scalar.h), as in k_spmv_fused
+    const int shift = rider.kind != 0 ? 1 : 0;
+    const int nwg = (int)gridDim.x - shift;
+    const int wg = (int)blockIdx.x - shift;
+    if (wg < 0) {
+        run_rider(rider, red);
+        return;
+    }
+    if (*stop != 0) return;
+    const int tid = threadIdx.x;
+    if (V8) sdict[tid] = dict[tid];  // visible after the first barrier below
+
+    double sx, sy, cy;
+    if (pin != nullptr) {  // lazy coefficients (spmv.h)
+        const double nrm = sqrt(block_sum_all<SELL_BLOCK>(pin, npin, red));
+        if (skip_if_zero && !(nrm > 0.0)) return;
+        sx = nrm > 0.0 ? 1.0 / nrm : 1.0;
+        cy = -nrm;
+        sy = slot_in->scale;
+        if (wg == 0 && tid == 0) {
+            slot_out->nrm = nrm;
+            slot_out->scale = sx;
+        }
+    } else {
+        if (coef->skip != 0) return;
+        sx = coef->sx;
+        sy = coef->sy;
+        cy = coef->cy;
+    }
+    if (V8) __syncthreads();
+
+    const int *__restrict__ sc32 = static_cast<const int *>(scolv);
+    const unsigned short *__restrict__ sc16 = static_cast<const unsigned short *>(scolv);
+    const double *__restrict__ sv = static_cast<const double *>(svalv);
+    const unsigned char *__restrict__ sv8 = static_cast<const unsigned char *>(svalv);
+    const int lane = tid & (WAVE - 1), wave = tid >> 6;
+
+    double sq = 0.0;
+    const XcdRange xr = xcd_range(nblk, nwg, wg);
+    for (int64_t b = xr.first; b < xr.end; b += xr.stride) {
+        const int s = (int)(b * SELL_SLICES) + wave;  // wave-uniform
+        if (s >= nslices) continue;
+        const unsigned o0 = (unsigned)__builtin_amdgcn_readfirstlane((int)soff[s]);
+        const unsigned o1 = (unsigned)__builtin_amdgcn_readfirstlane((int)soff[s + 1]);
+        const int W = (int)((o1 - o0) >> 6);
+        const int cb = C16 ? __builtin_amdgcn_readfirstlane(cbaseS[s]) : 0;
+        const int r = s * WAVE + lane;
+        const bool active = r < rows;
+        const int rc = active ? r : rows - 1;
+        const int len = active ? (int)rlen[rc] : 0;
+        const double y0 = y[rc];
+        double sum = 0.0;
+        size_t e = (size_t)o0 + lane;
+        int k0 = 0;
+        for (; W - k0 >= 8; k0 += 8, e += 8 * 64)
+            sum = sell_chunk<8, C16, V8>(sum, e, k0, len, cb, sc32, sc16, sv, sv8, sdict, x, sx);
+        switch (W - k0) {  // uniform
+        case 7: sum = sell_chunk<7, C16, V8>(sum, e, k0, len, cb, sc32, sc16, sv, sv8, sdict, x, sx); break;
+        case 6: sum = sell_chunk<6, C16, V8>(sum, e, k0, len, cb, sc32, sc16, sv, sv8, sdict, x, sx); break;
+        case 5: sum = sell_chunk<5, C16, V8>(sum, e, k0, len, cb, sc32, sc16, sv, sv8, sdict, x, sx); break;
+        case 4: sum = sell_chunk<4, C16, V8>(sum, e, k0, len, cb, sc32, sc16, sv, sv8, sdict, x, sx); break;
+        case 3: sum = sell_chunk<3, C16, V8>(sum, e, k0, len, cb, sc32, sc16, sv, sv8, sdict, x, sx); break;
+        case 2: sum = sell_chunk<2, C16, V8>(sum, e, k0, len, cb, sc32, sc16, sv, sv8, sdict, x, sx); break;
+        case 1: sum = sell_chunk<1, C16, V8>(sum, e, k0, len, cb, sc32, sc16, sv, sv8, sdict, x, sx); break;
+        default: break;
+        }
+        if (active) {
+            const double yn = cy * (y0 * sy) + sum;
+            y[r] = yn;
+            sq += yn * yn;
+        }
+    }
+    const double tot = block_sum<SELL_BLOCK>(sq, red);
+    if (tid == 0) partials[wg] = tot;
+}
+
+}  // namespace lsqrhip

@@ -82,9 +82,37 @@ static void launch_spmv_T(const SpmvArgs &a, double *y, hipEvent_t e0, hipEvent_
     }
 }
 
+template <bool C16, bool V8>
+static void launch_sell_C(const SpmvArgs &a)
+{
+    const Csr &c = *a.c;
+    const dim3 grid(c.grid + (a.rider.kind != 0 ? 1 : 0));
+    if (a.e0 == nullptr && a.e1 == nullptr)
+        hipLaunchKernelGGL((k_spmv_sell<C16, V8>), grid, dim3(SELL_BLOCK), 0, a.stream, (const unsigned *)c.soff,
+                           (const void *)c.scol, (const int *)c.cbaseS, (const void *)c.sval, (const double *)c.dict,
+                           (const unsigned char *)c.rlen, c.rows, c.nslices, c.nblk, a.x, a.y, a.coef, a.stop, a.pout,
+                           a.pin, a.npin, a.slot_in, a.slot_out, a.skip_if_zero, a.rider);
+    else
+        hipExtLaunchKernelGGL((k_spmv_sell<C16, V8>), grid, dim3(SELL_BLOCK), 0, a.stream, a.e0, a.e1, 0,
+                              (const unsigned *)c.soff, (const void *)c.scol, (const int *)c.cbaseS,
+                              (const void *)c.sval, (const double *)c.dict, (const unsigned char *)c.rlen, c.rows,
+                              c.nslices, c.nblk, a.x, a.y, a.coef, a.stop, a.pout, a.pin, a.npin, a.slot_in,
+                              a.slot_out, a.skip_if_zero, a.rider);
+}
+
 static void launch_spmv_args(H *h, const SpmvArgs &a)
 {
     const Csr &c = *a.c;
+    if (c.sell) {  // sliced-ELL layout (sell.h)
+        if (c.sell_c16) {
+            if (c.sell_v8) launch_sell_C<true, true>(a);
+            else launch_sell_C<true, false>(a);
+        } else {
+            if (c.sell_v8) launch_sell_C<false, true>(a);
+            else launch_sell_C<false, false>(a);
+        }
+        return;
+    }
     if (c.P <= 1) {
         if (h->off64) launch_spmv_T<long long, false>(a, a.y, a.e0, a.e1);
         else launch_spmv_T<int, false>(a, a.y, a.e0, a.e1);

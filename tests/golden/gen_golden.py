@@ -78,7 +78,7 @@ def main():
         if p.nnz > 1:
             sx = sa = sr = 0.0
             itns, istops = {r.itn}, {r.istop}
-            for seed in (1, 2, 3):
+            for seed in range(1, 13):   # 12 permutations: itn at a tolerance crossing needs a real sample
                 q = P.shuffled(p, seed)
                 rq = rf.solve(q.m, q.n, q.irow, q.icol, q.a, q.b, **o)
                 nx = float(np.linalg.norm(r.x))

@@ -1,0 +1,160 @@
+"""Storage formats behind aprod: the sliced-ELL layout for short even rows (csrc/sell.h), the
+one-byte value dictionary (csrc/valdict.h) and 16-bit columns.  None of them may change a
+result: aprod must stay bit-identical to the reference's row sums (oracle), and every
+combination of formats must agree with every other on a whole solve."""
+import itertools
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from lsqr_amd import problems as P
+from lsqr_amd.solver import lsqr_solver_ez
+
+pytestmark = pytest.mark.gpu
+
+KNOBS = ("LSQRHIP_SELL", "LSQRHIP_VAL8", "LSQRHIP_COL16", "LSQRHIP_PANELS", "LSQRHIP_PANEL_KB")
+
+
+@pytest.fixture(autouse=True)
+def clean_env():
+    old = {k: os.environ.pop(k, None) for k in KNOBS}
+    yield
+    for k, v in old.items():
+        os.environ.pop(k, None)
+        if v is not None:
+            os.environ[k] = v
+
+
+def _vec(stream, n):
+    return P.u64_to_unit(P.rng_u64(101, stream, np.arange(n, dtype=np.uint64)))
+
+
+def _banded_real(m, n, seed=3):
+    """Tridiagonal-plus-far-diagonal matrix with arbitrary real values (no dictionary), ragged
+    at the ends, with a few empty rows."""
+    rows, cols = [], []
+    for off in (-7, -1, 0, 1, 7):
+        r = np.arange(m)
+        c = r + off
+        ok = (c >= 0) & (c < n) & (r % 97 != 5)      # rows = 5 mod 97 are empty
+        rows.append(r[ok]); cols.append(c[ok])
+    irow = np.concatenate(rows); icol = np.concatenate(cols)
+    order = np.lexsort((icol, irow))
+    irow, icol = irow[order], icol[order]
+    a = P.u64_to_unit(P.rng_u64(seed, 1, np.arange(irow.size, dtype=np.uint64)))
+    b = _vec(7, m)
+    return m, n, (irow + 1).astype(np.int32), (icol + 1).astype(np.int32), a, b
+
+
+def test_default_formats_for_a_stencil():
+    p = P.poisson2d(300, 200)
+    s = lsqr_solver_ez().initialize(p.m, p.n, p.a, p.irow, p.icol)
+    info = s.info()
+    assert info["sell"] == 1 and info["sell_t"] == 1
+    assert info["dict_entries"] == 2 and info["value_bytes"] == 1     # {4, -1}
+    assert info["col_bytes"] == 2 and info["colt_bytes"] == 2
+    os.environ["LSQRHIP_SELL"] = "0"
+    os.environ["LSQRHIP_VAL8"] = "0"
+    info = lsqr_solver_ez().initialize(p.m, p.n, p.a, p.irow, p.icol).info()
+    assert info["sell"] == 0 and info["dict_entries"] == 0 and info["value_bytes"] == 8
+
+
+def test_irregular_rows_keep_the_window_layout():
+    p = P.powerlaw_rows(20000, 30000, dmax=300, seed=2)
+    info = lsqr_solver_ez().initialize(p.m, p.n, p.a, p.irow, p.icol).info()
+    assert info["sell"] == 0 and info["sell_t"] == 0 and info["dict_entries"] == 0
+    # rows of one fixed length but scattered columns: only when forced; the ragged transpose never
+    p = P.random_rows(20000, 200000, 8, seed=2)
+    info = lsqr_solver_ez().initialize(p.m, p.n, p.a, p.irow, p.icol).info()
+    assert info["sell"] == 0 and info["sell_t"] == 0
+    os.environ["LSQRHIP_SELL"] = "1"
+    info = lsqr_solver_ez().initialize(p.m, p.n, p.a, p.irow, p.icol).info()
+    assert info["sell"] == 1 and info["sell_t"] == 0 and info["col_bytes"] == 4
+
+
+@pytest.mark.parametrize("problem", ["poisson", "banded_real", "poisson_tall", "random_fixed"])
+def test_every_format_combination_gives_the_same_bits(problem):
+    if problem == "poisson":
+        p = P.poisson2d(257, 131)
+        m, n, irow, icol, a, b = p.m, p.n, p.irow, p.icol, p.a, p.b
+    elif problem == "poisson_tall":
+        p = P.poisson2d(64, 3)                       # exactly 3 slices, boundary rows everywhere
+        m, n, irow, icol, a, b = p.m, p.n, p.irow, p.icol, p.a, p.b
+    elif problem == "random_fixed":                  # 8 per row, scattered columns: 32-bit SELL when forced
+        p = P.random_rows(30000, 200000, 8, seed=4)
+        m, n, irow, icol, a, b = p.m, p.n, p.irow, p.icol, p.a, p.b
+    else:
+        m, n, irow, icol, a, b = _banded_real(70001, 70003)
+    po = oracle.port()
+    xp, yp = _vec(9, n), _vec(10, m)
+    _, y_ref = po.aprod(1, m, n, irow, icol, a, xp, yp)
+    x_ref, _ = po.aprod(2, m, n, irow, icol, a, xp, yp)
+    o = po.solve(m, n, irow, icol, a, b, damp=0.0, itnlim=30)
+    results = []
+    for sell, val8, col16 in itertools.product("10", repeat=3):
+        os.environ.update(LSQRHIP_SELL=sell, LSQRHIP_VAL8=val8, LSQRHIP_COL16=col16)
+        s = lsqr_solver_ez().initialize(m, n, a, irow, icol, itnlim=30)
+        info = s.info()
+        assert info["sell"] == int(sell)
+        x, y = xp.copy(), yp.copy()
+        s.aprod(1, m, n, x, y)
+        assert np.array_equal(y, y_ref), (sell, val8, col16)      # the reference's row sums, bit for bit
+        x, y = xp.copy(), yp.copy()
+        s.aprod(2, m, n, x, y)
+        assert np.array_equal(x, x_ref), (sell, val8, col16)
+        r = s.solve(b, 0.0)
+        assert (r.istop, r.itn) == (o.istop, o.itn)
+        assert np.linalg.norm(r.x - o.x) <= 1e-10 * np.linalg.norm(o.x)
+        assert abs(r.anorm - o.anorm) <= 1e-10 * o.anorm and abs(r.rnorm - o.rnorm) <= 1e-10 * max(o.rnorm, 1e-300)
+        results.append((sell, r))
+    # the value dictionary and the column width never change a bit within one layout
+    for layout in "10":
+        rs = [r for s_, r in results if s_ == layout]
+        for r in rs[1:]:
+            assert np.array_equal(r.x, rs[0].x) and r.anorm == rs[0].anorm and r.rnorm == rs[0].rnorm
+
+
+def test_dictionary_preserves_signed_zero_and_many_values():
+    """200 distinct values including -0.0 and +0.0 (distinct bit patterns): the coded matrix must
+    reproduce the 8-byte one exactly; 300 distinct values must fall back to 8-byte storage."""
+    m = n = 20000
+    for nvals, expect in ((200, 200), (300, 0)):
+        table = np.linspace(-3.0, 3.0, nvals)
+        table[0], table[1] = -0.0, 0.0
+        rows, cols = [], []
+        for off in (-2, 0, 3):
+            r = np.arange(m); c = r + off
+            ok = (c >= 0) & (c < n)
+            rows.append(r[ok]); cols.append(c[ok])
+        irow = np.concatenate(rows); icol = np.concatenate(cols)
+        order = np.lexsort((icol, irow))
+        irow, icol = irow[order], icol[order]
+        a = table[(P.rng_u64(5, 2, np.arange(irow.size, dtype=np.uint64)) % np.uint64(nvals)).astype(np.int64)]
+        irow1, icol1 = (irow + 1).astype(np.int32), (icol + 1).astype(np.int32)
+        s = lsqr_solver_ez().initialize(m, n, a, irow1, icol1)
+        assert s.info()["dict_entries"] == expect
+        xp, yp = _vec(3, n), np.zeros(m)
+        x, y = xp.copy(), yp.copy()
+        s.aprod(1, m, n, x, y)
+        _, y_ref = oracle.port().aprod(1, m, n, irow1, icol1, a, xp, yp)
+        assert np.array_equal(y, y_ref) and np.array_equal(np.signbit(y), np.signbit(y_ref))
+
+
+def test_sell_handles_non_finite_x_like_the_reference():
+    """Padding slots are loaded but never added: an inf in x must reach exactly the rows whose
+    real entries touch it (0 * inf would poison whole slices otherwise)."""
+    p = P.poisson2d(100, 100)
+    s = lsqr_solver_ez().initialize(p.m, p.n, p.a, p.irow, p.icol)
+    assert s.info()["sell"] == 1
+    xp = _vec(4, p.n)
+    xp[0] = np.inf            # column 1 is every slice's... smallest column only for slice 0
+    xp[5000] = np.inf
+    y = np.zeros(p.m)
+    x = xp.copy()
+    s.aprod(1, p.m, p.n, x, y)
+    with np.errstate(invalid="ignore"):
+        _, y_ref = oracle.port().aprod(1, p.m, p.n, p.irow, p.icol, p.a, xp, np.zeros(p.m))
+    assert np.array_equal(y, y_ref, equal_nan=True)
+    assert np.isfinite(y).sum() == np.isfinite(y_ref).sum() >= p.m - 10

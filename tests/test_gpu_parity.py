@@ -64,17 +64,23 @@ def test_solve_parity_vs_reference_golden(name):
         assert np.linalg.norm(r.x - gx) / nx <= tx
     else:
         assert np.all(r.x == 0.0)
-    stable = len(sens["itn"]) == 1          # the reference's own itn does not move under permutation
-    if stable:
+    # itn is pinned only where the reference's own iteration count AND its own stopping
+    # quantities do not move when its COO input is permuted (12 permutations, gen_golden.py):
+    # anorm enters every stopping test (src/lsqr.f90:759-790), so a run whose anorm drifts by
+    # 1e-4 under a permutation has no well-defined crossing iteration.
+    pinned = len(sens["itn"]) == 1 and max(sens["anorm"], sens["rnorm"]) <= 1e-6
+    if pinned:
         assert r.itn == g["itn"]
+    else:
+        assert min(sens["itn"]) - 1 <= r.itn <= max(sens["itn"]) + 1
+    stable = r.itn == g["itn"]              # same iteration -> the norms are comparable
+    if stable:
         assert rel(r.anorm, fh(g["anorm"])) <= max(TOL, 10 * sens["anorm"]) or fh(g["anorm"]) == 0.0
         if g["rnorm"] is not None:
             grn = fh(g["rnorm"])
             # a residual at rounding level (rnorm/bnorm ~ eps) has no significant digits
             assert rel(r.rnorm, grn) <= max(TOL, 10 * sens["rnorm"]) or grn <= 1e-13 * np.linalg.norm(p.b)
         assert rel(r.xnorm, fh(g["xnorm"])) <= max(1e-9, 10 * sens["x"]) or fh(g["xnorm"]) == 0.0
-    else:
-        assert min(sens["itn"]) - 1 <= r.itn <= max(sens["itn"]) + 1
     if g["rnorm"] is None:                   # istop = 0: rnorm defined as norm(b) (documented fix)
         assert r.rnorm == pytest.approx(np.linalg.norm(p.b), rel=1e-14)
     if o["wantse"]:
