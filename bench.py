@@ -12,8 +12,9 @@ already resident in HBM; W warm-up iterations run first as a separate solve.
 N = 1 workload: BASELINE.json configs[1] -- 1M x 1M 5-point Poisson (nnz 4 996 000),
 damp = 0.  N > 1: the row-block sharded solve (lsqr_amd/dist.py).
 
-Prints ONE JSON line (rank 0) with `roofline` (dominant kernel = mode-1 CSR SpMV, live HIP
-event timing) and `cpu_baseline` (the reference's own CPU path, 1 core, bounded sample).
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel = mode-1 SpMV, live HIP event
+timing, bytes of the layout the build chose) and `cpu_baseline` (the reference's own CPU path,
+1 core, bounded sample).
 """
 from __future__ import annotations
 
@@ -138,7 +139,16 @@ def run_single(args):
         # event pair per launch adds ~2 us of marker latency to a 17 us kernel).
         reps = K if p.nnz < 50_000_000 else max(10, min(K, 40))
         avg1, avg2, avg3 = (s.bench_kernel(w, reps) for w in (1, 2, 3))
-        ach = t2.spmv1_bytes / (avg1 * 1e-3) / 1e9
+        # Bytes one product must move IN THE LAYOUT THE BUILD CHOSE: the matrix as
+        # stored (lsqrhip_info: sliced-ELL / row windows, 1- or 8-byte values, 2- or 4-byte
+        # columns) + x once + y read and written.  SURVEY 8(d)'s CSR figure (8-byte values, 4-byte
+        # columns) is reported beside it; with a value dictionary it exceeds what is moved.
+        info = s.info()
+        fmt1 = info["csr_bytes"] + 8 * p.n + 16 * p.m
+        fmt2 = info["csrt_bytes"] + 8 * p.m + 16 * p.n
+        layout = "sell" if info["sell"] else ("panels" if info["panels"] > 1 else "row-windows")
+        kname = "k_spmv_sell" if info["sell"] else "k_spmv_fused"
+        ach = fmt1 / (avg1 * 1e-3) / 1e9
         traffic = None
         tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tp):
@@ -146,14 +156,20 @@ def run_single(args):
                 traffic = json.load(open(tp)).get(spec, {}).get("spmv_mode1_hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        out["roofline"] = {"bound": "hbm", "kernel": "k_spmv_fused (aprod mode 1, CSR of A)",
+        out["roofline"] = {"bound": "hbm", "kernel": f"{kname} (aprod mode 1)",
                            "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                           "traffic": traffic, "bytes_per_launch": t2.spmv1_bytes,
+                           "traffic": traffic, "bytes_per_launch": fmt1,
                            "avg_launch_us": avg1 * 1e3, "launches": reps,
-                           "in_loop_event_pair_us": in_loop[0] * 1e3}
+                           "in_loop_event_pair_us": in_loop[0] * 1e3,
+                           "format": {"layout": layout, "value_bytes": info["value_bytes"],
+                                      "col_bytes": info["col_bytes"], "dict_entries": info["dict_entries"]},
+                           "survey_8d_bytes": t2.spmv1_bytes,
+                           "survey_8d_gbps": t2.spmv1_bytes / (avg1 * 1e-3) / 1e9}
+        out["iter_format_bytes"] = fmt1 + fmt2 + t2.vec_bytes
+        out["iter_format_gbps"] = (fmt1 + fmt2 + t2.vec_bytes) * K / dt / 1e9
         out["kernels"] = {
-            "spmv_mode2": {"avg_launch_us": avg2 * 1e3, "bytes_per_launch": t2.spmv2_bytes,
-                           "gbps": t2.spmv2_bytes / (avg2 * 1e-3) / 1e9, "in_loop_event_pair_us": in_loop[1] * 1e3},
+            "spmv_mode2": {"avg_launch_us": avg2 * 1e3, "bytes_per_launch": fmt2,
+                           "gbps": fmt2 / (avg2 * 1e-3) / 1e9, "in_loop_event_pair_us": in_loop[1] * 1e3},
             "update_xw": {"avg_launch_us": avg3 * 1e3, "bytes_per_launch": t2.vec_bytes,
                           "gbps": t2.vec_bytes / (avg3 * 1e-3) / 1e9, "in_loop_event_pair_us": in_loop[2] * 1e3},
         }

@@ -351,8 +351,8 @@ static int try_sell(hipStream_t s, Csr &out, int64_t nnz, const double *dict, in
     out.sell_v8 = v8;
     out.dict = dict;
     out.nblk = (nslices + SELL_SLICES - 1) / SELL_SLICES;
-    out.bytes = (int64_t)sizeof(int) * (rows + 1) + (int64_t)padded * ((c16 ? 2 : 4) + (v8 ? 1 : 8)) +
-                (int64_t)nslices * 8 + rows;
+    // what one product reads of the matrix (the row pointers stay allocated but are not read)
+    out.bytes = (int64_t)padded * ((c16 ? 2 : 4) + (v8 ? 1 : 8)) + (int64_t)nslices * 8 + 4 + rows;
     return LSQRHIP_OK;
 }
 
