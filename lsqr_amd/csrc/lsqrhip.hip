@@ -526,7 +526,14 @@ static int build_dictionary(H *h, const double *d_a, unsigned long long *table, 
     keys.resize(VD_MAX, keys.back());  // padded: the SpMV loads all 256 entries
     HIPCHK(hipMalloc((void **)&h->dict, sizeof(double) * VD_MAX));
     HIPCHK(hipMemcpy(h->dict, keys.data(), sizeof(double) * VD_MAX, hipMemcpyHostToDevice));
-    h->ndict = got[0];
+    // every value must be in the table before a single code is written
+    HIPCHK(hipMemsetAsync(ctl, 0, sizeof(int), s));
+    hipLaunchKernelGGL(k_dict_verify, dim3(g), dim3(256), 0, s, d_a, nnz, (const unsigned long long *)h->dict, got[0], ctl);
+    HIPCHK(hipGetLastError());
+    int missing = 1;
+    HIPCHK(hipMemcpyAsync(&missing, ctl, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    h->ndict = missing ? 0 : got[0];
     return LSQRHIP_OK;
 }
 

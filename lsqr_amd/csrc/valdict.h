@@ -75,6 +75,30 @@ __global__ __launch_bounds__(256) void k_dict_collect(const double *__restrict__
     }
 }
 
+// *missing |= 1 if some val[k] is not in the ascending table dict_bits[nd]: the build only uses
+// a dictionary that provably holds every value of the matrix.
+__global__ __launch_bounds__(256) void k_dict_verify(const double *__restrict__ val, int64_t nnz,
+                                                     const unsigned long long *__restrict__ dict_bits, int nd,
+                                                     int *__restrict__ missing)
+{
+    __shared__ unsigned long long tab[VD_MAX];
+    if ((int)threadIdx.x < nd) tab[threadIdx.x] = dict_bits[threadIdx.x];
+    __syncthreads();
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int bad = 0;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nnz; k += stride) {
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(val[k]);
+        int lo = 0, hi = nd - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (tab[mid] < bits) lo = mid + 1;
+            else hi = mid;
+        }
+        if (tab[lo] != bits) bad = 1;
+    }
+    if (bad) atomicOr(missing, 1);
+}
+
 // code[k] = index of val[k]'s bit pattern in the ascending table dict_bits[nd] (nd <= 256).
 __global__ __launch_bounds__(256) void k_dict_encode(const double *__restrict__ val, int64_t nnz,
                                                      const unsigned long long *__restrict__ dict_bits, int nd,
