@@ -174,7 +174,10 @@ int lsqrhip_bench_kernel(lsqrhip_handle_t h, int which, int reps, double *avg_ms
 
 /* Options: "graph" (1 = hipGraph-captured iteration batches [default], 0 = eager
  * launches), "graph_iters" (iterations per captured batch), "time_kernels"
- * (1 = eager launches with HIP events around each hot kernel, fills *_ms above). */
+ * (1 = eager launches with HIP events around each hot kernel, fills *_ms above),
+ * "pipeline" (launch schedule of the loop; all three give the same bits:
+ * 0 = K1 S1 K2 S2 K4 S3, 1 = scalar steps ride inside the SpMV launches,
+ * 2 = additionally the x/w update rides inside the mode-1 launch [default]). */
 int lsqrhip_set_option(lsqrhip_handle_t h, const char *name, int64_t value);
 /* Run all work of this handle on an externally owned hipStream_t (e.g. the
  * caller's torch stream); NULL restores the handle's own stream. */

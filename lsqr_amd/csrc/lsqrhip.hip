@@ -179,7 +179,7 @@ struct lsqrhip_handle_s {
     hipEvent_t ev_loop0 = nullptr, ev_loop1 = nullptr;
     lsqrhip_timing_t timing{};
     // rider schedule (solve_loop.h)
-    int pipeline = 1;
+    int pipeline = 2;  // 0 sequential | 1 riders | 2 riders + x/w update fused into mode 1 (solve_loop.h)
     int gexec_pipeline = -1;
     double *P1[2] = {nullptr, nullptr};  // mode-1 partials by iteration parity
     double *P2[2] = {nullptr, nullptr};  // mode-2 partials by iteration parity
@@ -1028,7 +1028,7 @@ extern "C" int lsqrhip_set_option(lsqrhip_handle_t h, const char *name, int64_t 
         if (value < 1 || value > 1024) return fail(LSQRHIP_ERR_ARG, "graph_iters must be in [1,1024]");
         h->graph_iters = (int)value;
     } else if (k == "time_kernels") h->time_kernels = value != 0;
-    else if (k == "pipeline") h->pipeline = value != 0;
+    else if (k == "pipeline") h->pipeline = value < 0 ? 0 : (value > 2 ? 2 : (int)value);
     else return fail(LSQRHIP_ERR_ARG, "unknown option: " + k);
     return LSQRHIP_OK;
 }

@@ -63,6 +63,43 @@ __device__ __forceinline__ void s1_step(LsqrState *st, double sum)
     st->c2p.skip = st->c2.skip;
 }
 
+// The damping rotation and the QR rotation of one iteration (src/lsqr.f90:703-721) and the
+// coefficients of the x/w update (:729-745).  A pure function of its arguments: the scalar
+// machine (s2_step) and every workgroup of a fused mode-1 + update kernel evaluate it on the
+// same inputs and get the same bits.
+struct Rot {
+    double psi, phibar, rhobar, rho, phi, theta, tau, t1, t2, t3;
+};
+__device__ __forceinline__ Rot rot_step(double rhobar, double phibar, double damp, int damped, double alpha,
+                                        double beta)
+{
+    Rot r;
+    double rhbar1 = rhobar;
+    r.psi = 0.0;
+    if (damped) {
+        rhbar1 = d2norm(rhobar, damp);
+        const double cs1 = rhobar / rhbar1;
+        const double sn1 = damp / rhbar1;
+        r.psi = sn1 * phibar;
+        phibar = cs1 * phibar;
+    }
+    const double rho = d2norm(rhbar1, beta);
+    const double cs = rhbar1 / rho;
+    const double sn = beta / rho;
+    const double theta = sn * alpha;
+    r.rhobar = -cs * alpha;
+    const double phi = cs * phibar;
+    r.phibar = sn * phibar;
+    r.tau = sn * phi;
+    r.rho = rho;
+    r.phi = phi;
+    r.theta = theta;
+    r.t1 = phi / rho;
+    r.t2 = -theta / rho;
+    r.t3 = 1.0 / rho;
+    return r;
+}
+
 // ---- step 2: after mode 2.  alpha = norm(A'u - beta v); rotations; update coefficients (:695-726)
 __device__ __forceinline__ void s2_step(LsqrState *st, double sum, bool skipped)
 {
@@ -73,30 +110,18 @@ __device__ __forceinline__ void s2_step(LsqrState *st, double sum, bool skipped)
         st->alpha = alpha;
         st->sv = alpha > 0.0 ? 1.0 / alpha : 1.0;
     }
-    const double damp = st->damp;
-    double phibar = st->phibar;
-    double rhbar1 = st->rhobar;
-    if (st->damped) {
-        rhbar1 = d2norm(st->rhobar, damp);
-        const double cs1 = st->rhobar / rhbar1;
-        const double sn1 = damp / rhbar1;
-        st->psi = sn1 * phibar;
-        phibar = cs1 * phibar;
-    }
-    const double rho = d2norm(rhbar1, beta);
-    const double cs = rhbar1 / rho;
-    const double sn = beta / rho;
-    const double theta = sn * alpha;
-    st->rhobar = -cs * alpha;
-    const double phi = cs * phibar;
-    st->phibar = sn * phibar;
-    st->tau = sn * phi;
-    st->rho = rho;
-    st->phi = phi;
-    st->theta = theta;
-    st->t1 = phi / rho;
-    st->t2 = -theta / rho;
-    st->t3 = 1.0 / rho;
+    const int k = st->itn & 1;  // s1_step has already advanced itn to this iteration
+    const Rot r = rot_step(st->rhobar2[k ^ 1], st->phibar2[k ^ 1], st->damp, st->damped, alpha, beta);
+    if (st->damped) st->psi = r.psi;
+    st->rhobar2[k] = r.rhobar;
+    st->phibar2[k] = r.phibar;
+    st->tau = r.tau;
+    st->rho = r.rho;
+    st->phi = r.phi;
+    st->theta = r.theta;
+    st->t1 = r.t1;
+    st->t2 = r.t2;
+    st->t3 = r.t3;
     st->c1.sx = st->sv;
     st->c1.sy = st->su;
     st->c1.cy = -alpha;
@@ -157,8 +182,8 @@ __global__ __launch_bounds__(SC_BLOCK) void k_s_init2(const double *partials, in
         st->stop = 1;  // istop stays 0: x = 0 is the exact solution
         return;
     }
-    st->rhobar = alpha;
-    st->phibar = beta;
+    st->rhobar2[0] = alpha;  // itn = 0
+    st->phibar2[0] = beta;
     st->c1.sx = st->sv;
     st->c1.sy = st->su;
     st->c1.cy = -alpha;
@@ -232,7 +257,7 @@ __device__ __forceinline__ void s3_step(LsqrState *st, double sum, const double 
     const double acond = anorm * dnorm;
     st->acond = acond;
     st->res2 = d2norm(st->res2, st->psi);
-    const double rnorm = d2norm(st->res2, st->phibar);
+    const double rnorm = d2norm(st->res2, st->phibar2[itn & 1]);
     st->rnorm = rnorm;
     const double arnorm = alpha * fabs(tau);
     st->arnorm = arnorm;

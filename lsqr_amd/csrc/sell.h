@@ -36,6 +36,7 @@
 #include "scalar.h"
 #include "state.h"
 #include "valdict.h"
+#include "vec.h"
 
 namespace lsqrhip {
 
@@ -176,14 +177,17 @@ __device__ __forceinline__ double sell_chunk(double sum, size_t e, int k0, int l
     return sum;
 }
 
-template <bool C16, bool V8>
+static_assert(SELL_BLOCK == VEC_BLOCK, "the fused update runs k_update's blocks");
+
+// UPD = true: the launch also carries the x/w update of the previous iteration (UpdArgs).
+template <bool C16, bool V8, bool UPD>
 __global__ __launch_bounds__(SELL_BLOCK, 8) void k_spmv_sell(
     const unsigned *__restrict__ soff, const void *__restrict__ scolv, const int *__restrict__ cbaseS,
     const void *__restrict__ svalv, const double *__restrict__ dict, const unsigned char *__restrict__ rlen,
     int rows, int nslices, int64_t nblk, const double *__restrict__ x, double *__restrict__ y,
     const SpmvCoef *__restrict__ coef, const int *__restrict__ stop, double *__restrict__ partials,
     const double *__restrict__ pin, int npin, const NormSlot *__restrict__ slot_in,
-    NormSlot *__restrict__ slot_out, int skip_if_zero, Rider rider)
+    NormSlot *__restrict__ slot_out, int skip_if_zero, Rider rider, UpdArgs upd)
 {
     __shared__ double red[SELL_BLOCK / WAVE + 1];
     __shared__ double sdict[V8 ? VD_MAX : 1];
@@ -202,13 +206,35 @@ __global__ __launch_bounds__(SELL_BLOCK, 8) void k_spmv_sell(
     double sx, sy, cy;
     if (pin != nullptr) {  // lazy coefficients (spmv.h)
         const double nrm = sqrt(block_sum_all<SELL_BLOCK>(pin, npin, red));
-        if (skip_if_zero && !(nrm > 0.0)) return;
+        if (skip_if_zero && !(nrm > 0.0)) {  // mode 2 is skipped when beta == 0 (:691)
+            if (wg == 0 && tid == 0) {
+                slot_out->nrm = nrm;
+                slot_out->scale = 1.0;
+            }
+            return;
+        }
         sx = nrm > 0.0 ? 1.0 / nrm : 1.0;
         cy = -nrm;
         sy = slot_in->scale;
         if (wg == 0 && tid == 0) {
             slot_out->nrm = nrm;
             slot_out->scale = sx;
+        }
+        if (UPD && upd.on) {  // x/w update of the previous iteration (vec.h UpdArgs)
+            const double beta = slot_in->nrm;
+            double alpha = nrm, sv = sx;
+            if (!(beta > 0.0)) {  // mode 2 was skipped (src/lsqr.f90:691): alpha, v unchanged
+                alpha = upd.alpha_prev->nrm;
+                sv = upd.alpha_prev->scale;
+            }
+            const LsqrState *ust = upd.st;
+            const Rot rt = rot_step(ust->rhobar2[upd.par], ust->phibar2[upd.par], ust->damp, ust->damped, alpha, beta);
+            const bool wantse = ust->wantse != 0;
+            for (int ub = wg; ub < upd.ugrid; ub += nwg) {
+                const double tot = update_block(upd.x, upd.w, upd.V, upd.se, upd.n, rt.t1, rt.t2, rt.t3, sv, wantse,
+                                                ub, upd.ugrid, red);
+                if (tid == 0) upd.pout[ub] = tot;
+            }
         }
     } else {
         if (coef->skip != 0) return;

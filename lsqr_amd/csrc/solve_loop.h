@@ -1,10 +1,10 @@
 // solve_loop.h -- the device-resident LSQR loop (included by lsqrhip.hip).
 //
-// Two schedules over the same kernels (results are bit-identical; tests compare them):
+// Three schedules over the same arithmetic (results are bit-identical; tests compare them):
 //
 //  sequential ("pipeline" = 0)      K1 -> S1 -> K2 -> S2 -> K4 -> S3            6 launches / iteration
 //
-//  riders     ("pipeline" = 1, default)                                          3 launches / iteration
+//  riders     ("pipeline" = 1)                                                   3 launches / iteration
 //      K1(i+1) (+) S12(i)  ->  K4(i)  ->  K2(i+1) (+) S3(i)  ->  K1(i+2) (+) S12(i+1)  -> ...
 //
 //      K1 = mode-1 SpMV, K2 = mode-2 SpMV, K4 = x/w update, S* = the scalar steps (scalar.h).
@@ -24,6 +24,20 @@
 //      even number of iterations so a captured graph replays with the right parity.  Each
 //      batch ends with the last iteration's S12 -> K4 -> S3 as plain kernels so that the host
 //      polls a settled state.
+//
+//  fused update ("pipeline" = 2, default; needs a non-panelled A)               2 launches / iteration
+//      K1(i+1) (+) S12(i) (+) K4(i)  ->  K2(i+1) (+) S3(i)  ->  ...
+//
+//      K4(i) needs t1, t2, t3 of iteration i, which S12(i) computes in the SAME launch.  Every
+//      workgroup therefore evaluates the rotation itself (scalar.h rot_step: a dozen flops)
+//      from inputs that are complete before the launch: alpha (its own lazy norm), beta (the
+//      slot mode 2 published) and rhobar / phibar of iteration i-1, which the state keeps by
+//      iteration parity so that the rider's writes for iteration i land in the other slot.
+//      Same function, same inputs => the same bits as the scalar machine.  Each workgroup then
+//      runs whole blocks of k_update's own decomposition (vec.h update_block), so the update
+//      partials -- and with them dnorm, acond and the stopping tests -- are bit-identical to
+//      the separate kernel's.  Removes a launch boundary and lets the update's streaming
+//      traffic overlap the latency-bound SpMV phases.
 //
 //      (A two-stream variant -- scalar machine and K4 on a side stream beside the next
 //      SpMV -- was measured first: 73 us/iteration device time against 60 sequential.
@@ -46,11 +60,12 @@ struct SpmvArgs {
     const int *stop = nullptr;
     double *pout = nullptr;
     Rider rider{};                   // scalar work carried by one extra workgroup (kind 0 = none)
+    UpdArgs upd{};                   // x/w update of the previous iteration carried by this launch (on = 0: none)
     hipStream_t stream = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;  // kernel begin/end timestamps (hipExtLaunchKernelGGL)
 };
 
-template <typename OffT, bool PANEL, bool C16, bool V8>
+template <typename OffT, bool PANEL, bool C16, bool V8, bool UPD>
 static void launch_spmv_C(const SpmvArgs &a, double *y, hipEvent_t e0, hipEvent_t e1)
 {
     const Csr &c = *a.c;
@@ -58,58 +73,72 @@ static void launch_spmv_C(const SpmvArgs &a, double *y, hipEvent_t e0, hipEvent_
     const void *colv = C16 ? (const void *)c.col16 : (const void *)c.col;
     const void *valv = V8 ? (const void *)c.val8 : (const void *)c.val;
     if (e0 == nullptr && e1 == nullptr)  // plain launch (the only form used under stream capture)
-        hipLaunchKernelGGL((k_spmv_fused<OffT, PANEL, C16, V8>), grid, dim3(SPMV_BLOCK), 0, a.stream,
+        hipLaunchKernelGGL((k_spmv_fused<OffT, PANEL, C16, V8, UPD>), grid, dim3(SPMV_BLOCK), 0, a.stream,
                            (const OffT *)c.rowptr, colv, (const int *)c.cbase, valv, (const double *)c.dict,
                            (const RowBlock *)c.blk, c.nblk, a.x, y, a.coef, a.stop, a.pout, a.pin, a.npin, a.slot_in,
-                           a.slot_out, a.skip_if_zero, a.rider);
+                           a.slot_out, a.skip_if_zero, a.rider, a.upd);
     else
-        hipExtLaunchKernelGGL((k_spmv_fused<OffT, PANEL, C16, V8>), grid, dim3(SPMV_BLOCK), 0, a.stream, e0, e1, 0,
+        hipExtLaunchKernelGGL((k_spmv_fused<OffT, PANEL, C16, V8, UPD>), grid, dim3(SPMV_BLOCK), 0, a.stream, e0, e1, 0,
                               (const OffT *)c.rowptr, colv, (const int *)c.cbase, valv, (const double *)c.dict,
                               (const RowBlock *)c.blk, c.nblk, a.x, y, a.coef, a.stop, a.pout, a.pin, a.npin,
-                              a.slot_in, a.slot_out, a.skip_if_zero, a.rider);
+                              a.slot_in, a.slot_out, a.skip_if_zero, a.rider, a.upd);
 }
 
 template <typename OffT, bool PANEL>
 static void launch_spmv_T(const SpmvArgs &a, double *y, hipEvent_t e0, hipEvent_t e1)
 {
     const bool v8 = a.c->val8 != nullptr;
+    if (!PANEL && a.upd.on) {  // mode 1 carrying the x/w update (never a panelled product)
+        if (a.c->col16 != nullptr) {
+            if (v8) launch_spmv_C<OffT, false, true, true, true>(a, y, e0, e1);
+            else launch_spmv_C<OffT, false, true, false, true>(a, y, e0, e1);
+        } else {
+            if (v8) launch_spmv_C<OffT, false, false, true, true>(a, y, e0, e1);
+            else launch_spmv_C<OffT, false, false, false, true>(a, y, e0, e1);
+        }
+        return;
+    }
     if (!PANEL && a.c->col16 != nullptr) {
-        if (v8) launch_spmv_C<OffT, false, true, true>(a, y, e0, e1);
-        else launch_spmv_C<OffT, false, true, false>(a, y, e0, e1);
+        if (v8) launch_spmv_C<OffT, false, true, true, false>(a, y, e0, e1);
+        else launch_spmv_C<OffT, false, true, false, false>(a, y, e0, e1);
     } else {
-        if (v8) launch_spmv_C<OffT, PANEL, false, true>(a, y, e0, e1);
-        else launch_spmv_C<OffT, PANEL, false, false>(a, y, e0, e1);
+        if (v8) launch_spmv_C<OffT, PANEL, false, true, false>(a, y, e0, e1);
+        else launch_spmv_C<OffT, PANEL, false, false, false>(a, y, e0, e1);
     }
 }
 
-template <bool C16, bool V8>
+template <bool C16, bool V8, bool UPD>
 static void launch_sell_C(const SpmvArgs &a)
 {
     const Csr &c = *a.c;
     const dim3 grid(c.grid + (a.rider.kind != 0 ? 1 : 0));
     if (a.e0 == nullptr && a.e1 == nullptr)
-        hipLaunchKernelGGL((k_spmv_sell<C16, V8>), grid, dim3(SELL_BLOCK), 0, a.stream, (const unsigned *)c.soff,
+        hipLaunchKernelGGL((k_spmv_sell<C16, V8, UPD>), grid, dim3(SELL_BLOCK), 0, a.stream, (const unsigned *)c.soff,
                            (const void *)c.scol, (const int *)c.cbaseS, (const void *)c.sval, (const double *)c.dict,
                            (const unsigned char *)c.rlen, c.rows, c.nslices, c.nblk, a.x, a.y, a.coef, a.stop, a.pout,
-                           a.pin, a.npin, a.slot_in, a.slot_out, a.skip_if_zero, a.rider);
+                           a.pin, a.npin, a.slot_in, a.slot_out, a.skip_if_zero, a.rider, a.upd);
     else
-        hipExtLaunchKernelGGL((k_spmv_sell<C16, V8>), grid, dim3(SELL_BLOCK), 0, a.stream, a.e0, a.e1, 0,
+        hipExtLaunchKernelGGL((k_spmv_sell<C16, V8, UPD>), grid, dim3(SELL_BLOCK), 0, a.stream, a.e0, a.e1, 0,
                               (const unsigned *)c.soff, (const void *)c.scol, (const int *)c.cbaseS,
                               (const void *)c.sval, (const double *)c.dict, (const unsigned char *)c.rlen, c.rows,
                               c.nslices, c.nblk, a.x, a.y, a.coef, a.stop, a.pout, a.pin, a.npin, a.slot_in,
-                              a.slot_out, a.skip_if_zero, a.rider);
+                              a.slot_out, a.skip_if_zero, a.rider, a.upd);
 }
 
 static void launch_spmv_args(H *h, const SpmvArgs &a)
 {
     const Csr &c = *a.c;
     if (c.sell) {  // sliced-ELL layout (sell.h)
-        if (c.sell_c16) {
-            if (c.sell_v8) launch_sell_C<true, true>(a);
-            else launch_sell_C<true, false>(a);
-        } else {
-            if (c.sell_v8) launch_sell_C<false, true>(a);
-            else launch_sell_C<false, false>(a);
+        const int key = (c.sell_c16 ? 4 : 0) | (c.sell_v8 ? 2 : 0) | (a.upd.on ? 1 : 0);
+        switch (key) {
+        case 7: launch_sell_C<true, true, true>(a); break;
+        case 6: launch_sell_C<true, true, false>(a); break;
+        case 5: launch_sell_C<true, false, true>(a); break;
+        case 4: launch_sell_C<true, false, false>(a); break;
+        case 3: launch_sell_C<false, true, true>(a); break;
+        case 2: launch_sell_C<false, true, false>(a); break;
+        case 1: launch_sell_C<false, false, true>(a); break;
+        default: launch_sell_C<false, false, false>(a); break;
         }
         return;
     }
@@ -188,7 +217,8 @@ static Rider rider_s3(H *h)  // step 3 of the iteration whose K4 ran last
 }
 
 // mode-1 SpMV of iteration i: alpha from the mode-2 partials of iteration i-1
-static void launch_k1(H *h, int i, const Rider &rider, hipEvent_t e0, hipEvent_t e1)
+// `fuse`: the launch also carries the x/w update of iteration i-1 (vec.h UpdArgs)
+static void launch_k1(H *h, int i, const Rider &rider, hipEvent_t e0, hipEvent_t e1, bool fuse = false)
 {
     const int par = i & 1, prev = par ^ 1;
     NormSlot *slotA = h->slots, *slotB = h->slots + 2;
@@ -196,6 +226,16 @@ static void launch_k1(H *h, int i, const Rider &rider, hipEvent_t e0, hipEvent_t
     a.c = &h->A; a.x = h->V; a.y = h->U; a.pin = h->P2[prev]; a.npin = h->AT.out_grid;
     a.slot_in = &slotB[prev]; a.slot_out = &slotA[par]; a.skip_if_zero = 0; a.stop = &h->d_state->stop;
     a.pout = h->P1[par]; a.rider = rider; a.stream = h->stream; a.e0 = e0; a.e1 = e1;
+    if (fuse) {
+        UpdArgs &u = a.upd;
+        u.on = 1;
+        u.par = (i - 2) & 1;  // the rotation of iteration i-1 reads rhobar2 / phibar2 of iteration i-2
+        u.ugrid = h->vgrid_n;
+        u.x = h->X; u.w = h->W; u.se = h->SE; u.V = h->V; u.n = h->n;
+        u.st = h->d_state;
+        u.alpha_prev = &slotA[prev];  // published by the mode-1 launch of iteration i-1
+        u.pout = h->P3;
+    }
     launch_spmv_args(h, a);
 }
 // mode-2 SpMV of iteration i: beta from the mode-1 partials of the same iteration
@@ -224,10 +264,16 @@ static int launch_batch(H *h, int i0, int G, hipEvent_t *ev)
     const Rider none{};
     launch_k1(h, i0, none, E(0, 0), E(0, 1));
     launch_k2(h, i0, none, E(0, 2), E(0, 3));
+    // pipeline 2: K4 rides inside K1 (fused update) -- two launches per iteration
+    const bool fuse = h->pipeline >= 2 && h->A.P <= 1;
     for (int j = 1; j < G; ++j) {
         const int i = i0 + j;
-        launch_k1(h, i, rider_s12(h, i - 1), E(j, 0), E(j, 1));   // K1(i)  (+) S12(i-1)
-        launch_update(h, h->P3, E(j - 1, 4), E(j - 1, 5));         // K4(i-1)
+        if (fuse) {
+            launch_k1(h, i, rider_s12(h, i - 1), E(j, 0), E(j, 1), true);  // K1(i) (+) S12(i-1) (+) K4(i-1)
+        } else {
+            launch_k1(h, i, rider_s12(h, i - 1), E(j, 0), E(j, 1));   // K1(i)  (+) S12(i-1)
+            launch_update(h, h->P3, E(j - 1, 4), E(j - 1, 5));         // K4(i-1)
+        }
         launch_k2(h, i, rider_s3(h), E(j, 2), E(j, 3));            // K2(i)  (+) S3(i-1)
     }
     const int il = i0 + G - 1;  // settle the last iteration of the batch with plain kernels
@@ -348,6 +394,7 @@ static int solve_core(H *h, const double *b, bool b_on_device, double damp, doub
     int G = std::max(1, h->graph_iters);
     if (h->pipeline) G = (G + 1) & ~1;  // even: parity-consistent batches
     const bool timed = h->time_kernels != 0;
+    const bool fused_update = h->pipeline >= 2 && h->A.P <= 1;
     const bool graph = h->use_graph != 0 && !timed;
     if (graph) RET(ensure_graph(h, G));
     if (timed && (int)h->ev.size() < 6 * G) {
@@ -377,14 +424,18 @@ static int solve_core(H *h, const double *b, bool b_on_device, double damp, doub
                 float a = 0, c = 0, d = 0;
                 (void)hipEventElapsedTime(&a, h->ev[6 * k + 0], h->ev[6 * k + 1]);
                 (void)hipEventElapsedTime(&c, h->ev[6 * k + 2], h->ev[6 * k + 3]);
-                (void)hipEventElapsedTime(&d, h->ev[6 * k + 4], h->ev[6 * k + 5]);
+                // fused schedule: only the batch's last update is a kernel of its own
+                const bool own_update = !fused_update || k == G - 1;
+                if (own_update) {
+                    (void)hipEventElapsedTime(&d, h->ev[6 * k + 4], h->ev[6 * k + 5]);
+                    tm.update_launches += 1;
+                }
                 tm.spmv1_ms += a;
                 tm.spmv2_ms += c;
                 tm.update_ms += d;
             }
             tm.spmv1_launches += live;
             tm.spmv2_launches += live;
-            tm.update_launches += live;
         }
         if (h->h_state->stop != 0) break;
     }

@@ -47,6 +47,7 @@
 #include "scalar.h"
 #include "state.h"
 #include "valdict.h"
+#include "vec.h"
 
 namespace lsqrhip {
 
@@ -54,6 +55,7 @@ constexpr int SPMV_BLOCK = 256;
 constexpr int SPMV_C = 1024;          // window size in work units (nonzeros + rows)
 constexpr int SPMV_LDS = 2 * SPMV_C;  // products staged per row block (doubles)
 constexpr int SPMV_MAX_GRID = 2048;   // 8 workgroups per CU x 256 CUs
+static_assert(SPMV_BLOCK == VEC_BLOCK, "the fused update runs k_update's blocks");
 
 // rb[k] = first row r in [0, m] with rowptr[r] + r >= k*C ; rb[nblk] = m.
 template <typename OffT>
@@ -172,13 +174,14 @@ __global__ void k_block_desc(const OffT *__restrict__ rowptr, const int *__restr
 //
 // V8 = true: one-byte value codes into the matrix-wide dictionary dict[256] (valdict.h), held in
 // LDS: 1 instead of 8 bytes per nonzero when the matrix has <= 256 distinct values.
-template <typename OffT, bool PANEL, bool C16, bool V8>
+// UPD = true: the launch also carries the x/w update of the previous iteration (vec.h UpdArgs).
+template <typename OffT, bool PANEL, bool C16, bool V8, bool UPD>
 __global__ __launch_bounds__(SPMV_BLOCK, 8) void k_spmv_fused(
     const OffT *__restrict__ rowptr, const void *__restrict__ colv, const int *__restrict__ cbase,
     const void *__restrict__ valv, const double *__restrict__ dict, const RowBlock *__restrict__ blk, int64_t nblk, const double *__restrict__ x, double *__restrict__ y,
     const SpmvCoef *__restrict__ coef, const int *__restrict__ stop, double *__restrict__ partials,
     const double *__restrict__ pin, int npin, const NormSlot *__restrict__ slot_in,
-    NormSlot *__restrict__ slot_out, int skip_if_zero, Rider rider)
+    NormSlot *__restrict__ slot_out, int skip_if_zero, Rider rider, UpdArgs upd)
 {
     __shared__ double prod[SPMV_LDS];
     __shared__ double red[SPMV_BLOCK / WAVE + 1];
@@ -204,13 +207,35 @@ __global__ __launch_bounds__(SPMV_BLOCK, 8) void k_spmv_fused(
     double sx, sy, cy;
     if (pin != nullptr) {  // lazy coefficients (uniform branch)
         const double nrm = sqrt(block_sum_all<SPMV_BLOCK>(pin, npin, red));
-        if (skip_if_zero && !(nrm > 0.0)) return;  // mode 2 is skipped when beta == 0 (:691)
+        if (skip_if_zero && !(nrm > 0.0)) {  // mode 2 is skipped when beta == 0 (:691)
+            if (wg == 0 && tid == 0) {
+                slot_out->nrm = nrm;
+                slot_out->scale = 1.0;
+            }
+            return;
+        }  // mode 2 is skipped when beta == 0 (:691)
         sx = nrm > 0.0 ? 1.0 / nrm : 1.0;
         cy = -nrm;
         sy = slot_in->scale;
         if (wg == 0 && tid == 0) {
             slot_out->nrm = nrm;
             slot_out->scale = sx;
+        }
+        if (UPD && upd.on) {  // x/w update of the previous iteration (vec.h UpdArgs)
+            const double beta = slot_in->nrm;
+            double alpha = nrm, sv = sx;
+            if (!(beta > 0.0)) {  // mode 2 was skipped (src/lsqr.f90:691): alpha, v unchanged
+                alpha = upd.alpha_prev->nrm;
+                sv = upd.alpha_prev->scale;
+            }
+            const LsqrState *ust = upd.st;
+            const Rot rt = rot_step(ust->rhobar2[upd.par], ust->phibar2[upd.par], ust->damp, ust->damped, alpha, beta);
+            const bool wantse = ust->wantse != 0;
+            for (int ub = wg; ub < upd.ugrid; ub += nwg) {
+                const double tot = update_block(upd.x, upd.w, upd.V, upd.se, upd.n, rt.t1, rt.t2, rt.t3, sv, wantse,
+                                                ub, upd.ugrid, red);
+                if (tid == 0) upd.pout[ub] = tot;
+            }
         }
     } else {
         if (coef->skip != 0) return;

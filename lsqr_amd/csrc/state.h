@@ -48,7 +48,12 @@ struct LsqrState {
     SpmvCoef c2;    // mode-2 launch of this iteration:     V <- (-beta)*(V*sv) + A'(U*su)
     SpmvCoef c2p;   // row-sharded mode 2: T_p <- A_p'(U_p*su) (then V <- c2.cy*(V*c2.sy) + sum_p T_p)
     // rotations / estimates (names as in the reference) ------------------------
-    double rhobar, phibar, anorm, acond, dnorm, dxmax, res2, psi;
+    // rhobar / phibar are kept by iteration parity: step 2 of iteration k reads [(k-1)&1] and
+    // writes [k&1] ([0] = the initial values).  The fused x/w update of iteration k runs
+    // inside the mode-1 kernel of iteration k+1 and recomputes the rotation from [(k-1)&1]
+    // while that kernel's rider writes [k&1] (solve_loop.h "fused update").
+    double rhobar2[2], phibar2[2];
+    double anorm, acond, dnorm, dxmax, res2, psi;
     double xnorm, xnorm1, cs2, sn2, z, bnorm, rnorm, arnorm;
     double rho, phi, theta, tau;  // S2 -> S3
     double t1, t2, t3;            // coefficients of the x/w update kernel

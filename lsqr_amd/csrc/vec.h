@@ -27,23 +27,24 @@ namespace lsqrhip {
 constexpr int VEC_BLOCK = 256;
 constexpr int VEC_MAX_GRID = 2048;
 
-__global__ __launch_bounds__(VEC_BLOCK) void k_update(
-    double *__restrict__ x, double *__restrict__ w, const double *__restrict__ V,
-    double *__restrict__ se, int64_t n, const LsqrState *__restrict__ st,
-    double *__restrict__ partials)
+// The work of ONE workgroup of the x/w update: block `ub` of a grid of `ugrid` blocks of
+// VEC_BLOCK threads.  Returns (in thread 0) the block's partial of sum (t3 w)^2.  k_update
+// runs it as a kernel of its own; the fused mode-1 kernels (spmv.h / sell.h, UpdArgs) run the
+// same blocks from inside the SpMV launch -- same elements per thread, same order, same
+// reduction, hence the same partials bit for bit.
+__device__ __forceinline__ double update_block(double *__restrict__ x, double *__restrict__ w,
+                                               const double *__restrict__ V, double *__restrict__ se, int64_t n,
+                                               double t1, double t2, double t3, double sv, bool wantse, int ub,
+                                               int ugrid, double *red)
 {
-    if (st->stop != 0) return;
-    const double t1 = st->t1, t2 = st->t2, t3 = st->t3, sv = st->sv;
-    const bool wantse = st->wantse != 0;
-    __shared__ double red[VEC_BLOCK / WAVE];
     double dk = 0.0;
     const int64_t n2 = n >> 1;
-    const int64_t stride = (int64_t)gridDim.x * VEC_BLOCK;
+    const int64_t stride = (int64_t)ugrid * VEC_BLOCK;
     double2 *x2 = reinterpret_cast<double2 *>(x);
     double2 *w2 = reinterpret_cast<double2 *>(w);
     const double2 *V2 = reinterpret_cast<const double2 *>(V);
     double2 *se2 = reinterpret_cast<double2 *>(se);
-    for (int64_t i = (int64_t)blockIdx.x * VEC_BLOCK + threadIdx.x; i < n2; i += stride) {
+    for (int64_t i = (int64_t)ub * VEC_BLOCK + threadIdx.x; i < n2; i += stride) {
         const double2 t = w2[i];
         double2 xv = x2[i];
         const double2 vv = V2[i];
@@ -64,7 +65,7 @@ __global__ __launch_bounds__(VEC_BLOCK) void k_update(
         dk += d0;
         dk += d1;
     }
-    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    if ((n & 1) && ub == 0 && threadIdx.x == 0) {
         const int64_t i = n - 1;
         const double t = w[i];
         x[i] = t1 * t + x[i];
@@ -73,9 +74,36 @@ __global__ __launch_bounds__(VEC_BLOCK) void k_update(
         if (wantse) se[i] = d + se[i];
         dk += d;
     }
-    const double tot = block_sum<VEC_BLOCK>(dk, red);
+    return block_sum<VEC_BLOCK>(dk, red);
+}
+
+__global__ __launch_bounds__(VEC_BLOCK) void k_update(
+    double *__restrict__ x, double *__restrict__ w, const double *__restrict__ V,
+    double *__restrict__ se, int64_t n, const LsqrState *__restrict__ st,
+    double *__restrict__ partials)
+{
+    if (st->stop != 0) return;
+    const double t1 = st->t1, t2 = st->t2, t3 = st->t3, sv = st->sv;
+    const bool wantse = st->wantse != 0;
+    __shared__ double red[VEC_BLOCK / WAVE];
+    const double tot = update_block(x, w, V, se, n, t1, t2, t3, sv, wantse, (int)blockIdx.x, (int)gridDim.x, red);
     if (threadIdx.x == 0) partials[blockIdx.x] = tot;
 }
+
+// The x/w update of the PREVIOUS iteration carried by a lazy mode-1 SpMV launch ("fused
+// update", solve_loop.h).  on = 0: nothing to do.
+struct UpdArgs {
+    int on;
+    int par;      // parity of the rotation inputs: st->rhobar2[par], st->phibar2[par]
+    int ugrid;    // blocks of the update (== the grid k_update would use)
+    int pad;
+    double *x, *w, *se;
+    const double *V;
+    int64_t n;
+    const LsqrState *st;
+    const NormSlot *alpha_prev;  // (alpha, 1/alpha) of the previous iteration: used when beta == 0
+    double *pout;                // update partials [ugrid]
+};
 
 // partials[b] = sum over this workgroup's share of x[i]*y[i]  (y == x: sum of squares)
 __global__ __launch_bounds__(VEC_BLOCK) void k_dot(const double *__restrict__ x,

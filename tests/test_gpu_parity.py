@@ -229,13 +229,14 @@ def test_graph_and_eager_launch_modes_agree_bitwise():
 @pytest.mark.parametrize("name", ["poisson_20x20_it50", "random_over_se", "powerlaw_small", "illcond_conlim",
                                   "empty_rows_cols", "t1_readme_damped", "b_zero"])
 def test_pipelined_and_sequential_schedules_agree_bitwise(name):
-    """solve_loop.h: the two-stream pipelined schedule (SpMVs derive their own norm, scalar
-    machine + x/w update beside the next SpMV) must reproduce the plain sequential schedule
-    bit for bit -- same x, se, scalars, istop, itn -- in graph and in eager mode."""
+    """solve_loop.h: the rider schedule (SpMVs derive their own norm, scalar machine inside the
+    next SpMV launch) and the fused-update schedule (x/w update inside the mode-1 launch, every
+    workgroup recomputing the rotation) must reproduce the plain sequential schedule bit for
+    bit -- same x, se, scalars, istop, itn -- in graph and in eager mode."""
     p, o = CASES[name]
     s = make(p, o)
     ref = None
-    for pipeline in (0, 1):
+    for pipeline in (0, 1, 2):
         for graph in (1, 0):
             s.set_option("pipeline", pipeline)
             s.set_option("graph", graph)
