@@ -46,7 +46,15 @@ __global__ __launch_bounds__(256) void k_dict_collect(const double *__restrict__
             return;
         }
         const unsigned long long bits = (unsigned long long)__double_as_longlong(val[k]);
-        const unsigned hs = (unsigned)((bits * 0x9E3779B97F4A7C15ull) >> 40);
+        // splitmix64 finaliser: doubles such as 4.0 or -1.0 have 52 zero low bits, a single
+        // multiply would leave the low hash bits zero and every value in the same filter slot
+        unsigned long long z = bits;
+        z ^= z >> 31;
+        z *= 0x9E3779B97F4A7C15ull;
+        z ^= z >> 29;
+        z *= 0xBF58476D1CE4E5B9ull;
+        z ^= z >> 32;
+        const unsigned hs = (unsigned)z;
         volatile unsigned long long *vs = seen;
         if (vs[hs & 511] == bits) continue;  // already in the global table
         if (bits == VD_EMPTY) {
@@ -54,7 +62,7 @@ __global__ __launch_bounds__(256) void k_dict_collect(const double *__restrict__
             *vgive = 1;
             return;
         }
-        unsigned h = (hs >> 12) & (VD_SLOTS - 1);
+        unsigned h = (hs >> 9) & (VD_SLOTS - 1);
         for (int probe = 0; probe < VD_SLOTS; ++probe) {
             unsigned long long cur = ((volatile unsigned long long *)table)[h];
             if (cur == VD_EMPTY) {
