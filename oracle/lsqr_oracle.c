@@ -159,22 +159,36 @@ int oracle_validate(int m, int n, long long nnz, const int *irow, const int *ico
 }
 
 /* ---------------------------------------------------------------------- */
+/* The operator interface of the abstract class (src/lsqr.f90:16-30, 67-82):  */
+/* aprod(mode, m, n, x, y) -- mode 1: y += A x, mode 2: x += A' y.            */
+/* ---------------------------------------------------------------------- */
+struct coo_ctx {
+    long long nnz;
+    const int *irow, *icol;
+    const double *a;
+    double *scratch; /* max(m, n) */
+};
+static void coo_aprod(void *vctx, int mode, int m, int n, double *x, double *y)
+{
+    struct coo_ctx *c = (struct coo_ctx *)vctx;
+    oracle_aprod(mode, m, n, c->nnz, c->irow, c->icol, c->a, x, y, c->scratch);
+}
+
+/* ---------------------------------------------------------------------- */
 /* LSQR (src/lsqr.f90:432-882) through solve_ez (src/lsqr.f90:207-259)     */
 /* ---------------------------------------------------------------------- */
 
-int oracle_lsqr_ez(int m, int n, long long nnz, const int *irow, const int *icol, const double *a,
+int oracle_lsqr_op(int m, int n, oracle_aprod_fn aprod, void *ctx,
                    const double *b, double damp, double atol, double btol, double conlim,
                    int itnlim, int wantse, double *x, double *se, int *istop_out, int *itn_out,
                    double *anorm_out, double *acond_out, double *rnorm_out, double *arnorm_out,
                    double *xnorm_out, double *log, int logcap)
 {
-    int mx = m > n ? m : n;
     double *u = (double *)malloc(sizeof(double) * (size_t)(m > 0 ? m : 1));
     double *v = (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
     double *w = (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
-    double *scratch = (double *)malloc(sizeof(double) * (size_t)(mx > 0 ? mx : 1));
-    if (!u || !v || !w || !scratch) {
-        free(u); free(v); free(w); free(scratch);
+    if (!u || !v || !w) {
+        free(u); free(v); free(w);
         return 1;
     }
     memcpy(u, b, sizeof(double) * (size_t)m); /* solve_ez :242 */
@@ -199,7 +213,7 @@ int oracle_lsqr_ez(int m, int n, long long nnz, const int *irow, const int *icol
     double beta = oracle_dnrm2(m, u, 1);
     if (beta > 0.0) {
         oracle_dscal(m, 1.0 / beta, u, 1);
-        oracle_aprod(2, m, n, nnz, irow, icol, a, v, u, scratch);
+        aprod(ctx, 2, m, n, v, u);
         alpha = oracle_dnrm2(n, v, 1);
     }
     if (alpha > 0.0) {
@@ -222,7 +236,7 @@ int oracle_lsqr_ez(int m, int n, long long nnz, const int *irow, const int *icol
 
             /* :681-683 */
             oracle_dscal(m, -alpha, u, 1);
-            oracle_aprod(1, m, n, nnz, irow, icol, a, v, u, scratch);
+            aprod(ctx, 1, m, n, v, u);
             beta = oracle_dnrm2(m, u, 1);
 
             /* :687-689 */
@@ -234,7 +248,7 @@ int oracle_lsqr_ez(int m, int n, long long nnz, const int *irow, const int *icol
             if (beta > 0.0) {
                 oracle_dscal(m, 1.0 / beta, u, 1);
                 oracle_dscal(n, -beta, v, 1);
-                oracle_aprod(2, m, n, nnz, irow, icol, a, v, u, scratch);
+                aprod(ctx, 2, m, n, v, u);
                 alpha = oracle_dnrm2(n, v, 1);
                 if (alpha > 0.0) oracle_dscal(n, 1.0 / alpha, v, 1);
             }
@@ -364,21 +378,35 @@ int oracle_lsqr_ez(int m, int n, long long nnz, const int *irow, const int *icol
     if (rnorm_out) *rnorm_out = rnorm;
     if (arnorm_out) *arnorm_out = arnorm;
     if (xnorm_out) *xnorm_out = xnorm;
-    free(u); free(v); free(w); free(scratch);
+    free(u); free(v); free(w);
     return 0;
 }
 
+/* solve_ez (src/lsqr.f90:207-259): LSQR on the COO operator */
+int oracle_lsqr_ez(int m, int n, long long nnz, const int *irow, const int *icol, const double *a,
+                   const double *b, double damp, double atol, double btol, double conlim,
+                   int itnlim, int wantse, double *x, double *se, int *istop_out, int *itn_out,
+                   double *anorm_out, double *acond_out, double *rnorm_out, double *arnorm_out,
+                   double *xnorm_out, double *log, int logcap)
+{
+    int mx = m > n ? m : n;
+    struct coo_ctx c = {nnz, irow, icol, a, (double *)malloc(sizeof(double) * (size_t)(mx > 0 ? mx : 1))};
+    if (!c.scratch) return 1;
+    int rc = oracle_lsqr_op(m, n, coo_aprod, &c, b, damp, atol, btol, conlim, itnlim, wantse, x, se, istop_out,
+                            itn_out, anorm_out, acond_out, rnorm_out, arnorm_out, xnorm_out, log, logcap);
+    free(c.scratch);
+    return rc;
+}
+
 /* ---------------------------------------------------------------------- */
-/* acheck (src/lsqr.f90:908-994) on the COO operator                      */
+/* acheck (src/lsqr.f90:908-994)                                          */
 /* ---------------------------------------------------------------------- */
-int oracle_acheck(int m, int n, long long nnz, const int *irow, const int *icol, const double *a,
-                  double eps, double *err_out)
+int oracle_acheck_op(int m, int n, oracle_aprod_fn aprod, void *ctx, double eps, double *err_out)
 {
     double *v = (double *)malloc(sizeof(double) * (size_t)n);
     double *w = (double *)malloc(sizeof(double) * (size_t)m);
     double *x = (double *)malloc(sizeof(double) * (size_t)n);
     double *y = (double *)malloc(sizeof(double) * (size_t)m);
-    double *scratch = (double *)malloc(sizeof(double) * (size_t)(m > n ? m : n));
     const double tol = pow(eps, 0.5); /* :939 */
     double t = 1.0;
     for (int j = 0; j < n; ++j) { t = t + 1.0; x[j] = sqrt(t); }          /* :946-950 */
@@ -390,37 +418,46 @@ int oracle_acheck(int m, int n, long long nnz, const int *irow, const int *icol,
     oracle_dscal(m, 1.0 / beta, y, 1);
     oracle_dcopy(m, y, 1, w, 1);                                          /* :969-972 */
     oracle_dcopy(n, x, 1, v, 1);
-    oracle_aprod(1, m, n, nnz, irow, icol, a, x, w, scratch);
-    oracle_aprod(2, m, n, nnz, irow, icol, a, v, y, scratch);
+    aprod(ctx, 1, m, n, x, w);
+    aprod(ctx, 2, m, n, v, y);
     alfa = oracle_ddot(m, y, 1, w, 1);                                    /* :976-980 */
     beta = oracle_ddot(n, x, 1, v, 1);
     double test1 = fabs(alfa - beta);
     double test2 = 1.0 + fabs(alfa) + fabs(beta);
     double test3 = test1 / test2;
     if (err_out) *err_out = test3;
-    free(v); free(w); free(x); free(y); free(scratch);
+    free(v); free(w); free(x); free(y);
     return test3 <= tol ? 0 : 1;                                          /* :984-992 */
 }
 
+int oracle_acheck(int m, int n, long long nnz, const int *irow, const int *icol, const double *a,
+                  double eps, double *err_out)
+{
+    int mx = m > n ? m : n;
+    struct coo_ctx c = {nnz, irow, icol, a, (double *)malloc(sizeof(double) * (size_t)(mx > 0 ? mx : 1))};
+    int inform = oracle_acheck_op(m, n, coo_aprod, &c, eps, err_out);
+    free(c.scratch);
+    return inform;
+}
+
 /* ---------------------------------------------------------------------- */
-/* xcheck (src/lsqr.f90:1015-1154) on the COO operator                    */
+/* xcheck (src/lsqr.f90:1015-1154)                                        */
 /* ---------------------------------------------------------------------- */
-int oracle_xcheck(int m, int n, long long nnz, const int *irow, const int *icol, const double *a,
-                  double anorm, double damp, double eps, const double *b, const double *x,
-                  double *u, double *v, double *w, double *tests /* [3] */)
+int oracle_xcheck_op(int m, int n, oracle_aprod_fn aprod, void *ctx,
+                     double anorm, double damp, double eps, const double *b, const double *x,
+                     double *u, double *v, double *w, double *tests /* [3] */)
 {
     double *xtmp = (double *)malloc(sizeof(double) * (size_t)n);
-    double *scratch = (double *)malloc(sizeof(double) * (size_t)(m > n ? m : n));
     const double dampsq = damp * damp;
     const double tol = pow(eps, 0.5);
     memcpy(xtmp, x, sizeof(double) * (size_t)n);
 
     oracle_dcopy(m, b, 1, u, 1);                                          /* :1073-1076 */
     oracle_dscal(m, -1.0, u, 1);
-    oracle_aprod(1, m, n, nnz, irow, icol, a, xtmp, u, scratch);
+    aprod(ctx, 1, m, n, xtmp, u);
     oracle_dscal(m, -1.0, u, 1);
     for (int j = 0; j < n; ++j) v[j] = 0.0;                               /* :1080-1083 */
-    oracle_aprod(2, m, n, nnz, irow, icol, a, v, u, scratch);
+    aprod(ctx, 2, m, n, v, u);
     oracle_dcopy(n, v, 1, w, 1);                                          /* :1089-1094 */
     if (damp != 0.0)
         for (int j = 0; j < n; ++j) w[j] = w[j] - dampsq * x[j];
@@ -453,6 +490,17 @@ int oracle_xcheck(int m, int n, long long nnz, const int *irow, const int *icol,
         if (test1 <= tol) inform = 1;
     }
     tests[0] = test1; tests[1] = test2; tests[2] = test3;
-    free(xtmp); free(scratch);
+    free(xtmp);
+    return inform;
+}
+
+int oracle_xcheck(int m, int n, long long nnz, const int *irow, const int *icol, const double *a,
+                  double anorm, double damp, double eps, const double *b, const double *x,
+                  double *u, double *v, double *w, double *tests /* [3] */)
+{
+    int mx = m > n ? m : n;
+    struct coo_ctx c = {nnz, irow, icol, a, (double *)malloc(sizeof(double) * (size_t)(mx > 0 ? mx : 1))};
+    int inform = oracle_xcheck_op(m, n, coo_aprod, &c, anorm, damp, eps, b, x, u, v, w, tests);
+    free(c.scratch);
     return inform;
 }

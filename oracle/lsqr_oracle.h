@@ -20,6 +20,18 @@ int oracle_aprod(int mode, int m, int n, long long nnz, const int *irow, const i
                  const double *a, double *x, double *y, double *scratch);
 int oracle_validate(int m, int n, long long nnz, const int *irow, const int *icol);
 
+/* the abstract class's operator (src/lsqr.f90:67-82): mode 1 y += A x, mode 2 x += A' y */
+typedef void (*oracle_aprod_fn)(void *ctx, int mode, int m, int n, double *x, double *y);
+
+int oracle_lsqr_op(int m, int n, oracle_aprod_fn aprod, void *ctx,
+                   const double *b, double damp, double atol, double btol, double conlim,
+                   int itnlim, int wantse, double *x, double *se, int *istop, int *itn,
+                   double *anorm, double *acond, double *rnorm, double *arnorm, double *xnorm,
+                   double *log, int logcap);
+int oracle_acheck_op(int m, int n, oracle_aprod_fn aprod, void *ctx, double eps, double *err_out);
+int oracle_xcheck_op(int m, int n, oracle_aprod_fn aprod, void *ctx, double anorm, double damp, double eps,
+                     const double *b, const double *x, double *u, double *v, double *w, double *tests);
+
 int oracle_lsqr_ez(int m, int n, long long nnz, const int *irow, const int *icol, const double *a,
                    const double *b, double damp, double atol, double btol, double conlim,
                    int itnlim, int wantse, double *x, double *se, int *istop, int *itn,
