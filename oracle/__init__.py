@@ -89,6 +89,35 @@ class _Port:
         L.oracle_xcheck.argtypes = [C.c_int, C.c_int, C.c_longlong, _i32p, _i32p, _f64p, C.c_double,
                                     C.c_double, C.c_double, _f64p, _f64p, _f64p, _f64p, _f64p, _f64p]
 
+        L.oracle_lstp_generate.restype = C.c_int
+        L.oracle_lstp_generate.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, _f64p, _f64p, _f64p,
+                                           _f64p, _f64p, C.c_void_p, C.c_void_p]
+        L.oracle_lstp_test.restype = C.c_int
+        L.oracle_lstp_test.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, _f64p, _f64p, _f64p, _f64p]
+
+    # the reference's test-problem class (lstp_oracle.c) -------------------
+    def lstp_generate(self, m, n, nduplc, npower, damp):
+        """lstp (test/lsqrtest_module.f90:422-505): dict(xtrue, b, d, hy, hz, acond, rnorm)."""
+        xtrue, b, d, hy, hz = np.zeros(n), np.zeros(m), np.zeros(min(m, n)), np.zeros(m), np.zeros(n)
+        acond, rnorm = C.c_double(), C.c_double()
+        rc = self.L.oracle_lstp_generate(m, n, nduplc, npower, damp, xtrue, b, d, hy, hz,
+                                         C.addressof(acond), C.addressof(rnorm))
+        assert rc == 0
+        return dict(xtrue=xtrue, b=b, d=d, hy=hy, hz=hz, acond=acond.value, rnorm=rnorm.value)
+
+    def lstp_test(self, m, n, nduplc, npower, damp):
+        """One problem of the 18-problem suite (test/lsqrtest_module.f90:119-272)."""
+        x, xtrue, b, res = np.zeros(n), np.zeros(n), np.zeros(m), np.zeros(16)
+        rc = self.L.oracle_lstp_test(m, n, nduplc, npower, damp, x, xtrue, b, res)
+        assert rc == 0
+        keys = ("acond_lstp", "rnorm_lstp", "acheck_inform", "acheck_err", "istop", "itn", "anorm", "acond",
+                "rnorm", "arnorm", "xnorm", "xcheck_inform", "test1", "test2", "test3", "enorm")
+        out = dict(zip(keys, res.tolist()))
+        for k in ("acheck_inform", "istop", "itn", "xcheck_inform"):
+            out[k] = int(out[k])
+        out.update(x=x, xtrue=xtrue, b=b)
+        return out
+
     # BLAS-1 -------------------------------------------------------------
     def dnrm2(self, x, incx=1, n=None):
         x = np.ascontiguousarray(x, dtype=np.float64)
@@ -255,6 +284,40 @@ class _Ref:
 
 _port = None
 _ref = None
+
+
+SUITE = [(m, n, 40, p, 10.0 ** (-p - 6)) for (m, n) in ((2000, 1000), (1000, 1000), (1000, 2000))
+         for p in range(2, 8)]
+"""The 18 problems of lsqr_test (test/lsqrtest_module.f90:55-94): (m, n, nduplc, npower, damp)."""
+
+
+def parse_lis(text: str) -> list[dict]:
+    """Numeric fields of an LSQR.LIS log (the file the reference's test program writes), one
+    dict per problem: header, acheck error, exit scalars, xcheck inform/tests, x(1:8), verdict."""
+    import re
+    num = r"[-+]?\d*\.?\d+(?:[EeDd][-+]?\d+)?"
+    out = []
+    for blk in text.split("Least-Squares Test Problem")[1:]:
+        d = {}
+        h = re.search(r"P\(\s*(\d+)\s+(\d+)\s+(\d+)\s+(\d+)\s+(" + num + r")\s*\)", blk)
+        d["m"], d["n"], d["nduplc"], d["npower"] = (int(h.group(i)) for i in range(1, 5))
+        d["damp"] = float(h.group(5))
+        d["acond_lstp"] = float(re.search(r"Condition no\. =\s*(" + num + ")", blk).group(1))
+        d["rnorm_lstp"] = float(re.search(r"Residual function =\s*(" + num + ")", blk).group(1))
+        d["acheck_err"] = float(re.search(r"aprod seems OK\.\s+Relative error =\s*(" + num + ")", blk).group(1))
+        d["istop"] = int(re.search(r"istop\s+=\s*(\d+)", blk).group(1))
+        d["itn"] = int(re.search(r"itn\s+=\s*(\d+)", blk).group(1))
+        for k in ("anorm", "acond", "bnorm", "xnorm", "rnorm", "arnorm"):
+            d[k] = float(re.search(r"Exit  LSQR\..*?\b" + k + r"\s*=\s*(" + num + ")", blk).group(1))
+        d["xcheck_inform"] = int(re.search(r"inform\s+=\s*(\d+)", blk).group(1))
+        for i in (1, 2, 3):
+            d[f"test{i}"] = float(re.search(rf"test{i}\s+=\s*(" + num + ")", blk).group(1))
+        sol = blk.split("Solution  x:")[1].split("LSQR  appears")[0]
+        d["x8"] = [float(v) for _, v in re.findall(r"(\d+)\s+(" + num + ")", sol)][:8]
+        d["success"] = "appears to be successful" in blk
+        d["enorm"] = float(re.search(r"Relative error in  x  =\s*(" + num + ")", blk).group(1))
+        out.append(d)
+    return out
 
 
 def port() -> _Port:

@@ -44,6 +44,22 @@ int oracle_xcheck(int m, int n, long long nnz, const int *irow, const int *icol,
                   double anorm, double damp, double eps, const double *b, const double *x,
                   double *u, double *v, double *w, double *tests);
 
+/* ---- the reference's test-problem class (oracle/lstp_oracle.c; test/lsqrtest_module.f90) ---- */
+typedef struct {
+    int m, n;
+    double *d, *hy, *hz, *w; /* d(min(m,n)), hy(m), hz(n), w(max(m,n)) workspace */
+} oracle_lstp_t;
+void oracle_hprod(int n, const double *hz, const double *x, double *y);
+void oracle_lstp_aprod(void *ctx, int mode, int m, int n, double *x, double *y);
+int oracle_lstp_alloc(oracle_lstp_t *c, int m, int n);
+void oracle_lstp_free(oracle_lstp_t *c);
+void oracle_lstp(oracle_lstp_t *c, int nduplc, int npower, double damp, double *x, double *b,
+                 double *acond, double *rnorm);
+int oracle_lstp_generate(int m, int n, int nduplc, int npower, double damp, double *xtrue, double *b, double *d,
+                         double *hy, double *hz, double *acond, double *rnorm);
+int oracle_lstp_test(int m, int n, int nduplc, int npower, double damp, double *x, double *xtrue, double *b,
+                     double *res);
+
 #ifdef __cplusplus
 }
 #endif

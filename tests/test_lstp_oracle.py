@@ -1,0 +1,83 @@
+"""The oracle's restatement of the reference's test-problem class (oracle/lstp_oracle.c:
+hprod, aprod1/aprod2, lstp, the `test` driver) pinned against the reference itself:
+
+* tests/golden/LSQR_ref_amdflang.LIS -- the log the unmodified reference test program wrote when
+  compiled in the build container (tests/golden/gen_lstp_golden.py): every printed digit of every
+  problem must be reproduced (istop, itn, exit scalars, acheck error, xcheck tests, x(1:8), error);
+* tests/golden/LSQR_shipped_facts.json -- the log the reference ships (test/LSQR.LIS, another
+  compiler): same istop, same xcheck inform, same success / failure pattern (P5, P6 fail),
+  iteration counts within the spread two compilers of the SAME code show.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = oracle.parse_lis(open(os.path.join(HERE, "golden", "LSQR_ref_amdflang.LIS")).read())
+SHIP = json.load(open(os.path.join(HERE, "golden", "LSQR_shipped_facts.json")))
+
+
+def printed(value, ref, digits):
+    """`value` rounds to the `digits` significant digits the log printed for `ref`."""
+    if ref == 0.0:
+        return abs(value) < 1e-300 or abs(value) < 10.0 ** (-digits)
+    return abs(value - ref) <= 0.51 * 10.0 ** (np.floor(np.log10(abs(ref))) - digits + 1)
+
+
+def test_suite_definition_matches_both_logs():
+    assert len(REF) == len(SHIP) == len(oracle.SUITE) == 18
+    for (m, n, nd, p, damp), r, s in zip(oracle.SUITE, REF, SHIP):
+        for d in (r, s):
+            assert (d["m"], d["n"], d["nduplc"], d["npower"]) == (m, n, nd, p)
+            assert d["damp"] == pytest.approx(damp, rel=1e-3)
+
+
+@pytest.mark.parametrize("k", range(18))
+def test_port_reproduces_the_compiled_reference_log(k):
+    m, n, nd, p, damp = oracle.SUITE[k]
+    r = REF[k]
+    o = oracle.port().lstp_test(m, n, nd, p, damp)
+    assert (o["istop"], o["itn"]) == (r["istop"], r["itn"])
+    assert o["xcheck_inform"] == r["xcheck_inform"] and o["acheck_inform"] == 0
+    assert printed(o["acond_lstp"], r["acond_lstp"], 5) and printed(o["rnorm_lstp"], r["rnorm_lstp"], 10)
+    assert printed(o["acheck_err"], r["acheck_err"], 2)
+    for key in ("anorm", "acond", "xnorm", "rnorm", "arnorm"):
+        assert printed(o[key], r[key], 6), key
+    for i in (1, 2, 3):
+        assert printed(o[f"test{i}"], r[f"test{i}"], 4)
+    for xv, xr in zip(o["x"][:8], r["x8"]):
+        assert printed(xv, xr, 6)
+    assert printed(o["enorm"], r["enorm"], 3)
+    assert (o["enorm"] <= 1e-3) == r["success"]
+
+
+@pytest.mark.parametrize("k", range(18))
+def test_port_agrees_with_the_shipped_log_where_compilers_agree(k):
+    m, n, nd, p, damp = oracle.SUITE[k]
+    s, r = SHIP[k], REF[k]
+    o = oracle.port().lstp_test(m, n, nd, p, damp)
+    assert o["istop"] == s["istop"] == 3
+    assert o["xcheck_inform"] == s["xcheck_inform"]
+    assert (o["enorm"] <= 1e-3) == s["success"]            # "failed" only on P5 and P6
+    assert s["success"] == (k not in (4, 5))
+    assert printed(o["acond_lstp"], s["acond_lstp"], 5) and printed(o["rnorm_lstp"], s["rnorm_lstp"], 10)
+    # the same source under two compilers: 0..31 iterations apart on these 18 problems
+    assert abs(o["itn"] - s["itn"]) <= max(3, int(0.15 * s["itn"]))
+    assert o["anorm"] == pytest.approx(s["anorm"], rel=0.05)
+    if s["success"]:
+        # both x are within their own reported error of xtrue (enorm = |x - xtrue| / (1 + |xtrue|))
+        bound = (o["enorm"] + s["enorm"]) * (1.0 + np.linalg.norm(o["xtrue"]))
+        np.testing.assert_allclose(o["x"][:8], s["x8"], rtol=1e-5, atol=bound)
+
+
+def test_generated_operator_is_consistent():
+    """acheck's identity on the restated operator and the structure of lstp's outputs."""
+    po = oracle.port()
+    g = po.lstp_generate(1000, 2000, 40, 3, 1e-9)
+    assert abs(np.linalg.norm(g["hy"]) - 1) < 1e-14 and abs(np.linalg.norm(g["hz"]) - 1) < 1e-14
+    assert np.all(np.diff(g["d"]) >= 0) and g["d"][-1] == 1.0
+    assert g["acond"] == pytest.approx(np.sqrt((g["d"][-1] ** 2 + 1e-18) / (g["d"][0] ** 2 + 1e-18)))
