@@ -64,7 +64,9 @@ def test_port_agrees_with_the_shipped_log_where_compilers_agree(k):
     assert o["xcheck_inform"] == s["xcheck_inform"]
     assert (o["enorm"] <= 1e-3) == s["success"]            # "failed" only on P5 and P6
     assert s["success"] == (k not in (4, 5))
-    assert printed(o["acond_lstp"], s["acond_lstp"], 5) and printed(o["rnorm_lstp"], s["rnorm_lstp"], 10)
+    assert printed(o["acond_lstp"], s["acond_lstp"], 5)
+    # m <= n: the residual function is dampsq-sized rounding residue, compiler dependent beyond 4 digits
+    assert o["rnorm_lstp"] == pytest.approx(s["rnorm_lstp"], rel=1e-9 if m > n else 1e-3)
     # the same source under two compilers: 0..31 iterations apart on these 18 problems
     assert abs(o["itn"] - s["itn"]) <= max(3, int(0.15 * s["itn"]))
     assert o["anorm"] == pytest.approx(s["anorm"], rel=0.05)
