@@ -172,6 +172,31 @@ int lsqrhip_last_timing(lsqrhip_handle_t h, lsqrhip_timing_t *t);
  * are unspecified afterwards. */
 int lsqrhip_bench_kernel(lsqrhip_handle_t h, int which, int reps, double *avg_ms);
 
+/* ---- LSQR on a user-supplied DEVICE operator ---------------------------------
+ * Replaces the reference's abstract class `lsqr_solver` with a deferred `aprod`
+ * (src/lsqr.f90:16-30; interface :67-82) for operators that live on the GPU.  The callback
+ * must ENQUEUE on `hip_stream` (a hipStream_t)
+ *     mode 1:  y <- y + A  x          mode 2:  x <- x + A' y
+ * with x (n) and y (m) DEVICE pointers, and return 0.  It must not synchronise with, or wait
+ * for, the host: the solver queues several iterations ahead.  Past the stopping iteration it
+ * may still be called, with an all-zero input vector.
+ * The handle works with lsqrhip_solve / _solve_device (LSQR, :432-882), lsqrhip_aprod /
+ * _aprod_device, lsqrhip_acheck (:908-994), lsqrhip_xcheck (:1015-1154), the log and BLAS-1
+ * entry points; option "op_batch" = iterations queued ahead of each stop poll (default 8). */
+typedef int (*lsqrhip_aprod_fn)(void *user, int mode, int m, int n, double *d_x, double *d_y, void *hip_stream);
+int lsqrhip_create_operator(int m, int n, lsqrhip_aprod_fn aprod, void *user, lsqrhip_handle_t *h);
+
+/* The reference's own test operator A = HY * D * HZ as a device operator, with the problem
+ * generator `lstp` (test/lsqrtest_module.f90: hprod :385-403, aprod1 :319-343, aprod2 :353-377,
+ * lstp :422-505): creates an operator handle for problem P(m, n, nduplc, npower, damp) and
+ * returns the generator's condition number and residual norm.  lsqrhip_lstp_vectors copies out
+ * the generated xtrue (n), b (m), d (min(m,n)), hy (m), hz (n) (any may be NULL) and the device
+ * address of b. */
+int lsqrhip_lstp_create(int m, int n, int nduplc, int npower, double damp, lsqrhip_handle_t *h, double *acond,
+                        double *rnorm);
+int lsqrhip_lstp_vectors(lsqrhip_handle_t h, double *xtrue, double *b, double *d, double *hy, double *hz,
+                         const double **d_b);
+
 /* Options: "graph" (1 = hipGraph-captured iteration batches [default], 0 = eager
  * launches), "graph_iters" (iterations per captured batch), "time_kernels"
  * (1 = eager launches with HIP events around each hot kernel, fills *_ms above),

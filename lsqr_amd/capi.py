@@ -31,7 +31,12 @@ EXPORTS = [
     "lsqrhip_dev_free", "lsqrhip_dev_upload", "lsqrhip_dev_download", "lsqrhip_dev_sync",
     "lsqrhip_shard_begin", "lsqrhip_shard_stage", "lsqrhip_shard_poll", "lsqrhip_shard_end", "lsqrhip_sum_chunks",
     "lsqrhip_gen_count", "lsqrhip_gen_coo",
+    "lsqrhip_create_operator", "lsqrhip_lstp_create", "lsqrhip_lstp_vectors",
 ]
+
+
+# int aprod(void *user, int mode, int m, int n, double *d_x, double *d_y, void *hip_stream)
+APROD_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p)
 
 
 class LsqrHipError(RuntimeError):
@@ -103,6 +108,9 @@ def lib() -> C.CDLL:
     L.lsqrhip_gen_count.restype = i64
     L.lsqrhip_gen_count.argtypes = [i32, i64, i64, i64, i64, i64, i64]
     L.lsqrhip_gen_coo.argtypes = [i32, C.c_uint64, i64, i64, i64, i64, i64, i64, vp, vp, vp, vp, vp, vp]
+    L.lsqrhip_create_operator.argtypes = [i32, i32, APROD_FN, vp, C.POINTER(vp)]
+    L.lsqrhip_lstp_create.argtypes = [i32, i32, i32, i32, f64, C.POINTER(vp), C.POINTER(f64), C.POINTER(f64)]
+    L.lsqrhip_lstp_vectors.argtypes = [vp, vp, vp, vp, vp, vp, C.POINTER(vp)]
     for name in EXPORTS:
         getattr(L, name)  # every declared symbol must be exported
     _lib = L

@@ -185,6 +185,13 @@ struct lsqrhip_handle_s {
     double *P2[2] = {nullptr, nullptr};  // mode-2 partials by iteration parity
     double *P3 = nullptr;                // x/w update partials
     NormSlot *slots = nullptr;           // [0..1] alpha side (from mode 1), [2..3] beta side (from mode 2)
+    // user device operator (op_api.h); A / AT are empty for such a handle
+    lsqrhip_aprod_fn op = nullptr;
+    void *op_user = nullptr;
+    void (*op_free)(void *) = nullptr;  // releases op_user with the handle (built-in operators)
+    bool op_is_lstp = false;
+    double *opX = nullptr, *opY = nullptr;  // scaled copies handed to the operator (n, m)
+    int op_batch = 8;                       // iterations enqueued ahead of each stop poll
     // row-sharded solve (shard_api.h): caller-owned exchange buffers
     double *shard_T = nullptr, *shard_sums = nullptr;
     int shard_wantse = 0;
@@ -248,8 +255,9 @@ extern "C" int lsqrhip_destroy(lsqrhip_handle_t h)
     destroy_graph(h);
     free_csr(h->A);
     free_csr(h->AT);
-    for (double *p : {h->U, h->V, h->W, h->X, h->SE, h->Z, h->partials, h->d_scalar, h->d_log, h->dict})
+    for (double *p : {h->U, h->V, h->W, h->X, h->SE, h->Z, h->partials, h->d_scalar, h->d_log, h->dict, h->opX, h->opY})
         if (p) (void)hipFree(p);
+    if (h->op_free) h->op_free(h->op_user);
     if (h->d_state) (void)hipFree(h->d_state);
     if (h->h_state) (void)hipHostFree(h->h_state);
     if (h->d_unit) (void)hipFree(h->d_unit);
@@ -500,6 +508,43 @@ static void choose_panels(int rows, int cols, double mean_dev, int *panels, int 
     *pw = (int)width;
 }
 
+// work vectors, partial buffers, state: everything a solve needs besides the operator
+static int alloc_workspace(H *h)
+{
+    hipStream_t s = h->stream;
+    const size_t m1 = (size_t)std::max(h->m, 1), n1 = (size_t)std::max(h->n, 1);
+    HIPCHK(hipMalloc((void **)&h->U, sizeof(double) * m1));
+    HIPCHK(hipMalloc((void **)&h->V, sizeof(double) * n1));
+    HIPCHK(hipMalloc((void **)&h->W, sizeof(double) * n1));
+    HIPCHK(hipMalloc((void **)&h->X, sizeof(double) * n1));
+    HIPCHK(hipMalloc((void **)&h->SE, sizeof(double) * n1));
+    HIPCHK(hipMalloc((void **)&h->partials, sizeof(double) * SPMV_MAX_GRID));
+    {
+        const int64_t zn = std::max<int64_t>(h->A.P > 1 ? h->A.rows_v : 0, h->AT.P > 1 ? h->AT.rows_v : 0);
+        if (zn > 0) HIPCHK(hipMalloc((void **)&h->Z, sizeof(double) * (size_t)zn));
+    }
+    HIPCHK(hipMalloc((void **)&h->d_scalar, sizeof(double) * 4));
+    for (double **pp : {&h->P1[0], &h->P1[1], &h->P2[0], &h->P2[1], &h->P3}) {
+        HIPCHK(hipMalloc((void **)pp, sizeof(double) * SPMV_MAX_GRID));
+        HIPCHK(hipMemsetAsync(*pp, 0, sizeof(double) * SPMV_MAX_GRID, s));
+    }
+    HIPCHK(hipMalloc((void **)&h->slots, sizeof(NormSlot) * 4));
+    HIPCHK(hipMemsetAsync(h->slots, 0, sizeof(NormSlot) * 4, s));
+    HIPCHK(hipMalloc((void **)&h->d_state, sizeof(LsqrState)));
+    HIPCHK(hipHostMalloc((void **)&h->h_state, sizeof(LsqrState)));
+    HIPCHK(hipMalloc((void **)&h->d_unit, sizeof(SpmvCoef)));
+    HIPCHK(hipMalloc((void **)&h->d_zero, sizeof(int)));
+    SpmvCoef unit{1.0, 1.0, 1.0, 0, 0};
+    HIPCHK(hipMemcpyAsync(h->d_unit, &unit, sizeof(unit), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemsetAsync(h->d_zero, 0, sizeof(int), s));
+    HIPCHK(hipEventCreate(&h->ev_loop0));
+    HIPCHK(hipEventCreate(&h->ev_loop1));
+    h->vgrid_m = vec_grid(h->m);
+    h->vgrid_n = vec_grid(h->n);
+    HIPCHK(hipStreamSynchronize(s));
+    return LSQRHIP_OK;
+}
+
 // Value dictionary (valdict.h): h->dict / h->ndict when the matrix has <= 256 distinct values.
 // LSQRHIP_VAL8=0 keeps 8-byte values.  `table` is scratch of >= VD_SLOTS words, `ctl` of 4 ints.
 static int build_dictionary(H *h, const double *d_a, unsigned long long *table, int *ctl)
@@ -587,37 +632,7 @@ static int finish_create(H *h, const int *d_irow, const int *d_icol, const doubl
     (void)hipFree(d_flags);
     RET(rc);
 
-    const size_t m1 = (size_t)std::max(h->m, 1), n1 = (size_t)std::max(h->n, 1);
-    HIPCHK(hipMalloc((void **)&h->U, sizeof(double) * m1));
-    HIPCHK(hipMalloc((void **)&h->V, sizeof(double) * n1));
-    HIPCHK(hipMalloc((void **)&h->W, sizeof(double) * n1));
-    HIPCHK(hipMalloc((void **)&h->X, sizeof(double) * n1));
-    HIPCHK(hipMalloc((void **)&h->SE, sizeof(double) * n1));
-    HIPCHK(hipMalloc((void **)&h->partials, sizeof(double) * SPMV_MAX_GRID));
-    {
-        const int64_t zn = std::max<int64_t>(h->A.P > 1 ? h->A.rows_v : 0, h->AT.P > 1 ? h->AT.rows_v : 0);
-        if (zn > 0) HIPCHK(hipMalloc((void **)&h->Z, sizeof(double) * (size_t)zn));
-    }
-    HIPCHK(hipMalloc((void **)&h->d_scalar, sizeof(double) * 4));
-    for (double **pp : {&h->P1[0], &h->P1[1], &h->P2[0], &h->P2[1], &h->P3}) {
-        HIPCHK(hipMalloc((void **)pp, sizeof(double) * SPMV_MAX_GRID));
-        HIPCHK(hipMemsetAsync(*pp, 0, sizeof(double) * SPMV_MAX_GRID, s));
-    }
-    HIPCHK(hipMalloc((void **)&h->slots, sizeof(NormSlot) * 4));
-    HIPCHK(hipMemsetAsync(h->slots, 0, sizeof(NormSlot) * 4, s));
-    HIPCHK(hipMalloc((void **)&h->d_state, sizeof(LsqrState)));
-    HIPCHK(hipHostMalloc((void **)&h->h_state, sizeof(LsqrState)));
-    HIPCHK(hipMalloc((void **)&h->d_unit, sizeof(SpmvCoef)));
-    HIPCHK(hipMalloc((void **)&h->d_zero, sizeof(int)));
-    SpmvCoef unit{1.0, 1.0, 1.0, 0, 0};
-    HIPCHK(hipMemcpyAsync(h->d_unit, &unit, sizeof(unit), hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemsetAsync(h->d_zero, 0, sizeof(int), s));
-    HIPCHK(hipEventCreate(&h->ev_loop0));
-    HIPCHK(hipEventCreate(&h->ev_loop1));
-    h->vgrid_m = vec_grid(h->m);
-    h->vgrid_n = vec_grid(h->n);
-    HIPCHK(hipStreamSynchronize(s));
-    return LSQRHIP_OK;
+    return alloc_workspace(h);
 }
 
 static int new_handle(int m, int n, int64_t nnz, H **out)
@@ -707,6 +722,7 @@ extern "C" int lsqrhip_info(lsqrhip_handle_t h, int64_t *dims)
 // ---------------------------------------------------------------------------
 // launch helpers, iteration schedules, solve_core
 // ---------------------------------------------------------------------------
+static int op_call(H *h, int mode, double *d_x, double *d_y);  // op_api.h
 #include "solve_loop.h"
 
 extern "C" int lsqrhip_solve(lsqrhip_handle_t h, const double *b, double damp, double atol, double btol,
@@ -734,6 +750,11 @@ extern "C" int lsqrhip_aprod_device(lsqrhip_handle_t h, int mode, double *d_x, d
     if (!h) return fail(LSQRHIP_ERR_NOT_INIT, lsqrhip_error_string(LSQRHIP_ERR_NOT_INIT));
     if (mode != 1 && mode != 2) return fail(LSQRHIP_ERR_MODE, lsqrhip_error_string(LSQRHIP_ERR_MODE));
     HIPCHK(hipSetDevice(h->device));
+    if (h->op) {  // user device operator (op_api.h)
+        RET(op_call(h, mode, d_x, d_y));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        return LSQRHIP_OK;
+    }
     if (mode == 1) launch_spmv(h, h->A, d_x, d_y, h->d_unit, h->d_zero);   // y += A x
     else launch_spmv(h, h->AT, d_y, d_x, h->d_unit, h->d_zero);            // x += A' y
     HIPCHK(hipGetLastError());
@@ -952,6 +973,7 @@ extern "C" int lsqrhip_xcheck(lsqrhip_handle_t h, double anorm, double damp, dou
 extern "C" int lsqrhip_bench_kernel(lsqrhip_handle_t h, int which, int reps, double *avg_ms)
 {
     if (!h || !avg_ms || reps < 1 || which < 1 || which > 3) return fail(LSQRHIP_ERR_ARG, "bad bench_kernel arguments");
+    if (h->op && which != 3) return fail(LSQRHIP_ERR_ARG, "operator handles have no SpMV kernel to time");
     HIPCHK(hipSetDevice(h->device));
     hipStream_t s = h->stream;
     // operands: finite, small; coefficients that keep them bounded over `reps` launches
@@ -1028,6 +1050,7 @@ extern "C" int lsqrhip_set_option(lsqrhip_handle_t h, const char *name, int64_t 
         if (value < 1 || value > 1024) return fail(LSQRHIP_ERR_ARG, "graph_iters must be in [1,1024]");
         h->graph_iters = (int)value;
     } else if (k == "time_kernels") h->time_kernels = value != 0;
+    else if (k == "op_batch") h->op_batch = value < 1 ? 1 : (int)value;
     else if (k == "pipeline") h->pipeline = value < 0 ? 0 : (value > 2 ? 2 : (int)value);
     else return fail(LSQRHIP_ERR_ARG, "unknown option: " + k);
     return LSQRHIP_OK;
@@ -1076,5 +1099,6 @@ extern "C" int lsqrhip_dev_sync(void)
 }
 
 // row-block sharded solve (multi-GPU) and on-device problem generators
+#include "op_api.h"
 #include "shard_api.h"
 #include "gen_api.h"

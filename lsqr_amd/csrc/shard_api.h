@@ -58,6 +58,7 @@ extern "C" int lsqrhip_shard_begin(lsqrhip_handle_t h, const double *d_b_local, 
 {
     if (!h) return fail(LSQRHIP_ERR_NOT_INIT, lsqrhip_error_string(LSQRHIP_ERR_NOT_INIT));
     if (!d_T || !d_sums || (!d_b_local && h->m > 0)) return fail(LSQRHIP_ERR_ARG, "null shard buffer");
+    if (h->op) return fail(LSQRHIP_ERR_ARG, "the row-sharded solve needs a matrix handle, not an operator");
     HIPCHK(hipSetDevice(h->device));
     hipStream_t s = h->stream;
     LsqrState init;

@@ -305,25 +305,14 @@ static int ensure_graph(H *h, int G)
 }
 
 // ---------------------------------------------------------------------------
-// solve
+// pieces of a solve shared by the matrix path (solve_core) and the operator path (op_api.h)
 // ---------------------------------------------------------------------------
-static int solve_core(H *h, const double *b, bool b_on_device, double damp, double atol, double btol, double conlim,
-                      int itnlim, int wantse, int want_log, double *x, double *se, bool out_on_device, int *istop,
-                      int *itn, double *anorm, double *acond, double *rnorm, double *arnorm, double *xnorm)
+static int prepare_log(H *h, int itnlim, int want_log)
 {
-    if (!h) return fail(LSQRHIP_ERR_NOT_INIT, lsqrhip_error_string(LSQRHIP_ERR_NOT_INIT));
-    if (!istop || (!x && h->n > 0) || (!b && h->m > 0)) return fail(LSQRHIP_ERR_ARG, "null b, x or istop");
-    if (wantse && !se) return fail(LSQRHIP_ERR_ARG, "wantse set but se is null");
-    HIPCHK(hipSetDevice(h->device));
-    const auto t_host0 = std::chrono::steady_clock::now();
-    hipStream_t s = h->stream;
-    const int m = h->m, n = h->n;
-    LsqrState *st = h->d_state;
-
     if (want_log) {
         // printable iterations: the first/last 10, every 10th, near convergence -- or all of
         // them when n <= 40 (src/lsqr.f90:815-822); bounded at 2^20 records (112 MB)
-        const int64_t want = (n <= 40) ? (int64_t)itnlim : (int64_t)itnlim / 10 + 64;
+        const int64_t want = (h->n <= 40) ? (int64_t)itnlim : (int64_t)itnlim / 10 + 64;
         const int cap = (int)std::min<int64_t>(std::max<int64_t>(want, 64), 1 << 20);
         if (cap > h->log_cap) {
             if (h->d_log) (void)hipFree(h->d_log);
@@ -334,8 +323,13 @@ static int solve_core(H *h, const double *b, bool b_on_device, double damp, doub
         }
     }
     h->log_count = 0;
+    return LSQRHIP_OK;
+}
 
-    // ---- initial state (src/lsqr.f90:597-617) -------------------------------
+// initial state (src/lsqr.f90:597-617)
+static int upload_initial_state(H *h, double damp, double atol, double btol, double conlim, int itnlim, int wantse,
+                                int want_log)
+{
     LsqrState init;
     std::memset(&init, 0, sizeof(init));
     init.itnlim = itnlim;
@@ -343,8 +337,8 @@ static int solve_core(H *h, const double *b, bool b_on_device, double damp, doub
     init.wantse = wantse != 0;
     init.want_log = want_log != 0;
     init.log_cap = h->log_cap;
-    init.m = m;
-    init.n = n;
+    init.m = h->m;
+    init.n = h->n;
     init.damp = damp;
     init.atol = atol;
     init.btol = btol;
@@ -353,7 +347,75 @@ static int solve_core(H *h, const double *b, bool b_on_device, double damp, doub
     init.su = init.sv = 1.0;
     init.c1.skip = init.c2.skip = init.c2p.skip = 1;
     *h->h_state = init;
-    HIPCHK(hipMemcpyAsync(st, h->h_state, sizeof(LsqrState), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(h->d_state, h->h_state, sizeof(LsqrState), hipMemcpyHostToDevice, h->stream));
+    return LSQRHIP_OK;
+}
+
+// epilogue: se (:857-865), istop 2 -> 3 (:871), outputs.  h->h_state holds the settled state.
+static int finish_solve(H *h, int wantse, int want_log, double *x, double *se, bool out_on_device, int *istop,
+                        int *itn, double *anorm, double *acond, double *rnorm, double *arnorm, double *xnorm,
+                        bool timed, std::chrono::steady_clock::time_point t_host0)
+{
+    hipStream_t s = h->stream;
+    const int n = h->n;
+    lsqrhip_timing_t &tm = h->timing;
+    if (wantse && n > 0)
+        hipLaunchKernelGGL(k_se_finish, dim3(h->vgrid_n), dim3(VEC_BLOCK), 0, s, h->SE, (int64_t)n,
+                           (const LsqrState *)h->d_state);
+    const hipMemcpyKind out_kind = out_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+    if (n > 0) HIPCHK(hipMemcpyAsync(x, h->X, sizeof(double) * (size_t)n, out_kind, s));
+    if (wantse && n > 0) HIPCHK(hipMemcpyAsync(se, h->SE, sizeof(double) * (size_t)n, out_kind, s));
+    const LsqrState &r = *h->h_state;
+    if (want_log && r.itn > 0) {
+        h->log_count = std::min(r.log_count, h->log_cap);
+        h->h_log.resize((size_t)h->log_count * LOG_STRIDE);
+        HIPCHK(hipMemcpyAsync(h->h_log.data(), h->d_log, sizeof(double) * h->h_log.size(), hipMemcpyDeviceToHost, s));
+    }
+    HIPCHK(hipStreamSynchronize(s));
+    float loop_ms = 0;
+    (void)hipEventElapsedTime(&loop_ms, h->ev_loop0, h->ev_loop1);
+    tm.loop_ms = loop_ms;
+    tm.itn = r.itn;
+    if (!timed) tm.spmv1_launches = tm.spmv2_launches = tm.update_launches = r.itn;
+
+    int is = r.istop;
+    if (r.damped && is == 2) is = 3;
+    *istop = is;
+    if (itn) *itn = r.itn;
+    if (anorm) *anorm = r.anorm;
+    if (acond) *acond = r.acond;
+    if (rnorm) *rnorm = r.rnorm;
+    if (arnorm) *arnorm = r.arnorm;
+    if (xnorm) *xnorm = r.xnorm;
+    tm.solve_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_host0).count();
+    return LSQRHIP_OK;
+}
+
+static int solve_op(H *h, const double *b, bool b_on_device, double damp, double atol, double btol, double conlim,
+                    int itnlim, int wantse, int want_log, double *x, double *se, bool out_on_device, int *istop,
+                    int *itn, double *anorm, double *acond, double *rnorm, double *arnorm, double *xnorm);
+
+// ---------------------------------------------------------------------------
+// solve
+// ---------------------------------------------------------------------------
+static int solve_core(H *h, const double *b, bool b_on_device, double damp, double atol, double btol, double conlim,
+                      int itnlim, int wantse, int want_log, double *x, double *se, bool out_on_device, int *istop,
+                      int *itn, double *anorm, double *acond, double *rnorm, double *arnorm, double *xnorm)
+{
+    if (!h) return fail(LSQRHIP_ERR_NOT_INIT, lsqrhip_error_string(LSQRHIP_ERR_NOT_INIT));
+    if (!istop || (!x && h->n > 0) || (!b && h->m > 0)) return fail(LSQRHIP_ERR_ARG, "null b, x or istop");
+    if (wantse && !se) return fail(LSQRHIP_ERR_ARG, "wantse set but se is null");
+    HIPCHK(hipSetDevice(h->device));
+    if (h->op)  // user device operator (op_api.h)
+        return solve_op(h, b, b_on_device, damp, atol, btol, conlim, itnlim, wantse, want_log, x, se, out_on_device,
+                        istop, itn, anorm, acond, rnorm, arnorm, xnorm);
+    const auto t_host0 = std::chrono::steady_clock::now();
+    hipStream_t s = h->stream;
+    const int m = h->m, n = h->n;
+    LsqrState *st = h->d_state;
+
+    RET(prepare_log(h, itnlim, want_log));
+    RET(upload_initial_state(h, damp, atol, btol, conlim, itnlim, wantse, want_log));
 
     // u = b (solve_ez :242); v = 0, x = 0, se = 0 (:621-630)
     if (m > 0)
@@ -441,35 +503,6 @@ static int solve_core(H *h, const double *b, bool b_on_device, double damp, doub
     }
     HIPCHK(hipEventRecord(h->ev_loop1, s));
 
-    // ---- epilogue: se (:857-865), istop 2 -> 3 (:871), outputs --------------
-    if (wantse && n > 0)
-        hipLaunchKernelGGL(k_se_finish, dim3(h->vgrid_n), dim3(VEC_BLOCK), 0, s, h->SE, (int64_t)n,
-                           (const LsqrState *)st);
-    const hipMemcpyKind out_kind = out_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
-    if (n > 0) HIPCHK(hipMemcpyAsync(x, h->X, sizeof(double) * (size_t)n, out_kind, s));
-    if (wantse && n > 0) HIPCHK(hipMemcpyAsync(se, h->SE, sizeof(double) * (size_t)n, out_kind, s));
-    const LsqrState &r = *h->h_state;
-    if (want_log && r.itn > 0) {
-        h->log_count = std::min(r.log_count, h->log_cap);
-        h->h_log.resize((size_t)h->log_count * LOG_STRIDE);
-        HIPCHK(hipMemcpyAsync(h->h_log.data(), h->d_log, sizeof(double) * h->h_log.size(), hipMemcpyDeviceToHost, s));
-    }
-    HIPCHK(hipStreamSynchronize(s));
-    float loop_ms = 0;
-    (void)hipEventElapsedTime(&loop_ms, h->ev_loop0, h->ev_loop1);
-    tm.loop_ms = loop_ms;
-    tm.itn = r.itn;
-    if (!timed) tm.spmv1_launches = tm.spmv2_launches = tm.update_launches = r.itn;
-
-    int is = r.istop;
-    if (r.damped && is == 2) is = 3;
-    *istop = is;
-    if (itn) *itn = r.itn;
-    if (anorm) *anorm = r.anorm;
-    if (acond) *acond = r.acond;
-    if (rnorm) *rnorm = r.rnorm;
-    if (arnorm) *arnorm = r.arnorm;
-    if (xnorm) *xnorm = r.xnorm;
-    tm.solve_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_host0).count();
-    return LSQRHIP_OK;
+    return finish_solve(h, wantse, want_log, x, se, out_on_device, istop, itn, anorm, acond, rnorm, arnorm, xnorm,
+                        timed, t_host0);
 }
