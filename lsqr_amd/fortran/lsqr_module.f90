@@ -21,6 +21,8 @@ module lsqr_module
 
    integer, parameter :: LOG_STRIDE = 14   !< LSQRHIP_LOG_STRIDE
 
+   public :: lsqr_print_device_log, lsqr_check_status
+
    type, abstract, public :: lsqr_solver
       !! Solver driven by a user-written operator (reference src/lsqr.f90:16-30).
    contains
@@ -186,6 +188,12 @@ contains
       end select
    end subroutine check
 
+   !> `check` for sibling modules (lsqr_device_module).
+   subroutine lsqr_check_status(rc)
+      integer(c_int), intent(in) :: rc
+      call check(rc)
+   end subroutine lsqr_check_status
+
    !> Constructor (replaces src/lsqr.f90:91-127).  `me` is intent(out): any matrix the object
    !! held before is released (finalisation) and every option returns to its default.
    subroutine initialize_ez(me, m, n, a, irow, icol, atol, btol, conlim, itnlim, nout)
@@ -307,36 +315,47 @@ contains
       real(wp), intent(in) :: damp, anorm, acond, rnorm, arnorm, xnorm
       logical, intent(in) :: wantse
       integer, intent(in) :: istop, itn
+      call lsqr_print_device_log(me%handle, me%nout, me%m, me%n, damp, wantse, me%atol, me%btol, me%conlim, &
+                                 me%itnlim, istop, itn, anorm, acond, rnorm, arnorm, xnorm)
+   end subroutine print_device_log
+
+   !> The same for any lsqrhip handle (used by lsqr_device_module for operator handles).
+   subroutine lsqr_print_device_log(handle, nout, m, n, damp, wantse, atol, btol, conlim, itnlim, &
+                                    istop, itn, anorm, acond, rnorm, arnorm, xnorm)
+      type(c_ptr), intent(in) :: handle
+      integer, intent(in) :: nout, m, n, itnlim, istop, itn
+      real(wp), intent(in) :: damp, atol, btol, conlim, anorm, acond, rnorm, arnorm, xnorm
+      logical, intent(in) :: wantse
       real(c_double), allocatable :: rec(:, :)
       real(c_double) :: ex(6)
       real(wp) :: ctol, test3
       integer :: k, nrec, it, ist
       logical :: show
 
-      call log_header(me%nout, me%m, me%n, damp, wantse, me%atol, me%btol, me%conlim, me%itnlim)
-      call check(lsqrhip_log_extras(me%handle, ex))
-      nrec = lsqrhip_log_count(me%handle)
+      call log_header(nout, m, n, damp, wantse, atol, btol, conlim, itnlim)
+      call check(lsqrhip_log_extras(handle, ex))
+      nrec = lsqrhip_log_count(handle)
       ctol = zero
-      if (me%conlim > zero) ctol = one/me%conlim
+      if (conlim > zero) ctol = one/conlim
       if (itn > 0 .or. istop /= 0) then
-         call log_titles(me%nout, damp > zero, ex(5), ex(6))
+         call log_titles(nout, damp > zero, ex(5), ex(6))
          if (nrec > 0) then
             allocate (rec(LOG_STRIDE, nrec))
-            call check(lsqrhip_log_fetch(me%handle, 0_c_int, int(nrec, c_int), rec))
+            call check(lsqrhip_log_fetch(handle, 0_c_int, int(nrec, c_int), rec))
             do k = 1, nrec
                it = nint(rec(1, k))
                ist = nint(rec(12, k))
                test3 = huge(one)
                if (rec(7, k) /= zero) test3 = one/rec(7, k)
-               show = (me%n <= 40) .or. (it <= 10) .or. (it >= me%itnlim - 10) .or. (mod(it, 10) == 0) .or. &
-                      (test3 <= 2.0_wp*ctol) .or. (rec(5, k) <= 10.0_wp*me%atol) .or. &
+               show = (n <= 40) .or. (it <= 10) .or. (it >= itnlim - 10) .or. (mod(it, 10) == 0) .or. &
+                      (test3 <= 2.0_wp*ctol) .or. (rec(5, k) <= 10.0_wp*atol) .or. &
                       (rec(4, k) <= 10.0_wp*rec(13, k)) .or. (ist /= 0)
-               if (show) write (me%nout, iter_fmt) it, rec(2:11, k)
+               if (show) write (nout, iter_fmt) it, rec(2:11, k)
             end do
          end if
       end if
-      call log_exit(me%nout, istop, itn, anorm, acond, ex(1), xnorm, rnorm, arnorm, ex(2), nint(ex(3)))
-   end subroutine print_device_log
+      call log_exit(nout, istop, itn, anorm, acond, ex(1), xnorm, rnorm, arnorm, ex(2), nint(ex(3)))
+   end subroutine lsqr_print_device_log
 
    ! =========================================================================================
    !  log text shared by the GPU path and the host path

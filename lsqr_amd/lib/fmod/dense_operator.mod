@@ -1,5 +1,5 @@
-﻿!mod$ v1 sum:740dbd66f9078684
-!need$ b7fed9d38d706627 n lsqr_module
+﻿!mod$ v1 sum:1ffec0e3c8955341
+!need$ 21717a00586b85b6 n lsqr_module
 !need$ 8587e60dcd189e35 n lsqr_kinds
 module dense_operator
 use lsqr_module,only:lsqr_solver

@@ -1,10 +1,12 @@
-﻿!mod$ v1 sum:21717a00586b85b6
+﻿!mod$ v1 sum:78e29451f6407fca
+!need$ 21717a00586b85b6 n lsqr_module
 !need$ 0bde2ac47243ead2 i iso_c_binding
-!need$ 389225140ffd66f8 n lsqpblas_module
 !need$ bb381bf46e508468 i __fortran_builtins
 !need$ 8587e60dcd189e35 n lsqr_kinds
-module lsqr_module
+module lsqr_device_module
 use,intrinsic::__fortran_builtins,only:__builtin_c_ptr
+use lsqr_module,only:lsqr_print_device_log
+use lsqr_module,only:lsqr_check_status
 use,intrinsic::iso_c_binding,only:c_associated
 use,intrinsic::iso_c_binding,only:c_funloc
 use,intrinsic::iso_c_binding,only:c_funptr
@@ -83,12 +85,10 @@ use,intrinsic::iso_c_binding,only:c_f_procpointer
 use lsqr_kinds,only:wp
 use lsqr_kinds,only:zero
 use lsqr_kinds,only:one
-use lsqpblas_module,only:dcopy
-use lsqpblas_module,only:ddot
-use lsqpblas_module,only:dnrm2
-use lsqpblas_module,only:dscal
 use,intrinsic::__fortran_builtins,only:iso_c_binding$__fortran_builtins$c_associated_c_ptr=>c_associated_c_ptr
 private::__builtin_c_ptr
+private::lsqr_print_device_log
+private::lsqr_check_status
 private::c_associated
 private::c_funloc
 private::c_funptr
@@ -167,75 +167,95 @@ private::c_f_procpointer
 private::wp
 private::zero
 private::one
-private::dcopy
-private::ddot
-private::dnrm2
-private::dscal
 private::iso_c_binding$__fortran_builtins$c_associated_c_ptr
-integer(4),parameter,private::log_stride=14_4
-type,abstract::lsqr_solver
+type::lsqr_device_handle
+type(c_ptr)::handle=__builtin_c_ptr(__address=0_8)
+integer(4)::m=0_4
+integer(4)::n=0_4
 contains
-procedure(aprod_func),deferred::aprod
-procedure::lsqr
-procedure::acheck
-procedure::xcheck
+procedure::lsqr=>lsqr_dev
+procedure::acheck=>acheck_dev
+procedure::xcheck=>xcheck_dev
+procedure::destroy=>destroy_dev
 end type
-type,extends(lsqr_solver)::lsqr_solver_ez
-integer(4),private::m=0_4
-integer(4),private::n=0_4
-integer(4),private::num_nonzero_elements=0_4
-real(8),private::atol=0._8
-real(8),private::btol=0._8
-real(8),private::conlim=0._8
-integer(4),private::itnlim=100_4
-integer(4),private::nout=0_4
-type(c_ptr),private::handle=__builtin_c_ptr(__address=0_8)
+type,private::dev_box
+class(lsqr_solver_device),pointer::p=>NULL()
+end type
+intrinsic::null
+private::null
+type,abstract,extends(lsqr_device_handle)::lsqr_solver_device
+type(dev_box),pointer,private::box=>NULL()
 contains
-procedure::initialize=>initialize_ez
-procedure::solve=>solve_ez
-procedure::aprod=>aprod_ez
-procedure::destroy=>destroy_ez
-procedure,private::copy_ez
-generic::assignment(=)=>copy_ez
-final::finalize_ez
+procedure(aprod_device_func),deferred::aprod_device
+procedure::initialize_device
 end type
-private::aprod_func
+type,extends(lsqr_device_handle)::lsqr_test_problem_device
+real(8)::acond=0._8
+real(8)::rnorm=0._8
+real(8),allocatable::b(:)
+real(8),allocatable::xtrue(:)
+contains
+procedure::create=>create_test_problem
+end type
+private::aprod_device_func
 abstract interface
-subroutine aprod_func(me,mode,m,n,x,y)
-import::lsqr_solver
-class(lsqr_solver),intent(inout)::me
+subroutine aprod_device_func(me,mode,m,n,x,y,stream)
+import::c_ptr
+import::lsqr_solver_device
+class(lsqr_solver_device),intent(inout)::me
 integer(4),intent(in)::mode
 integer(4),intent(in)::m
 integer(4),intent(in)::n
-real(8),intent(inout)::x(:)
-real(8),intent(inout)::y(:)
+type(c_ptr),intent(in)::x
+type(c_ptr),intent(in)::y
+type(c_ptr),intent(in)::stream
 end
 end interface
-private::lsqrhip_create
+private::lsqrhip_create_operator
 interface
-function lsqrhip_create(m,n,nnz,irow,icol,a,h) bind(c,name="lsqrhip_create") result(rc)
+function lsqrhip_create_operator(m,n,aprod,user,h) bind(c,name="lsqrhip_create_operator") result(rc)
+import::c_funptr
 import::c_ptr
 integer(4),value::m
 integer(4),value::n
-integer(8),value::nnz
-integer(4),intent(in)::irow(1_8:*)
-integer(4),intent(in)::icol(1_8:*)
-real(8),intent(in)::a(1_8:*)
+type(c_funptr),value::aprod
+type(c_ptr),value::user
 type(c_ptr),intent(out)::h
+integer(4)::rc
+end
+end interface
+private::lsqrhip_lstp_create
+interface
+function lsqrhip_lstp_create(m,n,nduplc,npower,damp,h,acond,rnorm) bind(c,name="lsqrhip_lstp_create") result(rc)
+import::c_ptr
+integer(4),value::m
+integer(4),value::n
+integer(4),value::nduplc
+integer(4),value::npower
+real(8),value::damp
+type(c_ptr),intent(out)::h
+real(8),intent(out)::acond
+real(8),intent(out)::rnorm
+integer(4)::rc
+end
+end interface
+private::lsqrhip_lstp_vectors
+interface
+function lsqrhip_lstp_vectors(h,xtrue,b,d,hy,hz,d_b) bind(c,name="lsqrhip_lstp_vectors") result(rc)
+import::c_ptr
+type(c_ptr),value::h
+real(8),intent(out)::xtrue(1_8:*)
+real(8),intent(out)::b(1_8:*)
+type(c_ptr),value::d
+type(c_ptr),value::hy
+type(c_ptr),value::hz
+type(c_ptr),value::d_b
 integer(4)::rc
 end
 end interface
 private::lsqrhip_destroy
 interface
 function lsqrhip_destroy(h) bind(c,name="lsqrhip_destroy") result(rc)
-import::c_ptr
-type(c_ptr),value::h
-integer(4)::rc
-end
-end interface
-private::lsqrhip_retain
-interface
-function lsqrhip_retain(h) bind(c,name="lsqrhip_retain") result(rc)
 import::c_ptr
 type(c_ptr),value::h
 integer(4)::rc
@@ -266,199 +286,89 @@ real(8),intent(out)::xnorm
 integer(4)::rc
 end
 end interface
-private::lsqrhip_aprod
+private::lsqrhip_acheck
 interface
-function lsqrhip_aprod(h,mode,x,y) bind(c,name="lsqrhip_aprod") result(rc)
+function lsqrhip_acheck(h,eps,inform,relerr) bind(c,name="lsqrhip_acheck") result(rc)
+import::c_ptr
+type(c_ptr),value::h
+real(8),value::eps
+integer(4),intent(out)::inform
+real(8),intent(out)::relerr
+integer(4)::rc
+end
+end interface
+private::lsqrhip_xcheck
+interface
+function lsqrhip_xcheck(h,anorm,damp,eps,b,x,u,v,w,inform,tests) bind(c,name="lsqrhip_xcheck") result(rc)
+import::c_ptr
+type(c_ptr),value::h
+real(8),value::anorm
+real(8),value::damp
+real(8),value::eps
+real(8),intent(in)::b(1_8:*)
+real(8),intent(in)::x(1_8:*)
+real(8),intent(out)::u(1_8:*)
+real(8),intent(out)::v(1_8:*)
+real(8),intent(out)::w(1_8:*)
+integer(4),intent(out)::inform
+real(8),intent(out)::tests(1_8:3_8)
+integer(4)::rc
+end
+end interface
+interface
+function lsqrhip_aprod_device(h,mode,d_x,d_y) bind(c,name="lsqrhip_aprod_device") result(rc)
 import::c_ptr
 type(c_ptr),value::h
 integer(4),value::mode
-real(8),intent(inout)::x(1_8:*)
-real(8),intent(inout)::y(1_8:*)
+type(c_ptr),value::d_x
+type(c_ptr),value::d_y
 integer(4)::rc
 end
 end interface
-private::lsqrhip_log_count
 interface
-function lsqrhip_log_count(h) bind(c,name="lsqrhip_log_count") result(k)
+function lsqrhip_set_stream(h,stream) bind(c,name="lsqrhip_set_stream") result(rc)
 import::c_ptr
 type(c_ptr),value::h
-integer(4)::k
-end
-end interface
-private::lsqrhip_log_fetch
-interface
-function lsqrhip_log_fetch(h,first,count,records) bind(c,name="lsqrhip_log_fetch") result(rc)
-import::c_ptr
-type(c_ptr),value::h
-integer(4),value::first
-integer(4),value::count
-real(8),intent(out)::records(1_8:*)
+type(c_ptr),value::stream
 integer(4)::rc
 end
 end interface
-private::lsqrhip_log_extras
-interface
-function lsqrhip_log_extras(h,ex) bind(c,name="lsqrhip_log_extras") result(rc)
-import::c_ptr
-type(c_ptr),value::h
-real(8),intent(out)::ex(1_8:*)
-integer(4)::rc
-end
-end interface
-private::lsqrhip_last_error
-interface
-function lsqrhip_last_error() bind(c,name="lsqrhip_last_error") result(p)
-import::c_ptr
-type(c_ptr)::p
-end
-end interface
-private::c_strlen
-interface
-function c_strlen(s) bind(c,name="strlen") result(k)
-import::c_ptr
-type(c_ptr),value::s
-integer(8)::k
-end
-end interface
-character(*,1),parameter,private::enter_tag=" Enter LSQR.  "
-character(*,1),parameter,private::exit_tag=" Exit  LSQR.  "
-character(*,1),parameter,private::iter_fmt="(1P, I6, 2E17.9, 4E10.2, E9.1, 3E8.1)"
-character(53_4,1),parameter,private::stop_msg(0_8:5_8)=[CHARACTER(KIND=1,LEN=53)::"The exact solution is x = 0                          ","A solution to Ax = b was found, given atol, btol     ","A least-squares solution was found, given atol       ","A damped least-squares solution was found, given atol","Cond(Abar) seems to be too large, given conlim       ","The iteration limit was reached                      "]
-private::check
-private::initialize_ez
-private::destroy_ez
-private::finalize_ez
-private::copy_ez
-private::aprod_ez
-private::solve_ez
-private::print_device_log
-private::log_header
-private::log_titles
-private::log_exit
-private::d2norm
-private::lsqr
-private::acheck
-private::xcheck
+private::trampoline
+private::initialize_device
+private::destroy_dev
+private::create_test_problem
+private::lsqr_dev
+private::acheck_dev
+private::xcheck_dev
 contains
-subroutine check(rc)
-integer(4),intent(in)::rc
+function trampoline(user,mode,m,n,d_x,d_y,stream) bind(c) result(rc)
+type(c_ptr),value::user
+integer(4),value::mode
+integer(4),value::m
+integer(4),value::n
+type(c_ptr),value::d_x
+type(c_ptr),value::d_y
+type(c_ptr),value::stream
+integer(4)::rc
 end
-subroutine lsqr_check_status(rc)
-integer(4),intent(in)::rc
-end
-subroutine initialize_ez(me,m,n,a,irow,icol,atol,btol,conlim,itnlim,nout)
-class(lsqr_solver_ez),intent(out)::me
+subroutine initialize_device(me,m,n)
+class(lsqr_solver_device),intent(inout),target::me
 integer(4),intent(in)::m
 integer(4),intent(in)::n
-real(8),intent(in)::a(:)
-integer(4),intent(in)::irow(:)
-integer(4),intent(in)::icol(:)
-real(8),intent(in),optional::atol
-real(8),intent(in),optional::btol
-real(8),intent(in),optional::conlim
-integer(4),intent(in),optional::itnlim
-integer(4),intent(in),optional::nout
 end
-subroutine destroy_ez(me)
-class(lsqr_solver_ez),intent(inout)::me
+subroutine destroy_dev(me)
+class(lsqr_device_handle),intent(inout)::me
 end
-subroutine finalize_ez(me)
-type(lsqr_solver_ez),intent(inout)::me
-end
-subroutine copy_ez(lhs,rhs)
-class(lsqr_solver_ez),intent(inout)::lhs
-class(lsqr_solver_ez),intent(in)::rhs
-end
-subroutine aprod_ez(me,mode,m,n,x,y)
-class(lsqr_solver_ez),intent(inout)::me
-integer(4),intent(in)::mode
+subroutine create_test_problem(me,m,n,nduplc,npower,damp)
+class(lsqr_test_problem_device),intent(inout)::me
 integer(4),intent(in)::m
 integer(4),intent(in)::n
-real(8),intent(inout)::x(:)
-real(8),intent(inout)::y(:)
-end
-subroutine solve_ez(me,b,damp,x,istop,se,itn,anorm,acond,rnorm,arnorm,xnorm)
-class(lsqr_solver_ez),intent(inout)::me
-real(8),intent(in)::b(1_8:int(me%m,kind=8))
+integer(4),intent(in)::nduplc
+integer(4),intent(in)::npower
 real(8),intent(in)::damp
-real(8),intent(out)::x(1_8:int(me%n,kind=8))
-integer(4),intent(out)::istop
-real(8),intent(out),optional::se(1_8:int(me%n,kind=8))
-integer(4),intent(out),optional::itn
-real(8),intent(out),optional::anorm
-real(8),intent(out),optional::acond
-real(8),intent(out),optional::rnorm
-real(8),intent(out),optional::arnorm
-real(8),intent(out),optional::xnorm
 end
-subroutine print_device_log(me,damp,wantse,istop,itn,anorm,acond,rnorm,arnorm,xnorm)
-class(lsqr_solver_ez),intent(in)::me
-real(8),intent(in)::damp
-logical(4),intent(in)::wantse
-integer(4),intent(in)::istop
-integer(4),intent(in)::itn
-real(8),intent(in)::anorm
-real(8),intent(in)::acond
-real(8),intent(in)::rnorm
-real(8),intent(in)::arnorm
-real(8),intent(in)::xnorm
-end
-subroutine lsqr_print_device_log(handle,nout,m,n,damp,wantse,atol,btol,conlim,itnlim,istop,itn,anorm,acond,rnorm,arnorm,xnorm)
-type(c_ptr),intent(in)::handle
-integer(4),intent(in)::nout
-integer(4),intent(in)::m
-integer(4),intent(in)::n
-real(8),intent(in)::damp
-logical(4),intent(in)::wantse
-real(8),intent(in)::atol
-real(8),intent(in)::btol
-real(8),intent(in)::conlim
-integer(4),intent(in)::itnlim
-integer(4),intent(in)::istop
-integer(4),intent(in)::itn
-real(8),intent(in)::anorm
-real(8),intent(in)::acond
-real(8),intent(in)::rnorm
-real(8),intent(in)::arnorm
-real(8),intent(in)::xnorm
-end
-subroutine log_header(nout,m,n,damp,wantse,atol,btol,conlim,itnlim)
-integer(4),intent(in)::nout
-integer(4),intent(in)::m
-integer(4),intent(in)::n
-real(8),intent(in)::damp
-logical(4),intent(in)::wantse
-real(8),intent(in)::atol
-real(8),intent(in)::btol
-real(8),intent(in)::conlim
-integer(4),intent(in)::itnlim
-end
-subroutine log_titles(nout,damped,beta,test2)
-integer(4),intent(in)::nout
-logical(4),intent(in)::damped
-real(8),intent(in)::beta
-real(8),intent(in)::test2
-end
-subroutine log_exit(nout,istop,itn,anorm,acond,bnorm,xnorm,rnorm,arnorm,dxmax,maxdx)
-integer(4),intent(in)::nout
-integer(4),intent(in)::istop
-integer(4),intent(in)::itn
-real(8),intent(in)::anorm
-real(8),intent(in)::acond
-real(8),intent(in)::bnorm
-real(8),intent(in)::xnorm
-real(8),intent(in)::rnorm
-real(8),intent(in)::arnorm
-real(8),intent(in)::dxmax
-integer(4),intent(in)::maxdx
-end
-pure function d2norm(a,b) result(r)
-real(8),intent(in)::a
-real(8),intent(in)::b
-real(8)::r
-end
-subroutine lsqr(me,m,n,damp,wantse,u,v,w,x,se,atol,btol,conlim,itnlim,nout,istop,itn,anorm,acond,rnorm,arnorm,xnorm)
-class(lsqr_solver),intent(inout)::me
+subroutine lsqr_dev(me,m,n,damp,wantse,u,v,w,x,se,atol,btol,conlim,itnlim,nout,istop,itn,anorm,acond,rnorm,arnorm,xnorm)
+class(lsqr_device_handle),intent(inout)::me
 integer(4),intent(in)::m
 integer(4),intent(in)::n
 real(8),intent(in)::damp
@@ -467,7 +377,7 @@ real(8),intent(inout)::u(1_8:int(m,kind=8))
 real(8),intent(inout)::v(1_8:int(n,kind=8))
 real(8),intent(inout)::w(1_8:int(n,kind=8))
 real(8),intent(out)::x(1_8:int(n,kind=8))
-real(8),intent(out)::se(1_8:*)
+real(8),intent(inout)::se(1_8:*)
 real(8),intent(in)::atol
 real(8),intent(in)::btol
 real(8),intent(in)::conlim
@@ -481,20 +391,20 @@ real(8),intent(out)::rnorm
 real(8),intent(out)::arnorm
 real(8),intent(out)::xnorm
 end
-subroutine acheck(me,m,n,nout,eps,v,w,x,y,inform)
-class(lsqr_solver),intent(inout)::me
+subroutine acheck_dev(me,m,n,nout,eps,v,w,x,y,inform)
+class(lsqr_device_handle),intent(inout)::me
 integer(4),intent(in)::m
 integer(4),intent(in)::n
 integer(4),intent(in)::nout
 real(8),intent(in)::eps
-real(8)::v(1_8:int(n,kind=8))
-real(8)::w(1_8:int(m,kind=8))
-real(8)::x(1_8:int(n,kind=8))
-real(8)::y(1_8:int(m,kind=8))
+real(8),intent(inout)::v(1_8:int(n,kind=8))
+real(8),intent(inout)::w(1_8:int(m,kind=8))
+real(8),intent(inout)::x(1_8:int(n,kind=8))
+real(8),intent(inout)::y(1_8:int(m,kind=8))
 integer(4),intent(out)::inform
 end
-subroutine xcheck(me,m,n,nout,anorm,damp,eps,b,u,v,w,x,inform,test1,test2,test3)
-class(lsqr_solver),intent(inout)::me
+subroutine xcheck_dev(me,m,n,nout,anorm,damp,eps,b,u,v,w,x,inform,test1,test2,test3)
+class(lsqr_device_handle),intent(inout)::me
 integer(4),intent(in)::m
 integer(4),intent(in)::n
 integer(4),intent(in)::nout

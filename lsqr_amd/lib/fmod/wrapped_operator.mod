@@ -1,0 +1,107 @@
+﻿!mod$ v1 sum:9858a778cb402f77
+!need$ 0bde2ac47243ead2 i iso_c_binding
+!need$ 8587e60dcd189e35 n lsqr_kinds
+!need$ 78e29451f6407fca n lsqr_device_module
+module wrapped_operator
+use,intrinsic::__fortran_builtins,only:__builtin_c_ptr
+use,intrinsic::iso_c_binding,only:c_associated
+use,intrinsic::iso_c_binding,only:c_funloc
+use,intrinsic::iso_c_binding,only:c_funptr
+use,intrinsic::iso_c_binding,only:c_f_pointer
+use,intrinsic::iso_c_binding,only:c_loc
+use,intrinsic::iso_c_binding,only:c_null_funptr
+use,intrinsic::iso_c_binding,only:c_null_ptr
+use,intrinsic::iso_c_binding,only:c_ptr
+use,intrinsic::iso_c_binding,only:c_sizeof
+use,intrinsic::iso_c_binding,only:operator(==)
+use,intrinsic::iso_c_binding,only:operator(/=)
+use,intrinsic::iso_c_binding,only:c_int8_t
+use,intrinsic::iso_c_binding,only:c_int16_t
+use,intrinsic::iso_c_binding,only:c_int32_t
+use,intrinsic::iso_c_binding,only:c_int64_t
+use,intrinsic::iso_c_binding,only:c_int128_t
+use,intrinsic::iso_c_binding,only:c_int
+use,intrinsic::iso_c_binding,only:c_short
+use,intrinsic::iso_c_binding,only:c_long
+use,intrinsic::iso_c_binding,only:c_long_long
+use,intrinsic::iso_c_binding,only:c_signed_char
+use,intrinsic::iso_c_binding,only:c_size_t
+use,intrinsic::iso_c_binding,only:c_intmax_t
+use,intrinsic::iso_c_binding,only:c_intptr_t
+use,intrinsic::iso_c_binding,only:c_ptrdiff_t
+use,intrinsic::iso_c_binding,only:c_int_least8_t
+use,intrinsic::iso_c_binding,only:c_int_fast8_t
+use,intrinsic::iso_c_binding,only:c_int_least16_t
+use,intrinsic::iso_c_binding,only:c_int_fast16_t
+use,intrinsic::iso_c_binding,only:c_int_least32_t
+use,intrinsic::iso_c_binding,only:c_int_fast32_t
+use,intrinsic::iso_c_binding,only:c_int_least64_t
+use,intrinsic::iso_c_binding,only:c_int_fast64_t
+use,intrinsic::iso_c_binding,only:c_int_least128_t
+use,intrinsic::iso_c_binding,only:c_int_fast128_t
+use,intrinsic::iso_c_binding,only:c_float
+use,intrinsic::iso_c_binding,only:c_double
+use,intrinsic::iso_c_binding,only:c_long_double
+use,intrinsic::iso_c_binding,only:c_float_complex
+use,intrinsic::iso_c_binding,only:c_double_complex
+use,intrinsic::iso_c_binding,only:c_long_double_complex
+use,intrinsic::iso_c_binding,only:c_bool
+use,intrinsic::iso_c_binding,only:c_char
+use,intrinsic::iso_c_binding,only:c_null_char
+use,intrinsic::iso_c_binding,only:c_alert
+use,intrinsic::iso_c_binding,only:c_backspace
+use,intrinsic::iso_c_binding,only:c_form_feed
+use,intrinsic::iso_c_binding,only:c_new_line
+use,intrinsic::iso_c_binding,only:c_carriage_return
+use,intrinsic::iso_c_binding,only:c_horizontal_tab
+use,intrinsic::iso_c_binding,only:c_vertical_tab
+use,intrinsic::iso_c_binding,only:c_float128
+use,intrinsic::iso_c_binding,only:c_float128_complex
+use,intrinsic::iso_c_binding,only:c_uint8_t
+use,intrinsic::iso_c_binding,only:c_uint16_t
+use,intrinsic::iso_c_binding,only:c_uint32_t
+use,intrinsic::iso_c_binding,only:c_uint64_t
+use,intrinsic::iso_c_binding,only:c_uint128_t
+use,intrinsic::iso_c_binding,only:c_unsigned_char
+use,intrinsic::iso_c_binding,only:c_unsigned_short
+use,intrinsic::iso_c_binding,only:c_unsigned
+use,intrinsic::iso_c_binding,only:c_unsigned_long
+use,intrinsic::iso_c_binding,only:c_unsigned_long_long
+use,intrinsic::iso_c_binding,only:c_uintmax_t
+use,intrinsic::iso_c_binding,only:c_uint_fast8_t
+use,intrinsic::iso_c_binding,only:c_uint_fast16_t
+use,intrinsic::iso_c_binding,only:c_uint_fast32_t
+use,intrinsic::iso_c_binding,only:c_uint_fast64_t
+use,intrinsic::iso_c_binding,only:c_uint_fast128_t
+use,intrinsic::iso_c_binding,only:c_uint_least8_t
+use,intrinsic::iso_c_binding,only:c_uint_least16_t
+use,intrinsic::iso_c_binding,only:c_uint_least32_t
+use,intrinsic::iso_c_binding,only:c_uint_least64_t
+use,intrinsic::iso_c_binding,only:c_uint_least128_t
+use,intrinsic::iso_c_binding,only:c_f_procpointer
+use lsqr_kinds,only:wp
+use lsqr_kinds,only:zero
+use lsqr_kinds,only:one
+use lsqr_device_module,only:lsqr_device_handle
+use lsqr_device_module,only:lsqr_solver_device
+use lsqr_device_module,only:lsqr_test_problem_device
+use lsqr_device_module,only:lsqrhip_aprod_device
+use lsqr_device_module,only:lsqrhip_set_stream
+private::__builtin_c_ptr
+type,extends(lsqr_solver_device)::wrapped_solver
+type(c_ptr)::inner=__builtin_c_ptr(__address=0_8)
+integer(4)::calls=0_4
+contains
+procedure::aprod_device=>wrapped_aprod
+end type
+contains
+subroutine wrapped_aprod(me,mode,m,n,x,y,stream)
+class(wrapped_solver),intent(inout)::me
+integer(4),intent(in)::mode
+integer(4),intent(in)::m
+integer(4),intent(in)::n
+type(c_ptr),intent(in)::x
+type(c_ptr),intent(in)::y
+type(c_ptr),intent(in)::stream
+end
+end

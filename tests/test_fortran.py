@@ -141,3 +141,29 @@ def test_fortran_error_stops_on_gpu(which):
 def test_fortran_error_driver_ok_case():
     p = run_err("ok")
     assert p.returncode == 0 and "OK istop= 1" in p.stdout
+
+
+@pytest.mark.gpu
+def test_fortran_device_operator_and_user_subclass_on_gpu():
+    """lsqr_device_module: the reference's test problem P(2000,1000,40,3,1e-9) as a device
+    operator driven from Fortran with the reference's argument lists, and a user type extending
+    lsqr_solver_device whose aprod_device enqueues library work on the stream it is handed."""
+    out = run("test_device_operator").stdout
+    assert "DEVICE OPERATOR TESTS PASSED" in out
+    line = {k: l for l in out.splitlines() for k in ("LSTP acond", "ACHECK", "LSQR istop", "LSQR norms", "XCHECK",
+                                                      "ENORM", "X8", "USER istop", "USER maxdiff") if l.startswith(k)}
+    o = oracle.port().lstp_test(2000, 1000, 40, 3, 1e-9)
+    acond, rnorm = numbers(line["LSTP acond"])
+    assert acond == pytest.approx(o["acond_lstp"], rel=1e-14) and rnorm == pytest.approx(o["rnorm_lstp"], rel=1e-13)
+    assert "inform= 0" in line["ACHECK"]
+    istop, itn = (int(t) for t in re.findall(r"=\s*(\d+)", line["LSQR istop"]))
+    assert istop == o["istop"] == 3
+    assert 0.75 * o["itn"] - 3 <= itn <= 1.05 * o["itn"] + 3      # see tests/test_gpu_operator.py
+    assert int(re.search(r"inform,tests=\s*(\d+)", line["XCHECK"]).group(1)) == o["xcheck_inform"]
+    enorm = numbers(line["ENORM"])[0]
+    assert enorm <= 50 * o["enorm"] + 1e-13
+    np.testing.assert_allclose(numbers(line["X8"]), o["xtrue"][:8], rtol=0,
+                               atol=1.01 * enorm * (1.0 + np.linalg.norm(o["xtrue"])))
+    uistop, uitn, calls = (int(t) for t in re.findall(r"=\s*(\d+)", line["USER istop"]))
+    assert (uistop, uitn) == (istop, itn) and calls >= 2 * itn + 1
+    assert numbers(line["USER maxdiff"])[0] == 0.0
