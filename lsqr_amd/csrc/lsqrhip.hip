@@ -364,6 +364,19 @@ static int try_sell(hipStream_t s, Csr &out, int64_t nnz, const double *dict, in
     return LSQRHIP_OK;
 }
 
+// in-place exclusive scan of a[0..L); `sums` is scratch of L / SCAN_CHUNK + 1 words
+static void launch_scan(hipStream_t s, unsigned *a, int64_t L, unsigned *sums)
+{
+    if (L <= 4 * SCAN_CHUNK) {
+        hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, s, a, L);
+        return;
+    }
+    const int64_t nc = (L + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    hipLaunchKernelGGL(k_scan_sums, dim3((unsigned)nc), dim3(256), 0, s, (const unsigned *)a, L, sums);
+    hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, s, sums, nc);
+    hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nc), dim3(256), 0, s, a, L, (const unsigned *)sums);
+}
+
 template <typename OffT>
 static int build_csr_T(hipStream_t s, const int *d_keys, const int *d_other, const double *d_a, int64_t nnz,
                        int rows, int cols, int bad_code, int bad_code_other, int panels, int pw,
@@ -406,7 +419,7 @@ static int build_csr_T(hipStream_t s, const int *d_keys, const int *d_other, con
             unsigned long long *in = bufA, *outb = bufB;
             for (int shift = 32; shift < 32 + nbits; shift += 8) {
                 hipLaunchKernelGGL(k_radix_hist, dim3((unsigned)nb), dim3(RS_BLOCK), 0, s, in, nnz, shift, nb, hist);
-                hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, s, hist, (int64_t)256 * nb);
+                launch_scan(s, hist, (int64_t)256 * nb, hist + (size_t)256 * nb);
                 hipLaunchKernelGGL(k_radix_scatter, dim3((unsigned)nb), dim3(RS_BLOCK), 0, s, in, outb, nnz, shift, nb, hist);
                 HIPCHK(hipGetLastError());
                 std::swap(in, outb);
@@ -592,7 +605,8 @@ static int finish_create(H *h, const int *d_irow, const int *d_icol, const doubl
     const int64_t nb = std::max<int64_t>((nnz + RS_TILE - 1) / RS_TILE, 1);
     HIPCHK(hipMalloc((void **)&bufA, sizeof(unsigned long long) * (size_t)std::max<int64_t>(nnz, 1)));
     HIPCHK(hipMalloc((void **)&bufB, sizeof(unsigned long long) * (size_t)std::max<int64_t>(nnz, 1)));
-    HIPCHK(hipMalloc((void **)&hist, sizeof(unsigned) * 256 * (size_t)nb));
+    // histogram + the block sums of its scan (csr_build.h k_scan_*)
+    HIPCHK(hipMalloc((void **)&hist, sizeof(unsigned) * (256 * (size_t)nb + (256 * (size_t)nb) / SCAN_CHUNK + 64)));
     HIPCHK(hipMalloc((void **)&d_flags, 4 * sizeof(int)));
     // locality of the column pattern (only looked at when a vector exceeds L2; indices that are
     // out of range are caught by the build below, the measure merely becomes meaningless)

@@ -62,6 +62,14 @@ __global__ __launch_bounds__(256) void k_dict_collect(const double *__restrict__
             *vgive = 1;
             return;
         }
+        // a value this workgroup has not seen: look at the overflow flag before touching the
+        // shared table (once a matrix with arbitrary values has overflowed it, every remaining
+        // thread leaves here on its first element instead of queueing up on one atomic counter:
+        // 459 ms -> well under 1 ms for 4e8 random values)
+        if (vctl[1] != 0) {
+            *vgive = 1;
+            return;
+        }
         unsigned h = (hs >> 9) & (VD_SLOTS - 1);
         for (int probe = 0; probe < VD_SLOTS; ++probe) {
             unsigned long long cur = ((volatile unsigned long long *)table)[h];
