@@ -8,6 +8,7 @@ configurations never touch PCIe.  `row0 / nrows` select a row block of the globa
 from __future__ import annotations
 
 import ctypes as C
+import time
 from dataclasses import dataclass
 
 import numpy as np
@@ -85,7 +86,10 @@ def generate(spec: str, row0: int = 0, nrows: int | None = None, seed: int = 123
     check(L.lsqrhip_gen_coo(kind, seed, m, n, p0, p1, row0, nrows, d_rowptr.ptr if d_rowptr else None,
                             d_irow.ptr, d_icol.ptr, d_a.ptr, pb, C.addressof(out)))
     assert out.value == nnz, (out.value, nnz)
+    check(L.lsqrhip_dev_sync())
+    t_build = time.perf_counter()
     s = lsqr_solver_ez().initialize_from_device_coo(nrows, n, nnz, d_irow.ptr, d_icol.ptr, d_a.ptr, **solver_kw)
+    s.build_seconds = time.perf_counter() - t_build      # initialize: device COO -> ready-to-solve layouts
     for buf in (d_irow, d_icol, d_a, d_rowptr):
         if buf is not None:
             buf.free()
