@@ -189,16 +189,21 @@ contains
       class(lsqr_test_problem_device), intent(inout) :: me
       integer, intent(in) :: m, n, nduplc, npower
       real(wp), intent(in) :: damp
+      real(c_double) :: ac, rn
+      real(c_double), allocatable :: bl(:), xl(:)
       call me%destroy()
       me%m = m
       me%n = n
       call lsqr_check_status(lsqrhip_lstp_create(int(m, c_int), int(n, c_int), int(nduplc, c_int), &
-                                                  int(npower, c_int), damp, me%handle, me%acond, me%rnorm))
+                                                  int(npower, c_int), real(damp, c_double), me%handle, ac, rn))
+      me%acond = real(ac, wp)
+      me%rnorm = real(rn, wp)
       if (allocated(me%b)) deallocate (me%b)
       if (allocated(me%xtrue)) deallocate (me%xtrue)
-      allocate (me%b(m), me%xtrue(n))
-      call lsqr_check_status(lsqrhip_lstp_vectors(me%handle, me%xtrue, me%b, c_null_ptr, c_null_ptr, c_null_ptr, &
-                                                   c_null_ptr))
+      allocate (me%b(m), me%xtrue(n), bl(m), xl(n))
+      call lsqr_check_status(lsqrhip_lstp_vectors(me%handle, xl, bl, c_null_ptr, c_null_ptr, c_null_ptr, c_null_ptr))
+      me%b = real(bl, wp)
+      me%xtrue = real(xl, wp)
    end subroutine create_test_problem
 
    !> LSQR (src/lsqr.f90:432-882) on the device operator.  Argument list of the reference:
@@ -216,17 +221,22 @@ contains
       integer, intent(out) :: istop, itn
       real(wp), intent(out) :: anorm, acond, rnorm, arnorm, xnorm
       integer(c_int) :: istop_, itn_
-      real(c_double) :: dummy(1)
+      real(c_double) :: sc(5)
+      real(c_double), allocatable :: bl(:), xl(:), sel(:)
       if (.not. c_associated(me%handle) .or. m /= me%m .or. n /= me%n) call lsqr_check_status(4_c_int)
-      if (wantse) then
-         call lsqr_check_status(lsqrhip_solve(me%handle, u, damp, atol, btol, conlim, int(itnlim, c_int), 1_c_int, &
-                                              merge(1_c_int, 0_c_int, nout /= 0), x, se, istop_, itn_, anorm, acond, &
-                                              rnorm, arnorm, xnorm))
-      else
-         call lsqr_check_status(lsqrhip_solve(me%handle, u, damp, atol, btol, conlim, int(itnlim, c_int), 0_c_int, &
-                                              merge(1_c_int, 0_c_int, nout /= 0), x, dummy, istop_, itn_, anorm, &
-                                              acond, rnorm, arnorm, xnorm))
-      end if
+      allocate (bl(max(m, 1)), xl(max(n, 1)), sel(max(n, 1)))
+      bl(1:m) = u(1:m)
+      call lsqr_check_status(lsqrhip_solve(me%handle, bl, real(damp, c_double), real(atol, c_double), &
+                                           real(btol, c_double), real(conlim, c_double), int(itnlim, c_int), &
+                                           merge(1_c_int, 0_c_int, wantse), merge(1_c_int, 0_c_int, nout /= 0), xl, sel, &
+                                           istop_, itn_, sc(1), sc(2), sc(3), sc(4), sc(5)))
+      x(1:n) = real(xl(1:n), wp)
+      if (wantse) se(1:n) = real(sel(1:n), wp)
+      anorm = real(sc(1), wp)
+      acond = real(sc(2), wp)
+      rnorm = real(sc(3), wp)
+      arnorm = real(sc(4), wp)
+      xnorm = real(sc(5), wp)
       istop = istop_
       itn = itn_
       if (nout /= 0) call lsqr_print_device_log(me%handle, nout, m, n, damp, wantse, atol, btol, conlim, itnlim, &
@@ -244,7 +254,7 @@ contains
       integer(c_int) :: inf
       real(c_double) :: err
       if (.not. c_associated(me%handle) .or. m /= me%m .or. n /= me%n) call lsqr_check_status(4_c_int)
-      call lsqr_check_status(lsqrhip_acheck(me%handle, eps, inf, err))
+      call lsqr_check_status(lsqrhip_acheck(me%handle, real(eps, c_double), inf, err))
       inform = inf
       if (nout /= 0) then
          write (nout, '(//A)') ' Enter acheck.     Test of aprod for LSQR and CRAIG'
@@ -268,12 +278,20 @@ contains
       real(wp), intent(out) :: test1, test2, test3
       integer(c_int) :: inf
       real(c_double) :: tests(3)
+      real(c_double), allocatable :: bl(:), xl(:), ul(:), vl(:), wl(:)
       if (.not. c_associated(me%handle) .or. m /= me%m .or. n /= me%n) call lsqr_check_status(4_c_int)
-      call lsqr_check_status(lsqrhip_xcheck(me%handle, anorm, damp, eps, b, x, u, v, w, inf, tests))
+      allocate (bl(max(m, 1)), xl(max(n, 1)), ul(max(m, 1)), vl(max(n, 1)), wl(max(n, 1)))
+      bl(1:m) = b
+      xl(1:n) = x
+      call lsqr_check_status(lsqrhip_xcheck(me%handle, real(anorm, c_double), real(damp, c_double), &
+                                            real(eps, c_double), bl, xl, ul, vl, wl, inf, tests))
+      u = real(ul(1:m), wp)
+      v = real(vl(1:n), wp)
+      w = real(wl(1:n), wp)
       inform = inf
-      test1 = tests(1)
-      test2 = tests(2)
-      test3 = tests(3)
+      test1 = real(tests(1), wp)
+      test2 = real(tests(2), wp)
+      test3 = real(tests(3), wp)
       if (nout /= 0) then
          write (nout, '(//A)') ' Enter xcheck.     Does x solve Ax = b, etc?'
          write (nout, '(/A,I2)') '    inform          =', inform

@@ -293,7 +293,8 @@ contains
       want_log = merge(1_c_int, 0_c_int, me%nout /= 0)
       allocate (xl(max(me%n, 1)), sel(max(me%n, 1)), bl(max(me%m, 1)))
       bl(1:me%m) = b
-      call check(lsqrhip_solve(me%handle, bl, damp, me%atol, me%btol, me%conlim, int(me%itnlim, c_int), wantse, &
+      call check(lsqrhip_solve(me%handle, bl, real(damp, c_double), real(me%atol, c_double), &
+                               real(me%btol, c_double), real(me%conlim, c_double), int(me%itnlim, c_int), wantse, &
                                want_log, xl, sel, istop_, itn_, anorm_, acond_, rnorm_, arnorm_, xnorm_))
       x = xl(1:me%n)
       istop = istop_
@@ -304,8 +305,8 @@ contains
       if (present(rnorm)) rnorm = rnorm_
       if (present(arnorm)) arnorm = arnorm_
       if (present(xnorm)) xnorm = xnorm_
-      if (me%nout /= 0) call print_device_log(me, damp, present(se), int(istop_), int(itn_), anorm_, acond_, &
-                                              rnorm_, arnorm_, xnorm_)
+      if (me%nout /= 0) call print_device_log(me, damp, present(se), int(istop_), int(itn_), real(anorm_, wp), &
+                                              real(acond_, wp), real(rnorm_, wp), real(arnorm_, wp), real(xnorm_, wp))
    end subroutine solve_ez
 
    !> Write the iteration log of a GPU solve from the device records, with the reference's
@@ -338,7 +339,7 @@ contains
       ctol = zero
       if (conlim > zero) ctol = one/conlim
       if (itn > 0 .or. istop /= 0) then
-         call log_titles(nout, damp > zero, ex(5), ex(6))
+         call log_titles(nout, damp > zero, real(ex(5), wp), real(ex(6), wp))
          if (nrec > 0) then
             allocate (rec(LOG_STRIDE, nrec))
             call check(lsqrhip_log_fetch(handle, 0_c_int, int(nrec, c_int), rec))
@@ -346,7 +347,7 @@ contains
                it = nint(rec(1, k))
                ist = nint(rec(12, k))
                test3 = huge(one)
-               if (rec(7, k) /= zero) test3 = one/rec(7, k)
+               if (rec(7, k) /= 0.0_c_double) test3 = real(1.0_c_double/rec(7, k), wp)
                show = (n <= 40) .or. (it <= 10) .or. (it >= itnlim - 10) .or. (mod(it, 10) == 0) .or. &
                       (test3 <= 2.0_wp*ctol) .or. (rec(5, k) <= 10.0_wp*atol) .or. &
                       (rec(4, k) <= 10.0_wp*rec(13, k)) .or. (ist /= 0)
@@ -354,7 +355,8 @@ contains
             end do
          end if
       end if
-      call log_exit(nout, istop, itn, anorm, acond, ex(1), xnorm, rnorm, arnorm, ex(2), nint(ex(3)))
+      call log_exit(nout, istop, itn, anorm, acond, real(ex(1), wp), xnorm, rnorm, arnorm, real(ex(2), wp), &
+                    nint(ex(3)))
    end subroutine lsqr_print_device_log
 
    ! =========================================================================================

@@ -1,6 +1,6 @@
-﻿!mod$ v1 sum:1ffec0e3c8955341
-!need$ 21717a00586b85b6 n lsqr_module
-!need$ 8587e60dcd189e35 n lsqr_kinds
+﻿!mod$ v1 sum:01dc125599448983
+!need$ e240aee1d6d8483a n lsqr_module
+!need$ 56c4c5b6fa2ed0dc n lsqr_kinds
 module dense_operator
 use lsqr_module,only:lsqr_solver
 use lsqr_kinds,only:wp

@@ -1,7 +1,7 @@
-﻿!mod$ v1 sum:9858a778cb402f77
+﻿!mod$ v1 sum:1b26a820d15908b9
 !need$ 0bde2ac47243ead2 i iso_c_binding
-!need$ 8587e60dcd189e35 n lsqr_kinds
-!need$ 78e29451f6407fca n lsqr_device_module
+!need$ 56c4c5b6fa2ed0dc n lsqr_kinds
+!need$ caa2fa2c0e7b0fa0 n lsqr_device_module
 module wrapped_operator
 use,intrinsic::__fortran_builtins,only:__builtin_c_ptr
 use,intrinsic::iso_c_binding,only:c_associated

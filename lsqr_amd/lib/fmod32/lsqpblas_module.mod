@@ -1,5 +1,5 @@
-﻿!mod$ v1 sum:39721a1c89e2c288
-!need$ 56c4c5b6fa2ed0dc n lsqr_kinds
+﻿!mod$ v1 sum:bfae6b404ba0ad73
+!need$ 3138c98327cd2df8 n lsqr_kinds
 module lsqpblas_module
 use lsqr_kinds,only:wp
 use lsqr_kinds,only:zero
@@ -11,29 +11,29 @@ private::first_index
 contains
 subroutine dcopy(n,dx,incx,dy,incy)
 integer(4)::n
-real(8)::dx(1_8:*)
+real(4)::dx(1_8:*)
 integer(4)::incx
-real(8)::dy(1_8:*)
+real(4)::dy(1_8:*)
 integer(4)::incy
 end
 function ddot(n,dx,incx,dy,incy)
 integer(4)::n
-real(8)::dx(1_8:*)
+real(4)::dx(1_8:*)
 integer(4)::incx
-real(8)::dy(1_8:*)
+real(4)::dy(1_8:*)
 integer(4)::incy
-real(8)::ddot
+real(4)::ddot
 end
 function dnrm2(n,x,incx)
 integer(4)::n
-real(8)::x(1_8:*)
+real(4)::x(1_8:*)
 integer(4)::incx
-real(8)::dnrm2
+real(4)::dnrm2
 end
 subroutine dscal(n,da,dx,incx)
 integer(4)::n
-real(8)::da
-real(8)::dx(1_8:*)
+real(4)::da
+real(4)::dx(1_8:*)
 integer(4)::incx
 end
 pure function first_index(n,inc)

@@ -1,8 +1,8 @@
-﻿!mod$ v1 sum:caa2fa2c0e7b0fa0
-!need$ e240aee1d6d8483a n lsqr_module
+﻿!mod$ v1 sum:88aefd23d3712bf0
+!need$ 50ccce7e511721c5 n lsqr_module
 !need$ 0bde2ac47243ead2 i iso_c_binding
 !need$ bb381bf46e508468 i __fortran_builtins
-!need$ 56c4c5b6fa2ed0dc n lsqr_kinds
+!need$ 3138c98327cd2df8 n lsqr_kinds
 module lsqr_device_module
 use,intrinsic::__fortran_builtins,only:__builtin_c_ptr
 use lsqr_module,only:lsqr_print_device_log
@@ -190,10 +190,10 @@ procedure(aprod_device_func),deferred::aprod_device
 procedure::initialize_device
 end type
 type,extends(lsqr_device_handle)::lsqr_test_problem_device
-real(8)::acond=0._8
-real(8)::rnorm=0._8
-real(8),allocatable::b(:)
-real(8),allocatable::xtrue(:)
+real(4)::acond=0._4
+real(4)::rnorm=0._4
+real(4),allocatable::b(:)
+real(4),allocatable::xtrue(:)
 contains
 procedure::create=>create_test_problem
 end type
@@ -365,42 +365,42 @@ integer(4),intent(in)::m
 integer(4),intent(in)::n
 integer(4),intent(in)::nduplc
 integer(4),intent(in)::npower
-real(8),intent(in)::damp
+real(4),intent(in)::damp
 end
 subroutine lsqr_dev(me,m,n,damp,wantse,u,v,w,x,se,atol,btol,conlim,itnlim,nout,istop,itn,anorm,acond,rnorm,arnorm,xnorm)
 class(lsqr_device_handle),intent(inout)::me
 integer(4),intent(in)::m
 integer(4),intent(in)::n
-real(8),intent(in)::damp
+real(4),intent(in)::damp
 logical(4),intent(in)::wantse
-real(8),intent(inout)::u(1_8:int(m,kind=8))
-real(8),intent(inout)::v(1_8:int(n,kind=8))
-real(8),intent(inout)::w(1_8:int(n,kind=8))
-real(8),intent(out)::x(1_8:int(n,kind=8))
-real(8),intent(inout)::se(1_8:*)
-real(8),intent(in)::atol
-real(8),intent(in)::btol
-real(8),intent(in)::conlim
+real(4),intent(inout)::u(1_8:int(m,kind=8))
+real(4),intent(inout)::v(1_8:int(n,kind=8))
+real(4),intent(inout)::w(1_8:int(n,kind=8))
+real(4),intent(out)::x(1_8:int(n,kind=8))
+real(4),intent(inout)::se(1_8:*)
+real(4),intent(in)::atol
+real(4),intent(in)::btol
+real(4),intent(in)::conlim
 integer(4),intent(in)::itnlim
 integer(4),intent(in)::nout
 integer(4),intent(out)::istop
 integer(4),intent(out)::itn
-real(8),intent(out)::anorm
-real(8),intent(out)::acond
-real(8),intent(out)::rnorm
-real(8),intent(out)::arnorm
-real(8),intent(out)::xnorm
+real(4),intent(out)::anorm
+real(4),intent(out)::acond
+real(4),intent(out)::rnorm
+real(4),intent(out)::arnorm
+real(4),intent(out)::xnorm
 end
 subroutine acheck_dev(me,m,n,nout,eps,v,w,x,y,inform)
 class(lsqr_device_handle),intent(inout)::me
 integer(4),intent(in)::m
 integer(4),intent(in)::n
 integer(4),intent(in)::nout
-real(8),intent(in)::eps
-real(8),intent(inout)::v(1_8:int(n,kind=8))
-real(8),intent(inout)::w(1_8:int(m,kind=8))
-real(8),intent(inout)::x(1_8:int(n,kind=8))
-real(8),intent(inout)::y(1_8:int(m,kind=8))
+real(4),intent(in)::eps
+real(4),intent(inout)::v(1_8:int(n,kind=8))
+real(4),intent(inout)::w(1_8:int(m,kind=8))
+real(4),intent(inout)::x(1_8:int(n,kind=8))
+real(4),intent(inout)::y(1_8:int(m,kind=8))
 integer(4),intent(out)::inform
 end
 subroutine xcheck_dev(me,m,n,nout,anorm,damp,eps,b,u,v,w,x,inform,test1,test2,test3)
@@ -408,17 +408,17 @@ class(lsqr_device_handle),intent(inout)::me
 integer(4),intent(in)::m
 integer(4),intent(in)::n
 integer(4),intent(in)::nout
-real(8),intent(in)::anorm
-real(8),intent(in)::damp
-real(8),intent(in)::eps
-real(8),intent(in)::b(1_8:int(m,kind=8))
-real(8),intent(out)::u(1_8:int(m,kind=8))
-real(8),intent(out)::v(1_8:int(n,kind=8))
-real(8),intent(out)::w(1_8:int(n,kind=8))
-real(8),intent(in)::x(1_8:int(n,kind=8))
+real(4),intent(in)::anorm
+real(4),intent(in)::damp
+real(4),intent(in)::eps
+real(4),intent(in)::b(1_8:int(m,kind=8))
+real(4),intent(out)::u(1_8:int(m,kind=8))
+real(4),intent(out)::v(1_8:int(n,kind=8))
+real(4),intent(out)::w(1_8:int(n,kind=8))
+real(4),intent(in)::x(1_8:int(n,kind=8))
 integer(4),intent(out)::inform
-real(8),intent(out)::test1
-real(8),intent(out)::test2
-real(8),intent(out)::test3
+real(4),intent(out)::test1
+real(4),intent(out)::test2
+real(4),intent(out)::test3
 end
 end

@@ -1,8 +1,8 @@
-﻿!mod$ v1 sum:e240aee1d6d8483a
+﻿!mod$ v1 sum:50ccce7e511721c5
 !need$ 0bde2ac47243ead2 i iso_c_binding
-!need$ 39721a1c89e2c288 n lsqpblas_module
+!need$ bfae6b404ba0ad73 n lsqpblas_module
 !need$ bb381bf46e508468 i __fortran_builtins
-!need$ 56c4c5b6fa2ed0dc n lsqr_kinds
+!need$ 3138c98327cd2df8 n lsqr_kinds
 module lsqr_module
 use,intrinsic::__fortran_builtins,only:__builtin_c_ptr
 use,intrinsic::iso_c_binding,only:c_associated
@@ -184,9 +184,9 @@ type,extends(lsqr_solver)::lsqr_solver_ez
 integer(4),private::m=0_4
 integer(4),private::n=0_4
 integer(4),private::num_nonzero_elements=0_4
-real(8),private::atol=0._8
-real(8),private::btol=0._8
-real(8),private::conlim=0._8
+real(4),private::atol=0._4
+real(4),private::btol=0._4
+real(4),private::conlim=0._4
 integer(4),private::itnlim=100_4
 integer(4),private::nout=0_4
 type(c_ptr),private::handle=__builtin_c_ptr(__address=0_8)
@@ -207,8 +207,8 @@ class(lsqr_solver),intent(inout)::me
 integer(4),intent(in)::mode
 integer(4),intent(in)::m
 integer(4),intent(in)::n
-real(8),intent(inout)::x(:)
-real(8),intent(inout)::y(:)
+real(4),intent(inout)::x(:)
+real(4),intent(inout)::y(:)
 end
 end interface
 private::lsqrhip_create
@@ -350,12 +350,12 @@ subroutine initialize_ez(me,m,n,a,irow,icol,atol,btol,conlim,itnlim,nout)
 class(lsqr_solver_ez),intent(out)::me
 integer(4),intent(in)::m
 integer(4),intent(in)::n
-real(8),intent(in)::a(:)
+real(4),intent(in)::a(:)
 integer(4),intent(in)::irow(:)
 integer(4),intent(in)::icol(:)
-real(8),intent(in),optional::atol
-real(8),intent(in),optional::btol
-real(8),intent(in),optional::conlim
+real(4),intent(in),optional::atol
+real(4),intent(in),optional::btol
+real(4),intent(in),optional::conlim
 integer(4),intent(in),optional::itnlim
 integer(4),intent(in),optional::nout
 end
@@ -374,123 +374,123 @@ class(lsqr_solver_ez),intent(inout)::me
 integer(4),intent(in)::mode
 integer(4),intent(in)::m
 integer(4),intent(in)::n
-real(8),intent(inout)::x(:)
-real(8),intent(inout)::y(:)
+real(4),intent(inout)::x(:)
+real(4),intent(inout)::y(:)
 end
 subroutine solve_ez(me,b,damp,x,istop,se,itn,anorm,acond,rnorm,arnorm,xnorm)
 class(lsqr_solver_ez),intent(inout)::me
-real(8),intent(in)::b(1_8:int(me%m,kind=8))
-real(8),intent(in)::damp
-real(8),intent(out)::x(1_8:int(me%n,kind=8))
+real(4),intent(in)::b(1_8:int(me%m,kind=8))
+real(4),intent(in)::damp
+real(4),intent(out)::x(1_8:int(me%n,kind=8))
 integer(4),intent(out)::istop
-real(8),intent(out),optional::se(1_8:int(me%n,kind=8))
+real(4),intent(out),optional::se(1_8:int(me%n,kind=8))
 integer(4),intent(out),optional::itn
-real(8),intent(out),optional::anorm
-real(8),intent(out),optional::acond
-real(8),intent(out),optional::rnorm
-real(8),intent(out),optional::arnorm
-real(8),intent(out),optional::xnorm
+real(4),intent(out),optional::anorm
+real(4),intent(out),optional::acond
+real(4),intent(out),optional::rnorm
+real(4),intent(out),optional::arnorm
+real(4),intent(out),optional::xnorm
 end
 subroutine print_device_log(me,damp,wantse,istop,itn,anorm,acond,rnorm,arnorm,xnorm)
 class(lsqr_solver_ez),intent(in)::me
-real(8),intent(in)::damp
+real(4),intent(in)::damp
 logical(4),intent(in)::wantse
 integer(4),intent(in)::istop
 integer(4),intent(in)::itn
-real(8),intent(in)::anorm
-real(8),intent(in)::acond
-real(8),intent(in)::rnorm
-real(8),intent(in)::arnorm
-real(8),intent(in)::xnorm
+real(4),intent(in)::anorm
+real(4),intent(in)::acond
+real(4),intent(in)::rnorm
+real(4),intent(in)::arnorm
+real(4),intent(in)::xnorm
 end
 subroutine lsqr_print_device_log(handle,nout,m,n,damp,wantse,atol,btol,conlim,itnlim,istop,itn,anorm,acond,rnorm,arnorm,xnorm)
 type(c_ptr),intent(in)::handle
 integer(4),intent(in)::nout
 integer(4),intent(in)::m
 integer(4),intent(in)::n
-real(8),intent(in)::damp
+real(4),intent(in)::damp
 logical(4),intent(in)::wantse
-real(8),intent(in)::atol
-real(8),intent(in)::btol
-real(8),intent(in)::conlim
+real(4),intent(in)::atol
+real(4),intent(in)::btol
+real(4),intent(in)::conlim
 integer(4),intent(in)::itnlim
 integer(4),intent(in)::istop
 integer(4),intent(in)::itn
-real(8),intent(in)::anorm
-real(8),intent(in)::acond
-real(8),intent(in)::rnorm
-real(8),intent(in)::arnorm
-real(8),intent(in)::xnorm
+real(4),intent(in)::anorm
+real(4),intent(in)::acond
+real(4),intent(in)::rnorm
+real(4),intent(in)::arnorm
+real(4),intent(in)::xnorm
 end
 subroutine log_header(nout,m,n,damp,wantse,atol,btol,conlim,itnlim)
 integer(4),intent(in)::nout
 integer(4),intent(in)::m
 integer(4),intent(in)::n
-real(8),intent(in)::damp
+real(4),intent(in)::damp
 logical(4),intent(in)::wantse
-real(8),intent(in)::atol
-real(8),intent(in)::btol
-real(8),intent(in)::conlim
+real(4),intent(in)::atol
+real(4),intent(in)::btol
+real(4),intent(in)::conlim
 integer(4),intent(in)::itnlim
 end
 subroutine log_titles(nout,damped,beta,test2)
 integer(4),intent(in)::nout
 logical(4),intent(in)::damped
-real(8),intent(in)::beta
-real(8),intent(in)::test2
+real(4),intent(in)::beta
+real(4),intent(in)::test2
 end
 subroutine log_exit(nout,istop,itn,anorm,acond,bnorm,xnorm,rnorm,arnorm,dxmax,maxdx)
 integer(4),intent(in)::nout
 integer(4),intent(in)::istop
 integer(4),intent(in)::itn
-real(8),intent(in)::anorm
-real(8),intent(in)::acond
-real(8),intent(in)::bnorm
-real(8),intent(in)::xnorm
-real(8),intent(in)::rnorm
-real(8),intent(in)::arnorm
-real(8),intent(in)::dxmax
+real(4),intent(in)::anorm
+real(4),intent(in)::acond
+real(4),intent(in)::bnorm
+real(4),intent(in)::xnorm
+real(4),intent(in)::rnorm
+real(4),intent(in)::arnorm
+real(4),intent(in)::dxmax
 integer(4),intent(in)::maxdx
 end
 pure function d2norm(a,b) result(r)
-real(8),intent(in)::a
-real(8),intent(in)::b
-real(8)::r
+real(4),intent(in)::a
+real(4),intent(in)::b
+real(4)::r
 end
 subroutine lsqr(me,m,n,damp,wantse,u,v,w,x,se,atol,btol,conlim,itnlim,nout,istop,itn,anorm,acond,rnorm,arnorm,xnorm)
 class(lsqr_solver),intent(inout)::me
 integer(4),intent(in)::m
 integer(4),intent(in)::n
-real(8),intent(in)::damp
+real(4),intent(in)::damp
 logical(4),intent(in)::wantse
-real(8),intent(inout)::u(1_8:int(m,kind=8))
-real(8),intent(inout)::v(1_8:int(n,kind=8))
-real(8),intent(inout)::w(1_8:int(n,kind=8))
-real(8),intent(out)::x(1_8:int(n,kind=8))
-real(8),intent(out)::se(1_8:*)
-real(8),intent(in)::atol
-real(8),intent(in)::btol
-real(8),intent(in)::conlim
+real(4),intent(inout)::u(1_8:int(m,kind=8))
+real(4),intent(inout)::v(1_8:int(n,kind=8))
+real(4),intent(inout)::w(1_8:int(n,kind=8))
+real(4),intent(out)::x(1_8:int(n,kind=8))
+real(4),intent(out)::se(1_8:*)
+real(4),intent(in)::atol
+real(4),intent(in)::btol
+real(4),intent(in)::conlim
 integer(4),intent(in)::itnlim
 integer(4),intent(in)::nout
 integer(4),intent(out)::istop
 integer(4),intent(out)::itn
-real(8),intent(out)::anorm
-real(8),intent(out)::acond
-real(8),intent(out)::rnorm
-real(8),intent(out)::arnorm
-real(8),intent(out)::xnorm
+real(4),intent(out)::anorm
+real(4),intent(out)::acond
+real(4),intent(out)::rnorm
+real(4),intent(out)::arnorm
+real(4),intent(out)::xnorm
 end
 subroutine acheck(me,m,n,nout,eps,v,w,x,y,inform)
 class(lsqr_solver),intent(inout)::me
 integer(4),intent(in)::m
 integer(4),intent(in)::n
 integer(4),intent(in)::nout
-real(8),intent(in)::eps
-real(8)::v(1_8:int(n,kind=8))
-real(8)::w(1_8:int(m,kind=8))
-real(8)::x(1_8:int(n,kind=8))
-real(8)::y(1_8:int(m,kind=8))
+real(4),intent(in)::eps
+real(4)::v(1_8:int(n,kind=8))
+real(4)::w(1_8:int(m,kind=8))
+real(4)::x(1_8:int(n,kind=8))
+real(4)::y(1_8:int(m,kind=8))
 integer(4),intent(out)::inform
 end
 subroutine xcheck(me,m,n,nout,anorm,damp,eps,b,u,v,w,x,inform,test1,test2,test3)
@@ -498,17 +498,17 @@ class(lsqr_solver),intent(inout)::me
 integer(4),intent(in)::m
 integer(4),intent(in)::n
 integer(4),intent(in)::nout
-real(8),intent(in)::anorm
-real(8),intent(in)::damp
-real(8),intent(in)::eps
-real(8),intent(in)::b(1_8:int(m,kind=8))
-real(8),intent(out)::u(1_8:int(m,kind=8))
-real(8),intent(out)::v(1_8:int(n,kind=8))
-real(8),intent(out)::w(1_8:int(n,kind=8))
-real(8),intent(in)::x(1_8:int(n,kind=8))
+real(4),intent(in)::anorm
+real(4),intent(in)::damp
+real(4),intent(in)::eps
+real(4),intent(in)::b(1_8:int(m,kind=8))
+real(4),intent(out)::u(1_8:int(m,kind=8))
+real(4),intent(out)::v(1_8:int(n,kind=8))
+real(4),intent(out)::w(1_8:int(n,kind=8))
+real(4),intent(in)::x(1_8:int(n,kind=8))
 integer(4),intent(out)::inform
-real(8),intent(out)::test1
-real(8),intent(out)::test2
-real(8),intent(out)::test3
+real(4),intent(out)::test1
+real(4),intent(out)::test2
+real(4),intent(out)::test3
 end
 end

@@ -1,0 +1,50 @@
+!> TEST INFRASTRUCTURE.  Runs the UNMODIFIED reference, compiled with its own REAL32 macro
+!! (src/lsqr_kinds.F90:16-17), on the two systems of lsqr_amd/fortran/tests/test_real32.f90 and
+!! prints the results; tests/golden/gen_real32_golden.py stores them as a fixture.
+program ref32_driver
+   use lsqr_kinds
+   use lsqr_module, only: lsqr_solver_ez
+   implicit none
+   integer, parameter :: nx = 40, ny = 30, n = nx*ny
+   integer, allocatable :: irow(:), icol(:)
+   real(wp), allocatable :: a(:), b(:), x(:), se(:)
+   real(wp) :: anorm, acond, rnorm, arnorm, xnorm
+   integer :: i, j, k, nnz, istop, itn
+   type(lsqr_solver_ez) :: s
+
+   call s%initialize(3, 3, real([1, 4, 7, 2, 5, 88, 3, 66, 9], wp), [1, 2, 3, 1, 2, 3, 1, 2, 3], &
+                     [1, 1, 1, 2, 2, 2, 3, 3, 3])
+   allocate (x(3))
+   call s%solve(real([1, 2, 3], wp), zero, x, istop)
+   write (*, '(A,I2,1P,3E16.8)') 'README32 istop,x=', istop, x
+   deallocate (x)
+   allocate (irow(5*n), icol(5*n), a(5*n), b(n), x(n), se(n))
+   nnz = 0
+   do j = 1, ny
+      do i = 1, nx
+         k = (j - 1)*nx + i
+         call put(k, k, 4.25_wp)
+         if (i > 1) call put(k, k - 1, -1.125_wp)
+         if (i < nx) call put(k, k + 1, -0.875_wp)
+         if (j > 1) call put(k, k - nx, -1.0625_wp)
+         if (j < ny) call put(k, k + nx, -0.9375_wp)
+         b(k) = real(mod(7*k, 13), wp)*0.25_wp - 1.5_wp
+      end do
+   end do
+   call s%initialize(n, n, a(1:nnz), irow(1:nnz), icol(1:nnz), atol=1.0e-7_wp, btol=1.0e-7_wp, itnlim=500)
+   call s%solve(b, 0.0625_wp, x, istop, se=se, itn=itn, anorm=anorm, acond=acond, rnorm=rnorm, arnorm=arnorm, &
+                xnorm=xnorm)
+   write (*, '(A,I2,A,I4)') 'STENCIL32 istop=', istop, ' itn=', itn
+   write (*, '(A,1P,5E16.8)') 'STENCIL32 norms=', anorm, acond, rnorm, arnorm, xnorm
+   write (*, '(A,1P,*(E16.8))') 'STENCIL32 x=', x
+   write (*, '(A,1P,*(E16.8))') 'STENCIL32 se=', se(1:8)
+contains
+   subroutine put(r, c, v)
+      integer, intent(in) :: r, c
+      real(wp), intent(in) :: v
+      nnz = nnz + 1
+      irow(nnz) = r
+      icol(nnz) = c
+      a(nnz) = v
+   end subroutine put
+end program ref32_driver

@@ -167,3 +167,51 @@ def test_fortran_device_operator_and_user_subclass_on_gpu():
     uistop, uitn, calls = (int(t) for t in re.findall(r"=\s*(\d+)", line["USER istop"]))
     assert (uistop, uitn) == (istop, itn) and calls >= 2 * itn + 1
     assert numbers(line["USER maxdiff"])[0] == 0.0
+
+
+@pytest.mark.gpu
+def test_real32_build_mixed_precision_on_gpu():
+    """-DREAL32 build of the host layer (wp = real32 like the reference's REAL32 macro): real32 in
+    and out, binary64 on the device.  Against (1) the binary64 oracle on the same real32-valued
+    inputs: agreement to real32 rounding of the outputs; (2) the unmodified reference compiled with
+    -DREAL32 (tests/golden/real32_ref.json): agreement to what an all-real32 iteration can hold."""
+    import json
+    out = run("test_real32").stdout
+    assert "REAL32 TESTS PASSED" in out
+    line = {l.split("=")[0].strip(): l for l in out.splitlines() if "=" in l}
+    ref32 = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "real32_ref.json")))
+    # the same stencil in binary64 (every coefficient and b is exactly representable in real32)
+    nx, ny = 40, 30
+    irow, icol, a, b = [], [], [], []
+    for j in range(1, ny + 1):
+        for i in range(1, nx + 1):
+            k = (j - 1) * nx + i
+            ent = [(k, 4.25)]
+            if i > 1: ent.append((k - 1, -1.125))
+            if i < nx: ent.append((k + 1, -0.875))
+            if j > 1: ent.append((k - nx, -1.0625))
+            if j < ny: ent.append((k + nx, -0.9375))
+            for c, v in ent:
+                irow.append(k); icol.append(c); a.append(v)
+            b.append((7 * k % 13) * 0.25 - 1.5)
+    n = nx * ny
+    f32 = lambda v: float(np.float32(v))
+    o = oracle.port().solve(n, n, irow, icol, a, np.array(b), damp=0.0625, atol=f32(1e-7), btol=f32(1e-7),
+                            itnlim=500, wantse=True)
+    istop, itn = (int(t) for t in re.findall(r"=\s*(\d+)", line["STENCIL32 istop"]))
+    assert (istop, itn) == (o.istop, o.itn)
+    x = numbers(line["STENCIL32 x"])
+    assert np.max(np.abs(x - o.x)) <= 1.2e-7 * np.max(np.abs(o.x))          # real32 rounding of the output
+    norms = numbers(line["STENCIL32 norms"])
+    np.testing.assert_allclose(norms[[2, 4]], [o.rnorm, o.xnorm], rtol=1.2e-7)
+    # anorm / acond are running sums over all 170 Lanczos steps: two binary64 runs that differ in
+    # summation order drift apart in them long before they do in x (DESIGN.md 3.3)
+    np.testing.assert_allclose(norms[[0, 1]], [o.anorm, o.acond], rtol=5e-3)
+    np.testing.assert_allclose(numbers(line["STENCIL32 se"]), o.se[:8], rtol=1e-2)
+    # the all-real32 reference: same stopping reason, same answer to ~1e-4 (it needs 171
+    # iterations where binary64 arithmetic needs fewer: its Lanczos vectors lose orthogonality sooner)
+    r = ref32["STENCIL32 istop"]["ints"]
+    assert r[0] == istop and itn <= r[1]
+    x32 = np.array(ref32["STENCIL32 x"]["nums"])
+    assert np.linalg.norm(x - x32) <= 2e-4 * np.linalg.norm(x32)
+    assert np.allclose(numbers(line["README32 istop,x"])[-3:], ref32["README32 istop,x"]["nums"][-3:], rtol=2e-5)
