@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=40)
     ap.add_argument("--workload", default="auto",
                     help="auto | poisson2d:NX:NY | random:M:N:PER_ROW | powerlaw:M:N:DMAX")
-    ap.add_argument("--cpu-iters", type=int, default=300, help="iterations of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-iters", type=int, default=1000, help="iterations of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
 
