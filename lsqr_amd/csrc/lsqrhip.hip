@@ -661,7 +661,8 @@ static int new_handle(int m, int n, int64_t nnz, H **out)
     h->m = m;
     h->n = n;
     h->nnz = nnz;
-    h->off64 = nnz >= (1ll << 31);
+    // 64-bit row pointers from 2^31 nonzeros on (LSQRHIP_OFF64=1 forces them: test hook for that path)
+    h->off64 = nnz >= (1ll << 31) || env_int("LSQRHIP_OFF64", 0) != 0;
     hipError_t e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         delete h;

@@ -14,7 +14,7 @@ from lsqr_amd.solver import lsqr_solver_ez
 
 pytestmark = pytest.mark.gpu
 
-KNOBS = ("LSQRHIP_SELL", "LSQRHIP_VAL8", "LSQRHIP_COL16", "LSQRHIP_PANELS", "LSQRHIP_PANEL_KB")
+KNOBS = ("LSQRHIP_SELL", "LSQRHIP_VAL8", "LSQRHIP_COL16", "LSQRHIP_PANELS", "LSQRHIP_PANEL_KB", "LSQRHIP_OFF64")
 
 
 @pytest.fixture(autouse=True)
@@ -158,3 +158,40 @@ def test_sell_handles_non_finite_x_like_the_reference():
         _, y_ref = oracle.port().aprod(1, p.m, p.n, p.irow, p.icol, p.a, xp, np.zeros(p.m))
     assert np.array_equal(y, y_ref, equal_nan=True)
     assert np.isfinite(y).sum() == np.isfinite(y_ref).sum() >= p.m - 10
+
+
+@pytest.mark.parametrize("panels", [False, True])
+def test_64bit_row_pointers_path(panels):
+    """nnz >= 2^31 switches the build to 64-bit row pointers (OffT = long long kernels, no sliced
+    ELL).  LSQRHIP_OFF64=1 forces that path at test scale: same bits as the 32-bit build, with and
+    without column panels, in all three launch schedules."""
+    p = P.random_rows(30000, 40000, 9, seed=8, damp=1e-3) if panels else P.poisson2d(150, 120)
+    if panels:
+        os.environ.update(LSQRHIP_PANELS="1", LSQRHIP_PANEL_KB="64")
+    res = []
+    for off64 in ("0", "1"):
+        os.environ["LSQRHIP_OFF64"] = off64
+        s = lsqr_solver_ez().initialize(p.m, p.n, p.a, p.irow, p.icol, itnlim=25)
+        info = s.info()
+        assert info["rowptr_bytes"] == (8 if off64 == "1" else 4)
+        if off64 == "1":
+            assert info["sell"] == 0
+        os.environ["LSQRHIP_SELL"] = "0"          # compare like with like (row windows both times)
+        s = lsqr_solver_ez().initialize(p.m, p.n, p.a, p.irow, p.icol, itnlim=25)
+        xp, yp = _vec(9, p.n), _vec(10, p.m)
+        x, y = xp.copy(), yp.copy()
+        s.aprod(1, p.m, p.n, x, y)
+        out = [y.copy()]
+        for pipeline in (0, 1, 2):
+            s.set_option("pipeline", pipeline)
+            r = s.solve(p.b, p.damp)
+            out.append((r.x.copy(), r.anorm, r.rnorm, r.itn, r.istop))
+        res.append(out)
+        os.environ.pop("LSQRHIP_SELL")
+    assert np.array_equal(res[0][0], res[1][0])
+    for a, b in zip(res[0][1:], res[1][1:]):
+        assert np.array_equal(a[0], b[0]) and a[1:] == b[1:]
+    for k in (2, 3):                                     # schedules agree with each other too
+        assert np.array_equal(res[1][1][0], res[1][k][0]) and res[1][1][1:] == res[1][k][1:]
+    o = oracle.port().solve(p.m, p.n, p.irow, p.icol, p.a, p.b, damp=p.damp, itnlim=25)
+    assert np.linalg.norm(res[1][1][0] - o.x) <= 1e-10 * np.linalg.norm(o.x)
