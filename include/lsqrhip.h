@@ -80,11 +80,12 @@ int lsqrhip_destroy(lsqrhip_handle_t h);
  * reference deep-copies its allocatable components) share one device matrix safely. */
 int lsqrhip_retain(lsqrhip_handle_t h);
 
-/* Matrix facts: dims[0..13] = m, n, nnz, bytes of CSR(A), bytes of CSR(A') as stored,
+/* Matrix facts: dims[0..15] = m, n, nnz, bytes of CSR(A), bytes of CSR(A') as stored,
  * bytes per row pointer (4 or 8), value-dictionary entries (0 = none), bytes per stored
  * value (8, or 1 with the dictionary), bytes per column index in CSR(A) and CSR(A')
  * (4, or 2 for block-relative indices), column panels of CSR(A) and CSR(A'), and whether
- * the sliced-ELL layout is in use for A and for A' (0/1). */
+ * the sliced-ELL layout is in use for A and for A' (0/1), whether the panels are LDS-resident
+ * for A and for A' (0/1). */
 int lsqrhip_info(lsqrhip_handle_t h, int64_t *dims);
 
 /* ---------------------------------------------------------------------- */

@@ -142,6 +142,7 @@ struct Csr {
     int grid = 0;      // workgroups of the SpMV launch
     int out_grid = 0;  // partials one product leaves behind (== grid, or the combine kernel's grid)
     int P = 1;         // column panels (1 = plain CSR)
+    int xlds = 0;      // panels narrow enough for an LDS-resident x slice (spmv.h XL)
     int pw = 0;        // panel width in columns
     int64_t rows_v = 0;  // virtual rows = P * rows (what rowptr / rb / blk index)
     int64_t bytes = 0;
@@ -379,7 +380,7 @@ static void launch_scan(hipStream_t s, unsigned *a, int64_t L, unsigned *sums)
 
 template <typename OffT>
 static int build_csr_T(hipStream_t s, const int *d_keys, const int *d_other, const double *d_a, int64_t nnz,
-                       int rows, int cols, int bad_code, int bad_code_other, int panels, int pw,
+                       int rows, int cols, int bad_code, int bad_code_other, int panels, int pw, int xlds,
                        unsigned long long *bufA, unsigned long long *bufB, unsigned *hist, int *d_flags,
                        const double *dict, int ndict, Csr &out)
 {
@@ -387,6 +388,7 @@ static int build_csr_T(hipStream_t s, const int *d_keys, const int *d_other, con
     out.cols = cols;
     out.P = panels > 1 ? panels : 1;
     out.pw = out.P > 1 ? pw : cols;
+    out.xlds = out.P > 1 ? xlds : 0;
     out.rows_v = (int64_t)out.P * rows;
     const int rows_v = (int)out.rows_v;  // < 2^31, checked by the caller
     HIPCHK(hipMalloc(&out.rowptr, sizeof(OffT) * ((size_t)rows_v + 1)));
@@ -505,16 +507,36 @@ static int build_csr_T(hipStream_t s, const int *d_keys, const int *d_other, con
 //   LSQRHIP_PANELS    0 never | 1 whenever x exceeds one panel | unset: only if the columns are not local
 //   LSQRHIP_PANEL_KB  panel size in KiB of x (default 2048: half an XCD's 4 MiB L2, the rest streams;
 //                     swept 1024 / 2560 / 3584: profiles/r01/sweep_panels.txt)
-static void choose_panels(int rows, int cols, double mean_dev, int *panels, int *pw)
+//   LSQRHIP_XLDS      0 never | 1 whenever x exceeds one LDS panel | unset: scattered columns and
+//                     >= 6 nonzeros per (row, LDS panel) -- panels of LSQRHIP_XLDS_COLS (7168) columns
+//                     whose x slice lives in LDS (spmv.h XL): gathers stop being the bound
+static void choose_panels(int rows, int cols, int64_t nnz, double mean_dev, int *panels, int *pw, int *xlds)
 {
     *panels = 1;
     *pw = cols;
+    *xlds = 0;
     const int mode = env_int("LSQRHIP_PANELS", -1);
-    if (mode == 0) return;
     const int64_t kb = std::max(64, env_int("LSQRHIP_PANEL_KB", 2048));
     const int64_t width = (kb * 1024 / 8 + 1023) & ~(int64_t)1023;
+    const bool scattered = mode == 1 || (mode != 0 && mean_dev >= 0.25 * (double)width);
+    // LDS panels first: they win whenever the rows are dense enough to pay for many narrow panels
+    const int xmode = env_int("LSQRHIP_XLDS", -1);
+    if (xmode != 0) {
+        const int64_t wl = std::min<int64_t>(XL_COLS, (std::max(1024, env_int("LSQRHIP_XLDS_COLS", XL_COLS)) + 1023) &
+                                                           ~(int64_t)1023);
+        const int64_t Pl = ((int64_t)cols + wl - 1) / wl;
+        const bool fits = Pl > 1 && Pl * (int64_t)rows < (1ll << 31);
+        const bool dense = nnz >= 6 * Pl * (int64_t)rows;
+        if (fits && (xmode == 1 || (scattered && dense && (int64_t)cols > 2 * width))) {
+            *panels = (int)Pl;
+            *pw = (int)wl;
+            *xlds = 1;
+            return;
+        }
+    }
+    if (mode == 0) return;
     if ((int64_t)cols <= 2 * width) return;                  // x (nearly) fits L2 as it is
-    if (mode != 1 && mean_dev < 0.25 * (double)width) return;  // banded / local: plain CSR is better
+    if (!scattered) return;                                  // banded / local: plain CSR is better
     const int64_t P = ((int64_t)cols + width - 1) / width;
     if (P * (int64_t)rows >= (1ll << 31)) return;            // virtual rows must fit int32
     *panels = (int)P;
@@ -627,18 +649,18 @@ static int finish_create(H *h, const int *d_irow, const int *d_icol, const doubl
         (void)hipFree(d_flags);
         return rcd;
     }
-    int pa = 1, pwa = h->n, pt = 1, pwt = h->m;
-    choose_panels(h->m, h->n, mean_dev, &pa, &pwa);                                   // mode 1 gathers V (n)
-    choose_panels(h->n, h->m, mean_dev * (double)std::max(h->m, 1) / (double)std::max(h->n, 1), &pt, &pwt);  // mode 2 gathers U (m)
+    int pa = 1, pwa = h->n, pt = 1, pwt = h->m, xa = 0, xt = 0;
+    choose_panels(h->m, h->n, nnz, mean_dev, &pa, &pwa, &xa);                         // mode 1 gathers V (n)
+    choose_panels(h->n, h->m, nnz, mean_dev * (double)std::max(h->m, 1) / (double)std::max(h->n, 1), &pt, &pwt, &xt);  // mode 2 gathers U (m)
     int rc;
     if (h->off64) {
-        rc = build_csr_T<long long>(s, d_irow, d_icol, d_a, nnz, h->m, h->n, LSQRHIP_ERR_IROW, LSQRHIP_ERR_ICOL, pa, pwa, bufA, bufB, hist, d_flags, h->dict, h->ndict, h->A);
+        rc = build_csr_T<long long>(s, d_irow, d_icol, d_a, nnz, h->m, h->n, LSQRHIP_ERR_IROW, LSQRHIP_ERR_ICOL, pa, pwa, xa, bufA, bufB, hist, d_flags, h->dict, h->ndict, h->A);
         if (rc == LSQRHIP_OK)
-            rc = build_csr_T<long long>(s, d_icol, d_irow, d_a, nnz, h->n, h->m, LSQRHIP_ERR_ICOL, LSQRHIP_ERR_IROW, pt, pwt, bufA, bufB, hist, d_flags, h->dict, h->ndict, h->AT);
+            rc = build_csr_T<long long>(s, d_icol, d_irow, d_a, nnz, h->n, h->m, LSQRHIP_ERR_ICOL, LSQRHIP_ERR_IROW, pt, pwt, xt, bufA, bufB, hist, d_flags, h->dict, h->ndict, h->AT);
     } else {
-        rc = build_csr_T<int>(s, d_irow, d_icol, d_a, nnz, h->m, h->n, LSQRHIP_ERR_IROW, LSQRHIP_ERR_ICOL, pa, pwa, bufA, bufB, hist, d_flags, h->dict, h->ndict, h->A);
+        rc = build_csr_T<int>(s, d_irow, d_icol, d_a, nnz, h->m, h->n, LSQRHIP_ERR_IROW, LSQRHIP_ERR_ICOL, pa, pwa, xa, bufA, bufB, hist, d_flags, h->dict, h->ndict, h->A);
         if (rc == LSQRHIP_OK)
-            rc = build_csr_T<int>(s, d_icol, d_irow, d_a, nnz, h->n, h->m, LSQRHIP_ERR_ICOL, LSQRHIP_ERR_IROW, pt, pwt, bufA, bufB, hist, d_flags, h->dict, h->ndict, h->AT);
+            rc = build_csr_T<int>(s, d_icol, d_irow, d_a, nnz, h->n, h->m, LSQRHIP_ERR_ICOL, LSQRHIP_ERR_IROW, pt, pwt, xt, bufA, bufB, hist, d_flags, h->dict, h->ndict, h->AT);
     }
     (void)hipFree(bufA);
     (void)hipFree(bufB);
@@ -731,6 +753,8 @@ extern "C" int lsqrhip_info(lsqrhip_handle_t h, int64_t *dims)
     dims[11] = h->AT.P;                          //                  CSR(A')
     dims[12] = h->A.sell;                        // sliced-ELL layout in use for A
     dims[13] = h->AT.sell;                       //                          for A'
+    dims[14] = h->A.xlds;                        // LDS-resident panels for A
+    dims[15] = h->AT.xlds;                       //                     for A'
     return LSQRHIP_OK;
 }
 

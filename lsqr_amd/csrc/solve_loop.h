@@ -65,23 +65,24 @@ struct SpmvArgs {
     hipEvent_t e0 = nullptr, e1 = nullptr;  // kernel begin/end timestamps (hipExtLaunchKernelGGL)
 };
 
-template <typename OffT, bool PANEL, bool C16, bool V8, bool UPD>
+template <typename OffT, bool PANEL, bool C16, bool V8, bool UPD, bool XL = false>
 static void launch_spmv_C(const SpmvArgs &a, double *y, hipEvent_t e0, hipEvent_t e1)
 {
     const Csr &c = *a.c;
     const dim3 grid(c.grid + (a.rider.kind != 0 ? 1 : 0));
     const void *colv = C16 ? (const void *)c.col16 : (const void *)c.col;
     const void *valv = V8 ? (const void *)c.val8 : (const void *)c.val;
+    const XlArgs xa{c.rows, c.pw, c.cols};
     if (e0 == nullptr && e1 == nullptr)  // plain launch (the only form used under stream capture)
-        hipLaunchKernelGGL((k_spmv_fused<OffT, PANEL, C16, V8, UPD>), grid, dim3(SPMV_BLOCK), 0, a.stream,
+        hipLaunchKernelGGL((k_spmv_fused<OffT, PANEL, C16, V8, UPD, XL>), grid, dim3(SPMV_BLOCK), 0, a.stream,
                            (const OffT *)c.rowptr, colv, (const int *)c.cbase, valv, (const double *)c.dict,
                            (const RowBlock *)c.blk, c.nblk, a.x, y, a.coef, a.stop, a.pout, a.pin, a.npin, a.slot_in,
-                           a.slot_out, a.skip_if_zero, a.rider, a.upd);
+                           a.slot_out, a.skip_if_zero, a.rider, a.upd, xa);
     else
-        hipExtLaunchKernelGGL((k_spmv_fused<OffT, PANEL, C16, V8, UPD>), grid, dim3(SPMV_BLOCK), 0, a.stream, e0, e1, 0,
+        hipExtLaunchKernelGGL((k_spmv_fused<OffT, PANEL, C16, V8, UPD, XL>), grid, dim3(SPMV_BLOCK), 0, a.stream, e0, e1, 0,
                               (const OffT *)c.rowptr, colv, (const int *)c.cbase, valv, (const double *)c.dict,
                               (const RowBlock *)c.blk, c.nblk, a.x, y, a.coef, a.stop, a.pout, a.pin, a.npin,
-                              a.slot_in, a.slot_out, a.skip_if_zero, a.rider, a.upd);
+                              a.slot_in, a.slot_out, a.skip_if_zero, a.rider, a.upd, xa);
 }
 
 template <typename OffT, bool PANEL>
@@ -96,6 +97,11 @@ static void launch_spmv_T(const SpmvArgs &a, double *y, hipEvent_t e0, hipEvent_
             if (v8) launch_spmv_C<OffT, false, false, true, true>(a, y, e0, e1);
             else launch_spmv_C<OffT, false, false, false, true>(a, y, e0, e1);
         }
+        return;
+    }
+    if (PANEL && a.c->xlds) {  // LDS-resident panels (spmv.h XL)
+        if (v8) launch_spmv_C<OffT, PANEL, false, true, false, PANEL>(a, y, e0, e1);
+        else launch_spmv_C<OffT, PANEL, false, false, false, PANEL>(a, y, e0, e1);
         return;
     }
     if (!PANEL && a.c->col16 != nullptr) {

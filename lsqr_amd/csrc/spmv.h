@@ -175,15 +175,32 @@ __global__ void k_block_desc(const OffT *__restrict__ rowptr, const int *__restr
 // V8 = true: one-byte value codes into the matrix-wide dictionary dict[256] (valdict.h), held in
 // LDS: 1 instead of 8 bytes per nonzero when the matrix has <= 256 distinct values.
 // UPD = true: the launch also carries the x/w update of the previous iteration (vec.h UpdArgs).
-template <typename OffT, bool PANEL, bool C16, bool V8, bool UPD>
-__global__ __launch_bounds__(SPMV_BLOCK, 8) void k_spmv_fused(
+//
+// XL = true (PANEL only): LDS-resident panels.  When the panel width is <= XL_COLS the current
+// panel's slice of x (already multiplied by sx) is held in LDS and the gathers never leave the
+// CU: the product is then bound by streaming (val, col), not by the ~0.29 L1 misses per clock a
+// CU can retire.  Needs >= ~6 nonzeros per virtual row to pay for the partial
+// sums of its many narrow panels: BASELINE config 3 at its literal 1000 per row.  72 KB of LDS
+// per workgroup -> 2 workgroups per CU.  The few entries of a window that reaches into the
+// next panel are gathered from global memory.
+constexpr int XL_COLS = 7168;  // 56 KB of x per panel
+
+struct XlArgs {
+    int rows;   // real rows of the product (virtual row v = panel * rows + r)
+    int pw;     // panel width in columns (<= XL_COLS when XL)
+    int ncols;  // columns of the matrix
+};
+
+template <typename OffT, bool PANEL, bool C16, bool V8, bool UPD, bool XL = false>
+__global__ __launch_bounds__(SPMV_BLOCK, XL ? 2 : 8) void k_spmv_fused(
     const OffT *__restrict__ rowptr, const void *__restrict__ colv, const int *__restrict__ cbase,
     const void *__restrict__ valv, const double *__restrict__ dict, const RowBlock *__restrict__ blk, int64_t nblk, const double *__restrict__ x, double *__restrict__ y,
     const SpmvCoef *__restrict__ coef, const int *__restrict__ stop, double *__restrict__ partials,
     const double *__restrict__ pin, int npin, const NormSlot *__restrict__ slot_in,
-    NormSlot *__restrict__ slot_out, int skip_if_zero, Rider rider, UpdArgs upd)
+    NormSlot *__restrict__ slot_out, int skip_if_zero, Rider rider, UpdArgs upd, XlArgs xa)
 {
     __shared__ double prod[SPMV_LDS];
+    __shared__ double xs[XL ? XL_COLS : 1];
     __shared__ double red[SPMV_BLOCK / WAVE + 1];
     __shared__ double sdict[V8 ? VD_MAX : 1];
     // One extra workgroup carries scalar work (scalar.h "riders").  It is block 0, the first
@@ -246,6 +263,15 @@ __global__ __launch_bounds__(SPMV_BLOCK, 8) void k_spmv_fused(
     if (V8) __syncthreads();
 
     double sq = 0.0;  // this thread's share of sum(y_new^2)
+    int xpid = -1, xbase = 0;  // XL: panel whose slice is in xs[], and its first column
+    // x_j * sx for column j: from the LDS slice when the column is inside it
+    auto gx = [&](int cj) -> double {
+        if (XL) {
+            const unsigned off = (unsigned)(cj - xbase);
+            if (off < (unsigned)xa.pw) return xs[off];
+        }
+        return x[cj] * sx;
+    };
 
     // Independent loads are issued up front: the descriptor of the NEXT block, this block's
     // (val, col), and the row pointers + y of the row this lane will reduce.
@@ -266,6 +292,18 @@ __global__ __launch_bounds__(SPMV_BLOCK, 8) void k_spmv_fused(
         }
         const int r0 = cur.r0, r1 = cur.r1;
         if (r0 >= r1) continue;  // uniform
+        if (XL) {  // this window's panel slice of x (times sx) into LDS, when it changes
+            const int pid = r0 / xa.rows;
+            if (pid != xpid) {  // uniform; the barrier at the end of the last trip covers xs
+                xpid = pid;
+                xbase = pid * xa.pw;
+                for (int i = tid; i < xa.pw; i += SPMV_BLOCK) {
+                    const int cx = xbase + i;
+                    xs[i] = cx < xa.ncols ? x[cx] * sx : 0.0;
+                }
+                __syncthreads();
+            }
+        }
         const OffT p0 = (OffT)cur.p0, plast = (OffT)cur.plast, pend = (OffT)cur.pend;
         const bool has_long = (pend - plast) >= (OffT)SPMV_C;
         const int r1s = has_long ? r1 - 1 : r1;
@@ -315,11 +353,11 @@ __global__ __launch_bounds__(SPMV_BLOCK, 8) void k_spmv_fused(
         if (cnt > 0) {
             double xv[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) xv[j] = x[c[j]];
+            for (int j = 0; j < 4; ++j) xv[j] = gx(c[j]);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int t = tid + j * SPMV_BLOCK;
-                if (t < cnt) prod[t] = a[j] * (xv[j] * sx);
+                if (t < cnt) prod[t] = a[j] * xv[j];
             }
             for (int k = tid + 4 * SPMV_BLOCK; k < cnt; k += 4 * SPMV_BLOCK) {  // cnt in (1024, 2C)
 #pragma unroll
@@ -333,11 +371,11 @@ __global__ __launch_bounds__(SPMV_BLOCK, 8) void k_spmv_fused(
                     c[j] = C16 ? cb + (int)col16[p0 + kk[j]] : col[p0 + kk[j]];
                 }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) xv[j] = x[c[j]];
+                for (int j = 0; j < 4; ++j) xv[j] = gx(c[j]);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int t = k + j * SPMV_BLOCK;
-                    if (t < cnt) prod[t] = a[j] * (xv[j] * sx);
+                    if (t < cnt) prod[t] = a[j] * xv[j];
                 }
             }
         }
@@ -389,11 +427,11 @@ __global__ __launch_bounds__(SPMV_BLOCK, 8) void k_spmv_fused(
                 }
                 double xl[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) xl[j] = x[cl[j]];
+                for (int j = 0; j < 4; ++j) xl[j] = gx(cl[j]);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const OffT t = k + j * SPMV_BLOCK;
-                    if (t < len) s = s + al[j] * (xl[j] * sx);
+                    if (t < len) s = s + al[j] * xl[j];
                 }
             }
             const double tot = block_sum<SPMV_BLOCK>(s, red);

@@ -100,3 +100,52 @@ def test_col16_and_col32_paths_agree_bitwise():
         res.append((r.x.copy(), r.anorm, r.rnorm, r.itn))
     os.environ.pop("LSQRHIP_COL16", None)
     assert np.array_equal(res[0][0], res[1][0]) and res[0][1:] == res[1][1:]
+
+
+@pytest.fixture
+def forced_xlds():
+    keys = ("LSQRHIP_XLDS", "LSQRHIP_XLDS_COLS", "LSQRHIP_PANELS", "LSQRHIP_PANEL_KB")
+    old = {k: os.environ.get(k) for k in keys}
+    os.environ["LSQRHIP_XLDS"] = "1"
+    os.environ["LSQRHIP_XLDS_COLS"] = "1024"        # 1024-column panels whose x slice lives in LDS
+    yield
+    for k, v in old.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
+
+
+@pytest.mark.parametrize("shape", [(3000, 20000, 120), (20000, 3000, 60), (5000, 5000, 9), (2500, 9000, 1500)])
+def test_lds_resident_panels_match_oracle(forced_xlds, shape):
+    """spmv.h XL: panels narrow enough for the x slice to live in LDS (BASELINE config 3 at its
+    literal 1000 per row chooses them by itself); forced here at test scale, including rows long
+    enough for the workgroup-split path (1500 per row) and windows that straddle two panels."""
+    m, n, per = shape
+    p = P.random_rows(m, n, per, seed=6, damp=1e-3)
+    s = lsqr_solver_ez().initialize(p.m, p.n, p.a, p.irow, p.icol, itnlim=12)
+    info = s.info()
+    assert info["xlds"] == (1 if n > 1024 else 0) and info["xlds_t"] == (1 if m > 1024 else 0)
+    assert info["panels"] == -(-n // 1024) and info["panels_t"] == -(-m // 1024)
+    po = oracle.port()
+    xp = P.u64_to_unit(P.rng_u64(101, 9, np.arange(p.n, dtype=np.uint64)))
+    yp = P.u64_to_unit(P.rng_u64(102, 9, np.arange(p.m, dtype=np.uint64)))
+    x, y = xp.copy(), yp.copy()
+    s.aprod(1, p.m, p.n, x, y)
+    _, y_ref = po.aprod(1, p.m, p.n, p.irow, p.icol, p.a, xp, yp)
+    assert np.max(np.abs(y - y_ref)) <= 1e-13 * max(np.max(np.abs(y_ref)), 1.0)
+    x, y = xp.copy(), yp.copy()
+    s.aprod(2, p.m, p.n, x, y)
+    x_ref, _ = po.aprod(2, p.m, p.n, p.irow, p.icol, p.a, xp, yp)
+    assert np.max(np.abs(x - x_ref)) <= 1e-13 * max(np.max(np.abs(x_ref)), 1.0)
+    r = s.solve(p.b, 1e-3)
+    o = po.solve(p.m, p.n, p.irow, p.icol, p.a, p.b, damp=1e-3, itnlim=12)
+    assert (r.istop, r.itn) == (o.istop, o.itn)
+    assert np.linalg.norm(r.x - o.x) <= 1e-10 * np.linalg.norm(o.x)
+    assert abs(r.anorm - o.anorm) <= 1e-10 * o.anorm and abs(r.rnorm - o.rnorm) <= 1e-10 * o.rnorm
+    r2 = s.solve(p.b, 1e-3)
+    assert np.array_equal(r.x, r2.x) and r.anorm == r2.anorm          # deterministic
+    for pipeline in (0, 1):
+        s.set_option("pipeline", pipeline)
+        r3 = s.solve(p.b, 1e-3)
+        assert np.array_equal(r.x, r3.x) and r.anorm == r3.anorm      # every schedule, same bits
