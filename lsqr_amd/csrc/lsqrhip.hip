@@ -27,6 +27,7 @@
 #include "scalar.h"
 #include "sell.h"
 #include "spmv.h"
+#include "xl.h"
 #include "state.h"
 #include "vec.h"
 
@@ -142,7 +143,8 @@ struct Csr {
     int grid = 0;      // workgroups of the SpMV launch
     int out_grid = 0;  // partials one product leaves behind (== grid, or the combine kernel's grid)
     int P = 1;         // column panels (1 = plain CSR)
-    int xlds = 0;      // panels narrow enough for an LDS-resident x slice (spmv.h XL)
+    int xlds = 0;      // LDS-resident x slices: 1 = spmv.h XL (256-thread), 2 = xl.h (1024-thread workgroups)
+    int xgrid = 0;     // grid of the xl.h kernel
     int pw = 0;        // panel width in columns
     int64_t rows_v = 0;  // virtual rows = P * rows (what rowptr / rb / blk index)
     int64_t bytes = 0;
@@ -389,6 +391,7 @@ static int build_csr_T(hipStream_t s, const int *d_keys, const int *d_other, con
     out.P = panels > 1 ? panels : 1;
     out.pw = out.P > 1 ? pw : cols;
     out.xlds = out.P > 1 ? xlds : 0;
+    if (out.xlds && env_int("LSQRHIP_XLDS_WG", 1024) == 1024) out.xlds = 2;
     out.rows_v = (int64_t)out.P * rows;
     const int rows_v = (int)out.rows_v;  // < 2^31, checked by the caller
     HIPCHK(hipMalloc(&out.rowptr, sizeof(OffT) * ((size_t)rows_v + 1)));
@@ -447,12 +450,13 @@ static int build_csr_T(hipStream_t s, const int *d_keys, const int *d_other, con
     }
 
     // row blocks ("row windows", spmv.h) over the (virtual) rows
-    out.nblk = std::max<int64_t>((nnz + rows_v + SPMV_C - 1) / SPMV_C, 1);
+    const int winC = out.xlds == 2 ? XLW_C : SPMV_C;  // wave-sized windows for xl.h
+    out.nblk = std::max<int64_t>((nnz + rows_v + winC - 1) / winC, 1);
     HIPCHK(hipMalloc((void **)&out.rb, sizeof(int) * (size_t)(out.nblk + 1)));
     out.bytes += (int64_t)sizeof(int) * (out.nblk + 1);
     const int64_t nt = out.nblk + 1;
     hipLaunchKernelGGL(k_row_blocks<OffT>, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, s,
-                       (const OffT *)out.rowptr, rows_v, out.nblk, out.rb);
+                       (const OffT *)out.rowptr, rows_v, out.nblk, out.rb, winC);
     HIPCHK(hipMalloc((void **)&out.blk, sizeof(RowBlock) * (size_t)out.nblk));
     out.bytes += (int64_t)sizeof(RowBlock) * out.nblk;
     hipLaunchKernelGGL(k_block_desc<OffT>, dim3((unsigned)((out.nblk + 255) / 256)), dim3(256), 0, s,
@@ -499,6 +503,11 @@ static int build_csr_T(hipStream_t s, const int *d_keys, const int *d_other, con
     if (grid >= 8) grid &= ~(int64_t)7;  // multiple of 8: XCD-aware mapping (common.h)
     out.grid = (int)std::max<int64_t>(grid, 1);
     out.out_grid = out.P > 1 ? vec_grid(2 * (int64_t)rows) : out.grid;
+    {   // xl.h: one 1024-thread workgroup per CU, trips of XLW_WAVES windows
+        int64_t xg = std::min<int64_t>((out.nblk + XLW_WAVES - 1) / XLW_WAVES, 256);
+        if (xg >= 8) xg &= ~(int64_t)7;
+        out.xgrid = (int)std::max<int64_t>(xg, 1);
+    }
     HIPCHK(hipStreamSynchronize(s));
     return LSQRHIP_OK;
 }

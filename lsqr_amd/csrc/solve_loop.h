@@ -131,6 +131,24 @@ static void launch_sell_C(const SpmvArgs &a)
                               a.slot_out, a.skip_if_zero, a.rider, a.upd);
 }
 
+template <typename OffT, bool V8>
+static void launch_xl(const SpmvArgs &a, double *z)
+{
+    const Csr &c = *a.c;
+    const dim3 grid(c.xgrid + (a.rider.kind != 0 ? 1 : 0));
+    const void *valv = V8 ? (const void *)c.val8 : (const void *)c.val;
+    const XlArgs xa{c.rows, c.pw, c.cols};
+    if (a.e0 == nullptr)
+        hipLaunchKernelGGL((k_spmv_xlw<OffT, V8>), grid, dim3(XLW_BLOCK), 0, a.stream, (const OffT *)c.rowptr,
+                           (const int *)c.col, valv, (const double *)c.dict, (const RowBlock *)c.blk, c.nblk, a.x, z,
+                           a.coef, a.stop, a.pin, a.npin, a.slot_out, a.skip_if_zero, a.rider, xa);
+    else
+        hipExtLaunchKernelGGL((k_spmv_xlw<OffT, V8>), grid, dim3(XLW_BLOCK), 0, a.stream, a.e0, nullptr, 0,
+                              (const OffT *)c.rowptr, (const int *)c.col, valv, (const double *)c.dict,
+                              (const RowBlock *)c.blk, c.nblk, a.x, z, a.coef, a.stop, a.pin, a.npin, a.slot_out,
+                              a.skip_if_zero, a.rider, xa);
+}
+
 static void launch_spmv_args(H *h, const SpmvArgs &a)
 {
     const Csr &c = *a.c;
@@ -155,8 +173,20 @@ static void launch_spmv_args(H *h, const SpmvArgs &a)
     }
     // panelled product: per-panel row sums into Z, then the combine (spmv.h "Column panels");
     // a timed launch brackets both kernels (begin of the first, end of the second)
-    if (h->off64) launch_spmv_T<long long, true>(a, h->Z, a.e0, nullptr);
-    else launch_spmv_T<int, true>(a, h->Z, a.e0, nullptr);
+    if (c.xlds == 2) {  // LDS-resident panels, 1024-thread workgroups (xl.h)
+        const bool v8 = c.val8 != nullptr;
+        if (h->off64) {
+            if (v8) launch_xl<long long, true>(a, h->Z);
+            else launch_xl<long long, false>(a, h->Z);
+        } else {
+            if (v8) launch_xl<int, true>(a, h->Z);
+            else launch_xl<int, false>(a, h->Z);
+        }
+    } else if (h->off64) {
+        launch_spmv_T<long long, true>(a, h->Z, a.e0, nullptr);
+    } else {
+        launch_spmv_T<int, true>(a, h->Z, a.e0, nullptr);
+    }
     if (a.e1 == nullptr)
         hipLaunchKernelGGL(k_panel_combine, dim3(c.out_grid), dim3(SPMV_BLOCK), 0, a.stream, a.y, (const double *)h->Z,
                            c.rows, c.P, a.coef, a.stop, a.pout, a.pin, a.npin, a.slot_in, a.skip_if_zero);

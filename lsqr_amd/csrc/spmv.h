@@ -57,9 +57,10 @@ constexpr int SPMV_LDS = 2 * SPMV_C;  // products staged per row block (doubles)
 constexpr int SPMV_MAX_GRID = 2048;   // 8 workgroups per CU x 256 CUs
 static_assert(SPMV_BLOCK == VEC_BLOCK, "the fused update runs k_update's blocks");
 
-// rb[k] = first row r in [0, m] with rowptr[r] + r >= k*C ; rb[nblk] = m.
+// rb[k] = first row r in [0, m] with rowptr[r] + r >= k*C ; rb[nblk] = m.  C = window size in work
+// units (SPMV_C, or XLW_C for the wave-window layout of xl.h).
 template <typename OffT>
-__global__ void k_row_blocks(const OffT *__restrict__ rowptr, int m, int64_t nblk, int *__restrict__ rb)
+__global__ void k_row_blocks(const OffT *__restrict__ rowptr, int m, int64_t nblk, int *__restrict__ rb, int C)
 {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k > nblk) return;
@@ -67,7 +68,7 @@ __global__ void k_row_blocks(const OffT *__restrict__ rowptr, int m, int64_t nbl
         rb[k] = m;
         return;
     }
-    const int64_t target = k * (int64_t)SPMV_C;
+    const int64_t target = k * (int64_t)C;
     int lo = 0, hi = m;  // answer in [lo, hi]
     while (lo < hi) {
         const int mid = lo + ((hi - lo) >> 1);

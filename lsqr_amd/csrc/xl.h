@@ -1,0 +1,224 @@
+// xl.h -- panelled product with LDS-resident x slices and WAVE-sized windows.
+//
+// With the panel's slice of x in LDS the gathers are free (scripts/gather_roof.hip: 492 G
+// nonzeros/s = 5.9 TB/s of (val, col) stream with LDS gathers, against 181 G/s when they go
+// to L2), so what is left to lose is the window machinery itself: in k_spmv_fused<XL> a
+// 256-thread workgroup alternates streaming, staging, barrier, row sums, barrier, and with
+// 72 KB of LDS only two of them fit a CU -- 21 ms per product at config 3's literal size, and
+// four sub-groups in lockstep inside one 1024-thread workgroup are no faster (they share the
+// barriers, so the memory pipe idles just the same).
+//
+// Here ONE 1024-thread workgroup per CU owns the 56 KB slice and each of its 16 WAVES runs
+// windows of its own (XLW_C = 256 work units, built with that window size) with no workgroup
+// barrier at all: a wave streams its window (up to 8 nonzeros in flight per lane), gathers from
+// the slice, stages the products in its private 4 KB of LDS (in-order LDS queue: no barrier
+// needed inside a wave), forms the row sums and moves on.  Sixteen independent streams per CU
+// hide each other's phases.  The only workgroup barrier is at a change of panel.
+//
+// A trip's slice is the panel of the FIRST non-empty window of its 16; entries of a window that
+// reaches into the next panel are gathered from global memory (gx).  Output z[v] = raw sum of
+// the (panel, row) segment, combined by k_panel_combine (spmv.h).
+#pragma once
+
+#include "common.h"
+#include "scalar.h"
+#include "spmv.h"
+#include "state.h"
+#include "valdict.h"
+
+namespace lsqrhip {
+
+constexpr int XLW_BLOCK = 1024;
+constexpr int XLW_WAVES = XLW_BLOCK / WAVE;  // 16 windows per trip
+constexpr int XLW_C = 256;                   // window size in work units (nonzeros + rows)
+constexpr int XLW_U = 8;                     // nonzeros in flight per lane: 2 * XLW_C = 8 * 64
+
+template <typename OffT, bool V8>
+__global__ __launch_bounds__(XLW_BLOCK, 1) void k_spmv_xlw(
+    const OffT *__restrict__ rowptr, const int *__restrict__ col, const void *__restrict__ valv,
+    const double *__restrict__ dict, const RowBlock *__restrict__ blk, int64_t nblk, const double *__restrict__ x,
+    double *__restrict__ z, const SpmvCoef *__restrict__ coef, const int *__restrict__ stop,
+    const double *__restrict__ pin, int npin, NormSlot *__restrict__ slot_out, int skip_if_zero, Rider rider,
+    XlArgs xa)
+{
+    __shared__ double xs[XL_COLS];
+    __shared__ double prod[XLW_WAVES][2 * XLW_C];
+    __shared__ double red[SC_BLOCK / WAVE + 1];
+    __shared__ double sdict[V8 ? VD_MAX : 1];
+    __shared__ double bcast;
+    const int tid = threadIdx.x;
+    const int lane = tid & (WAVE - 1), w = tid >> 6;
+    const int shift = rider.kind != 0 ? 1 : 0;
+    const int nwg = (int)gridDim.x - shift;
+    const int wg = (int)blockIdx.x - shift;
+    if (wg < 0) {  // the scalar rider is written for 256 threads: the other waves leave
+        if (tid >= SC_BLOCK) return;
+        run_rider(rider, red);
+        return;
+    }
+    if (*stop != 0) return;
+    const double *__restrict__ val = static_cast<const double *>(valv);
+    const unsigned char *__restrict__ val8 = static_cast<const unsigned char *>(valv);
+    if (V8 && tid < VD_MAX) sdict[tid] = dict[tid];
+
+    double sx;
+    if (pin != nullptr) {
+        // the 256-thread fixed-order reduction of the other kernels, bit for bit
+        double s = 0.0;
+        if (tid < SC_BLOCK && npin > 0) s = strided_sum<SC_BLOCK>(pin, npin);
+        s = wave_sum(s);
+        if (tid < SC_BLOCK && lane == 0) red[w] = s;
+        __syncthreads();
+        if (tid == 0) {
+            double r = 0.0;
+#pragma unroll
+            for (int i = 0; i < SC_BLOCK / WAVE; ++i) r += red[i];
+            bcast = r;
+        }
+        __syncthreads();
+        const double nrm = sqrt(bcast);
+        if (skip_if_zero && !(nrm > 0.0)) {
+            if (wg == 0 && tid == 0) {
+                slot_out->nrm = nrm;
+                slot_out->scale = 1.0;
+            }
+            return;
+        }
+        sx = nrm > 0.0 ? 1.0 / nrm : 1.0;
+        if (wg == 0 && tid == 0) {
+            slot_out->nrm = nrm;
+            slot_out->scale = sx;
+        }
+    } else {
+        if (coef->skip != 0) return;
+        sx = coef->sx;
+    }
+    __syncthreads();  // sdict visible
+
+    int xpid = -1, xbase = 0;
+    auto gx = [&](int cj) -> double {
+        const unsigned off = (unsigned)(cj - xbase);
+        if (off < (unsigned)xa.pw) return xs[off];
+        return x[cj] * sx;
+    };
+    double *__restrict__ myprod = prod[w];
+
+    const int64_t ngrp = (nblk + XLW_WAVES - 1) / XLW_WAVES;
+    const XcdRange xr = xcd_range(ngrp, nwg, wg);
+    for (int64_t grp = xr.first; grp < xr.end; grp += xr.stride) {
+        const int64_t b0 = grp * XLW_WAVES;
+        // ---- uniform over the workgroup: which panel's slice this trip uses ------------------
+        int first_r0 = -1;
+        for (int i = 0; i < XLW_WAVES && first_r0 < 0; ++i) {
+            if (b0 + i < nblk) {
+                const RowBlock q = blk[b0 + i];  // uniform index
+                if (q.r0 < q.r1) first_r0 = q.r0;
+            }
+        }
+        if (first_r0 >= 0) {
+            const int pid = first_r0 / xa.rows;
+            if (pid != xpid) {
+                __syncthreads();  // every wave has finished gathering from the old slice
+                xpid = pid;
+                xbase = pid * xa.pw;
+                for (int i = tid; i < xa.pw; i += XLW_BLOCK) {
+                    const int cx = xbase + i;
+                    xs[i] = cx < xa.ncols ? x[cx] * sx : 0.0;
+                }
+                __syncthreads();
+            }
+        }
+        // ---- this wave's window: no workgroup barrier from here to the end of the trip -------
+        if (b0 + w >= nblk) continue;
+        const RowBlock cur = blk[b0 + w];
+        const int r0 = cur.r0, r1 = cur.r1;
+        if (r0 >= r1) continue;
+        const OffT p0 = (OffT)cur.p0, plast = (OffT)cur.plast, pend = (OffT)cur.pend;
+        const bool has_long = (pend - plast) >= (OffT)XLW_C;
+        const int r1s = has_long ? r1 - 1 : r1;
+        const int cnt = (int)((has_long ? plast : pend) - p0);  // < 2 * XLW_C
+        const int nr = r1s - r0;
+        int G = 1;
+        if (nr > 0) {
+            const int avg = cnt / nr;
+            while (G < WAVE && avg > 16 * G) G <<= 1;
+        }
+        const int gl = lane & (G - 1), gid = lane / G, ngroups = WAVE / G;
+
+        // early loads for phase 2: the bounds of this lane's first row
+        const int rfirst = r0 + gid;
+        const bool have_row = rfirst < r1s;
+        OffT q0 = 0, q1 = 0;
+        if (have_row) {
+            q0 = rowptr[rfirst];
+            q1 = rowptr[rfirst + 1];
+        }
+        // phase 1: the whole window in one round of loads
+        if (cnt > 0) {
+            const int last = cnt - 1;
+            int kk[XLW_U], cc[XLW_U];
+            double a[XLW_U];
+#pragma unroll
+            for (int j = 0; j < XLW_U; ++j) {
+                const int e = lane + j * WAVE;
+                kk[j] = e < last ? e : last;
+            }
+#pragma unroll
+            for (int j = 0; j < XLW_U; ++j) {
+                a[j] = V8 ? sdict[val8[p0 + kk[j]]] : val[p0 + kk[j]];
+                cc[j] = col[p0 + kk[j]];
+            }
+#pragma unroll
+            for (int j = 0; j < XLW_U; ++j) {
+                const int e = lane + j * WAVE;
+                if (e < cnt) myprod[e] = a[j] * gx(cc[j]);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();  // same wave, in-order LDS queue: the products are visible
+
+        // phase 2: row sums out of this wave's products
+        if (have_row) {
+            int r = rfirst;
+            for (;;) {
+                const int s0 = (int)(q0 - p0), s1 = (int)(q1 - p0);
+                double s = 0.0;
+                for (int k = s0 + gl; k < s1; k += G) s = s + myprod[k];
+                for (int off = G >> 1; off > 0; off >>= 1) s += __shfl_xor(s, off, WAVE);
+                if (gl == 0) z[r] = s;
+                r += ngroups;
+                if (r >= r1s) break;
+                q0 = rowptr[r];
+                q1 = rowptr[r + 1];
+            }
+        }
+
+        // phase 3: a long last row, split across the wave
+        if (has_long) {
+            const OffT len = pend - plast;
+            double s = 0.0;
+            for (OffT k = lane; k < len; k += 4 * WAVE) {
+                double al[4], xl[4];
+                int cl[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const OffT e = k + j * WAVE;
+                    const OffT ke = e < len ? e : len - 1;
+                    al[j] = V8 ? sdict[val8[plast + ke]] : val[plast + ke];
+                    cl[j] = col[plast + ke];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) xl[j] = gx(cl[j]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const OffT e = k + j * WAVE;
+                    if (e < len) s = s + al[j] * xl[j];
+                }
+            }
+            s = wave_sum(s);
+            if (lane == 0) z[r1 - 1] = s;
+        }
+        __builtin_amdgcn_wave_barrier();  // the next window of this wave rewrites its products
+    }
+}
+
+}  // namespace lsqrhip

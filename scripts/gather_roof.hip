@@ -68,6 +68,54 @@ __global__ __launch_bounds__(256, 8) void k_gather(const int *__restrict__ col, 
     if (acc == 123.456) out[0] = acc;  // keep the work
 }
 
+// Same work, each lane taking 4 CONSECUTIVE nonzeros per step: (val, col) arrive as 16-byte loads
+// (two dwordx4 of values, one dwordx4 of columns) instead of 8- and 4-byte ones.  MODE 0: gathers
+// from global memory, 1: no gather at all (pure stream), 2: gathers from an LDS copy of x (<= 56 KB).
+template <int MODE>
+__global__ __launch_bounds__(256, 8) void k_gather_wide(const int *__restrict__ col, const double *__restrict__ val,
+                                                        const double *__restrict__ x, int64_t nnz, int ncols,
+                                                        double *__restrict__ out)
+{
+    __shared__ double xs[MODE == 2 ? 7168 : 1];
+    if (MODE == 2) {
+        for (int i = threadIdx.x; i < 7168; i += 256) xs[i] = x[i % ncols];
+        __syncthreads();
+    }
+    double acc = 0.0;
+    const int64_t n4 = nnz >> 2;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    const int4 *col4 = reinterpret_cast<const int4 *>(col);
+    const double2 *val2 = reinterpret_cast<const double2 *>(val);
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < n4; q += stride) {
+        const int4 c = col4[q];
+        const double2 a01 = val2[2 * q], a23 = val2[2 * q + 1];
+        double x0 = 1.0, x1 = 1.0, x2 = 1.0, x3 = 1.0;
+        if (MODE == 0) { x0 = x[c.x]; x1 = x[c.y]; x2 = x[c.z]; x3 = x[c.w]; }
+        if (MODE == 2) { x0 = xs[c.x % 7168]; x1 = xs[c.y % 7168]; x2 = xs[c.z % 7168]; x3 = xs[c.w % 7168]; }
+        if (MODE == 1) { x0 = (double)c.x; x1 = (double)c.y; x2 = (double)c.z; x3 = (double)c.w; }
+        acc += a01.x * x0 + a01.y * x1 + a23.x * x2 + a23.y * x3;
+    }
+    if (acc == 123.456) out[0] = acc;
+}
+
+template <int MODE>
+static double run_wide(const int *col, const double *val, const double *x, int64_t nnz, int ncols, double *out, int reps)
+{
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(k_gather_wide<MODE>, dim3(2048), dim3(256), 0, 0, col, val, x, nnz, ncols, out);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0, 0));
+    for (int r = 0; r < reps; ++r)
+        hipLaunchKernelGGL(k_gather_wide<MODE>, dim3(2048), dim3(256), 0, 0, col, val, x, nnz, ncols, out);
+    CK(hipEventRecord(e1, 0));
+    CK(hipEventSynchronize(e1));
+    float ms = 0;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    return ms / reps;
+}
+
 template <int U>
 static double run(const int *col, const double *val, const double *x, int64_t nnz, double *out, int reps)
 {
@@ -108,6 +156,21 @@ int main()
             std::printf("%-14zu %-4d %10.3f %12.1f %14.3f %12.0f\n", xb, U, ms, gps, gps * 1e9 / (256.0 * 2.4e9),
                         12.0 * nnz / (ms * 1e-3) / 1e9);
         }
+    }
+    std::printf("\nwide loads (4 consecutive nonzeros per lane, 16-byte loads):\n%-26s %10s %12s %12s\n", "variant", "ms",
+                "Gnnz/s", "stream GB/s");
+    {
+        const int ncols = (2u << 20) / 8;
+        hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, col, val, nnz, ncols, 0);
+        CK(hipDeviceSynchronize());
+        const double t1 = run_wide<1>(col, val, x, nnz, ncols, out, 5);
+        const double t0 = run_wide<0>(col, val, x, nnz, ncols, out, 5);
+        const double t2 = run_wide<2>(col, val, x, nnz, ncols, out, 5);
+        const double ts[3] = {t1, t0, t2};
+        const char *nm[3] = {"stream only", "gather from 2 MB (L2)", "gather from LDS"};
+        for (int k = 0; k < 3; ++k)
+            std::printf("%-26s %10.3f %12.1f %12.0f\n", nm[k], ts[k], nnz / (ts[k] * 1e-3) / 1e9,
+                        12.0 * nnz / (ts[k] * 1e-3) / 1e9);
     }
     return 0;
 }
