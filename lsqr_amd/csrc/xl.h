@@ -20,6 +20,8 @@
 // the (panel, row) segment, combined by k_panel_combine (spmv.h).
 #pragma once
 
+#include <type_traits>
+
 #include "common.h"
 #include "scalar.h"
 #include "spmv.h"
@@ -103,8 +105,44 @@ __global__ __launch_bounds__(XLW_BLOCK, 1) void k_spmv_xlw(
     };
     double *__restrict__ myprod = prod[w];
 
+    // Software pipeline per wave: the (val, col) stream of the NEXT window is issued before this
+    // window's products are staged and summed; descriptors run two windows ahead.
+    typedef typename std::conditional<V8, int, double>::type RawV;
     const int64_t ngrp = (nblk + XLW_WAVES - 1) / XLW_WAVES;
     const XcdRange xr = xcd_range(ngrp, nwg, wg);
+    RowBlock none;
+    none.p0 = none.plast = none.pend = 0;
+    none.r0 = none.r1 = 0;
+    auto desc = [&](int64_t grp) -> RowBlock {
+        const int64_t b = grp * XLW_WAVES + w;
+        return (grp < xr.end && b < nblk) ? blk[b] : none;
+    };
+    auto load_head = [&](const RowBlock &q, RawV (&av)[XLW_U], int (&cv)[XLW_U]) {
+        const bool hl = (q.pend - q.plast) >= (long long)XLW_C;
+        const int nq = q.r0 < q.r1 ? (int)((hl ? q.plast : q.pend) - q.p0) : 0;
+        if (nq > 0) {
+            const int lastq = nq - 1;
+            const OffT qp = (OffT)q.p0;
+#pragma unroll
+            for (int j = 0; j < XLW_U; ++j) {
+                const int e = lane + j * WAVE;
+                const int ke = e < lastq ? e : lastq;
+                if (V8) av[j] = (RawV)val8[qp + ke];
+                else av[j] = (RawV)val[qp + ke];
+                cv[j] = col[qp + ke];
+            }
+        }
+    };
+    RowBlock d1 = desc(xr.first), d2 = desc(xr.first + xr.stride);
+    RawV araw[XLW_U];
+    int cc[XLW_U];
+#pragma unroll
+    for (int j = 0; j < XLW_U; ++j) {
+        araw[j] = 0;
+        cc[j] = 0;
+    }
+    load_head(d1, araw, cc);
+
     for (int64_t grp = xr.first; grp < xr.end; grp += xr.stride) {
         const int64_t b0 = grp * XLW_WAVES;
         // ---- uniform over the workgroup: which panel's slice this trip uses ------------------
@@ -129,95 +167,96 @@ __global__ __launch_bounds__(XLW_BLOCK, 1) void k_spmv_xlw(
             }
         }
         // ---- this wave's window: no workgroup barrier from here to the end of the trip -------
-        if (b0 + w >= nblk) continue;
-        const RowBlock cur = blk[b0 + w];
+        const RowBlock cur = d1;
+        d1 = d2;
+        d2 = desc(grp + 2 * xr.stride);
+        RawV anext[XLW_U];
+        int cnext[XLW_U];
+#pragma unroll
+        for (int j = 0; j < XLW_U; ++j) {
+            anext[j] = 0;
+            cnext[j] = 0;
+        }
+        load_head(d1, anext, cnext);  // next window's stream: in flight while this one is summed
         const int r0 = cur.r0, r1 = cur.r1;
-        if (r0 >= r1) continue;
-        const OffT p0 = (OffT)cur.p0, plast = (OffT)cur.plast, pend = (OffT)cur.pend;
-        const bool has_long = (pend - plast) >= (OffT)XLW_C;
-        const int r1s = has_long ? r1 - 1 : r1;
-        const int cnt = (int)((has_long ? plast : pend) - p0);  // < 2 * XLW_C
-        const int nr = r1s - r0;
-        int G = 1;
-        if (nr > 0) {
-            const int avg = cnt / nr;
-            while (G < WAVE && avg > 16 * G) G <<= 1;
-        }
-        const int gl = lane & (G - 1), gid = lane / G, ngroups = WAVE / G;
+        if (r0 < r1) {
+            const OffT p0 = (OffT)cur.p0, plast = (OffT)cur.plast, pend = (OffT)cur.pend;
+            const bool has_long = (pend - plast) >= (OffT)XLW_C;
+            const int r1s = has_long ? r1 - 1 : r1;
+            const int cnt = (int)((has_long ? plast : pend) - p0);  // < 2 * XLW_C
+            const int nr = r1s - r0;
+            int G = 1;
+            if (nr > 0) {
+                const int avg = cnt / nr;
+                while (G < WAVE && avg > 16 * G) G <<= 1;
+            }
+            const int gl = lane & (G - 1), gid = lane / G, ngroups = WAVE / G;
 
-        // early loads for phase 2: the bounds of this lane's first row
-        const int rfirst = r0 + gid;
-        const bool have_row = rfirst < r1s;
-        OffT q0 = 0, q1 = 0;
-        if (have_row) {
-            q0 = rowptr[rfirst];
-            q1 = rowptr[rfirst + 1];
-        }
-        // phase 1: the whole window in one round of loads
-        if (cnt > 0) {
-            const int last = cnt - 1;
-            int kk[XLW_U], cc[XLW_U];
-            double a[XLW_U];
+            // early loads for phase 2: the bounds of this lane's first row
+            const int rfirst = r0 + gid;
+            const bool have_row = rfirst < r1s;
+            OffT q0 = 0, q1 = 0;
+            if (have_row) {
+                q0 = rowptr[rfirst];
+                q1 = rowptr[rfirst + 1];
+            }
+            // phase 1: stage the products of the window (its stream was loaded a trip ago)
 #pragma unroll
             for (int j = 0; j < XLW_U; ++j) {
                 const int e = lane + j * WAVE;
-                kk[j] = e < last ? e : last;
+                const double av = V8 ? sdict[(int)araw[j]] : (double)araw[j];
+                if (e < cnt) myprod[e] = av * gx(cc[j]);
             }
-#pragma unroll
-            for (int j = 0; j < XLW_U; ++j) {
-                a[j] = V8 ? sdict[val8[p0 + kk[j]]] : val[p0 + kk[j]];
-                cc[j] = col[p0 + kk[j]];
-            }
-#pragma unroll
-            for (int j = 0; j < XLW_U; ++j) {
-                const int e = lane + j * WAVE;
-                if (e < cnt) myprod[e] = a[j] * gx(cc[j]);
-            }
-        }
-        __builtin_amdgcn_wave_barrier();  // same wave, in-order LDS queue: the products are visible
+            __builtin_amdgcn_wave_barrier();  // same wave, in-order LDS queue: the products are visible
 
-        // phase 2: row sums out of this wave's products
-        if (have_row) {
-            int r = rfirst;
-            for (;;) {
-                const int s0 = (int)(q0 - p0), s1 = (int)(q1 - p0);
+            // phase 2: row sums out of this wave's products
+            if (have_row) {
+                int r = rfirst;
+                for (;;) {
+                    const int s0 = (int)(q0 - p0), s1 = (int)(q1 - p0);
+                    double s = 0.0;
+                    for (int k = s0 + gl; k < s1; k += G) s = s + myprod[k];
+                    for (int off = G >> 1; off > 0; off >>= 1) s += __shfl_xor(s, off, WAVE);
+                    if (gl == 0) z[r] = s;
+                    r += ngroups;
+                    if (r >= r1s) break;
+                    q0 = rowptr[r];
+                    q1 = rowptr[r + 1];
+                }
+            }
+
+            // phase 3: a long last row, split across the wave
+            if (has_long) {
+                const OffT len = pend - plast;
                 double s = 0.0;
-                for (int k = s0 + gl; k < s1; k += G) s = s + myprod[k];
-                for (int off = G >> 1; off > 0; off >>= 1) s += __shfl_xor(s, off, WAVE);
-                if (gl == 0) z[r] = s;
-                r += ngroups;
-                if (r >= r1s) break;
-                q0 = rowptr[r];
-                q1 = rowptr[r + 1];
-            }
-        }
-
-        // phase 3: a long last row, split across the wave
-        if (has_long) {
-            const OffT len = pend - plast;
-            double s = 0.0;
-            for (OffT k = lane; k < len; k += 4 * WAVE) {
-                double al[4], xl[4];
-                int cl[4];
+                for (OffT k = lane; k < len; k += 4 * WAVE) {
+                    double al[4], xl[4];
+                    int cl[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const OffT e = k + j * WAVE;
-                    const OffT ke = e < len ? e : len - 1;
-                    al[j] = V8 ? sdict[val8[plast + ke]] : val[plast + ke];
-                    cl[j] = col[plast + ke];
+                    for (int j = 0; j < 4; ++j) {
+                        const OffT e = k + j * WAVE;
+                        const OffT ke = e < len ? e : len - 1;
+                        al[j] = V8 ? sdict[val8[plast + ke]] : val[plast + ke];
+                        cl[j] = col[plast + ke];
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) xl[j] = gx(cl[j]);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const OffT e = k + j * WAVE;
+                        if (e < len) s = s + al[j] * xl[j];
+                    }
                 }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) xl[j] = gx(cl[j]);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const OffT e = k + j * WAVE;
-                    if (e < len) s = s + al[j] * xl[j];
-                }
+                s = wave_sum(s);
+                if (lane == 0) z[r1 - 1] = s;
             }
-            s = wave_sum(s);
-            if (lane == 0) z[r1 - 1] = s;
+            __builtin_amdgcn_wave_barrier();  // the next window of this wave rewrites its products
         }
-        __builtin_amdgcn_wave_barrier();  // the next window of this wave rewrites its products
+#pragma unroll
+        for (int j = 0; j < XLW_U; ++j) {
+            araw[j] = anext[j];
+            cc[j] = cnext[j];
+        }
     }
 }
 
