@@ -462,6 +462,18 @@ static int build_csr_T(hipStream_t s, const int *d_keys, const int *d_other, con
     hipLaunchKernelGGL(k_block_desc<OffT>, dim3((unsigned)((out.nblk + 255) / 256)), dim3(256), 0, s,
                        (const OffT *)out.rowptr, (const int *)out.rb, out.nblk, out.blk);
     HIPCHK(hipGetLastError());
+    // wave-window LDS panels (xl.h): 16-bit columns relative to the window's own panel, always possible
+    if (out.xlds == 2 && nnz > 0 && env_int("LSQRHIP_COL16", 1) != 0) {
+        HIPCHK(hipMalloc((void **)&out.col16, sizeof(unsigned short) * (size_t)nnz));
+        const unsigned gb = (unsigned)std::min<int64_t>((out.nblk + 3) / 4, 65535);
+        hipLaunchKernelGGL(k_xl_col16, dim3(gb), dim3(256), 0, s, (const RowBlock *)out.blk, out.nblk,
+                           (const int *)out.col, rows, out.pw, out.col16);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(s));
+        (void)hipFree(out.col);
+        out.col = nullptr;
+        out.bytes -= 2 * nnz;
+    }
     // 16-bit block-relative columns when every row block is narrower than 65536 columns
     // (LSQRHIP_COL16=0 keeps 32-bit indices)
     if (out.P <= 1 && nnz > 0 && env_int("LSQRHIP_COL16", 1) != 0) {

@@ -131,22 +131,28 @@ static void launch_sell_C(const SpmvArgs &a)
                               a.slot_out, a.skip_if_zero, a.rider, a.upd);
 }
 
-template <typename OffT, bool V8>
-static void launch_xl(const SpmvArgs &a, double *z)
+template <typename OffT, bool V8, bool C16>
+static void launch_xl_C(const SpmvArgs &a, double *z)
 {
     const Csr &c = *a.c;
     const dim3 grid(c.xgrid + (a.rider.kind != 0 ? 1 : 0));
     const void *valv = V8 ? (const void *)c.val8 : (const void *)c.val;
+    const void *colv = C16 ? (const void *)c.col16 : (const void *)c.col;
     const XlArgs xa{c.rows, c.pw, c.cols};
     if (a.e0 == nullptr)
-        hipLaunchKernelGGL((k_spmv_xlw<OffT, V8>), grid, dim3(XLW_BLOCK), 0, a.stream, (const OffT *)c.rowptr,
-                           (const int *)c.col, valv, (const double *)c.dict, (const RowBlock *)c.blk, c.nblk, a.x, z,
-                           a.coef, a.stop, a.pin, a.npin, a.slot_out, a.skip_if_zero, a.rider, xa);
+        hipLaunchKernelGGL((k_spmv_xlw<OffT, V8, C16>), grid, dim3(XLW_BLOCK), 0, a.stream, (const OffT *)c.rowptr,
+                           colv, valv, (const double *)c.dict, (const RowBlock *)c.blk, c.nblk, a.x, z, a.coef, a.stop,
+                           a.pin, a.npin, a.slot_out, a.skip_if_zero, a.rider, xa);
     else
-        hipExtLaunchKernelGGL((k_spmv_xlw<OffT, V8>), grid, dim3(XLW_BLOCK), 0, a.stream, a.e0, nullptr, 0,
-                              (const OffT *)c.rowptr, (const int *)c.col, valv, (const double *)c.dict,
-                              (const RowBlock *)c.blk, c.nblk, a.x, z, a.coef, a.stop, a.pin, a.npin, a.slot_out,
-                              a.skip_if_zero, a.rider, xa);
+        hipExtLaunchKernelGGL((k_spmv_xlw<OffT, V8, C16>), grid, dim3(XLW_BLOCK), 0, a.stream, a.e0, nullptr, 0,
+                              (const OffT *)c.rowptr, colv, valv, (const double *)c.dict, (const RowBlock *)c.blk,
+                              c.nblk, a.x, z, a.coef, a.stop, a.pin, a.npin, a.slot_out, a.skip_if_zero, a.rider, xa);
+}
+template <typename OffT, bool V8>
+static void launch_xl(const SpmvArgs &a, double *z)
+{
+    if (a.c->col16 != nullptr) launch_xl_C<OffT, V8, true>(a, z);
+    else launch_xl_C<OffT, V8, false>(a, z);
 }
 
 static void launch_spmv_args(H *h, const SpmvArgs &a)

@@ -35,9 +35,27 @@ constexpr int XLW_WAVES = XLW_BLOCK / WAVE;  // 16 windows per trip
 constexpr int XLW_C = 256;                   // window size in work units (nonzeros + rows)
 constexpr int XLW_U = 8;                     // nonzeros in flight per lane: 2 * XLW_C = 8 * 64
 
-template <typename OffT, bool V8>
+// 16-bit columns for the wave-window layout: relative to the first column of the panel the
+// window STARTS in.  A window reaches at most into the next panel, so the offsets stay below
+// 2 * pw <= 14336: always representable.  One wave per window.
+__global__ __launch_bounds__(256) void k_xl_col16(const RowBlock *__restrict__ blk, int64_t nblk,
+                                                  const int *__restrict__ col, int rows, int pw,
+                                                  unsigned short *__restrict__ col16)
+{
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int64_t nw = (int64_t)gridDim.x * (256 / WAVE);
+    for (int64_t b = (int64_t)blockIdx.x * (256 / WAVE) + (threadIdx.x >> 6); b < nblk; b += nw) {
+        const RowBlock q = blk[b];
+        if (q.r0 >= q.r1) continue;
+        const int cb = (q.r0 / rows) * pw;
+        for (long long k = q.p0 + lane; k < q.pend; k += WAVE) col16[k] = (unsigned short)(col[k] - cb);
+    }
+}
+
+// C16 = true: 16-bit window-relative columns (k_xl_col16).
+template <typename OffT, bool V8, bool C16>
 __global__ __launch_bounds__(XLW_BLOCK, 1) void k_spmv_xlw(
-    const OffT *__restrict__ rowptr, const int *__restrict__ col, const void *__restrict__ valv,
+    const OffT *__restrict__ rowptr, const void *__restrict__ colv, const void *__restrict__ valv,
     const double *__restrict__ dict, const RowBlock *__restrict__ blk, int64_t nblk, const double *__restrict__ x,
     double *__restrict__ z, const SpmvCoef *__restrict__ coef, const int *__restrict__ stop,
     const double *__restrict__ pin, int npin, NormSlot *__restrict__ slot_out, int skip_if_zero, Rider rider,
@@ -61,6 +79,8 @@ __global__ __launch_bounds__(XLW_BLOCK, 1) void k_spmv_xlw(
     if (*stop != 0) return;
     const double *__restrict__ val = static_cast<const double *>(valv);
     const unsigned char *__restrict__ val8 = static_cast<const unsigned char *>(valv);
+    const int *__restrict__ col = static_cast<const int *>(colv);
+    const unsigned short *__restrict__ col16 = static_cast<const unsigned short *>(colv);
     if (V8 && tid < VD_MAX) sdict[tid] = dict[tid];
 
     double sx;
@@ -129,7 +149,7 @@ __global__ __launch_bounds__(XLW_BLOCK, 1) void k_spmv_xlw(
                 const int ke = e < lastq ? e : lastq;
                 if (V8) av[j] = (RawV)val8[qp + ke];
                 else av[j] = (RawV)val[qp + ke];
-                cv[j] = col[qp + ke];
+                cv[j] = C16 ? (int)col16[qp + ke] : col[qp + ke];
             }
         }
     };
@@ -191,6 +211,7 @@ __global__ __launch_bounds__(XLW_BLOCK, 1) void k_spmv_xlw(
                 while (G < WAVE && avg > 16 * G) G <<= 1;
             }
             const int gl = lane & (G - 1), gid = lane / G, ngroups = WAVE / G;
+            const int cb = C16 ? (r0 / xa.rows) * xa.pw : 0;  // first column of the window's own panel
 
             // early loads for phase 2: the bounds of this lane's first row
             const int rfirst = r0 + gid;
@@ -205,7 +226,7 @@ __global__ __launch_bounds__(XLW_BLOCK, 1) void k_spmv_xlw(
             for (int j = 0; j < XLW_U; ++j) {
                 const int e = lane + j * WAVE;
                 const double av = V8 ? sdict[(int)araw[j]] : (double)araw[j];
-                if (e < cnt) myprod[e] = av * gx(cc[j]);
+                if (e < cnt) myprod[e] = av * gx(cb + cc[j]);
             }
             __builtin_amdgcn_wave_barrier();  // same wave, in-order LDS queue: the products are visible
 
@@ -237,7 +258,7 @@ __global__ __launch_bounds__(XLW_BLOCK, 1) void k_spmv_xlw(
                         const OffT e = k + j * WAVE;
                         const OffT ke = e < len ? e : len - 1;
                         al[j] = V8 ? sdict[val8[plast + ke]] : val[plast + ke];
-                        cl[j] = col[plast + ke];
+                        cl[j] = C16 ? cb + (int)col16[plast + ke] : col[plast + ke];
                     }
 #pragma unroll
                     for (int j = 0; j < 4; ++j) xl[j] = gx(cl[j]);
