@@ -146,8 +146,14 @@ def run_single(args):
         info = s.info()
         fmt1 = info["csr_bytes"] + 8 * p.n + 16 * p.m
         fmt2 = info["csrt_bytes"] + 8 * p.m + 16 * p.n
-        layout = "sell" if info["sell"] else ("panels" if info["panels"] > 1 else "row-windows")
-        kname = "k_spmv_sell" if info["sell"] else "k_spmv_fused"
+        if info["sell"]:
+            layout, kname = "sell", "k_spmv_sell"
+        elif info["xlds"] == 2:
+            layout, kname = "lds-panels (wave windows)", "k_spmv_xlw + k_panel_combine"
+        elif info["panels"] > 1:
+            layout, kname = "l2-panels", "k_spmv_fused + k_panel_combine"
+        else:
+            layout, kname = "row-windows", "k_spmv_fused"
         # roofline.achieved follows the contract: ALGORITHMIC bytes of the product (fp64
         # values, int32 columns, row pointers, x once, y read + written) / average launch time.
         # The bytes the chosen layout really moves are reported beside it (layout_*): with the
