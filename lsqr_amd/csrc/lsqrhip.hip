@@ -145,6 +145,7 @@ struct Csr {
     int P = 1;         // column panels (1 = plain CSR)
     int xlds = 0;      // LDS-resident x slices: 1 = spmv.h XL (256-thread), 2 = xl.h (1024-thread workgroups)
     int xgrid = 0;     // grid of the xl.h kernel
+    int *gpid = nullptr;  // xl.h: panel of every trip of XLW_WAVES windows
     int pw = 0;        // panel width in columns
     int64_t rows_v = 0;  // virtual rows = P * rows (what rowptr / rb / blk index)
     int64_t bytes = 0;
@@ -229,6 +230,7 @@ static void free_csr(Csr &c)
     if (c.cbaseS) (void)hipFree(c.cbaseS);
     if (c.rlen) (void)hipFree(c.rlen);
     if (c.rb) (void)hipFree(c.rb);
+    if (c.gpid) (void)hipFree(c.gpid);
     if (c.blk) (void)hipFree(c.blk);
     c = Csr();
 }
@@ -462,6 +464,13 @@ static int build_csr_T(hipStream_t s, const int *d_keys, const int *d_other, con
     hipLaunchKernelGGL(k_block_desc<OffT>, dim3((unsigned)((out.nblk + 255) / 256)), dim3(256), 0, s,
                        (const OffT *)out.rowptr, (const int *)out.rb, out.nblk, out.blk);
     HIPCHK(hipGetLastError());
+    if (out.xlds == 2) {  // xl.h: the panel of every trip of XLW_WAVES windows
+        const int64_t ngrp = (out.nblk + XLW_WAVES - 1) / XLW_WAVES;
+        HIPCHK(hipMalloc((void **)&out.gpid, sizeof(int) * (size_t)ngrp));
+        hipLaunchKernelGGL(k_xl_group_panel, dim3((unsigned)((ngrp + 255) / 256)), dim3(256), 0, s,
+                           (const RowBlock *)out.blk, out.nblk, rows, ngrp, out.gpid);
+        HIPCHK(hipGetLastError());
+    }
     // wave-window LDS panels (xl.h): 16-bit columns relative to the window's own panel, always possible
     if (out.xlds == 2 && nnz > 0 && env_int("LSQRHIP_COL16", 1) != 0) {
         HIPCHK(hipMalloc((void **)&out.col16, sizeof(unsigned short) * (size_t)nnz));

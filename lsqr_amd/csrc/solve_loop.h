@@ -141,12 +141,13 @@ static void launch_xl_C(const SpmvArgs &a, double *z)
     const XlArgs xa{c.rows, c.pw, c.cols};
     if (a.e0 == nullptr)
         hipLaunchKernelGGL((k_spmv_xlw<OffT, V8, C16>), grid, dim3(XLW_BLOCK), 0, a.stream, (const OffT *)c.rowptr,
-                           colv, valv, (const double *)c.dict, (const RowBlock *)c.blk, c.nblk, a.x, z, a.coef, a.stop,
-                           a.pin, a.npin, a.slot_out, a.skip_if_zero, a.rider, xa);
+                           colv, valv, (const double *)c.dict, (const RowBlock *)c.blk, c.nblk, (const int *)c.gpid, a.x, z,
+                           a.coef, a.stop, a.pin, a.npin, a.slot_out, a.skip_if_zero, a.rider, xa);
     else
         hipExtLaunchKernelGGL((k_spmv_xlw<OffT, V8, C16>), grid, dim3(XLW_BLOCK), 0, a.stream, a.e0, nullptr, 0,
                               (const OffT *)c.rowptr, colv, valv, (const double *)c.dict, (const RowBlock *)c.blk,
-                              c.nblk, a.x, z, a.coef, a.stop, a.pin, a.npin, a.slot_out, a.skip_if_zero, a.rider, xa);
+                              c.nblk, (const int *)c.gpid, a.x, z, a.coef, a.stop, a.pin, a.npin, a.slot_out,
+                              a.skip_if_zero, a.rider, xa);
 }
 template <typename OffT, bool V8>
 static void launch_xl(const SpmvArgs &a, double *z)

@@ -52,14 +52,32 @@ __global__ __launch_bounds__(256) void k_xl_col16(const RowBlock *__restrict__ b
     }
 }
 
+// gpid[g] = panel of the first non-empty window of trip g (XLW_WAVES windows), -1 if all are empty:
+// the kernel then learns a trip's slice from one prefetched word instead of scanning descriptors.
+__global__ __launch_bounds__(256) void k_xl_group_panel(const RowBlock *__restrict__ blk, int64_t nblk, int rows,
+                                                        int64_t ngrp, int *__restrict__ gpid)
+{
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= ngrp) return;
+    int pid = -1;
+    for (int i = 0; i < XLW_WAVES && pid < 0; ++i) {
+        const int64_t b = g * XLW_WAVES + i;
+        if (b < nblk) {
+            const RowBlock q = blk[b];
+            if (q.r0 < q.r1) pid = q.r0 / rows;
+        }
+    }
+    gpid[g] = pid;
+}
+
 // C16 = true: 16-bit window-relative columns (k_xl_col16).
 template <typename OffT, bool V8, bool C16>
 __global__ __launch_bounds__(XLW_BLOCK, 1) void k_spmv_xlw(
     const OffT *__restrict__ rowptr, const void *__restrict__ colv, const void *__restrict__ valv,
-    const double *__restrict__ dict, const RowBlock *__restrict__ blk, int64_t nblk, const double *__restrict__ x,
-    double *__restrict__ z, const SpmvCoef *__restrict__ coef, const int *__restrict__ stop,
-    const double *__restrict__ pin, int npin, NormSlot *__restrict__ slot_out, int skip_if_zero, Rider rider,
-    XlArgs xa)
+    const double *__restrict__ dict, const RowBlock *__restrict__ blk, int64_t nblk, const int *__restrict__ gpid,
+    const double *__restrict__ x, double *__restrict__ z, const SpmvCoef *__restrict__ coef,
+    const int *__restrict__ stop, const double *__restrict__ pin, int npin, NormSlot *__restrict__ slot_out,
+    int skip_if_zero, Rider rider, XlArgs xa)
 {
     __shared__ double xs[XL_COLS];
     __shared__ double prod[XLW_WAVES][2 * XLW_C];
@@ -163,28 +181,21 @@ __global__ __launch_bounds__(XLW_BLOCK, 1) void k_spmv_xlw(
     }
     load_head(d1, araw, cc);
 
+    int pid_next = xr.first < xr.end ? gpid[xr.first] : -1;
     for (int64_t grp = xr.first; grp < xr.end; grp += xr.stride) {
-        const int64_t b0 = grp * XLW_WAVES;
-        // ---- uniform over the workgroup: which panel's slice this trip uses ------------------
-        int first_r0 = -1;
-        for (int i = 0; i < XLW_WAVES && first_r0 < 0; ++i) {
-            if (b0 + i < nblk) {
-                const RowBlock q = blk[b0 + i];  // uniform index
-                if (q.r0 < q.r1) first_r0 = q.r0;
+        // ---- uniform over the workgroup: which panel's slice this trip uses (one word, read a
+        // trip ahead) -----------------------------------------------------------------------------
+        const int pid = pid_next;
+        pid_next = grp + xr.stride < xr.end ? gpid[grp + xr.stride] : -1;
+        if (pid >= 0 && pid != xpid) {
+            __syncthreads();  // every wave has finished gathering from the old slice
+            xpid = pid;
+            xbase = pid * xa.pw;
+            for (int i = tid; i < xa.pw; i += XLW_BLOCK) {
+                const int cx = xbase + i;
+                xs[i] = cx < xa.ncols ? x[cx] * sx : 0.0;
             }
-        }
-        if (first_r0 >= 0) {
-            const int pid = first_r0 / xa.rows;
-            if (pid != xpid) {
-                __syncthreads();  // every wave has finished gathering from the old slice
-                xpid = pid;
-                xbase = pid * xa.pw;
-                for (int i = tid; i < xa.pw; i += XLW_BLOCK) {
-                    const int cx = xbase + i;
-                    xs[i] = cx < xa.ncols ? x[cx] * sx : 0.0;
-                }
-                __syncthreads();
-            }
+            __syncthreads();
         }
         // ---- this wave's window: no workgroup barrier from here to the end of the trip -------
         const RowBlock cur = d1;
