@@ -155,9 +155,30 @@ __global__ __launch_bounds__(XLW_BLOCK, 1) void k_spmv_xlw(
         const int64_t b = grp * XLW_WAVES + w;
         return (grp < xr.end && b < nblk) ? blk[b] : none;
     };
-    auto load_head = [&](const RowBlock &q, RawV (&av)[XLW_U], int (&cv)[XLW_U]) {
+    // lanes per row from the window's mean row length (as in spmv.h)
+    auto lanes_per_row = [](int cnt, int nr) -> int {
+        int G = 1;
+        if (nr > 0) {
+            const int avg = cnt / nr;
+            while (G < WAVE && avg > 16 * G) G <<= 1;
+        }
+        return G;
+    };
+    // Everything a window needs from memory, issued one trip ahead and in the order it is
+    // consumed: a wave's loads return IN ORDER, so a load issued after the next window's stream
+    // would wait for that stream -- the bounds of this lane's first row therefore travel with it.
+    auto load_head = [&](const RowBlock &q, RawV (&av)[XLW_U], int (&cv)[XLW_U], OffT &qa, OffT &qb) {
         const bool hl = (q.pend - q.plast) >= (long long)XLW_C;
         const int nq = q.r0 < q.r1 ? (int)((hl ? q.plast : q.pend) - q.p0) : 0;
+        if (q.r0 < q.r1) {
+            const int r1q = hl ? q.r1 - 1 : q.r1;
+            const int Gq = lanes_per_row(nq, r1q - q.r0);
+            const int rf = q.r0 + lane / Gq;
+            if (rf < r1q) {
+                qa = rowptr[rf];
+                qb = rowptr[rf + 1];
+            }
+        }
         if (nq > 0) {
             const int lastq = nq - 1;
             const OffT qp = (OffT)q.p0;
@@ -179,7 +200,8 @@ __global__ __launch_bounds__(XLW_BLOCK, 1) void k_spmv_xlw(
         araw[j] = 0;
         cc[j] = 0;
     }
-    load_head(d1, araw, cc);
+    OffT q0 = 0, q1 = 0;
+    load_head(d1, araw, cc, q0, q1);
 
     int pid_next = xr.first < xr.end ? gpid[xr.first] : -1;
     for (int64_t grp = xr.first; grp < xr.end; grp += xr.stride) {
@@ -208,7 +230,8 @@ __global__ __launch_bounds__(XLW_BLOCK, 1) void k_spmv_xlw(
             anext[j] = 0;
             cnext[j] = 0;
         }
-        load_head(d1, anext, cnext);  // next window's stream: in flight while this one is summed
+        OffT q0n = 0, q1n = 0;
+        load_head(d1, anext, cnext, q0n, q1n);  // next window: in flight while this one is summed
         const int r0 = cur.r0, r1 = cur.r1;
         if (r0 < r1) {
             const OffT p0 = (OffT)cur.p0, plast = (OffT)cur.plast, pend = (OffT)cur.pend;
@@ -216,22 +239,11 @@ __global__ __launch_bounds__(XLW_BLOCK, 1) void k_spmv_xlw(
             const int r1s = has_long ? r1 - 1 : r1;
             const int cnt = (int)((has_long ? plast : pend) - p0);  // < 2 * XLW_C
             const int nr = r1s - r0;
-            int G = 1;
-            if (nr > 0) {
-                const int avg = cnt / nr;
-                while (G < WAVE && avg > 16 * G) G <<= 1;
-            }
+            const int G = lanes_per_row(cnt, nr);
             const int gl = lane & (G - 1), gid = lane / G, ngroups = WAVE / G;
             const int cb = C16 ? (r0 / xa.rows) * xa.pw : 0;  // first column of the window's own panel
-
-            // early loads for phase 2: the bounds of this lane's first row
             const int rfirst = r0 + gid;
-            const bool have_row = rfirst < r1s;
-            OffT q0 = 0, q1 = 0;
-            if (have_row) {
-                q0 = rowptr[rfirst];
-                q1 = rowptr[rfirst + 1];
-            }
+            const bool have_row = rfirst < r1s;  // its bounds q0, q1 arrived with the stream
             // phase 1: stage the products of the window (its stream was loaded a trip ago)
 #pragma unroll
             for (int j = 0; j < XLW_U; ++j) {
@@ -289,6 +301,8 @@ __global__ __launch_bounds__(XLW_BLOCK, 1) void k_spmv_xlw(
             araw[j] = anext[j];
             cc[j] = cnext[j];
         }
+        q0 = q0n;
+        q1 = q1n;
     }
 }
 
