@@ -85,7 +85,10 @@ __global__ __launch_bounds__(XLW_BLOCK, 1) void k_spmv_xlw(
     __shared__ double sdict[V8 ? VD_MAX : 1];
     __shared__ double bcast;
     const int tid = threadIdx.x;
-    const int lane = tid & (WAVE - 1), w = tid >> 6;
+    const int lane = tid & (WAVE - 1);
+    // wave index as a SCALAR: window descriptors and everything derived from them (bounds, counts,
+    // bases) then live in SGPRs and are fetched with scalar loads
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int shift = rider.kind != 0 ? 1 : 0;
     const int nwg = (int)gridDim.x - shift;
     const int wg = (int)blockIdx.x - shift;
@@ -193,20 +196,10 @@ __global__ __launch_bounds__(XLW_BLOCK, 1) void k_spmv_xlw(
         }
     };
     RowBlock d1 = desc(xr.first), d2 = desc(xr.first + xr.stride);
-    RawV araw[XLW_U];
-    int cc[XLW_U];
-#pragma unroll
-    for (int j = 0; j < XLW_U; ++j) {
-        araw[j] = 0;
-        cc[j] = 0;
-    }
-    OffT q0 = 0, q1 = 0;
-    load_head(d1, araw, cc, q0, q1);
-
+    // one trip's slice of x: the panel of the trip's first non-empty window (one word per trip,
+    // read a trip ahead); uniform over the workgroup
     int pid_next = xr.first < xr.end ? gpid[xr.first] : -1;
-    for (int64_t grp = xr.first; grp < xr.end; grp += xr.stride) {
-        // ---- uniform over the workgroup: which panel's slice this trip uses (one word, read a
-        // trip ahead) -----------------------------------------------------------------------------
+    auto slice_for = [&](int64_t grp) {
         const int pid = pid_next;
         pid_next = grp + xr.stride < xr.end ? gpid[grp + xr.stride] : -1;
         if (pid >= 0 && pid != xpid) {
@@ -219,90 +212,103 @@ __global__ __launch_bounds__(XLW_BLOCK, 1) void k_spmv_xlw(
             }
             __syncthreads();
         }
-        // ---- this wave's window: no workgroup barrier from here to the end of the trip -------
-        const RowBlock cur = d1;
-        d1 = d2;
-        d2 = desc(grp + 2 * xr.stride);
-        RawV anext[XLW_U];
-        int cnext[XLW_U];
-#pragma unroll
-        for (int j = 0; j < XLW_U; ++j) {
-            anext[j] = 0;
-            cnext[j] = 0;
-        }
-        OffT q0n = 0, q1n = 0;
-        load_head(d1, anext, cnext, q0n, q1n);  // next window: in flight while this one is summed
+    };
+    // one window, its stream (av, cv) and first row bounds (q0, q1) loaded a trip ago: no
+    // workgroup barrier in here
+    auto process = [&](const RowBlock &cur, const RawV (&av)[XLW_U], const int (&cv)[XLW_U], OffT q0, OffT q1) {
         const int r0 = cur.r0, r1 = cur.r1;
-        if (r0 < r1) {
-            const OffT p0 = (OffT)cur.p0, plast = (OffT)cur.plast, pend = (OffT)cur.pend;
-            const bool has_long = (pend - plast) >= (OffT)XLW_C;
-            const int r1s = has_long ? r1 - 1 : r1;
-            const int cnt = (int)((has_long ? plast : pend) - p0);  // < 2 * XLW_C
-            const int nr = r1s - r0;
-            const int G = lanes_per_row(cnt, nr);
-            const int gl = lane & (G - 1), gid = lane / G, ngroups = WAVE / G;
-            const int cb = C16 ? (r0 / xa.rows) * xa.pw : 0;  // first column of the window's own panel
-            const int rfirst = r0 + gid;
-            const bool have_row = rfirst < r1s;  // its bounds q0, q1 arrived with the stream
-            // phase 1: stage the products of the window (its stream was loaded a trip ago)
-#pragma unroll
-            for (int j = 0; j < XLW_U; ++j) {
-                const int e = lane + j * WAVE;
-                const double av = V8 ? sdict[(int)araw[j]] : (double)araw[j];
-                if (e < cnt) myprod[e] = av * gx(cb + cc[j]);
-            }
-            __builtin_amdgcn_wave_barrier();  // same wave, in-order LDS queue: the products are visible
-
-            // phase 2: row sums out of this wave's products
-            if (have_row) {
-                int r = rfirst;
-                for (;;) {
-                    const int s0 = (int)(q0 - p0), s1 = (int)(q1 - p0);
-                    double s = 0.0;
-                    for (int k = s0 + gl; k < s1; k += G) s = s + myprod[k];
-                    for (int off = G >> 1; off > 0; off >>= 1) s += __shfl_xor(s, off, WAVE);
-                    if (gl == 0) z[r] = s;
-                    r += ngroups;
-                    if (r >= r1s) break;
-                    q0 = rowptr[r];
-                    q1 = rowptr[r + 1];
-                }
-            }
-
-            // phase 3: a long last row, split across the wave
-            if (has_long) {
-                const OffT len = pend - plast;
-                double s = 0.0;
-                for (OffT k = lane; k < len; k += 4 * WAVE) {
-                    double al[4], xl[4];
-                    int cl[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const OffT e = k + j * WAVE;
-                        const OffT ke = e < len ? e : len - 1;
-                        al[j] = V8 ? sdict[val8[plast + ke]] : val[plast + ke];
-                        cl[j] = C16 ? cb + (int)col16[plast + ke] : col[plast + ke];
-                    }
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) xl[j] = gx(cl[j]);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const OffT e = k + j * WAVE;
-                        if (e < len) s = s + al[j] * xl[j];
-                    }
-                }
-                s = wave_sum(s);
-                if (lane == 0) z[r1 - 1] = s;
-            }
-            __builtin_amdgcn_wave_barrier();  // the next window of this wave rewrites its products
-        }
+        if (r0 >= r1) return;
+        const OffT p0 = (OffT)cur.p0, plast = (OffT)cur.plast, pend = (OffT)cur.pend;
+        const bool has_long = (pend - plast) >= (OffT)XLW_C;
+        const int r1s = has_long ? r1 - 1 : r1;
+        const int cnt = (int)((has_long ? plast : pend) - p0);  // < 2 * XLW_C
+        const int nr = r1s - r0;
+        const int G = lanes_per_row(cnt, nr);
+        const int gl = lane & (G - 1), gid = lane / G, ngroups = WAVE / G;
+        const int cb = C16 ? (r0 / xa.rows) * xa.pw : 0;  // first column of the window's own panel
+        const int rfirst = r0 + gid;
+        const bool have_row = rfirst < r1s;  // its bounds q0, q1 arrived with the stream
+        // phase 1: stage the products of the window
 #pragma unroll
         for (int j = 0; j < XLW_U; ++j) {
-            araw[j] = anext[j];
-            cc[j] = cnext[j];
+            const int e = lane + j * WAVE;
+            const double a = V8 ? sdict[(int)av[j]] : (double)av[j];
+            if (e < cnt) myprod[e] = a * gx(cb + cv[j]);
         }
-        q0 = q0n;
-        q1 = q1n;
+        __builtin_amdgcn_wave_barrier();  // same wave, in-order LDS queue: the products are visible
+        // phase 2: row sums out of this wave's products
+        if (have_row) {
+            int r = rfirst;
+            for (;;) {
+                const int s0 = (int)(q0 - p0), s1 = (int)(q1 - p0);
+                double sum = 0.0;
+                for (int k = s0 + gl; k < s1; k += G) sum = sum + myprod[k];
+                for (int off = G >> 1; off > 0; off >>= 1) sum += __shfl_xor(sum, off, WAVE);
+                if (gl == 0) z[r] = sum;
+                r += ngroups;
+                if (r >= r1s) break;
+                q0 = rowptr[r];
+                q1 = rowptr[r + 1];
+            }
+        }
+        // phase 3: a long last row, split across the wave
+        if (has_long) {
+            const OffT len = pend - plast;
+            double sum = 0.0;
+            for (OffT k = lane; k < len; k += 4 * WAVE) {
+                double al[4], xl[4];
+                int cl[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const OffT e = k + j * WAVE;
+                    const OffT ke = e < len ? e : len - 1;
+                    al[j] = V8 ? sdict[val8[plast + ke]] : val[plast + ke];
+                    cl[j] = C16 ? cb + (int)col16[plast + ke] : col[plast + ke];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) xl[j] = gx(cl[j]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const OffT e = k + j * WAVE;
+                    if (e < len) sum = sum + al[j] * xl[j];
+                }
+            }
+            sum = wave_sum(sum);
+            if (lane == 0) z[r1 - 1] = sum;
+        }
+        __builtin_amdgcn_wave_barrier();  // the next window of this wave rewrites its products
+    };
+
+    // Two register sets, A and B, used alternately (the loop is unrolled by two trips by hand: with
+    // a single set copied at the end of each trip the compiler folds the copy away and waits for
+    // the loads it has just issued).  In each half: issue the OTHER set's loads for the window
+    // after this one, then work on this set, whose loads were issued a whole trip ago.
+    RawV aA[XLW_U], aB[XLW_U];
+    int cA[XLW_U], cB[XLW_U];
+#pragma unroll
+    for (int j = 0; j < XLW_U; ++j) {
+        aA[j] = aB[j] = 0;
+        cA[j] = cB[j] = 0;
+    }
+    OffT qA0 = 0, qA1 = 0, qB0 = 0, qB1 = 0;
+    load_head(d1, aA, cA, qA0, qA1);
+    for (int64_t grp = xr.first; grp < xr.end; grp += 2 * xr.stride) {
+        {
+            slice_for(grp);
+            const RowBlock cur = d1;
+            d1 = d2;
+            d2 = desc(grp + 2 * xr.stride);
+            load_head(d1, aB, cB, qB0, qB1);
+            process(cur, aA, cA, qA0, qA1);
+        }
+        if (grp + xr.stride < xr.end) {  // uniform
+            slice_for(grp + xr.stride);
+            const RowBlock cur = d1;
+            d1 = d2;
+            d2 = desc(grp + 3 * xr.stride);
+            load_head(d1, aA, cA, qA0, qA1);
+            process(cur, aB, cB, qB0, qB1);
+        }
     }
 }
 
