@@ -170,29 +170,27 @@ __global__ __launch_bounds__(XLW_BLOCK, 1) void k_spmv_xlw(
     // Everything a window needs from memory, issued one trip ahead and in the order it is
     // consumed: a wave's loads return IN ORDER, so a load issued after the next window's stream
     // would wait for that stream -- the bounds of this lane's first row therefore travel with it.
+    // UNCONDITIONAL: always the same 2 + 2 * XLW_U loads (clamped indices; an empty window reads
+    // element 0 / row 0 and ignores them).  With loads under `if`s the number outstanding depends
+    // on the path and the compiler must then wait for far more than the previous window's data.
     auto load_head = [&](const RowBlock &q, RawV (&av)[XLW_U], int (&cv)[XLW_U], OffT &qa, OffT &qb) {
         const bool hl = (q.pend - q.plast) >= (long long)XLW_C;
         const int nq = q.r0 < q.r1 ? (int)((hl ? q.plast : q.pend) - q.p0) : 0;
-        if (q.r0 < q.r1) {
-            const int r1q = hl ? q.r1 - 1 : q.r1;
-            const int Gq = lanes_per_row(nq, r1q - q.r0);
-            const int rf = q.r0 + lane / Gq;
-            if (rf < r1q) {
-                qa = rowptr[rf];
-                qb = rowptr[rf + 1];
-            }
-        }
-        if (nq > 0) {
-            const int lastq = nq - 1;
-            const OffT qp = (OffT)q.p0;
+        const int r1q = hl ? q.r1 - 1 : q.r1;
+        const int Gq = lanes_per_row(nq, r1q - q.r0);
+        int rf = q.r0 + lane / Gq;
+        rf = rf < r1q ? rf : (r1q > q.r0 ? r1q - 1 : q.r0);  // clamped: a valid virtual row
+        qa = rowptr[rf];
+        qb = rowptr[rf + 1];
+        const int lastq = nq > 0 ? nq - 1 : 0;
+        const OffT qp = (OffT)q.p0;
 #pragma unroll
-            for (int j = 0; j < XLW_U; ++j) {
-                const int e = lane + j * WAVE;
-                const int ke = e < lastq ? e : lastq;
-                if (V8) av[j] = (RawV)val8[qp + ke];
-                else av[j] = (RawV)val[qp + ke];
-                cv[j] = C16 ? (int)col16[qp + ke] : col[qp + ke];
-            }
+        for (int j = 0; j < XLW_U; ++j) {
+            const int e = lane + j * WAVE;
+            const int ke = e < lastq ? e : lastq;
+            if (V8) av[j] = (RawV)val8[qp + ke];
+            else av[j] = (RawV)val[qp + ke];
+            cv[j] = C16 ? (int)col16[qp + ke] : col[qp + ke];
         }
     };
     RowBlock d1 = desc(xr.first), d2 = desc(xr.first + xr.stride);
