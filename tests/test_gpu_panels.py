@@ -149,3 +149,32 @@ def test_lds_resident_panels_match_oracle(forced_xlds, shape):
         s.set_option("pipeline", pipeline)
         r3 = s.solve(p.b, 1e-3)
         assert np.array_equal(r.x, r3.x) and r.anorm == r3.anorm      # every schedule, same bits
+
+
+@pytest.mark.parametrize("off64", ["0", "1"])
+def test_lds_panels_with_dictionary_values_and_64bit_row_pointers(forced_xlds, off64):
+    """The LDS-panel kernel's other template variants: one-byte dictionary values (V8) and 64-bit
+    row pointers (what BASELINE config 3 uses at its literal 4e9 nonzeros)."""
+    os.environ["LSQRHIP_OFF64"] = off64
+    try:
+        p = P.random_rows(4000, 9000, 40, seed=12, damp=1e-3)
+        vals = np.array([0.5, -1.0, 2.0, 0.25, -0.125, 3.0, -0.0])
+        a = vals[(P.rng_u64(3, 5, np.arange(p.a.size, dtype=np.uint64)) % np.uint64(vals.size)).astype(np.int64)]
+        s = lsqr_solver_ez().initialize(p.m, p.n, a, p.irow, p.icol, itnlim=10)
+        info = s.info()
+        assert info["xlds"] == 2 and info["xlds_t"] == 2 and info["dict_entries"] == vals.size
+        assert info["rowptr_bytes"] == (8 if off64 == "1" else 4) and info["col_bytes"] == 2
+        po = oracle.port()
+        xp = P.u64_to_unit(P.rng_u64(101, 9, np.arange(p.n, dtype=np.uint64)))
+        yp = P.u64_to_unit(P.rng_u64(102, 9, np.arange(p.m, dtype=np.uint64)))
+        for mode in (1, 2):
+            x, y = xp.copy(), yp.copy()
+            s.aprod(mode, p.m, p.n, x, y)
+            xr, yr = po.aprod(mode, p.m, p.n, p.irow, p.icol, a, xp, yp)
+            assert np.max(np.abs(x - xr)) <= 1e-13 * max(np.max(np.abs(xr)), 1.0)
+            assert np.max(np.abs(y - yr)) <= 1e-13 * max(np.max(np.abs(yr)), 1.0)
+        r = s.solve(p.b, 1e-3)
+        o = po.solve(p.m, p.n, p.irow, p.icol, a, p.b, damp=1e-3, itnlim=10)
+        assert (r.istop, r.itn) == (o.istop, o.itn) and np.linalg.norm(r.x - o.x) <= 1e-10 * np.linalg.norm(o.x)
+    finally:
+        os.environ.pop("LSQRHIP_OFF64", None)
