@@ -72,3 +72,33 @@ def test_scale_properties_on_100M_nonzero_random_system():
     s.aprod(1, dp.m, dp.n, xa, ya)
     s.aprod(1, dp.m, dp.n, 3.0 * xa, y2)
     assert np.max(np.abs(y2 - 3.0 * ya)) <= 1e-13 * np.max(np.abs(y2))
+
+
+def test_scale_properties_beyond_2_to_31_nonzeros_with_lds_panels():
+    """4M x 1M with 600 per row = 2.4e9 nonzeros (> 2^31: 64-bit row pointers at real scale; LDS
+    column panels chosen automatically): BASELINE config 3's shape at 60 % of its literal size, so
+    that the test needs ~140 GB of HBM and a few seconds.  Size-independent checks: acheck's adjoint
+    identity, xcheck on the solution of the damped problem, determinism."""
+    import torch
+    from lsqr_amd.capi import DeviceBuffer
+    free, total = torch.cuda.mem_get_info()
+    if free < 180e9:
+        pytest.skip("needs ~140 GB of free HBM")
+    spec = "random:4000000:1000000:600"
+    dp = devgen.generate(spec, atol=1e-9, btol=1e-9, itnlim=60)
+    s = dp.solver
+    info = s.info()
+    assert dp.nnz == 2_400_000_000 and info["rowptr_bytes"] == 8
+    assert info["xlds"] == 2 and info["xlds_t"] == 2 and info["col_bytes"] == 2
+    inform, err = s.acheck()
+    assert inform == 0 and err < 1e-12
+    d_x = DeviceBuffer(8 * dp.n)
+    r = s.solve_device(dp.d_b.ptr.value, d_x.ptr.value, 1e-3)
+    x = d_x.to_array(np.float64, dp.n)
+    b = dp.d_b.to_array(np.float64, dp.m)
+    assert r.istop == 3 and 3 < r.itn < 60
+    inform, tests, u, v, w = s.xcheck(r.anorm, 1e-3, b, x)
+    assert inform in (1, 2, 3) and tests[2] < 1e-7
+    r2 = s.solve_device(dp.d_b.ptr.value, d_x.ptr.value, 1e-3)
+    assert (r2.itn, r2.anorm, r2.rnorm) == (r.itn, r.anorm, r.rnorm)
+    assert np.array_equal(d_x.to_array(np.float64, dp.n), x)
