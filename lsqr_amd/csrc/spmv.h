@@ -34,9 +34,11 @@
 //             the mode-1 partials, with no scalar kernel on the critical path between them.
 //             Workgroup 0 publishes (nrm, 1/nrm) in slot_out for the next kernel's sy.
 //
-// Measured at config 2 (88 MB per launch): ~17 us = 5.2 TB/s.  Ablation (gather, LDS
-// reduce and y traffic removed) still needs 15.6 us for the (val, col) stream alone: the
-// kernel is bound by the memory system, not by its own phases.  Sweeps: window 512 / 1024 /
+// Measured at config 2 (88 MB per launch) with this kernel: ~17 us, 16 us with 16-bit columns,
+// 14 us with the value dictionary -- and ~4.2 us per resident round of windows whatever the
+// bytes: a trip through a window is a chain of dependent phases.  Matrices with
+// short even rows therefore go to the sliced-ELL kernel (sell.h: 10 us), dense scattered rows to
+// the LDS-panel kernel (xl.h); this one serves every other shape.  Sweeps: window 512 / 1024 /
 // 2048 / 4096 -> 23 / 17 / 21 / 31 us; one workgroup per row block instead of a persistent
 // grid: +-2 % on banded, +13 % on power-law rows.
 //
