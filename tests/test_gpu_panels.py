@@ -156,6 +156,7 @@ def test_lds_panels_with_dictionary_values_and_64bit_row_pointers(forced_xlds, o
     """The LDS-panel kernel's other template variants: one-byte dictionary values (V8) and 64-bit
     row pointers (what BASELINE config 3 uses at its literal 4e9 nonzeros)."""
     os.environ["LSQRHIP_OFF64"] = off64
+    saved_val8 = os.environ.pop("LSQRHIP_VAL8", None)      # this test is about the dictionary variant
     try:
         p = P.random_rows(4000, 9000, 40, seed=12, damp=1e-3)
         vals = np.array([0.5, -1.0, 2.0, 0.25, -0.125, 3.0, -0.0])
@@ -178,3 +179,5 @@ def test_lds_panels_with_dictionary_values_and_64bit_row_pointers(forced_xlds, o
         assert (r.istop, r.itn) == (o.istop, o.itn) and np.linalg.norm(r.x - o.x) <= 1e-10 * np.linalg.norm(o.x)
     finally:
         os.environ.pop("LSQRHIP_OFF64", None)
+        if saved_val8 is not None:
+            os.environ["LSQRHIP_VAL8"] = saved_val8
