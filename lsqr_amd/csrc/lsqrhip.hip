@@ -202,6 +202,32 @@ struct lsqrhip_handle_s {
 };
 typedef lsqrhip_handle_s H;
 
+// Device scratch owned by a scope: freed on every exit path (an allocation that fails half way
+// through a build must not strand the buffers before it).
+struct DevScratch {
+    void *p = nullptr;
+    DevScratch() = default;
+    DevScratch(const DevScratch &) = delete;
+    DevScratch &operator=(const DevScratch &) = delete;
+    ~DevScratch()
+    {
+        if (p) (void)hipFree(p);
+    }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes > 0 ? bytes : 1); }
+    template <typename T>
+    T *as() const
+    {
+        return static_cast<T *>(p);
+    }
+    template <typename T>
+    T *release()  // ownership moves to the caller
+    {
+        T *q = static_cast<T *>(p);
+        p = nullptr;
+        return q;
+    }
+};
+
 static int env_int(const char *name, int dflt)
 {
     const char *v = std::getenv(name);
@@ -301,8 +327,9 @@ static int try_sell(hipStream_t s, Csr &out, int64_t nnz, const double *dict, in
     if (nnz > 24 * (int64_t)rows) return LSQRHIP_OK;
     const int nslices = (rows + 63) / 64;
     const unsigned gr = (unsigned)(((int64_t)nslices * 64 + 255) / 256);
-    unsigned *soff = nullptr;
-    HIPCHK(hipMalloc((void **)&soff, sizeof(unsigned) * ((size_t)nslices + 1)));
+    DevScratch s_off, s_cb, s_col, s_val, s_len;  // released into `out` only on success
+    HIPCHK(s_off.alloc(sizeof(unsigned) * ((size_t)nslices + 1)));
+    unsigned *soff = s_off.as<unsigned>();
     HIPCHK(hipMemsetAsync(stats, 0, 4 * sizeof(unsigned long long), s));
     HIPCHK(hipMemsetAsync(soff + nslices, 0, sizeof(unsigned), s));
     hipLaunchKernelGGL(k_sell_width, dim3(gr), dim3(256), 0, s, (const int *)out.rowptr, rows, nslices, soff, stats);
@@ -313,30 +340,25 @@ static int try_sell(hipStream_t s, Csr &out, int64_t nnz, const double *dict, in
     const unsigned long long padded = st[0];
     if (st[1] > (unsigned long long)SELL_MAX_W || padded > (unsigned long long)(nnz + nnz / 8 + 4096) ||
         padded >= (1ull << 31)) {
-        (void)hipFree(soff);
         return LSQRHIP_OK;
     }
-    int *cbaseS = nullptr;
-    HIPCHK(hipMalloc((void **)&cbaseS, sizeof(int) * (size_t)nslices));
+    HIPCHK(s_cb.alloc(sizeof(int) * (size_t)nslices));
+    int *cbaseS = s_cb.as<int>();
     hipLaunchKernelGGL(k_sell_colspan, dim3(gr), dim3(256), 0, s, (const int *)out.rowptr, (const int *)out.col, rows,
                        nslices, cbaseS, stats);
     hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, s, soff, (int64_t)nslices + 1);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(st, stats, sizeof(st), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
-    if (st[2] != 0 && mode != 1) {
-        (void)hipFree(soff);
-        (void)hipFree(cbaseS);
-        return LSQRHIP_OK;
-    }
+    if (st[2] != 0 && mode != 1) return LSQRHIP_OK;
     const bool c16 = st[2] == 0 && env_int("LSQRHIP_COL16", 1) != 0;
     const bool v8 = ndict > 0;
     const size_t np = (size_t)std::max<unsigned long long>(padded, 1);
-    void *scol = nullptr, *sval = nullptr;
-    unsigned char *rlen = nullptr;
-    HIPCHK(hipMalloc(&scol, np * (c16 ? 2 : 4)));
-    HIPCHK(hipMalloc(&sval, np * (v8 ? 1 : 8)));
-    HIPCHK(hipMalloc((void **)&rlen, (size_t)rows));
+    HIPCHK(s_col.alloc(np * (c16 ? 2 : 4)));
+    HIPCHK(s_val.alloc(np * (v8 ? 1 : 8)));
+    HIPCHK(s_len.alloc((size_t)rows));
+    void *scol = s_col.p, *sval = s_val.p;
+    unsigned char *rlen = s_len.as<unsigned char>();
     const unsigned long long *db = (const unsigned long long *)dict;
 #define SELL_FILL(C16, V8)                                                                                          \
     hipLaunchKernelGGL((k_sell_fill<C16, V8>), dim3(gr), dim3(256), 0, s, (const int *)out.rowptr,                  \
@@ -354,11 +376,11 @@ static int try_sell(hipStream_t s, Csr &out, int64_t nnz, const double *dict, in
     out.col = nullptr;
     out.val = nullptr;
     out.sell = 1;
-    out.soff = soff;
-    out.scol = scol;
-    out.sval = sval;
-    out.cbaseS = cbaseS;
-    out.rlen = rlen;
+    out.soff = s_off.release<unsigned>();
+    out.scol = s_col.release<void>();
+    out.sval = s_val.release<void>();
+    out.cbaseS = s_cb.release<int>();
+    out.rlen = s_len.release<unsigned char>();
     out.nslices = nslices;
     out.sell_c16 = c16;
     out.sell_v8 = v8;
@@ -653,15 +675,15 @@ static int finish_create(H *h, const int *d_irow, const int *d_icol, const doubl
 {
     hipStream_t s = h->stream;
     const int64_t nnz = h->nnz;
-    unsigned long long *bufA = nullptr, *bufB = nullptr;
-    unsigned *hist = nullptr;
-    int *d_flags = nullptr;
+    DevScratch sA, sB, sH, sF;  // sort buffers, histogram (+ scan block sums), flags
     const int64_t nb = std::max<int64_t>((nnz + RS_TILE - 1) / RS_TILE, 1);
-    HIPCHK(hipMalloc((void **)&bufA, sizeof(unsigned long long) * (size_t)std::max<int64_t>(nnz, 1)));
-    HIPCHK(hipMalloc((void **)&bufB, sizeof(unsigned long long) * (size_t)std::max<int64_t>(nnz, 1)));
-    // histogram + the block sums of its scan (csr_build.h k_scan_*)
-    HIPCHK(hipMalloc((void **)&hist, sizeof(unsigned) * (256 * (size_t)nb + (256 * (size_t)nb) / SCAN_CHUNK + 64)));
-    HIPCHK(hipMalloc((void **)&d_flags, 4 * sizeof(int)));
+    HIPCHK(sA.alloc(sizeof(unsigned long long) * (size_t)std::max<int64_t>(nnz, 1)));
+    HIPCHK(sB.alloc(sizeof(unsigned long long) * (size_t)std::max<int64_t>(nnz, 1)));
+    HIPCHK(sH.alloc(sizeof(unsigned) * (256 * (size_t)nb + (256 * (size_t)nb) / SCAN_CHUNK + 64)));
+    HIPCHK(sF.alloc(4 * sizeof(int)));
+    unsigned long long *bufA = sA.as<unsigned long long>(), *bufB = sB.as<unsigned long long>();
+    unsigned *hist = sH.as<unsigned>();
+    int *d_flags = sF.as<int>();
     // locality of the column pattern (only looked at when a vector exceeds L2; indices that are
     // out of range are caught by the build below, the measure merely becomes meaningless)
     double mean_dev = 0.0;
@@ -674,13 +696,7 @@ static int finish_create(H *h, const int *d_irow, const int *d_icol, const doubl
         HIPCHK(hipStreamSynchronize(s));
         mean_dev = (double)dev / (double)nnz;
     }
-    if (int rcd = build_dictionary(h, d_a, bufA, d_flags)) {
-        (void)hipFree(bufA);
-        (void)hipFree(bufB);
-        (void)hipFree(hist);
-        (void)hipFree(d_flags);
-        return rcd;
-    }
+    RET(build_dictionary(h, d_a, bufA, d_flags));
     int pa = 1, pwa = h->n, pt = 1, pwt = h->m, xa = 0, xt = 0;
     choose_panels(h->m, h->n, nnz, mean_dev, &pa, &pwa, &xa);                         // mode 1 gathers V (n)
     choose_panels(h->n, h->m, nnz, mean_dev * (double)std::max(h->m, 1) / (double)std::max(h->n, 1), &pt, &pwt, &xt);  // mode 2 gathers U (m)
@@ -694,12 +710,7 @@ static int finish_create(H *h, const int *d_irow, const int *d_icol, const doubl
         if (rc == LSQRHIP_OK)
             rc = build_csr_T<int>(s, d_icol, d_irow, d_a, nnz, h->n, h->m, LSQRHIP_ERR_ICOL, LSQRHIP_ERR_IROW, pt, pwt, xt, bufA, bufB, hist, d_flags, h->dict, h->ndict, h->AT);
     }
-    (void)hipFree(bufA);
-    (void)hipFree(bufB);
-    (void)hipFree(hist);
-    (void)hipFree(d_flags);
     RET(rc);
-
     return alloc_workspace(h);
 }
 
@@ -750,22 +761,17 @@ extern "C" int lsqrhip_create(int m, int n, int64_t nnz, const int *irow, const 
     *out = nullptr;
     if (nnz > 0 && (!irow || !icol || !a)) return fail(LSQRHIP_ERR_SIZES, lsqrhip_error_string(LSQRHIP_ERR_SIZES));
     RET(use_device());
-    int *d_irow = nullptr, *d_icol = nullptr;
-    double *d_a = nullptr;
+    DevScratch sr, sc, sa;
     const size_t k = (size_t)std::max<int64_t>(nnz, 1);
-    HIPCHK(hipMalloc((void **)&d_irow, sizeof(int) * k));
-    HIPCHK(hipMalloc((void **)&d_icol, sizeof(int) * k));
-    HIPCHK(hipMalloc((void **)&d_a, sizeof(double) * k));
+    HIPCHK(sr.alloc(sizeof(int) * k));
+    HIPCHK(sc.alloc(sizeof(int) * k));
+    HIPCHK(sa.alloc(sizeof(double) * k));
     if (nnz > 0) {
-        HIPCHK(hipMemcpy(d_irow, irow, sizeof(int) * (size_t)nnz, hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(d_icol, icol, sizeof(int) * (size_t)nnz, hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(d_a, a, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(sr.p, irow, sizeof(int) * (size_t)nnz, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(sc.p, icol, sizeof(int) * (size_t)nnz, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(sa.p, a, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice));
     }
-    int rc = lsqrhip_create_from_device_coo(m, n, nnz, d_irow, d_icol, d_a, out);
-    (void)hipFree(d_irow);
-    (void)hipFree(d_icol);
-    (void)hipFree(d_a);
-    return rc;
+    return lsqrhip_create_from_device_coo(m, n, nnz, sr.as<int>(), sc.as<int>(), sa.as<double>(), out);
 }
 
 extern "C" int lsqrhip_info(lsqrhip_handle_t h, int64_t *dims)
