@@ -251,7 +251,10 @@ __global__ __launch_bounds__(SPMV_BLOCK, XL ? 2 : 8) void k_spmv_fused(
             const LsqrState *ust = upd.st;
             const Rot rt = rot_step(ust->rhobar2[upd.par], ust->phibar2[upd.par], ust->damp, ust->damped, alpha, beta);
             const bool wantse = ust->wantse != 0;
-            for (int ub = wg; ub < upd.ugrid; ub += nwg) {
+            // XCD-contiguous blocks, like the rows below: the slice of V this XCD updates from is
+            // the slice its rows gather from (one trip from beyond L2 instead of two)
+            const XcdRange ur = xcd_range(upd.ugrid, nwg, wg);
+            for (int ub = (int)ur.first; ub < (int)ur.end; ub += (int)ur.stride) {
                 const double tot = update_block(upd.x, upd.w, upd.V, upd.se, upd.n, rt.t1, rt.t2, rt.t3, sv, wantse,
                                                 ub, upd.ugrid, red);
                 if (tid == 0) upd.pout[ub] = tot;
