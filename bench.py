@@ -146,7 +146,9 @@ def run_single(args):
         info = s.info()
         fmt1 = info["csr_bytes"] + 8 * p.n + 16 * p.m
         fmt2 = info["csrt_bytes"] + 8 * p.m + 16 * p.n
-        if info["sell"]:
+        if info["sell"] == 2:
+            layout, kname = "sell, packed 16-byte records", "k_spmv_sellp"
+        elif info["sell"]:
             layout, kname = "sell", "k_spmv_sell"
         elif info["xlds"] == 2:
             layout, kname = "lds-panels (wave windows)", "k_spmv_xlw + k_panel_combine"

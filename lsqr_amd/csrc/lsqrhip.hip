@@ -128,8 +128,9 @@ struct Csr {
     unsigned char *val8 = nullptr;   // one-byte codes into dict (valdict.h) ...
     const double *dict = nullptr;    // ... the handle's dictionary (not owned)
     // sliced-ELL layout (sell.h), used instead of the arrays above when `sell` is set
-    int sell = 0;
-    unsigned *soff = nullptr;        // [nslices+1] first element of each 64-row slice
+    int sell = 0;                    // 1 = column-major slices, 2 = packed 16-byte records (sell.h)
+    unsigned *soff = nullptr;        // [nslices+1] first element (sell = 2: first record) of each 64-row slice
+    uint4 *srec = nullptr;           // sell = 2: records (5 columns, 5 value codes, row length)
     void *scol = nullptr;            // column-major columns (u16 relative to cbaseS, or i32)
     void *sval = nullptr;            // column-major values (u8 dictionary codes, or f64)
     int *cbaseS = nullptr;           // [nslices] smallest column of each slice
@@ -251,6 +252,7 @@ static void free_csr(Csr &c)
     if (c.val) (void)hipFree(c.val);
     if (c.val8) (void)hipFree(c.val8);
     if (c.soff) (void)hipFree(c.soff);
+    if (c.srec) (void)hipFree(c.srec);
     if (c.scol) (void)hipFree(c.scol);
     if (c.sval) (void)hipFree(c.sval);
     if (c.cbaseS) (void)hipFree(c.cbaseS);
@@ -316,6 +318,11 @@ static int bits_for(int limit)
 
 // Sliced-ELL layout for short, even rows (sell.h).  On success out.sell = 1 and the CSR arrays
 // col / val are released; otherwise `out` is left as it was.  `stats` is scratch of >= 4 words.
+static void launch_scan_small(hipStream_t s, unsigned *a, int64_t L)
+{
+    hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, s, a, L);
+}
+
 static int try_sell(hipStream_t s, Csr &out, int64_t nnz, const double *dict, int ndict, unsigned long long *stats)
 {
     const int rows = out.rows;
@@ -346,13 +353,46 @@ static int try_sell(hipStream_t s, Csr &out, int64_t nnz, const double *dict, in
     int *cbaseS = s_cb.as<int>();
     hipLaunchKernelGGL(k_sell_colspan, dim3(gr), dim3(256), 0, s, (const int *)out.rowptr, (const int *)out.col, rows,
                        nslices, cbaseS, stats);
-    hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, s, soff, (int64_t)nslices + 1);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(st, stats, sizeof(st), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     if (st[2] != 0 && mode != 1) return LSQRHIP_OK;
     const bool c16 = st[2] == 0 && env_int("LSQRHIP_COL16", 1) != 0;
     const bool v8 = ndict > 0;
+    // 3-byte nonzeros: packed 16-byte records when they cost <= 10 % more than the slices (sell.h)
+    const int pmode = env_int("LSQRHIP_SELLP", -1);
+    const unsigned long long nrec = st[3];
+    const bool packed = c16 && v8 && pmode != 0 && nrec < (1ull << 31) &&
+                        (pmode == 1 || 10 * 16 * nrec <= 11 * (3 * padded + (unsigned long long)rows));
+    if (packed) {
+        hipLaunchKernelGGL(k_sellp_chunks, dim3((unsigned)((nslices + 255) / 256)), dim3(256), 0, s, soff, nslices);
+        launch_scan_small(s, soff, (int64_t)nslices + 1);
+        HIPCHK(hipGetLastError());
+        DevScratch s_rec;
+        HIPCHK(s_rec.alloc(sizeof(uint4) * (size_t)std::max<unsigned long long>(nrec, 1)));
+        hipLaunchKernelGGL(k_sellp_fill, dim3(gr), dim3(256), 0, s, (const int *)out.rowptr, (const int *)out.col,
+                           (const double *)out.val, (const unsigned *)soff, (const int *)cbaseS,
+                           (const unsigned long long *)dict, ndict, rows, nslices, s_rec.as<uint4>());
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(s));
+        (void)hipFree(out.col);
+        (void)hipFree(out.val);
+        out.col = nullptr;
+        out.val = nullptr;
+        out.sell = 2;
+        out.soff = s_off.release<unsigned>();
+        out.srec = s_rec.release<uint4>();
+        out.cbaseS = s_cb.release<int>();
+        out.nslices = nslices;
+        out.sell_c16 = true;
+        out.sell_v8 = true;
+        out.dict = dict;
+        out.nblk = (nslices + SELL_SLICES - 1) / SELL_SLICES;
+        out.bytes = (int64_t)nrec * 16 + (int64_t)nslices * 8 + 4;
+        return LSQRHIP_OK;
+    }
+    launch_scan_small(s, soff, (int64_t)nslices + 1);
+    HIPCHK(hipGetLastError());
     const size_t np = (size_t)std::max<unsigned long long>(padded, 1);
     HIPCHK(s_col.alloc(np * (c16 ? 2 : 4)));
     HIPCHK(s_val.alloc(np * (v8 ? 1 : 8)));

@@ -43,8 +43,10 @@ namespace lsqrhip {
 constexpr int SELL_BLOCK = 256;                 // 4 slices per workgroup trip
 constexpr int SELL_SLICES = SELL_BLOCK / WAVE;
 constexpr int SELL_MAX_W = 64;
+constexpr int SELLP_K = 5;                      // nonzeros per 16-byte record of the packed layout
 
-// width64[s] = 64 * W_s (elements of slice s); stats[0] += 64 W_s, stats[1] = max W.
+// width64[s] = 64 * W_s (elements of slice s); stats[0] += 64 W_s, stats[1] = max W,
+// stats[3] += 64 * ceil(W_s / 5) (records of the packed layout below).
 __global__ __launch_bounds__(256) void k_sell_width(const int *__restrict__ rowptr, int rows, int nslices,
                                                     unsigned *__restrict__ width64,
                                                     unsigned long long *__restrict__ stats)
@@ -59,7 +61,15 @@ __global__ __launch_bounds__(256) void k_sell_width(const int *__restrict__ rowp
         width64[s] = (unsigned)len * 64u;
         atomicAdd(&stats[0], (unsigned long long)len * 64ull);
         atomicMax(&stats[1], (unsigned long long)len);
+        atomicAdd(&stats[3], (unsigned long long)((len + SELLP_K - 1) / SELLP_K) * 64ull);
     }
+}
+
+// width64[s] (64 W_s) -> 64 * ceil(W_s / 5): records of slice s in the packed layout
+__global__ __launch_bounds__(256) void k_sellp_chunks(unsigned *__restrict__ width64, int nslices)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < nslices) width64[s] = (((width64[s] >> 6) + SELLP_K - 1) / SELLP_K) * 64u;
 }
 
 // cbaseS[s] = smallest column of slice s (0 if empty); stats[2] |= 1 if a slice spans >= 65536 columns.
@@ -179,6 +189,64 @@ __device__ __forceinline__ double sell_chunk(double sum, size_t e, int k0, int l
 
 static_assert(SELL_BLOCK == VEC_BLOCK, "the fused update runs k_update's blocks");
 
+struct SellCoef {
+    double sx, sy, cy;
+};
+
+// What every workgroup of a sliced-ELL product does before its rows: the lazy coefficients from
+// the previous kernel's partial sums (spmv.h) and, with UPD, its share of the x/w update of the
+// previous iteration (vec.h UpdArgs).  false = this product is skipped.
+template <bool UPD>
+__device__ __forceinline__ bool sell_prologue(const SpmvCoef *__restrict__ coef, const double *__restrict__ pin, int npin,
+                                              const NormSlot *__restrict__ slot_in, NormSlot *__restrict__ slot_out,
+                                              int skip_if_zero, const UpdArgs &upd, int nwg, int wg, double *red,
+                                              SellCoef &k)
+{
+    const int tid = threadIdx.x;
+    if (pin != nullptr) {  // lazy coefficients (spmv.h)
+        const double nrm = sqrt(block_sum_all<SELL_BLOCK>(pin, npin, red));
+        if (skip_if_zero && !(nrm > 0.0)) {  // mode 2 is skipped when beta == 0 (:691)
+            if (wg == 0 && tid == 0) {
+                slot_out->nrm = nrm;
+                slot_out->scale = 1.0;
+            }
+            return false;
+        }
+        k.sx = nrm > 0.0 ? 1.0 / nrm : 1.0;
+        k.cy = -nrm;
+        k.sy = slot_in->scale;
+        if (wg == 0 && tid == 0) {
+            slot_out->nrm = nrm;
+            slot_out->scale = k.sx;
+        }
+        if (UPD && upd.on) {  // x/w update of the previous iteration (vec.h UpdArgs)
+            const double beta = slot_in->nrm;
+            double alpha = nrm, sv = k.sx;
+            if (!(beta > 0.0)) {  // mode 2 was skipped (src/lsqr.f90:691): alpha, v unchanged
+                alpha = upd.alpha_prev->nrm;
+                sv = upd.alpha_prev->scale;
+            }
+            const LsqrState *ust = upd.st;
+            const Rot rt = rot_step(ust->rhobar2[upd.par], ust->phibar2[upd.par], ust->damp, ust->damped, alpha, beta);
+            const bool wantse = ust->wantse != 0;
+            // XCD-contiguous blocks, like the rows below: the slice of V this XCD updates from is
+            // the slice its rows gather from (one trip from beyond L2 instead of two)
+            const XcdRange ur = xcd_range(upd.ugrid, nwg, wg);
+            for (int ub = (int)ur.first; ub < (int)ur.end; ub += (int)ur.stride) {
+                const double tot = update_block(upd.x, upd.w, upd.V, upd.se, upd.n, rt.t1, rt.t2, rt.t3, sv, wantse,
+                                                ub, upd.ugrid, red);
+                if (tid == 0) upd.pout[ub] = tot;
+            }
+        }
+        return true;
+    }
+    if (coef->skip != 0) return false;
+    k.sx = coef->sx;
+    k.sy = coef->sy;
+    k.cy = coef->cy;
+    return true;
+}
+
 // UPD = true: the launch also carries the x/w update of the previous iteration (UpdArgs).
 template <bool C16, bool V8, bool UPD>
 __global__ __launch_bounds__(SELL_BLOCK, 8) void k_spmv_sell(
@@ -203,60 +271,22 @@ __global__ __launch_bounds__(SELL_BLOCK, 8) void k_spmv_sell(
     const int tid = threadIdx.x;
     if (V8) sdict[tid] = dict[tid];  // visible after the first barrier below
 
-    double sx, sy, cy;
-    if (pin != nullptr) {  // lazy coefficients (spmv.h)
-        const double nrm = sqrt(block_sum_all<SELL_BLOCK>(pin, npin, red));
-        if (skip_if_zero && !(nrm > 0.0)) {  // mode 2 is skipped when beta == 0 (:691)
-            if (wg == 0 && tid == 0) {
-                slot_out->nrm = nrm;
-                slot_out->scale = 1.0;
-            }
-            return;
-        }
-        sx = nrm > 0.0 ? 1.0 / nrm : 1.0;
-        cy = -nrm;
-        sy = slot_in->scale;
-        if (wg == 0 && tid == 0) {
-            slot_out->nrm = nrm;
-            slot_out->scale = sx;
-        }
-        if (UPD && upd.on) {  // x/w update of the previous iteration (vec.h UpdArgs)
-            const double beta = slot_in->nrm;
-            double alpha = nrm, sv = sx;
-            if (!(beta > 0.0)) {  // mode 2 was skipped (src/lsqr.f90:691): alpha, v unchanged
-                alpha = upd.alpha_prev->nrm;
-                sv = upd.alpha_prev->scale;
-            }
-            const LsqrState *ust = upd.st;
-            const Rot rt = rot_step(ust->rhobar2[upd.par], ust->phibar2[upd.par], ust->damp, ust->damped, alpha, beta);
-            const bool wantse = ust->wantse != 0;
-            // XCD-contiguous blocks, like the rows below: the slice of V this XCD updates from is
-            // the slice its rows gather from (one trip from beyond L2 instead of two)
-            const XcdRange ur = xcd_range(upd.ugrid, nwg, wg);
-            for (int ub = (int)ur.first; ub < (int)ur.end; ub += (int)ur.stride) {
-                const double tot = update_block(upd.x, upd.w, upd.V, upd.se, upd.n, rt.t1, rt.t2, rt.t3, sv, wantse,
-                                                ub, upd.ugrid, red);
-                if (tid == 0) upd.pout[ub] = tot;
-            }
-        }
-    } else {
-        if (coef->skip != 0) return;
-        sx = coef->sx;
-        sy = coef->sy;
-        cy = coef->cy;
-    }
+    SellCoef kc;
+    if (!sell_prologue<UPD>(coef, pin, npin, slot_in, slot_out, skip_if_zero, upd, nwg, wg, red, kc)) return;
+    const double sx = kc.sx, sy = kc.sy, cy = kc.cy;
     if (V8) __syncthreads();
 
     const int *__restrict__ sc32 = static_cast<const int *>(scolv);
     const unsigned short *__restrict__ sc16 = static_cast<const unsigned short *>(scolv);
     const double *__restrict__ sv = static_cast<const double *>(svalv);
     const unsigned char *__restrict__ sv8 = static_cast<const unsigned char *>(svalv);
-    const int lane = tid & (WAVE - 1), wave = tid >> 6;
+    const int lane = tid & (WAVE - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: slice descriptors through the scalar cache
 
     double sq = 0.0;
     const XcdRange xr = xcd_range(nblk, nwg, wg);
     for (int64_t b = xr.first; b < xr.end; b += xr.stride) {
-        const int s = (int)(b * SELL_SLICES) + wave;  // wave-uniform
+        const int s = (int)(b * SELL_SLICES) + wave;
         if (s >= nslices) continue;
         const unsigned o0 = (unsigned)__builtin_amdgcn_readfirstlane((int)soff[s]);
         const unsigned o1 = (unsigned)__builtin_amdgcn_readfirstlane((int)soff[s + 1]);
@@ -281,6 +311,157 @@ __global__ __launch_bounds__(SELL_BLOCK, 8) void k_spmv_sell(
         case 2: sum = sell_chunk<2, C16, V8>(sum, e, k0, len, cb, sc32, sc16, sv, sv8, sdict, x, sx); break;
         case 1: sum = sell_chunk<1, C16, V8>(sum, e, k0, len, cb, sc32, sc16, sv, sv8, sdict, x, sx); break;
         default: break;
+        }
+        if (active) {
+            const double yn = cy * (y0 * sy) + sum;
+            y[r] = yn;
+            sq += yn * yn;
+        }
+    }
+    const double tot = block_sum<SELL_BLOCK>(sq, red);
+    if (tid == 0) partials[wg] = tot;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Packed records (sell = 2).  With 16-bit columns AND one-byte value codes a nonzero is 3 bytes,
+// and the product above spends its time issuing loads, not moving bytes: per 64-row slice of a
+// 5-point stencil 5 two-byte and 5 one-byte loads + the row lengths, each a wave instruction that
+// fetches 64-128 B.  Here the same bytes come as ONE 16-byte load per lane:
+//
+//     record = 5 x u16 column (relative to the slice's smallest)  |  5 x u8 value code  |  u8 row length
+//
+// chunk j of slice s holds nonzeros 5j .. 5j+4 of its 64 rows: rec[roff[s] + 64 j + lane]; the row
+// length is repeated in every chunk, rows of W nonzeros take ceil(W/5) records.  At config 2
+// (W = 5) that is byte for byte the size of the unpacked layout; the product drops from 9.1 to
+// 7.3 us (scripts/sell_roof.hip: 4.4 -> 5.5 TB/s, a pure stream of the same bytes takes 5.8).
+// Chosen when the records cost <= 10 % more bytes than the unpacked slices (LSQRHIP_SELLP=0 never,
+// =1 whenever columns and values qualify).  The sums are the same left-to-right sums.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_sellp_fill(const int *__restrict__ rowptr, const int *__restrict__ col,
+                                                    const double *__restrict__ val, const unsigned *__restrict__ roff,
+                                                    const int *__restrict__ cbaseS,
+                                                    const unsigned long long *__restrict__ dict_bits, int nd, int rows,
+                                                    int nslices, uint4 *__restrict__ rec)
+{
+    __shared__ unsigned long long tab[VD_MAX];
+    if ((int)threadIdx.x < nd) tab[threadIdx.x] = dict_bits[threadIdx.x];
+    __syncthreads();
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int s = (int)(r >> 6), lane = (int)(r & 63);
+    if (s >= nslices) return;
+    const unsigned o0 = roff[s];
+    const int nch = (int)((roff[s + 1] - o0) >> 6);
+    const int cb = cbaseS[s];
+    int q0 = 0, len = 0;
+    if (r < rows) {
+        q0 = rowptr[r];
+        len = rowptr[r + 1] - q0;
+    }
+    for (int j = 0; j < nch; ++j) {
+        unsigned c[SELLP_K], code[SELLP_K];
+#pragma unroll
+        for (int t = 0; t < SELLP_K; ++t) {
+            const int k = SELLP_K * j + t;
+            c[t] = 0;
+            code[t] = 0;
+            if (k < len) {
+                c[t] = (unsigned)(col[q0 + k] - cb);
+                const unsigned long long bits = (unsigned long long)__double_as_longlong(val[q0 + k]);
+                int lo = 0, hi = nd - 1;
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (tab[mid] < bits) lo = mid + 1;
+                    else hi = mid;
+                }
+                code[t] = (unsigned)lo;
+            }
+        }
+        uint4 q;
+        q.x = c[0] | (c[1] << 16);
+        q.y = c[2] | (c[3] << 16);
+        q.z = c[4] | (code[0] << 16) | (code[1] << 24);
+        q.w = code[2] | (code[3] << 8) | (code[4] << 16) | ((unsigned)len << 24);
+        rec[(size_t)o0 + (size_t)j * 64 + lane] = q;
+    }
+}
+
+// the 5 products of one record, added left to right where they exist (k0 = index of its first nonzero)
+__device__ __forceinline__ double sellp_add(double sum, const uint4 q, int k0, int cb, const double *sdict,
+                                            const double *__restrict__ x, double sx)
+{
+    int c[SELLP_K], code[SELLP_K];
+    c[0] = cb + (int)(q.x & 0xffffu);
+    c[1] = cb + (int)(q.x >> 16);
+    c[2] = cb + (int)(q.y & 0xffffu);
+    c[3] = cb + (int)(q.y >> 16);
+    c[4] = cb + (int)(q.z & 0xffffu);
+    code[0] = (int)((q.z >> 16) & 0xffu);
+    code[1] = (int)(q.z >> 24);
+    code[2] = (int)(q.w & 0xffu);
+    code[3] = (int)((q.w >> 8) & 0xffu);
+    code[4] = (int)((q.w >> 16) & 0xffu);
+    const int len = (int)(q.w >> 24);
+    double xv[SELLP_K];
+#pragma unroll
+    for (int t = 0; t < SELLP_K; ++t) xv[t] = x[c[t]];
+#pragma unroll
+    for (int t = 0; t < SELLP_K; ++t) {
+        const double p = sdict[code[t]] * (xv[t] * sx);
+        if (k0 + t < len) sum = sum + p;
+    }
+    return sum;
+}
+
+template <bool UPD>
+__global__ __launch_bounds__(SELL_BLOCK, 8) void k_spmv_sellp(
+    const unsigned *__restrict__ roff, const uint4 *__restrict__ rec, const int *__restrict__ cbaseS,
+    const double *__restrict__ dict, int rows, int nslices, int64_t nblk, const double *__restrict__ x,
+    double *__restrict__ y, const SpmvCoef *__restrict__ coef, const int *__restrict__ stop,
+    double *__restrict__ partials, const double *__restrict__ pin, int npin, const NormSlot *__restrict__ slot_in,
+    NormSlot *__restrict__ slot_out, int skip_if_zero, Rider rider, UpdArgs upd)
+{
+    __shared__ double red[SELL_BLOCK / WAVE + 1];
+    __shared__ double sdict[VD_MAX];
+    const int shift = rider.kind != 0 ? 1 : 0;
+    const int nwg = (int)gridDim.x - shift;
+    const int wg = (int)blockIdx.x - shift;
+    if (wg < 0) {
+        run_rider(rider, red);
+        return;
+    }
+    if (*stop != 0) return;
+    const int tid = threadIdx.x;
+    sdict[tid] = dict[tid];  // visible after the barrier below
+
+    SellCoef kc;
+    if (!sell_prologue<UPD>(coef, pin, npin, slot_in, slot_out, skip_if_zero, upd, nwg, wg, red, kc)) return;
+    const double sx = kc.sx, sy = kc.sy, cy = kc.cy;
+    __syncthreads();
+
+    const int lane = tid & (WAVE - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: the slice descriptors arrive in SGPRs
+    double sq = 0.0;
+    const XcdRange xr = xcd_range(nblk, nwg, wg);
+    for (int64_t b = xr.first; b < xr.end; b += xr.stride) {
+        const int s = (int)(b * SELL_SLICES) + wave;
+        if (s >= nslices) continue;
+        const unsigned o0 = roff[s];
+        const int nch = (int)((roff[s + 1] - o0) >> 6);
+        const int cb = cbaseS[s];
+        const int r = s * WAVE + lane;
+        const bool active = r < rows;
+        const double y0 = y[active ? r : rows - 1];
+        const uint4 *__restrict__ p = rec + (size_t)o0 + lane;
+        double sum = 0.0;
+        if (nch == 1) {
+            sum = sellp_add(sum, p[0], 0, cb, sdict, x, sx);
+        } else {
+            for (int j = 0; j < nch; j += 2) {  // two records in flight; the second one clamped, not branched on
+                const uint4 qa = p[(size_t)j * 64];
+                const uint4 qb = p[(size_t)min(j + 1, nch - 1) * 64];
+                sum = sellp_add(sum, qa, SELLP_K * j, cb, sdict, x, sx);
+                if (j + 1 < nch) sum = sellp_add(sum, qb, SELLP_K * (j + 1), cb, sdict, x, sx);
+            }
         }
         if (active) {
             const double yn = cy * (y0 * sy) + sum;

@@ -131,6 +131,23 @@ static void launch_sell_C(const SpmvArgs &a)
                               a.slot_out, a.skip_if_zero, a.rider, a.upd);
 }
 
+template <bool UPD>
+static void launch_sellp(const SpmvArgs &a)
+{
+    const Csr &c = *a.c;
+    const dim3 grid(c.grid + (a.rider.kind != 0 ? 1 : 0));
+    if (a.e0 == nullptr && a.e1 == nullptr)
+        hipLaunchKernelGGL((k_spmv_sellp<UPD>), grid, dim3(SELL_BLOCK), 0, a.stream, (const unsigned *)c.soff,
+                           (const uint4 *)c.srec, (const int *)c.cbaseS, (const double *)c.dict, c.rows, c.nslices,
+                           c.nblk, a.x, a.y, a.coef, a.stop, a.pout, a.pin, a.npin, a.slot_in, a.slot_out,
+                           a.skip_if_zero, a.rider, a.upd);
+    else
+        hipExtLaunchKernelGGL((k_spmv_sellp<UPD>), grid, dim3(SELL_BLOCK), 0, a.stream, a.e0, a.e1, 0,
+                              (const unsigned *)c.soff, (const uint4 *)c.srec, (const int *)c.cbaseS,
+                              (const double *)c.dict, c.rows, c.nslices, c.nblk, a.x, a.y, a.coef, a.stop, a.pout,
+                              a.pin, a.npin, a.slot_in, a.slot_out, a.skip_if_zero, a.rider, a.upd);
+}
+
 template <typename OffT, bool V8, bool C16>
 static void launch_xl_C(const SpmvArgs &a, double *z)
 {
@@ -159,6 +176,11 @@ static void launch_xl(const SpmvArgs &a, double *z)
 static void launch_spmv_args(H *h, const SpmvArgs &a)
 {
     const Csr &c = *a.c;
+    if (c.sell == 2) {  // sliced ELL, packed records (sell.h)
+        if (a.upd.on) launch_sellp<true>(a);
+        else launch_sellp<false>(a);
+        return;
+    }
     if (c.sell) {  // sliced-ELL layout (sell.h)
         const int key = (c.sell_c16 ? 4 : 0) | (c.sell_v8 ? 2 : 0) | (a.upd.on ? 1 : 0);
         switch (key) {

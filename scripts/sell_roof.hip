@@ -1,0 +1,356 @@
+// sell_roof.hip -- what limits the sliced-ELL product at config 2 (5-point Poisson, 1-byte value
+// codes, 16-bit slice-relative columns), and what would a packed-record layout buy?
+//
+// The product moves 40 B per row (15 B of matrix + 1 B row length + x + y read and written); a
+// pure streaming kernel moves 40 MB in ~5 us on this chip (scripts/grid_barrier.hip, data in the
+// Infinity Cache) while k_spmv_sell takes ~10 us.  Variants, all computing the same
+// y <- cy*(y*sy) + A (x*sx) and the same per-workgroup sum of squares, no lazy-norm prologue:
+//   A  the layout of csrc/sell.h: per k one 2-byte column load and one 1-byte code load per lane,
+//      descriptors (slice offset, column base) fetched with vector loads
+//   B  A with the wave index made scalar: descriptors arrive through the scalar cache
+//   C  packed records: one 16-byte load per row = 5 columns (u16) + 5 codes (u8) + length (u8)
+//   D  C with two slices per wave in flight
+//   S  stream only: 16 B record + y + x[row] (no gather), y written
+// on nx x ny = 1000^2 and 2000^2, persistent grid of 2048 workgroups (XCD-contiguous) or one
+// workgroup per 4 slices.
+//
+//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off scripts/sell_roof.hip -o scripts/_bin/sell_roof
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+
+#define CK(e)                                                                          \
+    do {                                                                               \
+        hipError_t _e = (e);                                                           \
+        if (_e != hipSuccess) {                                                        \
+            std::fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(_e)); \
+            std::exit(1);                                                              \
+        }                                                                              \
+    } while (0)
+
+constexpr int W = 5;
+
+struct Mat {
+    int rows, nslices;
+    unsigned *soff;         // nslices + 1
+    int *cbase;             // nslices
+    unsigned short *sc16;   // 64 W per slice, column-major
+    unsigned char *sv8, *rlen;
+    uint4 *rec;             // rows (padded to slices)
+    double *dict;           // 256
+};
+
+__global__ void k_build(Mat m, int nx, int ny)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    const int s = r >> 6, lane = r & 63;
+    if (s >= m.nslices) return;
+    const int r0 = s * 64;
+    const int cb = max(0, r0 - nx);
+    if (lane == 0) {
+        m.soff[s] = (unsigned)s * 64u * W;
+        if (s == m.nslices - 1) m.soff[s + 1] = (unsigned)(s + 1) * 64u * W;
+        m.cbase[s] = cb;
+    }
+    int c[W], code[W], len = 0;
+    if (r < m.rows) {
+        const int i = r % nx, j = r / nx;
+        if (j > 0) { c[len] = r - nx; code[len++] = 1; }
+        if (i > 0) { c[len] = r - 1; code[len++] = 1; }
+        c[len] = r; code[len++] = 0;
+        if (i < nx - 1) { c[len] = r + 1; code[len++] = 1; }
+        if (j < ny - 1) { c[len] = r + nx; code[len++] = 1; }
+    }
+    for (int k = len; k < W; ++k) { c[k] = cb; code[k] = 0; }
+    for (int k = 0; k < W; ++k) {
+        m.sc16[(size_t)s * 64 * W + 64 * k + lane] = (unsigned short)(c[k] - cb);
+        m.sv8[(size_t)s * 64 * W + 64 * k + lane] = (unsigned char)code[k];
+    }
+    if (r < m.rows) m.rlen[r] = (unsigned char)len;
+    uint4 q;
+    q.x = (unsigned)(c[0] - cb) | ((unsigned)(c[1] - cb) << 16);
+    q.y = (unsigned)(c[2] - cb) | ((unsigned)(c[3] - cb) << 16);
+    q.z = (unsigned)(c[4] - cb) | ((unsigned)code[0] << 16) | ((unsigned)code[1] << 24);
+    q.w = (unsigned)code[2] | ((unsigned)code[3] << 8) | ((unsigned)code[4] << 16) | ((unsigned)len << 24);
+    m.rec[r] = q;
+}
+
+struct Range {
+    int first, end, stride;
+};
+__device__ __forceinline__ Range xcd_range(int nitems, int g, int wg)
+{
+    Range r;
+    const int xcd = wg & 7, slot = wg >> 3;
+    const int per = (nitems + 7) >> 3;
+    r.first = xcd * per + slot;
+    r.end = min((xcd + 1) * per, nitems);
+    r.stride = g >> 3;
+    return r;
+}
+
+__device__ __forceinline__ double block_sum(double v, double *red)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+// VAR 0 = A, 1 = B
+template <int VAR>
+__global__ __launch_bounds__(256, 8) void k_cur(Mat m, const double *__restrict__ x, double *__restrict__ y, double sx,
+                                                double sy, double cy, double *__restrict__ partials, int nblk, int persistent)
+{
+    __shared__ double red[4];
+    __shared__ double sdict[256];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = VAR == 1 ? __builtin_amdgcn_readfirstlane(tid >> 6) : (tid >> 6);
+    sdict[tid] = m.dict[tid];
+    __syncthreads();
+    double sq = 0.0;
+    Range xr = persistent ? xcd_range(nblk, gridDim.x, blockIdx.x) : Range{(int)blockIdx.x, nblk, (int)gridDim.x};
+    for (int b = xr.first; b < xr.end; b += xr.stride) {
+        const int s = b * 4 + wave;
+        if (s >= m.nslices) continue;
+        unsigned o0, o1;
+        int cb;
+        if (VAR == 1) {
+            o0 = m.soff[s];
+            o1 = m.soff[s + 1];
+            cb = m.cbase[s];
+        } else {
+            o0 = (unsigned)__builtin_amdgcn_readfirstlane((int)m.soff[s]);
+            o1 = (unsigned)__builtin_amdgcn_readfirstlane((int)m.soff[s + 1]);
+            cb = __builtin_amdgcn_readfirstlane(m.cbase[s]);
+        }
+        const int Ws = (int)((o1 - o0) >> 6);
+        const int r = s * 64 + lane;
+        const bool active = r < m.rows;
+        const int rc = active ? r : m.rows - 1;
+        const int len = active ? (int)m.rlen[rc] : 0;
+        const double y0 = y[rc];
+        double sum = 0.0;
+        if (Ws == W) {
+            int c[W], code[W];
+            double xv[W];
+#pragma unroll
+            for (int k = 0; k < W; ++k) {
+                c[k] = cb + (int)m.sc16[(size_t)o0 + 64 * k + lane];
+                code[k] = (int)m.sv8[(size_t)o0 + 64 * k + lane];
+            }
+#pragma unroll
+            for (int k = 0; k < W; ++k) xv[k] = x[c[k]];
+#pragma unroll
+            for (int k = 0; k < W; ++k) {
+                const double p = sdict[code[k]] * (xv[k] * sx);
+                if (k < len) sum = sum + p;
+            }
+        }
+        if (active) {
+            const double yn = cy * (y0 * sy) + sum;
+            y[r] = yn;
+            sq += yn * yn;
+        }
+    }
+    const double tot = block_sum(sq, red);
+    if (tid == 0) partials[blockIdx.x] = tot;
+}
+
+struct Rec {
+    uint4 q;
+    double y0;
+};
+
+__device__ __forceinline__ double rec_sum(const uint4 q, int cb, const double *__restrict__ x, const double *sdict,
+                                          double sx, bool gather, int r)
+{
+    int c[W], code[W];
+    c[0] = cb + (int)(q.x & 0xffffu);
+    c[1] = cb + (int)(q.x >> 16);
+    c[2] = cb + (int)(q.y & 0xffffu);
+    c[3] = cb + (int)(q.y >> 16);
+    c[4] = cb + (int)(q.z & 0xffffu);
+    code[0] = (int)((q.z >> 16) & 0xffu);
+    code[1] = (int)(q.z >> 24);
+    code[2] = (int)(q.w & 0xffu);
+    code[3] = (int)((q.w >> 8) & 0xffu);
+    code[4] = (int)((q.w >> 16) & 0xffu);
+    const int len = (int)(q.w >> 24);
+    double xv[W];
+    if (gather) {
+#pragma unroll
+        for (int k = 0; k < W; ++k) xv[k] = x[c[k]];
+    } else {
+        const double t = x[r];
+#pragma unroll
+        for (int k = 0; k < W; ++k) xv[k] = t + (double)c[k];
+    }
+    double sum = 0.0;
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+        const double p = sdict[code[k]] * (xv[k] * sx);
+        if (k < len) sum = sum + p;
+    }
+    return sum;
+}
+
+// VAR 2 = C (one slice per wave trip), 3 = D (two slices in flight), 4 = S (no gather)
+template <int VAR>
+__global__ __launch_bounds__(256, 8) void k_rec(Mat m, const double *__restrict__ x, double *__restrict__ y, double sx,
+                                                double sy, double cy, double *__restrict__ partials, int nblk, int persistent)
+{
+    __shared__ double red[4];
+    __shared__ double sdict[256];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    sdict[tid] = m.dict[tid];
+    __syncthreads();
+    double sq = 0.0;
+    Range xr = persistent ? xcd_range(nblk, gridDim.x, blockIdx.x) : Range{(int)blockIdx.x, nblk, (int)gridDim.x};
+    const int last = m.nslices - 1;
+    if (VAR == 3) {
+        for (int b = xr.first; b < xr.end; b += 2 * xr.stride) {
+            const int sa = b * 4 + wave;
+            const int b2 = b + xr.stride;
+            const int sbv = b2 * 4 + wave;
+            const bool hasA = sa <= last, hasB = b2 < xr.end && sbv <= last;
+            const int sA = min(sa, last), sB = min(sbv, last);
+            const int rA = min(sA * 64 + lane, m.rows - 1), rB = min(sB * 64 + lane, m.rows - 1);
+            const uint4 qa = m.rec[sA * 64 + lane];
+            const uint4 qb = m.rec[sB * 64 + lane];
+            const int cba = m.cbase[sA], cbb = m.cbase[sB];
+            const double ya = y[rA], yb = y[rB];
+            const double suma = rec_sum(qa, cba, x, sdict, sx, true, rA);
+            const double sumb = rec_sum(qb, cbb, x, sdict, sx, true, rB);
+            if (hasA && sa * 64 + lane < m.rows) {
+                const double yn = cy * (ya * sy) + suma;
+                y[rA] = yn;
+                sq += yn * yn;
+            }
+            if (hasB && sbv * 64 + lane < m.rows) {
+                const double yn = cy * (yb * sy) + sumb;
+                y[rB] = yn;
+                sq += yn * yn;
+            }
+        }
+    } else {
+        for (int b = xr.first; b < xr.end; b += xr.stride) {
+            const int s = b * 4 + wave;
+            if (s > last) continue;
+            const int r = s * 64 + lane;
+            const bool active = r < m.rows;
+            const int rc = active ? r : m.rows - 1;
+            const uint4 q = m.rec[s * 64 + lane];
+            const int cb = m.cbase[s];
+            const double y0 = y[rc];
+            const double sum = rec_sum(q, cb, x, sdict, sx, VAR != 4, rc);
+            if (active) {
+                const double yn = cy * (y0 * sy) + sum;
+                y[r] = yn;
+                sq += yn * yn;
+            }
+        }
+    }
+    const double tot = block_sum(sq, red);
+    if (tid == 0) partials[blockIdx.x] = tot;
+}
+
+template <typename F>
+static double time_us(F launch, int reps)
+{
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    for (int r = 0; r < 5; ++r) launch();
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0, 0));
+    for (int r = 0; r < reps; ++r) launch();
+    CK(hipEventRecord(e1, 0));
+    CK(hipEventSynchronize(e1));
+    float ms = 0;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    return 1e3 * ms / reps;
+}
+
+int main()
+{
+    for (int nx : {500, 1000, 2000, 4000}) {
+        const int ny = nx;
+        Mat m{};
+        m.rows = nx * ny;
+        m.nslices = (m.rows + 63) / 64;
+        const size_t ne = (size_t)m.nslices * 64 * W;
+        CK(hipMalloc(&m.soff, 4 * (m.nslices + 1)));
+        CK(hipMalloc(&m.cbase, 4 * m.nslices));
+        CK(hipMalloc(&m.sc16, 2 * ne));
+        CK(hipMalloc(&m.sv8, ne));
+        CK(hipMalloc(&m.rlen, m.rows));
+        CK(hipMalloc(&m.rec, 16 * (size_t)m.nslices * 64));
+        CK(hipMalloc(&m.dict, 8 * 256));
+        double hd[256] = {4.0, -1.0};
+        CK(hipMemcpy(m.dict, hd, sizeof hd, hipMemcpyHostToDevice));
+        double *x, *y, *ya, *partials;
+        CK(hipMalloc(&x, 8 * (size_t)m.rows));
+        CK(hipMalloc(&y, 8 * (size_t)m.rows));
+        CK(hipMalloc(&ya, 8 * (size_t)m.rows));
+        CK(hipMalloc(&partials, 8 * 65536));
+        hipLaunchKernelGGL(k_build, dim3((m.nslices * 64 + 255) / 256), dim3(256), 0, 0, m, nx, ny);
+        CK(hipDeviceSynchronize());
+        double *hx = (double *)malloc(8 * (size_t)m.rows);
+        for (int i = 0; i < m.rows; ++i) hx[i] = 1.0 + (i % 7) * 0.125;
+        CK(hipMemcpy(x, hx, 8 * (size_t)m.rows, hipMemcpyHostToDevice));
+        const int nblk = (m.nslices + 3) / 4;
+        const double sx = 0.5, sy = 1.0, cy = 0.0;  // y = A (x/2): the same every launch
+        // agreement A vs C
+        CK(hipMemset(y, 0, 8 * (size_t)m.rows));
+        CK(hipMemset(ya, 0, 8 * (size_t)m.rows));
+        hipLaunchKernelGGL(k_cur<0>, dim3(2048), dim3(256), 0, 0, m, x, ya, sx, sy, cy, partials, nblk, 1);
+        hipLaunchKernelGGL(k_rec<3>, dim3(2048), dim3(256), 0, 0, m, x, y, sx, sy, cy, partials, nblk, 1);
+        CK(hipDeviceSynchronize());
+        double *h1 = (double *)malloc(8 * (size_t)m.rows), *h2 = (double *)malloc(8 * (size_t)m.rows);
+        CK(hipMemcpy(h1, ya, 8 * (size_t)m.rows, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(h2, y, 8 * (size_t)m.rows, hipMemcpyDeviceToHost));
+        size_t bad = 0;
+        for (int i = 0; i < m.rows; ++i) bad += h1[i] != h2[i];
+        std::printf("\nPoisson %d x %d: %d rows, %.1f MB per product (40 B/row); A vs D mismatches: %zu\n", nx, ny, m.rows,
+                    40e-6 * m.rows, bad);
+        std::printf("%-52s %10s %10s\n", "variant", "us", "TB/s");
+        const int reps = 200;
+        for (int persistent : {1, 0}) {
+            const int grid = persistent ? 2048 : nblk;
+            const char *g = persistent ? "2048 wg" : "1 wg / 4 slices";
+            auto rep = [&](const char *name, double us) {
+                char buf[96];
+                std::snprintf(buf, sizeof buf, "%s [%s]", name, g);
+                std::printf("%-52s %10.2f %10.2f\n", buf, us, 40e-6 * m.rows / us);
+            };
+            rep("A  sell.h layout, vector descriptors", time_us([&] {
+                    hipLaunchKernelGGL(k_cur<0>, dim3(grid), dim3(256), 0, 0, m, x, y, sx, sy, cy, partials, nblk, persistent);
+                }, reps));
+            rep("B  sell.h layout, scalar descriptors", time_us([&] {
+                    hipLaunchKernelGGL(k_cur<1>, dim3(grid), dim3(256), 0, 0, m, x, y, sx, sy, cy, partials, nblk, persistent);
+                }, reps));
+            rep("C  16-byte records", time_us([&] {
+                    hipLaunchKernelGGL(k_rec<2>, dim3(grid), dim3(256), 0, 0, m, x, y, sx, sy, cy, partials, nblk, persistent);
+                }, reps));
+            if (persistent)
+                rep("D  16-byte records, two slices in flight", time_us([&] {
+                        hipLaunchKernelGGL(k_rec<3>, dim3(grid), dim3(256), 0, 0, m, x, y, sx, sy, cy, partials, nblk, 1);
+                    }, reps));
+            rep("S  16-byte records, no gather (stream)", time_us([&] {
+                    hipLaunchKernelGGL(k_rec<4>, dim3(grid), dim3(256), 0, 0, m, x, y, sx, sy, cy, partials, nblk, persistent);
+                }, reps));
+        }
+        for (void *p : {(void *)m.soff, (void *)m.cbase, (void *)m.sc16, (void *)m.sv8, (void *)m.rlen, (void *)m.rec,
+                        (void *)m.dict, (void *)x, (void *)y, (void *)ya, (void *)partials})
+            CK(hipFree(p));
+        free(hx);
+        free(h1);
+        free(h2);
+    }
+    return 0;
+}

@@ -14,7 +14,7 @@ from lsqr_amd.solver import lsqr_solver_ez
 
 pytestmark = pytest.mark.gpu
 
-KNOBS = ("LSQRHIP_SELL", "LSQRHIP_VAL8", "LSQRHIP_COL16", "LSQRHIP_PANELS", "LSQRHIP_PANEL_KB", "LSQRHIP_OFF64")
+KNOBS = ("LSQRHIP_SELL", "LSQRHIP_SELLP", "LSQRHIP_VAL8", "LSQRHIP_COL16", "LSQRHIP_PANELS", "LSQRHIP_PANEL_KB", "LSQRHIP_OFF64")
 
 
 @pytest.fixture(autouse=True)
@@ -52,9 +52,12 @@ def test_default_formats_for_a_stencil():
     p = P.poisson2d(300, 200)
     s = lsqr_solver_ez().initialize(p.m, p.n, p.a, p.irow, p.icol)
     info = s.info()
-    assert info["sell"] == 1 and info["sell_t"] == 1
+    assert info["sell"] == 2 and info["sell_t"] == 2                   # 3-byte nonzeros: packed records
     assert info["dict_entries"] == 2 and info["value_bytes"] == 1     # {4, -1}
     assert info["col_bytes"] == 2 and info["colt_bytes"] == 2
+    os.environ["LSQRHIP_SELLP"] = "0"
+    info = lsqr_solver_ez().initialize(p.m, p.n, p.a, p.irow, p.icol).info()
+    assert info["sell"] == 1 and info["sell_t"] == 1 and info["value_bytes"] == 1
     os.environ["LSQRHIP_SELL"] = "0"
     os.environ["LSQRHIP_VAL8"] = "0"
     info = lsqr_solver_ez().initialize(p.m, p.n, p.a, p.irow, p.icol).info()
@@ -93,11 +96,14 @@ def test_every_format_combination_gives_the_same_bits(problem):
     x_ref, _ = po.aprod(2, m, n, irow, icol, a, xp, yp)
     o = po.solve(m, n, irow, icol, a, b, damp=0.0, itnlim=30)
     results = []
-    for sell, val8, col16 in itertools.product("10", repeat=3):
-        os.environ.update(LSQRHIP_SELL=sell, LSQRHIP_VAL8=val8, LSQRHIP_COL16=col16)
+    combos = [c + ("1",) for c in itertools.product("10", repeat=3)] + [("1", "1", "1", "0")]
+    for sell, val8, col16, sellp in combos:
+        os.environ.update(LSQRHIP_SELL=sell, LSQRHIP_VAL8=val8, LSQRHIP_COL16=col16, LSQRHIP_SELLP=sellp)
         s = lsqr_solver_ez().initialize(m, n, a, irow, icol, itnlim=30)
         info = s.info()
-        assert info["sell"] == int(sell)
+        assert (info["sell"] != 0) == (sell == "1")
+        packed = sell == val8 == col16 == sellp == "1" and info["dict_entries"] > 0 and info["col_bytes"] == 2
+        assert (info["sell"] == 2) == packed, (info, sell, val8, col16, sellp)
         x, y = xp.copy(), yp.copy()
         s.aprod(1, m, n, x, y)
         assert np.array_equal(y, y_ref), (sell, val8, col16)      # the reference's row sums, bit for bit
@@ -146,18 +152,86 @@ def test_sell_handles_non_finite_x_like_the_reference():
     """Padding slots are loaded but never added: an inf in x must reach exactly the rows whose
     real entries touch it (0 * inf would poison whole slices otherwise)."""
     p = P.poisson2d(100, 100)
-    s = lsqr_solver_ez().initialize(p.m, p.n, p.a, p.irow, p.icol)
-    assert s.info()["sell"] == 1
     xp = _vec(4, p.n)
     xp[0] = np.inf            # column 1 is every slice's... smallest column only for slice 0
     xp[5000] = np.inf
-    y = np.zeros(p.m)
-    x = xp.copy()
-    s.aprod(1, p.m, p.n, x, y)
     with np.errstate(invalid="ignore"):
         _, y_ref = oracle.port().aprod(1, p.m, p.n, p.irow, p.icol, p.a, xp, np.zeros(p.m))
-    assert np.array_equal(y, y_ref, equal_nan=True)
-    assert np.isfinite(y).sum() == np.isfinite(y_ref).sum() >= p.m - 10
+    for sellp in ("1", "0"):
+        os.environ["LSQRHIP_SELLP"] = sellp
+        s = lsqr_solver_ez().initialize(p.m, p.n, p.a, p.irow, p.icol)
+        assert s.info()["sell"] == (2 if sellp == "1" else 1)
+        y = np.zeros(p.m)
+        x = xp.copy()
+        s.aprod(1, p.m, p.n, x, y)
+        assert np.array_equal(y, y_ref, equal_nan=True)
+        assert np.isfinite(y).sum() == np.isfinite(y_ref).sum() >= p.m - 10
+
+
+def _ragged_local(m, n, wmax, seed):
+    """Rows of 1..wmax nonzeros (the width changes every 128 rows; a few rows are shorter or
+    empty), columns within +-40 of the diagonal in a COO order that is NOT column-sorted, values
+    from a 7-entry table."""
+    rs = np.random.RandomState(seed)
+    table = np.array([-2.5, -1.0, -0.0, 0.0, 0.75, 3.0, 1e-3])
+    irow, icol = [], []
+    for r in range(m):
+        cap = 1 + (r // 128) % wmax
+        k = 0 if r % 131 == 0 else (rs.randint(0, cap + 1) if r % 17 == 3 else cap)
+        c0 = min(max(int(r * (n - 1) / max(m - 1, 1)), 40), n - 41)
+        cs = c0 + rs.choice(81, size=k, replace=False) - 40
+        irow += [r] * k
+        icol += list(cs)
+    irow, icol = np.array(irow), np.array(icol)
+    a = table[rs.randint(0, table.size, size=irow.size)]
+    b = _vec(17, m)
+    return m, n, (irow + 1).astype(np.int32), (icol + 1).astype(np.int32), a, b
+
+
+@pytest.mark.parametrize("shape", [(5000, 4000, 5), (4100, 6000, 13), (3333, 3333, 23)])
+def test_packed_records_with_ragged_multi_record_rows(shape):
+    """Slices of 1..23 nonzeros per row = 1..5 records per row, empty rows, a last slice that is
+    not full: the packed layout (forced) must give the reference's row sums bit for bit in both
+    modes and the same solve as the unpacked slices and the row windows, in every schedule."""
+    m, n, wmax = shape
+    m, n, irow, icol, a, b = _ragged_local(m, n, wmax, seed=wmax)
+    po = oracle.port()
+    xp, yp = _vec(9, n), _vec(10, m)
+    _, y_ref = po.aprod(1, m, n, irow, icol, a, xp, yp)
+    x_ref, _ = po.aprod(2, m, n, irow, icol, a, xp, yp)
+    o = po.solve(m, n, irow, icol, a, b, damp=1e-2, itnlim=40)
+    sols = []
+    for sell, sellp, want in (("1", "1", 2), ("1", "0", 1), ("0", "0", 0)):
+        os.environ.update(LSQRHIP_SELL=sell, LSQRHIP_SELLP=sellp)
+        s = lsqr_solver_ez().initialize(m, n, a, irow, icol, itnlim=40)
+        info = s.info()
+        assert info["sell"] == want, info
+        x, y = xp.copy(), yp.copy()
+        s.aprod(1, m, n, x, y)
+        if want != 0:      # one lane per row: the reference's left-to-right sums
+            assert np.array_equal(y, y_ref), (want, int(np.sum(y != y_ref)))
+        else:              # row windows split rows longer than 16 over several lanes (spmv.h)
+            assert np.max(np.abs(y - y_ref)) <= 1e-14 * np.max(np.abs(y_ref))
+        x, y = xp.copy(), yp.copy()
+        s.aprod(2, m, n, x, y)
+        if info["sell_t"] != 0:
+            assert np.array_equal(x, x_ref)
+        else:              # (the ragged transpose usually stays in row windows)
+            assert np.max(np.abs(x - x_ref)) <= 1e-14 * np.max(np.abs(x_ref))
+        for pipeline in (0, 1, 2):
+            s.set_option("pipeline", pipeline)
+            r = s.solve(b, 1e-2, wantse=True)
+            assert (r.istop, r.itn) == (o.istop, o.itn)
+            # 40 iterations, far from converged: the tree-summed norms move x by ~1e-10 against
+            # the oracle's sequential ones (tests/test_gpu_parity.py bands); what is exact here is
+            # the agreement BETWEEN the layouts, checked below
+            assert np.linalg.norm(r.x - o.x) <= 1e-8 * np.linalg.norm(o.x)
+            sols.append(r)
+    for r in sols[1:]:
+        assert r.anorm == pytest.approx(sols[0].anorm, rel=1e-12)
+    for k in (0, 3, 6):                             # within one layout the schedules agree bit for bit
+        assert np.array_equal(sols[k].x, sols[k + 1].x) and np.array_equal(sols[k].x, sols[k + 2].x)
+    assert np.array_equal(sols[0].x, sols[3].x)     # packed vs unpacked slices: the same sums
 
 
 @pytest.mark.parametrize("panels", [False, True])
