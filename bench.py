@@ -34,13 +34,19 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=400)
-    ap.add_argument("--warmup", type=int, default=40)
+    ap.add_argument("--steps", type=int, default=None, help="timed LSQR iterations (default 2000; 400 for --gpus > 1)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed iterations first (default steps / 10)")
     ap.add_argument("--workload", default="auto",
                     help="auto | poisson2d:NX:NY | random:M:N:PER_ROW | powerlaw:M:N:DMAX")
     ap.add_argument("--cpu-iters", type=int, default=1000, help="iterations of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
-    return ap.parse_args()
+    a = ap.parse_args()
+    multi = a.gpus > 1 or int(os.environ.get("WORLD_SIZE", "1")) > 1
+    if a.steps is None:        # N = 1: ~26 us per iteration; N > 1 (10^9 nonzeros): milliseconds
+        a.steps = 400 if multi else 2000
+    if a.warmup is None:
+        a.warmup = max(1, a.steps // 10)
+    return a
 
 
 def make_problem(spec: str):
@@ -96,7 +102,7 @@ def run_single(args):
     d_x = capi.DeviceBuffer(8 * max(p.n, 1))
     # graph batch: a divisor of K when there is a good one (no predicated-off tail iterations in
     # the timed solve), else up to 50 iterations (launches past the stop are ~us-scale no-ops)
-    gi = next((g for g in (50, 40, 32, 26, 20, 16) if K % g == 0), min(50, K + (K & 1)))
+    gi = next((g for g in (100, 50, 40, 32, 26, 20, 16) if K % g == 0), min(50, K + (K & 1)))
     s.set_option("graph_iters", gi)
 
     if W > 0:
@@ -137,7 +143,7 @@ def run_single(args):
         # K back-to-back launches of each hot kernel inside ONE event pair: the per-launch
         # average rocprofv3's kernel trace reports (kernels abut on the stream; a start/stop
         # event pair per launch adds ~2 us of marker latency to a 17 us kernel).
-        reps = K if p.nnz < 50_000_000 else max(10, min(K, 40))
+        reps = min(K, 1000) if p.nnz < 50_000_000 else max(10, min(K, 40))
         avg1, avg2, avg3 = (s.bench_kernel(w, reps) for w in (1, 2, 3))
         # Bytes one product must move IN THE LAYOUT THE BUILD CHOSE: the matrix as
         # stored (lsqrhip_info: sliced-ELL / row windows, 1- or 8-byte values, 2- or 4-byte

@@ -203,7 +203,11 @@ int lsqrhip_lstp_vectors(lsqrhip_handle_t h, double *xtrue, double *b, double *d
  * (1 = eager launches with HIP events around each hot kernel, fills *_ms above),
  * "pipeline" (launch schedule of the loop; all three give the same bits:
  * 0 = K1 S1 K2 S2 K4 S3, 1 = scalar steps ride inside the SpMV launches,
- * 2 = additionally the x/w update rides inside the mode-1 launch [default]). */
+ * 2 = additionally the x/w update rides inside the mode-1 launch [default]),
+ * "poll_ahead" (1 [default] = with graphs, the next batch is enqueued before the host waits
+ * for the current one's stop flag, so the poll and the graph launch overlap device work; a
+ * solve that stops inside batch k then runs batch k+1 as no-op launches; 0 = strict
+ * launch-wait-check). */
 int lsqrhip_set_option(lsqrhip_handle_t h, const char *name, int64_t value);
 /* Run all work of this handle on an externally owned hipStream_t (e.g. the
  * caller's torch stream); NULL restores the handle's own stream. */

@@ -166,7 +166,7 @@ struct lsqrhip_handle_s {
     double *partials = nullptr;  // SPMV_MAX_GRID
     int vgrid_m = 1, vgrid_n = 1;
     LsqrState *d_state = nullptr;
-    LsqrState *h_state = nullptr;  // pinned
+    LsqrState *h_state = nullptr;  // pinned; [1], [2] = per-batch snapshots of the look-ahead poll (solve_loop.h)
     SpmvCoef *d_unit = nullptr;    // (1,1,1): plain y += A x
     int *d_zero = nullptr;         // a stop flag that is never set
     double *d_scalar = nullptr;    // 4 doubles scratch
@@ -177,6 +177,8 @@ struct lsqrhip_handle_s {
     hipStream_t own_stream = nullptr, stream = nullptr;
     // options
     int use_graph = 1, graph_iters = 32, time_kernels = 0;
+    int poll_ahead = 1;  // enqueue the next graph batch before waiting on the current one
+    hipEvent_t ev_batch[2] = {nullptr, nullptr};
     hipGraphExec_t gexec = nullptr;
     int gexec_iters = 0;
     bool graph_dirty = true;
@@ -299,6 +301,8 @@ extern "C" int lsqrhip_destroy(lsqrhip_handle_t h)
     for (double *p : {h->P1[0], h->P1[1], h->P2[0], h->P2[1], h->P3})
         if (p) (void)hipFree(p);
     if (h->slots) (void)hipFree(h->slots);
+    for (hipEvent_t e : h->ev_batch)
+        if (e) (void)hipEventDestroy(e);
     if (h->ev_loop0) (void)hipEventDestroy(h->ev_loop0);
     if (h->ev_loop1) (void)hipEventDestroy(h->ev_loop1);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -660,7 +664,8 @@ static int alloc_workspace(H *h)
     HIPCHK(hipMalloc((void **)&h->slots, sizeof(NormSlot) * 4));
     HIPCHK(hipMemsetAsync(h->slots, 0, sizeof(NormSlot) * 4, s));
     HIPCHK(hipMalloc((void **)&h->d_state, sizeof(LsqrState)));
-    HIPCHK(hipHostMalloc((void **)&h->h_state, sizeof(LsqrState)));
+    HIPCHK(hipHostMalloc((void **)&h->h_state, 3 * sizeof(LsqrState)));
+    for (hipEvent_t &e : h->ev_batch) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HIPCHK(hipMalloc((void **)&h->d_unit, sizeof(SpmvCoef)));
     HIPCHK(hipMalloc((void **)&h->d_zero, sizeof(int)));
     SpmvCoef unit{1.0, 1.0, 1.0, 0, 0};
@@ -1167,6 +1172,7 @@ extern "C" int lsqrhip_set_option(lsqrhip_handle_t h, const char *name, int64_t 
         if (value < 1 || value > 1024) return fail(LSQRHIP_ERR_ARG, "graph_iters must be in [1,1024]");
         h->graph_iters = (int)value;
     } else if (k == "time_kernels") h->time_kernels = value != 0;
+    else if (k == "poll_ahead") h->poll_ahead = value != 0;
     else if (k == "op_batch") h->op_batch = value < 1 ? 1 : (int)value;
     else if (k == "pipeline") h->pipeline = value < 0 ? 0 : (value > 2 ? 2 : (int)value);
     else return fail(LSQRHIP_ERR_ARG, "unknown option: " + k);

@@ -533,38 +533,64 @@ static int solve_core(H *h, const double *b, bool b_on_device, double damp, doub
     // S3 raises `stop` at itn == itnlim at the latest; anything beyond this many batches
     // means the device loop is not advancing (never spin on a dead stream).
     const int64_t max_batches = (int64_t)std::max(itnlim, 0) / G + 2;
-    for (int64_t batch = 0;; ++batch) {
-        if (batch > max_batches)
-            return fail(LSQRHIP_ERR_HIP, "iteration loop did not terminate (device state not advancing)");
-        if (graph) {
+    if (graph && h->poll_ahead) {
+        // Look-ahead poll: batch k+1 is enqueued BEFORE the host waits for batch k's snapshot, so
+        // the wait, the check and the next graph launch (~80 us per batch of 50 at config 2)
+        // overlap device work.  Never beyond itnlim; after a stop inside batch k the kernels of
+        // batch k+1 return at their first instruction (stop flag) and change nothing.
+        auto enqueue = [&](int64_t k) -> int {
             HIPCHK(hipGraphLaunch(h->gexec, s));
-        } else {
-            RET(launch_batch(h, 1 + (int)(batch * G), G, timed ? h->ev.data() : nullptr));
-            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemcpyAsync(h->h_state + 1 + (k & 1), st, sizeof(LsqrState), hipMemcpyDeviceToHost, s));
+            HIPCHK(hipEventRecord(h->ev_batch[k & 1], s));
+            return LSQRHIP_OK;
+        };
+        RET(enqueue(0));
+        for (int64_t batch = 0;; ++batch) {
+            if (batch > max_batches)
+                return fail(LSQRHIP_ERR_HIP, "iteration loop did not terminate (device state not advancing)");
+            if ((batch + 1) * G < (int64_t)itnlim) RET(enqueue(batch + 1));
+            HIPCHK(hipEventSynchronize(h->ev_batch[batch & 1]));
+            if (h->h_state[1 + (batch & 1)].stop != 0) break;
+            if ((batch + 1) * G >= (int64_t)itnlim)  // S3 stops at itnlim at the latest
+                return fail(LSQRHIP_ERR_HIP, "iteration loop did not terminate (device state not advancing)");
         }
+        // the settled state (any batch enqueued past the stop has not touched it)
         HIPCHK(hipMemcpyAsync(h->h_state, st, sizeof(LsqrState), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
-        if (timed) {
-            // launches after the stop flag was raised are no-ops: count only live ones
-            const int live = std::min(G, h->h_state->itn - (int)tm.spmv1_launches);
-            for (int k = 0; k < live; ++k) {
-                float a = 0, c = 0, d = 0;
-                (void)hipEventElapsedTime(&a, h->ev[6 * k + 0], h->ev[6 * k + 1]);
-                (void)hipEventElapsedTime(&c, h->ev[6 * k + 2], h->ev[6 * k + 3]);
-                // fused schedule: only the batch's last update is a kernel of its own
-                const bool own_update = !fused_update || k == G - 1;
-                if (own_update) {
-                    (void)hipEventElapsedTime(&d, h->ev[6 * k + 4], h->ev[6 * k + 5]);
-                    tm.update_launches += 1;
-                }
-                tm.spmv1_ms += a;
-                tm.spmv2_ms += c;
-                tm.update_ms += d;
+    } else {
+        for (int64_t batch = 0;; ++batch) {
+            if (batch > max_batches)
+                return fail(LSQRHIP_ERR_HIP, "iteration loop did not terminate (device state not advancing)");
+            if (graph) {
+                HIPCHK(hipGraphLaunch(h->gexec, s));
+            } else {
+                RET(launch_batch(h, 1 + (int)(batch * G), G, timed ? h->ev.data() : nullptr));
+                HIPCHK(hipGetLastError());
             }
-            tm.spmv1_launches += live;
-            tm.spmv2_launches += live;
+            HIPCHK(hipMemcpyAsync(h->h_state, st, sizeof(LsqrState), hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+            if (timed) {
+                // launches after the stop flag was raised are no-ops: count only live ones
+                const int live = std::min(G, h->h_state->itn - (int)tm.spmv1_launches);
+                for (int k = 0; k < live; ++k) {
+                    float a = 0, c = 0, d = 0;
+                    (void)hipEventElapsedTime(&a, h->ev[6 * k + 0], h->ev[6 * k + 1]);
+                    (void)hipEventElapsedTime(&c, h->ev[6 * k + 2], h->ev[6 * k + 3]);
+                    // fused schedule: only the batch's last update is a kernel of its own
+                    const bool own_update = !fused_update || k == G - 1;
+                    if (own_update) {
+                        (void)hipEventElapsedTime(&d, h->ev[6 * k + 4], h->ev[6 * k + 5]);
+                        tm.update_launches += 1;
+                    }
+                    tm.spmv1_ms += a;
+                    tm.spmv2_ms += c;
+                    tm.update_ms += d;
+                }
+                tm.spmv1_launches += live;
+                tm.spmv2_launches += live;
+            }
+            if (h->h_state->stop != 0) break;
         }
-        if (h->h_state->stop != 0) break;
     }
     HIPCHK(hipEventRecord(h->ev_loop1, s));
 

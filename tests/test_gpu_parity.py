@@ -228,6 +228,38 @@ def test_graph_and_eager_launch_modes_agree_bitwise():
     assert np.array_equal(r7.x, r_graph.x) and r7.itn == r_graph.itn
 
 
+@pytest.mark.parametrize("name", ["poisson_20x20_it50", "random_over_se", "illcond_conlim", "itnlim_1", "b_zero"])
+def test_look_ahead_poll_changes_nothing(name):
+    """solve_loop.h: with graphs the host enqueues batch k+1 before it waits for batch k's stop
+    flag.  A stop in the middle of a batch, at a batch boundary, before the first batch ends, or
+    an iteration limit that is not a multiple of the batch must give the strict loop's answer."""
+    p, o = CASES[name]
+    s = make(p, o)
+    s.set_option("poll_ahead", 0)
+    ref = s.solve(p.b, o["damp"], wantse=o["wantse"])
+    for gi in (2, 4, 6, 16, max(2, ref.itn), max(2, ref.itn + 1), 200):
+        for pa in (1, 0):
+            s.set_option("graph_iters", gi)
+            s.set_option("poll_ahead", pa)
+            r = s.solve(p.b, o["damp"], wantse=o["wantse"])
+            assert (r.istop, r.itn, r.anorm, r.acond, r.rnorm, r.arnorm, r.xnorm) == \
+                   (ref.istop, ref.itn, ref.anorm, ref.acond, ref.rnorm, ref.arnorm, ref.xnorm), (gi, pa)
+            assert np.array_equal(r.x, ref.x)
+            if o["wantse"]:
+                assert np.array_equal(r.se, ref.se)
+    # the limit reached exactly at / one past / one short of a batch boundary
+    for itnlim in (7, 8, 9):
+        out = []
+        for pa in (0, 1):
+            s.set_option("graph_iters", 8)
+            s.set_option("poll_ahead", pa)
+            s.itnlim = itnlim
+            s.atol = s.btol = s.conlim = 0.0
+            r = s.solve(p.b, o["damp"])
+            out.append((r.istop, r.itn, r.anorm, r.rnorm, r.x.copy()))
+        assert out[0][:4] == out[1][:4] and np.array_equal(out[0][4], out[1][4])
+
+
 @pytest.mark.parametrize("name", ["poisson_20x20_it50", "random_over_se", "powerlaw_small", "illcond_conlim",
                                   "empty_rows_cols", "t1_readme_damped", "b_zero"])
 def test_pipelined_and_sequential_schedules_agree_bitwise(name):
