@@ -198,16 +198,38 @@ __device__ __forceinline__ double rec_sum(const uint4 q, int cb, const double *_
     return sum;
 }
 
-// VAR 2 = C (one slice per wave trip), 3 = D (two slices in flight), 4 = S (no gather)
+// the library's lazy-norm prologue: every workgroup reduces the previous kernel's 2048 partials
+__device__ __forceinline__ double all_sum(const double *__restrict__ p, int np, double *red)
+{
+    double s = 0.0;
+    for (int i = threadIdx.x; i < np; i += 256) s += p[i];
+    const double r = block_sum(s, red);
+    __syncthreads();
+    if (threadIdx.x == 0) red[4] = r;
+    __syncthreads();
+    const double out = red[4];
+    __syncthreads();
+    return out;
+}
+
+// VAR 2 = C (one slice per wave trip), 3 = D (two slices in flight), 4 = S (no gather),
+// 5 = C + stop-flag check first, 6 = C + stop flag + reduction of 2048 partials (lazy coefficients)
 template <int VAR>
 __global__ __launch_bounds__(256, 8) void k_rec(Mat m, const double *__restrict__ x, double *__restrict__ y, double sx,
-                                                double sy, double cy, double *__restrict__ partials, int nblk, int persistent)
+                                                double sy, double cy, double *__restrict__ partials, int nblk, int persistent,
+                                                const int *__restrict__ stop = nullptr,
+                                                const double *__restrict__ pin = nullptr)
 {
-    __shared__ double red[4];
+    __shared__ double red[5];
     __shared__ double sdict[256];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (VAR >= 5 && *stop != 0) return;
     sdict[tid] = m.dict[tid];
+    if (VAR == 6) {
+        const double nrm = all_sum(pin, 2048, red);
+        sx = sx + 0.0 * nrm;   // the body depends on the reduced value, as in the library
+    }
     __syncthreads();
     double sq = 0.0;
     Range xr = persistent ? xcd_range(nblk, gridDim.x, blockIdx.x) : Range{(int)blockIdx.x, nblk, (int)gridDim.x};
@@ -259,6 +281,67 @@ __global__ __launch_bounds__(256, 8) void k_rec(Mat m, const double *__restrict_
     if (tid == 0) partials[blockIdx.x] = tot;
 }
 
+// Workgroup shape: BS threads (BS/64 slices per trip), `np` = grid partials reduced by every
+// workgroup when LAZY (fewer, fatter workgroups -> fewer partials to re-read).
+template <int BS, bool LAZY>
+__global__ __launch_bounds__(BS, 2048 / BS) void k_big(Mat m, const double *__restrict__ x, double *__restrict__ y,
+                                                       double sx, double sy, double cy, double *__restrict__ partials,
+                                                       int nblk, const int *__restrict__ stop,
+                                                       const double *__restrict__ pin, int np)
+{
+    constexpr int NW = BS / 64;
+    __shared__ double red[NW + 1];
+    __shared__ double sdict[256];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (*stop != 0) return;
+    if (tid < 256) sdict[tid] = m.dict[tid];
+    if (LAZY) {
+        double s = 0.0;
+        for (int i = tid; i < np; i += BS) s += pin[i];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+        if (lane == 0) red[wave] = s;
+        __syncthreads();
+        if (tid == 0) {
+            double t = 0.0;
+            for (int w = 0; w < NW; ++w) t += red[w];
+            red[NW] = t;
+        }
+        __syncthreads();
+        sx = sx + 0.0 * red[NW];
+    }
+    __syncthreads();
+    double sq = 0.0;
+    const Range xr = xcd_range(nblk, gridDim.x, blockIdx.x);
+    const int last = m.nslices - 1;
+    for (int b = xr.first; b < xr.end; b += xr.stride) {
+        const int s = b * NW + wave;
+        if (s > last) continue;
+        const int r = s * 64 + lane;
+        const bool active = r < m.rows;
+        const int rc = active ? r : m.rows - 1;
+        const uint4 q = m.rec[s * 64 + lane];
+        const int cb = m.cbase[s];
+        const double y0 = y[rc];
+        const double sum = rec_sum(q, cb, x, sdict, sx, true, rc);
+        if (active) {
+            const double yn = cy * (y0 * sy) + sum;
+            y[r] = yn;
+            sq += yn * yn;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off, 64);
+    if (lane == 0) red[wave] = sq;
+    __syncthreads();
+    if (tid == 0) {
+        double t = 0.0;
+        for (int w = 0; w < NW; ++w) t += red[w];
+        partials[blockIdx.x] = t;
+    }
+}
+
 template <typename F>
 static double time_us(F launch, int reps)
 {
@@ -278,7 +361,7 @@ static double time_us(F launch, int reps)
 
 int main()
 {
-    for (int nx : {500, 1000, 2000, 4000}) {
+    for (int nx : {1000, 2000}) {
         const int ny = nx;
         Mat m{};
         m.rows = nx * ny;
@@ -298,6 +381,12 @@ int main()
         CK(hipMalloc(&y, 8 * (size_t)m.rows));
         CK(hipMalloc(&ya, 8 * (size_t)m.rows));
         CK(hipMalloc(&partials, 8 * 65536));
+        int *zero;
+        double *pin;
+        CK(hipMalloc(&zero, 64));
+        CK(hipMemset(zero, 0, 64));
+        CK(hipMalloc(&pin, 8 * 2048));
+        CK(hipMemset(pin, 0, 8 * 2048));
         hipLaunchKernelGGL(k_build, dim3((m.nslices * 64 + 255) / 256), dim3(256), 0, 0, m, nx, ny);
         CK(hipDeviceSynchronize());
         double *hx = (double *)malloc(8 * (size_t)m.rows);
@@ -341,9 +430,38 @@ int main()
                 rep("D  16-byte records, two slices in flight", time_us([&] {
                         hipLaunchKernelGGL(k_rec<3>, dim3(grid), dim3(256), 0, 0, m, x, y, sx, sy, cy, partials, nblk, 1);
                     }, reps));
+            if (persistent) {
+                rep("C5 C + stop-flag load and branch first", time_us([&] {
+                        hipLaunchKernelGGL(k_rec<5>, dim3(grid), dim3(256), 0, 0, m, x, y, sx, sy, cy, partials, nblk, 1,
+                                           (const int *)zero, (const double *)pin);
+                    }, reps));
+                rep("C6 C5 + every workgroup reduces 2048 partials", time_us([&] {
+                        hipLaunchKernelGGL(k_rec<6>, dim3(grid), dim3(256), 0, 0, m, x, y, sx, sy, cy, partials, nblk, 1,
+                                           (const int *)zero, (const double *)pin);
+                    }, reps));
+            }
             rep("S  16-byte records, no gather (stream)", time_us([&] {
                     hipLaunchKernelGGL(k_rec<4>, dim3(grid), dim3(256), 0, 0, m, x, y, sx, sy, cy, partials, nblk, persistent);
                 }, reps));
+        }
+        {
+            auto rep = [&](const char *name, int bs, int grid, double us) {
+                std::printf("%-36s %5d thr x %5d wg %10.2f %10.2f\n", name, bs, grid, us, 40e-6 * m.rows / us);
+            };
+#define BIG(BS, GRID)                                                                                                  \
+    {                                                                                                                  \
+        const int nb = (m.nslices + (BS) / 64 - 1) / ((BS) / 64);                                                      \
+        rep("records, coefficients given", BS, GRID, time_us([&] {                                                     \
+                hipLaunchKernelGGL((k_big<BS, false>), dim3(GRID), dim3(BS), 0, 0, m, x, y, sx, sy, cy, partials, nb,   \
+                                   (const int *)zero, (const double *)pin, GRID);                                     \
+            }, reps));                                                                                                 \
+        rep("records, lazy (reduce grid partials)", BS, GRID, time_us([&] {                                            \
+                hipLaunchKernelGGL((k_big<BS, true>), dim3(GRID), dim3(BS), 0, 0, m, x, y, sx, sy, cy, partials, nb,    \
+                                   (const int *)zero, (const double *)pin, GRID);                                     \
+            }, reps));                                                                                                 \
+    }
+            BIG(256, 2048) BIG(256, 1024) BIG(512, 1024) BIG(512, 512) BIG(1024, 512) BIG(1024, 256)
+#undef BIG
         }
         for (void *p : {(void *)m.soff, (void *)m.cbase, (void *)m.sc16, (void *)m.sv8, (void *)m.rlen, (void *)m.rec,
                         (void *)m.dict, (void *)x, (void *)y, (void *)ya, (void *)partials})
