@@ -40,6 +40,8 @@ def parse():
                     help="auto | poisson2d:NX:NY | random:M:N:PER_ROW | powerlaw:M:N:DMAX")
     ap.add_argument("--cpu-iters", type=int, default=1000, help="iterations of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-scaling-ref", action="store_true",
+                    help="skip the N = 1 point of the multi-GPU series (configs[3] whole on this GPU)")
     a = ap.parse_args()
     multi = a.gpus > 1 or int(os.environ.get("WORLD_SIZE", "1")) > 1
     if a.steps is None:        # N = 1: ~26 us per iteration; N > 1 (10^9 nonzeros): milliseconds
@@ -73,6 +75,33 @@ def cpu_baseline(p, iters: int):
     return {"value": r.itn / dt, "unit": "it/s", "cores": 1, "kind": kind,
             "sample": f"{p.name}: same (irow,icol,a,b), {iters} iterations in {dt:.2f} s, "
                       f"{'oracle/_ref (reference compiled with amdflang -O2)' if kind == 'reference' else 'oracle C port'}"}
+
+
+def scaling_series_n1(torch):
+    """N = 1 of the series `--gpus 2/4/8` continues: BASELINE configs[3] (10M x 10M, 100 per row,
+    10^9 nonzeros, damp 1e-3 -- lsqr_amd/dist_bench.py) whole on this GPU.  The N > 1 lines are
+    strong scaling of THIS workload, not of configs[1] above; outside the timed region."""
+    from lsqr_amd import capi, devgen
+    from lsqr_amd.dist_bench import DEFAULT_SPEC
+    try:
+        full = devgen.generate(DEFAULT_SPEC)
+        cfg = devgen.parse_spec(DEFAULT_SPEC)
+        d_x = capi.DeviceBuffer(8 * cfg["n"])
+        full.solver.atol = full.solver.btol = full.solver.conlim = 0.0
+        full.solver.itnlim = 4
+        full.solver.solve_device(full.d_b.ptr.value, d_x.ptr.value, cfg["damp"])
+        kr = 40
+        full.solver.itnlim = kr
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        r = full.solver.solve_device(full.d_b.ptr.value, d_x.ptr.value, cfg["damp"])
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        return {"workload": f"{DEFAULT_SPEC} nnz={full.nnz} damp={cfg['damp']} (BASELINE.json configs[3], whole on one GPU)",
+                "n_gpus": 1, "steps": r.itn, "value": r.itn / dt, "unit": "it/s", "ms_per_step": 1e3 * dt / r.itn,
+                "note": "the --gpus N > 1 lines shard this matrix by row blocks: compare their value with this one"}
+    except Exception as e:      # never fail the headline measurement over the side one
+        return {"error": repr(e)}
 
 
 def run_single(args):
@@ -199,6 +228,8 @@ def run_single(args):
                           "gbps": t2.vec_bytes / (avg3 * 1e-3) / 1e9, "in_loop_event_pair_us": in_loop[2] * 1e3},
         }
 
+    if spec == "poisson2d:1000:1000" and not args.no_scaling_ref:
+        out["strong_scaling_n1"] = scaling_series_n1(torch)
     if args.cpu_iters > 0 and host_ok:
         out["cpu_baseline"] = cpu_baseline(p, args.cpu_iters)
     elif args.cpu_iters > 0:

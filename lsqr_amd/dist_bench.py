@@ -97,6 +97,18 @@ def run_distributed(args):
         except Exception as e:  # e.g. not enough HBM for the whole matrix: report, do not fail the run
             ref = {"error": repr(e)}
 
+    # RCCL (NCCL_DEBUG=VERSION on the GPU boxes) writes its banner to STDOUT through C stdio,
+    # which sits in a buffer until the process exits -- i.e. after the JSON line.  Drain every
+    # rank's C buffers first so that the JSON line is the last thing this job prints on stdout.
+    import ctypes
+    import sys
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
+    dist.barrier()
+
     if rank == 0:
         out = {
             "metric": "lsqr_iterations_per_sec", "value": K / dt, "unit": "it/s", "n_gpus": world, "steps": K,
