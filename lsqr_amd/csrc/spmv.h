@@ -348,12 +348,19 @@ __global__ __launch_bounds__(SPMV_BLOCK, XL ? 2 : 8) void k_spmv_fused(
         const int rfirst = r0 + gid;
         const bool have_row = rfirst < r1s;
         const int rclamp = have_row ? rfirst : r0;
-        OffT q0 = 0, q1 = 0;
-        double y0 = 0.0;
+        OffT q0 = 0, q1 = 0, q0b = 0, q1b = 0;
+        double y0 = 0.0, y0b = 0.0;
         if (nr > 0) {
             q0 = rowptr[rclamp];
             q1 = rowptr[rclamp + 1];
             if (!PANEL) y0 = y[rclamp];
+            // the row of this lane's SECOND round too (clamped, unconditional): with 2-3 nonzeros
+            // per (row, panel) a window holds ~290 rows for 256 lanes, and fetching the second
+            // round's bounds only after the first sum put a dependent load on every window
+            const int r2 = rfirst + ngroups < r1s ? rfirst + ngroups : rclamp;
+            q0b = rowptr[r2];
+            q1b = rowptr[r2 + 1];
+            if (!PANEL) y0b = y[r2];
         }
         // ---- gather x, stage products ---------------------------------------------------
         if (cnt > 0) {
@@ -406,9 +413,15 @@ __global__ __launch_bounds__(SPMV_BLOCK, XL ? 2 : 8) void k_spmv_fused(
                 }
                 r += ngroups;
                 if (r >= r1s) break;
-                q0 = rowptr[r];
-                q1 = rowptr[r + 1];
-                if (!PANEL) y0 = y[r];
+                if (r == rfirst + ngroups) {  // second round: already here
+                    q0 = q0b;
+                    q1 = q1b;
+                    y0 = y0b;
+                } else {
+                    q0 = rowptr[r];
+                    q1 = rowptr[r + 1];
+                    if (!PANEL) y0 = y[r];
+                }
             }
         }
 
