@@ -39,23 +39,32 @@ __device__ __forceinline__ double block_sum(double v, double *lds)
 // order.  The first 8 loads are issued together (np <= 2048 = every grid cap in this library),
 // because a plain `for (...) s += p[i]` waits for each load in turn: 8 dependent L2 round
 // trips, ~4 us of every scalar kernel and every lazy SpMV prologue before this was unrolled.
-template <int BLOCK>
-__device__ __forceinline__ double strided_sum(const double *__restrict__ p, int np)
+template <int BLOCK, int K>
+__device__ __forceinline__ double strided_sum_k(const double *__restrict__ p, int np)
 {
     const int t = threadIdx.x;
     const int last = np > 0 ? np - 1 : 0;
-    double v[8];
+    double v[K];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
+    for (int k = 0; k < K; ++k) {
         const int i = t + k * BLOCK;
         v[k] = p[i < last ? i : last];
     }
     double s = 0.0;
 #pragma unroll
-    for (int k = 0; k < 8; ++k)
+    for (int k = 0; k < K; ++k)
         if (t + k * BLOCK < np) s += v[k];
-    for (int i = t + 8 * BLOCK; i < np; i += BLOCK) s += p[i];
+    for (int i = t + K * BLOCK; i < np; i += BLOCK) s += p[i];
     return s;
+}
+// Only as many loads as np needs (uniform branch): every workgroup of a lazy product runs this,
+// and at 2048 workgroups the loads themselves are the cost (scripts/sell_roof.hip "prologue").
+template <int BLOCK>
+__device__ __forceinline__ double strided_sum(const double *__restrict__ p, int np)
+{
+    if (np <= 2 * BLOCK) return strided_sum_k<BLOCK, 2>(p, np);
+    if (np <= 4 * BLOCK) return strided_sum_k<BLOCK, 4>(p, np);
+    return strided_sum_k<BLOCK, 8>(p, np);
 }
 
 // Fixed-order sum of np doubles by the whole workgroup, result returned to EVERY thread.

@@ -342,6 +342,65 @@ __global__ __launch_bounds__(BS, 2048 / BS) void k_big(Mat m, const double *__re
     }
 }
 
+// Prologue anatomy.  PV: 0 none | 1 every thread loads its 8 partials, wave sum only (no barrier) |
+// 2 the library's shape (loads + 3 barriers) | 3 only wave 0 loads (32 per lane), one barrier |
+// 4 shape 2 on 64 partials only.  The partials read are the ones the PREVIOUS launch wrote
+// (ping-pong), as in the solver: they come from beyond L2.
+template <int PV>
+__global__ __launch_bounds__(256, 8) void k_pro(Mat m, const double *__restrict__ x, double *__restrict__ y, double sx,
+                                                double sy, double cy, double *__restrict__ pout, int nblk,
+                                                const int *__restrict__ stop, const double *__restrict__ pin)
+{
+    __shared__ double red[5];
+    __shared__ double sdict[256];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (*stop != 0) return;
+    sdict[tid] = m.dict[tid];
+    if (PV == 1) {
+        double s = 0.0;
+        for (int i = tid; i < 2048; i += 256) s += pin[i];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+        sx = sx + 0.0 * s;
+    } else if (PV == 2 || PV == 4) {
+        const double nrm = all_sum(pin, PV == 4 ? 64 : 2048, red);
+        sx = sx + 0.0 * nrm;
+    } else if (PV == 3) {
+        if (wave == 0) {
+            double s = 0.0;
+            for (int i = lane; i < 2048; i += 64) s += pin[i];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+            if (lane == 0) red[4] = s;
+        }
+        __syncthreads();
+        sx = sx + 0.0 * red[4];
+    }
+    __syncthreads();
+    double sq = 0.0;
+    const Range xr = xcd_range(nblk, gridDim.x, blockIdx.x);
+    const int last = m.nslices - 1;
+    for (int b = xr.first; b < xr.end; b += xr.stride) {
+        const int s = b * 4 + wave;
+        if (s > last) continue;
+        const int r = s * 64 + lane;
+        const bool active = r < m.rows;
+        const int rc = active ? r : m.rows - 1;
+        const uint4 q = m.rec[s * 64 + lane];
+        const int cb = m.cbase[s];
+        const double y0 = y[rc];
+        const double sum = rec_sum(q, cb, x, sdict, sx, true, rc);
+        if (active) {
+            const double yn = cy * (y0 * sy) + sum;
+            y[r] = yn;
+            sq += yn * yn;
+        }
+    }
+    const double tot = block_sum(sq, red);
+    if (tid == 0) pout[blockIdx.x] = tot;
+}
+
 template <typename F>
 static double time_us(F launch, int reps)
 {
@@ -443,6 +502,27 @@ int main()
             rep("S  16-byte records, no gather (stream)", time_us([&] {
                     hipLaunchKernelGGL(k_rec<4>, dim3(grid), dim3(256), 0, 0, m, x, y, sx, sy, cy, partials, nblk, persistent);
                 }, reps));
+        }
+        {
+            double *pp[2];
+            CK(hipMalloc(&pp[0], 8 * 2048));
+            CK(hipMalloc(&pp[1], 8 * 2048));
+            CK(hipMemset(pp[0], 0, 8 * 2048));
+            CK(hipMemset(pp[1], 0, 8 * 2048));
+            int flip = 0;
+            auto rp = [&](const char *name, double us) { std::printf("%-60s %10.2f\n", name, us); };
+#define PRO(PV, NAME)                                                                                                  \
+    rp(NAME, time_us([&] {                                                                                             \
+           hipLaunchKernelGGL(k_pro<PV>, dim3(2048), dim3(256), 0, 0, m, x, y, sx, sy, cy, pp[flip ^ 1], nblk,         \
+                              (const int *)zero, (const double *)pp[flip]);                                           \
+           flip ^= 1;                                                                                                  \
+       }, reps));
+            PRO(0, "prologue: none")
+            PRO(1, "prologue: 8 loads per thread + wave sum, no barrier")
+            PRO(2, "prologue: library shape (8 loads, 3 barriers), 2048 partials")
+            PRO(4, "prologue: library shape, 64 partials")
+            PRO(3, "prologue: wave 0 loads all 2048, one barrier")
+#undef PRO
         }
         {
             auto rep = [&](const char *name, int bs, int grid, double us) {
