@@ -35,7 +35,7 @@
 //             Workgroup 0 publishes (nrm, 1/nrm) in slot_out for the next kernel's sy.
 //
 // Measured at config 2 (88 MB per launch) with this kernel: ~17 us, 16 us with 16-bit columns,
-// 14 us with the value dictionary -- and ~4.2 us per resident round of windows whatever the
+// 14.4 us with the value dictionary (15.7 before the first round skipped its all-clamped slots) -- and ~4.2 us per resident round of windows whatever the
 // bytes: a trip through a window is a chain of dependent phases.  Matrices with
 // short even rows therefore go to the sliced-ELL kernel (sell.h: 10 us), dense scattered rows to
 // the LDS-panel kernel (xl.h); this one serves every other shape.  Sweeps: window 512 / 1024 /
@@ -44,6 +44,8 @@
 //
 // Algorithmic HBM bytes per launch:  12*nnz + P*(rows+1) + 8*cols + 16*rows.
 #pragma once
+
+#include <type_traits>
 
 #include "common.h"
 #include "scalar.h"
@@ -327,52 +329,64 @@ __global__ __launch_bounds__(SPMV_BLOCK, XL ? 2 : 8) void k_spmv_fused(
         const int gl = tid & (G - 1), gid = tid / G, ngroups = SPMV_BLOCK / G;
 
         // ---- phase 1 loads: (val, col) of the block; indices clamped, not predicated, so
-        // the loads of a round issue back to back (no per-element branch + wait) ----------
+        // the loads of a round issue back to back (no per-element branch + wait).  The first
+        // round runs as straight-line code for exactly the NS = ceil(cnt / 256) slots that hold
+        // nonzeros (uniform switch): with 2-3 nonzeros per (row, panel) a window holds ~730
+        // nonzeros, and a fourth, all-clamped slot is a quarter more memory instructions for the
+        // texture addresser, which is what bounds this kernel (PMC: TA busy 76 % of the launch).
         const int last = cnt > 0 ? cnt - 1 : 0;
-        int kk[4];
-        double a[4];
-        int c[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int t = tid + j * SPMV_BLOCK;
-            kk[j] = t < last ? t : last;
-        }
-        if (cnt > 0) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                a[j] = V8 ? sdict[val8[p0 + kk[j]]] : val[p0 + kk[j]];
-                c[j] = C16 ? cb + (int)col16[p0 + kk[j]] : col[p0 + kk[j]];
-            }
-        }
         // ---- early loads for phase 2: this lane's first row ---------------------------
         const int rfirst = r0 + gid;
         const bool have_row = rfirst < r1s;
         const int rclamp = have_row ? rfirst : r0;
         OffT q0 = 0, q1 = 0, q0b = 0, q1b = 0;
         double y0 = 0.0, y0b = 0.0;
-        if (nr > 0) {
-            q0 = rowptr[rclamp];
-            q1 = rowptr[rclamp + 1];
-            if (!PANEL) y0 = y[rclamp];
-            // the row of this lane's SECOND round too (clamped, unconditional): with 2-3 nonzeros
-            // per (row, panel) a window holds ~290 rows for 256 lanes, and fetching the second
-            // round's bounds only after the first sum put a dependent load on every window
-            const int r2 = rfirst + ngroups < r1s ? rfirst + ngroups : rclamp;
-            q0b = rowptr[r2];
-            q1b = rowptr[r2 + 1];
-            if (!PANEL) y0b = y[r2];
-        }
-        // ---- gather x, stage products ---------------------------------------------------
-        if (cnt > 0) {
-            double xv[4];
+        auto stage = [&](auto ns_tag) {
+            constexpr int NS = decltype(ns_tag)::value;
+            constexpr int NA = NS > 0 ? NS : 1;
+            int kk[NA];
+            double a[NA];
+            int c[NA];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) xv[j] = gx(c[j]);
+            for (int j = 0; j < NS; ++j) {
+                const int t = tid + j * SPMV_BLOCK;
+                kk[j] = t < last ? t : last;
+            }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < NS; ++j) {
+                a[j] = V8 ? sdict[val8[p0 + kk[j]]] : val[p0 + kk[j]];
+                c[j] = C16 ? cb + (int)col16[p0 + kk[j]] : col[p0 + kk[j]];
+            }
+            if (nr > 0) {
+                q0 = rowptr[rclamp];
+                q1 = rowptr[rclamp + 1];
+                if (!PANEL) y0 = y[rclamp];
+                if (nr > ngroups) {  // uniform: this lane's SECOND round too (clamped)
+                    const int r2 = rfirst + ngroups < r1s ? rfirst + ngroups : rclamp;
+                    q0b = rowptr[r2];
+                    q1b = rowptr[r2 + 1];
+                    if (!PANEL) y0b = y[r2];
+                }
+            }
+            double xv[NA];
+#pragma unroll
+            for (int j = 0; j < NS; ++j) xv[j] = gx(c[j]);
+#pragma unroll
+            for (int j = 0; j < NS; ++j) {
                 const int t = tid + j * SPMV_BLOCK;
                 if (t < cnt) prod[t] = a[j] * xv[j];
             }
-            for (int k = tid + 4 * SPMV_BLOCK; k < cnt; k += 4 * SPMV_BLOCK) {  // cnt in (1024, 2C)
+        };
+        if (cnt <= 0) stage(std::integral_constant<int, 0>{});
+        else if (cnt <= SPMV_BLOCK) stage(std::integral_constant<int, 1>{});
+        else if (cnt <= 2 * SPMV_BLOCK) stage(std::integral_constant<int, 2>{});
+        else if (cnt <= 3 * SPMV_BLOCK) stage(std::integral_constant<int, 3>{});
+        else stage(std::integral_constant<int, 4>{});
+        if (cnt > 4 * SPMV_BLOCK) {  // cnt in (1024, 2C): the rest in clamped rounds of four
+            int kk[4];
+            double a[4], xv[4];
+            int c[4];
+            for (int k = tid + 4 * SPMV_BLOCK; k < cnt; k += 4 * SPMV_BLOCK) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int t = k + j * SPMV_BLOCK;
