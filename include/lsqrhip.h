@@ -199,7 +199,7 @@ int lsqrhip_lstp_vectors(lsqrhip_handle_t h, double *xtrue, double *b, double *d
                          const double **d_b);
 
 /* Options: "graph" (1 = hipGraph-captured iteration batches [default], 0 = eager
- * launches), "graph_iters" (iterations per captured batch), "time_kernels"
+ * launches), "graph_iters" (iterations per captured batch, default 64), "time_kernels"
  * (1 = eager launches with HIP events around each hot kernel, fills *_ms above),
  * "pipeline" (launch schedule of the loop; all three give the same bits:
  * 0 = K1 S1 K2 S2 K4 S3, 1 = scalar steps ride inside the SpMV launches,

@@ -176,7 +176,7 @@ struct lsqrhip_handle_s {
     int log_count = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
     // options
-    int use_graph = 1, graph_iters = 32, time_kernels = 0;
+    int use_graph = 1, graph_iters = 64, time_kernels = 0;
     int poll_ahead = 1;  // enqueue the next graph batch before waiting on the current one
     hipEvent_t ev_batch[2] = {nullptr, nullptr};
     hipGraphExec_t gexec = nullptr;
@@ -510,7 +510,10 @@ static int build_csr_T(hipStream_t s, const int *d_keys, const int *d_other, con
         if (rcs != LSQRHIP_OK) return rcs;
     }
     if (out.sell) {
-        int64_t grid = std::min<int64_t>(out.nblk, SPMV_MAX_GRID);
+        // 6 workgroups per CU: measured best at every size (config 2: 25.0 vs 26.1 us per iteration
+        // with 8 per CU; fewer partial sums to re-read, still enough waves for the streams)
+        const int cap = std::min(std::max(env_int("LSQRHIP_SELL_GRID", SELL_MAX_GRID), 8), SPMV_MAX_GRID);
+        int64_t grid = std::min<int64_t>(out.nblk, cap);
         if (grid >= 8) grid &= ~(int64_t)7;
         out.grid = (int)std::max<int64_t>(grid, 1);
         out.out_grid = out.grid;
@@ -586,7 +589,7 @@ static int build_csr_T(hipStream_t s, const int *d_keys, const int *d_other, con
         out.dict = dict;
         out.bytes -= 7 * nnz;
     }
-    int64_t grid = std::min<int64_t>(out.nblk, SPMV_MAX_GRID);
+    int64_t grid = std::min<int64_t>(out.nblk, std::min(std::max(env_int("LSQRHIP_SPMV_GRID", SPMV_MAX_GRID), 8), SPMV_MAX_GRID));
     if (grid >= 8) grid &= ~(int64_t)7;  // multiple of 8: XCD-aware mapping (common.h)
     out.grid = (int)std::max<int64_t>(grid, 1);
     out.out_grid = out.P > 1 ? vec_grid(2 * (int64_t)rows) : out.grid;
@@ -783,12 +786,15 @@ static int new_handle(int m, int n, int64_t nnz, H **out)
     return LSQRHIP_OK;
 }
 
+static int tune_panel_grids(H *h);  // after solve_loop.h (needs the launchers)
+
 extern "C" int lsqrhip_create_from_device_coo(int m, int n, int64_t nnz, const int *d_irow, const int *d_icol,
                                               const double *d_a, lsqrhip_handle_t *out)
 {
     H *h = nullptr;
     RET(new_handle(m, n, nnz, &h));
     int rc = finish_create(h, d_irow, d_icol, d_a);
+    if (rc == LSQRHIP_OK) rc = tune_panel_grids(h);
     if (rc != LSQRHIP_OK) {
         std::string keep = g_last_error;
         lsqrhip_destroy(h);
@@ -846,6 +852,65 @@ extern "C" int lsqrhip_info(lsqrhip_handle_t h, int64_t *dims)
 // ---------------------------------------------------------------------------
 static int op_call(H *h, int mode, double *d_x, double *d_y);  // op_api.h
 #include "solve_loop.h"
+
+// Workgroups of a panelled product (row-window kernel over L2 column panels), chosen by timing.
+// That kernel is bound by the vector-memory pipeline (PMC: texture addressers busy 76 %), and how
+// many workgroups a CU should hold depends on the rows: uniform rows with 2-3 nonzeros per (row,
+// panel) run up to 25 % FASTER with 4 workgroups per CU than with 8 (config 4: 10.4 -> 7.8 ms per
+// product), skewed rows (power law, mode 1) up to 50 % slower.  So each panelled matrix is tried
+// at a few grid sizes once (1 + 2 launches each) and keeps the fastest.  A panelled product's
+// results do not depend on the grid (per-panel row sums, then k_panel_combine with its own grid),
+// so the choice can never change a bit.  LSQRHIP_SPMV_GRID fixes the grid, LSQRHIP_TUNE=0 skips.
+static int tune_one_panel_grid(H *h, Csr &c, const double *x, double *y)
+{
+    if (c.P <= 1 || c.sell || c.xlds == 2 || c.nblk <= 0) return LSQRHIP_OK;
+    if (env_int("LSQRHIP_SPMV_GRID", 0) > 0 || env_int("LSQRHIP_TUNE", 1) == 0) return LSQRHIP_OK;
+    hipStream_t s = h->stream;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    const int original = c.grid;
+    int best = original;
+    float best_ms = 0.f;
+    int rc = LSQRHIP_OK;
+    for (int cand : {SPMV_MAX_GRID, 1536, 1024, 768}) {
+        int64_t g = std::min<int64_t>(c.nblk, cand);
+        if (g >= 8) g &= ~(int64_t)7;
+        if (g < 1 || (cand != SPMV_MAX_GRID && g == original)) continue;
+        c.grid = (int)g;
+        SpmvArgs a;
+        a.c = &c; a.x = x; a.y = y; a.coef = h->d_unit; a.stop = h->d_zero; a.pout = h->partials; a.stream = s;
+        launch_spmv_args(h, a);  // warm
+        if (hipEventRecord(e0, s) != hipSuccess) { rc = LSQRHIP_ERR_HIP; break; }
+        launch_spmv_args(h, a);
+        launch_spmv_args(h, a);
+        if (hipEventRecord(e1, s) != hipSuccess || hipEventSynchronize(e1) != hipSuccess ||
+            hipGetLastError() != hipSuccess) { rc = LSQRHIP_ERR_HIP; break; }
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        if (best_ms == 0.f || ms < 0.97f * best_ms) {  // a smaller grid must win by 3 %
+            best_ms = ms;
+            best = (int)g;
+        }
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    c.grid = rc == LSQRHIP_OK ? best : original;
+    if (rc != LSQRHIP_OK) return fail(rc, "grid tuning of a panelled product failed");
+    return LSQRHIP_OK;
+}
+
+static int tune_panel_grids(H *h)
+{
+    if (h->A.P <= 1 && h->AT.P <= 1) return LSQRHIP_OK;
+    hipStream_t s = h->stream;
+    HIPCHK(hipMemsetAsync(h->U, 0, sizeof(double) * (size_t)std::max(h->m, 1), s));
+    HIPCHK(hipMemsetAsync(h->V, 0, sizeof(double) * (size_t)std::max(h->n, 1), s));
+    RET(tune_one_panel_grid(h, h->A, h->V, h->U));   // mode 1: y (m) += A x (n)
+    RET(tune_one_panel_grid(h, h->AT, h->U, h->V));  // mode 2: x (n) += A' y (m)
+    HIPCHK(hipStreamSynchronize(s));
+    return LSQRHIP_OK;
+}
 
 extern "C" int lsqrhip_solve(lsqrhip_handle_t h, const double *b, double damp, double atol, double btol,
                              double conlim, int itnlim, int wantse, int want_log, double *x, double *se, int *istop,

@@ -43,6 +43,7 @@ namespace lsqrhip {
 constexpr int SELL_BLOCK = 256;                 // 4 slices per workgroup trip
 constexpr int SELL_SLICES = SELL_BLOCK / WAVE;
 constexpr int SELL_MAX_W = 64;
+constexpr int SELL_MAX_GRID = 1536;             // 6 workgroups per CU x 256 CUs (lsqrhip.hip)
 constexpr int SELLP_K = 5;                      // nonzeros per 16-byte record of the packed layout
 
 // width64[s] = 64 * W_s (elements of slice s); stats[0] += 64 W_s, stats[1] = max W,
