@@ -116,16 +116,18 @@ static double run_wide(const int *col, const double *val, const double *x, int64
     return ms / reps;
 }
 
+static int g_grid = 2048;  // workgroups of 256 threads (8 per CU); argv[1] overrides
+
 template <int U>
 static double run(const int *col, const double *val, const double *x, int64_t nnz, double *out, int reps)
 {
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
-    hipLaunchKernelGGL(k_gather<U>, dim3(2048), dim3(256), 0, 0, col, val, x, nnz, out);
+    hipLaunchKernelGGL(k_gather<U>, dim3(g_grid), dim3(256), 0, 0, col, val, x, nnz, out);
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0, 0));
-    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(k_gather<U>, dim3(2048), dim3(256), 0, 0, col, val, x, nnz, out);
+    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(k_gather<U>, dim3(g_grid), dim3(256), 0, 0, col, val, x, nnz, out);
     CK(hipEventRecord(e1, 0));
     CK(hipEventSynchronize(e1));
     float ms = 0;
@@ -133,8 +135,10 @@ static double run(const int *col, const double *val, const double *x, int64_t nn
     return ms / reps;
 }
 
-int main()
+int main(int argc, char **argv)
 {
+    if (argc > 1) g_grid = std::atoi(argv[1]);
+    std::printf("grid %d workgroups of 256 threads\n", g_grid);
     const int64_t nnz = 400000000ll;  // 4.8 GB of (val, col): far beyond every cache
     int *col;
     double *val, *x, *out;
