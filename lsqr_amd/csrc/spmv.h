@@ -59,6 +59,11 @@ constexpr int SPMV_BLOCK = 256;
 constexpr int SPMV_C = 1024;          // window size in work units (nonzeros + rows)
 constexpr int SPMV_LDS = 2 * SPMV_C;  // products staged per row block (doubles)
 constexpr int SPMV_MAX_GRID = 2048;   // 8 workgroups per CU x 256 CUs
+// Nonzeros per lane before a row gets more lanes in phase 2.  16 keeps rows of <= 16 nonzeros on ONE
+// lane (the reference's left-to-right sum, bit for bit); panelled products regroup a row's sum by
+// panel anyway and take more lanes earlier (8: 4M x 1M x 100 -2 %, power law -2 %; 4: power law
+// mode 1 -7 % but 4M x 1M mode 2 +4 %).
+constexpr int SPMV_G_PANEL = 8;
 static_assert(SPMV_BLOCK == VEC_BLOCK, "the fused update runs k_update's blocks");
 
 // rb[k] = first row r in [0, m] with rowptr[r] + r >= k*C ; rb[nblk] = m.  C = window size in work
@@ -324,7 +329,7 @@ __global__ __launch_bounds__(SPMV_BLOCK, XL ? 2 : 8) void k_spmv_fused(
         int G = 1;
         if (nr > 0) {
             const int avg = cnt / nr;
-            while (G < WAVE && avg > 16 * G) G <<= 1;  // uniform
+            while (G < WAVE && avg > (PANEL ? SPMV_G_PANEL : 16) * G) G <<= 1;  // uniform
         }
         const int gl = tid & (G - 1), gid = tid / G, ngroups = SPMV_BLOCK / G;
 
