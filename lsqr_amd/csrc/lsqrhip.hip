@@ -147,6 +147,7 @@ struct Csr {
     int xlds = 0;      // LDS-resident x slices: 1 = spmv.h XL (256-thread), 2 = xl.h (1024-thread workgroups)
     int xgrid = 0;     // grid of the xl.h kernel
     int *gpid = nullptr;  // xl.h: panel of every trip of XLW_WAVES windows
+    unsigned char *skew = nullptr;  // spmv.h: windows of a panelled matrix that hold a segment > SPMV_LONGCUT
     int pw = 0;        // panel width in columns
     int64_t rows_v = 0;  // virtual rows = P * rows (what rowptr / rb / blk index)
     int64_t bytes = 0;
@@ -254,6 +255,7 @@ static void free_csr(Csr &c)
     if (c.val) (void)hipFree(c.val);
     if (c.val8) (void)hipFree(c.val8);
     if (c.soff) (void)hipFree(c.soff);
+    if (c.skew) (void)hipFree(c.skew);
     if (c.srec) (void)hipFree(c.srec);
     if (c.scol) (void)hipFree(c.scol);
     if (c.sval) (void)hipFree(c.sval);
@@ -533,6 +535,21 @@ static int build_csr_T(hipStream_t s, const int *d_keys, const int *d_other, con
     hipLaunchKernelGGL(k_block_desc<OffT>, dim3((unsigned)((out.nblk + 255) / 256)), dim3(256), 0, s,
                        (const OffT *)out.rowptr, (const int *)out.rb, out.nblk, out.blk);
     HIPCHK(hipGetLastError());
+    if (out.P > 1 && out.xlds != 2 && env_int("LSQRHIP_SKEW", 1) != 0) {  // skewed windows (spmv.h phase 2b)
+        HIPCHK(hipMalloc((void **)&out.skew, (size_t)out.nblk));
+        HIPCHK(hipMemsetAsync(d_flags, 0, sizeof(int), s));
+        hipLaunchKernelGGL(k_block_skew<OffT>, dim3((unsigned)((out.nblk + 255) / 256)), dim3(256), 0, s,
+                           (const OffT *)out.rowptr, (const RowBlock *)out.blk, out.nblk, out.skew, d_flags);
+        int any = 0;
+        HIPCHK(hipMemcpyAsync(&any, d_flags, sizeof(int), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        if (!any) {  // nothing to set aside anywhere: the kernel skips the lookup
+            (void)hipFree(out.skew);
+            out.skew = nullptr;
+        } else {
+            out.bytes += out.nblk;
+        }
+    }
     if (out.xlds == 2) {  // xl.h: the panel of every trip of XLW_WAVES windows
         const int64_t ngrp = (out.nblk + XLW_WAVES - 1) / XLW_WAVES;
         HIPCHK(hipMalloc((void **)&out.gpid, sizeof(int) * (size_t)ngrp));

@@ -199,7 +199,36 @@ struct XlArgs {
     int rows;   // real rows of the product (virtual row v = panel * rows + r)
     int pw;     // panel width in columns (<= XL_COLS when XL)
     int ncols;  // columns of the matrix
+    const unsigned char *skew;  // PANEL: skew[b] != 0 = window b holds a segment > SPMV_LONGCUT (or null)
 };
+
+// Skewed windows (power-law rows cut by panels: a third of the nonzeros sit in segments of more than
+// 64 while the window's mean is 3).  Phase 2 gives every row the lanes the window's MEAN calls
+// for, so one lane would walk such a segment alone while the workgroup waits.  In windows the
+// build has flagged, segments longer than SPMV_LONGCUT are set aside in phase 2 and summed
+// afterwards by a whole wave each (stride-64 partial sums + shuffle tree).  Panelled products only:
+// their kernel carries no sum of squares, so which wave takes which segment cannot change a bit.
+constexpr int SPMV_LONGCUT = 128;
+constexpr int SPMV_MAXLONG = 2 * SPMV_C / SPMV_LONGCUT;  // segments > LONGCUT in one window (< 2C nonzeros)
+
+template <typename OffT>
+__global__ void k_block_skew(const OffT *__restrict__ rowptr, const RowBlock *__restrict__ blk, int64_t nblk,
+                             unsigned char *__restrict__ skew, int *__restrict__ any)
+{
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nblk) return;
+    const RowBlock d = blk[b];
+    int r1s = d.r1;
+    if (d.r0 < d.r1 && d.pend - d.plast >= (long long)SPMV_C) r1s = d.r1 - 1;  // phase 3 takes that one
+    unsigned char f = 0;
+    for (int r = d.r0; r < r1s; ++r)
+        if ((long long)rowptr[r + 1] - (long long)rowptr[r] > SPMV_LONGCUT) {
+            f = 1;
+            break;
+        }
+    skew[b] = f;
+    if (f) *any = 1;
+}
 
 template <typename OffT, bool PANEL, bool C16, bool V8, bool UPD, bool XL = false>
 __global__ __launch_bounds__(SPMV_BLOCK, XL ? 2 : 8) void k_spmv_fused(
@@ -213,6 +242,8 @@ __global__ __launch_bounds__(SPMV_BLOCK, XL ? 2 : 8) void k_spmv_fused(
     __shared__ double xs[XL ? XL_COLS : 1];
     __shared__ double red[SPMV_BLOCK / WAVE + 1];
     __shared__ double sdict[V8 ? VD_MAX : 1];
+    __shared__ int longlist[PANEL ? SPMV_MAXLONG : 1];
+    __shared__ int nlong;
     // One extra workgroup carries scalar work (scalar.h "riders").  It is block 0, the first
     // one dispatched, so it runs beside the SpMV from the start (as the LAST block of a grid
     // that exceeds the resident slots it would only start when the first SpMV block retires).
@@ -305,6 +336,8 @@ __global__ __launch_bounds__(SPMV_BLOCK, XL ? 2 : 8) void k_spmv_fused(
         }
         const int r0 = cur.r0, r1 = cur.r1;
         if (r0 >= r1) continue;  // uniform
+        const bool skewed = PANEL && xa.skew != nullptr && xa.skew[b] != 0;  // uniform
+        if (skewed && tid == 0) nlong = 0;  // visible after the barrier that ends phase 1
         if (XL) {  // this window's panel slice of x (times sx) into LDS, when it changes
             const int pid = r0 / xa.rows;
             if (pid != xpid) {  // uniform; the barrier at the end of the last trip covers xs
@@ -419,10 +452,15 @@ __global__ __launch_bounds__(SPMV_BLOCK, XL ? 2 : 8) void k_spmv_fused(
             for (;;) {
                 const int s0 = (int)(q0 - p0), s1 = (int)(q1 - p0);
                 double s = 0.0;
-                for (int k = s0 + gl; k < s1; k += G) s = s + prod[k];
-                for (int off = G >> 1; off > 0; off >>= 1) s += __shfl_xor(s, off, WAVE);
+                const bool aside = skewed && s1 - s0 > SPMV_LONGCUT;  // the same for the G lanes of a row
+                if (!aside) {
+                    for (int k = s0 + gl; k < s1; k += G) s = s + prod[k];
+                    for (int off = G >> 1; off > 0; off >>= 1) s += __shfl_xor(s, off, WAVE);
+                }
                 if (gl == 0) {
-                    if (PANEL) {
+                    if (aside) {
+                        longlist[atomicAdd(&nlong, 1)] = r;
+                    } else if (PANEL) {
                         y[r] = s;  // z[v]: raw sum of this (panel, row) segment
                     } else {
                         const double yn = cy * (y0 * sy) + s;
@@ -441,6 +479,21 @@ __global__ __launch_bounds__(SPMV_BLOCK, XL ? 2 : 8) void k_spmv_fused(
                     q1 = rowptr[r + 1];
                     if (!PANEL) y0 = y[r];
                 }
+            }
+        }
+
+        // ---- phase 2b: the segments set aside in a skewed window, one wave each --------
+        if (skewed) {
+            __syncthreads();
+            const int nl = nlong;
+            const int lane = tid & (WAVE - 1);
+            for (int i = tid >> 6; i < nl; i += SPMV_BLOCK / WAVE) {
+                const int r = longlist[i];
+                const int s0 = (int)(rowptr[r] - p0), s1 = (int)(rowptr[r + 1] - p0);
+                double s = 0.0;
+                for (int k = s0 + lane; k < s1; k += WAVE) s = s + prod[k];
+                s = wave_sum(s);
+                if (lane == 0) y[r] = s;
             }
         }
 
