@@ -57,6 +57,55 @@ def test_panelled_aprod_and_solve_match_oracle(forced_panels, shape):
     assert np.array_equal(r.x, r3.x) and r.anorm == r3.anorm          # both schedules, same bits
 
 
+def test_skewed_windows_set_long_segments_aside(forced_panels):
+    """Power-law rows cut by 4 panels: windows whose mean segment is ~5 hold segments of 130-1000
+    (and a few >= 1024 for phase 3).  The build flags those windows and a whole wave sums each
+    long segment after phase 2 (spmv.h "phase 2b").  Against the oracle to rounding, identical
+    from run to run and across schedules, and agreeing with the unflagged path (LSQRHIP_SKEW=0:
+    every segment on the lanes its window's mean calls for) to rounding."""
+    p = P.powerlaw_rows(6000, 30000, seed=11, dmin=4, dmax=5000, gamma=1.6, damp=1e-3)
+    deg = np.bincount(p.irow - 1, minlength=p.m)
+    assert (deg > 4 * 140).sum() > 20 and deg.max() >= 4096        # long segments and a phase-3 row
+    po = oracle.port()
+    xp = P.u64_to_unit(P.rng_u64(101, 9, np.arange(p.n, dtype=np.uint64)))
+    yp = P.u64_to_unit(P.rng_u64(102, 9, np.arange(p.m, dtype=np.uint64)))
+    _, y_ref = po.aprod(1, p.m, p.n, p.irow, p.icol, p.a, xp, yp)
+    x_ref, _ = po.aprod(2, p.m, p.n, p.irow, p.icol, p.a, xp, yp)
+    o = po.solve(p.m, p.n, p.irow, p.icol, p.a, p.b, damp=1e-3, itnlim=10)
+    res = {}
+    for skew in ("1", "0"):
+        os.environ["LSQRHIP_SKEW"] = skew
+        os.environ["LSQRHIP_XLDS"] = "0"            # L2 panels (rows this dense would go to LDS panels)
+        try:
+            s = lsqr_solver_ez().initialize(p.m, p.n, p.a, p.irow, p.icol, itnlim=10)
+            assert s.info()["panels"] == 4 and s.info()["xlds"] == 0
+            x, y = xp.copy(), yp.copy()
+            s.aprod(1, p.m, p.n, x, y)
+            assert np.max(np.abs(y - y_ref)) <= 1e-13 * np.max(np.abs(y_ref))
+            y1 = y.copy()
+            x, y = xp.copy(), yp.copy()
+            s.aprod(1, p.m, p.n, x, y)
+            assert np.array_equal(y, y1)                                 # which wave takes which segment never shows
+            x, y = xp.copy(), yp.copy()
+            s.aprod(2, p.m, p.n, x, y)
+            assert np.max(np.abs(x - x_ref)) <= 1e-13 * np.max(np.abs(x_ref))
+            out = []
+            for pipeline in (0, 1, 2):
+                s.set_option("pipeline", pipeline)
+                r = s.solve(p.b, 1e-3)
+                assert (r.istop, r.itn) == (o.istop, o.itn)
+                assert np.linalg.norm(r.x - o.x) <= 1e-9 * np.linalg.norm(o.x)
+                out.append(r)
+            assert all(np.array_equal(out[0].x, r.x) and out[0].anorm == r.anorm for r in out[1:])
+            res[skew] = (y1, out[0])
+        finally:
+            os.environ.pop("LSQRHIP_SKEW", None)
+            os.environ.pop("LSQRHIP_XLDS", None)
+    assert not np.array_equal(res["1"][0], res["0"][0])                   # the flagged path really ran
+    assert np.max(np.abs(res["1"][0] - res["0"][0])) <= 1e-13 * np.max(np.abs(y_ref))
+    assert np.linalg.norm(res["1"][1].x - res["0"][1].x) <= 1e-9 * np.linalg.norm(o.x)
+
+
 def test_panels_are_not_used_for_banded_matrices():
     """Auto mode keeps the plain CSR for a banded system even when x exceeds L2: the aprod
     result stays bit-identical to the reference's row sums (only the plain path is)."""
