@@ -33,7 +33,8 @@ namespace lsqrhip {
 constexpr int XLW_BLOCK = 1024;
 constexpr int XLW_WAVES = XLW_BLOCK / WAVE;  // 16 windows per trip
 constexpr int XLW_C = 256;                   // window size in work units (nonzeros + rows)
-constexpr int XLW_U = 8;                     // nonzeros in flight per lane: 2 * XLW_C = 8 * 64
+constexpr int XLW_U = 4;                     // nonzeros per lane issued a trip ahead: XLW_C = 4 * 64; the rest
+                                             // of a window (< 2 * XLW_C nonzeros: a long last row) is fetched late
 
 // 16-bit columns for the wave-window layout: relative to the first column of the panel the
 // window STARTS in.  A window reaches at most into the next panel, so the offsets stay below
@@ -232,6 +233,15 @@ __global__ __launch_bounds__(XLW_BLOCK, 1) void k_spmv_xlw(
             const int e = lane + j * WAVE;
             const double a = V8 ? sdict[(int)av[j]] : (double)av[j];
             if (e < cnt) myprod[e] = a * gx(cb + cv[j]);
+        }
+        // A window holds XLW_C units = nonzeros + rows, so only one whose last row runs long has
+        // more than XLW_U * 64 nonzeros (config 3: 224 per window): those few are fetched here,
+        // un-pipelined, instead of doubling the loads every window issues ahead (half of which
+        // were clamped duplicates).
+        for (int e = lane + XLW_U * WAVE; e < cnt; e += WAVE) {
+            const double a = V8 ? sdict[val8[p0 + e]] : val[p0 + e];
+            const int c = C16 ? (int)col16[p0 + e] : col[p0 + e];
+            myprod[e] = a * gx(cb + c);
         }
         __builtin_amdgcn_wave_barrier();  // same wave, in-order LDS queue: the products are visible
         // phase 2: row sums out of this wave's products
