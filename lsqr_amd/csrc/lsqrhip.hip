@@ -624,7 +624,7 @@ static int build_csr_T(hipStream_t s, const int *d_keys, const int *d_other, con
 //   LSQRHIP_PANEL_KB  panel size in KiB of x (default 2048: half an XCD's 4 MiB L2, the rest streams;
 //                     swept 1024 / 2560 / 3584: profiles/r01/sweep_panels.txt)
 //   LSQRHIP_XLDS      0 never | 1 whenever x exceeds one LDS panel | unset: scattered columns and
-//                     >= 1.6 nonzeros per (row, LDS panel) -- panels of LSQRHIP_XLDS_COLS (7168) columns
+//                     >= 1.3 nonzeros per (row, LDS panel) -- panels of LSQRHIP_XLDS_COLS (7168) columns
 //                     whose x slice lives in LDS (spmv.h XL): gathers stop being the bound
 static void choose_panels(int rows, int cols, int64_t nnz, double mean_dev, int *panels, int *pw, int *xlds)
 {
@@ -642,9 +642,10 @@ static void choose_panels(int rows, int cols, int64_t nnz, double mean_dev, int 
                                                            ~(int64_t)1023);
         const int64_t Pl = ((int64_t)cols + wl - 1) / wl;
         const bool fits = Pl > 1 && Pl * (int64_t)rows < (1ll << 31);
-        // measured crossover against L2 panels (4M x 1M, r per row; ms per product L2 / LDS): r = 150
-        // (1.1 per virtual row) 3.8 / 4.3, r = 200 (1.4) 4.9 / 4.9, r = 300 (2.1) 7.4 / 6.1, r = 600 14.8 / 8.7
-        const bool dense = 10 * nnz >= 16 * Pl * (int64_t)rows;
+        // measured crossover against L2 panels (4M x 1M, r per row; ms per product L2 / LDS, both with
+        // this round's kernels): r = 100 (0.7 per virtual row) 2.3 / 3.7, r = 150 (1.1) 3.4 / 3.7,
+        // r = 200 (1.4) 4.6 / 4.3, r = 300 (2.1) 7.4 / 4.7, r = 600 14.8 / 8.0
+        const bool dense = 10 * nnz >= 13 * Pl * (int64_t)rows;
         if (fits && (xmode == 1 || (scattered && dense && (int64_t)cols > 2 * width))) {
             *panels = (int)Pl;
             *pw = (int)wl;

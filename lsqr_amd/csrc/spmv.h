@@ -189,7 +189,7 @@ __global__ void k_block_desc(const OffT *__restrict__ rowptr, const int *__restr
 // XL = true (PANEL only): LDS-resident panels.  When the panel width is <= XL_COLS the current
 // panel's slice of x (already multiplied by sx) is held in LDS and the gathers never leave the
 // CU: the product is then bound by streaming (val, col), not by the ~0.29 L1 misses per clock a
-// CU can retire.  Needs >= ~1.6 nonzeros per virtual row to pay for the partial
+// CU can retire.  Needs >= ~1.3 nonzeros per virtual row to pay for the partial
 // sums of its many narrow panels: BASELINE config 3 at its literal 1000 per row.  72 KB of LDS
 // per workgroup -> 2 workgroups per CU.  The few entries of a window that reaches into the
 // next panel are gathered from global memory.
