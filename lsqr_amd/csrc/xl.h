@@ -9,7 +9,7 @@
 // barriers, so the memory pipe idles just the same).
 //
 // Here ONE 1024-thread workgroup per CU owns the 56 KB slice and each of its 16 WAVES runs
-// windows of its own (XLW_C = 256 work units, built with that window size) with no workgroup
+// windows of its own (XLW_C = 512 work units, built with that window size) with no workgroup
 // barrier at all: a wave streams its window (up to 8 nonzeros in flight per lane), gathers from
 // the slice, stages the products in its private 4 KB of LDS (in-order LDS queue: no barrier
 // needed inside a wave), forms the row sums and moves on.  Sixteen independent streams per CU
@@ -32,10 +32,14 @@ namespace lsqrhip {
 
 constexpr int XLW_BLOCK = 1024;
 constexpr int XLW_WAVES = XLW_BLOCK / WAVE;  // 16 windows per trip
-constexpr int XLW_C = 384;                   // window size in work units (nonzeros + rows); 256 / 320 / 384:
-                                             // 11.8 / 10.9 / 10.2 ms per product at config 3 literal; LDS-bound
-constexpr int XLW_U = 6;                     // nonzeros per lane issued a trip ahead: XLW_C = 6 * 64; the rest
+constexpr int XLW_C = 512;                   // window size in work units (nonzeros + rows); 256 / 320 / 384 /
+                                             // 512: 11.8 / 10.9 / 10.2 / 9.9 ms per product at config 3 literal
+constexpr int XLW_U = 8;                     // nonzeros per lane issued a trip ahead: XLW_C = 8 * 64; the rest
                                              // of a window (< 2 * XLW_C nonzeros: a long last row) is fetched late
+
+// A last row of XLW_LONG nonzeros or more is streamed by the wave (phase 3) instead of staged, so a
+// window stages fewer than XLW_C + XLW_LONG products: that bound, not 2 * XLW_C, sizes the LDS.
+constexpr int XLW_LONG = XLW_C / 2;
 
 // 16-bit columns for the wave-window layout: relative to the first column of the panel the
 // window STARTS in.  A window reaches at most into the next panel, so the offsets stay below
@@ -82,7 +86,7 @@ __global__ __launch_bounds__(XLW_BLOCK, 1) void k_spmv_xlw(
     int skip_if_zero, Rider rider, XlArgs xa)
 {
     __shared__ double xs[XL_COLS];
-    __shared__ double prod[XLW_WAVES][2 * XLW_C];
+    __shared__ double prod[XLW_WAVES][XLW_C + XLW_LONG];
     __shared__ double red[SC_BLOCK / WAVE + 1];
     __shared__ double sdict[V8 ? VD_MAX : 1];
     __shared__ double bcast;
@@ -176,7 +180,7 @@ __global__ __launch_bounds__(XLW_BLOCK, 1) void k_spmv_xlw(
     // element 0 / row 0 and ignores them).  With loads under `if`s the number outstanding depends
     // on the path and the compiler must then wait for far more than the previous window's data.
     auto load_head = [&](const RowBlock &q, RawV (&av)[XLW_U], int (&cv)[XLW_U], OffT &qa, OffT &qb) {
-        const bool hl = (q.pend - q.plast) >= (long long)XLW_C;
+        const bool hl = (q.pend - q.plast) >= (long long)XLW_LONG;
         const int nq = q.r0 < q.r1 ? (int)((hl ? q.plast : q.pend) - q.p0) : 0;
         const int r1q = hl ? q.r1 - 1 : q.r1;
         const int Gq = lanes_per_row(nq, r1q - q.r0);
@@ -219,9 +223,9 @@ __global__ __launch_bounds__(XLW_BLOCK, 1) void k_spmv_xlw(
         const int r0 = cur.r0, r1 = cur.r1;
         if (r0 >= r1) return;
         const OffT p0 = (OffT)cur.p0, plast = (OffT)cur.plast, pend = (OffT)cur.pend;
-        const bool has_long = (pend - plast) >= (OffT)XLW_C;
+        const bool has_long = (pend - plast) >= (OffT)XLW_LONG;
         const int r1s = has_long ? r1 - 1 : r1;
-        const int cnt = (int)((has_long ? plast : pend) - p0);  // < 2 * XLW_C
+        const int cnt = (int)((has_long ? plast : pend) - p0);  // < XLW_C + XLW_LONG
         const int nr = r1s - r0;
         const int G = lanes_per_row(cnt, nr);
         const int gl = lane & (G - 1), gid = lane / G, ngroups = WAVE / G;
