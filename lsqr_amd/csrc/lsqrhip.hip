@@ -147,6 +147,7 @@ struct Csr {
     int xlds = 0;      // LDS-resident x slices: 1 = spmv.h XL (256-thread), 2 = xl.h (1024-thread workgroups)
     int xgrid = 0;     // grid of the xl.h kernel
     int *gpid = nullptr;  // xl.h: panel of every trip of XLW_WAVES windows
+    unsigned short *rel16 = nullptr;  // xl.h: 16-bit row starts relative to their window (rowptr is then released)
     unsigned char *skew = nullptr;  // spmv.h: windows of a panelled matrix that hold a segment > SPMV_LONGCUT
     int pw = 0;        // panel width in columns
     int64_t rows_v = 0;  // virtual rows = P * rows (what rowptr / rb / blk index)
@@ -256,6 +257,7 @@ static void free_csr(Csr &c)
     if (c.val8) (void)hipFree(c.val8);
     if (c.soff) (void)hipFree(c.soff);
     if (c.skew) (void)hipFree(c.skew);
+    if (c.rel16) (void)hipFree(c.rel16);
     if (c.srec) (void)hipFree(c.srec);
     if (c.scol) (void)hipFree(c.scol);
     if (c.sval) (void)hipFree(c.sval);
@@ -568,6 +570,16 @@ static int build_csr_T(hipStream_t s, const int *d_keys, const int *d_other, con
         (void)hipFree(out.col);
         out.col = nullptr;
         out.bytes -= 2 * nnz;
+        // ... and 16-bit row bounds relative to the same windows; the row pointers are no longer needed
+        HIPCHK(hipMalloc((void **)&out.rel16, sizeof(unsigned short) * ((size_t)rows_v + 2)));
+        HIPCHK(hipMemsetAsync(out.rel16, 0, sizeof(unsigned short) * ((size_t)rows_v + 2), s));
+        hipLaunchKernelGGL(k_xl_rel16<OffT>, dim3(gb), dim3(256), 0, s, (const RowBlock *)out.blk, out.nblk,
+                           (const OffT *)out.rowptr, out.rel16);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(s));
+        (void)hipFree(out.rowptr);
+        out.rowptr = nullptr;
+        out.bytes -= (int64_t)(sizeof(OffT) - 2) * rows_v;
     }
     // 16-bit block-relative columns when every row block is narrower than 65536 columns
     // (LSQRHIP_COL16=0 keeps 32-bit indices)

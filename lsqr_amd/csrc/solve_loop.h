@@ -72,7 +72,7 @@ static void launch_spmv_C(const SpmvArgs &a, double *y, hipEvent_t e0, hipEvent_
     const dim3 grid(c.grid + (a.rider.kind != 0 ? 1 : 0));
     const void *colv = C16 ? (const void *)c.col16 : (const void *)c.col;
     const void *valv = V8 ? (const void *)c.val8 : (const void *)c.val;
-    const XlArgs xa{c.rows, c.pw, c.cols, c.skew};
+    const XlArgs xa{c.rows, c.pw, c.cols, c.skew, c.rel16};
     if (e0 == nullptr && e1 == nullptr)  // plain launch (the only form used under stream capture)
         hipLaunchKernelGGL((k_spmv_fused<OffT, PANEL, C16, V8, UPD, XL>), grid, dim3(SPMV_BLOCK), 0, a.stream,
                            (const OffT *)c.rowptr, colv, (const int *)c.cbase, valv, (const double *)c.dict,
@@ -155,7 +155,7 @@ static void launch_xl_C(const SpmvArgs &a, double *z)
     const dim3 grid(c.xgrid + (a.rider.kind != 0 ? 1 : 0));
     const void *valv = V8 ? (const void *)c.val8 : (const void *)c.val;
     const void *colv = C16 ? (const void *)c.col16 : (const void *)c.col;
-    const XlArgs xa{c.rows, c.pw, c.cols, c.skew};
+    const XlArgs xa{c.rows, c.pw, c.cols, c.skew, c.rel16};
     if (a.e0 == nullptr)
         hipLaunchKernelGGL((k_spmv_xlw<OffT, V8, C16>), grid, dim3(XLW_BLOCK), 0, a.stream, (const OffT *)c.rowptr,
                            colv, valv, (const double *)c.dict, (const RowBlock *)c.blk, c.nblk, (const int *)c.gpid, a.x, z,

@@ -200,6 +200,7 @@ struct XlArgs {
     int pw;     // panel width in columns (<= XL_COLS when XL)
     int ncols;  // columns of the matrix
     const unsigned char *skew;  // PANEL: skew[b] != 0 = window b holds a segment > SPMV_LONGCUT (or null)
+    const unsigned short *rel16;  // xl.h C16: row starts relative to their window's first nonzero
 };
 
 // Skewed windows (power-law rows cut by panels: a third of the nonzeros sit in segments of more than

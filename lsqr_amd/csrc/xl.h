@@ -58,6 +58,23 @@ __global__ __launch_bounds__(256) void k_xl_col16(const RowBlock *__restrict__ b
     }
 }
 
+// 16-bit row bounds to go with them: rel16[v] = rowptr[v] - p0 of the window that owns virtual row v.
+// Every row of a window STARTS within the window's XLW_C work units, so the offsets are < XLW_C; a
+// row ends where the next one starts, the last row of a window at the descriptor's `pend`.  The
+// product then reads 2 bytes per (row, panel) instead of the 8-byte row pointer (config 3 literal:
+// 1.1 GB instead of 4.5 GB per product), and the row pointers are released.  One wave per window.
+template <typename OffT>
+__global__ __launch_bounds__(256) void k_xl_rel16(const RowBlock *__restrict__ blk, int64_t nblk,
+                                                  const OffT *__restrict__ rowptr, unsigned short *__restrict__ rel16)
+{
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int64_t nw = (int64_t)gridDim.x * (256 / WAVE);
+    for (int64_t b = (int64_t)blockIdx.x * (256 / WAVE) + (threadIdx.x >> 6); b < nblk; b += nw) {
+        const RowBlock q = blk[b];
+        for (int r = q.r0 + lane; r < q.r1; r += WAVE) rel16[r] = (unsigned short)((long long)rowptr[r] - q.p0);
+    }
+}
+
 // gpid[g] = panel of the first non-empty window of trip g (XLW_WAVES windows), -1 if all are empty:
 // the kernel then learns a trip's slice from one prefetched word instead of scanning descriptors.
 __global__ __launch_bounds__(256) void k_xl_group_panel(const RowBlock *__restrict__ blk, int64_t nblk, int rows,
@@ -76,7 +93,8 @@ __global__ __launch_bounds__(256) void k_xl_group_panel(const RowBlock *__restri
     gpid[g] = pid;
 }
 
-// C16 = true: 16-bit window-relative columns (k_xl_col16).
+// C16 = true: 16-bit window-relative columns (k_xl_col16) and row bounds (k_xl_rel16, xa.rel16; rowptr
+// is then null).
 template <typename OffT, bool V8, bool C16>
 __global__ __launch_bounds__(XLW_BLOCK, 1) void k_spmv_xlw(
     const OffT *__restrict__ rowptr, const void *__restrict__ colv, const void *__restrict__ valv,
@@ -186,8 +204,14 @@ __global__ __launch_bounds__(XLW_BLOCK, 1) void k_spmv_xlw(
         const int Gq = lanes_per_row(nq, r1q - q.r0);
         int rf = q.r0 + lane / Gq;
         rf = rf < r1q ? rf : (r1q > q.r0 ? r1q - 1 : q.r0);  // clamped: a valid virtual row
-        qa = rowptr[rf];
-        qb = rowptr[rf + 1];
+        if (C16) {  // raw 16-bit starts of this row and the next (the next may belong to another window:
+                    // process() then takes the descriptor's end instead)
+            qa = (OffT)xa.rel16[rf];
+            qb = (OffT)xa.rel16[rf + 1];
+        } else {
+            qa = rowptr[rf];
+            qb = rowptr[rf + 1];
+        }
         const int lastq = nq > 0 ? nq - 1 : 0;
         const OffT qp = (OffT)q.p0;
 #pragma unroll
@@ -252,16 +276,23 @@ __global__ __launch_bounds__(XLW_BLOCK, 1) void k_spmv_xlw(
         // phase 2: row sums out of this wave's products
         if (have_row) {
             int r = rfirst;
+            const int wend = (int)(pend - p0);  // where the window's last row ends
             for (;;) {
-                const int s0 = (int)(q0 - p0), s1 = (int)(q1 - p0);
+                const int s0 = C16 ? (int)q0 : (int)(q0 - p0);
+                const int s1 = C16 ? (r + 1 < r1 ? (int)q1 : wend) : (int)(q1 - p0);
                 double sum = 0.0;
                 for (int k = s0 + gl; k < s1; k += G) sum = sum + myprod[k];
                 for (int off = G >> 1; off > 0; off >>= 1) sum += __shfl_xor(sum, off, WAVE);
                 if (gl == 0) z[r] = sum;
                 r += ngroups;
                 if (r >= r1s) break;
-                q0 = rowptr[r];
-                q1 = rowptr[r + 1];
+                if (C16) {
+                    q0 = (OffT)xa.rel16[r];
+                    q1 = (OffT)xa.rel16[r + 1];
+                } else {
+                    q0 = rowptr[r];
+                    q1 = rowptr[r + 1];
+                }
             }
         }
         // phase 3: a long last row, split across the wave
