@@ -1,0 +1,116 @@
+#!/usr/bin/env python3
+"""Random small systems through every layout (forced by the knobs) against the oracle's aprod and a
+short solve.  Edge cases on purpose: empty rows / columns, one very long row, m < n, m > n, nnz = 0,
+duplicates, dictionary and non-dictionary values.  usage: fuzz_layouts.py [ncases] [seed]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import oracle
+from lsqr_amd.solver import lsqr_solver_ez
+
+KNOBS = ["LSQRHIP_SELL", "LSQRHIP_SELLP", "LSQRHIP_VAL8", "LSQRHIP_COL16", "LSQRHIP_PANELS", "LSQRHIP_PANEL_KB",
+         "LSQRHIP_XLDS", "LSQRHIP_XLDS_COLS", "LSQRHIP_OFF64", "LSQRHIP_SKEW", "LSQRHIP_TUNE"]
+LAYOUTS = [
+    {},                                                                        # whatever the build chooses
+    {"LSQRHIP_SELL": "0"},
+    {"LSQRHIP_PANELS": "1", "LSQRHIP_PANEL_KB": "64", "LSQRHIP_XLDS": "0"},    # L2 panels (8192 columns)
+    {"LSQRHIP_PANELS": "1", "LSQRHIP_PANEL_KB": "64", "LSQRHIP_XLDS": "0", "LSQRHIP_OFF64": "1", "LSQRHIP_SKEW": "0"},
+    {"LSQRHIP_XLDS": "1", "LSQRHIP_XLDS_COLS": "1024"},                        # LDS panels (1024 columns)
+    {"LSQRHIP_XLDS": "1", "LSQRHIP_XLDS_COLS": "1024", "LSQRHIP_COL16": "0", "LSQRHIP_OFF64": "1"},
+    {"LSQRHIP_SELL": "1", "LSQRHIP_SELLP": "0"},
+]
+
+
+def make_case(rs):
+    kind = rs.randint(0, 6)
+    m = int(rs.choice([1, 2, 63, 64, 65, 300, 1000, 5000, 20000]))
+    n = int(rs.choice([1, 2, 63, 64, 65, 300, 1000, 5000, 30000]))
+    if kind == 0:      # uniform sparse
+        per = rs.randint(0, 12)
+        irow = np.repeat(np.arange(m), per); icol = rs.randint(0, n, size=irow.size)
+    elif kind == 1:    # banded (SELL territory)
+        offs = rs.choice(np.arange(-5, 6), size=rs.randint(1, 6), replace=False)
+        r = np.arange(m); rows = []; cols = []
+        for o in offs:
+            c = r * n // max(m, 1) + o
+            ok = (c >= 0) & (c < n) & (rs.rand(m) > 0.05)
+            rows.append(r[ok]); cols.append(c[ok])
+        irow = np.concatenate(rows); icol = np.concatenate(cols)
+    elif kind == 2:    # power law with a few very long rows
+        deg = np.minimum((rs.pareto(1.2, size=m) * 3).astype(int), 4 * n)
+        deg[rs.randint(0, m)] = min(6000, 4 * n)
+        irow = np.repeat(np.arange(m), deg); icol = rs.randint(0, n, size=irow.size)
+    elif kind == 3:    # empty matrix / nearly empty
+        k = rs.randint(0, 3)
+        irow = rs.randint(0, m, size=k); icol = rs.randint(0, n, size=k)
+    elif kind == 4:    # dense-ish rows (LDS panel territory)
+        per = rs.randint(50, 400)
+        mm = min(m, 400)
+        irow = np.repeat(np.arange(mm), per); icol = rs.randint(0, n, size=irow.size)
+    else:              # a few dense columns + random
+        k = rs.randint(1, 4000)
+        irow = rs.randint(0, m, size=k); icol = np.where(rs.rand(k) < 0.3, rs.randint(0, min(n, 3), size=k), rs.randint(0, n, size=k))
+    if rs.rand() < 0.5:
+        a = rs.choice([-1.0, 4.0, 0.5, -0.0, 2.25], size=irow.size)            # dictionary
+    else:
+        a = rs.uniform(-1, 1, size=irow.size)
+    perm = rs.permutation(irow.size) if rs.rand() < 0.5 else np.arange(irow.size)
+    irow, icol, a = irow[perm], icol[perm], a[perm]
+    b = rs.uniform(-1, 1, size=m)
+    return m, n, (irow + 1).astype(np.int32), (icol + 1).astype(np.int32), a.astype(np.float64), b
+
+
+def run(ncases, seed, verbose=True):
+    rs = np.random.RandomState(seed)
+    po = oracle.port()
+    bad = 0
+    for case in range(ncases):
+        m, n, irow, icol, a, b = make_case(rs)
+        xp, yp = rs.uniform(-1, 1, size=n), rs.uniform(-1, 1, size=m)
+        _, y_ref = po.aprod(1, m, n, irow, icol, a, xp, yp)
+        x_ref, _ = po.aprod(2, m, n, irow, icol, a, xp, yp)
+        o = po.solve(m, n, irow, icol, a, b, damp=1e-2, itnlim=6)
+        for lay in LAYOUTS:
+            for k in KNOBS:
+                os.environ.pop(k, None)
+            os.environ.update(lay)
+            try:
+                s = lsqr_solver_ez().initialize(m, n, a, irow, icol, itnlim=6)
+                x, y = xp.copy(), yp.copy()
+                s.aprod(1, m, n, x, y)
+                e1 = np.max(np.abs(y - y_ref)) / max(np.max(np.abs(y_ref)), 1.0)
+                x, y = xp.copy(), yp.copy()
+                s.aprod(2, m, n, x, y)
+                e2 = np.max(np.abs(x - x_ref)) / max(np.max(np.abs(x_ref)), 1.0)
+                r = s.solve(b, 1e-2)
+                e3 = np.linalg.norm(r.x - o.x) / max(np.linalg.norm(o.x), 1e-300) if o.itn > 0 else float(np.max(np.abs(r.x)))
+                # 6 iterations at most; a system that converges to machine precision earlier may stop one
+                # iteration apart (eps-level tests): x must agree either way
+                # rows (or columns, for mode 2) longer than 16 are summed by several lanes -- a tree, not the
+                # reference's left-to-right sum -- and LSQR amplifies that rounding difference: on a 64 x 1000
+                # system with one 4000-entry row the reference itself moves x by 5e-4 .. 5e-3 in 6 iterations
+                # when its COO input is permuted.  The products above are the layout check;
+                # the solve is held to 1e-9 only where every sum is the reference's own.
+                longest = max(int(np.bincount(irow - 1, minlength=m).max()), int(np.bincount(icol - 1, minlength=n).max())) if irow.size else 0
+                tol3 = 1e-9 if longest <= 16 else 0.1
+                # an eps-level stopping test (1 + test2 <= 1) that fires for one and not the other at the
+                # same iteration changes istop but not x: accepted when x agrees to 1e-12
+                # (a 2-row system is solved exactly after 2 iterations; the reference runs 2 more on noise)
+                ok = e1 < 1e-12 and e2 < 1e-12 and (e3 < 1e-12 or (e3 < tol3 and abs(r.itn - o.itn) <= 1 and
+                                                                    (r.istop == o.istop or r.itn != o.itn)))
+                info = s.info()
+            except Exception as ex:        # noqa: BLE001
+                ok, e1, e2, e3, info = False, -1, -1, -1, repr(ex)
+            if not ok:
+                bad += 1
+                ri, rn = (r.istop, r.itn) if e1 >= 0 else (None, None)
+                print(f"FAIL case {case} m={m} n={n} nnz={irow.size} layout={lay} e1={e1:.2e} e2={e2:.2e} e3={e3:.2e} istop {ri}/{o.istop} itn {rn}/{o.itn} {info}", flush=True)
+    for k in KNOBS:
+        os.environ.pop(k, None)
+    if verbose:
+        print(f"{ncases} cases x {len(LAYOUTS)} layouts: {bad} failures")
+    return bad
+
+
+if __name__ == "__main__":
+    sys.exit(1 if run(int(sys.argv[1]) if len(sys.argv) > 1 else 60, int(sys.argv[2]) if len(sys.argv) > 2 else 1) else 0)
