@@ -11,9 +11,11 @@
 // Here ONE 1024-thread workgroup per CU owns the 56 KB slice and each of its 16 WAVES runs
 // windows of its own (XLW_C = 512 work units, built with that window size) with no workgroup
 // barrier at all: a wave streams its window (up to 8 nonzeros in flight per lane), gathers from
-// the slice, stages the products in its private 4 KB of LDS (in-order LDS queue: no barrier
+// the slice, stages the products in its private 6 KB of LDS (in-order LDS queue: no barrier
 // needed inside a wave), forms the row sums and moves on.  Sixteen independent streams per CU
-// hide each other's phases.  The only workgroup barrier is at a change of panel.
+// hide each other's phases.  The only workgroup barrier is at a change of panel.  Columns and row
+// bounds are 16-bit, relative to the window (k_xl_col16, k_xl_rel16): 10 bytes per nonzero and 2
+// per (panel, row).  Config 3 literal: 9.5-10 ms per product.
 //
 // A trip's slice is the panel of the FIRST non-empty window of its 16; entries of a window that
 // reaches into the next panel are gathered from global memory (gx).  Output z[v] = raw sum of
