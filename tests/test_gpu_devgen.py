@@ -105,3 +105,50 @@ def test_scale_properties_beyond_2_to_31_nonzeros_with_lds_panels():
     r2 = s.solve_device(dp.d_b.ptr.value, d_x.ptr.value, 1e-3)
     assert (r2.itn, r2.anorm, r2.rnorm) == (r.itn, r.anorm, r.rnorm)
     assert np.array_equal(d_x.to_array(np.float64, dp.n), x)
+
+
+@pytest.mark.parametrize("spec,expect", [
+    ("random:10000000:10000000:100", dict(nnz=1_000_000_000, panels=39)),      # BASELINE configs[3]: what --gpus N shards
+    ("powerlaw:5000000:2000000:10000", dict(panels=8)),                        # BASELINE configs[4]: skewed rows
+])
+def test_scale_properties_of_the_panelled_baseline_configurations(spec, expect):
+    """BASELINE configs[3] and configs[4] at their full size, generated in HBM: L2 column panels with
+    the grid chosen by timing, and (power law) the long-segment waves of spmv.h phase 2b.  No CPU
+    oracle fits in test time, so: acheck's adjoint identity (A and A' are built and laid out
+    independently), linearity, bit-level determinism of both products (neither the tuned grid nor
+    which wave takes which long segment may show), and a short solve that repeats itself exactly
+    and agrees across the launch schedules."""
+    import torch
+    from lsqr_amd.capi import DeviceBuffer
+    free, _ = torch.cuda.mem_get_info()
+    if free < 120e9:
+        pytest.skip("needs ~80 GB of free HBM")
+    dp = devgen.generate(spec, itnlim=12)
+    s = dp.solver
+    info = s.info()
+    if "nnz" in expect:
+        assert dp.nnz == expect["nnz"]
+    assert info["panels"] == expect["panels"] and info["xlds"] == 0 and info["sell"] == 0
+    inform, err = s.acheck()
+    assert inform == 0 and err < 1e-12
+    xa = P.u64_to_unit(P.rng_u64(1, 9, np.arange(dp.n, dtype=np.uint64)))
+    yb = P.u64_to_unit(P.rng_u64(2, 9, np.arange(dp.m, dtype=np.uint64)))
+    y1, y2, y3 = np.zeros(dp.m), np.zeros(dp.m), np.zeros(dp.m)
+    s.aprod(1, dp.m, dp.n, xa, y1)
+    s.aprod(1, dp.m, dp.n, xa, y2)
+    s.aprod(1, dp.m, dp.n, 3.0 * xa, y3)
+    assert np.array_equal(y1, y2)
+    assert np.max(np.abs(y3 - 3.0 * y1)) <= 1e-13 * np.max(np.abs(y3))
+    x1, x2 = np.zeros(dp.n), np.zeros(dp.n)
+    s.aprod(2, dp.m, dp.n, x1, yb)
+    s.aprod(2, dp.m, dp.n, x2, yb)
+    assert np.array_equal(x1, x2)
+    d_x = DeviceBuffer(8 * dp.n)
+    out = []
+    for pipeline in (2, 2, 1):
+        s.set_option("pipeline", pipeline)
+        r = s.solve_device(dp.d_b.ptr.value, d_x.ptr.value, 1e-3)
+        out.append((r.istop, r.itn, r.anorm, r.rnorm, r.xnorm, d_x.to_array(np.float64, dp.n)))
+    assert out[0][:2] == (5, 12)
+    for o in out[1:]:
+        assert o[:5] == out[0][:5] and np.array_equal(o[5], out[0][5])
