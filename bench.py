@@ -2,6 +2,7 @@
 """bench.py -- LSQR iterations/s + aprod SpMV GB/s on MI355X (BASELINE.json metric).
 
     python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N ...                     # starts its N ranks itself (torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" is ONE LSQR iteration (mode-1 SpMV + mode-2 SpMV + x/w update + the scalar
@@ -10,25 +11,45 @@ iterations (atol = btol = conlim = 0, itnlim = K -> istop = 5) with the matrix, 
 already resident in HBM; W warm-up iterations run first as a separate solve.
 
 N = 1 workload: BASELINE.json configs[1] -- 1M x 1M 5-point Poisson (nnz 4 996 000),
-damp = 0.  N > 1: the row-block sharded solve (lsqr_amd/dist.py).
+damp = 0.  N > 1: the row-block sharded solve of configs[3] (lsqr_amd/dist_bench.py).
 
-Prints ONE JSON line (rank 0) with `roofline` (dominant kernel = mode-1 SpMV, live HIP event
-timing, bytes of the layout the build chose) and `cpu_baseline` (the reference's own CPU path,
-1 core, bounded sample).
+The ONE JSON line (rank 0) carries, for the dominant kernel (aprod mode 1):
+  roofline          PHYSICAL: bytes of the layout the build chose / average launch time (HIP events on
+                    the solver's stream), frac = that / 8 TB/s (always <= 1); `traffic` = HBM bytes per
+                    launch from rocprofv3 PMC passes of THIS build made by this run (FETCH_SIZE and
+                    WRITE_SIZE in passes of their own, FETCH_SIZE x2 on gfx950); `effective_gbps` = the
+                    SURVEY 8d algorithmic bytes (12 B per nonzero ...) / the same time, labelled as such.
+  roofline_hbm      the same kernel family on HBM-RESIDENT instances (configs[1] fits the 256 MB
+                    Infinity Cache): poisson2d:4000:4000 with the value dictionary and with 8-byte values.
+  strong_scaling_n1 configs[3] (10M x 10M, 1e9 nonzeros) whole on this GPU, with its own roofline:
+                    N = 1 of the series the --gpus N lines continue.
+  cpu_baseline      the reference's own CPU path (oracle/_ref), 1 core, bounded sample.
+`--workload SPEC --extras off` measures one workload alone (what profiles/r02/*.txt were made with).
 """
 from __future__ import annotations
 
 import argparse
+import csv
+import glob
 import json
 import os
+import shutil
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s measured float4 copy)
+INFINITY_CACHE = 256 << 20
+HEADLINE = "poisson2d:1000:1000"
+HBM_INSTANCES = [("poisson2d:4000:4000", {}, "value dictionary (1-byte codes), 16-bit columns"),
+                 ("poisson2d:4000:4000", {"LSQRHIP_VAL8": "0"}, "8-byte values, 16-bit columns")]
+PRODUCT_KERNELS = ("k_spmv_", "k_panel_combine")
 
 
 def parse():
@@ -40,8 +61,13 @@ def parse():
                     help="auto | poisson2d:NX:NY | random:M:N:PER_ROW | powerlaw:M:N:DMAX")
     ap.add_argument("--cpu-iters", type=int, default=1000, help="iterations of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--extras", choices=["on", "off"], default="on",
+                    help="off: only the one workload (no HBM-resident instances, no configs[3] point)")
     ap.add_argument("--no-scaling-ref", action="store_true",
                     help="skip the N = 1 point of the multi-GPU series (configs[3] whole on this GPU)")
+    ap.add_argument("--traffic", choices=["live", "off"], default="live",
+                    help="live: HBM bytes per launch from rocprofv3 PMC passes run as child processes")
+    ap.add_argument("--pmc-child", default=None, help=argparse.SUPPRESS)
     a = ap.parse_args()
     multi = a.gpus > 1 or int(os.environ.get("WORLD_SIZE", "1")) > 1
     if a.steps is None:        # N = 1: ~26 us per iteration; N > 1 (10^9 nonzeros): milliseconds
@@ -77,183 +103,322 @@ def cpu_baseline(p, iters: int):
                       f"{'oracle/_ref (reference compiled with amdflang -O2)' if kind == 'reference' else 'oracle C port'}"}
 
 
-def scaling_series_n1(torch):
-    """N = 1 of the series `--gpus 2/4/8` continues: BASELINE configs[3] (10M x 10M, 100 per row,
-    10^9 nonzeros, damp 1e-3 -- lsqr_amd/dist_bench.py) whole on this GPU.  The N > 1 lines are
-    strong scaling of THIS workload, not of configs[1] above; outside the timed region."""
+# ---------------------------------------------------------------------------------------------
+# one workload on this GPU
+# ---------------------------------------------------------------------------------------------
+class _Env:
+    """LSQRHIP_* knobs for the duration of one build (the library reads them at create)."""
+
+    def __init__(self, env):
+        self.env = env or {}
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.env}
+        os.environ.update(self.env)
+
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v
+
+
+def build_workload(spec: str, env=None, itnlim=100):
+    """(solver, d_b, facts) with the matrix resident in HBM; small systems also keep the host copy."""
     from lsqr_amd import capi, devgen
-    from lsqr_amd.dist_bench import DEFAULT_SPEC
-    try:
-        full = devgen.generate(DEFAULT_SPEC)
-        cfg = devgen.parse_spec(DEFAULT_SPEC)
-        d_x = capi.DeviceBuffer(8 * cfg["n"])
-        full.solver.atol = full.solver.btol = full.solver.conlim = 0.0
-        full.solver.itnlim = 4
-        full.solver.solve_device(full.d_b.ptr.value, d_x.ptr.value, cfg["damp"])
-        kr = 40
-        full.solver.itnlim = kr
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        r = full.solver.solve_device(full.d_b.ptr.value, d_x.ptr.value, cfg["damp"])
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        return {"workload": f"{DEFAULT_SPEC} nnz={full.nnz} damp={cfg['damp']} (BASELINE.json configs[3], whole on one GPU)",
-                "n_gpus": 1, "steps": r.itn, "value": r.itn / dt, "unit": "it/s", "ms_per_step": 1e3 * dt / r.itn,
-                "note": "the --gpus N > 1 lines shard this matrix by row blocks: compare their value with this one"}
-    except Exception as e:      # never fail the headline measurement over the side one
-        return {"error": repr(e)}
-
-
-def run_single(args):
-    import torch
-    from lsqr_amd import capi
     from lsqr_amd.solver import lsqr_solver_ez
-
-    if not torch.cuda.is_available() or capi.device_count() < 1:
-        raise SystemExit("bench.py: no MI355X visible; the HIP path has no CPU fallback")
-    from lsqr_amd import devgen
-    spec = "poisson2d:1000:1000" if args.workload == "auto" else args.workload
-    K, W = args.steps, args.warmup
     cfg = devgen.parse_spec(spec)
     nnz_est = cfg["m"] * (5 if cfg["kind"] == "poisson2d" else cfg.get("per_row", 30))
-    host_ok = nnz_est <= 60_000_000          # the host copy only exists for the CPU baseline
-    if host_ok:
-        p = make_problem(spec)
-        s = lsqr_solver_ez().initialize(p.m, p.n, p.a, p.irow, p.icol, itnlim=K)
-        d_b = capi.DeviceBuffer.from_array(p.b)
-    else:                                     # generated in HBM (bit-identical generator, csrc/gen_api.h)
-        dp = devgen.generate(spec, itnlim=K)
-        s, d_b = dp.solver, dp.d_b
+    host = None
+    with _Env(env):
+        if nnz_est <= 60_000_000 and not env:       # the host copy only exists for the CPU baseline
+            host = make_problem(spec)
+            s = lsqr_solver_ez().initialize(host.m, host.n, host.a, host.irow, host.icol, itnlim=itnlim)
+            d_b = capi.DeviceBuffer.from_array(host.b)
+            facts = dict(name=host.name, m=host.m, n=host.n, nnz=host.nnz, damp=host.damp)
+        else:                                        # generated in HBM (bit-identical generator, csrc/gen_api.h)
+            dp = devgen.generate(spec, itnlim=itnlim)
+            s, d_b = dp.solver, dp.d_b
+            facts = dict(name=spec, m=dp.m, n=dp.n, nnz=dp.nnz, damp=dp.damp)
+    return s, d_b, facts, host
 
-        class _P:                             # what the report below needs
-            name, m, n, nnz, damp = spec, dp.m, dp.n, dp.nnz, dp.damp
-        p = _P
-    d_x = capi.DeviceBuffer(8 * max(p.n, 1))
-    # graph batch: a divisor of K when there is a good one (no predicated-off tail iterations in
-    # the timed solve), else up to 50 iterations (launches past the stop are ~us-scale no-ops)
-    gi = next((g for g in (100, 50, 40, 32, 26, 20, 16) if K % g == 0), min(50, K + (K & 1)))
-    s.set_option("graph_iters", gi)
 
-    if W > 0:
-        s.itnlim = W
-        s.solve_device(d_b.ptr.value, d_x.ptr.value, p.damp)
-    # EXACTLY K iterations.  With atol = btol = conlim = 0 the default workloads never stop before
-    # the limit (1000^2 Poisson needs > 10^5 iterations), but a well-conditioned --workload can reach
-    # machine precision first (random 4M x 1M, damp 1e-3: 50 iterations): the solve is then started
-    # again on the same b until K iterations have run; `restarts` in the report counts that.
+def describe_layout(info):
+    if info["sell"] == 2:
+        return "sliced ELL, packed 16-byte records", "k_spmv_sellp"
+    if info["sell"]:
+        return "sliced ELL", "k_spmv_sell"
+    if info["xlds"] == 3:
+        return "column-swept row blocks (LDS accumulators)", "k_spmv_csb"
+    if info["xlds"] == 2:
+        return "LDS column panels (wave windows)", "k_spmv_xlw + k_panel_combine"
+    if info["panels"] > 1:
+        return "L2 column panels", "k_spmv_fused + k_panel_combine"
+    return "row windows", "k_spmv_fused"
+
+
+def product_roofline(s, facts, reps, traffic=None):
+    """The `roofline` object of the mode-1 product of a built workload: average of `reps` back-to-back
+    launches inside ONE HIP event pair on the solver's stream (what rocprofv3's kernel trace reports as
+    the kernel's average duration), against the bytes of the layout in use."""
+    info = s.info()
+    m, n, nnz = facts["m"], facts["n"], facts["nnz"]
+    P = info["rowptr_bytes"]
+    alg1 = 12 * nnz + P * (m + 1) + 8 * n + 16 * m            # SURVEY 8d: B1
+    alg2 = 12 * nnz + P * (n + 1) + 8 * m + 16 * n            # B2
+    lay1 = info["csr_bytes"] + 8 * n + 16 * m                  # matrix as stored + x once + y read and written
+    lay2 = info["csrt_bytes"] + 8 * m + 16 * n
+    avg1, avg2, avg3 = (s.bench_kernel(w, reps) for w in (1, 2, 3))
+    layout, kname = describe_layout(info)
+    ach = lay1 / (avg1 * 1e-3) / 1e9
+    frac = ach / HBM_PEAK_GBS
+    assert frac <= 1.0, ("a roofline fraction above 1 is not a fraction", frac)
+    wset = info["csr_bytes"] + info["csrt_bytes"] + 8 * (m + 4 * n)
+    roof = {"bound": "hbm", "kernel": f"{kname} (aprod mode 1)", "achieved": ach, "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": frac, "traffic": None, "bytes_per_launch": lay1,
+            "avg_launch_us": avg1 * 1e3, "launches": reps,
+            "bytes_are": "the layout in use: matrix as stored + x once + y read and written (physical)",
+            "effective_gbps": alg1 / (avg1 * 1e-3) / 1e9, "effective_bytes_per_launch": alg1,
+            "effective_is": "SURVEY 8d algorithmic bytes (8-byte values, 4-byte columns, row pointers) / the same time; "
+                            "exceeds the physical rate whenever the layout compresses -- not a roofline fraction",
+            "format": {"layout": layout, "value_bytes": info["value_bytes"], "col_bytes": info["col_bytes"],
+                       "dict_entries": info["dict_entries"]},
+            "resident": ("infinity cache (iteration working set %.0f MB < 256 MB: 'HBM' bytes are fabric requests "
+                         "that may be served on-die)" % (wset / 1e6)) if wset < INFINITY_CACHE else
+                        "hbm (iteration working set %.1f GB)" % (wset / 1e9)}
+    if traffic:
+        roof["traffic"] = traffic.get("bytes_per_launch")
+        roof["traffic_detail"] = traffic
+    kernels = {
+        "spmv_mode2": {"avg_launch_us": avg2 * 1e3, "bytes_per_launch": lay2, "gbps": lay2 / (avg2 * 1e-3) / 1e9,
+                       "frac": lay2 / (avg2 * 1e-3) / 1e9 / HBM_PEAK_GBS, "effective_gbps": alg2 / (avg2 * 1e-3) / 1e9},
+        "update_xw": {"avg_launch_us": avg3 * 1e3, "bytes_per_launch": 40 * n,
+                      "gbps": 40 * n / (avg3 * 1e-3) / 1e9, "frac": 40 * n / (avg3 * 1e-3) / 1e9 / HBM_PEAK_GBS},
+    }
+    return roof, kernels, (alg1, alg2, lay1, lay2)
+
+
+def timed_solve(s, d_b, d_x, damp, K):
+    """EXACTLY K iterations.  With atol = btol = conlim = 0 the default workloads never stop before
+    the limit; a well-conditioned --workload can reach machine precision first: the solve is then
+    started again on the same b until K iterations have run (`restarts`)."""
+    import torch
     done, restarts, loop_ms = 0, 0, 0.0
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     while done < K:
         s.itnlim = K - done
-        r = s.solve_device(d_b.ptr.value, d_x.ptr.value, p.damp)
+        r = s.solve_device(d_b.ptr.value, d_x.ptr.value, damp)
         done += r.itn
         loop_ms += s.last_timing().loop_ms
         if done < K:
             restarts += 1
             if r.itn == 0:
-                raise SystemExit(f"bench.py: workload {spec} stops at iteration 0 (b = 0?)")
+                raise SystemExit("bench.py: workload stops at iteration 0 (b = 0?)")
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     assert done == K and (restarts > 0 or r.istop == 5), (done, r.itn, r.istop)
-    tm = s.last_timing()
-    tm.loop_ms = loop_ms
+    return dt, r, restarts, loop_ms
 
+
+def side_workload(spec, env, note, K, traffic):
+    """An additional instance of the same path (HBM-resident Poisson, configs[3]): a short solve and
+    the product's roofline.  Never fails the headline measurement."""
+    from lsqr_amd import capi
+    try:
+        s, d_b, facts, _ = build_workload(spec, env, itnlim=K)
+        d_x = capi.DeviceBuffer(8 * max(facts["n"], 1))
+        s.atol = s.btol = s.conlim = 0.0
+        s.set_option("graph_iters", min(K + (K & 1), 50))
+        s.itnlim = min(4, K)
+        s.solve_device(d_b.ptr.value, d_x.ptr.value, facts["damp"])
+        dt, r, restarts, _ = timed_solve(s, d_b, d_x, facts["damp"], K)
+        reps = 100 if facts["nnz"] < 200_000_000 else 10
+        roof, kernels, (alg1, alg2, lay1, lay2) = product_roofline(s, facts, reps, traffic)
+        out = {"workload": f"{spec} m={facts['m']} n={facts['n']} nnz={facts['nnz']} damp={facts['damp']}",
+               "variant": note, "env": env or {}, "n_gpus": 1, "steps": K, "value": K / dt, "unit": "it/s",
+               "ms_per_step": 1e3 * dt / K, "restarts": restarts,
+               "iter_bytes_layout": lay1 + lay2 + 40 * facts["n"],
+               "iter_gbps_layout": (lay1 + lay2 + 40 * facts["n"]) * K / dt / 1e9,
+               "roofline": roof, "kernels": kernels}
+        del s, d_b, d_x
+        return out
+    except Exception as e:      # noqa: BLE001
+        return {"workload": spec, "variant": note, "error": repr(e)}
+
+
+# ---------------------------------------------------------------------------------------------
+# HBM traffic per launch: rocprofv3 PMC passes of this build, as child processes
+# ---------------------------------------------------------------------------------------------
+def pmc_child(counter: str):
+    """Runs under `rocprofv3 --pmc COUNTER`: builds each workload of the plan (stdin: JSON list of
+    [spec, env]) and launches its mode-1 product 3 + reps times; prints the launch manifest."""
+    plan = json.loads(sys.stdin.read())
+    manifest = []
+    for spec, env in plan:
+        s, d_b, facts, _ = build_workload(spec, env)
+        reps = 10 if facts["nnz"] < 200_000_000 else 4
+        s.bench_kernel(1, reps)
+        manifest.append({"spec": spec, "env": env, "launches": 3 + reps,
+                         "kernels_per_product": 2 if ("panel" in describe_layout(s.info())[1]) else 1})
+        del s, d_b
+    print("PMC_MANIFEST " + json.dumps(manifest), flush=True)
+
+
+def live_traffic(plan, timeout=600):
+    """{(spec, env-json): {bytes_per_launch, fetch_bytes, write_bytes}}.  FETCH_SIZE and WRITE_SIZE are
+    collected in passes of their own (TCC slots); FETCH_SIZE is doubled (gfx950 tallies 128-byte
+    requests at 64 bytes, MI355X_MICROARCH.md "HBM").  Returns ({}, reason) when rocprofv3 cannot run."""
+    rp = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rp):
+        return {}, "rocprofv3 not found"
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return {}, "this run is itself being profiled; PMC passes skipped"
+    env = {k: v for k, v in os.environ.items() if not k.startswith(("ROCPROF", "ROCP_", "HSA_TOOLS"))}
+    env["TMPDIR"] = "/tmp"
+    sums = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="lsqr_pmc_", dir="/tmp")
+        try:
+            cp = subprocess.run([rp, "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "pmc", "--",
+                                 sys.executable, os.path.join(ROOT, "bench.py"), "--pmc-child", counter],
+                                input=json.dumps(plan), capture_output=True, text=True, timeout=timeout, cwd="/tmp",
+                                env=env)
+            man = [ln for ln in cp.stdout.splitlines() if ln.startswith("PMC_MANIFEST ")]
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if cp.returncode != 0 or not man or not files:
+                return {}, f"PMC pass {counter} failed (rc {cp.returncode}): {cp.stderr[-300:]}"
+            manifest = json.loads(man[0][len("PMC_MANIFEST "):])
+            rows = []
+            for f in files:
+                for r in csv.DictReader(open(f)):
+                    if r.get("Counter_Name") == counter and any(k in r.get("Kernel_Name", "") for k in PRODUCT_KERNELS):
+                        rows.append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
+            rows.sort()
+            pos = 0
+            for mf in manifest:       # dispatch order = plan order; the build launches no product kernel
+                nk = mf["launches"] * mf["kernels_per_product"]
+                vals = [v for _, v in rows[pos:pos + nk]]
+                pos += nk
+                if len(vals) != nk:
+                    return {}, f"PMC pass {counter}: {len(rows)} product dispatches, manifest wants more"
+                live = vals[3 * mf["kernels_per_product"]:]          # skip the 3 warm launches
+                per_launch = sum(live) / (len(live) / mf["kernels_per_product"])
+                sums.setdefault((mf["spec"], json.dumps(mf["env"], sort_keys=True)), {})[counter] = per_launch
+            if pos != len(rows):
+                return {}, f"PMC pass {counter}: {len(rows) - pos} unexpected product dispatches"
+        except Exception as e:      # noqa: BLE001
+            return {}, f"PMC pass {counter}: {e!r}"
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    out = {}
+    for key, c in sums.items():
+        if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            fetch, write = 2.0 * c["FETCH_SIZE"] * 1024.0, c["WRITE_SIZE"] * 1024.0     # counters are in KB
+            out[key] = {"bytes_per_launch": fetch + write, "fetch_bytes": fetch, "write_bytes": write,
+                        "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes made by this run (same build), "
+                                  "FETCH_SIZE x2 (gfx950), KB -> bytes; mean over the live launches"}
+    return out, None
+
+
+# ---------------------------------------------------------------------------------------------
+def run_single(args):
+    spec = HEADLINE if args.workload == "auto" else args.workload
+    extras = args.extras == "on" and spec == HEADLINE
+    want_n1 = extras and not args.no_scaling_ref
+    from lsqr_amd.dist_bench import DEFAULT_SPEC
+
+    # PMC passes first, as children, before this process touches the GPU
+    plan = [[spec, {}]]
+    if extras:
+        plan += [[sp, env] for sp, env, _ in HBM_INSTANCES]
+    if want_n1:
+        plan += [[DEFAULT_SPEC, {}]]
+    traffic, traffic_note = ({}, "--traffic off")
+    if args.traffic == "live" and not args.no_roofline:
+        traffic, traffic_note = live_traffic(plan)
+
+    def tr(sp, env):
+        return traffic.get((sp, json.dumps(env or {}, sort_keys=True)))
+
+    import torch
+    from lsqr_amd import capi
+    if not torch.cuda.is_available() or capi.device_count() < 1:
+        raise SystemExit("bench.py: no MI355X visible; the HIP path has no CPU fallback")
+    K, W = args.steps, args.warmup
+    s, d_b, facts, host = build_workload(spec, None, itnlim=K)
+    d_x = capi.DeviceBuffer(8 * max(facts["n"], 1))
+    # graph batch: a divisor of K when there is a good one (no predicated-off tail iterations in
+    # the timed solve), else up to 50 iterations (launches past the stop are ~us-scale no-ops)
+    gi = next((g for g in (100, 50, 40, 32, 26, 20, 16) if K % g == 0), min(50, K + (K & 1)))
+    s.set_option("graph_iters", gi)
+    s.atol = s.btol = s.conlim = 0.0
+    if W > 0:
+        s.itnlim = W
+        s.solve_device(d_b.ptr.value, d_x.ptr.value, facts["damp"])
+    dt, r, restarts, loop_ms = timed_solve(s, d_b, d_x, facts["damp"], K)
+
+    cfgname = " (BASELINE.json configs[1])" if spec == HEADLINE else ""
     out = {
         "metric": "lsqr_iterations_per_sec", "value": K / dt, "unit": "it/s", "n_gpus": 1,
         "steps": K, "warmup": W, "ms_per_step": 1e3 * dt / K, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"{p.name} m={p.m} n={p.n} nnz={p.nnz} damp={p.damp} "
-                               f"(BASELINE.json configs[1])" if spec == "poisson2d:1000:1000" else
-                               f"{p.name} m={p.m} n={p.n} nnz={p.nnz} damp={p.damp}",
-                   "graph_iters": gi, "device_loop_ms": tm.loop_ms, "restarts": restarts},
+        "config": {"workload": f"{facts['name']} m={facts['m']} n={facts['n']} nnz={facts['nnz']} "
+                               f"damp={facts['damp']}{cfgname}",
+                   "graph_iters": gi, "device_loop_ms": loop_ms, "restarts": restarts},
         "result": {"istop": r.istop, "itn": r.itn, "anorm": r.anorm, "rnorm": r.rnorm},
-        "iter_bytes": tm.spmv1_bytes + tm.spmv2_bytes + tm.vec_bytes,
-        "iter_gbps": (tm.spmv1_bytes + tm.spmv2_bytes + tm.vec_bytes) * K / dt / 1e9,
     }
-
     if not args.no_roofline:
-        # Same K iterations again, eager launches with HIP events around each hot kernel
-        # (recorded on the stream the kernels run on).
-        s.set_option("time_kernels", 1)
-        s.itnlim = r.itn                      # the last (or only) solve of the timed region again
-        r2 = s.solve_device(d_b.ptr.value, d_x.ptr.value, p.damp)
-        t2 = s.last_timing()
-        s.set_option("time_kernels", 0)
-        assert r2.itn == r.itn and r2.anorm == r.anorm
-        in_loop = [t2.spmv1_ms / max(t2.spmv1_launches, 1), t2.spmv2_ms / max(t2.spmv2_launches, 1),
-                   t2.update_ms / max(t2.update_launches, 1)]
-        # K back-to-back launches of each hot kernel inside ONE event pair: the per-launch
-        # average rocprofv3's kernel trace reports (kernels abut on the stream; a start/stop
-        # event pair per launch adds ~2 us of marker latency to a 17 us kernel).
-        reps = min(K, 1000) if p.nnz < 50_000_000 else max(10, min(K, 40))
-        avg1, avg2, avg3 = (s.bench_kernel(w, reps) for w in (1, 2, 3))
-        # Bytes one product must move IN THE LAYOUT THE BUILD CHOSE (DESIGN.md 4): the matrix as
-        # stored (lsqrhip_info: sliced-ELL / row windows, 1- or 8-byte values, 2- or 4-byte
-        # columns) + x once + y read and written.  SURVEY 8(d)'s CSR figure (8-byte values, 4-byte
-        # columns) is reported beside it; with a value dictionary it exceeds what is moved.
-        info = s.info()
-        fmt1 = info["csr_bytes"] + 8 * p.n + 16 * p.m
-        fmt2 = info["csrt_bytes"] + 8 * p.m + 16 * p.n
-        if info["sell"] == 2:
-            layout, kname = "sell, packed 16-byte records", "k_spmv_sellp"
-        elif info["sell"]:
-            layout, kname = "sell", "k_spmv_sell"
-        elif info["xlds"] == 2:
-            layout, kname = "lds-panels (wave windows)", "k_spmv_xlw + k_panel_combine"
-        elif info["panels"] > 1:
-            layout, kname = "l2-panels", "k_spmv_fused + k_panel_combine"
-        else:
-            layout, kname = "row-windows", "k_spmv_fused"
-        # roofline.achieved follows the contract: ALGORITHMIC bytes of the product (SURVEY 8d: fp64
-        # values, int32 columns, row pointers, x once, y read + written) / average launch time.
-        # The bytes the chosen layout really moves are reported beside it (layout_*): with the
-        # value dictionary / 16-bit columns / sliced ELL they are fewer, so `achieved` can exceed
-        # what the memory system delivered -- `traffic` (PMC counters) is the physical figure.
-        ach = t2.spmv1_bytes / (avg1 * 1e-3) / 1e9
-        lay = fmt1 / (avg1 * 1e-3) / 1e9
-        traffic = None
-        tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tp):
-            try:
-                traffic = json.load(open(tp)).get(spec, {}).get("spmv_mode1_hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        compressed = fmt1 < 0.98 * t2.spmv1_bytes
-        out["roofline"] = {"bound": "hbm", "kernel": f"{kname} (aprod mode 1)",
-                           "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                           "traffic": traffic, "bytes_per_launch": t2.spmv1_bytes,
-                           "avg_launch_us": avg1 * 1e3, "launches": reps,
-                           "in_loop_event_pair_us": in_loop[0] * 1e3,
-                           "format": {"layout": layout, "value_bytes": info["value_bytes"],
-                                      "col_bytes": info["col_bytes"], "dict_entries": info["dict_entries"]},
-                           "layout_bytes_per_launch": fmt1, "layout_gbps": lay, "layout_frac": lay / HBM_PEAK_GBS,
-                           "note": ("algorithmic bytes = SURVEY 8d CSR count (12 B per nonzero); the layout in use "
-                                    "stores %d B per nonzero, so achieved is an EFFECTIVE rate -- layout_gbps and "
-                                    "traffic are the physical ones" % (info["value_bytes"] + info["col_bytes"]))
-                                   if compressed else "layout moves the algorithmic bytes"}
-        out["iter_format_bytes"] = fmt1 + fmt2 + t2.vec_bytes
-        out["iter_format_gbps"] = (fmt1 + fmt2 + t2.vec_bytes) * K / dt / 1e9
-        out["kernels"] = {
-            "spmv_mode2": {"avg_launch_us": avg2 * 1e3, "bytes_per_launch": t2.spmv2_bytes,
-                           "gbps": t2.spmv2_bytes / (avg2 * 1e-3) / 1e9, "layout_bytes_per_launch": fmt2,
-                           "layout_gbps": fmt2 / (avg2 * 1e-3) / 1e9, "in_loop_event_pair_us": in_loop[1] * 1e3},
-            "update_xw": {"avg_launch_us": avg3 * 1e3, "bytes_per_launch": t2.vec_bytes,
-                          "gbps": t2.vec_bytes / (avg3 * 1e-3) / 1e9, "in_loop_event_pair_us": in_loop[2] * 1e3},
-        }
-
-    if spec == "poisson2d:1000:1000" and not args.no_scaling_ref:
-        out["strong_scaling_n1"] = scaling_series_n1(torch)
-    if args.cpu_iters > 0 and host_ok:
-        out["cpu_baseline"] = cpu_baseline(p, args.cpu_iters)
+        reps = min(max(K, 100), 1000) if facts["nnz"] < 50_000_000 else (100 if facts["nnz"] < 200_000_000 else 10)
+        roof, kernels, (alg1, alg2, lay1, lay2) = product_roofline(s, facts, reps, tr(spec, {}))
+        if roof["traffic"] is None:
+            roof["traffic_note"] = traffic_note
+        out["roofline"] = roof
+        out["kernels"] = kernels
+        vec = 40 * facts["n"]
+        out["iter_bytes_layout"] = lay1 + lay2 + vec
+        out["iter_gbps_layout"] = (lay1 + lay2 + vec) * K / dt / 1e9
+        out["iter_bytes_survey8d"] = alg1 + alg2 + vec
+        out["iter_gbps_survey8d_effective"] = (alg1 + alg2 + vec) * K / dt / 1e9
+    del s, d_x
+    if extras and not args.no_roofline:
+        out["roofline_hbm"] = [side_workload(sp, env, note, 50, tr(sp, env)) for sp, env, note in HBM_INSTANCES]
+    if want_n1:
+        n1 = side_workload(DEFAULT_SPEC, {}, "BASELINE.json configs[3], whole on one GPU", 40, tr(DEFAULT_SPEC, {}))
+        n1["note"] = "the --gpus N > 1 lines shard this matrix by row blocks: compare their value with this one"
+        out["strong_scaling_n1"] = n1
+    if args.cpu_iters > 0 and host is not None:
+        out["cpu_baseline"] = cpu_baseline(host, args.cpu_iters)
     elif args.cpu_iters > 0:
         out["cpu_baseline"] = None   # workload generated in HBM only; the CPU sample is quoted on config 2
     print(json.dumps(out), flush=True)
 
 
+def spawn_ranks(args):
+    """`bench.py --gpus N` without a launcher: start the N ranks ourselves, as a child process (never an
+    exec), BEFORE this process touches the GPU, and pass the child's JSON line through."""
+    import torch
+    have = torch.cuda.device_count()          # does not initialise a context
+    if have < args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} needs {args.gpus} GPUs, this node shows {have}")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py")] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cp = subprocess.run(cmd, env=env)
+    raise SystemExit(cp.returncode)
+
+
 def main():
     args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.pmc_child:
+        return pmc_child(args.pmc_child)
+    world = int(os.environ.get("WORLD_SIZE", "0"))
+    if args.gpus > 1 and world == 0:
+        return spawn_ranks(args)
     if args.gpus > 1 or world > 1 or os.environ.get("LSQR_BENCH_FORCE_DIST") == "1":
         from lsqr_amd.dist_bench import run_distributed
         run_distributed(args)

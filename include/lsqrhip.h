@@ -84,8 +84,8 @@ int lsqrhip_retain(lsqrhip_handle_t h);
  * bytes per row pointer (4 or 8), value-dictionary entries (0 = none), bytes per stored
  * value (8, or 1 with the dictionary), bytes per column index in CSR(A) and CSR(A')
  * (4, or 2 for block-relative indices), column panels of CSR(A) and CSR(A'), and whether
- * the sliced-ELL layout is in use for A and for A' (0/1), whether the panels are LDS-resident
- * for A and for A' (0/1). */
+ * the sliced-ELL layout is in use for A and for A' (0/1/2), whether the panels are LDS-resident
+ * for A and for A' (0/1/2; 3 = column-swept row blocks, csrc/csb.h). */
 int lsqrhip_info(lsqrhip_handle_t h, int64_t *dims);
 
 /* ---------------------------------------------------------------------- */
@@ -209,6 +209,12 @@ int lsqrhip_lstp_vectors(lsqrhip_handle_t h, double *xtrue, double *b, double *d
  * solve that stops inside batch k then runs batch k+1 as no-op launches; 0 = strict
  * launch-wait-check). */
 int lsqrhip_set_option(lsqrhip_handle_t h, const char *name, int64_t value);
+/* Reads an option back.  Besides the above: "norm_exp" -- the fused in-loop norms (dnrm2,
+ * src/lsqrblas.f90:123-159) are sqrt(sum (y 2^-e)^2) 2^e with e = norm_exp fixed per matrix
+ * (2^e just above max|a_ij|: u and v live at the scale of the matrix), so that no norm over- or
+ * underflows whatever the scale of A and b.  The ranks of a row-sharded solve must agree on one e
+ * (set the maximum of their values on every rank before lsqrhip_shard_begin). */
+int lsqrhip_get_option(lsqrhip_handle_t h, const char *name, int64_t *value);
 /* Run all work of this handle on an externally owned hipStream_t (e.g. the
  * caller's torch stream); NULL restores the handle's own stream. */
 int lsqrhip_set_stream(lsqrhip_handle_t h, void *hip_stream);
@@ -230,7 +236,7 @@ int lsqrhip_dev_sync(void);
  * (torch.distributed / RCCL in lsqr_amd/dist.py):
  *
  *   begin(b_p, T, sums)
- *   stage 0                      -> all-reduce(sums[0])          |b|^2
+ *   stage 0                      -> all-reduce(sums[0..2])       |b|^2 (three range-safe sums)
  *   stage 1                      -> all-reduce(T[0..n))          A'u
  *   stage 2
  *   repeat:  stage 3             -> all-reduce(sums[0])          |u|^2
@@ -240,7 +246,9 @@ int lsqrhip_dev_sync(void);
  *            recurrences run replicated on identical all-reduced inputs)
  *   end(x)
  *
- * d_T: n doubles, d_sums: >= 2 doubles, both device memory owned by the caller. */
+ * d_T: n doubles, d_sums: >= 4 doubles, both device memory owned by the caller.  Stage 0 leaves
+ * THREE sums in d_sums[0..2] (Blue's small / mid / big accumulators of b^2, additive over ranks:
+ * norm(b) is then formed without over- or underflow, like the reference's dnrm2): all-reduce all three. */
 int lsqrhip_shard_begin(lsqrhip_handle_t h, const double *d_b_local, int64_t m_global, double damp,
                         double atol, double btol, double conlim, int itnlim, int wantse, double *d_T,
                         double *d_sums);

@@ -27,7 +27,7 @@ EXPORTS = [
     "lsqrhip_solve", "lsqrhip_solve_device", "lsqrhip_aprod", "lsqrhip_aprod_device",
     "lsqrhip_acheck", "lsqrhip_xcheck", "lsqrhip_log_count", "lsqrhip_log_fetch",
     "lsqrhip_log_extras", "lsqrhip_dnrm2", "lsqrhip_ddot", "lsqrhip_dscal", "lsqrhip_dcopy",
-    "lsqrhip_last_timing", "lsqrhip_bench_kernel", "lsqrhip_set_option", "lsqrhip_set_stream", "lsqrhip_dev_alloc",
+    "lsqrhip_last_timing", "lsqrhip_bench_kernel", "lsqrhip_set_option", "lsqrhip_get_option", "lsqrhip_set_stream", "lsqrhip_dev_alloc",
     "lsqrhip_dev_free", "lsqrhip_dev_upload", "lsqrhip_dev_download", "lsqrhip_dev_sync",
     "lsqrhip_shard_begin", "lsqrhip_shard_stage", "lsqrhip_shard_poll", "lsqrhip_shard_end", "lsqrhip_sum_chunks",
     "lsqrhip_gen_count", "lsqrhip_gen_coo",
@@ -95,6 +95,7 @@ def lib() -> C.CDLL:
     L.lsqrhip_last_timing.argtypes = [vp, C.POINTER(Timing)]
     L.lsqrhip_bench_kernel.argtypes = [vp, i32, i32, vp]
     L.lsqrhip_set_option.argtypes = [vp, C.c_char_p, i64]
+    L.lsqrhip_get_option.argtypes = [vp, C.c_char_p, C.POINTER(i64)]
     L.lsqrhip_set_stream.argtypes = [vp, vp]
     L.lsqrhip_dev_alloc.argtypes = [C.POINTER(vp), i64]
     L.lsqrhip_dev_free.argtypes = [vp]

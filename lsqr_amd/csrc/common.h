@@ -83,6 +83,43 @@ __device__ __forceinline__ double block_sum_all(const double *__restrict__ p, in
     return out;
 }
 
+// Blue's range-safe sum of squares (constants of LAPACK 3.10's dnrm2); see scalar.h "range-safe norms".
+constexpr double BLUE_TSML = 0x1p-511, BLUE_TBIG = 0x1p486, BLUE_SSML = 0x1p537, BLUE_SBIG = 0x1p-538;
+
+struct Blue3 {
+    double sml, med, big;
+};
+__device__ __forceinline__ void blue_add(Blue3 &a, double x)
+{
+    const double ax = fabs(x);
+    if (ax > BLUE_TBIG) {
+        const double t = ax * BLUE_SBIG;
+        a.big += t * t;
+    } else if (ax < BLUE_TSML) {
+        const double t = ax * BLUE_SSML;
+        a.sml += t * t;
+    } else {
+        a.med += ax * ax;  // (NaN lands here)
+    }
+}
+__device__ __forceinline__ double blue_norm(double asml, double amed, double abig)
+{
+    if (abig > 0.0) {
+        if (amed > 0.0 || amed != amed) abig += (amed * BLUE_SBIG) * BLUE_SBIG;
+        return sqrt(abig) / BLUE_SBIG;
+    }
+    if (asml > 0.0) {
+        if (amed > 0.0 || amed != amed) {
+            const double a = sqrt(amed), b = sqrt(asml) / BLUE_SSML;
+            const double ymin = a < b ? a : b, ymax = a < b ? b : a;
+            const double q = ymin / ymax;
+            return ymax * sqrt(1.0 + q * q);
+        }
+        return sqrt(asml) / BLUE_SSML;
+    }
+    return sqrt(amed);
+}
+
 // Blocks b and b+8 share an XCD (and its 4 MiB L2) under the observed round-robin
 // placement.  Give each XCD label one contiguous eighth of the work items so that
 // neighbouring row blocks -- which gather neighbouring parts of x -- share an L2.

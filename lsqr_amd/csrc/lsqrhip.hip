@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -23,6 +24,7 @@
 #include <type_traits>
 #include <vector>
 
+#include "csb.h"
 #include "csr_build.h"
 #include "scalar.h"
 #include "sell.h"
@@ -37,7 +39,7 @@ using namespace lsqrhip;
 // errors
 // ---------------------------------------------------------------------------
 static thread_local std::string g_last_error;
-static int g_device = 0;
+static std::atomic<int> g_device{0};  // device new handles are created on (process-wide, like hipSetDevice's default)
 
 static int fail(int code, const std::string &msg)
 {
@@ -107,12 +109,13 @@ static int use_device()
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0)
         return fail(LSQRHIP_ERR_NO_DEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
-    if (g_device >= n) return fail(LSQRHIP_ERR_NO_DEVICE, "selected device index out of range");
+    const int dev = g_device.load();
+    if (dev >= n) return fail(LSQRHIP_ERR_NO_DEVICE, "selected device index out of range");
     hipDeviceProp_t p;
-    HIPCHK(hipGetDeviceProperties(&p, g_device));
+    HIPCHK(hipGetDeviceProperties(&p, dev));
     if (std::strncmp(p.gcnArchName, "gfx950", 6) != 0)
         return fail(LSQRHIP_ERR_NO_DEVICE, std::string("device is ") + p.gcnArchName + ", kernels are built for gfx950 only");
-    HIPCHK(hipSetDevice(g_device));
+    HIPCHK(hipSetDevice(dev));
     return LSQRHIP_OK;
 }
 
@@ -152,10 +155,18 @@ struct Csr {
     int pw = 0;        // panel width in columns
     int64_t rows_v = 0;  // virtual rows = P * rows (what rowptr / rb / blk index)
     int64_t bytes = 0;
+    // column-swept row blocks (csb.h), used instead of everything above when `csb` is set
+    int csb = 0;
+    double *cval = nullptr;       // [nchunks * 256] values, each block sorted by column, padded to whole chunks
+    unsigned *cidx = nullptr;     // [nchunks * 256] local row << 18 | column - cbase[chunk]
+    int *ccb = nullptr;           // [nchunks] first column of each chunk
+    long long *cptr = nullptr;    // [nrb + 1] first chunk of each row block
+    int64_t nchunks = 0;
+    int nrb = 0, R = 0, H = 3;
 };
 
 struct lsqrhip_handle_s {
-    int refs = 1;  // lsqrhip_retain / lsqrhip_destroy
+    std::atomic<int> refs{1};  // lsqrhip_retain / lsqrhip_destroy
     int device = 0;
     int m = 0, n = 0;
     int64_t nnz = 0;
@@ -165,7 +176,11 @@ struct lsqrhip_handle_s {
     int ndict = 0;           // 0 = no dictionary
     double *U = nullptr, *V = nullptr, *W = nullptr, *X = nullptr, *SE = nullptr;
     double *Z = nullptr;         // per-panel row sums of a panelled product (max over A, A')
-    double *partials = nullptr;  // SPMV_MAX_GRID
+    double *partials = nullptr;  // 3 * SPMV_MAX_GRID (three planes for Blue's norm of b, vec.h k_sumsq3)
+    double *xmax_part = nullptr; // VEC_MAX_GRID partials of max|x| for csb.h products on caller vectors
+    NScale nsc{1.0, 1.0};        // fused norms: sum of (y * nsc.s)^2, sqrt(sum) * nsc.inv (scalar.h "range-safe norms")
+    int norm_exp = 0;            // nsc.s = 2^-norm_exp (option "norm_exp": ranks of a sharded solve agree on one)
+    int amax_exp = 0;            // 2^amax_exp > max|a_ij| of THIS matrix (csb.h's bound on the products)
     int vgrid_m = 1, vgrid_n = 1;
     LsqrState *d_state = nullptr;
     LsqrState *h_state = nullptr;  // pinned; [1], [2] = per-batch snapshots of the look-ahead poll (solve_loop.h)
@@ -266,6 +281,10 @@ static void free_csr(Csr &c)
     if (c.rb) (void)hipFree(c.rb);
     if (c.gpid) (void)hipFree(c.gpid);
     if (c.blk) (void)hipFree(c.blk);
+    if (c.cval) (void)hipFree(c.cval);
+    if (c.cidx) (void)hipFree(c.cidx);
+    if (c.ccb) (void)hipFree(c.ccb);
+    if (c.cptr) (void)hipFree(c.cptr);
     c = Csr();
 }
 
@@ -294,7 +313,8 @@ extern "C" int lsqrhip_destroy(lsqrhip_handle_t h)
     destroy_graph(h);
     free_csr(h->A);
     free_csr(h->AT);
-    for (double *p : {h->U, h->V, h->W, h->X, h->SE, h->Z, h->partials, h->d_scalar, h->d_log, h->dict, h->opX, h->opY})
+    for (double *p : {h->U, h->V, h->W, h->X, h->SE, h->Z, h->partials, h->xmax_part, h->d_scalar, h->d_log, h->dict, h->opX,
+                      h->opY})
         if (p) (void)hipFree(p);
     if (h->op_free) h->op_free(h->op_user);
     if (h->d_state) (void)hipFree(h->d_state);
@@ -631,6 +651,118 @@ static int build_csr_T(hipStream_t s, const int *d_keys, const int *d_other, con
     return LSQRHIP_OK;
 }
 
+// Stable LSD radix sort of 64-bit words on their bits [32, 32 + nbits) (csr_build.h); returns the
+// buffer that holds the sorted words (`in` or `tmp`).
+static unsigned long long *radix_sort_words(hipStream_t s, unsigned long long *in, unsigned long long *tmp, int64_t nnz,
+                                            int nbits, unsigned *hist)
+{
+    const int64_t nb = (nnz + RS_TILE - 1) / RS_TILE;
+    for (int shift = 32; shift < 32 + nbits; shift += 8) {
+        hipLaunchKernelGGL(k_radix_hist, dim3((unsigned)nb), dim3(RS_BLOCK), 0, s, in, nnz, shift, nb, hist);
+        launch_scan(s, hist, (int64_t)256 * nb, hist + (size_t)256 * nb);
+        hipLaunchKernelGGL(k_radix_scatter, dim3((unsigned)nb), dim3(RS_BLOCK), 0, s, in, tmp, nnz, shift, nb, hist);
+        std::swap(in, tmp);
+    }
+    return in;
+}
+
+// Column-swept row blocks (csb.h) of the product whose rows are `rowk` and whose gathered vector is
+// indexed by `colk`.  On success out.csb = 1; when a chunk would span 2^18 columns or more (an almost
+// empty row block) `out` is left untouched and the caller builds the panel layout instead.
+//   LSQRHIP_CSB_R  rows per block (test hook; default: as many as the LDS holds, cut so that the
+//                  blocks divide evenly among the 256 workgroups)
+static int build_csb(hipStream_t s, const int *rowk, const int *colk, const double *d_a, int64_t nnz, int rows,
+                     int cols, int bad_code, int bad_code_other, unsigned long long *bufA,
+                     unsigned long long *bufB, unsigned *hist, int *d_flags, Csr &out)
+{
+    if (rows <= 0 || cols <= 0) return LSQRHIP_OK;
+    int R = env_int("LSQRHIP_CSB_R", 0);
+    if (R <= 0) {
+        const int64_t k = ((int64_t)rows + (int64_t)CSB_GRID * CSB_RMAX - 1) / ((int64_t)CSB_GRID * CSB_RMAX);
+        R = (int)(((int64_t)rows + CSB_GRID * k - 1) / (CSB_GRID * k));
+        R = std::max(R, std::min(rows, 512));  // small systems: a few whole blocks rather than 256 slivers
+    }
+    R = std::min(std::max(R, 1), CSB_RMAX);
+    const int nrb = (rows + R - 1) / R;
+    if (nrb > SPMV_MAX_GRID) return LSQRHIP_OK;  // one partial of sum(y^2) per block
+    const int g = (int)std::min<int64_t>(std::max<int64_t>((nnz + 255) / 256, 1), 4096);
+    HIPCHK(hipMemsetAsync(d_flags, 0, 4 * sizeof(int), s));
+    int got[4] = {0, 0, 0, 0};
+    DevScratch s_pos, s_cnt, s_rbs;
+    HIPCHK(s_pos.alloc(sizeof(unsigned) * (size_t)std::max<int64_t>(nnz, 1)));
+    HIPCHK(s_cnt.alloc(sizeof(int) * ((size_t)rows + 1)));
+    HIPCHK(s_rbs.alloc(sizeof(long long) * ((size_t)nrb + 1)));
+    HIPCHK(hipMemsetAsync(s_cnt.p, 0, sizeof(int) * ((size_t)rows + 1), s));
+    unsigned long long *sorted2 = bufA;
+    if (nnz > 0) {
+        hipLaunchKernelGGL(k_csb_pack_col, dim3(g), dim3(256), 0, s, rowk, colk, nnz, rows, cols, bufA, d_flags);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(got, d_flags, sizeof(got), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        if (got[0]) return fail(bad_code, lsqrhip_error_string(bad_code));
+        if (got[2]) return fail(bad_code_other, lsqrhip_error_string(bad_code_other));
+        unsigned long long *sorted1 = bufA;
+        if (got[1]) sorted1 = radix_sort_words(s, bufA, bufB, nnz, bits_for(cols), hist);
+        hipLaunchKernelGGL(k_csb_pos, dim3(g), dim3(256), 0, s, (const unsigned long long *)sorted1, nnz, rowk,
+                           s_pos.as<unsigned>(), s_cnt.as<int>());
+        hipLaunchKernelGGL(k_csb_pack_rb, dim3(g), dim3(256), 0, s, rowk, (const unsigned *)s_pos.as<unsigned>(), nnz, R,
+                           bufA);
+        HIPCHK(hipGetLastError());
+        sorted2 = nrb > 1 ? radix_sort_words(s, bufA, bufB, nnz, bits_for(nrb), hist) : bufA;
+    }
+    hipLaunchKernelGGL(k_rowptr_from_sorted<long long>, dim3(g), dim3(256), 0, s, (const unsigned long long *)sorted2, nnz,
+                       nrb, s_rbs.as<long long>());
+    // the longest row: how many products one accumulator may receive
+    HIPCHK(hipMemsetAsync(d_flags, 0, 4 * sizeof(int), s));
+    hipLaunchKernelGGL(k_csb_maxint, dim3((unsigned)std::min<int64_t>(((int64_t)rows + 255) / 256, 2048)), dim3(256), 0, s,
+                       (const int *)s_cnt.as<int>(), (int64_t)rows, d_flags);
+    HIPCHK(hipGetLastError());
+    std::vector<long long> rbs((size_t)nrb + 1), cptr((size_t)nrb + 1);
+    HIPCHK(hipMemcpyAsync(rbs.data(), s_rbs.p, sizeof(long long) * rbs.size(), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(got, d_flags, sizeof(got), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    const int maxrow = got[0];
+    cptr[0] = 0;
+    for (int b = 0; b < nrb; ++b) cptr[b + 1] = cptr[b] + (rbs[b + 1] - rbs[b] + CSB_CHUNK - 1) / CSB_CHUNK;
+    const long long nchunks = cptr[nrb];
+    if (nchunks >= (1ll << 31)) return LSQRHIP_OK;
+    DevScratch s_val, s_idx, s_cb, s_cptr;
+    const size_t ne = (size_t)std::max<long long>(nchunks, 1) * CSB_CHUNK;
+    HIPCHK(s_val.alloc(sizeof(double) * ne));
+    HIPCHK(s_idx.alloc(sizeof(unsigned) * ne));
+    HIPCHK(s_cb.alloc(sizeof(int) * (size_t)std::max<long long>(nchunks, 1)));
+    HIPCHK(s_cptr.alloc(sizeof(long long) * cptr.size()));
+    HIPCHK(hipMemcpyAsync(s_cptr.p, cptr.data(), sizeof(long long) * cptr.size(), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemsetAsync(d_flags, 0, 4 * sizeof(int), s));
+    if (nchunks > 0)
+        hipLaunchKernelGGL(k_csb_fill, dim3((unsigned)nchunks), dim3(CSB_CHUNK), 0, s, (const unsigned long long *)sorted2,
+                           (const unsigned *)s_pos.as<unsigned>(), rowk, colk, d_a, (const long long *)s_rbs.as<long long>(),
+                           (const long long *)s_cptr.as<long long>(), nrb, R, s_val.as<double>(), s_idx.as<unsigned>(),
+                           s_cb.as<int>(), d_flags);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(got, d_flags, sizeof(got), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (got[3]) return LSQRHIP_OK;  // a chunk too wide for 18-bit local columns: not this layout
+    out = Csr();
+    out.rows = rows;
+    out.cols = cols;
+    out.rows_v = rows;
+    out.csb = 1;
+    out.cval = s_val.release<double>();
+    out.cidx = s_idx.release<unsigned>();
+    out.ccb = s_cb.release<int>();
+    out.cptr = s_cptr.release<long long>();
+    out.nchunks = nchunks;
+    out.nrb = nrb;
+    out.R = R;
+    out.H = std::max(3, bits_for(std::max(maxrow, 1)) + 1);
+    out.grid = std::max(1, std::min(nrb, CSB_GRID));
+    out.out_grid = nrb;
+    out.nblk = nrb;
+    out.bytes = (int64_t)nchunks * CSB_CHUNK * 12 + (int64_t)nchunks * 4 + (int64_t)(nrb + 1) * 8;
+    return LSQRHIP_OK;
+}
+
 // Column panels for a product whose x vector has `cols` entries?  (spmv.h "Column panels")
 //   LSQRHIP_PANELS    0 never | 1 whenever x exceeds one panel | unset: only if the columns are not local
 //   LSQRHIP_PANEL_KB  panel size in KiB of x (default 2048: half an XCD's 4 MiB L2, the rest streams;
@@ -684,7 +816,8 @@ static int alloc_workspace(H *h)
     HIPCHK(hipMalloc((void **)&h->W, sizeof(double) * n1));
     HIPCHK(hipMalloc((void **)&h->X, sizeof(double) * n1));
     HIPCHK(hipMalloc((void **)&h->SE, sizeof(double) * n1));
-    HIPCHK(hipMalloc((void **)&h->partials, sizeof(double) * SPMV_MAX_GRID));
+    HIPCHK(hipMalloc((void **)&h->partials, sizeof(double) * 3 * SPMV_MAX_GRID));
+    HIPCHK(hipMalloc((void **)&h->xmax_part, sizeof(double) * VEC_MAX_GRID));
     {
         const int64_t zn = std::max<int64_t>(h->A.P > 1 ? h->A.rows_v : 0, h->AT.P > 1 ? h->AT.rows_v : 0);
         if (zn > 0) HIPCHK(hipMalloc((void **)&h->Z, sizeof(double) * (size_t)zn));
@@ -775,17 +908,48 @@ static int finish_create(H *h, const int *d_irow, const int *d_icol, const doubl
         mean_dev = (double)dev / (double)nnz;
     }
     RET(build_dictionary(h, d_a, bufA, d_flags));
+    {   // 2^norm_exp > max|a_ij|: the power-of-two scale of the fused norms and of csb.h's binary grids
+        double amax = 0.0;
+        if (nnz > 0) {
+            double *part = (double *)bufB;  // scratch of >= nnz words
+            const int g = (int)std::min<int64_t>(std::max<int64_t>((nnz + 2 * VEC_BLOCK - 1) / (2 * VEC_BLOCK), 1),
+                                                 std::min<int64_t>(VEC_MAX_GRID, nnz));
+            std::vector<double> hp((size_t)g);
+            hipLaunchKernelGGL(k_amax, dim3(g), dim3(VEC_BLOCK), 0, s, d_a, nnz, part);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemcpyAsync(hp.data(), part, sizeof(double) * (size_t)g, hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+            for (double v : hp) amax = std::max(amax, v);
+        }
+        int e = 0;
+        if (amax > 0.0 && amax < 1.0e308) (void)std::frexp(amax, &e);
+        e = std::min(std::max(e, -1000), 1000);
+        h->amax_exp = e;
+        if (env_int("LSQRHIP_NORM_SCALE", 1) == 0) e = 0;  // ablation: plain sums of squares
+        h->norm_exp = e;
+        h->nsc.s = std::ldexp(1.0, -e);
+        h->nsc.inv = std::ldexp(1.0, e);
+    }
     int pa = 1, pwa = h->n, pt = 1, pwt = h->m, xa = 0, xt = 0;
     choose_panels(h->m, h->n, nnz, mean_dev, &pa, &pwa, &xa);                         // mode 1 gathers V (n)
     choose_panels(h->n, h->m, nnz, mean_dev * (double)std::max(h->m, 1) / (double)std::max(h->n, 1), &pt, &pwt, &xt);  // mode 2 gathers U (m)
-    int rc;
+    // Column-swept row blocks (csb.h) wherever the L2 column panels would have been chosen.
+    //   LSQRHIP_CSB   0 never | 1 for every matrix (tests) | unset: instead of L2 panels
+    const int cmode = env_int("LSQRHIP_CSB", -1);
+    const bool csb_a = cmode == 1 || (cmode != 0 && pa > 1 && xa == 0);
+    const bool csb_t = cmode == 1 || (cmode != 0 && pt > 1 && xt == 0);
+    if (csb_a) RET(build_csb(s, d_irow, d_icol, d_a, nnz, h->m, h->n, LSQRHIP_ERR_IROW, LSQRHIP_ERR_ICOL, bufA, bufB, hist, d_flags, h->A));
+    if (csb_t) RET(build_csb(s, d_icol, d_irow, d_a, nnz, h->n, h->m, LSQRHIP_ERR_ICOL, LSQRHIP_ERR_IROW, bufA, bufB, hist, d_flags, h->AT));
+    int rc = LSQRHIP_OK;
     if (h->off64) {
-        rc = build_csr_T<long long>(s, d_irow, d_icol, d_a, nnz, h->m, h->n, LSQRHIP_ERR_IROW, LSQRHIP_ERR_ICOL, pa, pwa, xa, bufA, bufB, hist, d_flags, h->dict, h->ndict, h->A);
-        if (rc == LSQRHIP_OK)
+        if (!h->A.csb)
+            rc = build_csr_T<long long>(s, d_irow, d_icol, d_a, nnz, h->m, h->n, LSQRHIP_ERR_IROW, LSQRHIP_ERR_ICOL, pa, pwa, xa, bufA, bufB, hist, d_flags, h->dict, h->ndict, h->A);
+        if (rc == LSQRHIP_OK && !h->AT.csb)
             rc = build_csr_T<long long>(s, d_icol, d_irow, d_a, nnz, h->n, h->m, LSQRHIP_ERR_ICOL, LSQRHIP_ERR_IROW, pt, pwt, xt, bufA, bufB, hist, d_flags, h->dict, h->ndict, h->AT);
     } else {
-        rc = build_csr_T<int>(s, d_irow, d_icol, d_a, nnz, h->m, h->n, LSQRHIP_ERR_IROW, LSQRHIP_ERR_ICOL, pa, pwa, xa, bufA, bufB, hist, d_flags, h->dict, h->ndict, h->A);
-        if (rc == LSQRHIP_OK)
+        if (!h->A.csb)
+            rc = build_csr_T<int>(s, d_irow, d_icol, d_a, nnz, h->m, h->n, LSQRHIP_ERR_IROW, LSQRHIP_ERR_ICOL, pa, pwa, xa, bufA, bufB, hist, d_flags, h->dict, h->ndict, h->A);
+        if (rc == LSQRHIP_OK && !h->AT.csb)
             rc = build_csr_T<int>(s, d_icol, d_irow, d_a, nnz, h->n, h->m, LSQRHIP_ERR_ICOL, LSQRHIP_ERR_IROW, pt, pwt, xt, bufA, bufB, hist, d_flags, h->dict, h->ndict, h->AT);
     }
     RET(rc);
@@ -800,7 +964,7 @@ static int new_handle(int m, int n, int64_t nnz, H **out)
     if (nnz >= (1ll << 32)) return fail(LSQRHIP_ERR_TOO_LARGE, lsqrhip_error_string(LSQRHIP_ERR_TOO_LARGE));
     RET(use_device());
     H *h = new H();
-    h->device = g_device;
+    h->device = g_device.load();
     h->m = m;
     h->n = n;
     h->nnz = nnz;
@@ -872,8 +1036,8 @@ extern "C" int lsqrhip_info(lsqrhip_handle_t h, int64_t *dims)
     dims[11] = h->AT.P;                          //                  CSR(A')
     dims[12] = h->A.sell;                        // sliced-ELL layout in use for A
     dims[13] = h->AT.sell;                       //                          for A'
-    dims[14] = h->A.xlds;                        // LDS-resident panels for A
-    dims[15] = h->AT.xlds;                       //                     for A'
+    dims[14] = h->A.csb ? 3 : h->A.xlds;         // LDS-resident panels for A (3 = column-swept row blocks, csb.h)
+    dims[15] = h->AT.csb ? 3 : h->AT.xlds;       //                     for A'
     return LSQRHIP_OK;
 }
 
@@ -1202,12 +1366,13 @@ extern "C" int lsqrhip_bench_kernel(lsqrhip_handle_t h, int which, int reps, dou
     tmp.t1 = 1.0e-3; tmp.t2 = -0.5; tmp.t3 = 1.0e-3; tmp.sv = 1.0; tmp.su = 1.0;
     tmp.c1.sx = 1.0; tmp.c1.sy = 0.5; tmp.c1.cy = -0.5;   // y <- -0.25 y + A x : bounded
     tmp.c2 = tmp.c1;
-    LsqrState *d_tmp = nullptr;
-    HIPCHK(hipMalloc((void **)&d_tmp, sizeof(LsqrState)));
+    DevScratch s_tmp;  // released on every exit path
+    HIPCHK(s_tmp.alloc(sizeof(LsqrState)));
+    LsqrState *d_tmp = s_tmp.as<LsqrState>();
     HIPCHK(hipMemcpyAsync(d_tmp, &tmp, sizeof(tmp), hipMemcpyHostToDevice, s));
     auto one = [&]() {
-        if (which == 1) launch_spmv(h, h->A, h->V, h->U, &d_tmp->c1, &d_tmp->stop);
-        else if (which == 2) launch_spmv(h, h->AT, h->U, h->V, &d_tmp->c2, &d_tmp->stop);
+        if (which == 1) launch_spmv(h, h->A, h->V, h->U, &d_tmp->c1, &d_tmp->stop, nullptr, nullptr, true);
+        else if (which == 2) launch_spmv(h, h->AT, h->U, h->V, &d_tmp->c2, &d_tmp->stop, nullptr, nullptr, true);
         else hipLaunchKernelGGL(k_update, dim3(h->vgrid_n), dim3(VEC_BLOCK), 0, s, h->X, h->W, h->V, h->SE,
                                 (int64_t)h->n, (const LsqrState *)d_tmp, h->partials);
     };
@@ -1219,7 +1384,6 @@ extern "C" int lsqrhip_bench_kernel(lsqrhip_handle_t h, int which, int reps, dou
     HIPCHK(hipStreamSynchronize(s));
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, h->ev_loop0, h->ev_loop1));
-    (void)hipFree(d_tmp);
     *avg_ms = (double)ms / reps;
     return LSQRHIP_OK;
 }
@@ -1269,6 +1433,26 @@ extern "C" int lsqrhip_set_option(lsqrhip_handle_t h, const char *name, int64_t 
     else if (k == "poll_ahead") h->poll_ahead = value != 0;
     else if (k == "op_batch") h->op_batch = value < 1 ? 1 : (int)value;
     else if (k == "pipeline") h->pipeline = value < 0 ? 0 : (value > 2 ? 2 : (int)value);
+    else if (k == "norm_exp") {  // the ranks of a row-sharded solve must scale their sums of squares alike
+        if (value < -1000 || value > 1000) return fail(LSQRHIP_ERR_ARG, "norm_exp must be in [-1000, 1000]");
+        h->norm_exp = (int)value;
+        h->nsc.s = std::ldexp(1.0, -(int)value);
+        h->nsc.inv = std::ldexp(1.0, (int)value);
+    } else return fail(LSQRHIP_ERR_ARG, "unknown option: " + k);
+    return LSQRHIP_OK;
+}
+
+extern "C" int lsqrhip_get_option(lsqrhip_handle_t h, const char *name, int64_t *value)
+{
+    if (!h || !name || !value) return fail(LSQRHIP_ERR_ARG, "null handle, option name or result");
+    const std::string k(name);
+    if (k == "graph") *value = h->use_graph;
+    else if (k == "graph_iters") *value = h->graph_iters;
+    else if (k == "time_kernels") *value = h->time_kernels;
+    else if (k == "poll_ahead") *value = h->poll_ahead;
+    else if (k == "op_batch") *value = h->op_batch;
+    else if (k == "pipeline") *value = h->pipeline;
+    else if (k == "norm_exp") *value = h->norm_exp;
     else return fail(LSQRHIP_ERR_ARG, "unknown option: " + k);
     return LSQRHIP_OK;
 }

@@ -59,16 +59,14 @@ static int op_iteration(H *h)
     hipLaunchKernelGGL(k_op_prep, dim3(gmn), dim3(VEC_BLOCK), 0, s, h->U, m, h->opX, (const double *)h->V, n,
                        (const SpmvCoef *)&st->c1, (const int *)&st->stop);
     RET(op_call(h, 1, h->opX, h->U));
-    hipLaunchKernelGGL(k_dot, dim3(h->vgrid_m), dim3(VEC_BLOCK), 0, s, (const double *)h->U, (const double *)h->U, m,
-                       h->partials);
-    hipLaunchKernelGGL(k_s1<true>, dim3(1), dim3(SC_BLOCK), 0, s, (const double *)h->partials, h->vgrid_m,
+    hipLaunchKernelGGL(k_sumsq3, dim3(h->vgrid_m), dim3(VEC_BLOCK), 0, s, (const double *)h->U, m, h->partials);
+    hipLaunchKernelGGL((k_s1<true, true>), dim3(1), dim3(SC_BLOCK), 0, s, (const double *)h->partials, h->vgrid_m,
                        (const double *)nullptr, st);
     hipLaunchKernelGGL(k_op_prep, dim3(gmn), dim3(VEC_BLOCK), 0, s, h->V, n, h->opY, (const double *)h->U, m,
                        (const SpmvCoef *)&st->c2, (const int *)&st->stop);
     RET(op_call(h, 2, h->V, h->opY));
-    hipLaunchKernelGGL(k_dot, dim3(h->vgrid_n), dim3(VEC_BLOCK), 0, s, (const double *)h->V, (const double *)h->V, n,
-                       h->partials);
-    hipLaunchKernelGGL(k_s2<true>, dim3(1), dim3(SC_BLOCK), 0, s, (const double *)h->partials, h->vgrid_n,
+    hipLaunchKernelGGL(k_sumsq3, dim3(h->vgrid_n), dim3(VEC_BLOCK), 0, s, (const double *)h->V, n, h->partials);
+    hipLaunchKernelGGL((k_s2<true, true>), dim3(1), dim3(SC_BLOCK), 0, s, (const double *)h->partials, h->vgrid_n,
                        (const double *)nullptr, st);
     launch_update(h, h->partials, nullptr, nullptr);
     hipLaunchKernelGGL(k_s3<true>, dim3(1), dim3(SC_BLOCK), 0, s, (const double *)h->partials, h->vgrid_n,
@@ -98,16 +96,16 @@ static int solve_op(H *h, const double *b, bool b_on_device, double damp, double
         if (wantse) HIPCHK(hipMemsetAsync(h->SE, 0, sizeof(double) * (size_t)n, s));
     }
     // beta = norm(u); u /= beta; v = A'u; alpha = norm(v); v /= alpha; w = v      (:632-644)
-    hipLaunchKernelGGL(k_dot, dim3(h->vgrid_m), dim3(VEC_BLOCK), 0, s, (const double *)h->U, (const double *)h->U,
-                       (int64_t)m, h->partials);
+    hipLaunchKernelGGL(k_sumsq3, dim3(h->vgrid_m), dim3(VEC_BLOCK), 0, s, (const double *)h->U, (int64_t)m,
+                       h->partials);
     hipLaunchKernelGGL(k_s_init1<true>, dim3(1), dim3(SC_BLOCK), 0, s, (const double *)h->partials, h->vgrid_m,
                        (const double *)nullptr, st, (NormSlot *)nullptr);
     hipLaunchKernelGGL(k_op_prep, dim3(vec_grid(std::max(m, n))), dim3(VEC_BLOCK), 0, s, h->V, (int64_t)n, h->opY,
                        (const double *)h->U, (int64_t)m, (const SpmvCoef *)&st->c2, (const int *)h->d_zero);
     RET(op_call(h, 2, h->V, h->opY));
-    hipLaunchKernelGGL(k_dot, dim3(h->vgrid_n), dim3(VEC_BLOCK), 0, s, (const double *)h->V, (const double *)h->V,
-                       (int64_t)n, h->partials);
-    hipLaunchKernelGGL(k_s_init2<true>, dim3(1), dim3(SC_BLOCK), 0, s, (const double *)h->partials, h->vgrid_n,
+    hipLaunchKernelGGL(k_sumsq3, dim3(h->vgrid_n), dim3(VEC_BLOCK), 0, s, (const double *)h->V, (int64_t)n,
+                       h->partials);
+    hipLaunchKernelGGL((k_s_init2<true, true>), dim3(1), dim3(SC_BLOCK), 0, s, (const double *)h->partials, h->vgrid_n,
                        (const double *)nullptr, st);
     hipLaunchKernelGGL(k_copy_scale, dim3(h->vgrid_n), dim3(VEC_BLOCK), 0, s, h->W, (const double *)h->V, (int64_t)n,
                        (const LsqrState *)st);

@@ -37,12 +37,37 @@ __device__ __forceinline__ double take_sum(const double *partials, int np, const
     return block_sum<SC_BLOCK>(s, red);  // valid in thread 0
 }
 
+// ---- range-safe norms (dnrm2, src/lsqrblas.f90:123-159) ----------------------------------------
+// The reference's dnrm2 is the scaled (dlassq) recurrence: it cannot over- or underflow.  Two
+// forms here, both one pass over the data and both with the reference's full range:
+//
+//  * fused in-loop norms of a MATRIX handle: the producing kernel sums (y * ns)^2 with ns a power
+//    of two fixed per matrix (2^-e, 2^e ~ max|a_ij|: u = A v - alpha u and v = A'u - beta v live at
+//    the scale of the matrix entries whatever b is), and every consumer takes sqrt(sum) * (1/ns).
+//    Scaling by a power of two is exact, so within the old range nothing changes by a bit.
+//  * norm(b) and every norm of a user OPERATOR (no matrix to take a scale from): Blue's three
+//    accumulators as in LAPACK 3.10's dnrm2 -- squares of big / small elements are summed in
+//    scaled form, the rest plainly -- combined by blue_norm.  Within the mid range (1.5e-154 <
+//    |x| < 2e146 for all elements) this is the plain sqrt(sum x^2), bit for bit.
+// The norm a scalar step starts from (valid in thread 0).  BLUE = false: sqrt(sum of the np partials
+// of (y * ns)^2) * ninv, or of the already reduced *pre.  BLUE = true: three planes of np partials
+// (small, mid, big) at partials, partials + np, partials + 2 np -- or pre[0..2].
+template <bool REDUCE, bool BLUE>
+__device__ __forceinline__ double take_norm(const double *partials, int np, const double *pre, double ninv,
+                                            double *red)
+{
+    if (!BLUE) return sqrt(take_sum<REDUCE>(partials, np, pre, red)) * ninv;
+    const double a0 = take_sum<REDUCE>(partials, np, pre, red);
+    const double a1 = take_sum<REDUCE>(partials + np, np, pre + 1, red);
+    const double a2 = take_sum<REDUCE>(partials + 2 * (size_t)np, np, pre + 2, red);
+    return blue_norm(a0, a1, a2);
+}
+
 // ---- step 1: after mode 1.  beta = norm(A v - alpha u); anorm        (:675, :683-693) ----
-__device__ __forceinline__ void s1_step(LsqrState *st, double sum)
+__device__ __forceinline__ void s1_step(LsqrState *st, double beta)
 {
     st->itn = st->itn + 1;
     const double alpha = st->alpha;
-    const double beta = sqrt(sum);
     st->beta = beta;
     double temp = d2norm(alpha, beta);
     temp = d2norm(temp, st->damp);
@@ -101,12 +126,12 @@ __device__ __forceinline__ Rot rot_step(double rhobar, double phibar, double dam
 }
 
 // ---- step 2: after mode 2.  alpha = norm(A'u - beta v); rotations; update coefficients (:695-726)
-__device__ __forceinline__ void s2_step(LsqrState *st, double sum, bool skipped)
+__device__ __forceinline__ void s2_step(LsqrState *st, double alpha_new, bool skipped)
 {
     double alpha = st->alpha;
     const double beta = st->beta;
     if (!skipped) {
-        alpha = sqrt(sum);
+        alpha = alpha_new;
         st->alpha = alpha;
         st->sv = alpha > 0.0 ? 1.0 / alpha : 1.0;
     }
@@ -128,16 +153,15 @@ __device__ __forceinline__ void s2_step(LsqrState *st, double sum, bool skipped)
     st->c1.skip = 0;
 }
 
-// after sum(b^2): beta = norm(b); u = b/beta     (src/lsqr.f90:597-617, 632-637)
+// after the three Blue sums of b (vec.h k_sumsq3): beta = norm(b); u = b/beta     (src/lsqr.f90:597-617, 632-637)
 // `slot` (optional) receives (beta, 1/beta) for the first pipelined mode-1 launch.
 template <bool REDUCE>
 __global__ __launch_bounds__(SC_BLOCK) void k_s_init1(const double *partials, int np, const double *pre,
                                                       LsqrState *st, NormSlot *slot)
 {
     __shared__ double red[SC_BLOCK / WAVE];
-    const double sum = take_sum<REDUCE>(partials, np, pre, red);
+    const double beta = take_norm<REDUCE, true>(partials, np, pre, 1.0, red);  // norm(b): Blue's form
     if (threadIdx.x != 0) return;
-    const double beta = sqrt(sum);
     st->beta = beta;
     st->alpha = 0.0;
     st->sv = 1.0;
@@ -159,16 +183,16 @@ __global__ __launch_bounds__(SC_BLOCK) void k_s_init1(const double *partials, in
 }
 
 // after sum(V^2): alpha = norm(A'u); v = V/alpha; arnorm; loop entry     (:638-653)
-template <bool REDUCE>
+template <bool REDUCE, bool BLUE = false>
 __global__ __launch_bounds__(SC_BLOCK) void k_s_init2(const double *partials, int np, const double *pre,
                                                       LsqrState *st)
 {
     __shared__ double red[SC_BLOCK / WAVE];
     const bool skipped = st->c2.skip != 0;
-    const double sum = take_sum<REDUCE>(partials, np, pre, red);
+    const double nrm = take_norm<REDUCE, BLUE>(partials, np, pre, st->ns_inv, red);
     if (threadIdx.x != 0) return;
     const double beta = st->beta;
-    const double alpha = skipped ? 0.0 : sqrt(sum);
+    const double alpha = skipped ? 0.0 : nrm;
     st->alpha = alpha;
     st->sv = alpha > 0.0 ? 1.0 / alpha : 1.0;
     st->arnorm = alpha * beta;
@@ -190,25 +214,25 @@ __global__ __launch_bounds__(SC_BLOCK) void k_s_init2(const double *partials, in
     st->c1.skip = 0;
 }
 
-template <bool REDUCE>
+template <bool REDUCE, bool BLUE = false>
 __global__ __launch_bounds__(SC_BLOCK) void k_s1(const double *partials, int np, const double *pre, LsqrState *st)
 {
     if (st->stop != 0) return;
     __shared__ double red[SC_BLOCK / WAVE];
-    const double sum = take_sum<REDUCE>(partials, np, pre, red);
+    const double nrm = take_norm<REDUCE, BLUE>(partials, np, pre, st->ns_inv, red);
     if (threadIdx.x != 0) return;
-    s1_step(st, sum);
+    s1_step(st, nrm);
 }
 
-template <bool REDUCE>
+template <bool REDUCE, bool BLUE = false>
 __global__ __launch_bounds__(SC_BLOCK) void k_s2(const double *partials, int np, const double *pre, LsqrState *st)
 {
     if (st->stop != 0) return;
     __shared__ double red[SC_BLOCK / WAVE];
     const bool skipped = st->c2.skip != 0;
-    const double sum = take_sum<REDUCE>(partials, np, pre, red);
+    const double nrm = take_norm<REDUCE, BLUE>(partials, np, pre, st->ns_inv, red);
     if (threadIdx.x != 0) return;
-    s2_step(st, sum, skipped);
+    s2_step(st, nrm, skipped);
 }
 
 // steps 1 and 2 in one launch: p1 = partials of the mode-1 SpMV, p2 = partials of the
@@ -221,8 +245,8 @@ __global__ __launch_bounds__(SC_BLOCK) void k_s12(const double *p1, int np1, con
     const double sum1 = take_sum<true>(p1, np1, nullptr, red);
     const double sum2 = take_sum<true>(p2, np2, nullptr, red);
     if (threadIdx.x != 0) return;
-    s1_step(st, sum1);
-    s2_step(st, sum2, st->c2.skip != 0);
+    s1_step(st, sqrt(sum1) * st->ns_inv);
+    s2_step(st, sqrt(sum2) * st->ns_inv, st->c2.skip != 0);
 }
 
 // ---- step 3: after the x/w update.  dknorm, norm estimates, stopping tests, istop (:751-810, 843-850)
@@ -338,8 +362,8 @@ __device__ __forceinline__ void run_rider(const Rider &r, double *red)
         const double sum1 = take_sum<true>(r.pa, r.na, nullptr, red);
         const double sum2 = take_sum<true>(r.pb, r.nb, nullptr, red);
         if (threadIdx.x != 0) return;
-        s1_step(st, sum1);
-        s2_step(st, sum2, st->c2.skip != 0);
+        s1_step(st, sqrt(sum1) * st->ns_inv);
+        s2_step(st, sqrt(sum2) * st->ns_inv, st->c2.skip != 0);
     } else if (r.kind == 2) {
         const double sum = take_sum<true>(r.pa, r.na, nullptr, red);
         if (threadIdx.x != 0) return;

@@ -201,11 +201,11 @@ template <bool UPD>
 __device__ __forceinline__ bool sell_prologue(const SpmvCoef *__restrict__ coef, const double *__restrict__ pin, int npin,
                                               const NormSlot *__restrict__ slot_in, NormSlot *__restrict__ slot_out,
                                               int skip_if_zero, const UpdArgs &upd, int nwg, int wg, double *red,
-                                              SellCoef &k)
+                                              SellCoef &k, const NScale nsc)
 {
     const int tid = threadIdx.x;
     if (pin != nullptr) {  // lazy coefficients (spmv.h)
-        const double nrm = sqrt(block_sum_all<SELL_BLOCK>(pin, npin, red));
+        const double nrm = sqrt(block_sum_all<SELL_BLOCK>(pin, npin, red)) * nsc.inv;
         if (skip_if_zero && !(nrm > 0.0)) {  // mode 2 is skipped when beta == 0 (:691)
             if (wg == 0 && tid == 0) {
                 slot_out->nrm = nrm;
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(SELL_BLOCK, 8) void k_spmv_sell(
     int rows, int nslices, int64_t nblk, const double *__restrict__ x, double *__restrict__ y,
     const SpmvCoef *__restrict__ coef, const int *__restrict__ stop, double *__restrict__ partials,
     const double *__restrict__ pin, int npin, const NormSlot *__restrict__ slot_in,
-    NormSlot *__restrict__ slot_out, int skip_if_zero, Rider rider, UpdArgs upd)
+    NormSlot *__restrict__ slot_out, int skip_if_zero, Rider rider, UpdArgs upd, NScale nsc)
 {
     __shared__ double red[SELL_BLOCK / WAVE + 1];
     __shared__ double sdict[V8 ? VD_MAX : 1];
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(SELL_BLOCK, 8) void k_spmv_sell(
     if (V8) sdict[tid] = dict[tid];  // visible after the first barrier below
 
     SellCoef kc;
-    if (!sell_prologue<UPD>(coef, pin, npin, slot_in, slot_out, skip_if_zero, upd, nwg, wg, red, kc)) return;
+    if (!sell_prologue<UPD>(coef, pin, npin, slot_in, slot_out, skip_if_zero, upd, nwg, wg, red, kc, nsc)) return;
     const double sx = kc.sx, sy = kc.sy, cy = kc.cy;
     if (V8) __syncthreads();
 
@@ -316,7 +316,8 @@ __global__ __launch_bounds__(SELL_BLOCK, 8) void k_spmv_sell(
         if (active) {
             const double yn = cy * (y0 * sy) + sum;
             y[r] = yn;
-            sq += yn * yn;
+            const double ys = yn * nsc.s;
+            sq += ys * ys;
         }
     }
     const double tot = block_sum<SELL_BLOCK>(sq, red);
@@ -419,7 +420,7 @@ __global__ __launch_bounds__(SELL_BLOCK, 8) void k_spmv_sellp(
     const double *__restrict__ dict, int rows, int nslices, int64_t nblk, const double *__restrict__ x,
     double *__restrict__ y, const SpmvCoef *__restrict__ coef, const int *__restrict__ stop,
     double *__restrict__ partials, const double *__restrict__ pin, int npin, const NormSlot *__restrict__ slot_in,
-    NormSlot *__restrict__ slot_out, int skip_if_zero, Rider rider, UpdArgs upd)
+    NormSlot *__restrict__ slot_out, int skip_if_zero, Rider rider, UpdArgs upd, NScale nsc)
 {
     __shared__ double red[SELL_BLOCK / WAVE + 1];
     __shared__ double sdict[VD_MAX];
@@ -435,7 +436,7 @@ __global__ __launch_bounds__(SELL_BLOCK, 8) void k_spmv_sellp(
     sdict[tid] = dict[tid];  // visible after the barrier below
 
     SellCoef kc;
-    if (!sell_prologue<UPD>(coef, pin, npin, slot_in, slot_out, skip_if_zero, upd, nwg, wg, red, kc)) return;
+    if (!sell_prologue<UPD>(coef, pin, npin, slot_in, slot_out, skip_if_zero, upd, nwg, wg, red, kc, nsc)) return;
     const double sx = kc.sx, sy = kc.sy, cy = kc.cy;
     __syncthreads();
 
@@ -467,7 +468,8 @@ __global__ __launch_bounds__(SELL_BLOCK, 8) void k_spmv_sellp(
         if (active) {
             const double yn = cy * (y0 * sy) + sum;
             y[r] = yn;
-            sq += yn * yn;
+            const double ys = yn * nsc.s;
+            sq += ys * ys;
         }
     }
     const double tot = block_sum<SELL_BLOCK>(sq, red);

@@ -18,7 +18,7 @@ namespace lsqrhip {
 __global__ __launch_bounds__(VEC_BLOCK) void k_vcombine(double *__restrict__ V, const double *__restrict__ T,
                                                         int64_t n, const SpmvCoef *__restrict__ coef,
                                                         const int *__restrict__ stop,
-                                                        double *__restrict__ partials)
+                                                        double *__restrict__ partials, NScale nsc)
 {
     if (*stop != 0 || coef->skip != 0) return;
     const double sy = coef->sy, cy = coef->cy;
@@ -28,7 +28,8 @@ __global__ __launch_bounds__(VEC_BLOCK) void k_vcombine(double *__restrict__ V, 
     for (int64_t i = (int64_t)blockIdx.x * VEC_BLOCK + threadIdx.x; i < n; i += stride) {
         const double v = cy * (V[i] * sy) + T[i];
         V[i] = v;
-        s += v * v;
+        const double vs = v * nsc.s;
+        s += vs * vs;
     }
     const double tot = block_sum<VEC_BLOCK>(s, red);
     if (threadIdx.x == 0) partials[blockIdx.x] = tot;
@@ -74,6 +75,7 @@ extern "C" int lsqrhip_shard_begin(lsqrhip_handle_t h, const double *d_b_local, 
     init.ctol = conlim > 0.0 ? 1.0 / conlim : 0.0;
     init.cs2 = -1.0;
     init.su = init.sv = 1.0;
+    init.ns_inv = h->nsc.inv;
     init.c1.skip = init.c2.skip = init.c2p.skip = 1;
     *h->h_state = init;
     HIPCHK(hipMemcpyAsync(h->d_state, h->h_state, sizeof(LsqrState), hipMemcpyHostToDevice, s));
@@ -86,7 +88,7 @@ extern "C" int lsqrhip_shard_begin(lsqrhip_handle_t h, const double *d_b_local, 
         HIPCHK(hipMemsetAsync(d_T, 0, sizeof(double) * n, s));
         if (wantse) HIPCHK(hipMemsetAsync(h->SE, 0, sizeof(double) * n, s));
     }
-    HIPCHK(hipMemsetAsync(d_sums, 0, 2 * sizeof(double), s));
+    HIPCHK(hipMemsetAsync(d_sums, 0, 4 * sizeof(double), s));
     h->shard_T = d_T;
     h->shard_sums = d_sums;
     h->shard_wantse = wantse;
@@ -103,38 +105,37 @@ extern "C" int lsqrhip_shard_stage(lsqrhip_handle_t h, int stage)
     double *T = h->shard_T, *sums = h->shard_sums;
     const int64_t n = h->n, m = h->m;
     switch (stage) {
-    case ST_SUMSQ_B:  // sums[0] = |b_p|^2
-        hipLaunchKernelGGL(k_dot, dim3(h->vgrid_m), dim3(VEC_BLOCK), 0, s, (const double *)h->U, (const double *)h->U, m,
-                           h->partials);
-        hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(VEC_BLOCK), 0, s, (const double *)h->partials,
+    case ST_SUMSQ_B:  // sums[0..2] = Blue's small / mid / big sums of b_p^2 (range-safe, additive over ranks)
+        hipLaunchKernelGGL(k_sumsq3, dim3(h->vgrid_m), dim3(VEC_BLOCK), 0, s, (const double *)h->U, m, h->partials);
+        hipLaunchKernelGGL(k_reduce_partials3, dim3(1), dim3(VEC_BLOCK), 0, s, (const double *)h->partials,
                            h->vgrid_m, sums);
         break;
-    case ST_INIT_BETA_ATU:  // beta from the all-reduced sums[0]; T_p = A_p'(U_p/beta)
+    case ST_INIT_BETA_ATU:  // beta from the all-reduced sums[0..2]; T_p = A_p'(U_p/beta)
         hipLaunchKernelGGL(k_s_init1<false>, dim3(1), dim3(SC_BLOCK), 0, s, (const double *)h->partials, 0,
                            (const double *)sums, st, (NormSlot *)nullptr);
-        launch_spmv(h, h->AT, h->U, T, &st->c2p, h->d_zero);
+        launch_spmv(h, h->AT, h->U, T, &st->c2p, h->d_zero, nullptr, nullptr, true);
         break;
     case ST_INIT_V:  // V = sum_p T_p (all-reduced); alpha, v, w
         hipLaunchKernelGGL(k_vcombine, dim3(h->vgrid_n), dim3(VEC_BLOCK), 0, s, h->V, (const double *)T, n,
-                           (const SpmvCoef *)&st->c2, (const int *)h->d_zero, h->partials);
+                           (const SpmvCoef *)&st->c2, (const int *)h->d_zero, h->partials, h->nsc);
         hipLaunchKernelGGL(k_s_init2<true>, dim3(1), dim3(SC_BLOCK), 0, s, (const double *)h->partials, h->vgrid_n,
                            (const double *)nullptr, st);
         hipLaunchKernelGGL(k_copy_scale, dim3(h->vgrid_n), dim3(VEC_BLOCK), 0, s, h->W, (const double *)h->V, n,
                            (const LsqrState *)st);
         break;
     case ST_MODE1:  // U_p <- (-alpha)(U_p su) + A_p (V sv); sums[0] = |U_p|^2
-        launch_spmv(h, h->A, h->V, h->U, &st->c1, &st->stop);
+        launch_spmv(h, h->A, h->V, h->U, &st->c1, &st->stop, nullptr, nullptr, true);
         hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(VEC_BLOCK), 0, s, (const double *)h->partials,
                            h->A.out_grid, sums);
         break;
     case ST_S1_ATU:  // beta, anorm from the all-reduced sums[0]; T_p = A_p'(U_p su)
         hipLaunchKernelGGL(k_s1<false>, dim3(1), dim3(SC_BLOCK), 0, s, (const double *)h->partials, 0,
                            (const double *)sums, st);
-        launch_spmv(h, h->AT, h->U, T, &st->c2p, &st->stop);
+        launch_spmv(h, h->AT, h->U, T, &st->c2p, &st->stop, nullptr, nullptr, true);
         break;
     case ST_VCOMBINE_UPDATE:  // V <- (-beta)(V sv) + sum_p T_p; alpha; rotations; x, w; tests
         hipLaunchKernelGGL(k_vcombine, dim3(h->vgrid_n), dim3(VEC_BLOCK), 0, s, h->V, (const double *)T, n,
-                           (const SpmvCoef *)&st->c2, (const int *)&st->stop, h->partials);
+                           (const SpmvCoef *)&st->c2, (const int *)&st->stop, h->partials, h->nsc);
         hipLaunchKernelGGL(k_s2<true>, dim3(1), dim3(SC_BLOCK), 0, s, (const double *)h->partials, h->vgrid_n,
                            (const double *)nullptr, st);
         hipLaunchKernelGGL(k_update, dim3(h->vgrid_n), dim3(VEC_BLOCK), 0, s, h->X, h->W, (const double *)h->V,

@@ -63,6 +63,8 @@ struct SpmvArgs {
     UpdArgs upd{};                   // x/w update of the previous iteration carried by this launch (on = 0: none)
     hipStream_t stream = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;  // kernel begin/end timestamps (hipExtLaunchKernelGGL)
+    NScale nsc{1.0, 1.0};            // power-of-two scale inside the sums of squares (filled in by launch_spmv_args)
+    bool unit_x = false;             // |x * sx| <= 1 is known (solver-internal vectors): csb.h needs no max|x| pass
 };
 
 template <typename OffT, bool PANEL, bool C16, bool V8, bool UPD, bool XL = false>
@@ -77,12 +79,12 @@ static void launch_spmv_C(const SpmvArgs &a, double *y, hipEvent_t e0, hipEvent_
         hipLaunchKernelGGL((k_spmv_fused<OffT, PANEL, C16, V8, UPD, XL>), grid, dim3(SPMV_BLOCK), 0, a.stream,
                            (const OffT *)c.rowptr, colv, (const int *)c.cbase, valv, (const double *)c.dict,
                            (const RowBlock *)c.blk, c.nblk, a.x, y, a.coef, a.stop, a.pout, a.pin, a.npin, a.slot_in,
-                           a.slot_out, a.skip_if_zero, a.rider, a.upd, xa);
+                           a.slot_out, a.skip_if_zero, a.rider, a.upd, xa, a.nsc);
     else
         hipExtLaunchKernelGGL((k_spmv_fused<OffT, PANEL, C16, V8, UPD, XL>), grid, dim3(SPMV_BLOCK), 0, a.stream, e0, e1, 0,
                               (const OffT *)c.rowptr, colv, (const int *)c.cbase, valv, (const double *)c.dict,
                               (const RowBlock *)c.blk, c.nblk, a.x, y, a.coef, a.stop, a.pout, a.pin, a.npin,
-                              a.slot_in, a.slot_out, a.skip_if_zero, a.rider, a.upd, xa);
+                              a.slot_in, a.slot_out, a.skip_if_zero, a.rider, a.upd, xa, a.nsc);
 }
 
 template <typename OffT, bool PANEL>
@@ -122,13 +124,13 @@ static void launch_sell_C(const SpmvArgs &a)
         hipLaunchKernelGGL((k_spmv_sell<C16, V8, UPD>), grid, dim3(SELL_BLOCK), 0, a.stream, (const unsigned *)c.soff,
                            (const void *)c.scol, (const int *)c.cbaseS, (const void *)c.sval, (const double *)c.dict,
                            (const unsigned char *)c.rlen, c.rows, c.nslices, c.nblk, a.x, a.y, a.coef, a.stop, a.pout,
-                           a.pin, a.npin, a.slot_in, a.slot_out, a.skip_if_zero, a.rider, a.upd);
+                           a.pin, a.npin, a.slot_in, a.slot_out, a.skip_if_zero, a.rider, a.upd, a.nsc);
     else
         hipExtLaunchKernelGGL((k_spmv_sell<C16, V8, UPD>), grid, dim3(SELL_BLOCK), 0, a.stream, a.e0, a.e1, 0,
                               (const unsigned *)c.soff, (const void *)c.scol, (const int *)c.cbaseS,
                               (const void *)c.sval, (const double *)c.dict, (const unsigned char *)c.rlen, c.rows,
                               c.nslices, c.nblk, a.x, a.y, a.coef, a.stop, a.pout, a.pin, a.npin, a.slot_in,
-                              a.slot_out, a.skip_if_zero, a.rider, a.upd);
+                              a.slot_out, a.skip_if_zero, a.rider, a.upd, a.nsc);
 }
 
 template <bool UPD>
@@ -140,12 +142,12 @@ static void launch_sellp(const SpmvArgs &a)
         hipLaunchKernelGGL((k_spmv_sellp<UPD>), grid, dim3(SELL_BLOCK), 0, a.stream, (const unsigned *)c.soff,
                            (const uint4 *)c.srec, (const int *)c.cbaseS, (const double *)c.dict, c.rows, c.nslices,
                            c.nblk, a.x, a.y, a.coef, a.stop, a.pout, a.pin, a.npin, a.slot_in, a.slot_out,
-                           a.skip_if_zero, a.rider, a.upd);
+                           a.skip_if_zero, a.rider, a.upd, a.nsc);
     else
         hipExtLaunchKernelGGL((k_spmv_sellp<UPD>), grid, dim3(SELL_BLOCK), 0, a.stream, a.e0, a.e1, 0,
                               (const unsigned *)c.soff, (const uint4 *)c.srec, (const int *)c.cbaseS,
                               (const double *)c.dict, c.rows, c.nslices, c.nblk, a.x, a.y, a.coef, a.stop, a.pout,
-                              a.pin, a.npin, a.slot_in, a.slot_out, a.skip_if_zero, a.rider, a.upd);
+                              a.pin, a.npin, a.slot_in, a.slot_out, a.skip_if_zero, a.rider, a.upd, a.nsc);
 }
 
 template <typename OffT, bool V8, bool C16>
@@ -159,12 +161,12 @@ static void launch_xl_C(const SpmvArgs &a, double *z)
     if (a.e0 == nullptr)
         hipLaunchKernelGGL((k_spmv_xlw<OffT, V8, C16>), grid, dim3(XLW_BLOCK), 0, a.stream, (const OffT *)c.rowptr,
                            colv, valv, (const double *)c.dict, (const RowBlock *)c.blk, c.nblk, (const int *)c.gpid, a.x, z,
-                           a.coef, a.stop, a.pin, a.npin, a.slot_out, a.skip_if_zero, a.rider, xa);
+                           a.coef, a.stop, a.pin, a.npin, a.slot_out, a.skip_if_zero, a.rider, xa, a.nsc);
     else
         hipExtLaunchKernelGGL((k_spmv_xlw<OffT, V8, C16>), grid, dim3(XLW_BLOCK), 0, a.stream, a.e0, nullptr, 0,
                               (const OffT *)c.rowptr, colv, valv, (const double *)c.dict, (const RowBlock *)c.blk,
                               c.nblk, (const int *)c.gpid, a.x, z, a.coef, a.stop, a.pin, a.npin, a.slot_out,
-                              a.skip_if_zero, a.rider, xa);
+                              a.skip_if_zero, a.rider, xa, a.nsc);
 }
 template <typename OffT, bool V8>
 static void launch_xl(const SpmvArgs &a, double *z)
@@ -173,9 +175,37 @@ static void launch_xl(const SpmvArgs &a, double *z)
     else launch_xl_C<OffT, V8, false>(a, z);
 }
 
-static void launch_spmv_args(H *h, const SpmvArgs &a)
+// column-swept row blocks (csb.h).  A product on caller vectors first needs max|x| (the bound on
+// the products that fixes the binary grids of the exact sums); the solver's own vectors are unit.
+static void launch_csb(H *h, const SpmvArgs &a)
 {
     const Csr &c = *a.c;
+    CsbX xb{nullptr, 0};
+    if (!a.unit_x) {
+        const int g = vec_grid(2 * (int64_t)c.cols);
+        hipLaunchKernelGGL(k_amax, dim3(g), dim3(VEC_BLOCK), 0, a.stream, a.x, (int64_t)c.cols, h->xmax_part);
+        xb.xmax = h->xmax_part;
+        xb.nxmax = g;
+    }
+    const CsbMat A{c.cval, c.cidx, c.ccb, c.cptr, c.nrb, c.R, c.rows, c.cols, h->amax_exp, c.H};
+    const dim3 grid(c.grid + (a.rider.kind != 0 ? 1 : 0));
+    if (a.e0 == nullptr && a.e1 == nullptr)
+        hipLaunchKernelGGL(k_spmv_csb, grid, dim3(CSB_BLOCK), 0, a.stream, A, a.x, a.y, a.coef, a.stop, a.pout, a.pin,
+                           a.npin, a.slot_in, a.slot_out, a.skip_if_zero, a.rider, xb, a.nsc);
+    else
+        hipExtLaunchKernelGGL(k_spmv_csb, grid, dim3(CSB_BLOCK), 0, a.stream, a.e0, a.e1, 0, A, a.x, a.y, a.coef, a.stop,
+                              a.pout, a.pin, a.npin, a.slot_in, a.slot_out, a.skip_if_zero, a.rider, xb, a.nsc);
+}
+
+static void launch_spmv_args(H *h, const SpmvArgs &a_in)
+{
+    SpmvArgs a = a_in;
+    a.nsc = h->nsc;
+    const Csr &c = *a.c;
+    if (c.csb) {
+        launch_csb(h, a);
+        return;
+    }
     if (c.sell == 2) {  // sliced ELL, packed records (sell.h)
         if (a.upd.on) launch_sellp<true>(a);
         else launch_sellp<false>(a);
@@ -218,20 +248,20 @@ static void launch_spmv_args(H *h, const SpmvArgs &a)
     }
     if (a.e1 == nullptr)
         hipLaunchKernelGGL(k_panel_combine, dim3(c.out_grid), dim3(SPMV_BLOCK), 0, a.stream, a.y, (const double *)h->Z,
-                           c.rows, c.P, a.coef, a.stop, a.pout, a.pin, a.npin, a.slot_in, a.skip_if_zero);
+                           c.rows, c.P, a.coef, a.stop, a.pout, a.pin, a.npin, a.slot_in, a.skip_if_zero, a.nsc);
     else
         hipExtLaunchKernelGGL(k_panel_combine, dim3(c.out_grid), dim3(SPMV_BLOCK), 0, a.stream, nullptr, a.e1, 0, a.y,
                               (const double *)h->Z, c.rows, c.P, a.coef, a.stop, a.pout, a.pin, a.npin, a.slot_in,
-                              a.skip_if_zero);
+                              a.skip_if_zero, a.nsc);
 }
 
 // explicit-coefficient form on the handle's stream, partials into h->partials
 static void launch_spmv(H *h, const Csr &c, const double *x, double *y, const SpmvCoef *coef, const int *stop,
-                        hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr)
+                        hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr, bool unit_x = false)
 {
     SpmvArgs a;
     a.c = &c; a.x = x; a.y = y; a.coef = coef; a.stop = stop; a.pout = h->partials; a.stream = h->stream;
-    a.e0 = e0; a.e1 = e1;
+    a.e0 = e0; a.e1 = e1; a.unit_x = unit_x;
     launch_spmv_args(h, a);
 }
 
@@ -251,10 +281,10 @@ static void launch_iteration_seq(H *h, hipEvent_t *ev)
 {
     LsqrState *st = h->d_state;
     hipStream_t s = h->stream;
-    launch_spmv(h, h->A, h->V, h->U, &st->c1, &st->stop, ev ? ev[0] : nullptr, ev ? ev[1] : nullptr);
+    launch_spmv(h, h->A, h->V, h->U, &st->c1, &st->stop, ev ? ev[0] : nullptr, ev ? ev[1] : nullptr, true);
     hipLaunchKernelGGL(k_s1<true>, dim3(1), dim3(SC_BLOCK), 0, s, (const double *)h->partials, h->A.out_grid,
                        (const double *)nullptr, st);
-    launch_spmv(h, h->AT, h->U, h->V, &st->c2, &st->stop, ev ? ev[2] : nullptr, ev ? ev[3] : nullptr);
+    launch_spmv(h, h->AT, h->U, h->V, &st->c2, &st->stop, ev ? ev[2] : nullptr, ev ? ev[3] : nullptr, true);
     hipLaunchKernelGGL(k_s2<true>, dim3(1), dim3(SC_BLOCK), 0, s, (const double *)h->partials, h->AT.out_grid,
                        (const double *)nullptr, st);
     launch_update(h, h->partials, ev ? ev[4] : nullptr, ev ? ev[5] : nullptr);
@@ -291,6 +321,7 @@ static void launch_k1(H *h, int i, const Rider &rider, hipEvent_t e0, hipEvent_t
     a.c = &h->A; a.x = h->V; a.y = h->U; a.pin = h->P2[prev]; a.npin = h->AT.out_grid;
     a.slot_in = &slotB[prev]; a.slot_out = &slotA[par]; a.skip_if_zero = 0; a.stop = &h->d_state->stop;
     a.pout = h->P1[par]; a.rider = rider; a.stream = h->stream; a.e0 = e0; a.e1 = e1;
+    a.unit_x = true;
     if (fuse) {
         UpdArgs &u = a.upd;
         u.on = 1;
@@ -312,6 +343,7 @@ static void launch_k2(H *h, int i, const Rider &rider, hipEvent_t e0, hipEvent_t
     a.c = &h->AT; a.x = h->U; a.y = h->V; a.pin = h->P1[par]; a.npin = h->A.out_grid;
     a.slot_in = &slotA[par]; a.slot_out = &slotB[par]; a.skip_if_zero = 1; a.stop = &h->d_state->stop;
     a.pout = h->P2[par]; a.rider = rider; a.stream = h->stream; a.e0 = e0; a.e1 = e1;
+    a.unit_x = true;
     launch_spmv_args(h, a);
 }
 
@@ -330,7 +362,7 @@ static int launch_batch(H *h, int i0, int G, hipEvent_t *ev)
     launch_k1(h, i0, none, E(0, 0), E(0, 1));
     launch_k2(h, i0, none, E(0, 2), E(0, 3));
     // pipeline 2: K4 rides inside K1 (fused update) -- two launches per iteration
-    const bool fuse = h->pipeline >= 2 && h->A.P <= 1;
+    const bool fuse = h->pipeline >= 2 && h->A.P <= 1 && !h->A.csb;
     for (int j = 1; j < G; ++j) {
         const int i = i0 + j;
         if (fuse) {
@@ -410,6 +442,7 @@ static int upload_initial_state(H *h, double damp, double atol, double btol, dou
     init.ctol = conlim > 0.0 ? 1.0 / conlim : 0.0;
     init.cs2 = -1.0;
     init.su = init.sv = 1.0;
+    init.ns_inv = h->nsc.inv;
     init.c1.skip = init.c2.skip = init.c2p.skip = 1;
     *h->h_state = init;
     HIPCHK(hipMemcpyAsync(h->d_state, h->h_state, sizeof(LsqrState), hipMemcpyHostToDevice, h->stream));
@@ -495,13 +528,14 @@ static int solve_core(H *h, const double *b, bool b_on_device, double damp, doub
     // beta = norm(u); u /= beta; v = A'u; alpha = norm(v); v /= alpha; w = v  (:632-644)
     // The mode-2 partials land in P2[0] and (beta, 1/beta) in slot B[0]: exactly what the
     // first lazy mode-1 launch (iteration 1: parity 1, previous parity 0) consumes.
-    hipLaunchKernelGGL(k_dot, dim3(h->vgrid_m), dim3(VEC_BLOCK), 0, s, (const double *)h->U, (const double *)h->U,
-                       (int64_t)m, h->partials);
+    hipLaunchKernelGGL(k_sumsq3, dim3(h->vgrid_m), dim3(VEC_BLOCK), 0, s, (const double *)h->U, (int64_t)m,
+                       h->partials);
     hipLaunchKernelGGL(k_s_init1<true>, dim3(1), dim3(SC_BLOCK), 0, s, (const double *)h->partials, h->vgrid_m,
                        (const double *)nullptr, st, h->slots + 2);
     {
         SpmvArgs a;
         a.c = &h->AT; a.x = h->U; a.y = h->V; a.coef = &st->c2; a.stop = h->d_zero; a.pout = h->P2[0]; a.stream = s;
+        a.unit_x = true;
         launch_spmv_args(h, a);
     }
     hipLaunchKernelGGL(k_s_init2<true>, dim3(1), dim3(SC_BLOCK), 0, s, (const double *)h->P2[0], h->AT.out_grid,
@@ -521,7 +555,7 @@ static int solve_core(H *h, const double *b, bool b_on_device, double damp, doub
     int G = std::max(1, h->graph_iters);
     if (h->pipeline) G = (G + 1) & ~1;  // even: parity-consistent batches
     const bool timed = h->time_kernels != 0;
-    const bool fused_update = h->pipeline >= 2 && h->A.P <= 1;
+    const bool fused_update = h->pipeline >= 2 && h->A.P <= 1 && !h->A.csb;
     const bool graph = h->use_graph != 0 && !timed;
     if (graph) RET(ensure_graph(h, G));
     if (timed && (int)h->ev.size() < 6 * G) {

@@ -237,7 +237,7 @@ __global__ __launch_bounds__(SPMV_BLOCK, XL ? 2 : 8) void k_spmv_fused(
     const void *__restrict__ valv, const double *__restrict__ dict, const RowBlock *__restrict__ blk, int64_t nblk, const double *__restrict__ x, double *__restrict__ y,
     const SpmvCoef *__restrict__ coef, const int *__restrict__ stop, double *__restrict__ partials,
     const double *__restrict__ pin, int npin, const NormSlot *__restrict__ slot_in,
-    NormSlot *__restrict__ slot_out, int skip_if_zero, Rider rider, UpdArgs upd, XlArgs xa)
+    NormSlot *__restrict__ slot_out, int skip_if_zero, Rider rider, UpdArgs upd, XlArgs xa, NScale nsc)
 {
     __shared__ double prod[SPMV_LDS];
     __shared__ double xs[XL ? XL_COLS : 1];
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(SPMV_BLOCK, XL ? 2 : 8) void k_spmv_fused(
 
     double sx, sy, cy;
     if (pin != nullptr) {  // lazy coefficients (uniform branch)
-        const double nrm = sqrt(block_sum_all<SPMV_BLOCK>(pin, npin, red));
+        const double nrm = sqrt(block_sum_all<SPMV_BLOCK>(pin, npin, red)) * nsc.inv;
         if (skip_if_zero && !(nrm > 0.0)) {  // mode 2 is skipped when beta == 0 (:691)
             if (wg == 0 && tid == 0) {
                 slot_out->nrm = nrm;
@@ -466,7 +466,8 @@ __global__ __launch_bounds__(SPMV_BLOCK, XL ? 2 : 8) void k_spmv_fused(
                     } else {
                         const double yn = cy * (y0 * sy) + s;
                         y[r] = yn;
-                        sq += yn * yn;
+                        const double ys = yn * nsc.s;
+                        sq += ys * ys;
                     }
                 }
                 r += ngroups;
@@ -534,7 +535,8 @@ __global__ __launch_bounds__(SPMV_BLOCK, XL ? 2 : 8) void k_spmv_fused(
                 } else {
                     const double yn = cy * (y[r] * sy) + tot;
                     y[r] = yn;
-                    sq += yn * yn;
+                    const double ys = yn * nsc.s;
+                    sq += ys * ys;
                 }
             }
         }
@@ -552,13 +554,13 @@ __global__ __launch_bounds__(SPMV_BLOCK, XL ? 2 : 8) void k_spmv_fused(
 __global__ __launch_bounds__(SPMV_BLOCK) void k_panel_combine(
     double *__restrict__ y, const double *__restrict__ z, int rows, int P,
     const SpmvCoef *__restrict__ coef, const int *__restrict__ stop, double *__restrict__ partials,
-    const double *__restrict__ pin, int npin, const NormSlot *__restrict__ slot_in, int skip_if_zero)
+    const double *__restrict__ pin, int npin, const NormSlot *__restrict__ slot_in, int skip_if_zero, NScale nsc)
 {
     if (*stop != 0) return;
     __shared__ double red[SPMV_BLOCK / WAVE + 1];
     double sy, cy;
     if (pin != nullptr) {
-        const double nrm = sqrt(block_sum_all<SPMV_BLOCK>(pin, npin, red));
+        const double nrm = sqrt(block_sum_all<SPMV_BLOCK>(pin, npin, red)) * nsc.inv;
         if (skip_if_zero && !(nrm > 0.0)) return;
         cy = -nrm;
         sy = slot_in->scale;
@@ -581,7 +583,8 @@ __global__ __launch_bounds__(SPMV_BLOCK) void k_panel_combine(
         for (; p < P; ++p) s = s + z[(int64_t)p * rows + r];
         const double yn = cy * (yold * sy) + s;
         y[r] = yn;
-        sq += yn * yn;
+        const double ys = yn * nsc.s;
+        sq += ys * ys;
     }
     const double tot = block_sum<SPMV_BLOCK>(sq, red);
     if (threadIdx.x == 0) partials[blockIdx.x] = tot;

@@ -24,6 +24,11 @@ struct NormSlot {
     double scale;  // 1/nrm, or 1 when nrm == 0  (the guards at src/lsqr.f90:635, 641, 691, 696)
 };
 
+// Power-of-two scale inside the fused sums of squares: partial += (y * s)^2, norm = sqrt(sum) * inv.
+struct NScale {
+    double s, inv;
+};
+
 struct LsqrState {
     // control ------------------------------------------------------------
     int stop;      // != 0: every kernel of the loop returns at once
@@ -42,6 +47,7 @@ struct LsqrState {
     double damp, atol, btol, ctol;
     // Golub-Kahan scalars ----------------------------------------------------
     double alpha, beta;
+    double ns_inv;  // fused norms are sqrt(sum of (y * ns)^2) * ns_inv, ns a power of two (scalar.h "range-safe norms")
     double su;  // pending scale of U: u = U * su   (1/beta, or 1 when beta == 0)
     double sv;  // pending scale of V: v = V * sv   (1/alpha, or 1 when alpha == 0)
     SpmvCoef c1;    // mode-1 launch of the next iteration: U <- (-alpha)*(U*su) + A (V*sv)

@@ -126,6 +126,46 @@ __global__ __launch_bounds__(VEC_BLOCK) void k_dot(const double *__restrict__ x,
     if (threadIdx.x == 0) partials[blockIdx.x] = tot;
 }
 
+// Blue's three range-safe accumulators of x^2 (scalar.h blue_add): partials[b], partials[g + b],
+// partials[2 g + b] = this workgroup's small / mid / big sums, g = gridDim.x.  Same element order per
+// thread as k_dot, so the mid plane of an in-range vector is k_dot(x, x)'s partials bit for bit.
+__global__ __launch_bounds__(VEC_BLOCK) void k_sumsq3(const double *__restrict__ x, int64_t n,
+                                                      double *__restrict__ partials)
+{
+    __shared__ double red[VEC_BLOCK / WAVE];
+    Blue3 a{0.0, 0.0, 0.0};
+    const int64_t n2 = n >> 1;
+    const int64_t stride = (int64_t)gridDim.x * VEC_BLOCK;
+    const double2 *x2 = reinterpret_cast<const double2 *>(x);
+    for (int64_t i = (int64_t)blockIdx.x * VEC_BLOCK + threadIdx.x; i < n2; i += stride) {
+        const double2 v = x2[i];
+        blue_add(a, v.x);
+        blue_add(a, v.y);
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) blue_add(a, x[n - 1]);
+    const double t0 = block_sum<VEC_BLOCK>(a.sml, red);
+    const double t1 = block_sum<VEC_BLOCK>(a.med, red);
+    const double t2 = block_sum<VEC_BLOCK>(a.big, red);
+    if (threadIdx.x == 0) {
+        partials[blockIdx.x] = t0;
+        partials[gridDim.x + blockIdx.x] = t1;
+        partials[2 * gridDim.x + blockIdx.x] = t2;
+    }
+}
+
+// out[0..2] = the three planes of k_sumsq3 reduced in fixed order (one workgroup): what the row-sharded
+// solve all-reduces for norm(b)
+__global__ __launch_bounds__(VEC_BLOCK) void k_reduce_partials3(const double *__restrict__ partials, int np,
+                                                                double *__restrict__ out)
+{
+    __shared__ double red[VEC_BLOCK / WAVE];
+    for (int k = 0; k < 3; ++k) {
+        const double s = np > 0 ? strided_sum<VEC_BLOCK>(partials + (size_t)k * np, np) : 0.0;
+        const double tot = block_sum<VEC_BLOCK>(s, red);
+        if (threadIdx.x == 0) out[k] = tot;
+    }
+}
+
 __global__ __launch_bounds__(VEC_BLOCK) void k_scale(double *__restrict__ x, int64_t n, double a)
 {
     const int64_t stride = (int64_t)gridDim.x * VEC_BLOCK;

@@ -103,7 +103,7 @@ __global__ __launch_bounds__(XLW_BLOCK, 1) void k_spmv_xlw(
     const double *__restrict__ dict, const RowBlock *__restrict__ blk, int64_t nblk, const int *__restrict__ gpid,
     const double *__restrict__ x, double *__restrict__ z, const SpmvCoef *__restrict__ coef,
     const int *__restrict__ stop, const double *__restrict__ pin, int npin, NormSlot *__restrict__ slot_out,
-    int skip_if_zero, Rider rider, XlArgs xa)
+    int skip_if_zero, Rider rider, XlArgs xa, NScale nsc)
 {
     __shared__ double xs[XL_COLS];
     __shared__ double prod[XLW_WAVES][XLW_C + XLW_LONG];
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(XLW_BLOCK, 1) void k_spmv_xlw(
             bcast = r;
         }
         __syncthreads();
-        const double nrm = sqrt(bcast);
+        const double nrm = sqrt(bcast) * nsc.inv;
         if (skip_if_zero && !(nrm > 0.0)) {
             if (wg == 0 && tid == 0) {
                 slot_out->nrm = nrm;

@@ -189,10 +189,17 @@ class HipShardBackend:
         capi.check(capi.lib().lsqrhip_set_stream(self.h, C.c_void_p(self.stream.cuda_stream)))
         with torch.cuda.stream(self.stream):
             self.T = torch.zeros(max(self.n, 1), dtype=torch.float64, device="cuda")
-            self.sums = torch.zeros(2, dtype=torch.float64, device="cuda")
+            self.sums = torch.zeros(4, dtype=torch.float64, device="cuda")
             self.x = torch.zeros(max(self.n, 1), dtype=torch.float64, device="cuda")
             self.se = None
         self.wantse = False
+        self.nsums_b = 3          # stage 0 leaves Blue's three sums of b^2 in sums[0..2]
+
+    def agree_norm_scale(self, comm):
+        e = C.c_int64()
+        self.capi.check(self.capi.lib().lsqrhip_get_option(self.h, b"norm_exp", C.byref(e)))
+        e_all = comm.agree_max(int(e.value) + 4096) - 4096
+        self.capi.check(self.capi.lib().lsqrhip_set_option(self.h, b"norm_exp", int(e_all)))
 
     def run(self, fn):
         with self.torch.cuda.stream(self.stream):
@@ -241,8 +248,8 @@ class ShardedLSQR:
         self.comm = comm
         self.poll_every = max(1, int(poll_every))
 
-    def _ar_scalar(self):
-        self.comm.all_reduce_sum(self.be.sums[:1])
+    def _ar_scalar(self, k: int = 1):
+        self.comm.all_reduce_sum(self.be.sums[:k])
 
     def _ar_vector(self):
         arv = getattr(self.comm, "all_reduce_vector", None)
@@ -255,9 +262,15 @@ class ShardedLSQR:
         be = self.be
 
         def body():
+            # the ranks scale their fused sums of squares by ONE power of two (csrc/scalar.h
+            # "range-safe norms"): the largest of the exponents their row blocks call for
+            agree = getattr(be, "agree_norm_scale", None)
+            if agree is not None:
+                agree(self.comm)
             be.begin(b_local, damp, atol, btol, conlim, itnlim, wantse)
             be.stage(ST_SUMSQ_B)
-            self._ar_scalar()
+            # norm(b): three range-safe partial sums (small / mid / big elements), additive over ranks
+            self._ar_scalar(getattr(be, "nsums_b", 1))
             be.stage(ST_INIT_BETA_ATU)
             self._ar_vector()
             be.stage(ST_INIT_V)

@@ -9,7 +9,7 @@ import oracle
 from lsqr_amd.solver import lsqr_solver_ez
 
 KNOBS = ["LSQRHIP_SELL", "LSQRHIP_SELLP", "LSQRHIP_VAL8", "LSQRHIP_COL16", "LSQRHIP_PANELS", "LSQRHIP_PANEL_KB",
-         "LSQRHIP_XLDS", "LSQRHIP_XLDS_COLS", "LSQRHIP_OFF64", "LSQRHIP_SKEW", "LSQRHIP_TUNE"]
+         "LSQRHIP_XLDS", "LSQRHIP_XLDS_COLS", "LSQRHIP_OFF64", "LSQRHIP_SKEW", "LSQRHIP_TUNE", "LSQRHIP_CSB", "LSQRHIP_CSB_R"]
 LAYOUTS = [
     {},                                                                        # whatever the build chooses
     {"LSQRHIP_SELL": "0"},
@@ -18,6 +18,8 @@ LAYOUTS = [
     {"LSQRHIP_XLDS": "1", "LSQRHIP_XLDS_COLS": "1024"},                        # LDS panels (1024 columns)
     {"LSQRHIP_XLDS": "1", "LSQRHIP_XLDS_COLS": "1024", "LSQRHIP_COL16": "0", "LSQRHIP_OFF64": "1"},
     {"LSQRHIP_SELL": "1", "LSQRHIP_SELLP": "0"},
+    {"LSQRHIP_CSB": "1"},                                                      # column-swept row blocks (csb.h)
+    {"LSQRHIP_CSB": "1", "LSQRHIP_CSB_R": "37"},                               # ... in many small blocks, ragged last one
 ]
 
 

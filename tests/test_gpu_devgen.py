@@ -112,8 +112,9 @@ def test_scale_properties_beyond_2_to_31_nonzeros_with_lds_panels():
     ("powerlaw:5000000:2000000:10000", dict(panels=8)),                        # BASELINE configs[4]: skewed rows
 ])
 def test_scale_properties_of_the_panelled_baseline_configurations(spec, expect):
-    """BASELINE configs[3] and configs[4] at their full size, generated in HBM: L2 column panels with
-    the grid chosen by timing, and (power law) the long-segment waves of spmv.h phase 2b.  No CPU
+    """BASELINE configs[3] and configs[4] at their full size, generated in HBM: column-swept row blocks
+    (csrc/csb.h; with LSQRHIP_CSB=0 the L2 column panels with the grid chosen by timing, and for the
+    power law the long-segment waves of spmv.h phase 2b).  No CPU
     oracle fits in test time, so: acheck's adjoint identity (A and A' are built and laid out
     independently), linearity, bit-level determinism of both products (neither the tuned grid nor
     which wave takes which long segment may show), and a short solve that repeats itself exactly
@@ -128,7 +129,10 @@ def test_scale_properties_of_the_panelled_baseline_configurations(spec, expect):
     info = s.info()
     if "nnz" in expect:
         assert dp.nnz == expect["nnz"]
-    assert info["panels"] == expect["panels"] and info["xlds"] == 0 and info["sell"] == 0
+    if os.environ.get("LSQRHIP_CSB") == "0":      # ablation knob: the L2 column panels of round 1
+        assert info["panels"] == expect["panels"] and info["xlds"] == 0 and info["sell"] == 0
+    else:                                          # column-swept row blocks (csrc/csb.h) for A and A'
+        assert info["xlds"] == 3 and info["xlds_t"] == 3 and info["panels"] == 1 and info["sell"] == 0
     inform, err = s.acheck()
     assert inform == 0 and err < 1e-12
     xa = P.u64_to_unit(P.rng_u64(1, 9, np.arange(dp.n, dtype=np.uint64)))

@@ -15,9 +15,10 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture
 def forced_panels():
-    old = {k: os.environ.get(k) for k in ("LSQRHIP_PANELS", "LSQRHIP_PANEL_KB")}
+    old = {k: os.environ.get(k) for k in ("LSQRHIP_PANELS", "LSQRHIP_PANEL_KB", "LSQRHIP_CSB")}
     os.environ["LSQRHIP_PANELS"] = "1"
     os.environ["LSQRHIP_PANEL_KB"] = "64"      # 8192 columns per panel
+    os.environ["LSQRHIP_CSB"] = "0"            # the panel kernels themselves (csb.h replaces them by default)
     yield
     for k, v in old.items():
         if v is None:
