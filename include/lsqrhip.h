@@ -227,37 +227,61 @@ int lsqrhip_dev_download(void *dst, const void *d_src, int64_t bytes);
 int lsqrhip_dev_sync(void);
 
 /* ---------------------------------------------------------------------- */
-/* row-block sharded solve (one process per GPU)                            */
+/* row-block sharded solve over the GPUs of one node                        */
 /* ---------------------------------------------------------------------- */
-/* The reference is serial; this is the multi-GPU form of the same iteration.
- * Rank p creates its handle from its own row block A_p (rows renumbered from 1, all n columns).
- * u, b are sharded with the rows; v, w, x are replicated.  The library only launches LOCAL
- * kernels; the host issues the two collectives per iteration on buffers it owns
- * (torch.distributed / RCCL in lsqr_amd/dist.py):
+/* The reference is serial; this is the multi-GPU form of the same iteration:
+ * A = [A_1; ...; A_P] in contiguous row blocks, u and b sharded with the rows, v replicated,
+ * x / w / se sharded by column slices of chunk = ceil(n / P); per iteration an all-reduce of one
+ * double (beta), a direct reduce-scatter of the n-vector A'u (every slice summed in rank order by
+ * its owner), an all-reduce of two doubles (alpha, dknorm) and an all-gather of the v slices.
  *
- *   begin(b_p, T, sums)
- *   stage 0                      -> all-reduce(sums[0..2])       |b|^2 (three range-safe sums)
- *   stage 1                      -> all-reduce(T[0..n))          A'u
- *   stage 2
- *   repeat:  stage 3             -> all-reduce(sums[0])          |u|^2
- *            stage 4             -> all-reduce(T[0..n))          A'u
- *            stage 5
- *            every k iterations: poll (all ranks see the same stop flag: the scalar
- *            recurrences run replicated on identical all-reduced inputs)
- *   end(x)
+ * (1) ONE process, ngpu devices -- what `initialize(..., ngpu=N)` of the Fortran layer binds
+ *     (replaces initialize_ez, src/lsqr.f90:91-127, for a node's worth of GPUs).  Same arguments and
+ *     validation as lsqrhip_create; rows are cut into ngpu blocks balanced by nonzeros, one sub-handle
+ *     per device (devices d0 .. d0+ngpu-1, d0 = lsqrhip_set_device's), RCCL communicator inside.  The
+ *     handle then works with lsqrhip_solve (host b, x, se: replaces solve_ez :207-259 + LSQR :432-882),
+ *     lsqrhip_aprod (host vectors, :134-200), lsqrhip_info, lsqrhip_retain, lsqrhip_destroy.
+ *     ngpu is clamped to the number of rows; more devices than the node has -> LSQRHIP_ERR_NO_DEVICE. */
+int lsqrhip_create_sharded(int m, int n, int64_t nnz, const int *irow, const int *icol, const double *a, int ngpu,
+                           lsqrhip_handle_t *out);
+
+/* (2) one process PER GPU (bench.py --gpus N under torch.distributed.run): every rank creates an
+ *     ordinary handle from its own row block (rows renumbered from 1, all n columns), rank 0 obtains a
+ *     128-byte RCCL id and the host program hands it to the others (any transport), every rank joins,
+ *     and lsqrhip_shard_solve runs the whole loop -- kernels and RCCL calls -- from C++:
+ *     d_b_local (m_p) in, d_x (n, and d_se if wantse) out on every rank, all device pointers. */
+int lsqrhip_rccl_unique_id(char *out128);
+int lsqrhip_shard_comm_init(lsqrhip_handle_t h, int world, int rank, int64_t row0, int64_t m_global,
+                            const char *id128);
+int lsqrhip_shard_solve(lsqrhip_handle_t h, const double *d_b_local, double damp, double atol, double btol,
+                        double conlim, int itnlim, int wantse, double *d_x, double *d_se, int *istop, int *itn,
+                        double *anorm, double *acond, double *rnorm, double *arnorm, double *xnorm);
+
+/* (3) the stages themselves, for a host that carries the exchanges (lsqr_amd/dist.py over
+ *     torch.distributed; gloo in the CPU tests).  The library launches only LOCAL kernels, asynchronously
+ *     on the handle's stream; between the stages the caller exchanges buffers it owns:
  *
- * d_T: n doubles, d_sums: >= 4 doubles, both device memory owned by the caller.  Stage 0 leaves
- * THREE sums in d_sums[0..2] (Blue's small / mid / big accumulators of b^2, additive over ranks:
- * norm(b) is then formed without over- or underflow, like the reference's dnrm2): all-reduce all three. */
-int lsqrhip_shard_begin(lsqrhip_handle_t h, const double *d_b_local, int64_t m_global, double damp,
-                        double atol, double btol, double conlim, int itnlim, int wantse, double *d_T,
-                        double *d_sums);
+ *   begin(b_p, world, rank, T, R, V, sums)       T, R, V: world * chunk doubles, sums: 4 doubles
+ *   stage 0                 -> all-reduce sums[0..2]                         three range-safe sums of b^2
+ *   stage 1                 -> R[r * chunk ..] <- rank r's T[rank * chunk ..]  for every r (all-to-all)
+ *   stage 2                 -> all-reduce sums[0..1]
+ *   stage 3                 -> all-gather V (slice of rank q at q * chunk)
+ *   repeat:  stage 4        -> all-reduce sums[0]                            |u|^2
+ *            stage 5        -> the all-to-all T -> R                         A'u
+ *            stage 6        -> all-reduce sums[0..1]                         |v|^2, |w|^2
+ *            stage 7        -> all-gather V
+ *            every k iterations: poll (all ranks see the same stop flag: the scalar recurrences run
+ *            replicated on identical all-reduced inputs)
+ *   end(x, se)              this rank's slices land at [rank * chunk, ..) of x, se: all-gather them
+ *
+ * All-reduces of the scalars must give every rank the SAME bits (shard_engine.h and dist.py sum the
+ * ranks' values in rank order). */
+int lsqrhip_shard_begin(lsqrhip_handle_t h, const double *d_b_local, int64_t m_global, int world, int rank,
+                        double damp, double atol, double btol, double conlim, int itnlim, int wantse, double *d_T,
+                        double *d_R, double *d_V, double *d_sums);
 int lsqrhip_shard_stage(lsqrhip_handle_t h, int stage);
 /* d_out[0..chunk) = sum_{r < nchunks} d_in[r*chunk + i], in rank order (asynchronous on the
- * handle's stream): the local step of a DIRECT reduce-scatter -- every rank sends slice j of its
- * partial n-vector to rank j over all xGMI links at once (all-to-all), sums what it received in
- * a fixed order, and the reduced slices are all-gathered.  xGMI is point-to-point, so this
- * shape is not per-link bound the way a ring all-reduce of the same 8n bytes is. */
+ * handle's stream). */
 int lsqrhip_sum_chunks(lsqrhip_handle_t h, const double *d_in, int nchunks, int64_t chunk, double *d_out);
 /* out[0..2] = stop, itn, istop (synchronises the handle's stream). */
 int lsqrhip_shard_poll(lsqrhip_handle_t h, int *out);

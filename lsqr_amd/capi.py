@@ -30,6 +30,7 @@ EXPORTS = [
     "lsqrhip_last_timing", "lsqrhip_bench_kernel", "lsqrhip_set_option", "lsqrhip_get_option", "lsqrhip_set_stream", "lsqrhip_dev_alloc",
     "lsqrhip_dev_free", "lsqrhip_dev_upload", "lsqrhip_dev_download", "lsqrhip_dev_sync",
     "lsqrhip_shard_begin", "lsqrhip_shard_stage", "lsqrhip_shard_poll", "lsqrhip_shard_end", "lsqrhip_sum_chunks",
+    "lsqrhip_create_sharded", "lsqrhip_rccl_unique_id", "lsqrhip_shard_comm_init", "lsqrhip_shard_solve",
     "lsqrhip_gen_count", "lsqrhip_gen_coo",
     "lsqrhip_create_operator", "lsqrhip_lstp_create", "lsqrhip_lstp_vectors",
 ]
@@ -101,7 +102,11 @@ def lib() -> C.CDLL:
     L.lsqrhip_dev_free.argtypes = [vp]
     L.lsqrhip_dev_upload.argtypes = [vp, vp, i64]
     L.lsqrhip_dev_download.argtypes = [vp, vp, i64]
-    L.lsqrhip_shard_begin.argtypes = [vp, vp, i64, f64, f64, f64, f64, i32, i32, vp, vp]
+    L.lsqrhip_shard_begin.argtypes = [vp, vp, i64, i32, i32, f64, f64, f64, f64, i32, i32, vp, vp, vp, vp]
+    L.lsqrhip_create_sharded.argtypes = [i32, i32, i64, vp, vp, vp, i32, C.POINTER(vp)]
+    L.lsqrhip_rccl_unique_id.argtypes = [vp]
+    L.lsqrhip_shard_comm_init.argtypes = [vp, i32, i32, i64, i64, vp]
+    L.lsqrhip_shard_solve.argtypes = [vp, vp, f64, f64, f64, f64, i32, i32, vp, vp] + [vp] * 7
     L.lsqrhip_shard_stage.argtypes = [vp, i32]
     L.lsqrhip_sum_chunks.argtypes = [vp, vp, i32, i64, vp]
     L.lsqrhip_shard_poll.argtypes = [vp, vp]

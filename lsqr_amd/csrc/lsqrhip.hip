@@ -163,7 +163,23 @@ struct Csr {
     long long *cptr = nullptr;    // [nrb + 1] first chunk of each row block
     int64_t nchunks = 0;
     int nrb = 0, R = 0, H = 3;
+    int lo32 = 0;                 // low parts of the row sums as 32-bit integers (csb.h)
 };
+
+// One rank's view of a row-sharded solve (shard_api.h): its place in the world, the caller-owned
+// exchange buffers of the current solve, and two device words of its own.
+struct ShardCtx {
+    int P = 1, rank = 0;
+    int64_t chunk = 0;            // ceil(n / P): columns per slice
+    int64_t my0 = 0, mylen = 0;   // this rank's column slice [my0, my0 + mylen)
+    double *T = nullptr, *R = nullptr, *V = nullptr, *sums = nullptr;  // caller-owned: P*chunk, P*chunk, P*chunk, 4
+    double *wsq = nullptr;        // [1] this rank's sum of w_q^2 (owned)
+    int *live = nullptr;          // [1] "this iteration runs" (owned)
+    int wantse = 0;
+    bool active = false;
+};
+
+struct ShardGroup;  // shard_engine.h: the ranks of a sharded solve driven from this process (RCCL)
 
 struct lsqrhip_handle_s {
     std::atomic<int> refs{1};  // lsqrhip_retain / lsqrhip_destroy
@@ -216,9 +232,10 @@ struct lsqrhip_handle_s {
     bool op_is_lstp = false;
     double *opX = nullptr, *opY = nullptr;  // scaled copies handed to the operator (n, m)
     int op_batch = 8;                       // iterations enqueued ahead of each stop poll
-    // row-sharded solve (shard_api.h): caller-owned exchange buffers
-    double *shard_T = nullptr, *shard_sums = nullptr;
-    int shard_wantse = 0;
+    // row-sharded solve
+    ShardCtx shard;                // this handle as one rank (shard_api.h)
+    ShardGroup *group = nullptr;   // this handle as a whole sharded system, one process (shard_engine.h); owned
+    ShardGroup *mp = nullptr;      // this handle as ONE rank of a multi-process world (shard_engine.h); owned
 };
 typedef lsqrhip_handle_s H;
 
@@ -288,6 +305,14 @@ static void free_csr(Csr &c)
     c = Csr();
 }
 
+static void release_groups(H *h);  // shard_engine.h
+static int solve_group_host(H *h, const double *b, double damp, double atol, double btol, double conlim, int itnlim,
+                            int wantse, double *x, double *se, int *istop, int *itn, double *anorm, double *acond,
+                            double *rnorm, double *arnorm, double *xnorm);
+static int aprod_group_host(H *h, int mode, double *x, double *y);
+
+static H *lsqrhip_group_rank0(H *h);
+
 static void destroy_graph(H *h)
 {
     if (h->gexec) {
@@ -308,6 +333,7 @@ extern "C" int lsqrhip_destroy(lsqrhip_handle_t h)
 {
     if (!h) return LSQRHIP_OK;
     if (--h->refs > 0) return LSQRHIP_OK;
+    release_groups(h);
     (void)hipSetDevice(h->device);
     if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
     destroy_graph(h);
@@ -317,6 +343,8 @@ extern "C" int lsqrhip_destroy(lsqrhip_handle_t h)
                       h->opY})
         if (p) (void)hipFree(p);
     if (h->op_free) h->op_free(h->op_user);
+    if (h->shard.wsq) (void)hipFree(h->shard.wsq);
+    if (h->shard.live) (void)hipFree(h->shard.live);
     if (h->d_state) (void)hipFree(h->d_state);
     if (h->h_state) (void)hipHostFree(h->h_state);
     if (h->d_unit) (void)hipFree(h->d_unit);
@@ -676,24 +704,15 @@ static int build_csb(hipStream_t s, const int *rowk, const int *colk, const doub
                      unsigned long long *bufB, unsigned *hist, int *d_flags, Csr &out)
 {
     if (rows <= 0 || cols <= 0) return LSQRHIP_OK;
-    int R = env_int("LSQRHIP_CSB_R", 0);
-    if (R <= 0) {
-        const int64_t k = ((int64_t)rows + (int64_t)CSB_GRID * CSB_RMAX - 1) / ((int64_t)CSB_GRID * CSB_RMAX);
-        R = (int)(((int64_t)rows + CSB_GRID * k - 1) / (CSB_GRID * k));
-        R = std::max(R, std::min(rows, 512));  // small systems: a few whole blocks rather than 256 slivers
-    }
-    R = std::min(std::max(R, 1), CSB_RMAX);
-    const int nrb = (rows + R - 1) / R;
-    if (nrb > SPMV_MAX_GRID) return LSQRHIP_OK;  // one partial of sum(y^2) per block
     const int g = (int)std::min<int64_t>(std::max<int64_t>((nnz + 255) / 256, 1), 4096);
     HIPCHK(hipMemsetAsync(d_flags, 0, 4 * sizeof(int), s));
     int got[4] = {0, 0, 0, 0};
     DevScratch s_pos, s_cnt, s_rbs;
     HIPCHK(s_pos.alloc(sizeof(unsigned) * (size_t)std::max<int64_t>(nnz, 1)));
     HIPCHK(s_cnt.alloc(sizeof(int) * ((size_t)rows + 1)));
-    HIPCHK(s_rbs.alloc(sizeof(long long) * ((size_t)nrb + 1)));
     HIPCHK(hipMemsetAsync(s_cnt.p, 0, sizeof(int) * ((size_t)rows + 1), s));
-    unsigned long long *sorted2 = bufA;
+    unsigned long long *sorted1 = bufA;
+    int maxrow = 0;
     if (nnz > 0) {
         hipLaunchKernelGGL(k_csb_pack_col, dim3(g), dim3(256), 0, s, rowk, colk, nnz, rows, cols, bufA, d_flags);
         HIPCHK(hipGetLastError());
@@ -701,10 +720,35 @@ static int build_csb(hipStream_t s, const int *rowk, const int *colk, const doub
         HIPCHK(hipStreamSynchronize(s));
         if (got[0]) return fail(bad_code, lsqrhip_error_string(bad_code));
         if (got[2]) return fail(bad_code_other, lsqrhip_error_string(bad_code_other));
-        unsigned long long *sorted1 = bufA;
         if (got[1]) sorted1 = radix_sort_words(s, bufA, bufB, nnz, bits_for(cols), hist);
         hipLaunchKernelGGL(k_csb_pos, dim3(g), dim3(256), 0, s, (const unsigned long long *)sorted1, nnz, rowk,
                            s_pos.as<unsigned>(), s_cnt.as<int>());
+        // the longest row: how many products one accumulator may receive
+        HIPCHK(hipMemsetAsync(d_flags, 0, 4 * sizeof(int), s));
+        hipLaunchKernelGGL(k_csb_maxint, dim3((unsigned)std::min<int64_t>(((int64_t)rows + 255) / 256, 2048)), dim3(256), 0,
+                           s, (const int *)s_cnt.as<int>(), (int64_t)rows, d_flags);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(got, d_flags, sizeof(got), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        maxrow = got[0];
+    }
+    const int H = std::max(3, bits_for(std::max(maxrow, 1)) + 1);
+    // rows of <= 512 nonzeros: the low part of the sums as 32-bit integers, a third more rows per block
+    // (csb.h "accumulators"); LSQRHIP_CSB_LO32=0 keeps 8-byte low parts
+    const bool lo32 = H <= CSB_LO32_MAXH && env_int("LSQRHIP_CSB_LO32", 1) != 0;
+    const int rmax = lo32 ? CSB_RMAX32 : CSB_RMAX;
+    int R = env_int("LSQRHIP_CSB_R", 0);
+    if (R <= 0) {
+        const int64_t k = ((int64_t)rows + (int64_t)CSB_GRID * rmax - 1) / ((int64_t)CSB_GRID * rmax);
+        R = (int)(((int64_t)rows + CSB_GRID * k - 1) / (CSB_GRID * k));
+        R = std::max(R, std::min(rows, 512));  // small systems: a few whole blocks rather than 256 slivers
+    }
+    R = std::min(std::max(R, 1), rmax);
+    const int nrb = (rows + R - 1) / R;
+    if (nrb > SPMV_MAX_GRID) return LSQRHIP_OK;  // one partial of sum(y^2) per block
+    HIPCHK(s_rbs.alloc(sizeof(long long) * ((size_t)nrb + 1)));
+    unsigned long long *sorted2 = bufA;
+    if (nnz > 0) {
         hipLaunchKernelGGL(k_csb_pack_rb, dim3(g), dim3(256), 0, s, rowk, (const unsigned *)s_pos.as<unsigned>(), nnz, R,
                            bufA);
         HIPCHK(hipGetLastError());
@@ -712,16 +756,10 @@ static int build_csb(hipStream_t s, const int *rowk, const int *colk, const doub
     }
     hipLaunchKernelGGL(k_rowptr_from_sorted<long long>, dim3(g), dim3(256), 0, s, (const unsigned long long *)sorted2, nnz,
                        nrb, s_rbs.as<long long>());
-    // the longest row: how many products one accumulator may receive
-    HIPCHK(hipMemsetAsync(d_flags, 0, 4 * sizeof(int), s));
-    hipLaunchKernelGGL(k_csb_maxint, dim3((unsigned)std::min<int64_t>(((int64_t)rows + 255) / 256, 2048)), dim3(256), 0, s,
-                       (const int *)s_cnt.as<int>(), (int64_t)rows, d_flags);
     HIPCHK(hipGetLastError());
     std::vector<long long> rbs((size_t)nrb + 1), cptr((size_t)nrb + 1);
     HIPCHK(hipMemcpyAsync(rbs.data(), s_rbs.p, sizeof(long long) * rbs.size(), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(got, d_flags, sizeof(got), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
-    const int maxrow = got[0];
     cptr[0] = 0;
     for (int b = 0; b < nrb; ++b) cptr[b + 1] = cptr[b] + (rbs[b + 1] - rbs[b] + CSB_CHUNK - 1) / CSB_CHUNK;
     const long long nchunks = cptr[nrb];
@@ -755,7 +793,8 @@ static int build_csb(hipStream_t s, const int *rowk, const int *colk, const doub
     out.nchunks = nchunks;
     out.nrb = nrb;
     out.R = R;
-    out.H = std::max(3, bits_for(std::max(maxrow, 1)) + 1);
+    out.H = H;
+    out.lo32 = lo32 ? 1 : 0;
     out.grid = std::max(1, std::min(nrb, CSB_GRID));
     out.out_grid = nrb;
     out.nblk = nrb;
@@ -1022,6 +1061,13 @@ extern "C" int lsqrhip_create(int m, int n, int64_t nnz, const int *irow, const 
 extern "C" int lsqrhip_info(lsqrhip_handle_t h, int64_t *dims)
 {
     if (!h || !dims) return fail(LSQRHIP_ERR_NOT_INIT, lsqrhip_error_string(LSQRHIP_ERR_NOT_INIT));
+    if (h->group) {  // sharded: the layouts of the first row block, the dimensions of the whole
+        RET(lsqrhip_info(lsqrhip_group_rank0(h), dims));
+        dims[0] = h->m;
+        dims[1] = h->n;
+        dims[2] = h->nnz;
+        return LSQRHIP_OK;
+    }
     dims[0] = h->m;
     dims[1] = h->n;
     dims[2] = h->nnz;
@@ -1129,6 +1175,7 @@ extern "C" int lsqrhip_aprod_device(lsqrhip_handle_t h, int mode, double *d_x, d
 {
     if (!h) return fail(LSQRHIP_ERR_NOT_INIT, lsqrhip_error_string(LSQRHIP_ERR_NOT_INIT));
     if (mode != 1 && mode != 2) return fail(LSQRHIP_ERR_MODE, lsqrhip_error_string(LSQRHIP_ERR_MODE));
+    if (h->group) return fail(LSQRHIP_ERR_ARG, "a sharded handle takes host vectors: lsqrhip_aprod");
     HIPCHK(hipSetDevice(h->device));
     if (h->op) {  // user device operator (op_api.h)
         RET(op_call(h, mode, d_x, d_y));
@@ -1146,6 +1193,7 @@ extern "C" int lsqrhip_aprod(lsqrhip_handle_t h, int mode, double *x, double *y)
 {
     if (!h) return fail(LSQRHIP_ERR_NOT_INIT, lsqrhip_error_string(LSQRHIP_ERR_NOT_INIT));
     if (mode != 1 && mode != 2) return fail(LSQRHIP_ERR_MODE, lsqrhip_error_string(LSQRHIP_ERR_MODE));
+    if (h->group) return aprod_group_host(h, mode, x, y);
     HIPCHK(hipSetDevice(h->device));
     hipStream_t s = h->stream;
     // borrow the solver's work vectors: V (n) for x, U (m) for y
@@ -1502,4 +1550,5 @@ extern "C" int lsqrhip_dev_sync(void)
 // row-block sharded solve (multi-GPU) and on-device problem generators
 #include "op_api.h"
 #include "shard_api.h"
+#include "shard_engine.h"
 #include "gen_api.h"

@@ -1,33 +1,49 @@
 // shard_api.h -- row-block sharded LSQR: the per-rank stages (included by lsqrhip.hip).
 //
-// One process per GPU holds A_p = rows [row0, row0 + m_p) of A (its own handle).  u and b are
-// sharded with the rows; v, w, x (n-vectors) are replicated.  Per iteration the ONLY exchanges
-// are:
-//     sum_p |u_p|^2        one double, all-reduce   (beta)
-//     sum_p A_p' u_p       n doubles,  all-reduce   (the n-vector after the A'-apply)
-// Everything else is local, and because every rank then holds identical v and identical
-// all-reduced sums, the replicated scalar recurrences stay bit-identical across ranks.
-// The collectives themselves are issued by the host (torch.distributed = RCCL over xGMI,
-// lsqr_amd/dist.py) on buffers it owns (T, sums); this file only launches local kernels on
-// the handle's stream, asynchronously.
+// Rank p of P holds A_p = rows [row0, row0 + m_p) of A (its own handle: the layouts of A_p and A_p').
+//     u, b          sharded with the rows                     (m_p entries)
+//     v             replicated: mode 1 gathers from all of it (P * chunk entries, chunk = ceil(n / P))
+//     x, w, se      sharded by COLUMN slices: rank q owns columns [q chunk, (q+1) chunk)
+// Per iteration (the "better" form):
+//     u_p  <- A_p v - alpha u_p                                      local
+//     sum_p |u_p|^2                                                  all-reduce, 1 double        (beta)
+//     T_p  =  A_p' u_p                                               local, n doubles
+//     reduce-scatter of T: slice q of every T_p goes to rank q       all-to-all over every xGMI link at once,
+//        and is summed there in RANK ORDER (deterministic)           (P-1)/P * 8n bytes out and in per GPU
+//     v_q  <- T_q - beta v_q ;  |v_q|^2, and |w_q|^2 of the last update        all-reduce, 2 doubles (alpha, dknorm)
+//     rotations; x_q += t1 w_q ; w_q <- t2 w_q + v_q ; stopping tests          slice-local (n / P each)
+//     all-gather of the v slices                                     (P-1)/P * 8n bytes in per GPU
+// so the n-vector work scales with P like the products do, and the only replicated work is the
+// scalar recurrences (bit-identical on every rank: their inputs are all-reduced values).
+// dknorm = sqrt(sum (t3 w_i)^2) (src/lsqr.f90:729-745) is formed as |t3| sqrt(sum w_i^2), so that its
+// sum rides in the same all-reduce as |v|^2 (w is the PREVIOUS iteration's, known before t3 is).
+//
+// This file only launches local kernels on the handle's stream, asynchronously.  The collectives
+// are issued by the caller between the stages on buffers it owns (T, R, V, sums): by
+// shard_engine.h (RCCL, from C++: lsqrhip_create_sharded / lsqrhip_shard_solve), or by
+// lsqr_amd/dist.py (torch.distributed; gloo in the CPU tests, which pin the arithmetic).
 #pragma once
 
 namespace lsqrhip {
 
-// V <- cy*(V*sy) + T ; partial sums of V^2          (the "combine" after the all-reduce)
-__global__ __launch_bounds__(VEC_BLOCK) void k_vcombine(double *__restrict__ V, const double *__restrict__ T,
-                                                        int64_t n, const SpmvCoef *__restrict__ coef,
-                                                        const int *__restrict__ stop,
-                                                        double *__restrict__ partials, NScale nsc)
+// Vq_i <- cy (Vq_i sy) + (R[0][i] + R[1][i] + ... + R[P-1][i])   (rank order); partials of sum (Vq ns)^2.
+// R[r] = slice q of rank r's T (what the all-to-all delivered), each `chunk` long; i < len <= chunk.
+__global__ __launch_bounds__(VEC_BLOCK) void k_rs_combine(double *__restrict__ Vq, const double *__restrict__ R,
+                                                          int P, int64_t chunk, int64_t len,
+                                                          const SpmvCoef *__restrict__ coef,
+                                                          const int *__restrict__ stop,
+                                                          double *__restrict__ partials, NScale nsc)
 {
     if (*stop != 0 || coef->skip != 0) return;
     const double sy = coef->sy, cy = coef->cy;
     __shared__ double red[VEC_BLOCK / WAVE];
     double s = 0.0;
     const int64_t stride = (int64_t)gridDim.x * VEC_BLOCK;
-    for (int64_t i = (int64_t)blockIdx.x * VEC_BLOCK + threadIdx.x; i < n; i += stride) {
-        const double v = cy * (V[i] * sy) + T[i];
-        V[i] = v;
+    for (int64_t i = (int64_t)blockIdx.x * VEC_BLOCK + threadIdx.x; i < len; i += stride) {
+        double t = R[i];
+        for (int r = 1; r < P; ++r) t = t + R[(int64_t)r * chunk + i];
+        const double v = cy * (Vq[i] * sy) + t;
+        Vq[i] = v;
         const double vs = v * nsc.s;
         s += vs * vs;
     }
@@ -35,8 +51,8 @@ __global__ __launch_bounds__(VEC_BLOCK) void k_vcombine(double *__restrict__ V, 
     if (threadIdx.x == 0) partials[blockIdx.x] = tot;
 }
 
-// out[i] = in[0*chunk + i] + in[1*chunk + i] + ... in rank order (the local sum of a direct
-// reduce-scatter: every element is summed once, by its owner, in a fixed order)
+// out[i] = in[0*chunk + i] + in[1*chunk + i] + ... in rank order (for callers that reduce a whole
+// vector themselves: lsqrhip_sum_chunks)
 __global__ __launch_bounds__(VEC_BLOCK) void k_sum_chunks(double *__restrict__ out, const double *__restrict__ in,
                                                           int nchunks, int64_t chunk)
 {
@@ -48,20 +64,123 @@ __global__ __launch_bounds__(VEC_BLOCK) void k_sum_chunks(double *__restrict__ o
     }
 }
 
+// The x / w / se update on this rank's column slice (src/lsqr.f90:729-745 with the dscal of :697
+// folded in), gated by `live` (set by k_shard_s2 in the SAME iteration: the stop flag that k_shard_s3
+// raises afterwards must not hide the last update).  partials = sum of w_new^2 (next iteration's dknorm).
+__global__ __launch_bounds__(VEC_BLOCK) void k_update_slice(double *__restrict__ x, double *__restrict__ w,
+                                                            const double *__restrict__ Vq, double *__restrict__ se,
+                                                            int64_t len, const LsqrState *__restrict__ st,
+                                                            const int *__restrict__ live,
+                                                            double *__restrict__ partials)
+{
+    if (*live == 0) return;
+    const double t1 = st->t1, t2 = st->t2, t3 = st->t3, sv = st->sv;
+    const bool wantse = st->wantse != 0;
+    __shared__ double red[VEC_BLOCK / WAVE];
+    double s = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * VEC_BLOCK;
+    for (int64_t i = (int64_t)blockIdx.x * VEC_BLOCK + threadIdx.x; i < len; i += stride) {
+        const double t = w[i];
+        x[i] = t1 * t + x[i];
+        const double wn = t2 * t + Vq[i] * sv;
+        w[i] = wn;
+        if (wantse) {
+            const double d = (t3 * t) * (t3 * t);
+            se[i] = d + se[i];
+        }
+        s += wn * wn;
+    }
+    const double tot = block_sum<VEC_BLOCK>(s, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = tot;
+}
+
+// w_q <- V_q sv (first w, src/lsqr.f90:641-644); partials of sum w_q^2
+__global__ __launch_bounds__(VEC_BLOCK) void k_init_w_slice(double *__restrict__ w, const double *__restrict__ Vq,
+                                                            int64_t len, const LsqrState *__restrict__ st,
+                                                            double *__restrict__ partials)
+{
+    const double sv = st->sv;
+    __shared__ double red[VEC_BLOCK / WAVE];
+    double s = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * VEC_BLOCK;
+    if (st->stop == 0)
+        for (int64_t i = (int64_t)blockIdx.x * VEC_BLOCK + threadIdx.x; i < len; i += stride) {
+            const double wn = Vq[i] * sv;
+            w[i] = wn;
+            s += wn * wn;
+        }
+    const double tot = block_sum<VEC_BLOCK>(s, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = tot;
+}
+
+// sums[0] <- the np partials of sum (V_q ns)^2 in fixed order, sums[1] <- *wsq (this rank's sum of w_q^2)
+__global__ __launch_bounds__(VEC_BLOCK) void k_shard_sums(const double *__restrict__ partials, int np,
+                                                          const double *__restrict__ wsq, double *__restrict__ sums,
+                                                          const SpmvCoef *__restrict__ coef)
+{
+    __shared__ double red[VEC_BLOCK / WAVE];
+    const double s = np > 0 ? strided_sum<VEC_BLOCK>(partials, np) : 0.0;
+    const double tot = block_sum<VEC_BLOCK>(s, red);
+    if (threadIdx.x == 0) {
+        sums[0] = coef->skip != 0 ? 0.0 : tot;  // a skipped product left no partials (beta == 0, :691)
+        sums[1] = *wsq;
+    }
+}
+
+// step 2 on all-reduced sums: alpha = sqrt(sums[0]) / ns, rotations, t1..t3; *live = "this iteration runs"
+__global__ void k_shard_s2(const double *__restrict__ sums, LsqrState *st, int *__restrict__ live)
+{
+    if (st->stop != 0) {
+        *live = 0;
+        return;
+    }
+    *live = 1;
+    s2_step(st, sqrt(sums[0]) * st->ns_inv, st->c2.skip != 0);
+}
+
+// step 3 on all-reduced sums: dknorm^2 = t3^2 * sum of the previous w^2
+__global__ void k_shard_s3(const double *__restrict__ sums, LsqrState *st, const int *__restrict__ live,
+                           const double *__restrict__ x, double *__restrict__ log)
+{
+    if (*live == 0) return;
+    s3_step(st, (st->t3 * st->t3) * sums[1], x, log);
+}
+
 }  // namespace lsqrhip
 
 // stage ids (keep in sync with lsqr_amd/dist.py)
-enum { ST_SUMSQ_B = 0, ST_INIT_BETA_ATU = 1, ST_INIT_V = 2, ST_MODE1 = 3, ST_S1_ATU = 4, ST_VCOMBINE_UPDATE = 5 };
+enum {
+    ST_SUMSQ_B = 0,        // sums[0..2] = Blue's sums of b_p^2                       -> all-reduce sums[0..2]
+    ST_INIT_BETA_ATU = 1,  // beta; T = A_p'(U_p / beta)                             -> exchange: slice q of T to rank q's R
+    ST_INIT_V = 2,         // V_q = sum_r R[r]; sums[0] = |V_q ns|^2                  -> all-reduce sums[0..1]
+    ST_INIT_W = 3,         // alpha; w_q = V_q / alpha; arnorm                        -> all-gather V
+    ST_MODE1 = 4,          // U_p <- (-alpha)(U_p su) + A_p (V sv); sums[0] = |U_p ns|^2   -> all-reduce sums[0]
+    ST_S1_ATU = 5,         // beta, anorm; T = A_p'(U_p su)                           -> exchange: slice q of T to rank q's R
+    ST_VCOMBINE = 6,       // V_q <- (-beta)(V_q sv) + sum_r R[r]; sums[0] = |V_q ns|^2, sums[1] = |w_q|^2   -> all-reduce sums[0..1]
+    ST_UPDATE = 7          // alpha, rotations; dknorm, tests; x_q, w_q, se_q         -> all-gather V
+};
 
-extern "C" int lsqrhip_shard_begin(lsqrhip_handle_t h, const double *d_b_local, int64_t m_global, double damp,
-                                   double atol, double btol, double conlim, int itnlim, int wantse, double *d_T,
-                                   double *d_sums)
+extern "C" int lsqrhip_shard_begin(lsqrhip_handle_t h, const double *d_b_local, int64_t m_global, int world, int rank,
+                                   double damp, double atol, double btol, double conlim, int itnlim, int wantse,
+                                   double *d_T, double *d_R, double *d_V, double *d_sums)
 {
     if (!h) return fail(LSQRHIP_ERR_NOT_INIT, lsqrhip_error_string(LSQRHIP_ERR_NOT_INIT));
-    if (!d_T || !d_sums || (!d_b_local && h->m > 0)) return fail(LSQRHIP_ERR_ARG, "null shard buffer");
+    if (!d_T || !d_R || !d_V || !d_sums || (!d_b_local && h->m > 0)) return fail(LSQRHIP_ERR_ARG, "null shard buffer");
+    if (world < 1 || rank < 0 || rank >= world) return fail(LSQRHIP_ERR_ARG, "bad world / rank");
     if (h->op) return fail(LSQRHIP_ERR_ARG, "the row-sharded solve needs a matrix handle, not an operator");
     HIPCHK(hipSetDevice(h->device));
     hipStream_t s = h->stream;
+    ShardCtx &c = h->shard;
+    c.P = world;
+    c.rank = rank;
+    c.chunk = ((int64_t)h->n + world - 1) / world;
+    c.my0 = std::min<int64_t>((int64_t)rank * c.chunk, h->n);
+    c.mylen = std::min<int64_t>(c.chunk, (int64_t)h->n - c.my0);
+    c.T = d_T; c.R = d_R; c.V = d_V; c.sums = d_sums;
+    c.wantse = wantse;
+    if (!c.wsq) HIPCHK(hipMalloc((void **)&c.wsq, sizeof(double)));
+    if (!c.live) HIPCHK(hipMalloc((void **)&c.live, sizeof(int)));
+    RET(prepare_log(h, itnlim, 0));
     LsqrState init;
     std::memset(&init, 0, sizeof(init));
     init.itnlim = itnlim;
@@ -79,69 +198,85 @@ extern "C" int lsqrhip_shard_begin(lsqrhip_handle_t h, const double *d_b_local, 
     init.c1.skip = init.c2.skip = init.c2p.skip = 1;
     *h->h_state = init;
     HIPCHK(hipMemcpyAsync(h->d_state, h->h_state, sizeof(LsqrState), hipMemcpyHostToDevice, s));
-    const size_t n = (size_t)h->n, m = (size_t)h->m;
+    const size_t m = (size_t)h->m, full = (size_t)(c.chunk * world);
+    const size_t sl = std::min((size_t)std::max<int64_t>(c.chunk, 0), (size_t)h->n);
     if (m > 0) HIPCHK(hipMemcpyAsync(h->U, d_b_local, sizeof(double) * m, hipMemcpyDeviceToDevice, s));
-    if (n > 0) {
-        HIPCHK(hipMemsetAsync(h->V, 0, sizeof(double) * n, s));
-        HIPCHK(hipMemsetAsync(h->X, 0, sizeof(double) * n, s));
-        HIPCHK(hipMemsetAsync(h->W, 0, sizeof(double) * n, s));
-        HIPCHK(hipMemsetAsync(d_T, 0, sizeof(double) * n, s));
-        if (wantse) HIPCHK(hipMemsetAsync(h->SE, 0, sizeof(double) * n, s));
+    if (full > 0) {
+        HIPCHK(hipMemsetAsync(c.V, 0, sizeof(double) * full, s));
+        HIPCHK(hipMemsetAsync(c.T, 0, sizeof(double) * full, s));
+        HIPCHK(hipMemsetAsync(c.R, 0, sizeof(double) * full, s));
+    }
+    if (sl > 0) {   // x_q, w_q, se_q live at the start of the handle's n-vectors
+        HIPCHK(hipMemsetAsync(h->X, 0, sizeof(double) * sl, s));
+        HIPCHK(hipMemsetAsync(h->W, 0, sizeof(double) * sl, s));
+        if (wantse) HIPCHK(hipMemsetAsync(h->SE, 0, sizeof(double) * sl, s));
     }
     HIPCHK(hipMemsetAsync(d_sums, 0, 4 * sizeof(double), s));
-    h->shard_T = d_T;
-    h->shard_sums = d_sums;
-    h->shard_wantse = wantse;
+    HIPCHK(hipMemsetAsync(c.wsq, 0, sizeof(double), s));
+    HIPCHK(hipMemsetAsync(c.live, 0, sizeof(int), s));
+    c.active = true;
     return LSQRHIP_OK;
 }
 
 // Enqueue one stage on the handle's stream (asynchronous).
 extern "C" int lsqrhip_shard_stage(lsqrhip_handle_t h, int stage)
 {
-    if (!h || !h->shard_T) return fail(LSQRHIP_ERR_NOT_INIT, "lsqrhip_shard_begin was not called");
+    if (!h || !h->shard.active) return fail(LSQRHIP_ERR_NOT_INIT, "lsqrhip_shard_begin was not called");
     HIPCHK(hipSetDevice(h->device));
     hipStream_t s = h->stream;
     LsqrState *st = h->d_state;
-    double *T = h->shard_T, *sums = h->shard_sums;
-    const int64_t n = h->n, m = h->m;
+    ShardCtx &c = h->shard;
+    double *T = c.T, *sums = c.sums;
+    double *Vq = c.V + c.my0;
+    const int64_t m = h->m;
+    const int gq = vec_grid(2 * std::max<int64_t>(c.mylen, 1));
     switch (stage) {
-    case ST_SUMSQ_B:  // sums[0..2] = Blue's small / mid / big sums of b_p^2 (range-safe, additive over ranks)
+    case ST_SUMSQ_B:
         hipLaunchKernelGGL(k_sumsq3, dim3(h->vgrid_m), dim3(VEC_BLOCK), 0, s, (const double *)h->U, m, h->partials);
         hipLaunchKernelGGL(k_reduce_partials3, dim3(1), dim3(VEC_BLOCK), 0, s, (const double *)h->partials,
                            h->vgrid_m, sums);
         break;
-    case ST_INIT_BETA_ATU:  // beta from the all-reduced sums[0..2]; T_p = A_p'(U_p/beta)
+    case ST_INIT_BETA_ATU:
         hipLaunchKernelGGL(k_s_init1<false>, dim3(1), dim3(SC_BLOCK), 0, s, (const double *)h->partials, 0,
                            (const double *)sums, st, (NormSlot *)nullptr);
         launch_spmv(h, h->AT, h->U, T, &st->c2p, h->d_zero, nullptr, nullptr, true);
         break;
-    case ST_INIT_V:  // V = sum_p T_p (all-reduced); alpha, v, w
-        hipLaunchKernelGGL(k_vcombine, dim3(h->vgrid_n), dim3(VEC_BLOCK), 0, s, h->V, (const double *)T, n,
+    case ST_INIT_V:
+        hipLaunchKernelGGL(k_rs_combine, dim3(gq), dim3(VEC_BLOCK), 0, s, Vq, (const double *)c.R, c.P, c.chunk, c.mylen,
                            (const SpmvCoef *)&st->c2, (const int *)h->d_zero, h->partials, h->nsc);
-        hipLaunchKernelGGL(k_s_init2<true>, dim3(1), dim3(SC_BLOCK), 0, s, (const double *)h->partials, h->vgrid_n,
-                           (const double *)nullptr, st);
-        hipLaunchKernelGGL(k_copy_scale, dim3(h->vgrid_n), dim3(VEC_BLOCK), 0, s, h->W, (const double *)h->V, n,
-                           (const LsqrState *)st);
+        hipLaunchKernelGGL(k_shard_sums, dim3(1), dim3(VEC_BLOCK), 0, s, (const double *)h->partials, gq,
+                           (const double *)c.wsq, sums, (const SpmvCoef *)&st->c2);
         break;
-    case ST_MODE1:  // U_p <- (-alpha)(U_p su) + A_p (V sv); sums[0] = |U_p|^2
-        launch_spmv(h, h->A, h->V, h->U, &st->c1, &st->stop, nullptr, nullptr, true);
+    case ST_INIT_W:
+        hipLaunchKernelGGL((k_s_init2<false>), dim3(1), dim3(SC_BLOCK), 0, s, (const double *)h->partials, 0,
+                           (const double *)sums, st);
+        hipLaunchKernelGGL(k_init_w_slice, dim3(gq), dim3(VEC_BLOCK), 0, s, h->W, (const double *)Vq, c.mylen,
+                           (const LsqrState *)st, h->partials);
+        hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(VEC_BLOCK), 0, s, (const double *)h->partials, gq, c.wsq);
+        break;
+    case ST_MODE1:
+        launch_spmv(h, h->A, c.V, h->U, &st->c1, &st->stop, nullptr, nullptr, true);
         hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(VEC_BLOCK), 0, s, (const double *)h->partials,
                            h->A.out_grid, sums);
         break;
-    case ST_S1_ATU:  // beta, anorm from the all-reduced sums[0]; T_p = A_p'(U_p su)
-        hipLaunchKernelGGL(k_s1<false>, dim3(1), dim3(SC_BLOCK), 0, s, (const double *)h->partials, 0,
+    case ST_S1_ATU:
+        hipLaunchKernelGGL((k_s1<false>), dim3(1), dim3(SC_BLOCK), 0, s, (const double *)h->partials, 0,
                            (const double *)sums, st);
         launch_spmv(h, h->AT, h->U, T, &st->c2p, &st->stop, nullptr, nullptr, true);
         break;
-    case ST_VCOMBINE_UPDATE:  // V <- (-beta)(V sv) + sum_p T_p; alpha; rotations; x, w; tests
-        hipLaunchKernelGGL(k_vcombine, dim3(h->vgrid_n), dim3(VEC_BLOCK), 0, s, h->V, (const double *)T, n,
+    case ST_VCOMBINE:
+        hipLaunchKernelGGL(k_rs_combine, dim3(gq), dim3(VEC_BLOCK), 0, s, Vq, (const double *)c.R, c.P, c.chunk, c.mylen,
                            (const SpmvCoef *)&st->c2, (const int *)&st->stop, h->partials, h->nsc);
-        hipLaunchKernelGGL(k_s2<true>, dim3(1), dim3(SC_BLOCK), 0, s, (const double *)h->partials, h->vgrid_n,
-                           (const double *)nullptr, st);
-        hipLaunchKernelGGL(k_update, dim3(h->vgrid_n), dim3(VEC_BLOCK), 0, s, h->X, h->W, (const double *)h->V,
-                           h->SE, n, (const LsqrState *)st, h->partials);
-        hipLaunchKernelGGL(k_s3<true>, dim3(1), dim3(SC_BLOCK), 0, s, (const double *)h->partials, h->vgrid_n,
-                           (const double *)nullptr, st, (const double *)h->X, h->d_log);
+        hipLaunchKernelGGL(k_shard_sums, dim3(1), dim3(VEC_BLOCK), 0, s, (const double *)h->partials, gq,
+                           (const double *)c.wsq, sums, (const SpmvCoef *)&st->c2);
+        break;
+    case ST_UPDATE:
+        hipLaunchKernelGGL(k_shard_s2, dim3(1), dim3(1), 0, s, (const double *)sums, st, c.live);
+        hipLaunchKernelGGL(k_shard_s3, dim3(1), dim3(1), 0, s, (const double *)sums, st, (const int *)c.live,
+                           (const double *)h->X, h->d_log);
+        hipLaunchKernelGGL(k_update_slice, dim3(gq), dim3(VEC_BLOCK), 0, s, h->X, h->W, (const double *)Vq, h->SE,
+                           c.mylen, (const LsqrState *)st, (const int *)c.live, h->partials);
+        hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(VEC_BLOCK), 0, s, (const double *)h->partials, gq, c.wsq);
         break;
     default:
         return fail(LSQRHIP_ERR_ARG, "unknown shard stage");
@@ -151,7 +286,7 @@ extern "C" int lsqrhip_shard_stage(lsqrhip_handle_t h, int stage)
 }
 
 // d_out[0..chunk) = sum over r < nchunks of d_in[r*chunk .. (r+1)*chunk), in rank order; asynchronous
-// on the handle's stream.  The local step of the direct reduce-scatter in lsqr_amd/dist.py.
+// on the handle's stream.
 extern "C" int lsqrhip_sum_chunks(lsqrhip_handle_t h, const double *d_in, int nchunks, int64_t chunk, double *d_out)
 {
     if (!h || !d_in || !d_out || nchunks < 1 || chunk < 0) return fail(LSQRHIP_ERR_ARG, "bad sum_chunks arguments");
@@ -176,19 +311,22 @@ extern "C" int lsqrhip_shard_poll(lsqrhip_handle_t h, int *out)
     return LSQRHIP_OK;
 }
 
-// Finish: se, istop 2 -> 3, copy x (and se) to device buffers of the caller, scalar outputs.
+// Finish: se, istop 2 -> 3; this rank's slices of x (and se) are written at their place
+// [rank * chunk, ...) of the caller's P * chunk buffers (the caller all-gathers them); scalar outputs.
 extern "C" int lsqrhip_shard_end(lsqrhip_handle_t h, double *d_x, double *d_se, int *istop, int *itn, double *anorm,
                                  double *acond, double *rnorm, double *arnorm, double *xnorm)
 {
-    if (!h || !h->shard_T) return fail(LSQRHIP_ERR_NOT_INIT, "lsqrhip_shard_begin was not called");
+    if (!h || !h->shard.active) return fail(LSQRHIP_ERR_NOT_INIT, "lsqrhip_shard_begin was not called");
     HIPCHK(hipSetDevice(h->device));
     hipStream_t s = h->stream;
-    const size_t n = (size_t)h->n;
-    if (h->shard_wantse && n > 0)
-        hipLaunchKernelGGL(k_se_finish, dim3(h->vgrid_n), dim3(VEC_BLOCK), 0, s, h->SE, (int64_t)n,
+    ShardCtx &c = h->shard;
+    const size_t len = (size_t)std::max<int64_t>(c.mylen, 0);
+    if (c.wantse && len > 0)
+        hipLaunchKernelGGL(k_se_finish, dim3(vec_grid(2 * (int64_t)len)), dim3(VEC_BLOCK), 0, s, h->SE, (int64_t)len,
                            (const LsqrState *)h->d_state);
-    if (d_x && n > 0) HIPCHK(hipMemcpyAsync(d_x, h->X, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
-    if (d_se && h->shard_wantse && n > 0) HIPCHK(hipMemcpyAsync(d_se, h->SE, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
+    if (d_x && len > 0) HIPCHK(hipMemcpyAsync(d_x + c.my0, h->X, sizeof(double) * len, hipMemcpyDeviceToDevice, s));
+    if (d_se && c.wantse && len > 0)
+        HIPCHK(hipMemcpyAsync(d_se + c.my0, h->SE, sizeof(double) * len, hipMemcpyDeviceToDevice, s));
     HIPCHK(hipMemcpyAsync(h->h_state, h->d_state, sizeof(LsqrState), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     const LsqrState &r = *h->h_state;
@@ -201,7 +339,6 @@ extern "C" int lsqrhip_shard_end(lsqrhip_handle_t h, double *d_x, double *d_se, 
     if (rnorm) *rnorm = r.rnorm;
     if (arnorm) *arnorm = r.arnorm;
     if (xnorm) *xnorm = r.xnorm;
-    h->shard_T = nullptr;
-    h->shard_sums = nullptr;
+    c.active = false;
     return LSQRHIP_OK;
 }

@@ -1,0 +1,513 @@
+// shard_engine.h -- the row-sharded LSQR iteration driven from C++ with RCCL over xGMI
+// (included by lsqrhip.hip).
+//
+// Two ways into the same loop (run_group):
+//   * ONE process, ngpu devices: lsqrhip_create_sharded(m, n, nnz, irow, icol, a, ngpu, &h) cuts
+//     the rows into ngpu contiguous blocks balanced by nonzeros, builds one sub-handle per device
+//     and a communicator over them (ncclCommInitAll); lsqrhip_solve / lsqrhip_aprod /
+//     lsqrhip_destroy then work on `h` as on any handle.  This is what the Fortran
+//     `initialize(..., ngpu=N)` binds: the drop-in boundary reaches every GPU of the node.
+//   * one process PER GPU (bench.py --gpus N under torch.distributed.run): every rank creates
+//     its own matrix handle from its row block, lsqrhip_shard_comm_init joins them with an
+//     ncclUniqueId that the host passes around, lsqrhip_shard_solve runs the loop.
+// The stages are those of shard_api.h; this file adds the four exchanges of an iteration:
+//     scalars   all-gather of each rank's 1-3 partial sums + a sum in RANK ORDER by every rank
+//               (identical bits everywhere, whatever algorithm RCCL picks for tiny messages)
+//     T -> R    the direct reduce-scatter: slice q of rank p's T is sent straight to rank q
+//               (ncclSend / ncclRecv inside one group: all 7 xGMI links of a GPU at once; a ring
+//               all-reduce of the same 8n bytes is per-link bound), summed there in rank order
+//     V         in-place all-gather of the column slices
+// RCCL is loaded with dlopen at first use (the library itself does not link it): a process that
+// already holds one (PyTorch) shares that copy, and single-GPU users never load it.
+#pragma once
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+namespace lsqrhip {
+
+// sums[j] <- gath[0*4 + j] + gath[1*4 + j] + ... (rank order), j < k
+__global__ void k_sum_ranks(const double *__restrict__ gath, int P, int k, double *__restrict__ sums)
+{
+    const int j = threadIdx.x;
+    if (j >= k) return;
+    double s = gath[j];
+    for (int r = 1; r < P; ++r) s = s + gath[4 * r + j];
+    sums[j] = s;
+}
+
+__global__ void k_max_int(const int *__restrict__ a, int n, int *__restrict__ out)
+{
+    int m = a[0];
+    for (int i = 1; i < n; ++i) m = a[i] > m ? a[i] : m;
+    *out = m;
+}
+
+}  // namespace lsqrhip
+
+struct Rccl {
+    void *lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+static Rccl *rccl()
+{
+    static Rccl r;
+    static bool tried = false;
+    if (tried) return r.lib ? &r : nullptr;
+    tried = true;
+    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (r.lib) break;
+    }
+    if (!r.lib) return nullptr;
+    bool ok = true;
+    auto sym = [&](const char *n) {
+        void *p = dlsym(r.lib, n);
+        if (!p) ok = false;
+        return p;
+    };
+    r.GetUniqueId = (decltype(r.GetUniqueId))sym("ncclGetUniqueId");
+    r.CommInitRank = (decltype(r.CommInitRank))sym("ncclCommInitRank");
+    r.CommInitAll = (decltype(r.CommInitAll))sym("ncclCommInitAll");
+    r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
+    r.AllGather = (decltype(r.AllGather))sym("ncclAllGather");
+    r.Send = (decltype(r.Send))sym("ncclSend");
+    r.Recv = (decltype(r.Recv))sym("ncclRecv");
+    r.GroupStart = (decltype(r.GroupStart))sym("ncclGroupStart");
+    r.GroupEnd = (decltype(r.GroupEnd))sym("ncclGroupEnd");
+    r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
+    if (!ok) {
+        r.lib = nullptr;
+        return nullptr;
+    }
+    return &r;
+}
+
+#define NCCLCHK(expr)                                                                              \
+    do {                                                                                           \
+        ncclResult_t _r = (expr);                                                                  \
+        if (_r != ncclSuccess)                                                                     \
+            return fail(LSQRHIP_ERR_HIP, std::string(#expr) + ": " + rccl()->GetErrorString(_r)); \
+    } while (0)
+
+struct ShardRank {
+    H *h = nullptr;          // this rank's matrix handle (owned by the group when `owned`)
+    int dev = -1;            // its device
+    int grank = 0;           // rank in the world
+    int64_t row0 = 0;        // first global row of the block
+    ncclComm_t comm = nullptr;
+    double *T = nullptr, *R = nullptr, *V = nullptr, *sums = nullptr, *gath = nullptr;  // exchange buffers (owned)
+    double *xfull = nullptr, *sefull = nullptr, *bloc = nullptr;                         // P*chunk, P*chunk, m_p
+};
+
+struct ShardGroup {
+    int P = 1;                     // world size
+    int m = 0, n = 0;
+    int64_t chunk = 0;
+    std::vector<ShardRank> r;      // the ranks driven by this process
+    bool owned = false;            // sub-handles belong to the group (single-process form)
+    int poll_every = 16;
+};
+
+static H *lsqrhip_group_rank0(H *h) { return h->group->r[0].h; }
+
+static void free_group(ShardGroup *g)
+{
+    if (!g) return;
+    for (ShardRank &k : g->r) {
+        if (k.h) (void)hipSetDevice(k.h->device);
+        else if (k.dev >= 0) (void)hipSetDevice(k.dev);
+        if (k.comm && rccl()) (void)rccl()->CommDestroy(k.comm);
+        for (double *p : {k.T, k.R, k.V, k.sums, k.gath, k.xfull, k.sefull, k.bloc})
+            if (p) (void)hipFree(p);
+        if (g->owned && k.h) lsqrhip_destroy(k.h);
+    }
+    delete g;
+}
+
+static void release_groups(H *h)
+{
+    if (h->mp) {
+        h->mp->r[0].h = nullptr;  // this very handle: not the group's to destroy
+        free_group(h->mp);
+        h->mp = nullptr;
+    }
+    if (h->group) {
+        free_group(h->group);
+        h->group = nullptr;
+    }
+}
+
+static int alloc_rank_buffers(ShardGroup &g, ShardRank &k)
+{
+    k.dev = k.h->device;
+    HIPCHK(hipSetDevice(k.h->device));
+    const size_t full = (size_t)std::max<int64_t>(g.chunk * g.P, 1);
+    for (double **pp : {&k.T, &k.R, &k.V, &k.xfull, &k.sefull}) HIPCHK(hipMalloc((void **)pp, sizeof(double) * full));
+    HIPCHK(hipMalloc((void **)&k.sums, sizeof(double) * 4));
+    HIPCHK(hipMalloc((void **)&k.gath, sizeof(double) * 4 * (size_t)g.P));
+    HIPCHK(hipMalloc((void **)&k.bloc, sizeof(double) * (size_t)std::max(k.h->m, 1)));
+    return LSQRHIP_OK;
+}
+
+// ---- the exchanges -------------------------------------------------------------------------------
+static int ex_scalars(ShardGroup &g, int k)  // sums[0..k) <- sum over ranks, in rank order, same bits everywhere
+{
+    Rccl *rc = rccl();
+    if (g.P > 1) {
+        NCCLCHK(rc->GroupStart());
+        for (ShardRank &q : g.r) NCCLCHK(rc->AllGather(q.sums, q.gath, 4, ncclDouble, q.comm, q.h->stream));
+        NCCLCHK(rc->GroupEnd());
+        for (ShardRank &q : g.r) {
+            HIPCHK(hipSetDevice(q.h->device));
+            hipLaunchKernelGGL(k_sum_ranks, dim3(1), dim3(4), 0, q.h->stream, (const double *)q.gath, g.P, k, q.sums);
+        }
+    }
+    return LSQRHIP_OK;
+}
+
+static int ex_scatter(ShardGroup &g)  // slice q of every rank's T -> rank q's R[rank]
+{
+    Rccl *rc = rccl();
+    const size_t c = (size_t)g.chunk;
+    if (g.P == 1 || c == 0) {
+        for (ShardRank &q : g.r)
+            if (c) HIPCHK(hipMemcpyAsync(q.R, q.T, sizeof(double) * c, hipMemcpyDeviceToDevice, q.h->stream));
+        return LSQRHIP_OK;
+    }
+    NCCLCHK(rc->GroupStart());
+    for (ShardRank &q : g.r)
+        for (int peer = 0; peer < g.P; ++peer) {
+            NCCLCHK(rc->Send(q.T + (size_t)peer * c, c, ncclDouble, peer, q.comm, q.h->stream));
+            NCCLCHK(rc->Recv(q.R + (size_t)peer * c, c, ncclDouble, peer, q.comm, q.h->stream));
+        }
+    NCCLCHK(rc->GroupEnd());
+    return LSQRHIP_OK;
+}
+
+static int ex_gather(ShardGroup &g, bool x_too, bool se_too)  // in-place all-gather of the column slices
+{
+    Rccl *rc = rccl();
+    const size_t c = (size_t)g.chunk;
+    if (g.P == 1 || c == 0) return LSQRHIP_OK;
+    NCCLCHK(rc->GroupStart());
+    for (ShardRank &q : g.r) {
+        if (!x_too) NCCLCHK(rc->AllGather(q.V + (size_t)q.grank * c, q.V, c, ncclDouble, q.comm, q.h->stream));
+        if (x_too) NCCLCHK(rc->AllGather(q.xfull + (size_t)q.grank * c, q.xfull, c, ncclDouble, q.comm, q.h->stream));
+        if (se_too) NCCLCHK(rc->AllGather(q.sefull + (size_t)q.grank * c, q.sefull, c, ncclDouble, q.comm, q.h->stream));
+    }
+    NCCLCHK(rc->GroupEnd());
+    return LSQRHIP_OK;
+}
+
+static int stage_all(ShardGroup &g, int st)
+{
+    for (ShardRank &q : g.r) RET(lsqrhip_shard_stage(q.h, st));
+    return LSQRHIP_OK;
+}
+
+// The loop.  b: every local rank's block is in q.bloc.  Outputs: x (and se) replicated in q.xfull / q.sefull.
+static int run_group(ShardGroup &g, double damp, double atol, double btol, double conlim, int itnlim, int wantse,
+                     int *istop, int *itn, double *anorm, double *acond, double *rnorm, double *arnorm, double *xnorm)
+{
+    if (g.P > 1 && !rccl()) return fail(LSQRHIP_ERR_HIP, "librccl.so.1 could not be loaded");
+    for (ShardRank &q : g.r)
+        RET(lsqrhip_shard_begin(q.h, q.bloc, g.m, g.P, q.grank, damp, atol, btol, conlim, itnlim, wantse, q.T, q.R, q.V,
+                                q.sums));
+    RET(stage_all(g, ST_SUMSQ_B));
+    RET(ex_scalars(g, 3));
+    RET(stage_all(g, ST_INIT_BETA_ATU));
+    RET(ex_scatter(g));
+    RET(stage_all(g, ST_INIT_V));
+    RET(ex_scalars(g, 2));
+    RET(stage_all(g, ST_INIT_W));
+    RET(ex_gather(g, false, false));
+    int st3[3] = {0, 0, 0};
+    auto poll = [&]() -> int {   // the scalar recurrences are replicated bit for bit: every rank sees the same flag
+        for (ShardRank &q : g.r) RET(lsqrhip_shard_poll(q.h, st3));
+        return LSQRHIP_OK;
+    };
+    RET(poll());
+    int64_t launched = 0;
+    while (!st3[0]) {
+        if (launched > (int64_t)itnlim + g.poll_every)
+            return fail(LSQRHIP_ERR_HIP, "sharded iteration loop did not terminate (device state not advancing)");
+        const int batch = (int)std::min<int64_t>(g.poll_every, std::max<int64_t>(1, (int64_t)itnlim - launched));
+        for (int k = 0; k < batch; ++k) {
+            RET(stage_all(g, ST_MODE1));
+            RET(ex_scalars(g, 1));
+            RET(stage_all(g, ST_S1_ATU));
+            RET(ex_scatter(g));
+            RET(stage_all(g, ST_VCOMBINE));
+            RET(ex_scalars(g, 2));
+            RET(stage_all(g, ST_UPDATE));
+            RET(ex_gather(g, false, false));
+        }
+        launched += batch;
+        RET(poll());
+    }
+    for (ShardRank &q : g.r) {
+        int is = 0, it = 0;
+        double sc[5];
+        RET(lsqrhip_shard_end(q.h, q.xfull, wantse ? q.sefull : nullptr, &is, &it, sc, sc + 1, sc + 2, sc + 3, sc + 4));
+        if (&q == &g.r[0]) {
+            if (istop) *istop = is;
+            if (itn) *itn = it;
+            if (anorm) *anorm = sc[0];
+            if (acond) *acond = sc[1];
+            if (rnorm) *rnorm = sc[2];
+            if (arnorm) *arnorm = sc[3];
+            if (xnorm) *xnorm = sc[4];
+        }
+    }
+    RET(ex_gather(g, true, wantse != 0));
+    for (ShardRank &q : g.r) {
+        HIPCHK(hipSetDevice(q.h->device));
+        HIPCHK(hipStreamSynchronize(q.h->stream));
+    }
+    return LSQRHIP_OK;
+}
+
+// Every rank of the world uses the largest norm_exp (scalar.h "range-safe norms").
+static int agree_norm_exp(ShardGroup &g)
+{
+    int e = -100000;
+    for (ShardRank &q : g.r) e = std::max(e, q.h->norm_exp);
+    if (g.P > (int)g.r.size()) {   // other processes: one tiny all-gather of ints (as doubles)
+        Rccl *rc = rccl();
+        for (ShardRank &q : g.r) {
+            HIPCHK(hipSetDevice(q.h->device));
+            double v[4] = {(double)e, 0, 0, 0};
+            HIPCHK(hipMemcpyAsync(q.sums, v, sizeof(v), hipMemcpyHostToDevice, q.h->stream));
+        }
+        NCCLCHK(rc->GroupStart());
+        for (ShardRank &q : g.r) NCCLCHK(rc->AllGather(q.sums, q.gath, 4, ncclDouble, q.comm, q.h->stream));
+        NCCLCHK(rc->GroupEnd());
+        std::vector<double> all(4 * (size_t)g.P);
+        ShardRank &q0 = g.r[0];
+        HIPCHK(hipSetDevice(q0.h->device));
+        HIPCHK(hipMemcpyAsync(all.data(), q0.gath, sizeof(double) * all.size(), hipMemcpyDeviceToHost, q0.h->stream));
+        HIPCHK(hipStreamSynchronize(q0.h->stream));
+        for (int r = 0; r < g.P; ++r) e = std::max(e, (int)all[4 * (size_t)r]);
+    }
+    for (ShardRank &q : g.r) RET(lsqrhip_set_option(q.h, "norm_exp", e));
+    return LSQRHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// one process, ngpu devices
+// ---------------------------------------------------------------------------------------------------
+extern "C" int lsqrhip_create_sharded(int m, int n, int64_t nnz, const int *irow, const int *icol, const double *a,
+                                      int ngpu, lsqrhip_handle_t *out)
+{
+    if (!out) return fail(LSQRHIP_ERR_ARG, "null handle pointer");
+    *out = nullptr;
+    if (ngpu < 1) return fail(LSQRHIP_ERR_ARG, "ngpu must be >= 1");
+    if (m < 0 || n < 0 || nnz < 0) return fail(LSQRHIP_ERR_ARG, "negative dimension");
+    const int ngpu_asked = ngpu;
+    if (nnz > 0 && (!irow || !icol || !a)) return fail(LSQRHIP_ERR_SIZES, lsqrhip_error_string(LSQRHIP_ERR_SIZES));
+    const int have = lsqrhip_device_count();
+    if (have < ngpu)
+        return fail(LSQRHIP_ERR_NO_DEVICE, "ngpu = " + std::to_string(ngpu) + " but this node shows " + std::to_string(have) +
+                                               " usable gfx950 device(s)");
+    ngpu = std::min(ngpu_asked, std::max(m, 1));  // never more row blocks than rows
+    if (ngpu > 1 && !rccl()) return fail(LSQRHIP_ERR_HIP, "librccl.so.1 could not be loaded");
+    // the reference's checks first (src/lsqr.f90:110-111), on the whole system
+    for (int64_t k = 0; k < nnz; ++k) {
+        if (irow[k] < 1 || irow[k] > m) return fail(LSQRHIP_ERR_IROW, lsqrhip_error_string(LSQRHIP_ERR_IROW));
+        if (icol[k] < 1 || icol[k] > n) return fail(LSQRHIP_ERR_ICOL, lsqrhip_error_string(LSQRHIP_ERR_ICOL));
+    }
+    // contiguous row blocks balanced by nonzeros (+1 per row: a row costs work even when empty)
+    std::vector<int64_t> cum((size_t)m + 1, 0);
+    for (int64_t k = 0; k < nnz; ++k) cum[(size_t)irow[k]] += 1;
+    for (int r = 0; r < m; ++r) cum[(size_t)r + 1] += cum[(size_t)r] + 1;
+    std::vector<int> cut((size_t)ngpu + 1, 0);
+    cut[(size_t)ngpu] = m;
+    for (int p = 1; p < ngpu; ++p) {
+        const int64_t target = cum[(size_t)m] * p / ngpu;
+        int r = (int)(std::lower_bound(cum.begin(), cum.end(), target) - cum.begin());
+        r = std::min(std::max(r, cut[(size_t)p - 1] + (m >= ngpu ? 1 : 0)), m - (m >= ngpu ? ngpu - p : 0));
+        cut[(size_t)p] = std::max(r, cut[(size_t)p - 1]);
+    }
+    std::vector<int> owner((size_t)m + 1, 0);
+    for (int p = 0; p < ngpu; ++p)
+        for (int r = cut[(size_t)p]; r < cut[(size_t)p + 1]; ++r) owner[(size_t)r] = p;
+    std::vector<int64_t> cnt((size_t)ngpu + 1, 0);
+    for (int64_t k = 0; k < nnz; ++k) cnt[(size_t)owner[(size_t)irow[k] - 1] + 1] += 1;
+    for (int p = 0; p < ngpu; ++p) cnt[(size_t)p + 1] += cnt[(size_t)p];
+
+    H *h = nullptr;
+    const int dev0 = g_device.load();
+    RET(new_handle(m, n, 0, &h));  // the parent: dimensions, error state, the group
+    h->nnz = nnz;
+    ShardGroup *g = new ShardGroup();
+    h->group = g;
+    g->P = ngpu;
+    g->m = m;
+    g->n = n;
+    g->chunk = ((int64_t)n + ngpu - 1) / ngpu;
+    g->owned = true;
+    g->r.resize((size_t)ngpu);
+    int rc = LSQRHIP_OK;
+    {
+        std::vector<int> lr, lc;
+        std::vector<double> la;
+        for (int p = 0; p < ngpu && rc == LSQRHIP_OK; ++p) {
+            const size_t np = (size_t)(cnt[(size_t)p + 1] - cnt[(size_t)p]);
+            lr.resize(np); lc.resize(np); la.resize(np);
+            size_t w = 0;
+            for (int64_t k = 0; k < nnz; ++k)   // COO order kept inside the block
+                if (owner[(size_t)irow[k] - 1] == p) {
+                    lr[w] = irow[k] - cut[(size_t)p];
+                    lc[w] = icol[k];
+                    la[w] = a[k];
+                    ++w;
+                }
+            g_device = dev0 + p;
+            ShardRank &q = g->r[(size_t)p];
+            q.grank = p;
+            q.row0 = cut[(size_t)p];
+            rc = lsqrhip_create(cut[(size_t)p + 1] - cut[(size_t)p], n, (int64_t)np, lr.data(), lc.data(), la.data(), &q.h);
+        }
+    }
+    g_device = dev0;
+    if (rc == LSQRHIP_OK)
+        for (ShardRank &q : g->r)
+            if ((rc = alloc_rank_buffers(*g, q)) != LSQRHIP_OK) break;
+    if (rc == LSQRHIP_OK && ngpu > 1) {
+        std::vector<int> devs;
+        std::vector<ncclComm_t> comms((size_t)ngpu);
+        for (ShardRank &q : g->r) devs.push_back(q.h->device);
+        ncclResult_t nr = rccl()->CommInitAll(comms.data(), ngpu, devs.data());
+        if (nr != ncclSuccess) rc = fail(LSQRHIP_ERR_HIP, std::string("ncclCommInitAll: ") + rccl()->GetErrorString(nr));
+        else
+            for (int p = 0; p < ngpu; ++p) g->r[(size_t)p].comm = comms[(size_t)p];
+    }
+    if (rc == LSQRHIP_OK) rc = agree_norm_exp(*g);
+    if (rc != LSQRHIP_OK) {
+        std::string keep = g_last_error;
+        lsqrhip_destroy(h);
+        g_last_error = keep;
+        return rc;
+    }
+    (void)hipSetDevice(dev0);
+    *out = h;
+    return LSQRHIP_OK;
+}
+
+// lsqrhip_solve on a sharded handle: b is cut into the row blocks, x (se) come back whole.
+static int solve_group_host(H *h, const double *b, double damp, double atol, double btol, double conlim, int itnlim,
+                            int wantse, double *x, double *se, int *istop, int *itn, double *anorm, double *acond,
+                            double *rnorm, double *arnorm, double *xnorm)
+{
+    ShardGroup &g = *h->group;
+    if (!istop || (!x && g.n > 0) || (!b && g.m > 0)) return fail(LSQRHIP_ERR_ARG, "null b, x or istop");
+    if (wantse && !se) return fail(LSQRHIP_ERR_ARG, "wantse set but se is null");
+    for (ShardRank &q : g.r) {
+        HIPCHK(hipSetDevice(q.h->device));
+        if (q.h->m > 0)
+            HIPCHK(hipMemcpyAsync(q.bloc, b + q.row0, sizeof(double) * (size_t)q.h->m, hipMemcpyHostToDevice, q.h->stream));
+    }
+    RET(run_group(g, damp, atol, btol, conlim, itnlim, wantse, istop, itn, anorm, acond, rnorm, arnorm, xnorm));
+    ShardRank &q0 = g.r[0];
+    HIPCHK(hipSetDevice(q0.h->device));
+    if (g.n > 0) HIPCHK(hipMemcpy(x, q0.xfull, sizeof(double) * (size_t)g.n, hipMemcpyDeviceToHost));
+    if (wantse && g.n > 0) HIPCHK(hipMemcpy(se, q0.sefull, sizeof(double) * (size_t)g.n, hipMemcpyDeviceToHost));
+    return LSQRHIP_OK;
+}
+
+// lsqrhip_aprod on a sharded handle (host vectors): the blocks one after the other
+static int aprod_group_host(H *h, int mode, double *x, double *y)
+{
+    ShardGroup &g = *h->group;
+    if (mode == 1) {
+        for (ShardRank &q : g.r) RET(lsqrhip_aprod(q.h, 1, x, y + q.row0));
+        return LSQRHIP_OK;
+    }
+    std::vector<double> t((size_t)std::max(g.n, 1)), acc((size_t)std::max(g.n, 1), 0.0);
+    for (ShardRank &q : g.r) {   // x += sum_p A_p' y_p, partial products added in rank order
+        std::fill(t.begin(), t.end(), 0.0);
+        RET(lsqrhip_aprod(q.h, 2, t.data(), y + q.row0));
+        for (int j = 0; j < g.n; ++j) acc[(size_t)j] = &q == &g.r[0] ? t[(size_t)j] : acc[(size_t)j] + t[(size_t)j];
+    }
+    for (int j = 0; j < g.n; ++j) x[j] = x[j] + acc[(size_t)j];
+    return LSQRHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// one process per GPU
+// ---------------------------------------------------------------------------------------------------
+extern "C" int lsqrhip_rccl_unique_id(char *out128)
+{
+    if (!out128) return fail(LSQRHIP_ERR_ARG, "null buffer");
+    Rccl *rc = rccl();
+    if (!rc) return fail(LSQRHIP_ERR_HIP, "librccl.so.1 could not be loaded");
+    ncclUniqueId id;
+    NCCLCHK(rc->GetUniqueId(&id));
+    std::memcpy(out128, id.internal, NCCL_UNIQUE_ID_BYTES);
+    return LSQRHIP_OK;
+}
+
+extern "C" int lsqrhip_shard_comm_init(lsqrhip_handle_t h, int world, int rank, int64_t row0, int64_t m_global,
+                                       const char *id128)
+{
+    if (!h || h->op || h->group) return fail(LSQRHIP_ERR_ARG, "needs a matrix handle that is not yet part of a group");
+    if (world < 1 || rank < 0 || rank >= world) return fail(LSQRHIP_ERR_ARG, "bad world / rank");
+    if (world > 1 && !id128) return fail(LSQRHIP_ERR_ARG, "null unique id");
+    if (world > 1 && !rccl()) return fail(LSQRHIP_ERR_HIP, "librccl.so.1 could not be loaded");
+    HIPCHK(hipSetDevice(h->device));
+    ShardGroup *g = new ShardGroup();
+    g->P = world;
+    g->m = (int)m_global;
+    g->n = h->n;
+    g->chunk = ((int64_t)h->n + world - 1) / world;
+    g->owned = false;
+    g->r.resize(1);
+    ShardRank &q = g->r[0];
+    q.h = h;
+    q.grank = rank;
+    q.row0 = row0;
+    int rc = alloc_rank_buffers(*g, q);
+    if (rc == LSQRHIP_OK && world > 1) {
+        ncclUniqueId id;
+        std::memcpy(id.internal, id128, NCCL_UNIQUE_ID_BYTES);
+        ncclResult_t nr = rccl()->CommInitRank(&q.comm, world, id, rank);
+        if (nr != ncclSuccess) rc = fail(LSQRHIP_ERR_HIP, std::string("ncclCommInitRank: ") + rccl()->GetErrorString(nr));
+    }
+    if (rc == LSQRHIP_OK) rc = agree_norm_exp(*g);
+    if (rc != LSQRHIP_OK) {
+        q.h = nullptr;  // not ours to destroy
+        free_group(g);
+        return rc;
+    }
+    h->mp = g;
+    return LSQRHIP_OK;
+}
+
+extern "C" int lsqrhip_shard_solve(lsqrhip_handle_t h, const double *d_b_local, double damp, double atol, double btol,
+                                   double conlim, int itnlim, int wantse, double *d_x, double *d_se, int *istop, int *itn,
+                                   double *anorm, double *acond, double *rnorm, double *arnorm, double *xnorm)
+{
+    if (!h || !h->mp) return fail(LSQRHIP_ERR_NOT_INIT, "lsqrhip_shard_comm_init was not called");
+    ShardGroup &g = *h->mp;
+    ShardRank &q = g.r[0];
+    HIPCHK(hipSetDevice(h->device));
+    if (h->m > 0) {
+        if (!d_b_local) return fail(LSQRHIP_ERR_ARG, "null b");
+        HIPCHK(hipMemcpyAsync(q.bloc, d_b_local, sizeof(double) * (size_t)h->m, hipMemcpyDeviceToDevice, h->stream));
+    }
+    RET(run_group(g, damp, atol, btol, conlim, itnlim, wantse, istop, itn, anorm, acond, rnorm, arnorm, xnorm));
+    if (d_x && g.n > 0) HIPCHK(hipMemcpy(d_x, q.xfull, sizeof(double) * (size_t)g.n, hipMemcpyDeviceToDevice));
+    if (d_se && wantse && g.n > 0) HIPCHK(hipMemcpy(d_se, q.sefull, sizeof(double) * (size_t)g.n, hipMemcpyDeviceToDevice));
+    return LSQRHIP_OK;
+}

@@ -187,14 +187,29 @@ static void launch_csb(H *h, const SpmvArgs &a)
         xb.xmax = h->xmax_part;
         xb.nxmax = g;
     }
-    const CsbMat A{c.cval, c.cidx, c.ccb, c.cptr, c.nrb, c.R, c.rows, c.cols, h->amax_exp, c.H};
-    const dim3 grid(c.grid + (a.rider.kind != 0 ? 1 : 0));
-    if (a.e0 == nullptr && a.e1 == nullptr)
-        hipLaunchKernelGGL(k_spmv_csb, grid, dim3(CSB_BLOCK), 0, a.stream, A, a.x, a.y, a.coef, a.stop, a.pout, a.pin,
-                           a.npin, a.slot_in, a.slot_out, a.skip_if_zero, a.rider, xb, a.nsc);
-    else
-        hipExtLaunchKernelGGL(k_spmv_csb, grid, dim3(CSB_BLOCK), 0, a.stream, a.e0, a.e1, 0, A, a.x, a.y, a.coef, a.stop,
-                              a.pout, a.pin, a.npin, a.slot_in, a.slot_out, a.skip_if_zero, a.rider, xb, a.nsc);
+    // One launch per ROUND of row blocks (256 at a time, one per CU).  Every workgroup sweeps x from its
+    // first to its last column; workgroups that start a sweep together stay close enough for the part of x
+    // they gather from to sit in their XCD's L2, and a kernel boundary re-aligns them for the next round
+    // (one launch over all blocks lets them drift apart: config 4 7.3 instead of 5.x ms).  The scalar rider
+    // goes with the first launch.  LSQRHIP_CSB_ROUNDS=0: one launch.
+    static const int rounds = env_int("LSQRHIP_CSB_ROUNDS", 1);
+    const int step = rounds ? c.grid : c.nrb;
+    for (int b0 = 0; b0 < c.nrb || b0 == 0; b0 += step) {
+        const int b1 = std::min(c.nrb, b0 + step);
+        const bool first = b0 == 0, last = b1 >= c.nrb;
+        const CsbMat A{c.cval, c.cidx, c.ccb, c.cptr, c.nrb, c.R, c.rows, c.cols, h->amax_exp, c.H, b0, b1};
+        Rider rider = first ? a.rider : Rider{};
+        const dim3 grid(std::max(1, std::min(c.grid, b1 - b0)) + (rider.kind != 0 ? 1 : 0));
+        hipEvent_t e0 = first ? a.e0 : nullptr, e1 = last ? a.e1 : nullptr;
+        auto kern = c.lo32 ? k_spmv_csb<true> : k_spmv_csb<false>;
+        if (e0 == nullptr && e1 == nullptr)
+            hipLaunchKernelGGL(kern, grid, dim3(CSB_BLOCK), 0, a.stream, A, a.x, a.y, a.coef, a.stop, a.pout, a.pin,
+                               a.npin, a.slot_in, a.slot_out, a.skip_if_zero, rider, xb, a.nsc);
+        else
+            hipExtLaunchKernelGGL(kern, grid, dim3(CSB_BLOCK), 0, a.stream, e0, e1, 0, A, a.x, a.y, a.coef, a.stop,
+                                  a.pout, a.pin, a.npin, a.slot_in, a.slot_out, a.skip_if_zero, rider, xb, a.nsc);
+        if (last) break;
+    }
 }
 
 static void launch_spmv_args(H *h, const SpmvArgs &a_in)
@@ -501,6 +516,12 @@ static int solve_core(H *h, const double *b, bool b_on_device, double damp, doub
                       int *itn, double *anorm, double *acond, double *rnorm, double *arnorm, double *xnorm)
 {
     if (!h) return fail(LSQRHIP_ERR_NOT_INIT, lsqrhip_error_string(LSQRHIP_ERR_NOT_INIT));
+    if (h->group) {  // a system sharded over several GPUs by this process (shard_engine.h)
+        if (b_on_device || out_on_device)
+            return fail(LSQRHIP_ERR_ARG, "a sharded handle takes host vectors (its devices each hold a row block)");
+        return solve_group_host(h, b, damp, atol, btol, conlim, itnlim, wantse, x, se, istop, itn, anorm, acond, rnorm,
+                                arnorm, xnorm);
+    }
     if (!istop || (!x && h->n > 0) || (!b && h->m > 0)) return fail(LSQRHIP_ERR_ARG, "null b, x or istop");
     if (wantse && !se) return fail(LSQRHIP_ERR_ARG, "wantse set but se is null");
     HIPCHK(hipSetDevice(h->device));

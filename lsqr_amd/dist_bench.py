@@ -21,7 +21,7 @@ def run_distributed(args):
     import torch.distributed as dist
 
     from . import capi, devgen
-    from .dist import HipShardBackend, ShardedLSQR, TorchComm, partition_rows
+    from .dist import EngineSolver, HipShardBackend, ShardedLSQR, TorchComm, partition_rows
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -32,6 +32,8 @@ def run_distributed(args):
     capi.check(capi.lib().lsqrhip_set_device(local))
     dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
     comm = TorchComm()
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)")
 
     spec = DEFAULT_SPEC if args.workload == "auto" else args.workload
     cfg = devgen.parse_spec(spec)
@@ -39,8 +41,15 @@ def run_distributed(args):
     blocks = partition_rows(cfg["m"], world, devgen.row_weights(cfg))
     row0, nrows = blocks[rank]
     prob = devgen.generate(spec, row0, nrows)
-    be = HipShardBackend(prob.solver, cfg["m"])
-    drv = ShardedLSQR(be, comm, poll_every=min(16, max(1, K)))
+    # the loop itself -- kernels and RCCL calls -- runs in C++ (csrc/shard_engine.h); LSQR_DIST_ENGINE=python
+    # selects the stage-by-stage driver over torch.distributed instead (same arithmetic)
+    engine = os.environ.get("LSQR_DIST_ENGINE", "c++")
+    if engine == "python":
+        be = HipShardBackend(prob.solver, cfg["m"], world, rank)
+        drv = ShardedLSQR(be, comm, poll_every=min(16, max(1, K)))
+    else:
+        be = None
+        drv = EngineSolver(prob.solver, row0, cfg["m"], world, rank)
     kw = dict(damp=cfg["damp"], atol=0.0, btol=0.0, conlim=0.0)
 
     if W > 0:
@@ -71,15 +80,18 @@ def run_distributed(args):
     dist.all_reduce(nnz_all)
     nnz_total = int(nnz_all.item())
 
-    # local SpMV rate of this rank's block (roofline of the dominant kernel)
-    be.close()
+    # local SpMV rate of this rank's block (roofline of the dominant kernel): PHYSICAL bytes of the
+    # layout in use / average launch time; the SURVEY 8d algorithmic rate beside it, labelled
+    if be is not None:
+        be.close()
     s = prob.solver
-    reps = max(20, min(K, 200))
+    reps = max(10, min(K, 100))
     avg1 = s.bench_kernel(1, reps)
-    tm = s.last_timing()
-    p = 8 if nnz_total >= 2 ** 31 and prob.nnz >= 2 ** 31 else 4
-    b1 = 12 * prob.nnz + p * (nrows + 1) + 8 * cfg["n"] + 16 * nrows
-    ach = b1 / (avg1 * 1e-3) / 1e9
+    info = s.info()
+    b1 = 12 * prob.nnz + info["rowptr_bytes"] * (nrows + 1) + 8 * cfg["n"] + 16 * nrows
+    lay1 = info["csr_bytes"] + 8 * cfg["n"] + 16 * nrows
+    ach = lay1 / (avg1 * 1e-3) / 1e9
+    kname = "k_spmv_csb" if info["xlds"] == 3 else ("k_spmv_fused + k_panel_combine" if info["panels"] > 1 else "k_spmv_*")
 
     # Same workload on ONE GPU (rank 0), outside the timed region: N = 1 of bench.py runs a
     # different configuration (BASELINE configs[1]), so the strong-scaling speedup of THIS
@@ -126,13 +138,18 @@ def run_distributed(args):
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{spec} m={cfg['m']} n={cfg['n']} nnz={nnz_total} damp={cfg['damp']} "
                                    f"(BASELINE.json configs[3]: 10M x 10M random, row-block sharded)",
-                       "rows_per_rank": [b[1] for b in blocks], "collectives_per_iteration":
-                           {"allreduce_scalar_f64": 1, "allreduce_vector_bytes": 8 * cfg["n"]},
-                       "backend": "nccl (RCCL over xGMI)", "restarts": restarts},
+                       "rows_per_rank": [b[1] for b in blocks], "exchanges_per_iteration":
+                           {"allreduce_scalars": "1 + 2 doubles (all-gather + rank-ordered sum)",
+                            "reduce_scatter_bytes_out_per_gpu": 8 * cfg["n"] * (world - 1) // world,
+                            "allgather_bytes_in_per_gpu": 8 * cfg["n"] * (world - 1) // world},
+                       "backend": "nccl (RCCL over xGMI)", "engine": engine, "world_size": dist.get_world_size(),
+                       "restarts": restarts},
             "result": {"istop": r.istop, "itn": r.itn, "anorm": r.anorm, "rnorm": r.rnorm},
-            "roofline": {"bound": "hbm", "kernel": "k_spmv_fused (aprod mode 1, local row block, rank 0)",
+            "roofline": {"bound": "hbm", "kernel": f"{kname} (aprod mode 1, local row block, rank 0)",
                          "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": None,
-                         "bytes_per_launch": b1, "avg_launch_us": avg1 * 1e3, "launches": reps},
+                         "bytes_per_launch": lay1, "avg_launch_us": avg1 * 1e3, "launches": reps,
+                         "bytes_are": "the layout in use: matrix as stored + x once + y read and written (physical)",
+                         "effective_gbps": b1 / (avg1 * 1e-3) / 1e9, "effective_bytes_per_launch": b1},
         }
         if ref is not None:
             out["strong_scaling_ref"] = ref

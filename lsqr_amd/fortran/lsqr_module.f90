@@ -44,6 +44,7 @@ module lsqr_module
       integer  :: itnlim = 100
       integer  :: nout = 0
       type(c_ptr) :: handle = c_null_ptr   !< lsqrhip_handle_t (reference-counted, see assignment)
+      logical  :: sharded = .false.        !< rows cut over several GPUs (`initialize(..., ngpu=)`): no iteration log
    contains
       procedure, public :: initialize => initialize_ez
       procedure, public :: solve => solve_ez
@@ -71,6 +72,15 @@ module lsqr_module
       function lsqrhip_create(m, n, nnz, irow, icol, a, h) bind(C, name='lsqrhip_create') result(rc)
          import :: c_int, c_int64_t, c_double, c_ptr
          integer(c_int), value :: m, n
+         integer(c_int64_t), value :: nnz
+         integer(c_int), intent(in) :: irow(*), icol(*)
+         real(c_double), intent(in) :: a(*)
+         type(c_ptr), intent(out) :: h
+         integer(c_int) :: rc
+      end function
+      function lsqrhip_create_sharded(m, n, nnz, irow, icol, a, ngpu, h) bind(C, name='lsqrhip_create_sharded') result(rc)
+         import :: c_int, c_int64_t, c_double, c_ptr
+         integer(c_int), value :: m, n, ngpu
          integer(c_int64_t), value :: nnz
          integer(c_int), intent(in) :: irow(*), icol(*)
          real(c_double), intent(in) :: a(*)
@@ -196,26 +206,36 @@ contains
 
    !> Constructor (replaces src/lsqr.f90:91-127).  `me` is intent(out): any matrix the object
    !! held before is released (finalisation) and every option returns to its default.
-   subroutine initialize_ez(me, m, n, a, irow, icol, atol, btol, conlim, itnlim, nout)
+   !!
+   !! `ngpu` (optional, last, not in the reference): the number of GPUs of this node to shard the
+   !! rows over (contiguous row blocks balanced by nonzeros, RCCL over xGMI inside the library).
+   !! Absent: one GPU.  More GPUs than the node has: `error stop`.
+   subroutine initialize_ez(me, m, n, a, irow, icol, atol, btol, conlim, itnlim, nout, ngpu)
       class(lsqr_solver_ez), intent(out) :: me
       integer, intent(in) :: m, n
       integer, dimension(:), intent(in) :: irow, icol
       real(wp), dimension(:), intent(in) :: a
       real(wp), intent(in), optional :: atol, btol, conlim
       integer, intent(in), optional :: itnlim, nout
+      integer, intent(in), optional :: ngpu
       integer(c_int), allocatable :: ir(:), ic(:)
       real(c_double), allocatable :: av(:)
+      integer(c_int64_t) :: nz
 
       if (size(a) /= size(irow) .or. size(a) /= size(icol)) call check(1_c_int)
       ir = irow            ! contiguous copies for the C side
       ic = icol
       av = a
+      nz = int(size(a), c_int64_t)
       if (size(av) == 0) then
          deallocate (ir, ic, av)
          allocate (ir(1), ic(1), av(1))
-         call check(lsqrhip_create(int(m, c_int), int(n, c_int), 0_c_int64_t, ir, ic, av, me%handle))
+      end if
+      if (present(ngpu)) then
+         call check(lsqrhip_create_sharded(int(m, c_int), int(n, c_int), nz, ir, ic, av, int(ngpu, c_int), me%handle))
+         me%sharded = .true.
       else
-         call check(lsqrhip_create(int(m, c_int), int(n, c_int), int(size(a), c_int64_t), ir, ic, av, me%handle))
+         call check(lsqrhip_create(int(m, c_int), int(n, c_int), nz, ir, ic, av, me%handle))
       end if
       me%m = m
       me%n = n
@@ -250,6 +270,7 @@ contains
       lhs%m = rhs%m; lhs%n = rhs%n; lhs%num_nonzero_elements = rhs%num_nonzero_elements
       lhs%atol = rhs%atol; lhs%btol = rhs%btol; lhs%conlim = rhs%conlim
       lhs%itnlim = rhs%itnlim; lhs%nout = rhs%nout
+      lhs%sharded = rhs%sharded
       lhs%handle = rhs%handle
       if (c_associated(lhs%handle)) rc = lsqrhip_retain(lhs%handle)
    end subroutine copy_ez
@@ -290,7 +311,7 @@ contains
 
       if (.not. c_associated(me%handle)) call check(4_c_int)
       wantse = merge(1_c_int, 0_c_int, present(se))
-      want_log = merge(1_c_int, 0_c_int, me%nout /= 0)
+      want_log = merge(1_c_int, 0_c_int, me%nout /= 0 .and. .not. me%sharded)
       allocate (xl(max(me%n, 1)), sel(max(me%n, 1)), bl(max(me%m, 1)))
       bl(1:me%m) = b
       call check(lsqrhip_solve(me%handle, bl, real(damp, c_double), real(me%atol, c_double), &
@@ -305,7 +326,8 @@ contains
       if (present(rnorm)) rnorm = rnorm_
       if (present(arnorm)) arnorm = arnorm_
       if (present(xnorm)) xnorm = xnorm_
-      if (me%nout /= 0) call print_device_log(me, damp, present(se), int(istop_), int(itn_), real(anorm_, wp), &
+      if (me%nout /= 0 .and. .not. me%sharded) &
+         call print_device_log(me, damp, present(se), int(istop_), int(itn_), real(anorm_, wp), &
                                               real(acond_, wp), real(rnorm_, wp), real(arnorm_, wp), real(xnorm_, wp))
    end subroutine solve_ez
 

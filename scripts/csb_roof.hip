@@ -138,10 +138,10 @@ static double run(const int *col, const double *val, const double *x, int64_t pe
     return ms / reps;
 }
 
-int main()
+int main(int argc, char **argv)
 {
-    const int nblocks = 512;
-    const int64_t per_max = 819200;
+    const int nblocks = argc > 1 ? std::atoi(argv[1]) : 512;
+    const int64_t per_max = 976640;
     const int64_t cap = per_max * nblocks;
     int *col;
     double *val, *x, *out;
@@ -153,6 +153,7 @@ int main()
     struct Cfg { const char *name; int ncols; int64_t per; int sorted; };
     const Cfg cfgs[] = {
         {"n=1e7 R*d=819200 (config 4: 8192 rows x 100) sorted", 10000000, 819200, 1},
+        {"n=1e7 R*d=976640 (config 4: 9766 rows x 100) sorted", 10000000, 976640, 1},
         {"n=1e7 R*d=819200 random order", 10000000, 819200, 0},
         {"n=1e7 R*d=488320 (N=8 shard: 4883 rows x 100) sorted", 10000000, 488320, 1},
         {"n=1e7 R*d=102400 (N=8 shard A': 8192 rows x 12.5, x=1.25e6)", 1250000, 102400, 1},

@@ -18,5 +18,6 @@ b3 = 40 * n
 t = [s.bench_kernel(w, reps) for w in (1, 2, 3)]
 t = [min(a, s.bench_kernel(w, reps)) for a, w in zip(t, (1, 2, 3))]
 env = " ".join(f"{k[8:]}={v}" for k, v in sorted(os.environ.items()) if k.startswith("LSQRHIP_"))
-print(f"{spec:34s} [{env:28s}] spmv1 {t[0]*1e3:8.2f} us {b1/t[0]/1e6:7.0f} GB/s | spmv2 {t[1]*1e3:8.2f} us {b2/t[1]/1e6:7.0f} GB/s"
+lay = f"A:sell{info['sell']}/xl{info['xlds']}/P{info['panels']} A':sell{info['sell_t']}/xl{info['xlds_t']}/P{info['panels_t']}"
+print(f"{spec:34s} [{env:28s}] {lay} spmv1 {t[0]*1e3:8.2f} us {b1/t[0]/1e6:7.0f} GB/s | spmv2 {t[1]*1e3:8.2f} us {b2/t[1]/1e6:7.0f} GB/s"
       f" | update {t[2]*1e3:7.2f} us {b3/t[2]/1e6:7.0f} GB/s", flush=True)

@@ -31,14 +31,14 @@ def main():
     comm = TorchComm()
     if backend == "numpy":
         from np_shard_backend import NumpyShardBackend
-        be = NumpyShardBackend(nrows, p.n, irow, icol, a, p.m)
+        be = NumpyShardBackend(nrows, p.n, irow, icol, a, p.m, world, rank)
         b_arg = b
     else:
         from lsqr_amd import capi
         from lsqr_amd.dist import HipShardBackend
         from lsqr_amd.solver import lsqr_solver_ez
         s = lsqr_solver_ez().initialize(nrows, p.n, a, irow, icol)
-        be = HipShardBackend(s, p.m)
+        be = HipShardBackend(s, p.m, world, rank)
         d_b = capi.DeviceBuffer.from_array(b if nrows else np.zeros(1))
         b_arg = d_b.ptr.value
     r = ShardedLSQR(be, comm, poll_every=3).solve(b_arg, damp=o["damp"], atol=o["atol"], btol=o["btol"],

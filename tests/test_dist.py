@@ -96,7 +96,9 @@ def check_against_oracle(case, res):
 
 
 @pytest.mark.parametrize("case,world", [("random_over_damped", 2), ("poisson_20x20_it50", 2),
-                                        ("random_over_se", 3), ("b_zero", 2)])
+                                        ("random_over_se", 3), ("b_zero", 2),
+                                        ("random_over_damped", 3),      # n = 500 over 3 ranks: ragged last column slice
+                                        ("shuffled_dups", 4)])          # n = 60, unsorted COO with duplicates
 def test_sharded_driver_gloo_cpu(case, world, tmp_path):
     res = run_world(case, world, "numpy", tmp_path)
     if case == "b_zero":

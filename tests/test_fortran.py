@@ -103,6 +103,36 @@ def test_ez_driver_on_gpu_matches_oracle():
     assert np.max(np.abs(xs - want)) <= 1e-10 * np.linalg.norm(o.x, np.inf)
 
 
+@pytest.mark.gpu
+def test_sharded_initialize_from_fortran():
+    """`initialize(..., ngpu=N)`: Fortran -> lsqrhip_create_sharded -> the C++ RCCL engine.  At ngpu = 1 on
+    a one-GPU box against the oracle; asking for more GPUs than the node has must `error stop`."""
+    path = os.path.join(LIB, "test_sharded")
+    assert os.path.exists(path), f"{path} missing: run __graft_entry__.build()"
+    p = subprocess.run([path, "1"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    out = p.stdout
+    assert "SHARDED TESTS PASSED ngpu=1" in out
+    readme = [l for l in out.splitlines() if l.startswith("README istop")][0]
+    assert "istop= 1" in readme
+    assert np.allclose(numbers(readme), [1.2424242424242424, -6.0606060606060594e-02, -4.0404040404040407e-02],
+                       rtol=1e-10, atol=0)
+    prob = P.poisson2d(64, 64)
+    o = oracle.port().solve(prob.m, prob.n, prob.irow, prob.icol, prob.a, prob.b, itnlim=60)
+    assert "istop=5 itn=60" in [l for l in out.splitlines() if l.startswith("POISSON nx=")][0]
+    nrm = numbers([l for l in out.splitlines() if l.startswith("POISSON_NORMS")][0])
+    xs = numbers([l for l in out.splitlines() if l.startswith("POISSON_X")][0])
+    assert abs(nrm[0] - o.anorm) <= 1e-10 * o.anorm and abs(nrm[1] - o.rnorm) <= 1e-10 * o.rnorm
+    n = prob.n
+    want = np.array([o.x[0], o.x[n // 3 - 1], o.x[n // 2 - 1], o.x[-1]])
+    assert np.max(np.abs(xs - want)) <= 1e-10 * np.linalg.norm(o.x, np.inf)
+    import torch
+    too_many = torch.cuda.device_count() + 1
+    p = subprocess.run([path, str(too_many)], capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and "SHARDED TESTS PASSED" not in p.stdout
+    assert "no usable MI355X" in (p.stdout + p.stderr) and f"ngpu = {too_many}" in (p.stdout + p.stderr)
+
+
 REF_MESSAGES = {   # the reference's `error stop` strings, src/lsqr.f90:109-111, 152, 197
     "sizes": "invalid a,icol,irow sizes in initialize_ez",
     "irow": "invalid irow or m in initialize_ez",

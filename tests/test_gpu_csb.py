@@ -20,7 +20,7 @@ CASES = build_cases()
 
 @pytest.fixture
 def csb_env():
-    keys = ("LSQRHIP_CSB", "LSQRHIP_CSB_R")
+    keys = ("LSQRHIP_CSB", "LSQRHIP_CSB_R", "LSQRHIP_CSB_LO32")
     old = {k: os.environ.get(k) for k in keys}
     os.environ["LSQRHIP_CSB"] = "1"
 
@@ -84,12 +84,16 @@ def test_products_and_solve_match_oracle(csb_env, name, R):
         assert abs(r.rnorm - g.rnorm) <= 1e-10 * g.rnorm or g.rnorm <= 1e-13 * np.linalg.norm(p.b)
 
 
-def test_results_do_not_depend_on_the_blocking_bit_for_bit(csb_env):
+@pytest.mark.parametrize("kind", ["powerlaw rows of 2500 (8-byte low parts)", "rows of 9 (32-bit integer low parts)"])
+def test_results_do_not_depend_on_the_blocking_bit_for_bit(csb_env, kind):
     """Every product is split exactly onto two fixed binary grids and the sums on those grids are
     exact, so the order of the adds -- and with it the block size, the launch shape, which wave took
     which chunk -- cannot change a bit of y.  A solve inherits that up to its partial sums of y^2
     (one per block, reduced in block order): identical blockings repeat exactly."""
-    p = P.powerlaw_rows(5000, 3000, seed=7, dmin=3, dmax=2500, damp=1e-3)
+    if kind.startswith("powerlaw"):
+        p = P.powerlaw_rows(5000, 3000, seed=7, dmin=3, dmax=2500, damp=1e-3)
+    else:
+        p = P.random_rows(6000, 2500, 9, seed=7, damp=1e-3)      # A: 9 per row; A': ~22 per row
     xp, yp = vecs(p)
     ys, xs = [], []
     for R in (None, 64, 1000, 4097):
