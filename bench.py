@@ -260,7 +260,7 @@ def pmc_child(counter: str):
         reps = 10 if facts["nnz"] < 200_000_000 else 4
         s.bench_kernel(1, reps)
         manifest.append({"spec": spec, "env": env, "launches": 3 + reps,
-                         "kernels_per_product": 2 if ("panel" in describe_layout(s.info())[1]) else 1})
+                         "kernels_per_product": s.get_option("launches_mode1")})
         del s, d_b
     print("PMC_MANIFEST " + json.dumps(manifest), flush=True)
 

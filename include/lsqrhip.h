@@ -213,7 +213,11 @@ int lsqrhip_set_option(lsqrhip_handle_t h, const char *name, int64_t value);
  * src/lsqrblas.f90:123-159) are sqrt(sum (y 2^-e)^2) 2^e with e = norm_exp fixed per matrix
  * (2^e just above max|a_ij|: u and v live at the scale of the matrix), so that no norm over- or
  * underflows whatever the scale of A and b.  The ranks of a row-sharded solve must agree on one e
- * (set the maximum of their values on every rank before lsqrhip_shard_begin). */
+ * (set the maximum of their values on every rank before lsqrhip_shard_begin).
+ * "log_truncated": 1 when the last solve had more printable iterations than the log buffer holds
+ * (itnlim / 10 + 64 records for n > 40): the earliest overflowing records were dropped, the record of
+ * the stopping iteration is always kept (last slot).  "launches_mode1" / "launches_mode2": kernel
+ * launches one product takes in the layout in use (for reading profiler output). */
 int lsqrhip_get_option(lsqrhip_handle_t h, const char *name, int64_t *value);
 /* Run all work of this handle on an externally owned hipStream_t (e.g. the
  * caller's torch stream); NULL restores the handle's own stream. */

@@ -1501,7 +1501,13 @@ extern "C" int lsqrhip_get_option(lsqrhip_handle_t h, const char *name, int64_t 
     else if (k == "op_batch") *value = h->op_batch;
     else if (k == "pipeline") *value = h->pipeline;
     else if (k == "norm_exp") *value = h->norm_exp;
-    else return fail(LSQRHIP_ERR_ARG, "unknown option: " + k);
+    else if (k == "log_truncated") *value = h->h_state ? h->h_state->log_truncated : 0;  // of the last solve
+    else if (k == "launches_mode1" || k == "launches_mode2") {  // kernel launches one product takes (profiling)
+        const Csr &c = k == "launches_mode1" ? h->A : h->AT;
+        static const int rounds = env_int("LSQRHIP_CSB_ROUNDS", 1);
+        if (c.csb) *value = rounds ? std::max(1, (c.nrb + c.grid - 1) / std::max(c.grid, 1)) : 1;
+        else *value = c.P > 1 ? 2 : 1;
+    } else return fail(LSQRHIP_ERR_ARG, "unknown option: " + k);
     return LSQRHIP_OK;
 }
 

@@ -311,9 +311,21 @@ __device__ __forceinline__ void s3_step(LsqrState *st, double sum, const double 
     const bool show = (st->n <= 40) || (itn <= 10) || (itn >= st->itnlim - 10) || (itn % 10 == 0) ||
                       (test3 <= 2.0 * st->ctol) || (test2 <= 10.0 * st->atol) || (test1 <= 10.0 * rtol) ||
                       (istop != 0);
-    if (st->want_log && show && st->log_count < st->log_cap) {
-        double *r = log + (size_t)st->log_count * LOG_STRIDE;
-        st->log_count = st->log_count + 1;
+    // A run that sits inside the "near convergence" bands for long can print more lines than the buffer
+    // holds: the last slot is kept for the record of the stopping iteration (the line every reader looks
+    // for), whatever had to be dropped is flagged (option "log_truncated").
+    int slot = -1;
+    if (st->want_log && show) {
+        if (st->log_count < st->log_cap - 1 || (istop != 0 && st->log_count < st->log_cap)) {
+            slot = st->log_count;
+            st->log_count = st->log_count + 1;
+        } else {
+            st->log_truncated = 1;
+            if (istop != 0 && st->log_cap > 0) slot = st->log_cap - 1;
+        }
+    }
+    if (slot >= 0) {
+        double *r = log + (size_t)slot * LOG_STRIDE;
         r[0] = (double)itn; r[1] = x[0]; r[2] = rnorm; r[3] = test1; r[4] = test2; r[5] = anorm;
         r[6] = acond; r[7] = phi; r[8] = dknorm; r[9] = dxk; r[10] = alfopt; r[11] = (double)istop;
         r[12] = rtol; r[13] = xnorm;

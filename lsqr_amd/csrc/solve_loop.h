@@ -422,10 +422,13 @@ static int ensure_graph(H *h, int G)
 static int prepare_log(H *h, int itnlim, int want_log)
 {
     if (want_log) {
-        // printable iterations: the first/last 10, every 10th, near convergence -- or all of
-        // them when n <= 40 (src/lsqr.f90:815-822); bounded at 2^20 records (112 MB)
-        const int64_t want = (h->n <= 40) ? (int64_t)itnlim : (int64_t)itnlim / 10 + 64;
-        const int cap = (int)std::min<int64_t>(std::max<int64_t>(want, 64), 1 << 20);
+        // Printable iterations (src/lsqr.f90:815-822): the first / last 10, every 10th, all of them when
+        // n <= 40 -- and EVERY iteration inside the "near convergence" bands (test1 <= 10 rtol, test2 <= 10 atol,
+        // test3 <= 2 ctol), which a slowly converging run can sit in for hundreds of iterations (48 x 37
+        // Poisson, atol = btol = 1e-4: 272 lines of 402 iterations).  So: room for every iteration, bounded
+        // at 2^20 records (112 MB); beyond that s3_step keeps the last slot for the stopping iteration and
+        // raises `log_truncated`.
+        const int cap = (int)std::min<int64_t>(std::max<int64_t>((int64_t)itnlim + 1, 64), 1 << 20);
         if (cap > h->log_cap) {
             if (h->d_log) (void)hipFree(h->d_log);
             h->d_log = nullptr;

@@ -42,6 +42,7 @@ struct LsqrState {
     int want_log;
     int log_cap;    // records the log buffer can hold
     int log_count;  // records written so far (only iterations the reference would print)
+    int log_truncated;  // records had to be dropped (the buffer keeps its last slot for the final iteration)
     int m, n;
     // user tolerances ------------------------------------------------------
     double damp, atol, btol, ctol;

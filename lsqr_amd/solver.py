@@ -184,6 +184,12 @@ class lsqr_solver_ez:  # noqa: N801  (name kept from the reference)
         self._need()
         check(lib().lsqrhip_set_option(self._h, name.encode(), int(value)))
 
+    def get_option(self, name: str) -> int:
+        self._need()
+        v = C.c_int64()
+        check(lib().lsqrhip_get_option(self._h, name.encode(), C.byref(v)))
+        return int(v.value)
+
     def bench_kernel(self, which: int, reps: int) -> float:
         """Average ms of `reps` back-to-back launches of hot kernel 1 (mode-1 SpMV), 2 (mode-2 SpMV)
         or 3 (x/w update), one HIP event pair around the whole run."""

@@ -23,11 +23,40 @@
 
 #include "lsqr_oracle.h"
 
+/* Order of the dot product inside hprod.  0 = the reference's (ascending, sequential): everything
+ * pinned against the reference uses it.  1 = descending, 2 = pairwise tree, 3 = eight interleaved
+ * partial sums: legal re-orderings of the same sum, used ONLY to measure how far the iteration counts of
+ * the 18-problem suite move under rounding (tests/golden/gen_lstp_band.py) -- the band a GPU run with
+ * tree sums is then held to. */
+static int g_sum_order = 0;
+void oracle_lstp_set_sum_order(int order) { g_sum_order = order; }
+
+static double pairwise_dot(const double *a, const double *b, int n)
+{
+    if (n <= 8) {
+        double s = 0.0;
+        for (int i = 0; i < n; ++i) s = a[i] * b[i] + s;
+        return s;
+    }
+    const int h = n / 2;
+    return pairwise_dot(a, b, h) + pairwise_dot(a + h, b + h, n - h);
+}
+
 /* y = (I - 2 hz hz') x                              test/lsqrtest_module.f90:385-403 */
 void oracle_hprod(int n, const double *hz, const double *x, double *y)
 {
     double s = 0.0;
-    for (int i = 0; i < n; ++i) s = hz[i] * x[i] + s;
+    if (g_sum_order == 1) {
+        for (int i = n - 1; i >= 0; --i) s = hz[i] * x[i] + s;
+    } else if (g_sum_order == 2) {
+        s = pairwise_dot(hz, x, n);
+    } else if (g_sum_order == 3) {
+        double p[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < n; ++i) p[i & 7] = hz[i] * x[i] + p[i & 7];
+        s = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+    } else {
+        for (int i = 0; i < n; ++i) s = hz[i] * x[i] + s;
+    }
     s = s + s;
     for (int i = 0; i < n; ++i) y[i] = x[i] - s * hz[i];
 }

@@ -124,7 +124,8 @@ def main():
                                    for k, v in bl.items()) + "\n}\n")
 
     # ---- iteration-log golden (nout /= 0; src/lsqr.f90:589-595, 655-671, 813-837, 872-880) ----
-    for name in ("t1_readme_default", "random_over_damped"):
+    from cases import TRUNCATED_TWINS
+    for name in ["t1_readme_default", "random_over_damped"] + TRUNCATED_TWINS:
         p, o = build_cases()[name]
         with tempfile.TemporaryDirectory() as td:
             lp = os.path.join(td, "log.txt")

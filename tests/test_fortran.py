@@ -188,7 +188,13 @@ def test_fortran_device_operator_and_user_subclass_on_gpu():
     assert "inform= 0" in line["ACHECK"]
     istop, itn = (int(t) for t in re.findall(r"=\s*(\d+)", line["LSQR istop"]))
     assert istop == o["istop"] == 3
-    assert 0.75 * o["itn"] - 3 <= itn <= 1.05 * o["itn"] + 3      # see tests/test_gpu_operator.py
+    # the measured spread of this problem's iteration count under legal summation orders
+    # (tests/golden/lstp_itn_band.json, see tests/test_gpu_operator.py)
+    import json
+    band = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lstp_itn_band.json")))
+    itns = list(next(b for b in band if (b["m"], b["n"], b["npower"]) == (2000, 1000, 3))["itn"].values())
+    width = max(3, max(itns) - min(itns))
+    assert itns[0] == o["itn"] and min(itns) - width <= itn <= max(itns) + width
     assert int(re.search(r"inform,tests=\s*(\d+)", line["XCHECK"]).group(1)) == o["xcheck_inform"]
     enorm = numbers(line["ENORM"])[0]
     assert enorm <= 50 * o["enorm"] + 1e-13

@@ -107,6 +107,36 @@ def test_scale_properties_beyond_2_to_31_nonzeros_with_lds_panels():
     assert np.array_equal(d_x.to_array(np.float64, dp.n), x)
 
 
+def test_scale_properties_of_baseline_config3_at_its_literal_size():
+    """BASELINE configs[2] LITERALLY: 4M x 1M with 0.1 % nonzeros = 1000 per row = 4.0e9 nonzeros (just
+    under the 2^32 this build's sort can index; 64-bit row pointers; LDS column panels chosen
+    automatically).  Needs ~210 GB of HBM while it builds.  Size-independent checks: acheck's adjoint
+    identity, a short solve that converges on atol (damped least squares), repeats itself bit for bit and
+    passes the reference's xcheck."""
+    import torch
+    from lsqr_amd.capi import DeviceBuffer
+    free, total = torch.cuda.mem_get_info()
+    if free < 230e9:
+        pytest.skip("needs ~210 GB of free HBM")
+    dp = devgen.generate("random:4000000:1000000:1000", atol=1e-8, btol=1e-8, itnlim=40)
+    s = dp.solver
+    info = s.info()
+    assert dp.nnz == 4_000_000_000 and info["rowptr_bytes"] == 8
+    assert info["xlds"] == 2 and info["xlds_t"] == 2
+    inform, err = s.acheck()
+    assert inform == 0 and err < 1e-12
+    d_x = DeviceBuffer(8 * dp.n)
+    r = s.solve_device(dp.d_b.ptr.value, d_x.ptr.value, 1e-3)
+    x = d_x.to_array(np.float64, dp.n)
+    b = dp.d_b.to_array(np.float64, dp.m)
+    assert r.istop == 3 and 3 < r.itn < 40
+    inform, tests, u, v, w = s.xcheck(r.anorm, 1e-3, b, x)
+    assert inform in (1, 2, 3) and tests[2] < 1e-6
+    r2 = s.solve_device(dp.d_b.ptr.value, d_x.ptr.value, 1e-3)
+    assert (r2.itn, r2.anorm, r2.rnorm) == (r.itn, r.anorm, r.rnorm)
+    assert np.array_equal(d_x.to_array(np.float64, dp.n), x)
+
+
 @pytest.mark.parametrize("spec,expect", [
     ("random:10000000:10000000:100", dict(nnz=1_000_000_000, panels=39)),      # BASELINE configs[3]: what --gpus N shards
     ("powerlaw:5000000:2000000:10000", dict(panels=8)),                        # BASELINE configs[4]: skewed rows

@@ -5,6 +5,8 @@ The checker is oracle/lstp_oracle.c, itself pinned digit for digit against the c
 reference's 18-problem log (tests/test_lstp_oracle.py)."""
 import ctypes as C
 import io
+import json
+import os
 
 import numpy as np
 import pytest
@@ -76,6 +78,7 @@ def test_the_18_problem_suite_on_the_gpu_matches_the_oracle_and_its_log_parses()
     parsed = oracle.parse_lis(buf.getvalue())
     assert len(res) == len(parsed) == 18
     po = oracle.port()
+    band = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lstp_itn_band.json")))
     for k, ((m, n, nd, p, damp), r, q) in enumerate(zip(SUITE, res, parsed)):
         o = po.lstp_test(m, n, nd, p, damp)
         assert r["istop"] == o["istop"] == 3, k
@@ -83,10 +86,18 @@ def test_the_18_problem_suite_on_the_gpu_matches_the_oracle_and_its_log_parses()
         assert r["xcheck_inform"] == o["xcheck_inform"], k
         assert r["success"] == (o["enorm"] <= 1e-3) == (k not in (4, 5)), k
         # 25 singular values repeated 40 times: exact arithmetic would finish in 25 iterations and
-        # rounding decides how many more it takes.  The device's tree sums are the more accurate
-        # ones and need 3-20 % FEWER iterations than the sequential sums (measured: 66/71 ...
-        # 638/740); never noticeably more.
-        assert 0.75 * o["itn"] - 3 <= r["itn"] <= 1.05 * o["itn"] + 3, (k, r["itn"], o["itn"])
+        # rounding decides how many more it takes.  tests/golden/lstp_itn_band.json holds the counts of the
+        # pinned CPU restatement under six legal evaluation orders of its sums (gen_lstp_band.py): they
+        # spread by up to 30 % (325 ... 424), and with pairwise dot products AND pairwise norms -- what a
+        # GPU does -- they land within a few iterations of the device's (65/66 vs 66, 140 vs 139, 209/208 vs
+        # 208): the device must fall inside that measured spread, widened by its own width.
+        itns = list(band[k]["itn"].values())
+        assert (band[k]["m"], band[k]["n"], band[k]["npower"]) == (m, n, p) and itns[0] == o["itn"]
+        width = max(3, max(itns) - min(itns))
+        assert min(itns) - width <= r["itn"] <= max(itns) + width, (k, r["itn"], itns)
+        # ... and close to the two variants that sum like a GPU (pairwise dots and norms)
+        like_gpu = itns[4:6]
+        assert min(like_gpu) * 0.88 - 3 <= r["itn"] <= max(like_gpu) * 1.12 + 3, (k, r["itn"], like_gpu)
         assert r["anorm"] == pytest.approx(o["anorm"], rel=0.15)     # an estimate that grows with itn
         bound = (r["enorm"] + o["enorm"]) * (1.0 + np.linalg.norm(o["xtrue"]))
         assert np.linalg.norm(r["x"] - o["x"]) <= 2 * bound + 1e-12, k

@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 
 import oracle
-from cases import build_cases
+from cases import TRUNCATED_TWINS, build_cases
 from golden.gen_golden import blas_vectors
 from lsqr_amd import capi, problems as P
 from lsqr_amd.capi import LsqrHipError
@@ -331,6 +331,69 @@ def test_iteration_log_text_matches_reference(name, tmp_path):
         assert same >= len(want) - 2
     # structure (headers, exit block, which iterations are printed) is identical
     assert [l[:6] for l in got] == [l[:6] for l in want]
+
+
+@pytest.mark.parametrize("name", TRUNCATED_TWINS)
+def test_truncated_twins_hold_the_strict_tolerance(name, tmp_path):
+    """The four long runs whose tolerance above is widened by the reference's own drift (illcond_conlim,
+    powerlaw_small, poisson_48x37_tol, empty_rows_cols), stopped where that drift is still < 1e-11: strict
+    1e-10 on x, anorm, rnorm with identical istop and itn, through all three launch schedules -- and every
+    printed line of the iteration log (x(1), rnorm to their 10 digits; test1, test2, anorm, acond to their
+    3; phi, dknorm, dxk, alfa_opt to their 2) against the reference's own log of the same run."""
+    import re
+    p, o = CASES[name]
+    g = SOLVE[name]
+    sens = g["sens"]
+    assert max(sens["x"], sens["anorm"], sens["rnorm"]) < 1e-11 and sens["itn"] == [g["itn"]]
+    gx = fhv(g["x"])
+    path = str(tmp_path / "log.txt")
+    for pipeline in (2, 1, 0):
+        s = lsqr_solver_ez().initialize(p.m, p.n, p.a, p.irow, p.icol, atol=o["atol"], btol=o["btol"],
+                                        conlim=o["conlim"], itnlim=o["itnlim"], nout=path if pipeline == 2 else None)
+        s.set_option("pipeline", pipeline)
+        r = s.solve(p.b, o["damp"])
+        assert (r.istop, r.itn) == (g["istop"], g["itn"])
+        assert np.linalg.norm(r.x - gx) <= TOL * np.linalg.norm(gx)
+        assert rel(r.anorm, fh(g["anorm"])) <= TOL and rel(r.rnorm, fh(g["rnorm"])) <= TOL
+        assert rel(r.xnorm, fh(g["xnorm"])) <= TOL and rel(r.acond, fh(g["acond"])) <= 1e-9
+    got = open(path).read().splitlines()
+    want = open(os.path.join(GOLD, f"log_{name}.txt")).read().splitlines()
+    assert len(got) == len(want)
+    num = re.compile(r"[-+]?\d\.\d+E[-+]\d+")
+    nrec = 0
+    for a, b in zip(got, want):
+        if not re.match(r"^\s+\d+\s+[-+]?\d\.\d{9}E", b):          # not an iteration record: text must be equal
+            if a != b:                                                 # (exit block: 5-digit scalars may round apart)
+                va, vb = [float(t) for t in num.findall(a)], [float(t) for t in num.findall(b)]
+                assert num.sub("#", a) == num.sub("#", b) and np.allclose(va, vb, rtol=2e-5, atol=0)
+            continue
+        nrec += 1
+        assert a[:6] == b[:6]                                          # the same iteration is printed
+        va, vb = [float(t) for t in num.findall(a)], [float(t) for t in num.findall(b)]
+        assert len(va) == len(vb)
+        digits = [10, 10, 3, 3, 3, 3, 2, 2, 2, 2]
+        for k, (x1, x2) in enumerate(zip(va, vb)):
+            tol = 1.01 * 10.0 ** (1 - digits[k])                       # one unit of the last printed digit
+            assert abs(x1 - x2) <= tol * max(abs(x2), 1e-300), (a, b, k)
+    assert nrec >= min(g["itn"], 10)
+
+
+def test_log_holds_every_line_of_a_run_that_lingers_near_convergence(tmp_path):
+    """The reference prints EVERY iteration whose tests are within a factor 10 of their tolerances
+    (src/lsqr.f90:815-822): 272 lines for the 402 iterations of this run.  The device keeps its records
+    in a buffer sized from itnlim: none may be dropped, and the stopping iteration is the last line."""
+    p = P.poisson2d(48, 37)
+    path = str(tmp_path / "log.txt")
+    s = lsqr_solver_ez().initialize(p.m, p.n, p.a, p.irow, p.icol, atol=1e-4, btol=1e-4, itnlim=1300, nout=path)
+    r = s.solve(p.b, 0.0)
+    o = oracle.port().solve(p.m, p.n, p.irow, p.icol, p.a, p.b, atol=1e-4, btol=1e-4, itnlim=1300)
+    assert (r.istop, r.itn) == (o.istop, o.itn) == (1, 402)
+    rec = s.log_records()
+    assert s.get_option("log_truncated") == 0
+    assert len(rec) == 272 and int(rec[-1][0]) == r.itn and int(rec[-1][11]) == 1
+    assert list(rec[:10, 0]) == list(range(1, 11))
+    lines = [l for l in open(path).read().splitlines() if l[:6].strip().isdigit()]
+    assert len(lines) == 273                                     # + the line of iteration 0
 
 
 def test_full_size_config2_poisson_vs_oracle():
