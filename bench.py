@@ -67,6 +67,9 @@ def parse():
                     help="skip the N = 1 point of the multi-GPU series (configs[3] whole on this GPU)")
     ap.add_argument("--traffic", choices=["live", "off"], default="live",
                     help="live: HBM bytes per launch from rocprofv3 PMC passes run as child processes")
+    ap.add_argument("--roofline-only", action="store_true",
+                    help="build the workload and time ONLY its mode-1 product (what a `rocprofv3 --kernel-trace "
+                         "--stats` of this command then averages: profiles/r02/*_roofline.txt)")
     ap.add_argument("--pmc-child", default=None, help=argparse.SUPPRESS)
     a = ap.parse_args()
     multi = a.gpus > 1 or int(os.environ.get("WORLD_SIZE", "1")) > 1
@@ -174,9 +177,12 @@ def product_roofline(s, facts, reps, traffic=None):
     frac = ach / HBM_PEAK_GBS
     assert frac <= 1.0, ("a roofline fraction above 1 is not a fraction", frac)
     wset = info["csr_bytes"] + info["csrt_bytes"] + 8 * (m + 4 * n)
+    lpp = s.get_option("launches_mode1")
     roof = {"bound": "hbm", "kernel": f"{kname} (aprod mode 1)", "achieved": ach, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": frac, "traffic": None, "bytes_per_launch": lay1,
             "avg_launch_us": avg1 * 1e3, "launches": reps,
+            "kernel_launches_per_product": lpp,      # > 1: a product is that many launches of the kernel (csb.h: one
+            "avg_kernel_launch_us": avg1 * 1e3 / lpp,  # per round of row blocks); rocprofv3's per-kernel average is this
             "bytes_are": "the layout in use: matrix as stored + x once + y read and written (physical)",
             "effective_gbps": alg1 / (avg1 * 1e-3) / 1e9, "effective_bytes_per_launch": alg1,
             "effective_is": "SURVEY 8d algorithmic bytes (8-byte values, 4-byte columns, row pointers) / the same time; "
@@ -219,6 +225,25 @@ def timed_solve(s, d_b, d_x, damp, K):
     dt = time.perf_counter() - t0
     assert done == K and (restarts > 0 or r.istop == 5), (done, r.itn, r.istop)
     return dt, r, restarts, loop_ms
+
+
+def roofline_only(args):
+    """Only the dominant kernel: 3 warm + `reps` back-to-back launches of the mode-1 product.  Under
+    `rocprofv3 --kernel-trace --stats` the kernel's average duration x kernel_launches_per_product is
+    roofline.avg_launch_us of the same line."""
+    spec = HEADLINE if args.workload == "auto" else args.workload
+    s, d_b, facts, _ = build_workload(spec, None)
+    info = s.info()
+    reps = 200 if facts["nnz"] < 50_000_000 else (50 if facts["nnz"] < 200_000_000 else 10)
+    avg1 = s.bench_kernel(1, reps)
+    lay1 = info["csr_bytes"] + 8 * facts["n"] + 16 * facts["m"]
+    lpp = s.get_option("launches_mode1")
+    ach = lay1 / (avg1 * 1e-3) / 1e9
+    print(json.dumps({"workload": spec, "env": {k: v for k, v in os.environ.items() if k.startswith("LSQRHIP_")},
+                      "roofline": {"kernel": describe_layout(info)[1] + " (aprod mode 1)", "bytes_per_launch": lay1,
+                                   "avg_launch_us": avg1 * 1e3, "kernel_launches_per_product": lpp,
+                                   "avg_kernel_launch_us": avg1 * 1e3 / lpp, "launches": reps, "achieved": ach,
+                                   "frac": ach / HBM_PEAK_GBS, "peak": HBM_PEAK_GBS, "unit": "GB/s"}}), flush=True)
 
 
 def side_workload(spec, env, note, K, traffic):
@@ -416,6 +441,8 @@ def main():
     args = parse()
     if args.pmc_child:
         return pmc_child(args.pmc_child)
+    if args.roofline_only:
+        return roofline_only(args)
     world = int(os.environ.get("WORLD_SIZE", "0"))
     if args.gpus > 1 and world == 0:
         return spawn_ranks(args)

@@ -71,6 +71,9 @@ struct CsbMat {
     int ea;  // 2^ea > max|a_ij|
     int H;   // 2^(H-1) >= nonzeros of the longest row, H >= 3
     int b0, b1;  // the row blocks of THIS launch: [b0, b1)
+    int S;       // column splits: S workgroups share a row block, each sweeping 1/S of its chunks (see below)
+    double *zhi, *zlo;  // S > 1: the splits' exact partial sums, [S][rows] each
+    double *q1out;      // S > 1: this launch's q1 for k_csb_combine
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -289,8 +292,18 @@ __global__ __launch_bounds__(CSB_BLOCK, 1) void k_spmv_csb(
     }
     __syncthreads();
 
-    for (int b = A.b0 + wg; b < A.b1; b += nwg) {
-        const long long c0 = A.cptr[b], c1 = A.cptr[b + 1];
+    if (A.S > 1 && wg == 0 && tid == 0) *A.q1out = q1;
+    // Column splits (few rows: fewer row blocks than CUs).  S workgroups share a block, each sweeping a
+    // contiguous S-th of its column-sorted chunks into accumulators of its own; their hi / lo sums go to
+    // zhi / zlo and k_csb_combine adds them -- sums on the grids are exact, so the result is bit for bit
+    // what ONE workgroup would have produced.  A block of R rows then still holds R d / n nonzeros per
+    // column although 256 / S blocks cover the matrix: R can stay large (one rank's block of config 4 at
+    // N = 8: 9766 instead of 4883 rows per block).
+    const int nunits = (A.b1 - A.b0) * A.S;
+    for (int u = wg; u < nunits; u += nwg) {
+        const int b = A.b0 + u / A.S, sp = u % A.S;
+        const long long cb0 = A.cptr[b], cb1 = A.cptr[b + 1];
+        const long long c0 = cb0 + ((cb1 - cb0) * sp) / A.S, c1 = cb0 + ((cb1 - cb0) * (sp + 1)) / A.S;
         // software pipeline: the (value, index) stream of the wave's NEXT chunk is in flight while the
         // gathers and the LDS adds of this one run (two register sets, loads unconditional: clamped)
         double av[CSB_U], bv[CSB_U];
@@ -344,6 +357,23 @@ __global__ __launch_bounds__(CSB_BLOCK, 1) void k_spmv_csb(
         const int row0 = b * A.R;
         const int nr = A.rows - row0 < A.R ? A.rows - row0 : A.R;
         double sq = 0.0;
+        if (A.S > 1) {  // a split: the exact sums as they are (integer steps of q1 as doubles when LO32)
+            double *zh = A.zhi + (size_t)sp * A.rows + row0, *zl = A.zlo + (size_t)sp * A.rows + row0;
+            for (int r = tid; r < nr; r += CSB_BLOCK) {
+                zh[r] = acc_hi[r];
+                zl[r] = LO32 ? (double)acc_li[r] : acc_lo[r];
+                acc_hi[r] = 0.0;
+                if (LO32) acc_li[r] = 0;
+                else acc_lo[r] = 0.0;
+            }
+            if (tid == 0) {
+                acc_hi[A.R] = 0.0;
+                if (LO32) acc_li[A.R] = 0;
+                else acc_lo[A.R] = 0.0;
+            }
+            __syncthreads();
+            continue;
+        }
         for (int r = tid; r < nr; r += CSB_BLOCK) {
             const double hi = acc_hi[r];
             const double lo = LO32 ? (double)acc_li[r] * q1 : acc_lo[r];
@@ -359,6 +389,73 @@ __global__ __launch_bounds__(CSB_BLOCK, 1) void k_spmv_csb(
             acc_hi[A.R] = 0.0;
             if (LO32) acc_li[A.R] = 0;
             else acc_lo[A.R] = 0.0;
+        }
+        sq = wave_sum(sq);
+        if (lane == 0) red[w] = sq;
+        __syncthreads();
+        if (tid == 0) {
+            double t = 0.0;
+#pragma unroll
+            for (int i = 0; i < CSB_WAVES; ++i) t += red[i];
+            partials[b] = t;
+        }
+        __syncthreads();
+    }
+}
+
+// The second launch of a column-split product: y and the blocks' partials of sum (y ns)^2 from the
+// splits' exact sums.  One workgroup per row block with the thread -> row mapping and the reduction of
+// k_spmv_csb's own epilogue, so y AND the partials are bit for bit those of the unsplit kernel.
+template <bool LO32>
+__global__ __launch_bounds__(CSB_BLOCK) void k_csb_combine(
+    CsbMat A, double *__restrict__ y, const SpmvCoef *__restrict__ coef, const int *__restrict__ stop,
+    double *__restrict__ partials, const double *__restrict__ pin, int npin, const NormSlot *__restrict__ slot_in,
+    int skip_if_zero, NScale nsc)
+{
+    __shared__ double red[CSB_WAVES + 2];
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1);
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (*stop != 0) return;
+    double sy, cy;
+    if (pin != nullptr) {
+        double s = 0.0;
+        if (tid < SC_BLOCK && npin > 0) s = strided_sum<SC_BLOCK>(pin, npin);
+        s = wave_sum(s);
+        if (tid < SC_BLOCK && lane == 0) red[w] = s;
+        __syncthreads();
+        if (tid == 0) {
+            double r = 0.0;
+#pragma unroll
+            for (int i = 0; i < SC_BLOCK / WAVE; ++i) r += red[i];
+            red[CSB_WAVES] = r;
+        }
+        __syncthreads();
+        const double nrm = sqrt(red[CSB_WAVES]) * nsc.inv;
+        __syncthreads();
+        if (skip_if_zero && !(nrm > 0.0)) return;
+        cy = -nrm;
+        sy = slot_in->scale;
+    } else {
+        if (coef->skip != 0) return;
+        sy = coef->sy;
+        cy = coef->cy;
+    }
+    const double q1 = *A.q1out;
+    for (int b = blockIdx.x; b < A.nrb; b += gridDim.x) {
+        const int row0 = b * A.R;
+        const int nr = A.rows - row0 < A.R ? A.rows - row0 : A.R;
+        double sq = 0.0;
+        for (int r = tid; r < nr; r += CSB_BLOCK) {
+            double hi = A.zhi[row0 + r], lo = A.zlo[row0 + r];
+            for (int sp = 1; sp < A.S; ++sp) {
+                hi = hi + A.zhi[(size_t)sp * A.rows + row0 + r];
+                lo = lo + A.zlo[(size_t)sp * A.rows + row0 + r];
+            }
+            if (LO32) lo = lo * q1;
+            const double yn = cy * (y[row0 + r] * sy) + (hi + lo);
+            y[row0 + r] = yn;
+            const double ys = yn * nsc.s;
+            sq += ys * ys;
         }
         sq = wave_sum(sq);
         if (lane == 0) red[w] = sq;

@@ -164,6 +164,8 @@ struct Csr {
     int64_t nchunks = 0;
     int nrb = 0, R = 0, H = 3;
     int lo32 = 0;                 // low parts of the row sums as 32-bit integers (csb.h)
+    int S = 1;                    // column splits per row block (csb.h): S workgroups share a block
+    double *zsplit = nullptr;     // S > 1: [2][S][rows] exact partial sums of the splits
 };
 
 // One rank's view of a row-sharded solve (shard_api.h): its place in the world, the caller-owned
@@ -302,6 +304,7 @@ static void free_csr(Csr &c)
     if (c.cidx) (void)hipFree(c.cidx);
     if (c.ccb) (void)hipFree(c.ccb);
     if (c.cptr) (void)hipFree(c.cptr);
+    if (c.zsplit) (void)hipFree(c.zsplit);
     c = Csr();
 }
 
@@ -737,11 +740,25 @@ static int build_csb(hipStream_t s, const int *rowk, const int *colk, const doub
     // (csb.h "accumulators"); LSQRHIP_CSB_LO32=0 keeps 8-byte low parts
     const bool lo32 = H <= CSB_LO32_MAXH && env_int("LSQRHIP_CSB_LO32", 1) != 0;
     const int rmax = lo32 ? CSB_RMAX32 : CSB_RMAX;
+    // Fewer rows than 256 full blocks: S workgroups share a block (column splits, csb.h) so that blocks
+    // stay tall -- what counts is R d / n, the nonzeros a block holds per column of x.
+    //   LSQRHIP_CSB_S  splits per block (test hook; default: as many as keep R <= rmax, at most 8)
+    int S = env_int("LSQRHIP_CSB_S", 0);
+    if (S <= 0) {
+        S = (int)std::min<int64_t>(8, std::max<int64_t>(1, (int64_t)rmax * CSB_GRID / std::max(rows, 1)));
+        if ((int64_t)rows * S < (int64_t)CSB_GRID * 512) S = 1;   // small systems: not worth a second launch
+    }
+    S = std::min(S, 8);
     int R = env_int("LSQRHIP_CSB_R", 0);
     if (R <= 0) {
-        const int64_t k = ((int64_t)rows + (int64_t)CSB_GRID * rmax - 1) / ((int64_t)CSB_GRID * rmax);
-        R = (int)(((int64_t)rows + CSB_GRID * k - 1) / (CSB_GRID * k));
-        R = std::max(R, std::min(rows, 512));  // small systems: a few whole blocks rather than 256 slivers
+        if (S > 1) {
+            const int nb = std::max(1, CSB_GRID / S);       // S * nb <= 256 units: one per CU, no second pass
+            R = (int)(((int64_t)rows + nb - 1) / nb);
+        } else {
+            const int64_t k = ((int64_t)rows + (int64_t)CSB_GRID * rmax - 1) / ((int64_t)CSB_GRID * rmax);
+            R = (int)(((int64_t)rows + CSB_GRID * k - 1) / (CSB_GRID * k));
+            R = std::max(R, std::min(rows, 512));  // small systems: a few whole blocks rather than 256 slivers
+        }
     }
     R = std::min(std::max(R, 1), rmax);
     const int nrb = (rows + R - 1) / R;
@@ -795,7 +812,9 @@ static int build_csb(hipStream_t s, const int *rowk, const int *colk, const doub
     out.R = R;
     out.H = H;
     out.lo32 = lo32 ? 1 : 0;
-    out.grid = std::max(1, std::min(nrb, CSB_GRID));
+    out.S = S;
+    if (S > 1) HIPCHK(hipMalloc((void **)&out.zsplit, sizeof(double) * 2 * (size_t)S * (size_t)rows));
+    out.grid = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)nrb * S, CSB_GRID));  // workgroups per launch
     out.out_grid = nrb;
     out.nblk = nrb;
     out.bytes = (int64_t)nchunks * CSB_CHUNK * 12 + (int64_t)nchunks * 4 + (int64_t)(nrb + 1) * 8;
@@ -1505,7 +1524,10 @@ extern "C" int lsqrhip_get_option(lsqrhip_handle_t h, const char *name, int64_t 
     else if (k == "launches_mode1" || k == "launches_mode2") {  // kernel launches one product takes (profiling)
         const Csr &c = k == "launches_mode1" ? h->A : h->AT;
         static const int rounds = env_int("LSQRHIP_CSB_ROUNDS", 1);
-        if (c.csb) *value = rounds ? std::max(1, (c.nrb + c.grid - 1) / std::max(c.grid, 1)) : 1;
+        if (c.csb) {
+            const int step = std::max(1, c.grid / std::max(c.S, 1));
+            *value = (rounds ? std::max(1, (c.nrb + step - 1) / step) : 1) + (c.S > 1 ? 1 : 0);
+        }
         else *value = c.P > 1 ? 2 : 1;
     } else return fail(LSQRHIP_ERR_ARG, "unknown option: " + k);
     return LSQRHIP_OK;

@@ -20,7 +20,7 @@ CASES = build_cases()
 
 @pytest.fixture
 def csb_env():
-    keys = ("LSQRHIP_CSB", "LSQRHIP_CSB_R", "LSQRHIP_CSB_LO32")
+    keys = ("LSQRHIP_CSB", "LSQRHIP_CSB_R", "LSQRHIP_CSB_LO32", "LSQRHIP_CSB_S")
     old = {k: os.environ.get(k) for k in keys}
     os.environ["LSQRHIP_CSB"] = "1"
 
@@ -87,8 +87,8 @@ def test_products_and_solve_match_oracle(csb_env, name, R):
 @pytest.mark.parametrize("kind", ["powerlaw rows of 2500 (8-byte low parts)", "rows of 9 (32-bit integer low parts)"])
 def test_results_do_not_depend_on_the_blocking_bit_for_bit(csb_env, kind):
     """Every product is split exactly onto two fixed binary grids and the sums on those grids are
-    exact, so the order of the adds -- and with it the block size, the launch shape, which wave took
-    which chunk -- cannot change a bit of y.  A solve inherits that up to its partial sums of y^2
+    exact, so the order of the adds -- and with it the block size, the column splits, the launch shape,
+    which wave took which chunk -- cannot change a bit of y.  A solve inherits that up to its partial sums of y^2
     (one per block, reduced in block order): identical blockings repeat exactly."""
     if kind.startswith("powerlaw"):
         p = P.powerlaw_rows(5000, 3000, seed=7, dmin=3, dmax=2500, damp=1e-3)
@@ -96,8 +96,12 @@ def test_results_do_not_depend_on_the_blocking_bit_for_bit(csb_env, kind):
         p = P.random_rows(6000, 2500, 9, seed=7, damp=1e-3)      # A: 9 per row; A': ~22 per row
     xp, yp = vecs(p)
     ys, xs = [], []
-    for R in (None, 64, 1000, 4097):
+    for R, S in ((None, None), (64, None), (1000, None), (4097, None), (1000, 2), (700, 3), (None, 5)):
         csb_env(R)
+        # column splits: S workgroups share a row block and their exact sums are added by a second kernel
+        os.environ.pop("LSQRHIP_CSB_S", None)
+        if S:
+            os.environ["LSQRHIP_CSB_S"] = str(S)
         s = lsqr_solver_ez().initialize(p.m, p.n, p.a, p.irow, p.icol, itnlim=15)
         x, y = xp.copy(), yp.copy()
         s.aprod(1, p.m, p.n, x, y)
@@ -116,6 +120,7 @@ def test_results_do_not_depend_on_the_blocking_bit_for_bit(csb_env, kind):
     for x in xs[1:]:
         assert np.array_equal(x, xs[0])
     # ... and scaling x by a power of two scales y exactly (the grids move with max|x|)
+    os.environ.pop("LSQRHIP_CSB_S", None)
     csb_env(None)
     s = lsqr_solver_ez().initialize(p.m, p.n, p.a, p.irow, p.icol)
     y0, y1 = np.zeros(p.m), np.zeros(p.m)
