@@ -35,8 +35,12 @@
 //     fixed-order reduction is independent of the launch shape) and clears the accumulators.
 //
 // Layout (built once by csb_build below from the COO triplets, stable LSD radix sorts of csr_build.h):
-//   block b = rows [b R, min((b+1) R, rows)); its nonzeros sorted by column (ties: COO order), padded
-//   to whole chunks of 256 (pad = value 0 aimed at a dummy accumulator);
+//   block b = rows [rstart[b], rstart[b+1]): at most R rows, cut so that every block holds about the
+//   same number of NONZEROS (equal sweeps: workgroups that start together must stay within ~1 % of
+//   each other's column for the x they gather to be in L2 -- with equal ROW counts a square random
+//   matrix's transpose, whose rows are Poisson(100) long, ran 16 % slower than the matrix itself);
+//   its nonzeros sorted by column (ties: COO order), padded to whole chunks of 256 (pad = value 0
+//   aimed at a dummy accumulator);
 //   cptr[b] = first chunk of block b; val[k], idx[k] = lrow << 18 | (col - cbase[k / 256]);
 //   cbase[c] = column of the first nonzero of chunk c.  A chunk spans < 2^18 columns or the build
 //   gives up (an almost empty block: such a matrix keeps the panel layout).
@@ -67,7 +71,8 @@ struct CsbMat {
     const unsigned *idx;
     const int *cbase;
     const long long *cptr;  // [nrb + 1], in chunks
-    int nrb, R, rows, cols;
+    const int *rstart;      // [nrb + 1] first row of each block (blocks are cut by NONZEROS, at most R rows each)
+    int nrb, R, rows, cols; // R = the dummy accumulator's index = rows per block at most
     int ea;  // 2^ea > max|a_ij|
     int H;   // 2^(H-1) >= nonzeros of the longest row, H >= 3
     int b0, b1;  // the row blocks of THIS launch: [b0, b1)
@@ -122,14 +127,21 @@ __global__ __launch_bounds__(256) void k_csb_maxint(const int *__restrict__ a, i
     if ((threadIdx.x & (WAVE - 1)) == 0 && m > 0) atomicMax(out, m);
 }
 
-// packed[i] = block(row of the i-th nonzero in column order) << 32 | i
+// packed[i] = block(row of the i-th nonzero in column order) << 32 | i;  block b = rows [rstart[b], rstart[b+1])
 __global__ __launch_bounds__(256) void k_csb_pack_rb(const int *__restrict__ rowk, const unsigned *__restrict__ pos1,
-                                                     int64_t nnz, int R, unsigned long long *__restrict__ packed)
+                                                     int64_t nnz, const int *__restrict__ rstart, int nrb,
+                                                     unsigned long long *__restrict__ packed)
 {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nnz; i += stride) {
-        const unsigned rb = (unsigned)(rowk[pos1[i]] - 1) / (unsigned)R;
-        packed[i] = ((unsigned long long)rb << 32) | (unsigned long long)(unsigned)i;
+        const int r = rowk[pos1[i]] - 1;
+        int lo = 0, hi = nrb - 1;  // last b with rstart[b] <= r
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (rstart[mid] <= r) lo = mid;
+            else hi = mid - 1;
+        }
+        packed[i] = ((unsigned long long)(unsigned)lo << 32) | (unsigned long long)(unsigned)i;
     }
 }
 
@@ -140,7 +152,8 @@ __global__ __launch_bounds__(CSB_CHUNK) void k_csb_fill(const unsigned long long
                                                         const int *__restrict__ rowk, const int *__restrict__ colk,
                                                         const double *__restrict__ a,
                                                         const long long *__restrict__ rbstart,
-                                                        const long long *__restrict__ cptr, int nrb, int R,
+                                                        const long long *__restrict__ cptr,
+                                                        const int *__restrict__ rstart, int nrb, int R,
                                                         double *__restrict__ val, unsigned *__restrict__ idx,
                                                         int *__restrict__ cbase, int *__restrict__ flags)
 {
@@ -166,7 +179,7 @@ __global__ __launch_bounds__(CSB_CHUNK) void k_csb_fill(const unsigned long long
         const unsigned i = (unsigned)(sorted2[j0 + e] & 0xffffffffull);
         const unsigned p = pos1[i];
         col = colk[p] - 1;
-        lrow = (rowk[p] - 1) - b * R;
+        lrow = (rowk[p] - 1) - rstart[b];
         v = a[p];
     }
     if (threadIdx.x == 0) s_cb = col;  // the first element of a chunk is never padding
@@ -354,8 +367,8 @@ __global__ __launch_bounds__(CSB_BLOCK, 1) void k_spmv_csb(
         }
         __syncthreads();
         // epilogue of the block: y, its partial of sum (y ns)^2, accumulators cleared
-        const int row0 = b * A.R;
-        const int nr = A.rows - row0 < A.R ? A.rows - row0 : A.R;
+        const int row0 = A.rstart[b];
+        const int nr = A.rstart[b + 1] - row0;
         double sq = 0.0;
         if (A.S > 1) {  // a split: the exact sums as they are (integer steps of q1 as doubles when LO32)
             double *zh = A.zhi + (size_t)sp * A.rows + row0, *zl = A.zlo + (size_t)sp * A.rows + row0;
@@ -442,8 +455,8 @@ __global__ __launch_bounds__(CSB_BLOCK) void k_csb_combine(
     }
     const double q1 = *A.q1out;
     for (int b = blockIdx.x; b < A.nrb; b += gridDim.x) {
-        const int row0 = b * A.R;
-        const int nr = A.rows - row0 < A.R ? A.rows - row0 : A.R;
+        const int row0 = A.rstart[b];
+        const int nr = A.rstart[b + 1] - row0;
         double sq = 0.0;
         for (int r = tid; r < nr; r += CSB_BLOCK) {
             double hi = A.zhi[row0 + r], lo = A.zlo[row0 + r];

@@ -161,6 +161,7 @@ struct Csr {
     unsigned *cidx = nullptr;     // [nchunks * 256] local row << 18 | column - cbase[chunk]
     int *ccb = nullptr;           // [nchunks] first column of each chunk
     long long *cptr = nullptr;    // [nrb + 1] first chunk of each row block
+    int *crs = nullptr;           // [nrb + 1] first row of each row block
     int64_t nchunks = 0;
     int nrb = 0, R = 0, H = 3;
     int lo32 = 0;                 // low parts of the row sums as 32-bit integers (csb.h)
@@ -304,6 +305,7 @@ static void free_csr(Csr &c)
     if (c.cidx) (void)hipFree(c.cidx);
     if (c.ccb) (void)hipFree(c.ccb);
     if (c.cptr) (void)hipFree(c.cptr);
+    if (c.crs) (void)hipFree(c.crs);
     if (c.zsplit) (void)hipFree(c.zsplit);
     c = Csr();
 }
@@ -743,9 +745,12 @@ static int build_csb(hipStream_t s, const int *rowk, const int *colk, const doub
     // Fewer rows than 256 full blocks: S workgroups share a block (column splits, csb.h) so that blocks
     // stay tall -- what counts is R d / n, the nonzeros a block holds per column of x.
     //   LSQRHIP_CSB_S  splits per block (test hook; default: as many as keep R <= rmax, at most 8)
+    // (blocks are cut by nonzeros, so where rows are short a block takes more rows than the mean: the mean
+    // stays a little below what the LDS holds -- 3 % for near-uniform rows, 15 % for skewed ones)
+    const int rfill = lo32 ? (int)(0.97 * rmax) : (int)(0.85 * rmax);
     int S = env_int("LSQRHIP_CSB_S", 0);
     if (S <= 0) {
-        S = (int)std::min<int64_t>(8, std::max<int64_t>(1, (int64_t)rmax * CSB_GRID / std::max(rows, 1)));
+        S = (int)std::min<int64_t>(8, std::max<int64_t>(1, (int64_t)rfill * CSB_GRID / std::max(rows, 1)));
         if ((int64_t)rows * S < (int64_t)CSB_GRID * 512) S = 1;   // small systems: not worth a second launch
     }
     S = std::min(S, 8);
@@ -755,19 +760,48 @@ static int build_csb(hipStream_t s, const int *rowk, const int *colk, const doub
             const int nb = std::max(1, CSB_GRID / S);       // S * nb <= 256 units: one per CU, no second pass
             R = (int)(((int64_t)rows + nb - 1) / nb);
         } else {
-            const int64_t k = ((int64_t)rows + (int64_t)CSB_GRID * rmax - 1) / ((int64_t)CSB_GRID * rmax);
+            const int64_t k = ((int64_t)rows + (int64_t)CSB_GRID * rfill - 1) / ((int64_t)CSB_GRID * rfill);
             R = (int)(((int64_t)rows + CSB_GRID * k - 1) / (CSB_GRID * k));
             R = std::max(R, std::min(rows, 512));  // small systems: a few whole blocks rather than 256 slivers
         }
     }
     R = std::min(std::max(R, 1), rmax);
-    const int nrb = (rows + R - 1) / R;
+    // Blocks of at most R rows holding about the same number of nonzeros: the boundaries from the row counts.
+    std::vector<int> rstart;
+    {
+        std::vector<int> cnt((size_t)rows);
+        HIPCHK(hipMemcpy(cnt.data(), s_cnt.p, sizeof(int) * (size_t)rows, hipMemcpyDeviceToHost));
+        const int nb0 = (rows + R - 1) / R;                       // blocks if they were cut by rows
+        const double target = (double)nnz / (double)nb0;         // nonzeros per block
+        // rows per block may exceed the mean where rows are short, up to what the LDS holds -- unless the
+        // block size was asked for (LSQRHIP_CSB_R: then blocks are exactly R rows, as the tests expect)
+        const int cap = env_int("LSQRHIP_CSB_R", 0) > 0 ? R : rmax;
+        rstart.push_back(0);
+        double acc = 0.0;
+        int inblk = 0;
+        const bool by_nnz = env_int("LSQRHIP_CSB_R", 0) <= 0 && nnz > 0;
+        for (int r = 0; r < rows; ++r) {
+            acc += cnt[(size_t)r];
+            ++inblk;
+            const bool full = inblk >= cap;
+            const bool enough = by_nnz ? acc >= target * (double)rstart.size() && inblk >= 1 : inblk >= R;
+            if ((full || enough) && r + 1 < rows) {
+                rstart.push_back(r + 1);
+                inblk = 0;
+            }
+        }
+        rstart.push_back(rows);
+    }
+    const int nrb = (int)rstart.size() - 1;
     if (nrb > SPMV_MAX_GRID) return LSQRHIP_OK;  // one partial of sum(y^2) per block
+    DevScratch s_rst;
+    HIPCHK(s_rst.alloc(sizeof(int) * rstart.size()));
+    HIPCHK(hipMemcpyAsync(s_rst.p, rstart.data(), sizeof(int) * rstart.size(), hipMemcpyHostToDevice, s));
     HIPCHK(s_rbs.alloc(sizeof(long long) * ((size_t)nrb + 1)));
     unsigned long long *sorted2 = bufA;
     if (nnz > 0) {
-        hipLaunchKernelGGL(k_csb_pack_rb, dim3(g), dim3(256), 0, s, rowk, (const unsigned *)s_pos.as<unsigned>(), nnz, R,
-                           bufA);
+        hipLaunchKernelGGL(k_csb_pack_rb, dim3(g), dim3(256), 0, s, rowk, (const unsigned *)s_pos.as<unsigned>(), nnz,
+                           (const int *)s_rst.as<int>(), nrb, bufA);
         HIPCHK(hipGetLastError());
         sorted2 = nrb > 1 ? radix_sort_words(s, bufA, bufB, nnz, bits_for(nrb), hist) : bufA;
     }
@@ -792,8 +826,8 @@ static int build_csb(hipStream_t s, const int *rowk, const int *colk, const doub
     if (nchunks > 0)
         hipLaunchKernelGGL(k_csb_fill, dim3((unsigned)nchunks), dim3(CSB_CHUNK), 0, s, (const unsigned long long *)sorted2,
                            (const unsigned *)s_pos.as<unsigned>(), rowk, colk, d_a, (const long long *)s_rbs.as<long long>(),
-                           (const long long *)s_cptr.as<long long>(), nrb, R, s_val.as<double>(), s_idx.as<unsigned>(),
-                           s_cb.as<int>(), d_flags);
+                           (const long long *)s_cptr.as<long long>(), (const int *)s_rst.as<int>(), nrb, rmax,
+                           s_val.as<double>(), s_idx.as<unsigned>(), s_cb.as<int>(), d_flags);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(got, d_flags, sizeof(got), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
@@ -807,9 +841,10 @@ static int build_csb(hipStream_t s, const int *rowk, const int *colk, const doub
     out.cidx = s_idx.release<unsigned>();
     out.ccb = s_cb.release<int>();
     out.cptr = s_cptr.release<long long>();
+    out.crs = s_rst.release<int>();
     out.nchunks = nchunks;
     out.nrb = nrb;
-    out.R = R;
+    out.R = rmax;   // the dummy accumulator's index (blocks hold at most this many rows)
     out.H = H;
     out.lo32 = lo32 ? 1 : 0;
     out.S = S;
@@ -996,8 +1031,10 @@ static int finish_create(H *h, const int *d_irow, const int *d_icol, const doubl
     const int cmode = env_int("LSQRHIP_CSB", -1);
     const bool csb_a = cmode == 1 || (cmode != 0 && pa > 1 && xa == 0);
     const bool csb_t = cmode == 1 || (cmode != 0 && pt > 1 && xt == 0);
+    const bool t_first = env_int("LSQRHIP_BUILD_T_FIRST", 0) != 0;   // (experiment: does allocation order show?)
+    if (csb_t && t_first) RET(build_csb(s, d_icol, d_irow, d_a, nnz, h->n, h->m, LSQRHIP_ERR_ICOL, LSQRHIP_ERR_IROW, bufA, bufB, hist, d_flags, h->AT));
     if (csb_a) RET(build_csb(s, d_irow, d_icol, d_a, nnz, h->m, h->n, LSQRHIP_ERR_IROW, LSQRHIP_ERR_ICOL, bufA, bufB, hist, d_flags, h->A));
-    if (csb_t) RET(build_csb(s, d_icol, d_irow, d_a, nnz, h->n, h->m, LSQRHIP_ERR_ICOL, LSQRHIP_ERR_IROW, bufA, bufB, hist, d_flags, h->AT));
+    if (csb_t && !t_first) RET(build_csb(s, d_icol, d_irow, d_a, nnz, h->n, h->m, LSQRHIP_ERR_ICOL, LSQRHIP_ERR_IROW, bufA, bufB, hist, d_flags, h->AT));
     int rc = LSQRHIP_OK;
     if (h->off64) {
         if (!h->A.csb)

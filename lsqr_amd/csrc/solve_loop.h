@@ -196,7 +196,8 @@ static void launch_csb(H *h, const SpmvArgs &a)
     const int S = std::max(c.S, 1);
     const int step = rounds ? std::max(1, c.grid / S) : std::max(c.nrb, 1);   // row blocks per launch
     double *zhi = c.zsplit, *zlo = c.zsplit ? c.zsplit + (size_t)S * c.rows : nullptr;
-    CsbMat A{c.cval, c.cidx, c.ccb, c.cptr, c.nrb, c.R, c.rows, c.cols, h->amax_exp, c.H, 0, 0, S, zhi, zlo, h->d_scalar + 3};
+    CsbMat A{c.cval, c.cidx, c.ccb, c.cptr, c.crs, c.nrb, c.R, c.rows, c.cols, h->amax_exp, c.H, 0, 0, S, zhi, zlo,
+             h->d_scalar + 3};
     for (int b0 = 0; b0 < c.nrb || b0 == 0; b0 += step) {
         const int b1 = std::min(c.nrb, b0 + step);
         const bool first = b0 == 0, last = b1 >= c.nrb;
