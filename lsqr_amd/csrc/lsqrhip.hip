@@ -216,6 +216,8 @@ struct lsqrhip_handle_s {
     int poll_ahead = 1;  // enqueue the next graph batch before waiting on the current one
     hipEvent_t ev_batch[2] = {nullptr, nullptr};
     hipGraphExec_t gexec = nullptr;
+    hipGraphExec_t gexec_first = nullptr;  // the start of a solve (state upload, memsets, the five initial kernels) + the first batch
+    int gexec_first_wantse = -1;
     int gexec_iters = 0;
     bool graph_dirty = true;
     std::vector<hipEvent_t> ev;
@@ -323,6 +325,10 @@ static void destroy_graph(H *h)
     if (h->gexec) {
         (void)hipGraphExecDestroy(h->gexec);
         h->gexec = nullptr;
+    }
+    if (h->gexec_first) {
+        (void)hipGraphExecDestroy(h->gexec_first);
+        h->gexec_first = nullptr;
     }
     h->graph_dirty = true;
 }

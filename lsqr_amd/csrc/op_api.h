@@ -86,6 +86,7 @@ static int solve_op(H *h, const double *b, bool b_on_device, double damp, double
     LsqrState *st = h->d_state;
     RET(prepare_log(h, itnlim, want_log));
     RET(upload_initial_state(h, damp, atol, btol, conlim, itnlim, wantse, want_log));
+    HIPCHK(hipMemcpyAsync(h->d_state, h->h_state, sizeof(LsqrState), hipMemcpyHostToDevice, s));
     if (m > 0)
         HIPCHK(hipMemcpyAsync(h->U, b, sizeof(double) * (size_t)m,
                               b_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));

@@ -412,21 +412,68 @@ static int launch_batch(H *h, int i0, int G, hipEvent_t *ev)
     return LSQRHIP_OK;
 }
 
-static int ensure_graph(H *h, int G)
+// The start of a solve on the handle's stream: initial state, u = b is already in U (solve_ez :242);
+// v = 0, x = 0, se = 0 (:621-630); beta = norm(u); u /= beta; v = A'u; alpha = norm(v); v /= alpha; w = v
+// (:632-644).  The mode-2 partials land in P2[0] and (beta, 1/beta) in slot B[0]: exactly what the first
+// lazy mode-1 launch (iteration 1: parity 1, previous parity 0) consumes.  Capturable.
+static int enqueue_solve_start(H *h, int wantse)
 {
-    if (h->gexec && !h->graph_dirty && h->gexec_iters == G && h->gexec_pipeline == h->pipeline) return LSQRHIP_OK;
-    destroy_graph(h);
+    hipStream_t s = h->stream;
+    const int m = h->m, n = h->n;
+    LsqrState *st = h->d_state;
+    HIPCHK(hipMemcpyAsync(h->d_state, h->h_state, sizeof(LsqrState), hipMemcpyHostToDevice, s));
+    if (n > 0) {
+        HIPCHK(hipMemsetAsync(h->V, 0, sizeof(double) * (size_t)n, s));
+        HIPCHK(hipMemsetAsync(h->X, 0, sizeof(double) * (size_t)n, s));
+        HIPCHK(hipMemsetAsync(h->W, 0, sizeof(double) * (size_t)n, s));
+        if (wantse) HIPCHK(hipMemsetAsync(h->SE, 0, sizeof(double) * (size_t)n, s));
+    }
+    hipLaunchKernelGGL(k_sumsq3, dim3(h->vgrid_m), dim3(VEC_BLOCK), 0, s, (const double *)h->U, (int64_t)m,
+                       h->partials);
+    hipLaunchKernelGGL(k_s_init1<true>, dim3(1), dim3(SC_BLOCK), 0, s, (const double *)h->partials, h->vgrid_m,
+                       (const double *)nullptr, st, h->slots + 2);
+    {
+        SpmvArgs a;
+        a.c = &h->AT; a.x = h->U; a.y = h->V; a.coef = &st->c2; a.stop = h->d_zero; a.pout = h->P2[0]; a.stream = s;
+        a.unit_x = true;
+        launch_spmv_args(h, a);
+    }
+    hipLaunchKernelGGL(k_s_init2<true>, dim3(1), dim3(SC_BLOCK), 0, s, (const double *)h->P2[0], h->AT.out_grid,
+                       (const double *)nullptr, st);
+    hipLaunchKernelGGL(k_copy_scale, dim3(h->vgrid_n), dim3(VEC_BLOCK), 0, s, h->W, (const double *)h->V, (int64_t)n,
+                       (const LsqrState *)st);
+    return LSQRHIP_OK;
+}
+
+// Two graphs: a batch of G iterations, and the same batch preceded by the start of a solve -- a solve of
+// up to G iterations is then ONE graph launch (a dozen eager calls at ~3.5 us each with the GPU idle
+// behind them were 8 % of a 20-iteration solve at config 2).
+static int capture_graph(H *h, int G, bool with_start, int wantse, hipGraphExec_t *out)
+{
     hipGraph_t g = nullptr;
     HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-    int rc = launch_batch(h, 1, G, nullptr);  // parity of iteration 1; G is even when riders are on
+    int rc = with_start ? enqueue_solve_start(h, wantse) : LSQRHIP_OK;
+    if (rc == LSQRHIP_OK) rc = launch_batch(h, 1, G, nullptr);  // parity of iteration 1; G is even when riders are on
     hipError_t e = hipStreamEndCapture(h->stream, &g);
     RET(rc);
     if (e != hipSuccess) return fail(LSQRHIP_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
-    e = hipGraphInstantiate(&h->gexec, g, nullptr, nullptr, 0);
+    e = hipGraphInstantiate(out, g, nullptr, nullptr, 0);
     (void)hipGraphDestroy(g);
     if (e != hipSuccess) return fail(LSQRHIP_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
+    return LSQRHIP_OK;
+}
+
+static int ensure_graph(H *h, int G, int wantse)
+{
+    if (h->gexec && h->gexec_first && !h->graph_dirty && h->gexec_iters == G && h->gexec_pipeline == h->pipeline &&
+        h->gexec_first_wantse == (wantse != 0))
+        return LSQRHIP_OK;
+    destroy_graph(h);
+    RET(capture_graph(h, G, false, wantse, &h->gexec));
+    RET(capture_graph(h, G, true, wantse, &h->gexec_first));
     h->gexec_iters = G;
     h->gexec_pipeline = h->pipeline;
+    h->gexec_first_wantse = wantse != 0;
     h->graph_dirty = false;
     return LSQRHIP_OK;
 }
@@ -477,8 +524,7 @@ static int upload_initial_state(H *h, double damp, double atol, double btol, dou
     init.su = init.sv = 1.0;
     init.ns_inv = h->nsc.inv;
     init.c1.skip = init.c2.skip = init.c2p.skip = 1;
-    *h->h_state = init;
-    HIPCHK(hipMemcpyAsync(h->d_state, h->h_state, sizeof(LsqrState), hipMemcpyHostToDevice, h->stream));
+    *h->h_state = init;   // enqueue_solve_start (or the caller) copies it to the device
     return LSQRHIP_OK;
 }
 
@@ -554,34 +600,22 @@ static int solve_core(H *h, const double *b, bool b_on_device, double damp, doub
     RET(prepare_log(h, itnlim, want_log));
     RET(upload_initial_state(h, damp, atol, btol, conlim, itnlim, wantse, want_log));
 
-    // u = b (solve_ez :242); v = 0, x = 0, se = 0 (:621-630)
+    int G = std::max(1, h->graph_iters);
+    if (h->pipeline) G = (G + 1) & ~1;  // even: parity-consistent batches
+    const bool timed = h->time_kernels != 0;
+    const bool fused_update = h->pipeline >= 2 && h->A.P <= 1 && !h->A.csb;
+    const bool graph = h->use_graph != 0 && !timed;
+    if (graph) RET(ensure_graph(h, G, wantse));   // before anything of THIS solve is enqueued (capture)
+
+    // u = b (solve_ez :242); then the start of the solve (enqueue_solve_start), eagerly or as the head of
+    // the first graph
     if (m > 0)
         HIPCHK(hipMemcpyAsync(h->U, b, sizeof(double) * (size_t)m,
                               b_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
-    if (n > 0) {
-        HIPCHK(hipMemsetAsync(h->V, 0, sizeof(double) * (size_t)n, s));
-        HIPCHK(hipMemsetAsync(h->X, 0, sizeof(double) * (size_t)n, s));
-        HIPCHK(hipMemsetAsync(h->W, 0, sizeof(double) * (size_t)n, s));
-        if (wantse) HIPCHK(hipMemsetAsync(h->SE, 0, sizeof(double) * (size_t)n, s));
+    if (!graph) {
+        RET(enqueue_solve_start(h, wantse));
+        HIPCHK(hipGetLastError());
     }
-    // beta = norm(u); u /= beta; v = A'u; alpha = norm(v); v /= alpha; w = v  (:632-644)
-    // The mode-2 partials land in P2[0] and (beta, 1/beta) in slot B[0]: exactly what the
-    // first lazy mode-1 launch (iteration 1: parity 1, previous parity 0) consumes.
-    hipLaunchKernelGGL(k_sumsq3, dim3(h->vgrid_m), dim3(VEC_BLOCK), 0, s, (const double *)h->U, (int64_t)m,
-                       h->partials);
-    hipLaunchKernelGGL(k_s_init1<true>, dim3(1), dim3(SC_BLOCK), 0, s, (const double *)h->partials, h->vgrid_m,
-                       (const double *)nullptr, st, h->slots + 2);
-    {
-        SpmvArgs a;
-        a.c = &h->AT; a.x = h->U; a.y = h->V; a.coef = &st->c2; a.stop = h->d_zero; a.pout = h->P2[0]; a.stream = s;
-        a.unit_x = true;
-        launch_spmv_args(h, a);
-    }
-    hipLaunchKernelGGL(k_s_init2<true>, dim3(1), dim3(SC_BLOCK), 0, s, (const double *)h->P2[0], h->AT.out_grid,
-                       (const double *)nullptr, st);
-    hipLaunchKernelGGL(k_copy_scale, dim3(h->vgrid_n), dim3(VEC_BLOCK), 0, s, h->W, (const double *)h->V, (int64_t)n,
-                       (const LsqrState *)st);
-    HIPCHK(hipGetLastError());
 
     // ---- the loop (src/lsqr.f90:673-852) ------------------------------------
     lsqrhip_timing_t &tm = h->timing;
@@ -591,12 +625,6 @@ static int solve_core(H *h, const double *b, bool b_on_device, double damp, doub
     tm.spmv2_bytes = 12 * h->nnz + (int64_t)P * (n + 1) + 8ll * m + 16ll * n;
     tm.vec_bytes = 40ll * n + (wantse ? 16ll * n : 0);
 
-    int G = std::max(1, h->graph_iters);
-    if (h->pipeline) G = (G + 1) & ~1;  // even: parity-consistent batches
-    const bool timed = h->time_kernels != 0;
-    const bool fused_update = h->pipeline >= 2 && h->A.P <= 1 && !h->A.csb;
-    const bool graph = h->use_graph != 0 && !timed;
-    if (graph) RET(ensure_graph(h, G));
     if (timed && (int)h->ev.size() < 6 * G) {
         const size_t old = h->ev.size();
         h->ev.resize(6 * (size_t)G);
@@ -612,30 +640,32 @@ static int solve_core(H *h, const double *b, bool b_on_device, double damp, doub
         // overlap device work.  Never beyond itnlim; after a stop inside batch k the kernels of
         // batch k+1 return at their first instruction (stop flag) and change nothing.
         auto enqueue = [&](int64_t k) -> int {
-            HIPCHK(hipGraphLaunch(h->gexec, s));
+            HIPCHK(hipGraphLaunch(k == 0 ? h->gexec_first : h->gexec, s));
             HIPCHK(hipMemcpyAsync(h->h_state + 1 + (k & 1), st, sizeof(LsqrState), hipMemcpyDeviceToHost, s));
             HIPCHK(hipEventRecord(h->ev_batch[k & 1], s));
             return LSQRHIP_OK;
         };
         RET(enqueue(0));
+        int64_t stopped_in = 0;
         for (int64_t batch = 0;; ++batch) {
             if (batch > max_batches)
                 return fail(LSQRHIP_ERR_HIP, "iteration loop did not terminate (device state not advancing)");
             if ((batch + 1) * G < (int64_t)itnlim) RET(enqueue(batch + 1));
             HIPCHK(hipEventSynchronize(h->ev_batch[batch & 1]));
+            stopped_in = batch;
             if (h->h_state[1 + (batch & 1)].stop != 0) break;
             if ((batch + 1) * G >= (int64_t)itnlim)  // S3 stops at itnlim at the latest
                 return fail(LSQRHIP_ERR_HIP, "iteration loop did not terminate (device state not advancing)");
         }
-        // the settled state (any batch enqueued past the stop has not touched it)
-        HIPCHK(hipMemcpyAsync(h->h_state, st, sizeof(LsqrState), hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));
+        // the settled state: the snapshot taken behind the stopping batch (a batch enqueued past the stop
+        // returns at its stop-flag tests and has not touched it)
+        *h->h_state = h->h_state[1 + (stopped_in & 1)];
     } else {
         for (int64_t batch = 0;; ++batch) {
             if (batch > max_batches)
                 return fail(LSQRHIP_ERR_HIP, "iteration loop did not terminate (device state not advancing)");
             if (graph) {
-                HIPCHK(hipGraphLaunch(h->gexec, s));
+                HIPCHK(hipGraphLaunch(batch == 0 ? h->gexec_first : h->gexec, s));
             } else {
                 RET(launch_batch(h, 1 + (int)(batch * G), G, timed ? h->ev.data() : nullptr));
                 HIPCHK(hipGetLastError());
