@@ -65,9 +65,15 @@ static_assert((CSB_RMAX32 + 64) * 12 <= CSB_LDS_BYTES, "both accumulator forms s
 constexpr int CSB_LCOL_BITS = 18;
 constexpr unsigned CSB_LCOL_MASK = (1u << CSB_LCOL_BITS) - 1u;
 constexpr int CSB_GRID = 256;                    // one workgroup per CU
+// The (value, index) stream is read once: loaded non-temporal so that it does not push the part of x the
+// XCD's workgroups are gathering from out of L2 (PMC before: 15 % of the gathers missed L2, 2.6x the
+// layout's bytes fetched; config 4 4.80 -> 4.20 ms, config 3 at 100 per row 956 -> 900 us).
+#ifndef CSB_NT_STREAM
+#define CSB_NT_STREAM 1
+#endif
 
 struct CsbMat {
-    const double *val;
+    const void *val;        // VT values (double; float for a REAL32 handle)
     const unsigned *idx;
     const int *cbase;
     const long long *cptr;  // [nrb + 1], in chunks
@@ -207,9 +213,9 @@ struct CsbX {
 // accumulated with ds_add_u32 (integer adds are exact and order-free by nature).  12 bytes per row
 // instead of 16: a third more rows per block, i.e. a third more nonzeros per column of x in every sweep
 // (config 4: 13021 instead of 9766 rows per block).  Dropped per product: < q1'/2 = 2^(E+2H-85).
-template <bool LO32>
+template <bool LO32, typename VT = double>
 __global__ __launch_bounds__(CSB_BLOCK, 1) void k_spmv_csb(
-    CsbMat A, const double *__restrict__ x, double *__restrict__ y, const SpmvCoef *__restrict__ coef,
+    CsbMat A, const VT *__restrict__ x, VT *__restrict__ y, const SpmvCoef *__restrict__ coef,
     const int *__restrict__ stop, double *__restrict__ partials, const double *__restrict__ pin, int npin,
     const NormSlot *__restrict__ slot_in, NormSlot *__restrict__ slot_out, int skip_if_zero, Rider rider, CsbX xb,
     NScale nsc)
@@ -232,6 +238,7 @@ __global__ __launch_bounds__(CSB_BLOCK, 1) void k_spmv_csb(
         return;
     }
     if (*stop != 0) return;
+    const VT *__restrict__ aval = static_cast<const VT *>(A.val);
 
     double sx, sy, cy;
     if (pin != nullptr) {
@@ -329,14 +336,19 @@ __global__ __launch_bounds__(CSB_BLOCK, 1) void k_spmv_csb(
             const long long k = cc * CSB_CHUNK + lane;
 #pragma unroll
             for (int j = 0; j < CSB_U; ++j) {
-                a[j] = A.val[k + j * WAVE];
-                i[j] = A.idx[k + j * WAVE];
+                if (CSB_NT_STREAM) {   // read-once stream: non-temporal, so that it does not push x out of L2
+                    a[j] = (double)__builtin_nontemporal_load(&aval[k + j * WAVE]);
+                    i[j] = __builtin_nontemporal_load(&A.idx[k + j * WAVE]);
+                } else {
+                    a[j] = (double)aval[k + j * WAVE];
+                    i[j] = A.idx[k + j * WAVE];
+                }
             }
         };
         auto work = [&](const double (&a)[CSB_U], const unsigned (&i)[CSB_U], int base) {
             double xv[CSB_U];
 #pragma unroll
-            for (int j = 0; j < CSB_U; ++j) xv[j] = x[base + (int)(i[j] & CSB_LCOL_MASK)];
+            for (int j = 0; j < CSB_U; ++j) xv[j] = (double)x[base + (int)(i[j] & CSB_LCOL_MASK)];
 #pragma unroll
             for (int j = 0; j < CSB_U; ++j) {
                 const double p = a[j] * (xv[j] * sx);
@@ -393,9 +405,9 @@ __global__ __launch_bounds__(CSB_BLOCK, 1) void k_spmv_csb(
             acc_hi[r] = 0.0;
             if (LO32) acc_li[r] = 0;
             else acc_lo[r] = 0.0;
-            const double yn = cy * (y[row0 + r] * sy) + (hi + lo);
+            const VT yn = (VT)(cy * ((double)y[row0 + r] * sy) + (hi + lo));
             y[row0 + r] = yn;
-            const double ys = yn * nsc.s;
+            const double ys = (double)yn * nsc.s;
             sq += ys * ys;
         }
         if (tid == 0) {  // the padding's dummy accumulator
@@ -419,9 +431,9 @@ __global__ __launch_bounds__(CSB_BLOCK, 1) void k_spmv_csb(
 // The second launch of a column-split product: y and the blocks' partials of sum (y ns)^2 from the
 // splits' exact sums.  One workgroup per row block with the thread -> row mapping and the reduction of
 // k_spmv_csb's own epilogue, so y AND the partials are bit for bit those of the unsplit kernel.
-template <bool LO32>
+template <bool LO32, typename VT = double>
 __global__ __launch_bounds__(CSB_BLOCK) void k_csb_combine(
-    CsbMat A, double *__restrict__ y, const SpmvCoef *__restrict__ coef, const int *__restrict__ stop,
+    CsbMat A, VT *__restrict__ y, const SpmvCoef *__restrict__ coef, const int *__restrict__ stop,
     double *__restrict__ partials, const double *__restrict__ pin, int npin, const NormSlot *__restrict__ slot_in,
     int skip_if_zero, NScale nsc)
 {
@@ -465,9 +477,9 @@ __global__ __launch_bounds__(CSB_BLOCK) void k_csb_combine(
                 lo = lo + A.zlo[(size_t)sp * A.rows + row0 + r];
             }
             if (LO32) lo = lo * q1;
-            const double yn = cy * (y[row0 + r] * sy) + (hi + lo);
+            const VT yn = (VT)(cy * ((double)y[row0 + r] * sy) + (hi + lo));
             y[row0 + r] = yn;
-            const double ys = yn * nsc.s;
+            const double ys = (double)yn * nsc.s;
             sq += ys * ys;
         }
         sq = wave_sum(sq);

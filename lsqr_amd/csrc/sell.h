@@ -161,11 +161,11 @@ __global__ __launch_bounds__(256) void k_sell_fill(const int *__restrict__ rowpt
 
 // U columns of one slice, starting at element `e` (= soff + 64 k0 + lane): all loads first,
 // then the predicated left-to-right adds.
-template <int U, bool C16, bool V8>
+template <int U, bool C16, bool V8, typename VT>
 __device__ __forceinline__ double sell_chunk(double sum, size_t e, int k0, int len, int cb,
                                              const int *__restrict__ sc32, const unsigned short *__restrict__ sc16,
-                                             const double *__restrict__ sv, const unsigned char *__restrict__ sv8,
-                                             const double *sdict, const double *__restrict__ x, double sx)
+                                             const VT *__restrict__ sv, const unsigned char *__restrict__ sv8,
+                                             const double *sdict, const VT *__restrict__ x, double sx)
 {
     int c[U];
     double a[U], xv[U];
@@ -175,10 +175,10 @@ __device__ __forceinline__ double sell_chunk(double sum, size_t e, int k0, int l
         const size_t idx = e + (size_t)j * 64;
         c[j] = C16 ? cb + (int)sc16[idx] : sc32[idx];
         if (V8) code[j] = (int)sv8[idx];
-        else a[j] = sv[idx];
+        else a[j] = (double)sv[idx];
     }
 #pragma unroll
-    for (int j = 0; j < U; ++j) xv[j] = x[c[j]];
+    for (int j = 0; j < U; ++j) xv[j] = (double)x[c[j]];
 #pragma unroll
     for (int j = 0; j < U; ++j) {
         const double av = V8 ? sdict[code[j]] : a[j];
@@ -197,7 +197,7 @@ struct SellCoef {
 // What every workgroup of a sliced-ELL product does before its rows: the lazy coefficients from
 // the previous kernel's partial sums (spmv.h) and, with UPD, its share of the x/w update of the
 // previous iteration (vec.h UpdArgs).  false = this product is skipped.
-template <bool UPD>
+template <bool UPD, typename VT>
 __device__ __forceinline__ bool sell_prologue(const SpmvCoef *__restrict__ coef, const double *__restrict__ pin, int npin,
                                               const NormSlot *__restrict__ slot_in, NormSlot *__restrict__ slot_out,
                                               int skip_if_zero, const UpdArgs &upd, int nwg, int wg, double *red,
@@ -234,8 +234,8 @@ __device__ __forceinline__ bool sell_prologue(const SpmvCoef *__restrict__ coef,
             // the slice its rows gather from (one trip from beyond L2 instead of two)
             const XcdRange ur = xcd_range(upd.ugrid, nwg, wg);
             for (int ub = (int)ur.first; ub < (int)ur.end; ub += (int)ur.stride) {
-                const double tot = update_block(upd.x, upd.w, upd.V, upd.se, upd.n, rt.t1, rt.t2, rt.t3, sv, wantse,
-                                                ub, upd.ugrid, red);
+                const double tot = update_block<VT>((VT *)upd.x, (VT *)upd.w, (const VT *)upd.V, (VT *)upd.se, upd.n, rt.t1,
+                                                    rt.t2, rt.t3, sv, wantse, ub, upd.ugrid, red);
                 if (tid == 0) upd.pout[ub] = tot;
             }
         }
@@ -249,11 +249,11 @@ __device__ __forceinline__ bool sell_prologue(const SpmvCoef *__restrict__ coef,
 }
 
 // UPD = true: the launch also carries the x/w update of the previous iteration (UpdArgs).
-template <bool C16, bool V8, bool UPD>
+template <bool C16, bool V8, bool UPD, typename VT = double>
 __global__ __launch_bounds__(SELL_BLOCK, 8) void k_spmv_sell(
     const unsigned *__restrict__ soff, const void *__restrict__ scolv, const int *__restrict__ cbaseS,
     const void *__restrict__ svalv, const double *__restrict__ dict, const unsigned char *__restrict__ rlen,
-    int rows, int nslices, int64_t nblk, const double *__restrict__ x, double *__restrict__ y,
+    int rows, int nslices, int64_t nblk, const VT *__restrict__ x, VT *__restrict__ y,
     const SpmvCoef *__restrict__ coef, const int *__restrict__ stop, double *__restrict__ partials,
     const double *__restrict__ pin, int npin, const NormSlot *__restrict__ slot_in,
     NormSlot *__restrict__ slot_out, int skip_if_zero, Rider rider, UpdArgs upd, NScale nsc)
@@ -273,13 +273,13 @@ __global__ __launch_bounds__(SELL_BLOCK, 8) void k_spmv_sell(
     if (V8) sdict[tid] = dict[tid];  // visible after the first barrier below
 
     SellCoef kc;
-    if (!sell_prologue<UPD>(coef, pin, npin, slot_in, slot_out, skip_if_zero, upd, nwg, wg, red, kc, nsc)) return;
+    if (!sell_prologue<UPD, VT>(coef, pin, npin, slot_in, slot_out, skip_if_zero, upd, nwg, wg, red, kc, nsc)) return;
     const double sx = kc.sx, sy = kc.sy, cy = kc.cy;
     if (V8) __syncthreads();
 
     const int *__restrict__ sc32 = static_cast<const int *>(scolv);
     const unsigned short *__restrict__ sc16 = static_cast<const unsigned short *>(scolv);
-    const double *__restrict__ sv = static_cast<const double *>(svalv);
+    const VT *__restrict__ sv = static_cast<const VT *>(svalv);
     const unsigned char *__restrict__ sv8 = static_cast<const unsigned char *>(svalv);
     const int lane = tid & (WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: slice descriptors through the scalar cache
@@ -297,26 +297,26 @@ __global__ __launch_bounds__(SELL_BLOCK, 8) void k_spmv_sell(
         const bool active = r < rows;
         const int rc = active ? r : rows - 1;
         const int len = active ? (int)rlen[rc] : 0;
-        const double y0 = y[rc];
+        const double y0 = (double)y[rc];
         double sum = 0.0;
         size_t e = (size_t)o0 + lane;
         int k0 = 0;
         for (; W - k0 >= 8; k0 += 8, e += 8 * 64)
-            sum = sell_chunk<8, C16, V8>(sum, e, k0, len, cb, sc32, sc16, sv, sv8, sdict, x, sx);
+            sum = sell_chunk<8, C16, V8, VT>(sum, e, k0, len, cb, sc32, sc16, sv, sv8, sdict, x, sx);
         switch (W - k0) {  // uniform
-        case 7: sum = sell_chunk<7, C16, V8>(sum, e, k0, len, cb, sc32, sc16, sv, sv8, sdict, x, sx); break;
-        case 6: sum = sell_chunk<6, C16, V8>(sum, e, k0, len, cb, sc32, sc16, sv, sv8, sdict, x, sx); break;
-        case 5: sum = sell_chunk<5, C16, V8>(sum, e, k0, len, cb, sc32, sc16, sv, sv8, sdict, x, sx); break;
-        case 4: sum = sell_chunk<4, C16, V8>(sum, e, k0, len, cb, sc32, sc16, sv, sv8, sdict, x, sx); break;
-        case 3: sum = sell_chunk<3, C16, V8>(sum, e, k0, len, cb, sc32, sc16, sv, sv8, sdict, x, sx); break;
-        case 2: sum = sell_chunk<2, C16, V8>(sum, e, k0, len, cb, sc32, sc16, sv, sv8, sdict, x, sx); break;
-        case 1: sum = sell_chunk<1, C16, V8>(sum, e, k0, len, cb, sc32, sc16, sv, sv8, sdict, x, sx); break;
+        case 7: sum = sell_chunk<7, C16, V8, VT>(sum, e, k0, len, cb, sc32, sc16, sv, sv8, sdict, x, sx); break;
+        case 6: sum = sell_chunk<6, C16, V8, VT>(sum, e, k0, len, cb, sc32, sc16, sv, sv8, sdict, x, sx); break;
+        case 5: sum = sell_chunk<5, C16, V8, VT>(sum, e, k0, len, cb, sc32, sc16, sv, sv8, sdict, x, sx); break;
+        case 4: sum = sell_chunk<4, C16, V8, VT>(sum, e, k0, len, cb, sc32, sc16, sv, sv8, sdict, x, sx); break;
+        case 3: sum = sell_chunk<3, C16, V8, VT>(sum, e, k0, len, cb, sc32, sc16, sv, sv8, sdict, x, sx); break;
+        case 2: sum = sell_chunk<2, C16, V8, VT>(sum, e, k0, len, cb, sc32, sc16, sv, sv8, sdict, x, sx); break;
+        case 1: sum = sell_chunk<1, C16, V8, VT>(sum, e, k0, len, cb, sc32, sc16, sv, sv8, sdict, x, sx); break;
         default: break;
         }
         if (active) {
-            const double yn = cy * (y0 * sy) + sum;
+            const VT yn = (VT)(cy * (y0 * sy) + sum);
             y[r] = yn;
-            const double ys = yn * nsc.s;
+            const double ys = (double)yn * nsc.s;
             sq += ys * ys;
         }
     }
@@ -388,8 +388,9 @@ __global__ __launch_bounds__(256) void k_sellp_fill(const int *__restrict__ rowp
 }
 
 // the 5 products of one record, added left to right where they exist (k0 = index of its first nonzero)
+template <typename VT>
 __device__ __forceinline__ double sellp_add(double sum, const uint4 q, int k0, int cb, const double *sdict,
-                                            const double *__restrict__ x, double sx)
+                                            const VT *__restrict__ x, double sx)
 {
     int c[SELLP_K], code[SELLP_K];
     c[0] = cb + (int)(q.x & 0xffffu);
@@ -405,7 +406,7 @@ __device__ __forceinline__ double sellp_add(double sum, const uint4 q, int k0, i
     const int len = (int)(q.w >> 24);
     double xv[SELLP_K];
 #pragma unroll
-    for (int t = 0; t < SELLP_K; ++t) xv[t] = x[c[t]];
+    for (int t = 0; t < SELLP_K; ++t) xv[t] = (double)x[c[t]];
 #pragma unroll
     for (int t = 0; t < SELLP_K; ++t) {
         const double p = sdict[code[t]] * (xv[t] * sx);
@@ -414,11 +415,11 @@ __device__ __forceinline__ double sellp_add(double sum, const uint4 q, int k0, i
     return sum;
 }
 
-template <bool UPD>
+template <bool UPD, typename VT = double>
 __global__ __launch_bounds__(SELL_BLOCK, 8) void k_spmv_sellp(
     const unsigned *__restrict__ roff, const uint4 *__restrict__ rec, const int *__restrict__ cbaseS,
-    const double *__restrict__ dict, int rows, int nslices, int64_t nblk, const double *__restrict__ x,
-    double *__restrict__ y, const SpmvCoef *__restrict__ coef, const int *__restrict__ stop,
+    const double *__restrict__ dict, int rows, int nslices, int64_t nblk, const VT *__restrict__ x,
+    VT *__restrict__ y, const SpmvCoef *__restrict__ coef, const int *__restrict__ stop,
     double *__restrict__ partials, const double *__restrict__ pin, int npin, const NormSlot *__restrict__ slot_in,
     NormSlot *__restrict__ slot_out, int skip_if_zero, Rider rider, UpdArgs upd, NScale nsc)
 {
@@ -436,7 +437,7 @@ __global__ __launch_bounds__(SELL_BLOCK, 8) void k_spmv_sellp(
     sdict[tid] = dict[tid];  // visible after the barrier below
 
     SellCoef kc;
-    if (!sell_prologue<UPD>(coef, pin, npin, slot_in, slot_out, skip_if_zero, upd, nwg, wg, red, kc, nsc)) return;
+    if (!sell_prologue<UPD, VT>(coef, pin, npin, slot_in, slot_out, skip_if_zero, upd, nwg, wg, red, kc, nsc)) return;
     const double sx = kc.sx, sy = kc.sy, cy = kc.cy;
     __syncthreads();
 
@@ -452,23 +453,23 @@ __global__ __launch_bounds__(SELL_BLOCK, 8) void k_spmv_sellp(
         const int cb = cbaseS[s];
         const int r = s * WAVE + lane;
         const bool active = r < rows;
-        const double y0 = y[active ? r : rows - 1];
+        const double y0 = (double)y[active ? r : rows - 1];
         const uint4 *__restrict__ p = rec + (size_t)o0 + lane;
         double sum = 0.0;
         if (nch == 1) {
-            sum = sellp_add(sum, p[0], 0, cb, sdict, x, sx);
+            sum = sellp_add<VT>(sum, p[0], 0, cb, sdict, x, sx);
         } else {
             for (int j = 0; j < nch; j += 2) {  // two records in flight; the second one clamped, not branched on
                 const uint4 qa = p[(size_t)j * 64];
                 const uint4 qb = p[(size_t)min(j + 1, nch - 1) * 64];
-                sum = sellp_add(sum, qa, SELLP_K * j, cb, sdict, x, sx);
-                if (j + 1 < nch) sum = sellp_add(sum, qb, SELLP_K * (j + 1), cb, sdict, x, sx);
+                sum = sellp_add<VT>(sum, qa, SELLP_K * j, cb, sdict, x, sx);
+                if (j + 1 < nch) sum = sellp_add<VT>(sum, qb, SELLP_K * (j + 1), cb, sdict, x, sx);
             }
         }
         if (active) {
-            const double yn = cy * (y0 * sy) + sum;
+            const VT yn = (VT)(cy * (y0 * sy) + sum);
             y[r] = yn;
-            const double ys = yn * nsc.s;
+            const double ys = (double)yn * nsc.s;
             sq += ys * ys;
         }
     }

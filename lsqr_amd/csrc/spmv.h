@@ -231,10 +231,12 @@ __global__ void k_block_skew(const OffT *__restrict__ rowptr, const RowBlock *__
     if (f) *any = 1;
 }
 
-template <typename OffT, bool PANEL, bool C16, bool V8, bool UPD, bool XL = false>
+// VT = storage type of x, y and the values (double; float for a REAL32 handle -- never with PANEL, whose
+// y is the double array Z).  Products and sums are formed in binary64 either way.
+template <typename OffT, bool PANEL, bool C16, bool V8, bool UPD, bool XL = false, typename VT = double>
 __global__ __launch_bounds__(SPMV_BLOCK, XL ? 2 : 8) void k_spmv_fused(
     const OffT *__restrict__ rowptr, const void *__restrict__ colv, const int *__restrict__ cbase,
-    const void *__restrict__ valv, const double *__restrict__ dict, const RowBlock *__restrict__ blk, int64_t nblk, const double *__restrict__ x, double *__restrict__ y,
+    const void *__restrict__ valv, const double *__restrict__ dict, const RowBlock *__restrict__ blk, int64_t nblk, const VT *__restrict__ x, VT *__restrict__ y,
     const SpmvCoef *__restrict__ coef, const int *__restrict__ stop, double *__restrict__ partials,
     const double *__restrict__ pin, int npin, const NormSlot *__restrict__ slot_in,
     NormSlot *__restrict__ slot_out, int skip_if_zero, Rider rider, UpdArgs upd, XlArgs xa, NScale nsc)
@@ -259,7 +261,7 @@ __global__ __launch_bounds__(SPMV_BLOCK, XL ? 2 : 8) void k_spmv_fused(
     const int tid = threadIdx.x;
     const int *__restrict__ col = static_cast<const int *>(colv);
     const unsigned short *__restrict__ col16 = static_cast<const unsigned short *>(colv);
-    const double *__restrict__ val = static_cast<const double *>(valv);
+    const VT *__restrict__ val = static_cast<const VT *>(valv);
     const unsigned char *__restrict__ val8 = static_cast<const unsigned char *>(valv);
     if (V8) sdict[tid] = dict[tid];  // visible after the first barrier below
 
@@ -294,8 +296,8 @@ __global__ __launch_bounds__(SPMV_BLOCK, XL ? 2 : 8) void k_spmv_fused(
             // the slice its rows gather from (one trip from beyond L2 instead of two)
             const XcdRange ur = xcd_range(upd.ugrid, nwg, wg);
             for (int ub = (int)ur.first; ub < (int)ur.end; ub += (int)ur.stride) {
-                const double tot = update_block(upd.x, upd.w, upd.V, upd.se, upd.n, rt.t1, rt.t2, rt.t3, sv, wantse,
-                                                ub, upd.ugrid, red);
+                const double tot = update_block<VT>((VT *)upd.x, (VT *)upd.w, (const VT *)upd.V, (VT *)upd.se, upd.n, rt.t1,
+                                                    rt.t2, rt.t3, sv, wantse, ub, upd.ugrid, red);
                 if (tid == 0) upd.pout[ub] = tot;
             }
         }
@@ -315,7 +317,7 @@ __global__ __launch_bounds__(SPMV_BLOCK, XL ? 2 : 8) void k_spmv_fused(
             const unsigned off = (unsigned)(cj - xbase);
             if (off < (unsigned)xa.pw) return xs[off];
         }
-        return x[cj] * sx;
+        return (double)x[cj] * sx;
     };
 
     // Independent loads are issued up front: the descriptor of the NEXT block, this block's
@@ -346,7 +348,7 @@ __global__ __launch_bounds__(SPMV_BLOCK, XL ? 2 : 8) void k_spmv_fused(
                 xbase = pid * xa.pw;
                 for (int i = tid; i < xa.pw; i += SPMV_BLOCK) {
                     const int cx = xbase + i;
-                    xs[i] = cx < xa.ncols ? x[cx] * sx : 0.0;
+                    xs[i] = cx < xa.ncols ? (double)x[cx] * sx : 0.0;
                 }
                 __syncthreads();
             }
@@ -393,18 +395,18 @@ __global__ __launch_bounds__(SPMV_BLOCK, XL ? 2 : 8) void k_spmv_fused(
             }
 #pragma unroll
             for (int j = 0; j < NS; ++j) {
-                a[j] = V8 ? sdict[val8[p0 + kk[j]]] : val[p0 + kk[j]];
+                a[j] = V8 ? sdict[val8[p0 + kk[j]]] : (double)val[p0 + kk[j]];
                 c[j] = C16 ? cb + (int)col16[p0 + kk[j]] : col[p0 + kk[j]];
             }
             if (nr > 0) {
                 q0 = rowptr[rclamp];
                 q1 = rowptr[rclamp + 1];
-                if (!PANEL) y0 = y[rclamp];
+                if (!PANEL) y0 = (double)y[rclamp];
                 if (nr > ngroups) {  // uniform: this lane's SECOND round too (clamped)
                     const int r2 = rfirst + ngroups < r1s ? rfirst + ngroups : rclamp;
                     q0b = rowptr[r2];
                     q1b = rowptr[r2 + 1];
-                    if (!PANEL) y0b = y[r2];
+                    if (!PANEL) y0b = (double)y[r2];
                 }
             }
             double xv[NA];
@@ -433,7 +435,7 @@ __global__ __launch_bounds__(SPMV_BLOCK, XL ? 2 : 8) void k_spmv_fused(
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    a[j] = V8 ? sdict[val8[p0 + kk[j]]] : val[p0 + kk[j]];
+                    a[j] = V8 ? sdict[val8[p0 + kk[j]]] : (double)val[p0 + kk[j]];
                     c[j] = C16 ? cb + (int)col16[p0 + kk[j]] : col[p0 + kk[j]];
                 }
 #pragma unroll
@@ -462,11 +464,11 @@ __global__ __launch_bounds__(SPMV_BLOCK, XL ? 2 : 8) void k_spmv_fused(
                     if (aside) {
                         longlist[atomicAdd(&nlong, 1)] = r;
                     } else if (PANEL) {
-                        y[r] = s;  // z[v]: raw sum of this (panel, row) segment
+                        y[r] = (VT)s;  // z[v]: raw sum of this (panel, row) segment
                     } else {
-                        const double yn = cy * (y0 * sy) + s;
+                        const VT yn = (VT)(cy * (y0 * sy) + s);   // as stored (rounded to float for a REAL32 handle)
                         y[r] = yn;
-                        const double ys = yn * nsc.s;
+                        const double ys = (double)yn * nsc.s;
                         sq += ys * ys;
                     }
                 }
@@ -479,7 +481,7 @@ __global__ __launch_bounds__(SPMV_BLOCK, XL ? 2 : 8) void k_spmv_fused(
                 } else {
                     q0 = rowptr[r];
                     q1 = rowptr[r + 1];
-                    if (!PANEL) y0 = y[r];
+                    if (!PANEL) y0 = (double)y[r];
                 }
             }
         }
@@ -495,7 +497,7 @@ __global__ __launch_bounds__(SPMV_BLOCK, XL ? 2 : 8) void k_spmv_fused(
                 double s = 0.0;
                 for (int k = s0 + lane; k < s1; k += WAVE) s = s + prod[k];
                 s = wave_sum(s);
-                if (lane == 0) y[r] = s;
+                if (lane == 0) y[r] = (VT)s;
             }
         }
 
@@ -515,7 +517,7 @@ __global__ __launch_bounds__(SPMV_BLOCK, XL ? 2 : 8) void k_spmv_fused(
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    al[j] = V8 ? sdict[val8[plast + kl[j]]] : val[plast + kl[j]];
+                    al[j] = V8 ? sdict[val8[plast + kl[j]]] : (double)val[plast + kl[j]];
                     cl[j] = C16 ? cb + (int)col16[plast + kl[j]] : col[plast + kl[j]];
                 }
                 double xl[4];
@@ -531,11 +533,11 @@ __global__ __launch_bounds__(SPMV_BLOCK, XL ? 2 : 8) void k_spmv_fused(
             if (tid == 0) {
                 const int r = r1 - 1;
                 if (PANEL) {
-                    y[r] = tot;
+                    y[r] = (VT)tot;
                 } else {
-                    const double yn = cy * (y[r] * sy) + tot;
+                    const VT yn = (VT)(cy * ((double)y[r] * sy) + tot);
                     y[r] = yn;
-                    const double ys = yn * nsc.s;
+                    const double ys = (double)yn * nsc.s;
                     sq += ys * ys;
                 }
             }

@@ -27,39 +27,49 @@ namespace lsqrhip {
 constexpr int VEC_BLOCK = 256;
 constexpr int VEC_MAX_GRID = 2048;
 
+// Vectors are stored as VT = double, or float in the all-REAL32 build of the reference's precision macro
+// (src/lsqr_kinds.F90:16-17): half the bytes of every vector pass.  Arithmetic is always binary64 in
+// registers; a float vector holds the rounded results.
+template <typename VT> struct Vec2;
+template <> struct Vec2<double> { typedef double2 type; };
+template <> struct Vec2<float> { typedef float2 type; };
+
 // The work of ONE workgroup of the x/w update: block `ub` of a grid of `ugrid` blocks of
 // VEC_BLOCK threads.  Returns (in thread 0) the block's partial of sum (t3 w)^2.  k_update
 // runs it as a kernel of its own; the fused mode-1 kernels (spmv.h / sell.h, UpdArgs) run the
 // same blocks from inside the SpMV launch -- same elements per thread, same order, same
 // reduction, hence the same partials bit for bit.
-__device__ __forceinline__ double update_block(double *__restrict__ x, double *__restrict__ w,
-                                               const double *__restrict__ V, double *__restrict__ se, int64_t n,
+template <typename VT>
+__device__ __forceinline__ double update_block(VT *__restrict__ x, VT *__restrict__ w,
+                                               const VT *__restrict__ V, VT *__restrict__ se, int64_t n,
                                                double t1, double t2, double t3, double sv, bool wantse, int ub,
                                                int ugrid, double *red)
 {
+    typedef typename Vec2<VT>::type V2T;
     double dk = 0.0;
     const int64_t n2 = n >> 1;
     const int64_t stride = (int64_t)ugrid * VEC_BLOCK;
-    double2 *x2 = reinterpret_cast<double2 *>(x);
-    double2 *w2 = reinterpret_cast<double2 *>(w);
-    const double2 *V2 = reinterpret_cast<const double2 *>(V);
-    double2 *se2 = reinterpret_cast<double2 *>(se);
+    V2T *x2 = reinterpret_cast<V2T *>(x);
+    V2T *w2 = reinterpret_cast<V2T *>(w);
+    const V2T *V2 = reinterpret_cast<const V2T *>(V);
+    V2T *se2 = reinterpret_cast<V2T *>(se);
     for (int64_t i = (int64_t)ub * VEC_BLOCK + threadIdx.x; i < n2; i += stride) {
-        const double2 t = w2[i];
-        double2 xv = x2[i];
-        const double2 vv = V2[i];
-        xv.x = t1 * t.x + xv.x;
-        xv.y = t1 * t.y + xv.y;
-        double2 wn;
-        wn.x = t2 * t.x + vv.x * sv;
-        wn.y = t2 * t.y + vv.y * sv;
-        const double d0 = (t3 * t.x) * (t3 * t.x), d1 = (t3 * t.y) * (t3 * t.y);
+        const V2T t = w2[i];
+        V2T xv = x2[i];
+        const V2T vv = V2[i];
+        const double tx = (double)t.x, ty = (double)t.y;
+        xv.x = (VT)(t1 * tx + (double)xv.x);
+        xv.y = (VT)(t1 * ty + (double)xv.y);
+        V2T wn;
+        wn.x = (VT)(t2 * tx + (double)vv.x * sv);
+        wn.y = (VT)(t2 * ty + (double)vv.y * sv);
+        const double d0 = (t3 * tx) * (t3 * tx), d1 = (t3 * ty) * (t3 * ty);
         x2[i] = xv;
         w2[i] = wn;
         if (wantse) {
-            double2 s = se2[i];
-            s.x = d0 + s.x;
-            s.y = d1 + s.y;
+            V2T s = se2[i];
+            s.x = (VT)(d0 + (double)s.x);
+            s.y = (VT)(d1 + (double)s.y);
             se2[i] = s;
         }
         dk += d0;
@@ -67,19 +77,20 @@ __device__ __forceinline__ double update_block(double *__restrict__ x, double *_
     }
     if ((n & 1) && ub == 0 && threadIdx.x == 0) {
         const int64_t i = n - 1;
-        const double t = w[i];
-        x[i] = t1 * t + x[i];
-        w[i] = t2 * t + V[i] * sv;
+        const double t = (double)w[i];
+        x[i] = (VT)(t1 * t + (double)x[i]);
+        w[i] = (VT)(t2 * t + (double)V[i] * sv);
         const double d = (t3 * t) * (t3 * t);
-        if (wantse) se[i] = d + se[i];
+        if (wantse) se[i] = (VT)(d + (double)se[i]);
         dk += d;
     }
     return block_sum<VEC_BLOCK>(dk, red);
 }
 
+template <typename VT>
 __global__ __launch_bounds__(VEC_BLOCK) void k_update(
-    double *__restrict__ x, double *__restrict__ w, const double *__restrict__ V,
-    double *__restrict__ se, int64_t n, const LsqrState *__restrict__ st,
+    VT *__restrict__ x, VT *__restrict__ w, const VT *__restrict__ V,
+    VT *__restrict__ se, int64_t n, const LsqrState *__restrict__ st,
     double *__restrict__ partials)
 {
     if (st->stop != 0) return;
@@ -97,8 +108,8 @@ struct UpdArgs {
     int par;      // parity of the rotation inputs: st->rhobar2[par], st->phibar2[par]
     int ugrid;    // blocks of the update (== the grid k_update would use)
     int pad;
-    double *x, *w, *se;
-    const double *V;
+    void *x, *w, *se;   // VT arrays (double, or float for a REAL32 handle)
+    const void *V;
     int64_t n;
     const LsqrState *st;
     const NormSlot *alpha_prev;  // (alpha, 1/alpha) of the previous iteration: used when beta == 0
@@ -129,20 +140,22 @@ __global__ __launch_bounds__(VEC_BLOCK) void k_dot(const double *__restrict__ x,
 // Blue's three range-safe accumulators of x^2 (scalar.h blue_add): partials[b], partials[g + b],
 // partials[2 g + b] = this workgroup's small / mid / big sums, g = gridDim.x.  Same element order per
 // thread as k_dot, so the mid plane of an in-range vector is k_dot(x, x)'s partials bit for bit.
-__global__ __launch_bounds__(VEC_BLOCK) void k_sumsq3(const double *__restrict__ x, int64_t n,
+template <typename VT>
+__global__ __launch_bounds__(VEC_BLOCK) void k_sumsq3(const VT *__restrict__ x, int64_t n,
                                                       double *__restrict__ partials)
 {
+    typedef typename Vec2<VT>::type V2T;
     __shared__ double red[VEC_BLOCK / WAVE];
     Blue3 a{0.0, 0.0, 0.0};
     const int64_t n2 = n >> 1;
     const int64_t stride = (int64_t)gridDim.x * VEC_BLOCK;
-    const double2 *x2 = reinterpret_cast<const double2 *>(x);
+    const V2T *x2 = reinterpret_cast<const V2T *>(x);
     for (int64_t i = (int64_t)blockIdx.x * VEC_BLOCK + threadIdx.x; i < n2; i += stride) {
-        const double2 v = x2[i];
-        blue_add(a, v.x);
-        blue_add(a, v.y);
+        const V2T v = x2[i];
+        blue_add(a, (double)v.x);
+        blue_add(a, (double)v.y);
     }
-    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) blue_add(a, x[n - 1]);
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) blue_add(a, (double)x[n - 1]);
     const double t0 = block_sum<VEC_BLOCK>(a.sml, red);
     const double t1 = block_sum<VEC_BLOCK>(a.med, red);
     const double t2 = block_sum<VEC_BLOCK>(a.big, red);
@@ -186,14 +199,15 @@ __global__ __launch_bounds__(VEC_BLOCK) void k_fill(double *__restrict__ x, int6
 }
 
 // w <- V * sv  (first w of the recurrence, src/lsqr.f90:641-644)
-__global__ __launch_bounds__(VEC_BLOCK) void k_copy_scale(double *__restrict__ w,
-                                                          const double *__restrict__ V, int64_t n,
+template <typename VT>
+__global__ __launch_bounds__(VEC_BLOCK) void k_copy_scale(VT *__restrict__ w,
+                                                          const VT *__restrict__ V, int64_t n,
                                                           const LsqrState *__restrict__ st)
 {
     if (st->stop != 0) return;
     const double sv = st->sv;
     const int64_t stride = (int64_t)gridDim.x * VEC_BLOCK;
-    for (int64_t i = (int64_t)blockIdx.x * VEC_BLOCK + threadIdx.x; i < n; i += stride) w[i] = V[i] * sv;
+    for (int64_t i = (int64_t)blockIdx.x * VEC_BLOCK + threadIdx.x; i < n; i += stride) w[i] = (VT)((double)V[i] * sv);
 }
 
 // y <- y + a*x   (xcheck's w = w - damp^2 x, src/lsqr.f90:1090-1094)
@@ -216,7 +230,8 @@ __global__ __launch_bounds__(VEC_BLOCK) void k_acheck_fill(double *__restrict__ 
 }
 
 // se <- t * sqrt(se), t = rnorm / sqrt(1 | m-n | m)   (src/lsqr.f90:857-865)
-__global__ __launch_bounds__(VEC_BLOCK) void k_se_finish(double *__restrict__ se, int64_t n,
+template <typename VT>
+__global__ __launch_bounds__(VEC_BLOCK) void k_se_finish(VT *__restrict__ se, int64_t n,
                                                          const LsqrState *__restrict__ st)
 {
     if (st->wantse == 0 || st->itn == 0) return;
@@ -226,17 +241,18 @@ __global__ __launch_bounds__(VEC_BLOCK) void k_se_finish(double *__restrict__ se
     t = st->rnorm / sqrt(t);
     const int64_t stride = (int64_t)gridDim.x * VEC_BLOCK;
     for (int64_t i = (int64_t)blockIdx.x * VEC_BLOCK + threadIdx.x; i < n; i += stride)
-        se[i] = t * sqrt(se[i]);
+        se[i] = (VT)(t * sqrt((double)se[i]));
 }
 
 // partials[b] = max |x[i]| over this workgroup's share (first pass of the scaled norm)
-__global__ __launch_bounds__(VEC_BLOCK) void k_amax(const double *__restrict__ x, int64_t n,
+template <typename VT>
+__global__ __launch_bounds__(VEC_BLOCK) void k_amax(const VT *__restrict__ x, int64_t n,
                                                     double *__restrict__ partials)
 {
     __shared__ double red[VEC_BLOCK];
     double m = 0.0;
     const int64_t stride = (int64_t)gridDim.x * VEC_BLOCK;
-    for (int64_t i = (int64_t)blockIdx.x * VEC_BLOCK + threadIdx.x; i < n; i += stride) m = fmax(m, fabs(x[i]));
+    for (int64_t i = (int64_t)blockIdx.x * VEC_BLOCK + threadIdx.x; i < n; i += stride) m = fmax(m, fabs((double)x[i]));
     red[threadIdx.x] = m;
     __syncthreads();
     for (int off = VEC_BLOCK / 2; off > 0; off >>= 1) {
@@ -259,6 +275,14 @@ __global__ __launch_bounds__(VEC_BLOCK) void k_sumsq_scaled(const double *__rest
     }
     const double tot = block_sum<VEC_BLOCK>(s, red);
     if (threadIdx.x == 0) partials[blockIdx.x] = tot;
+}
+
+// y <- (T) x elementwise (REAL32 handles: values and vectors converted at the boundary / after the build)
+template <typename TI, typename TO>
+__global__ __launch_bounds__(VEC_BLOCK) void k_convert(const TI *__restrict__ x, TO *__restrict__ y, int64_t n)
+{
+    const int64_t stride = (int64_t)gridDim.x * VEC_BLOCK;
+    for (int64_t i = (int64_t)blockIdx.x * VEC_BLOCK + threadIdx.x; i < n; i += stride) y[i] = (TO)x[i];
 }
 
 // out[0] = sum of partials[0..np) in fixed order (one workgroup).
