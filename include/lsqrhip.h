@@ -110,6 +110,34 @@ int lsqrhip_solve_device(lsqrhip_handle_t h, const double *d_b, double damp, dou
                          double *acond, double *rnorm, double *arnorm, double *xnorm);
 
 /* ---------------------------------------------------------------------- */
+/* REAL32: the reference's precision macro   src/lsqr_kinds.F90:16-17 (wp = real32) */
+/* ---------------------------------------------------------------------- */
+/* The same three entry points for a host built with wp = real32 (lsqr_amd/fortran with -DREAL32 binds
+ * these).  Storage on the device is real32 END TO END -- the matrix values and every vector of the
+ * iteration (u, v, w, x, se): half the bytes of every vector pass and of the value stream -- while the
+ * arithmetic in registers stays binary64 (products, row sums, norms, the scalar recurrences), so the
+ * result is at least as accurate as the reference's all-real32 iteration.  The tolerances, damp and the
+ * returned scalars are doubles (exact conversions of the host's real32 values).
+ * LSQRHIP_REAL32_MIXED=1 (environment, read at create): the mixed mode -- binary64 storage on the device,
+ * real32 only at this boundary.
+ * Layouts: sliced ELL, row windows, column-swept row blocks (no panel kernels).  A REAL32 handle works
+ * with lsqrhip_solve_f32, lsqrhip_aprod_f32, the log, timing, option and info entry points; the binary64
+ * entry points refuse it. */
+int lsqrhip_create_f32(int m, int n, int64_t nnz, const int *irow, const int *icol, const float *a,
+                       lsqrhip_handle_t *out);
+int lsqrhip_solve_f32(lsqrhip_handle_t h, const float *b, double damp, double atol, double btol, double conlim,
+                      int itnlim, int wantse, int want_log, float *x, float *se, int *istop, int *itn,
+                      double *anorm, double *acond, double *rnorm, double *arnorm, double *xnorm);
+int lsqrhip_aprod_f32(lsqrhip_handle_t h, int mode, float *x, float *y);
+/* b, x, se (and the aprod vectors) already in HBM as real32 arrays; all-real32 handles only (a mixed-mode
+ * handle keeps binary64 vectors on the device: lsqrhip_solve_device / lsqrhip_aprod_device). */
+int lsqrhip_solve_device_f32(lsqrhip_handle_t h, const float *d_b, double damp, double atol, double btol,
+                             double conlim, int itnlim, int wantse, int want_log, float *d_x, float *d_se,
+                             int *istop, int *itn, double *anorm, double *acond, double *rnorm, double *arnorm,
+                             double *xnorm);
+int lsqrhip_aprod_device_f32(lsqrhip_handle_t h, int mode, float *d_x, float *d_y);
+
+/* ---------------------------------------------------------------------- */
 /* aprod_ez                          replaces src/lsqr.f90:134-200          */
 /* ---------------------------------------------------------------------- */
 /* mode 1: y[m] += A x[n] (x unchanged); mode 2: x[n] += A' y[m] (y unchanged). */

@@ -30,6 +30,8 @@ EXPORTS = [
     "lsqrhip_last_timing", "lsqrhip_bench_kernel", "lsqrhip_set_option", "lsqrhip_get_option", "lsqrhip_set_stream", "lsqrhip_dev_alloc",
     "lsqrhip_dev_free", "lsqrhip_dev_upload", "lsqrhip_dev_download", "lsqrhip_dev_sync",
     "lsqrhip_shard_begin", "lsqrhip_shard_stage", "lsqrhip_shard_poll", "lsqrhip_shard_end", "lsqrhip_sum_chunks",
+    "lsqrhip_create_f32", "lsqrhip_solve_f32", "lsqrhip_aprod_f32", "lsqrhip_solve_device_f32",
+    "lsqrhip_aprod_device_f32",
     "lsqrhip_create_sharded", "lsqrhip_rccl_unique_id", "lsqrhip_shard_comm_init", "lsqrhip_shard_solve",
     "lsqrhip_gen_count", "lsqrhip_gen_coo",
     "lsqrhip_create_operator", "lsqrhip_lstp_create", "lsqrhip_lstp_vectors",
@@ -83,6 +85,11 @@ def lib() -> C.CDLL:
     L.lsqrhip_solve.argtypes = solve_args
     L.lsqrhip_solve_device.argtypes = solve_args
     L.lsqrhip_aprod.argtypes = [vp, i32, vp, vp]
+    L.lsqrhip_create_f32.argtypes = [i32, i32, i64, vp, vp, vp, C.POINTER(vp)]
+    L.lsqrhip_solve_f32.argtypes = solve_args
+    L.lsqrhip_aprod_f32.argtypes = [vp, i32, vp, vp]
+    L.lsqrhip_solve_device_f32.argtypes = solve_args
+    L.lsqrhip_aprod_device_f32.argtypes = [vp, i32, vp, vp]
     L.lsqrhip_aprod_device.argtypes = [vp, i32, vp, vp]
     L.lsqrhip_acheck.argtypes = [vp, f64, vp, vp]
     L.lsqrhip_xcheck.argtypes = [vp, f64, f64, f64, vp, vp, vp, vp, vp, vp, vp]

@@ -155,6 +155,7 @@ struct Csr {
     int pw = 0;        // panel width in columns
     int64_t rows_v = 0;  // virtual rows = P * rows (what rowptr / rb / blk index)
     int64_t bytes = 0;
+    int64_t nstored = 0; // value slots of the layout in use (nnz; padded elements of sliced ELL; csb chunks * 256)
     // column-swept row blocks (csb.h), used instead of everything above when `csb` is set
     int csb = 0;
     double *cval = nullptr;       // [nchunks * 256] values, each block sorted by column, padded to whole chunks
@@ -190,6 +191,10 @@ struct lsqrhip_handle_s {
     int m = 0, n = 0;
     int64_t nnz = 0;
     bool off64 = false;
+    bool f32_device_ok = false;  // (internal: lsqrhip_aprod_f32 calls lsqrhip_aprod_device on float vectors)
+    bool io32 = false;  // created by lsqrhip_create_f32 (whether stored as float or, mixed mode, as double)
+    bool f32 = false;   // REAL32 handle: values and the vectors U, V, W, X, SE are float arrays (the pointers below are
+                        // then float* in disguise); arithmetic in registers stays binary64 (lsqrhip_create_f32)
     Csr A, AT;
     double *dict = nullptr;  // <= 256 distinct values of the matrix, ascending bit patterns (valdict.h)
     int ndict = 0;           // 0 = no dictionary
@@ -483,6 +488,7 @@ static int try_sell(hipStream_t s, Csr &out, int64_t nnz, const double *dict, in
     out.col = nullptr;
     out.val = nullptr;
     out.sell = 1;
+    out.nstored = (int64_t)np;
     out.soff = s_off.release<unsigned>();
     out.scol = s_col.release<void>();
     out.sval = s_val.release<void>();
@@ -529,6 +535,7 @@ static int build_csr_T(hipStream_t s, const int *d_keys, const int *d_other, con
     HIPCHK(hipMalloc((void **)&out.col, sizeof(int) * (size_t)std::max<int64_t>(nnz, 1)));
     HIPCHK(hipMalloc((void **)&out.val, sizeof(double) * (size_t)std::max<int64_t>(nnz, 1)));
     out.bytes = (int64_t)sizeof(OffT) * (rows_v + 1) + 12 * nnz;
+    out.nstored = nnz;
 
     HIPCHK(hipMemsetAsync(d_flags, 0, 4 * sizeof(int), s));
     const int g = (int)std::min<int64_t>(std::max<int64_t>((nnz + 255) / 256, 1), 4096);
@@ -849,6 +856,7 @@ static int build_csb(hipStream_t s, const int *rowk, const int *colk, const doub
     out.cptr = s_cptr.release<long long>();
     out.crs = s_rst.release<int>();
     out.nchunks = nchunks;
+    out.nstored = (int64_t)nchunks * CSB_CHUNK;
     out.nrb = nrb;
     out.R = rmax;   // the dummy accumulator's index (blocks hold at most this many rows)
     out.H = H;
@@ -910,11 +918,12 @@ static int alloc_workspace(H *h)
 {
     hipStream_t s = h->stream;
     const size_t m1 = (size_t)std::max(h->m, 1), n1 = (size_t)std::max(h->n, 1);
-    HIPCHK(hipMalloc((void **)&h->U, sizeof(double) * m1));
-    HIPCHK(hipMalloc((void **)&h->V, sizeof(double) * n1));
-    HIPCHK(hipMalloc((void **)&h->W, sizeof(double) * n1));
-    HIPCHK(hipMalloc((void **)&h->X, sizeof(double) * n1));
-    HIPCHK(hipMalloc((void **)&h->SE, sizeof(double) * n1));
+    const size_t esz = h->f32 ? sizeof(float) : sizeof(double);
+    HIPCHK(hipMalloc((void **)&h->U, esz * m1));
+    HIPCHK(hipMalloc((void **)&h->V, esz * n1));
+    HIPCHK(hipMalloc((void **)&h->W, esz * n1));
+    HIPCHK(hipMalloc((void **)&h->X, esz * n1));
+    HIPCHK(hipMalloc((void **)&h->SE, esz * n1));
     HIPCHK(hipMalloc((void **)&h->partials, sizeof(double) * 3 * SPMV_MAX_GRID));
     HIPCHK(hipMalloc((void **)&h->xmax_part, sizeof(double) * VEC_MAX_GRID));
     {
@@ -981,6 +990,25 @@ static int build_dictionary(H *h, const double *d_a, unsigned long long *table, 
     return LSQRHIP_OK;
 }
 
+// REAL32 handle: the layout's 8-byte values become 4-byte ones (the build itself runs in binary64 on the
+// exactly converted inputs; dictionary codes stay codes, the 256-entry table stays binary64).
+static int values_to_f32(H *h, Csr &c)
+{
+    double **slot = c.csb ? &c.cval : (c.sell == 1 && !c.sell_v8 ? (double **)&c.sval : (!c.sell && c.val ? &c.val : nullptr));
+    if (!slot || !*slot || c.nstored <= 0) return LSQRHIP_OK;
+    float *f = nullptr;
+    HIPCHK(hipMalloc((void **)&f, sizeof(float) * (size_t)c.nstored));
+    const int g = (int)std::min<int64_t>((c.nstored + VEC_BLOCK - 1) / VEC_BLOCK, 65535);
+    hipLaunchKernelGGL((k_convert<double, float>), dim3(g), dim3(VEC_BLOCK), 0, h->stream, (const double *)*slot, f,
+                       c.nstored);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
+    (void)hipFree(*slot);
+    *slot = reinterpret_cast<double *>(f);
+    c.bytes -= 4 * c.nstored;
+    return LSQRHIP_OK;
+}
+
 static int finish_create(H *h, const int *d_irow, const int *d_icol, const double *d_a)
 {
     hipStream_t s = h->stream;
@@ -1035,12 +1063,17 @@ static int finish_create(H *h, const int *d_irow, const int *d_icol, const doubl
     // Column-swept row blocks (csb.h) wherever the L2 column panels would have been chosen.
     //   LSQRHIP_CSB   0 never | 1 for every matrix (tests) | unset: instead of L2 panels
     const int cmode = env_int("LSQRHIP_CSB", -1);
-    const bool csb_a = cmode == 1 || (cmode != 0 && pa > 1 && xa == 0);
-    const bool csb_t = cmode == 1 || (cmode != 0 && pt > 1 && xt == 0);
+    // (a REAL32 handle has no panel kernels: scattered columns always go to the column-swept blocks)
+    const bool csb_a = cmode == 1 || (cmode != 0 && pa > 1 && (xa == 0 || h->f32)) || (h->f32 && pa > 1);
+    const bool csb_t = cmode == 1 || (cmode != 0 && pt > 1 && (xt == 0 || h->f32)) || (h->f32 && pt > 1);
     const bool t_first = env_int("LSQRHIP_BUILD_T_FIRST", 0) != 0;   // (experiment: does allocation order show?)
     if (csb_t && t_first) RET(build_csb(s, d_icol, d_irow, d_a, nnz, h->n, h->m, LSQRHIP_ERR_ICOL, LSQRHIP_ERR_IROW, bufA, bufB, hist, d_flags, h->AT));
     if (csb_a) RET(build_csb(s, d_irow, d_icol, d_a, nnz, h->m, h->n, LSQRHIP_ERR_IROW, LSQRHIP_ERR_ICOL, bufA, bufB, hist, d_flags, h->A));
     if (csb_t && !t_first) RET(build_csb(s, d_icol, d_irow, d_a, nnz, h->n, h->m, LSQRHIP_ERR_ICOL, LSQRHIP_ERR_IROW, bufA, bufB, hist, d_flags, h->AT));
+    if (h->f32) {  // ... and row windows over the whole x where a block was too empty for them
+        if (!h->A.csb) { pa = 1; pwa = h->n; xa = 0; }
+        if (!h->AT.csb) { pt = 1; pwt = h->m; xt = 0; }
+    }
     int rc = LSQRHIP_OK;
     if (h->off64) {
         if (!h->A.csb)
@@ -1054,6 +1087,10 @@ static int finish_create(H *h, const int *d_irow, const int *d_icol, const doubl
             rc = build_csr_T<int>(s, d_icol, d_irow, d_a, nnz, h->n, h->m, LSQRHIP_ERR_ICOL, LSQRHIP_ERR_IROW, pt, pwt, xt, bufA, bufB, hist, d_flags, h->dict, h->ndict, h->AT);
     }
     RET(rc);
+    if (h->f32) {
+        RET(values_to_f32(h, h->A));
+        RET(values_to_f32(h, h->AT));
+    }
     return alloc_workspace(h);
 }
 
@@ -1071,6 +1108,9 @@ static int new_handle(int m, int n, int64_t nnz, H **out)
     h->nnz = nnz;
     // 64-bit row pointers from 2^31 nonzeros on (LSQRHIP_OFF64=1 forces them: test hook for that path)
     h->off64 = nnz >= (1ll << 31) || env_int("LSQRHIP_OFF64", 0) != 0;
+    // measurement hook: store values and vectors as float whatever entry point created the handle -- for
+    // lsqrhip_bench_kernel on device-generated systems ONLY (solve entry points then move float vectors)
+    h->f32 = env_int("LSQRHIP_STORE_F32", 0) != 0;
     hipError_t e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         delete h;
@@ -1213,10 +1253,17 @@ static int tune_panel_grids(H *h)
     return LSQRHIP_OK;
 }
 
+#define NOT_F32(h)                                                                                               \
+    do {                                                                                                         \
+        if ((h) && (h)->f32)                                                                                     \
+            return fail(LSQRHIP_ERR_ARG, "REAL32 handle: use lsqrhip_solve_f32 / lsqrhip_aprod_f32 (float vectors)"); \
+    } while (0)
+
 extern "C" int lsqrhip_solve(lsqrhip_handle_t h, const double *b, double damp, double atol, double btol,
                              double conlim, int itnlim, int wantse, int want_log, double *x, double *se, int *istop,
                              int *itn, double *anorm, double *acond, double *rnorm, double *arnorm, double *xnorm)
 {
+    NOT_F32(h);
     return solve_core(h, b, false, damp, atol, btol, conlim, itnlim, wantse, want_log, x, se, false, istop, itn,
                       anorm, acond, rnorm, arnorm, xnorm);
 }
@@ -1226,6 +1273,7 @@ extern "C" int lsqrhip_solve_device(lsqrhip_handle_t h, const double *d_b, doubl
                                     int *istop, int *itn, double *anorm, double *acond, double *rnorm,
                                     double *arnorm, double *xnorm)
 {
+    NOT_F32(h);
     return solve_core(h, d_b, true, damp, atol, btol, conlim, itnlim, wantse, want_log, d_x, d_se, true, istop, itn,
                       anorm, acond, rnorm, arnorm, xnorm);
 }
@@ -1236,6 +1284,7 @@ extern "C" int lsqrhip_solve_device(lsqrhip_handle_t h, const double *d_b, doubl
 extern "C" int lsqrhip_aprod_device(lsqrhip_handle_t h, int mode, double *d_x, double *d_y)
 {
     if (!h) return fail(LSQRHIP_ERR_NOT_INIT, lsqrhip_error_string(LSQRHIP_ERR_NOT_INIT));
+    if (h->f32 && !h->f32_device_ok) NOT_F32(h);
     if (mode != 1 && mode != 2) return fail(LSQRHIP_ERR_MODE, lsqrhip_error_string(LSQRHIP_ERR_MODE));
     if (h->group) return fail(LSQRHIP_ERR_ARG, "a sharded handle takes host vectors: lsqrhip_aprod");
     HIPCHK(hipSetDevice(h->device));
@@ -1254,6 +1303,7 @@ extern "C" int lsqrhip_aprod_device(lsqrhip_handle_t h, int mode, double *d_x, d
 extern "C" int lsqrhip_aprod(lsqrhip_handle_t h, int mode, double *x, double *y)
 {
     if (!h) return fail(LSQRHIP_ERR_NOT_INIT, lsqrhip_error_string(LSQRHIP_ERR_NOT_INIT));
+    NOT_F32(h);
     if (mode != 1 && mode != 2) return fail(LSQRHIP_ERR_MODE, lsqrhip_error_string(LSQRHIP_ERR_MODE));
     if (h->group) return aprod_group_host(h, mode, x, y);
     HIPCHK(hipSetDevice(h->device));
@@ -1370,6 +1420,7 @@ struct DevVec {
 extern "C" int lsqrhip_acheck(lsqrhip_handle_t h, double eps, int *inform, double *relerr)
 {
     if (!h || !inform) return fail(LSQRHIP_ERR_NOT_INIT, lsqrhip_error_string(LSQRHIP_ERR_NOT_INIT));
+    NOT_F32(h);
     HIPCHK(hipSetDevice(h->device));
     const int64_t m = h->m, n = h->n;
     hipStream_t s = h->stream;
@@ -1401,6 +1452,7 @@ extern "C" int lsqrhip_xcheck(lsqrhip_handle_t h, double anorm, double damp, dou
                               const double *x, double *u, double *v, double *w, int *inform, double *tests)
 {
     if (!h || !inform || !tests) return fail(LSQRHIP_ERR_NOT_INIT, lsqrhip_error_string(LSQRHIP_ERR_NOT_INIT));
+    NOT_F32(h);
     HIPCHK(hipSetDevice(h->device));
     const int64_t m = h->m, n = h->n;
     hipStream_t s = h->stream;
@@ -1467,10 +1519,15 @@ extern "C" int lsqrhip_bench_kernel(lsqrhip_handle_t h, int which, int reps, dou
     HIPCHK(hipSetDevice(h->device));
     hipStream_t s = h->stream;
     // operands: finite, small; coefficients that keep them bounded over `reps` launches
-    hipLaunchKernelGGL(k_fill, dim3(h->vgrid_m), dim3(VEC_BLOCK), 0, s, h->U, (int64_t)h->m, 1.0e-3);
-    hipLaunchKernelGGL(k_fill, dim3(h->vgrid_n), dim3(VEC_BLOCK), 0, s, h->V, (int64_t)h->n, 1.0e-3);
-    hipLaunchKernelGGL(k_fill, dim3(h->vgrid_n), dim3(VEC_BLOCK), 0, s, h->W, (int64_t)h->n, 1.0e-3);
-    hipLaunchKernelGGL(k_fill, dim3(h->vgrid_n), dim3(VEC_BLOCK), 0, s, h->X, (int64_t)h->n, 0.0);
+    if (h->f32) {  // (float vectors: zeros will do, no kernel here is data dependent)
+        HIPCHK(hipMemsetAsync(h->U, 0, sizeof(float) * (size_t)std::max(h->m, 1), s));
+        for (double *p : {h->V, h->W, h->X}) HIPCHK(hipMemsetAsync(p, 0, sizeof(float) * (size_t)std::max(h->n, 1), s));
+    } else {
+        hipLaunchKernelGGL(k_fill, dim3(h->vgrid_m), dim3(VEC_BLOCK), 0, s, h->U, (int64_t)h->m, 1.0e-3);
+        hipLaunchKernelGGL(k_fill, dim3(h->vgrid_n), dim3(VEC_BLOCK), 0, s, h->V, (int64_t)h->n, 1.0e-3);
+        hipLaunchKernelGGL(k_fill, dim3(h->vgrid_n), dim3(VEC_BLOCK), 0, s, h->W, (int64_t)h->n, 1.0e-3);
+        hipLaunchKernelGGL(k_fill, dim3(h->vgrid_n), dim3(VEC_BLOCK), 0, s, h->X, (int64_t)h->n, 0.0);
+    }
     LsqrState tmp;
     std::memset(&tmp, 0, sizeof(tmp));
     tmp.t1 = 1.0e-3; tmp.t2 = -0.5; tmp.t3 = 1.0e-3; tmp.sv = 1.0; tmp.su = 1.0;
@@ -1483,8 +1540,12 @@ extern "C" int lsqrhip_bench_kernel(lsqrhip_handle_t h, int which, int reps, dou
     auto one = [&]() {
         if (which == 1) launch_spmv(h, h->A, h->V, h->U, &d_tmp->c1, &d_tmp->stop, nullptr, nullptr, true);
         else if (which == 2) launch_spmv(h, h->AT, h->U, h->V, &d_tmp->c2, &d_tmp->stop, nullptr, nullptr, true);
-        else hipLaunchKernelGGL(k_update, dim3(h->vgrid_n), dim3(VEC_BLOCK), 0, s, h->X, h->W, h->V, h->SE,
-                                (int64_t)h->n, (const LsqrState *)d_tmp, h->partials);
+        else if (h->f32)
+            hipLaunchKernelGGL(k_update<float>, dim3(h->vgrid_n), dim3(VEC_BLOCK), 0, s, (float *)h->X, (float *)h->W,
+                               (const float *)h->V, (float *)h->SE, (int64_t)h->n, (const LsqrState *)d_tmp, h->partials);
+        else
+            hipLaunchKernelGGL(k_update<double>, dim3(h->vgrid_n), dim3(VEC_BLOCK), 0, s, h->X, h->W,
+                               (const double *)h->V, h->SE, (int64_t)h->n, (const LsqrState *)d_tmp, h->partials);
     };
     for (int i = 0; i < 3; ++i) one();  // warm
     HIPCHK(hipEventRecord(h->ev_loop0, s));
@@ -1615,6 +1676,125 @@ extern "C" int lsqrhip_dev_download(void *dst, const void *d_src, int64_t bytes)
 extern "C" int lsqrhip_dev_sync(void)
 {
     HIPCHK(hipDeviceSynchronize());
+    return LSQRHIP_OK;
+}
+
+// ---------------------------------------------------------------------------
+// REAL32: the reference's precision macro (src/lsqr_kinds.F90:16-17: wp = real32)
+// ---------------------------------------------------------------------------
+extern "C" int lsqrhip_create_f32(int m, int n, int64_t nnz, const int *irow, const int *icol, const float *a,
+                                  lsqrhip_handle_t *out)
+{
+    if (!out) return fail(LSQRHIP_ERR_ARG, "null handle pointer");
+    *out = nullptr;
+    if (nnz > 0 && (!irow || !icol || !a)) return fail(LSQRHIP_ERR_SIZES, lsqrhip_error_string(LSQRHIP_ERR_SIZES));
+    RET(use_device());
+    DevScratch sr, sc, sa, sf;
+    const size_t k = (size_t)std::max<int64_t>(nnz, 1);
+    HIPCHK(sr.alloc(sizeof(int) * k));
+    HIPCHK(sc.alloc(sizeof(int) * k));
+    HIPCHK(sa.alloc(sizeof(double) * k));
+    HIPCHK(sf.alloc(sizeof(float) * k));
+    if (nnz > 0) {
+        HIPCHK(hipMemcpy(sr.p, irow, sizeof(int) * (size_t)nnz, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(sc.p, icol, sizeof(int) * (size_t)nnz, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(sf.p, a, sizeof(float) * (size_t)nnz, hipMemcpyHostToDevice));
+        const int g = (int)std::min<int64_t>((nnz + VEC_BLOCK - 1) / VEC_BLOCK, 65535);
+        hipLaunchKernelGGL((k_convert<float, double>), dim3(g), dim3(VEC_BLOCK), 0, 0, (const float *)sf.as<float>(),
+                           sa.as<double>(), nnz);   // exact
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipDeviceSynchronize());
+    }
+    H *h = nullptr;
+    RET(new_handle(m, n, nnz, &h));
+    // all-REAL32 storage on the device unless the mixed mode is asked for (binary64 on the device, real32
+    // at the boundary only: LSQRHIP_REAL32_MIXED=1)
+    h->f32 = env_int("LSQRHIP_REAL32_MIXED", 0) == 0;
+    h->io32 = true;
+    int rc = finish_create(h, sr.as<int>(), sc.as<int>(), sa.as<double>());
+    if (rc == LSQRHIP_OK) rc = tune_panel_grids(h);
+    if (rc != LSQRHIP_OK) {
+        std::string keep = g_last_error;
+        lsqrhip_destroy(h);
+        g_last_error = keep;
+        return rc;
+    }
+    *out = h;
+    return LSQRHIP_OK;
+}
+
+extern "C" int lsqrhip_solve_f32(lsqrhip_handle_t h, const float *b, double damp, double atol, double btol,
+                                 double conlim, int itnlim, int wantse, int want_log, float *x, float *se, int *istop,
+                                 int *itn, double *anorm, double *acond, double *rnorm, double *arnorm, double *xnorm)
+{
+    if (!h) return fail(LSQRHIP_ERR_NOT_INIT, lsqrhip_error_string(LSQRHIP_ERR_NOT_INIT));
+    if (!h->io32) return fail(LSQRHIP_ERR_ARG, "not a handle of lsqrhip_create_f32");
+    if (h->f32)   // float vectors all the way: solve_core moves 4-byte elements for such a handle
+        return solve_core(h, reinterpret_cast<const double *>(b), false, damp, atol, btol, conlim, itnlim, wantse, want_log,
+                          reinterpret_cast<double *>(x), reinterpret_cast<double *>(se), false, istop, itn, anorm, acond,
+                          rnorm, arnorm, xnorm);
+    // mixed mode: binary64 on the device, real32 at the boundary
+    if ((!b && h->m > 0) || (!x && h->n > 0)) return fail(LSQRHIP_ERR_ARG, "null b or x");
+    std::vector<double> bd((size_t)std::max(h->m, 1)), xd((size_t)std::max(h->n, 1)), sd(wantse ? xd.size() : 1);
+    for (int i = 0; i < h->m; ++i) bd[(size_t)i] = (double)b[i];
+    RET(solve_core(h, bd.data(), false, damp, atol, btol, conlim, itnlim, wantse, want_log, xd.data(),
+                   wantse ? sd.data() : nullptr, false, istop, itn, anorm, acond, rnorm, arnorm, xnorm));
+    for (int j = 0; j < h->n; ++j) x[j] = (float)xd[(size_t)j];
+    if (wantse && se)
+        for (int j = 0; j < h->n; ++j) se[j] = (float)sd[(size_t)j];
+    return LSQRHIP_OK;
+}
+
+extern "C" int lsqrhip_solve_device_f32(lsqrhip_handle_t h, const float *d_b, double damp, double atol, double btol,
+                                        double conlim, int itnlim, int wantse, int want_log, float *d_x, float *d_se,
+                                        int *istop, int *itn, double *anorm, double *acond, double *rnorm,
+                                        double *arnorm, double *xnorm)
+{
+    if (!h) return fail(LSQRHIP_ERR_NOT_INIT, lsqrhip_error_string(LSQRHIP_ERR_NOT_INIT));
+    if (!h->f32) return fail(LSQRHIP_ERR_ARG, "not a REAL32 handle (binary64 vectors on the device: lsqrhip_solve_device)");
+    return solve_core(h, reinterpret_cast<const double *>(d_b), true, damp, atol, btol, conlim, itnlim, wantse, want_log,
+                      reinterpret_cast<double *>(d_x), reinterpret_cast<double *>(d_se), true, istop, itn, anorm, acond,
+                      rnorm, arnorm, xnorm);
+}
+
+extern "C" int lsqrhip_aprod_device_f32(lsqrhip_handle_t h, int mode, float *d_x, float *d_y)
+{
+    if (!h) return fail(LSQRHIP_ERR_NOT_INIT, lsqrhip_error_string(LSQRHIP_ERR_NOT_INIT));
+    if (!h->f32) return fail(LSQRHIP_ERR_ARG, "not a REAL32 handle (binary64 vectors on the device: lsqrhip_aprod_device)");
+    h->f32_device_ok = true;
+    const int rc = lsqrhip_aprod_device(h, mode, reinterpret_cast<double *>(d_x), reinterpret_cast<double *>(d_y));
+    h->f32_device_ok = false;
+    return rc;
+}
+
+extern "C" int lsqrhip_aprod_f32(lsqrhip_handle_t h, int mode, float *x, float *y)
+{
+    if (!h) return fail(LSQRHIP_ERR_NOT_INIT, lsqrhip_error_string(LSQRHIP_ERR_NOT_INIT));
+    if (!h->io32) return fail(LSQRHIP_ERR_ARG, "not a handle of lsqrhip_create_f32");
+    if (mode != 1 && mode != 2) return fail(LSQRHIP_ERR_MODE, lsqrhip_error_string(LSQRHIP_ERR_MODE));
+    if (!h->f32) {  // mixed mode
+        std::vector<double> xd((size_t)std::max(h->n, 1)), yd((size_t)std::max(h->m, 1));
+        for (int j = 0; j < h->n; ++j) xd[(size_t)j] = (double)x[j];
+        for (int i = 0; i < h->m; ++i) yd[(size_t)i] = (double)y[i];
+        RET(lsqrhip_aprod(h, mode, xd.data(), yd.data()));
+        if (mode == 1)
+            for (int i = 0; i < h->m; ++i) y[i] = (float)yd[(size_t)i];
+        else
+            for (int j = 0; j < h->n; ++j) x[j] = (float)xd[(size_t)j];
+        return LSQRHIP_OK;
+    }
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    // borrow the solver's work vectors (float arrays): V (n) for x, U (m) for y
+    if (h->n > 0) HIPCHK(hipMemcpyAsync(h->V, x, sizeof(float) * (size_t)h->n, hipMemcpyHostToDevice, s));
+    if (h->m > 0) HIPCHK(hipMemcpyAsync(h->U, y, sizeof(float) * (size_t)h->m, hipMemcpyHostToDevice, s));
+    h->f32_device_ok = true;
+    const int rc = lsqrhip_aprod_device(h, mode, h->V, h->U);
+    h->f32_device_ok = false;
+    RET(rc);
+    if (mode == 1 && h->m > 0) HIPCHK(hipMemcpyAsync(y, h->U, sizeof(float) * (size_t)h->m, hipMemcpyDeviceToHost, s));
+    if (mode == 2 && h->n > 0) HIPCHK(hipMemcpyAsync(x, h->V, sizeof(float) * (size_t)h->n, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
     return LSQRHIP_OK;
 }
 

@@ -70,7 +70,7 @@ static int op_iteration(H *h)
                        (const double *)nullptr, st);
     launch_update(h, h->partials, nullptr, nullptr);
     hipLaunchKernelGGL(k_s3<true>, dim3(1), dim3(SC_BLOCK), 0, s, (const double *)h->partials, h->vgrid_n,
-                       (const double *)nullptr, st, (const double *)h->X, h->d_log);
+                       (const double *)nullptr, st, (const void *)h->X, 0, h->d_log);
     HIPCHK(hipGetLastError());
     return LSQRHIP_OK;
 }

@@ -250,7 +250,14 @@ __global__ __launch_bounds__(SC_BLOCK) void k_s12(const double *p1, int np1, con
 }
 
 // ---- step 3: after the x/w update.  dknorm, norm estimates, stopping tests, istop (:751-810, 843-850)
-__device__ __forceinline__ void s3_step(LsqrState *st, double sum, const double *x, double *log)
+// x(1) for the log, from a vector stored as double or (REAL32 handle) float
+__device__ __forceinline__ double first_of(const void *x, int f32)
+{
+    if (x == nullptr) return 0.0;
+    return f32 ? (double)static_cast<const float *>(x)[0] : static_cast<const double *>(x)[0];
+}
+
+__device__ __forceinline__ void s3_step(LsqrState *st, double sum, double x1, double *log)
 {
     const int itn = st->itn;
     const double rho = st->rho, phi = st->phi, theta = st->theta, tau = st->tau;
@@ -294,9 +301,16 @@ __device__ __forceinline__ void s3_step(LsqrState *st, double sum, const double 
     double t1 = test1 / (1.0 + anorm * xnorm / bnorm);
     const double rtol = st->btol + st->atol * anorm * xnorm / bnorm;
 
-    const double t3 = 1.0 + test3;
-    const double t2 = 1.0 + test2;
+    double t3 = 1.0 + test3;
+    double t2 = 1.0 + test2;
     t1 = 1.0 + t1;
+    if (st->wp32) {
+        // wp = real32 (src/lsqr_kinds.F90:16-17): the reference forms these three sums in real32, i.e. the
+        // "machine precision" stops (src/lsqr.f90:795-797) fire at eps(real32) -- all that real32 vectors can reach
+        t3 = (double)(float)t3;
+        t2 = (double)(float)t2;
+        t1 = (double)(float)t1;
+    }
     int istop = st->istop;
     if (itn >= st->itnlim) istop = 5;
     if (t3 <= 1.0) istop = 4;
@@ -326,7 +340,7 @@ __device__ __forceinline__ void s3_step(LsqrState *st, double sum, const double 
     }
     if (slot >= 0) {
         double *r = log + (size_t)slot * LOG_STRIDE;
-        r[0] = (double)itn; r[1] = x[0]; r[2] = rnorm; r[3] = test1; r[4] = test2; r[5] = anorm;
+        r[0] = (double)itn; r[1] = x1; r[2] = rnorm; r[3] = test1; r[4] = test2; r[5] = anorm;
         r[6] = acond; r[7] = phi; r[8] = dknorm; r[9] = dxk; r[10] = alfopt; r[11] = (double)istop;
         r[12] = rtol; r[13] = xnorm;
     }
@@ -344,13 +358,13 @@ __device__ __forceinline__ void s3_step(LsqrState *st, double sum, const double 
 
 template <bool REDUCE>
 __global__ __launch_bounds__(SC_BLOCK) void k_s3(const double *partials, int np, const double *pre,
-                                                 LsqrState *st, const double *x, double *log)
+                                                 LsqrState *st, const void *x, int xf32, double *log)
 {
     if (st->stop != 0) return;
     __shared__ double red[SC_BLOCK / WAVE];
     const double sum = take_sum<REDUCE>(partials, np, pre, red);
     if (threadIdx.x != 0) return;
-    s3_step(st, sum, x, log);
+    s3_step(st, sum, first_of(x, xf32), log);
 }
 
 // ---- riders -----------------------------------------------------------------------------
@@ -362,7 +376,8 @@ struct Rider {
     int na, nb;
     const double *pa, *pb;
     LsqrState *st;
-    const double *x;     // step 3: x(1) for the log
+    const void *x;       // step 3: x(1) for the log
+    int xf32;            //         ... stored as float (REAL32 handle)
     double *log;
 };
 
@@ -379,7 +394,7 @@ __device__ __forceinline__ void run_rider(const Rider &r, double *red)
     } else if (r.kind == 2) {
         const double sum = take_sum<true>(r.pa, r.na, nullptr, red);
         if (threadIdx.x != 0) return;
-        s3_step(st, sum, r.x, r.log);
+        s3_step(st, sum, first_of(r.x, r.xf32), r.log);
     }
 }
 

@@ -143,7 +143,7 @@ __global__ void k_shard_s3(const double *__restrict__ sums, LsqrState *st, const
                            const double *__restrict__ x, double *__restrict__ log)
 {
     if (*live == 0) return;
-    s3_step(st, (st->t3 * st->t3) * sums[1], x, log);
+    s3_step(st, (st->t3 * st->t3) * sums[1], x != nullptr ? x[0] : 0.0, log);
 }
 
 }  // namespace lsqrhip
@@ -168,6 +168,7 @@ extern "C" int lsqrhip_shard_begin(lsqrhip_handle_t h, const double *d_b_local, 
     if (!d_T || !d_R || !d_V || !d_sums || (!d_b_local && h->m > 0)) return fail(LSQRHIP_ERR_ARG, "null shard buffer");
     if (world < 1 || rank < 0 || rank >= world) return fail(LSQRHIP_ERR_ARG, "bad world / rank");
     if (h->op) return fail(LSQRHIP_ERR_ARG, "the row-sharded solve needs a matrix handle, not an operator");
+    if (h->f32) return fail(LSQRHIP_ERR_ARG, "the row-sharded solve is binary64 only (not a REAL32 handle)");
     HIPCHK(hipSetDevice(h->device));
     hipStream_t s = h->stream;
     ShardCtx &c = h->shard;

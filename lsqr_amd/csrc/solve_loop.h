@@ -64,27 +64,48 @@ struct SpmvArgs {
     hipStream_t stream = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;  // kernel begin/end timestamps (hipExtLaunchKernelGGL)
     NScale nsc{1.0, 1.0};            // power-of-two scale inside the sums of squares (filled in by launch_spmv_args)
+    bool f32 = false;                // x, y, the values and the update's vectors are float arrays (REAL32 handle)
     bool unit_x = false;             // |x * sx| <= 1 is known (solver-internal vectors): csb.h needs no max|x| pass
 };
 
-template <typename OffT, bool PANEL, bool C16, bool V8, bool UPD, bool XL = false>
-static void launch_spmv_C(const SpmvArgs &a, double *y, hipEvent_t e0, hipEvent_t e1)
+template <typename OffT, bool PANEL, bool C16, bool V8, bool UPD, bool XL = false, typename VT = double>
+static void launch_spmv_C(const SpmvArgs &a, double *y_, hipEvent_t e0, hipEvent_t e1)
 {
+    const VT *x = reinterpret_cast<const VT *>(a.x);
+    VT *y = reinterpret_cast<VT *>(y_);
     const Csr &c = *a.c;
     const dim3 grid(c.grid + (a.rider.kind != 0 ? 1 : 0));
     const void *colv = C16 ? (const void *)c.col16 : (const void *)c.col;
     const void *valv = V8 ? (const void *)c.val8 : (const void *)c.val;
     const XlArgs xa{c.rows, c.pw, c.cols, c.skew, c.rel16};
     if (e0 == nullptr && e1 == nullptr)  // plain launch (the only form used under stream capture)
-        hipLaunchKernelGGL((k_spmv_fused<OffT, PANEL, C16, V8, UPD, XL>), grid, dim3(SPMV_BLOCK), 0, a.stream,
+        hipLaunchKernelGGL((k_spmv_fused<OffT, PANEL, C16, V8, UPD, XL, VT>), grid, dim3(SPMV_BLOCK), 0, a.stream,
                            (const OffT *)c.rowptr, colv, (const int *)c.cbase, valv, (const double *)c.dict,
-                           (const RowBlock *)c.blk, c.nblk, a.x, y, a.coef, a.stop, a.pout, a.pin, a.npin, a.slot_in,
+                           (const RowBlock *)c.blk, c.nblk, x, y, a.coef, a.stop, a.pout, a.pin, a.npin, a.slot_in,
                            a.slot_out, a.skip_if_zero, a.rider, a.upd, xa, a.nsc);
     else
-        hipExtLaunchKernelGGL((k_spmv_fused<OffT, PANEL, C16, V8, UPD, XL>), grid, dim3(SPMV_BLOCK), 0, a.stream, e0, e1, 0,
+        hipExtLaunchKernelGGL((k_spmv_fused<OffT, PANEL, C16, V8, UPD, XL, VT>), grid, dim3(SPMV_BLOCK), 0, a.stream, e0, e1, 0,
                               (const OffT *)c.rowptr, colv, (const int *)c.cbase, valv, (const double *)c.dict,
-                              (const RowBlock *)c.blk, c.nblk, a.x, y, a.coef, a.stop, a.pout, a.pin, a.npin,
+                              (const RowBlock *)c.blk, c.nblk, x, y, a.coef, a.stop, a.pout, a.pin, a.npin,
                               a.slot_in, a.slot_out, a.skip_if_zero, a.rider, a.upd, xa, a.nsc);
+}
+
+// row windows of a REAL32 handle (never panelled)
+template <typename OffT>
+static void launch_spmv_F(const SpmvArgs &a, double *y, hipEvent_t e0, hipEvent_t e1)
+{
+    const bool v8 = a.c->val8 != nullptr, c16 = a.c->col16 != nullptr;
+    const int key = (c16 ? 4 : 0) | (v8 ? 2 : 0) | (a.upd.on ? 1 : 0);
+    switch (key) {
+    case 7: launch_spmv_C<OffT, false, true, true, true, false, float>(a, y, e0, e1); break;
+    case 6: launch_spmv_C<OffT, false, true, true, false, false, float>(a, y, e0, e1); break;
+    case 5: launch_spmv_C<OffT, false, true, false, true, false, float>(a, y, e0, e1); break;
+    case 4: launch_spmv_C<OffT, false, true, false, false, false, float>(a, y, e0, e1); break;
+    case 3: launch_spmv_C<OffT, false, false, true, true, false, float>(a, y, e0, e1); break;
+    case 2: launch_spmv_C<OffT, false, false, true, false, false, float>(a, y, e0, e1); break;
+    case 1: launch_spmv_C<OffT, false, false, false, true, false, float>(a, y, e0, e1); break;
+    default: launch_spmv_C<OffT, false, false, false, false, false, float>(a, y, e0, e1); break;
+    }
 }
 
 template <typename OffT, bool PANEL>
@@ -115,38 +136,42 @@ static void launch_spmv_T(const SpmvArgs &a, double *y, hipEvent_t e0, hipEvent_
     }
 }
 
-template <bool C16, bool V8, bool UPD>
+template <bool C16, bool V8, bool UPD, typename VT = double>
 static void launch_sell_C(const SpmvArgs &a)
 {
     const Csr &c = *a.c;
+    const VT *x = reinterpret_cast<const VT *>(a.x);
+    VT *y = reinterpret_cast<VT *>(a.y);
     const dim3 grid(c.grid + (a.rider.kind != 0 ? 1 : 0));
     if (a.e0 == nullptr && a.e1 == nullptr)
-        hipLaunchKernelGGL((k_spmv_sell<C16, V8, UPD>), grid, dim3(SELL_BLOCK), 0, a.stream, (const unsigned *)c.soff,
+        hipLaunchKernelGGL((k_spmv_sell<C16, V8, UPD, VT>), grid, dim3(SELL_BLOCK), 0, a.stream, (const unsigned *)c.soff,
                            (const void *)c.scol, (const int *)c.cbaseS, (const void *)c.sval, (const double *)c.dict,
-                           (const unsigned char *)c.rlen, c.rows, c.nslices, c.nblk, a.x, a.y, a.coef, a.stop, a.pout,
+                           (const unsigned char *)c.rlen, c.rows, c.nslices, c.nblk, x, y, a.coef, a.stop, a.pout,
                            a.pin, a.npin, a.slot_in, a.slot_out, a.skip_if_zero, a.rider, a.upd, a.nsc);
     else
-        hipExtLaunchKernelGGL((k_spmv_sell<C16, V8, UPD>), grid, dim3(SELL_BLOCK), 0, a.stream, a.e0, a.e1, 0,
+        hipExtLaunchKernelGGL((k_spmv_sell<C16, V8, UPD, VT>), grid, dim3(SELL_BLOCK), 0, a.stream, a.e0, a.e1, 0,
                               (const unsigned *)c.soff, (const void *)c.scol, (const int *)c.cbaseS,
                               (const void *)c.sval, (const double *)c.dict, (const unsigned char *)c.rlen, c.rows,
-                              c.nslices, c.nblk, a.x, a.y, a.coef, a.stop, a.pout, a.pin, a.npin, a.slot_in,
+                              c.nslices, c.nblk, x, y, a.coef, a.stop, a.pout, a.pin, a.npin, a.slot_in,
                               a.slot_out, a.skip_if_zero, a.rider, a.upd, a.nsc);
 }
 
-template <bool UPD>
+template <bool UPD, typename VT = double>
 static void launch_sellp(const SpmvArgs &a)
 {
     const Csr &c = *a.c;
+    const VT *x = reinterpret_cast<const VT *>(a.x);
+    VT *y = reinterpret_cast<VT *>(a.y);
     const dim3 grid(c.grid + (a.rider.kind != 0 ? 1 : 0));
     if (a.e0 == nullptr && a.e1 == nullptr)
-        hipLaunchKernelGGL((k_spmv_sellp<UPD>), grid, dim3(SELL_BLOCK), 0, a.stream, (const unsigned *)c.soff,
+        hipLaunchKernelGGL((k_spmv_sellp<UPD, VT>), grid, dim3(SELL_BLOCK), 0, a.stream, (const unsigned *)c.soff,
                            (const uint4 *)c.srec, (const int *)c.cbaseS, (const double *)c.dict, c.rows, c.nslices,
-                           c.nblk, a.x, a.y, a.coef, a.stop, a.pout, a.pin, a.npin, a.slot_in, a.slot_out,
+                           c.nblk, x, y, a.coef, a.stop, a.pout, a.pin, a.npin, a.slot_in, a.slot_out,
                            a.skip_if_zero, a.rider, a.upd, a.nsc);
     else
-        hipExtLaunchKernelGGL((k_spmv_sellp<UPD>), grid, dim3(SELL_BLOCK), 0, a.stream, a.e0, a.e1, 0,
+        hipExtLaunchKernelGGL((k_spmv_sellp<UPD, VT>), grid, dim3(SELL_BLOCK), 0, a.stream, a.e0, a.e1, 0,
                               (const unsigned *)c.soff, (const uint4 *)c.srec, (const int *)c.cbaseS,
-                              (const double *)c.dict, c.rows, c.nslices, c.nblk, a.x, a.y, a.coef, a.stop, a.pout,
+                              (const double *)c.dict, c.rows, c.nslices, c.nblk, x, y, a.coef, a.stop, a.pout,
                               a.pin, a.npin, a.slot_in, a.slot_out, a.skip_if_zero, a.rider, a.upd, a.nsc);
 }
 
@@ -177,13 +202,16 @@ static void launch_xl(const SpmvArgs &a, double *z)
 
 // column-swept row blocks (csb.h).  A product on caller vectors first needs max|x| (the bound on
 // the products that fixes the binary grids of the exact sums); the solver's own vectors are unit.
+template <typename VT>
 static void launch_csb(H *h, const SpmvArgs &a)
 {
     const Csr &c = *a.c;
+    const VT *x = reinterpret_cast<const VT *>(a.x);
+    VT *y = reinterpret_cast<VT *>(a.y);
     CsbX xb{nullptr, 0};
     if (!a.unit_x) {
         const int g = vec_grid(2 * (int64_t)c.cols);
-        hipLaunchKernelGGL(k_amax, dim3(g), dim3(VEC_BLOCK), 0, a.stream, a.x, (int64_t)c.cols, h->xmax_part);
+        hipLaunchKernelGGL(k_amax<VT>, dim3(g), dim3(VEC_BLOCK), 0, a.stream, x, (int64_t)c.cols, h->xmax_part);
         xb.xmax = h->xmax_part;
         xb.nxmax = g;
     }
@@ -206,23 +234,23 @@ static void launch_csb(H *h, const SpmvArgs &a)
         Rider rider = first ? a.rider : Rider{};
         const dim3 grid(std::max(1, std::min(c.grid, (b1 - b0) * S)) + (rider.kind != 0 ? 1 : 0));
         hipEvent_t e0 = first ? a.e0 : nullptr, e1 = (last && S == 1) ? a.e1 : nullptr;
-        auto kern = c.lo32 ? k_spmv_csb<true> : k_spmv_csb<false>;
+        auto kern = c.lo32 ? k_spmv_csb<true, VT> : k_spmv_csb<false, VT>;
         if (e0 == nullptr && e1 == nullptr)
-            hipLaunchKernelGGL(kern, grid, dim3(CSB_BLOCK), 0, a.stream, A, a.x, a.y, a.coef, a.stop, a.pout, a.pin,
+            hipLaunchKernelGGL(kern, grid, dim3(CSB_BLOCK), 0, a.stream, A, x, y, a.coef, a.stop, a.pout, a.pin,
                                a.npin, a.slot_in, a.slot_out, a.skip_if_zero, rider, xb, a.nsc);
         else
-            hipExtLaunchKernelGGL(kern, grid, dim3(CSB_BLOCK), 0, a.stream, e0, e1, 0, A, a.x, a.y, a.coef, a.stop,
+            hipExtLaunchKernelGGL(kern, grid, dim3(CSB_BLOCK), 0, a.stream, e0, e1, 0, A, x, y, a.coef, a.stop,
                                   a.pout, a.pin, a.npin, a.slot_in, a.slot_out, a.skip_if_zero, rider, xb, a.nsc);
         if (last) break;
     }
     if (S > 1) {  // the splits' sums -> y and the blocks' partials (csb.h k_csb_combine)
-        auto comb = c.lo32 ? k_csb_combine<true> : k_csb_combine<false>;
+        auto comb = c.lo32 ? k_csb_combine<true, VT> : k_csb_combine<false, VT>;
         const dim3 grid(std::max(1, std::min(c.nrb, 2 * CSB_GRID)));
         if (a.e1 == nullptr)
-            hipLaunchKernelGGL(comb, grid, dim3(CSB_BLOCK), 0, a.stream, A, a.y, a.coef, a.stop, a.pout, a.pin, a.npin,
+            hipLaunchKernelGGL(comb, grid, dim3(CSB_BLOCK), 0, a.stream, A, y, a.coef, a.stop, a.pout, a.pin, a.npin,
                                a.slot_in, a.skip_if_zero, a.nsc);
         else
-            hipExtLaunchKernelGGL(comb, grid, dim3(CSB_BLOCK), 0, a.stream, nullptr, a.e1, 0, A, a.y, a.coef, a.stop,
+            hipExtLaunchKernelGGL(comb, grid, dim3(CSB_BLOCK), 0, a.stream, nullptr, a.e1, 0, A, y, a.coef, a.stop,
                                   a.pout, a.pin, a.npin, a.slot_in, a.skip_if_zero, a.nsc);
     }
 }
@@ -231,9 +259,34 @@ static void launch_spmv_args(H *h, const SpmvArgs &a_in)
 {
     SpmvArgs a = a_in;
     a.nsc = h->nsc;
+    a.f32 = h->f32;
     const Csr &c = *a.c;
     if (c.csb) {
-        launch_csb(h, a);
+        if (a.f32) launch_csb<float>(h, a);
+        else launch_csb<double>(h, a);
+        return;
+    }
+    if (a.f32) {  // REAL32 handle: float vectors and values (sliced ELL, row windows; never panels)
+        if (c.sell == 2) {
+            if (a.upd.on) launch_sellp<true, float>(a);
+            else launch_sellp<false, float>(a);
+        } else if (c.sell) {
+            const int key = (c.sell_c16 ? 4 : 0) | (c.sell_v8 ? 2 : 0) | (a.upd.on ? 1 : 0);
+            switch (key) {
+            case 7: launch_sell_C<true, true, true, float>(a); break;
+            case 6: launch_sell_C<true, true, false, float>(a); break;
+            case 5: launch_sell_C<true, false, true, float>(a); break;
+            case 4: launch_sell_C<true, false, false, float>(a); break;
+            case 3: launch_sell_C<false, true, true, float>(a); break;
+            case 2: launch_sell_C<false, true, false, float>(a); break;
+            case 1: launch_sell_C<false, false, true, float>(a); break;
+            default: launch_sell_C<false, false, false, float>(a); break;
+            }
+        } else if (h->off64) {
+            launch_spmv_F<long long>(a, a.y, a.e0, a.e1);
+        } else {
+            launch_spmv_F<int>(a, a.y, a.e0, a.e1);
+        }
         return;
     }
     if (c.sell == 2) {  // sliced ELL, packed records (sell.h)
@@ -295,15 +348,23 @@ static void launch_spmv(H *h, const Csr &c, const double *x, double *y, const Sp
     launch_spmv_args(h, a);
 }
 
-static void launch_update(H *h, double *pout, hipEvent_t e0, hipEvent_t e1)
+template <typename VT>
+static void launch_update_T(H *h, double *pout, hipEvent_t e0, hipEvent_t e1)
 {
     hipStream_t s = h->stream;
+    VT *X = reinterpret_cast<VT *>(h->X), *W = reinterpret_cast<VT *>(h->W), *SE = reinterpret_cast<VT *>(h->SE);
+    const VT *V = reinterpret_cast<const VT *>(h->V);
     if (e0)
-        hipExtLaunchKernelGGL(k_update, dim3(h->vgrid_n), dim3(VEC_BLOCK), 0, s, e0, e1, 0, h->X, h->W,
-                              (const double *)h->V, h->SE, (int64_t)h->n, (const LsqrState *)h->d_state, pout);
+        hipExtLaunchKernelGGL(k_update<VT>, dim3(h->vgrid_n), dim3(VEC_BLOCK), 0, s, e0, e1, 0, X, W, V, SE,
+                              (int64_t)h->n, (const LsqrState *)h->d_state, pout);
     else
-        hipLaunchKernelGGL(k_update, dim3(h->vgrid_n), dim3(VEC_BLOCK), 0, s, h->X, h->W, (const double *)h->V, h->SE,
-                           (int64_t)h->n, (const LsqrState *)h->d_state, pout);
+        hipLaunchKernelGGL(k_update<VT>, dim3(h->vgrid_n), dim3(VEC_BLOCK), 0, s, X, W, V, SE, (int64_t)h->n,
+                           (const LsqrState *)h->d_state, pout);
+}
+static void launch_update(H *h, double *pout, hipEvent_t e0, hipEvent_t e1)
+{
+    if (h->f32) launch_update_T<float>(h, pout, e0, e1);
+    else launch_update_T<double>(h, pout, e0, e1);
 }
 
 // ---- sequential schedule: 6 launches ----------------------------------------------------------
@@ -319,7 +380,7 @@ static void launch_iteration_seq(H *h, hipEvent_t *ev)
                        (const double *)nullptr, st);
     launch_update(h, h->partials, ev ? ev[4] : nullptr, ev ? ev[5] : nullptr);
     hipLaunchKernelGGL(k_s3<true>, dim3(1), dim3(SC_BLOCK), 0, s, (const double *)h->partials, h->vgrid_n,
-                       (const double *)nullptr, st, (const double *)h->X, h->d_log);
+                       (const double *)nullptr, st, (const void *)h->X, h->f32 ? 1 : 0, h->d_log);
 }
 
 // ---- rider schedule -------------------------------------------------------------------------
@@ -337,7 +398,7 @@ static Rider rider_s3(H *h)  // step 3 of the iteration whose K4 ran last
     Rider r{};
     r.kind = 2;
     r.pa = h->P3; r.na = h->vgrid_n;
-    r.st = h->d_state; r.x = h->X; r.log = h->d_log;
+    r.st = h->d_state; r.x = h->X; r.xf32 = h->f32 ? 1 : 0; r.log = h->d_log;
     return r;
 }
 
@@ -408,7 +469,7 @@ static int launch_batch(H *h, int i0, int G, hipEvent_t *ev)
                        (const double *)h->P2[il & 1], h->AT.out_grid, st);
     launch_update(h, h->P3, E(G - 1, 4), E(G - 1, 5));
     hipLaunchKernelGGL(k_s3<true>, dim3(1), dim3(SC_BLOCK), 0, s, (const double *)h->P3, h->vgrid_n,
-                       (const double *)nullptr, st, (const double *)h->X, h->d_log);
+                       (const double *)nullptr, st, (const void *)h->X, h->f32 ? 1 : 0, h->d_log);
     return LSQRHIP_OK;
 }
 
@@ -421,15 +482,20 @@ static int enqueue_solve_start(H *h, int wantse)
     hipStream_t s = h->stream;
     const int m = h->m, n = h->n;
     LsqrState *st = h->d_state;
+    const size_t esz = h->f32 ? sizeof(float) : sizeof(double);
     HIPCHK(hipMemcpyAsync(h->d_state, h->h_state, sizeof(LsqrState), hipMemcpyHostToDevice, s));
     if (n > 0) {
-        HIPCHK(hipMemsetAsync(h->V, 0, sizeof(double) * (size_t)n, s));
-        HIPCHK(hipMemsetAsync(h->X, 0, sizeof(double) * (size_t)n, s));
-        HIPCHK(hipMemsetAsync(h->W, 0, sizeof(double) * (size_t)n, s));
-        if (wantse) HIPCHK(hipMemsetAsync(h->SE, 0, sizeof(double) * (size_t)n, s));
+        HIPCHK(hipMemsetAsync(h->V, 0, esz * (size_t)n, s));
+        HIPCHK(hipMemsetAsync(h->X, 0, esz * (size_t)n, s));
+        HIPCHK(hipMemsetAsync(h->W, 0, esz * (size_t)n, s));
+        if (wantse) HIPCHK(hipMemsetAsync(h->SE, 0, esz * (size_t)n, s));
     }
-    hipLaunchKernelGGL(k_sumsq3, dim3(h->vgrid_m), dim3(VEC_BLOCK), 0, s, (const double *)h->U, (int64_t)m,
-                       h->partials);
+    if (h->f32)
+        hipLaunchKernelGGL(k_sumsq3<float>, dim3(h->vgrid_m), dim3(VEC_BLOCK), 0, s, (const float *)h->U, (int64_t)m,
+                           h->partials);
+    else
+        hipLaunchKernelGGL(k_sumsq3<double>, dim3(h->vgrid_m), dim3(VEC_BLOCK), 0, s, (const double *)h->U, (int64_t)m,
+                           h->partials);
     hipLaunchKernelGGL(k_s_init1<true>, dim3(1), dim3(SC_BLOCK), 0, s, (const double *)h->partials, h->vgrid_m,
                        (const double *)nullptr, st, h->slots + 2);
     {
@@ -440,8 +506,12 @@ static int enqueue_solve_start(H *h, int wantse)
     }
     hipLaunchKernelGGL(k_s_init2<true>, dim3(1), dim3(SC_BLOCK), 0, s, (const double *)h->P2[0], h->AT.out_grid,
                        (const double *)nullptr, st);
-    hipLaunchKernelGGL(k_copy_scale, dim3(h->vgrid_n), dim3(VEC_BLOCK), 0, s, h->W, (const double *)h->V, (int64_t)n,
-                       (const LsqrState *)st);
+    if (h->f32)
+        hipLaunchKernelGGL(k_copy_scale<float>, dim3(h->vgrid_n), dim3(VEC_BLOCK), 0, s, (float *)h->W,
+                           (const float *)h->V, (int64_t)n, (const LsqrState *)st);
+    else
+        hipLaunchKernelGGL(k_copy_scale<double>, dim3(h->vgrid_n), dim3(VEC_BLOCK), 0, s, h->W, (const double *)h->V,
+                           (int64_t)n, (const LsqrState *)st);
     return LSQRHIP_OK;
 }
 
@@ -523,6 +593,7 @@ static int upload_initial_state(H *h, double damp, double atol, double btol, dou
     init.cs2 = -1.0;
     init.su = init.sv = 1.0;
     init.ns_inv = h->nsc.inv;
+    init.wp32 = h->f32 ? 1 : 0;
     init.c1.skip = init.c2.skip = init.c2p.skip = 1;
     *h->h_state = init;   // enqueue_solve_start (or the caller) copies it to the device
     return LSQRHIP_OK;
@@ -536,12 +607,18 @@ static int finish_solve(H *h, int wantse, int want_log, double *x, double *se, b
     hipStream_t s = h->stream;
     const int n = h->n;
     lsqrhip_timing_t &tm = h->timing;
-    if (wantse && n > 0)
-        hipLaunchKernelGGL(k_se_finish, dim3(h->vgrid_n), dim3(VEC_BLOCK), 0, s, h->SE, (int64_t)n,
-                           (const LsqrState *)h->d_state);
+    const size_t esz = h->f32 ? sizeof(float) : sizeof(double);   // x, se: float arrays for a REAL32 handle
+    if (wantse && n > 0) {
+        if (h->f32)
+            hipLaunchKernelGGL(k_se_finish<float>, dim3(h->vgrid_n), dim3(VEC_BLOCK), 0, s, (float *)h->SE, (int64_t)n,
+                               (const LsqrState *)h->d_state);
+        else
+            hipLaunchKernelGGL(k_se_finish<double>, dim3(h->vgrid_n), dim3(VEC_BLOCK), 0, s, h->SE, (int64_t)n,
+                               (const LsqrState *)h->d_state);
+    }
     const hipMemcpyKind out_kind = out_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
-    if (n > 0) HIPCHK(hipMemcpyAsync(x, h->X, sizeof(double) * (size_t)n, out_kind, s));
-    if (wantse && n > 0) HIPCHK(hipMemcpyAsync(se, h->SE, sizeof(double) * (size_t)n, out_kind, s));
+    if (n > 0) HIPCHK(hipMemcpyAsync(x, h->X, esz * (size_t)n, out_kind, s));
+    if (wantse && n > 0) HIPCHK(hipMemcpyAsync(se, h->SE, esz * (size_t)n, out_kind, s));
     const LsqrState &r = *h->h_state;
     if (want_log && r.itn > 0) {
         h->log_count = std::min(r.log_count, h->log_cap);
@@ -610,7 +687,7 @@ static int solve_core(H *h, const double *b, bool b_on_device, double damp, doub
     // u = b (solve_ez :242); then the start of the solve (enqueue_solve_start), eagerly or as the head of
     // the first graph
     if (m > 0)
-        HIPCHK(hipMemcpyAsync(h->U, b, sizeof(double) * (size_t)m,
+        HIPCHK(hipMemcpyAsync(h->U, b, (h->f32 ? sizeof(float) : sizeof(double)) * (size_t)m,
                               b_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
     if (!graph) {
         RET(enqueue_solve_start(h, wantse));

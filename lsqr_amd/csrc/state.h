@@ -48,6 +48,7 @@ struct LsqrState {
     double damp, atol, btol, ctol;
     // Golub-Kahan scalars ----------------------------------------------------
     double alpha, beta;
+    int wp32;       // REAL32 handle: the "1 + test <= 1" stops are taken in real32 like the reference's REAL32 build
     double ns_inv;  // fused norms are sqrt(sum of (y * ns)^2) * ns_inv, ns a power of two (scalar.h "range-safe norms")
     double su;  // pending scale of U: u = U * su   (1/beta, or 1 when beta == 0)
     double sv;  // pending scale of V: v = V * sv   (1/alpha, or 1 when alpha == 0)

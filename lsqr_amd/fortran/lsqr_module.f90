@@ -44,6 +44,7 @@ module lsqr_module
       integer  :: itnlim = 100
       integer  :: nout = 0
       type(c_ptr) :: handle = c_null_ptr   !< lsqrhip_handle_t (reference-counted, see assignment)
+      logical  :: io32 = .false.           !< REAL32 build, one GPU: a handle of lsqrhip_create_f32 (real32 on the device)
       logical  :: sharded = .false.        !< rows cut over several GPUs (`initialize(..., ngpu=)`): no iteration log
    contains
       procedure, public :: initialize => initialize_ez
@@ -115,6 +116,36 @@ module lsqr_module
          type(c_ptr), value :: h
          integer(c_int), value :: mode
          real(c_double), intent(inout) :: x(*), y(*)
+         integer(c_int) :: rc
+      end function
+      ! the REAL32 build's entry points (include/lsqrhip.h, "REAL32"): real32 arrays, real32 on the device
+      function lsqrhip_create_f32(m, n, nnz, irow, icol, a, h) bind(C, name='lsqrhip_create_f32') result(rc)
+         import :: c_int, c_int64_t, c_float, c_ptr
+         integer(c_int), value :: m, n
+         integer(c_int64_t), value :: nnz
+         integer(c_int), intent(in) :: irow(*), icol(*)
+         real(c_float), intent(in) :: a(*)
+         type(c_ptr), intent(out) :: h
+         integer(c_int) :: rc
+      end function
+      function lsqrhip_solve_f32(h, b, damp, atol, btol, conlim, itnlim, wantse, want_log, x, se, istop, itn, &
+                                 anorm, acond, rnorm, arnorm, xnorm) bind(C, name='lsqrhip_solve_f32') result(rc)
+         import :: c_int, c_double, c_float, c_ptr
+         type(c_ptr), value :: h
+         real(c_float), intent(in) :: b(*)
+         real(c_double), value :: damp, atol, btol, conlim
+         integer(c_int), value :: itnlim, wantse, want_log
+         real(c_float), intent(out) :: x(*)
+         real(c_float), intent(inout) :: se(*)
+         integer(c_int), intent(out) :: istop, itn
+         real(c_double), intent(out) :: anorm, acond, rnorm, arnorm, xnorm
+         integer(c_int) :: rc
+      end function
+      function lsqrhip_aprod_f32(h, mode, x, y) bind(C, name='lsqrhip_aprod_f32') result(rc)
+         import :: c_int, c_float, c_ptr
+         type(c_ptr), value :: h
+         integer(c_int), value :: mode
+         real(c_float), intent(inout) :: x(*), y(*)
          integer(c_int) :: rc
       end function
       function lsqrhip_log_count(h) bind(C, name='lsqrhip_log_count') result(k)
@@ -220,22 +251,33 @@ contains
       integer, intent(in), optional :: ngpu
       integer(c_int), allocatable :: ir(:), ic(:)
       real(c_double), allocatable :: av(:)
+      real(c_float), allocatable :: af(:)
       integer(c_int64_t) :: nz
 
       if (size(a) /= size(irow) .or. size(a) /= size(icol)) call check(1_c_int)
       ir = irow            ! contiguous copies for the C side
       ic = icol
-      av = a
       nz = int(size(a), c_int64_t)
-      if (size(av) == 0) then
-         deallocate (ir, ic, av)
-         allocate (ir(1), ic(1), av(1))
+      if (size(ir) == 0) then
+         deallocate (ir, ic)
+         allocate (ir(1), ic(1))
       end if
-      if (present(ngpu)) then
-         call check(lsqrhip_create_sharded(int(m, c_int), int(n, c_int), nz, ir, ic, av, int(ngpu, c_int), me%handle))
-         me%sharded = .true.
+      if (wp == c_float .and. .not. present(ngpu)) then
+         ! the REAL32 build: real32 storage on the device too (binary64 in registers only)
+         allocate (af(max(size(a), 1)))
+         af(1:size(a)) = real(a, c_float)
+         call check(lsqrhip_create_f32(int(m, c_int), int(n, c_int), nz, ir, ic, af, me%handle))
+         me%io32 = .true.
       else
-         call check(lsqrhip_create(int(m, c_int), int(n, c_int), nz, ir, ic, av, me%handle))
+         allocate (av(max(size(a), 1)))
+         av(1:size(a)) = real(a, c_double)
+         if (present(ngpu)) then
+            ! (the row-sharded solve is binary64 on the devices in either build)
+            call check(lsqrhip_create_sharded(int(m, c_int), int(n, c_int), nz, ir, ic, av, int(ngpu, c_int), me%handle))
+            me%sharded = .true.
+         else
+            call check(lsqrhip_create(int(m, c_int), int(n, c_int), nz, ir, ic, av, me%handle))
+         end if
       end if
       me%m = m
       me%n = n
@@ -271,6 +313,7 @@ contains
       lhs%atol = rhs%atol; lhs%btol = rhs%btol; lhs%conlim = rhs%conlim
       lhs%itnlim = rhs%itnlim; lhs%nout = rhs%nout
       lhs%sharded = rhs%sharded
+      lhs%io32 = rhs%io32
       lhs%handle = rhs%handle
       if (c_associated(lhs%handle)) rc = lsqrhip_retain(lhs%handle)
    end subroutine copy_ez
@@ -282,15 +325,28 @@ contains
       real(wp), dimension(:), intent(inout) :: x   !! [n]
       real(wp), dimension(:), intent(inout) :: y   !! [m]
       real(c_double), allocatable :: xl(:), yl(:)
+      real(c_float), allocatable :: xf(:), yf(:)
       if (m /= me%m .or. n /= me%n .or. .not. c_associated(me%handle)) call check(4_c_int)
+      if (me%io32) then
+         allocate (xf(max(n, 1)), yf(max(m, 1)))
+         xf(1:n) = real(x(1:n), c_float)
+         yf(1:m) = real(y(1:m), c_float)
+         call check(lsqrhip_aprod_f32(me%handle, int(mode, c_int), xf, yf))
+         if (mode == 1) then
+            y(1:m) = real(yf(1:m), wp)
+         else
+            x(1:n) = real(xf(1:n), wp)
+         end if
+         return
+      end if
       allocate (xl(max(n, 1)), yl(max(m, 1)))
       xl(1:n) = x(1:n)
       yl(1:m) = y(1:m)
       call check(lsqrhip_aprod(me%handle, int(mode, c_int), xl, yl))
       if (mode == 1) then
-         y(1:m) = yl(1:m)
+         y(1:m) = real(yl(1:m), wp)
       else
-         x(1:n) = xl(1:n)
+         x(1:n) = real(xl(1:n), wp)
       end if
    end subroutine aprod_ez
 
@@ -306,20 +362,31 @@ contains
       real(wp), intent(out), optional :: anorm, acond, rnorm, arnorm, xnorm
 
       real(c_double), allocatable :: xl(:), sel(:), bl(:)
+      real(c_float), allocatable :: xf(:), sef(:), bf(:)
       integer(c_int) :: istop_, itn_, wantse, want_log
       real(c_double) :: anorm_, acond_, rnorm_, arnorm_, xnorm_
 
       if (.not. c_associated(me%handle)) call check(4_c_int)
       wantse = merge(1_c_int, 0_c_int, present(se))
       want_log = merge(1_c_int, 0_c_int, me%nout /= 0 .and. .not. me%sharded)
-      allocate (xl(max(me%n, 1)), sel(max(me%n, 1)), bl(max(me%m, 1)))
-      bl(1:me%m) = b
-      call check(lsqrhip_solve(me%handle, bl, real(damp, c_double), real(me%atol, c_double), &
-                               real(me%btol, c_double), real(me%conlim, c_double), int(me%itnlim, c_int), wantse, &
-                               want_log, xl, sel, istop_, itn_, anorm_, acond_, rnorm_, arnorm_, xnorm_))
-      x = xl(1:me%n)
+      if (me%io32) then
+         allocate (xf(max(me%n, 1)), sef(max(me%n, 1)), bf(max(me%m, 1)))
+         bf(1:me%m) = real(b, c_float)
+         call check(lsqrhip_solve_f32(me%handle, bf, real(damp, c_double), real(me%atol, c_double), &
+                                      real(me%btol, c_double), real(me%conlim, c_double), int(me%itnlim, c_int), wantse, &
+                                      want_log, xf, sef, istop_, itn_, anorm_, acond_, rnorm_, arnorm_, xnorm_))
+         x = real(xf(1:me%n), wp)
+         if (present(se)) se = real(sef(1:me%n), wp)
+      else
+         allocate (xl(max(me%n, 1)), sel(max(me%n, 1)), bl(max(me%m, 1)))
+         bl(1:me%m) = b
+         call check(lsqrhip_solve(me%handle, bl, real(damp, c_double), real(me%atol, c_double), &
+                                  real(me%btol, c_double), real(me%conlim, c_double), int(me%itnlim, c_int), wantse, &
+                                  want_log, xl, sel, istop_, itn_, anorm_, acond_, rnorm_, arnorm_, xnorm_))
+         x = real(xl(1:me%n), wp)
+         if (present(se)) se = real(sel(1:me%n), wp)
+      end if
       istop = istop_
-      if (present(se)) se = sel(1:me%n)
       if (present(itn)) itn = itn_
       if (present(anorm)) anorm = anorm_
       if (present(acond)) acond = acond_

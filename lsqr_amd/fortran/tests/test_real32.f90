@@ -1,6 +1,8 @@
 !> The REAL32 build of the host layer (-DREAL32: wp = real32, as src/lsqr_kinds.F90:16-17 of the
-!! reference): user arrays and scalars are real32, the device computes in binary64 on the exactly
-!! converted values, results are rounded to real32.  Prints results for tests/test_fortran.py.
+!! reference): user arrays and scalars are real32 and so is everything stored on the device (matrix
+!! values and u, v, w, x, se); arithmetic in registers is binary64.  LSQRHIP_REAL32_MIXED=1 in the
+!! environment: binary64 storage on the device, real32 at the boundary only.  Prints results for
+!! tests/test_fortran.py.
 program test_real32
    use lsqr_kinds
    use lsqr_module, only: lsqr_solver_ez
@@ -21,6 +23,16 @@ program test_real32
    write (*, '(A,I2,1P,3E16.8)') 'README32 istop,x=', istop, x
    if (istop /= 1) error stop 'TEST FAILED'
    if (any(abs(x - [1.242424_wp, -6.060606e-2_wp, -4.040404e-2_wp]) > 5.0e-6_wp)) error stop 'TEST FAILED'
+   ! aprod in real32 (mode 1: y + A x; mode 2: x + A' y): small integers, exact in any precision
+   block
+      real(wp) :: xx(3), yy(3)
+      xx = real([1, 2, 3], wp); yy = real([1, 1, 1], wp)
+      call s%aprod(1, 3, 3, xx, yy)
+      if (any(yy /= real([1 + 1 + 4 + 9, 1 + 4 + 10 + 198, 1 + 7 + 176 + 27], wp))) error stop 'TEST FAILED: aprod mode 1'
+      xx = real([1, 2, 3], wp); yy = real([1, 0, 2], wp)
+      call s%aprod(2, 3, 3, xx, yy)
+      if (any(xx /= real([1 + 1 + 14, 2 + 2 + 176, 3 + 3 + 18], wp))) error stop 'TEST FAILED: aprod mode 2'
+   end block
    deallocate (x)
 
    ! 5-point stencil with non-integer coefficients, damped, with standard errors

@@ -58,6 +58,7 @@ class lsqr_solver_ez:  # noqa: N801  (name kept from the reference)
         self.conlim = 0.0
         self.itnlim = 100
         self.nout = 0
+        self.real32 = False
 
     def _free(self):
         if getattr(self, "_h", None):
@@ -71,19 +72,24 @@ class lsqr_solver_ez:  # noqa: N801  (name kept from the reference)
             pass
 
     # -- initialize_ez, src/lsqr.f90:91-127 ------------------------------------
-    def initialize(self, m, n, a, irow, icol, atol=None, btol=None, conlim=None, itnlim=None, nout=None):
-        """`me` is intent(out) in the reference (:95): every call starts from the defaults."""
+    def initialize(self, m, n, a, irow, icol, atol=None, btol=None, conlim=None, itnlim=None, nout=None,
+                   real32=False):
+        """`me` is intent(out) in the reference (:95): every call starts from the defaults.
+
+        real32=True is the reference's REAL32 build (src/lsqr_kinds.F90:16-17: wp = real32): a, b, x, se
+        are float32 here and on the device (binary64 in registers only)."""
         self._free()
         self._reset()
-        a = np.ascontiguousarray(a, dtype=np.float64)
+        a = np.ascontiguousarray(a, dtype=np.float32 if real32 else np.float64)
         irow = np.ascontiguousarray(irow, dtype=np.int32)
         icol = np.ascontiguousarray(icol, dtype=np.int32)
         if not (a.size == irow.size == icol.size):                      # :109
             raise LsqrHipError(capi.ERR_SIZES, lib().lsqrhip_error_string(capi.ERR_SIZES).decode())
         h = C.c_void_p()
-        check(lib().lsqrhip_create(int(m), int(n), a.size, irow.ctypes.data, icol.ctypes.data,
-                                   a.ctypes.data, C.byref(h)))         # :110-118
+        create = lib().lsqrhip_create_f32 if real32 else lib().lsqrhip_create
+        check(create(int(m), int(n), a.size, irow.ctypes.data, icol.ctypes.data, a.ctypes.data, C.byref(h)))  # :110-118
         self._h = h
+        self.real32 = bool(real32)
         self.m, self.n, self.num_nonzero_elements = int(m), int(n), int(a.size)
         if atol is not None:
             self.atol = float(atol)                                     # :121-125
@@ -122,18 +128,20 @@ class lsqr_solver_ez:  # noqa: N801  (name kept from the reference)
     # -- solve_ez, src/lsqr.f90:207-259 ----------------------------------------
     def solve(self, b, damp=0.0, wantse=False) -> SolveResult:
         self._need()
-        b = np.ascontiguousarray(b, dtype=np.float64)
+        wp = np.float32 if self.real32 else np.float64
+        b = np.ascontiguousarray(b, dtype=wp)
         if b.shape != (self.m,):
             raise ValueError(f"b must have shape ({self.m},)")          # explicit-shape dummy b(me%m), :213
-        x = np.zeros(max(self.n, 1))
-        se = np.zeros(max(self.n, 1)) if wantse else None
+        x = np.zeros(max(self.n, 1), dtype=wp)
+        se = np.zeros(max(self.n, 1), dtype=wp) if wantse else None
         istop, itn = C.c_int(), C.c_int()
         sc = [C.c_double() for _ in range(5)]
         want_log = 1 if self.nout else 0
-        check(lib().lsqrhip_solve(self._h, b.ctypes.data, float(damp), self.atol, self.btol, self.conlim,
-                                  self.itnlim, int(bool(wantse)), want_log, x.ctypes.data,
-                                  se.ctypes.data if wantse else None, C.addressof(istop), C.addressof(itn),
-                                  *[C.addressof(s) for s in sc]))
+        solve = lib().lsqrhip_solve_f32 if self.real32 else lib().lsqrhip_solve
+        check(solve(self._h, b.ctypes.data, float(damp), self.atol, self.btol, self.conlim,
+                    self.itnlim, int(bool(wantse)), want_log, x.ctypes.data,
+                    se.ctypes.data if wantse else None, C.addressof(istop), C.addressof(itn),
+                    *[C.addressof(s) for s in sc]))
         r = SolveResult(x[:self.n], istop.value, itn.value, *[s.value for s in sc],
                         se=se[:self.n] if wantse else None)
         if self.nout:
@@ -152,14 +160,17 @@ class lsqr_solver_ez:  # noqa: N801  (name kept from the reference)
 
     # -- aprod_ez, src/lsqr.f90:134-200 ----------------------------------------
     def aprod(self, mode, m, n, x, y):
-        """mode 1: y += A x ; mode 2: x += A' y.  x, y are float64 numpy arrays updated in place."""
+        """mode 1: y += A x ; mode 2: x += A' y.  x, y are float64 (real32 build: float32) numpy arrays
+        updated in place."""
         self._need()
         if m != self.m or n != self.n:                                  # :152
             raise LsqrHipError(capi.ERR_NOT_INIT, lib().lsqrhip_error_string(capi.ERR_NOT_INIT).decode())
+        wp = np.float32 if self.real32 else np.float64
         for v, k in ((x, self.n), (y, self.m)):
-            if not (isinstance(v, np.ndarray) and v.dtype == np.float64 and v.flags.c_contiguous and v.size == k):
-                raise ValueError("x, y must be contiguous float64 arrays of length n, m")
-        check(lib().lsqrhip_aprod(self._h, int(mode), x.ctypes.data, y.ctypes.data))  # :197 -> ERR_MODE
+            if not (isinstance(v, np.ndarray) and v.dtype == wp and v.flags.c_contiguous and v.size == k):
+                raise ValueError(f"x, y must be contiguous {np.dtype(wp).name} arrays of length n, m")
+        aprod = lib().lsqrhip_aprod_f32 if self.real32 else lib().lsqrhip_aprod
+        check(aprod(self._h, int(mode), x.ctypes.data, y.ctypes.data))  # :197 -> ERR_MODE
 
     # -- acheck / xcheck, src/lsqr.f90:908-994, 1015-1154 ------------------------
     def acheck(self, eps=_EPS):

@@ -19,10 +19,11 @@ LIB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 
 NUM = r"[-+]?\d\.\d+E[-+]\d+"
 
 
-def run(exe, check=True):
+def run(exe, check=True, env=None):
     path = os.path.join(LIB, exe)
     assert os.path.exists(path), f"{path} missing: run __graft_entry__.build()"
-    return subprocess.run([path], capture_output=True, text=True, timeout=300, check=check)
+    return subprocess.run([path], capture_output=True, text=True, timeout=300, check=check,
+                          env=None if env is None else {**os.environ, **env})
 
 
 def numbers(line):
@@ -206,13 +207,17 @@ def test_fortran_device_operator_and_user_subclass_on_gpu():
 
 
 @pytest.mark.gpu
-def test_real32_build_mixed_precision_on_gpu():
-    """-DREAL32 build of the host layer (wp = real32 like the reference's REAL32 macro): real32 in
-    and out, binary64 on the device.  Against (1) the binary64 oracle on the same real32-valued
-    inputs: agreement to real32 rounding of the outputs; (2) the unmodified reference compiled with
-    -DREAL32 (tests/golden/real32_ref.json): agreement to what an all-real32 iteration can hold."""
+@pytest.mark.parametrize("mode", ["real32", "mixed"])
+def test_real32_build_on_gpu(mode):
+    """-DREAL32 build of the host layer (wp = real32 like the reference's REAL32 macro).
+    "real32" (the default): real32 arrays in, out AND on the device (values, u, v, w, x, se), binary64
+    in registers.  "mixed" (LSQRHIP_REAL32_MIXED=1): binary64 on the device, real32 at the boundary.
+    Against (1) the binary64 oracle on the same real32-valued inputs: mixed agrees to real32 rounding of
+    the outputs, all-real32 to what rounding the vectors once per iteration costs; (2) the unmodified
+    reference compiled with -DREAL32 (tests/golden/real32_ref.json): agreement to what an all-real32
+    iteration can hold, and never further from the binary64 answer than that reference is."""
     import json
-    out = run("test_real32").stdout
+    out = run("test_real32", env={"LSQRHIP_REAL32_MIXED": "1" if mode == "mixed" else "0"}).stdout
     assert "REAL32 TESTS PASSED" in out
     line = {l.split("=")[0].strip(): l for l in out.splitlines() if "=" in l}
     ref32 = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "real32_ref.json")))
@@ -235,19 +240,25 @@ def test_real32_build_mixed_precision_on_gpu():
     o = oracle.port().solve(n, n, irow, icol, a, np.array(b), damp=0.0625, atol=f32(1e-7), btol=f32(1e-7),
                             itnlim=500, wantse=True)
     istop, itn = (int(t) for t in re.findall(r"=\s*(\d+)", line["STENCIL32 istop"]))
-    assert (istop, itn) == (o.istop, o.itn)
     x = numbers(line["STENCIL32 x"])
-    assert np.max(np.abs(x - o.x)) <= 1.2e-7 * np.max(np.abs(o.x))          # real32 rounding of the output
     norms = numbers(line["STENCIL32 norms"])
-    np.testing.assert_allclose(norms[[2, 4]], [o.rnorm, o.xnorm], rtol=1.2e-7)
+    x32 = np.array(ref32["STENCIL32 x"]["nums"])
+    if mode == "mixed":
+        assert (istop, itn) == (o.istop, o.itn)
+        assert np.max(np.abs(x - o.x)) <= 1.2e-7 * np.max(np.abs(o.x))      # real32 rounding of the output
+        np.testing.assert_allclose(norms[[2, 4]], [o.rnorm, o.xnorm], rtol=1.2e-7)
+    else:
+        assert istop == o.istop and abs(itn - o.itn) <= 3
+        assert np.linalg.norm(x - o.x) <= 1e-4 * np.linalg.norm(o.x)
+        assert np.linalg.norm(x - o.x) <= 1.5 * np.linalg.norm(x32 - o.x)  # no worse than the all-real32 reference
+        np.testing.assert_allclose(norms[[2, 4]], [o.rnorm, o.xnorm], rtol=1e-4)
     # anorm / acond are running sums over all 170 Lanczos steps: two binary64 runs that differ in
     # summation order drift apart in them long before they do in x
     np.testing.assert_allclose(norms[[0, 1]], [o.anorm, o.acond], rtol=5e-3)
-    np.testing.assert_allclose(numbers(line["STENCIL32 se"]), o.se[:8], rtol=1e-2)
+    np.testing.assert_allclose(numbers(line["STENCIL32 se"]), o.se[:8], rtol=1e-2 if mode == "mixed" else 3e-2)
     # the all-real32 reference: same stopping reason, same answer to ~1e-4 (it needs 171
     # iterations where binary64 arithmetic needs fewer: its Lanczos vectors lose orthogonality sooner)
     r = ref32["STENCIL32 istop"]["ints"]
-    assert r[0] == istop and itn <= r[1]
-    x32 = np.array(ref32["STENCIL32 x"]["nums"])
+    assert r[0] == istop and itn <= r[1] + 3
     assert np.linalg.norm(x - x32) <= 2e-4 * np.linalg.norm(x32)
     assert np.allclose(numbers(line["README32 istop,x"])[-3:], ref32["README32 istop,x"]["nums"][-3:], rtol=2e-5)
