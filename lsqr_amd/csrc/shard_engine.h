@@ -116,6 +116,8 @@ struct ShardGroup {
     int64_t chunk = 0;
     std::vector<ShardRank> r;      // the ranks driven by this process
     bool owned = false;            // sub-handles belong to the group (single-process form)
+    bool loopback = false;         // exchanges by device copies inside this process instead of RCCL (all ranks are local)
+    std::vector<hipEvent_t> ev;    // loopback: one event per rank
     int poll_every = 16;
 };
 
@@ -124,6 +126,10 @@ static H *lsqrhip_group_rank0(H *h) { return h->group->r[0].h; }
 static void free_group(ShardGroup *g)
 {
     if (!g) return;
+    for (size_t i = 0; i < g->ev.size(); ++i) {
+        (void)hipSetDevice(g->r[i].dev >= 0 ? g->r[i].dev : 0);
+        if (g->ev[i]) (void)hipEventDestroy(g->ev[i]);
+    }
     for (ShardRank &k : g->r) {
         if (k.h) (void)hipSetDevice(k.h->device);
         else if (k.dev >= 0) (void)hipSetDevice(k.dev);
@@ -161,9 +167,53 @@ static int alloc_rank_buffers(ShardGroup &g, ShardRank &k)
 }
 
 // ---- the exchanges -------------------------------------------------------------------------------
+// Loopback (LSQRHIP_SHARD_LOOPBACK=1, single-process groups only; a TEST HARNESS, never chosen by itself): the same
+// three exchanges as device-to-device copies between the ranks' buffers, for nodes with fewer GPUs than ranks --
+// several ranks then share a device, which RCCL refuses.  Everything but the RCCL calls themselves is the
+// production path: stages, buffers, slices, order of the sums.
+static int fence_ranks(ShardGroup &g)  // every rank's stream waits for all that is queued on every other rank's
+{
+    if (g.ev.empty()) {
+        g.ev.assign(g.r.size(), nullptr);
+        for (size_t i = 0; i < g.r.size(); ++i) {
+            HIPCHK(hipSetDevice(g.r[i].h->device));
+            HIPCHK(hipEventCreateWithFlags(&g.ev[i], hipEventDisableTiming));
+        }
+    }
+    for (size_t i = 0; i < g.r.size(); ++i) {
+        HIPCHK(hipSetDevice(g.r[i].h->device));
+        HIPCHK(hipEventRecord(g.ev[i], g.r[i].h->stream));
+    }
+    for (size_t i = 0; i < g.r.size(); ++i) {
+        HIPCHK(hipSetDevice(g.r[i].h->device));
+        for (size_t j = 0; j < g.r.size(); ++j)
+            if (j != i) HIPCHK(hipStreamWaitEvent(g.r[i].h->stream, g.ev[j], 0));
+    }
+    return LSQRHIP_OK;
+}
+
+static int loop_copy(ShardRank &dst, double *d, const double *s, size_t count)
+{
+    if (!count) return LSQRHIP_OK;
+    HIPCHK(hipSetDevice(dst.h->device));
+    HIPCHK(hipMemcpyAsync(d, s, sizeof(double) * count, hipMemcpyDeviceToDevice, dst.h->stream));
+    return LSQRHIP_OK;
+}
+
 static int ex_scalars(ShardGroup &g, int k)  // sums[0..k) <- sum over ranks, in rank order, same bits everywhere
 {
     Rccl *rc = rccl();
+    if (g.P > 1 && g.loopback) {
+        RET(fence_ranks(g));
+        for (ShardRank &q : g.r)
+            for (ShardRank &p : g.r) RET(loop_copy(q, q.gath + 4 * (size_t)p.grank, p.sums, 4));
+        RET(fence_ranks(g));
+        for (ShardRank &q : g.r) {
+            HIPCHK(hipSetDevice(q.h->device));
+            hipLaunchKernelGGL(k_sum_ranks, dim3(1), dim3(4), 0, q.h->stream, (const double *)q.gath, g.P, k, q.sums);
+        }
+        return LSQRHIP_OK;
+    }
     if (g.P > 1) {
         NCCLCHK(rc->GroupStart());
         for (ShardRank &q : g.r) NCCLCHK(rc->AllGather(q.sums, q.gath, 4, ncclDouble, q.comm, q.h->stream));
@@ -185,9 +235,22 @@ static int ex_scatter(ShardGroup &g)  // slice q of every rank's T -> rank q's R
             if (c) HIPCHK(hipMemcpyAsync(q.R, q.T, sizeof(double) * c, hipMemcpyDeviceToDevice, q.h->stream));
         return LSQRHIP_OK;
     }
+    if (g.loopback) {
+        RET(fence_ranks(g));
+        for (ShardRank &q : g.r)
+            for (ShardRank &p : g.r) RET(loop_copy(q, q.R + (size_t)p.grank * c, p.T + (size_t)q.grank * c, c));
+        return fence_ranks(g);
+    }
+    // the rank's own slice never leaves the device; the others go to their owners over all links at once
+    for (ShardRank &q : g.r) {
+        HIPCHK(hipSetDevice(q.h->device));
+        HIPCHK(hipMemcpyAsync(q.R + (size_t)q.grank * c, q.T + (size_t)q.grank * c, sizeof(double) * c,
+                              hipMemcpyDeviceToDevice, q.h->stream));
+    }
     NCCLCHK(rc->GroupStart());
     for (ShardRank &q : g.r)
         for (int peer = 0; peer < g.P; ++peer) {
+            if (peer == q.grank) continue;
             NCCLCHK(rc->Send(q.T + (size_t)peer * c, c, ncclDouble, peer, q.comm, q.h->stream));
             NCCLCHK(rc->Recv(q.R + (size_t)peer * c, c, ncclDouble, peer, q.comm, q.h->stream));
         }
@@ -200,6 +263,18 @@ static int ex_gather(ShardGroup &g, bool x_too, bool se_too)  // in-place all-ga
     Rccl *rc = rccl();
     const size_t c = (size_t)g.chunk;
     if (g.P == 1 || c == 0) return LSQRHIP_OK;
+    if (g.loopback) {
+        RET(fence_ranks(g));
+        for (ShardRank &q : g.r)
+            for (ShardRank &p : g.r) {
+                if (&p == &q) continue;
+                const size_t o = (size_t)p.grank * c;
+                if (!x_too) RET(loop_copy(q, q.V + o, p.V + o, c));
+                if (x_too) RET(loop_copy(q, q.xfull + o, p.xfull + o, c));
+                if (se_too) RET(loop_copy(q, q.sefull + o, p.sefull + o, c));
+            }
+        return fence_ranks(g);
+    }
     NCCLCHK(rc->GroupStart());
     for (ShardRank &q : g.r) {
         if (!x_too) NCCLCHK(rc->AllGather(q.V + (size_t)q.grank * c, q.V, c, ncclDouble, q.comm, q.h->stream));
@@ -220,7 +295,7 @@ static int stage_all(ShardGroup &g, int st)
 static int run_group(ShardGroup &g, double damp, double atol, double btol, double conlim, int itnlim, int wantse,
                      int *istop, int *itn, double *anorm, double *acond, double *rnorm, double *arnorm, double *xnorm)
 {
-    if (g.P > 1 && !rccl()) return fail(LSQRHIP_ERR_HIP, "librccl.so.1 could not be loaded");
+    if (g.P > 1 && !g.loopback && !rccl()) return fail(LSQRHIP_ERR_HIP, "librccl.so.1 could not be loaded");
     for (ShardRank &q : g.r)
         RET(lsqrhip_shard_begin(q.h, q.bloc, g.m, g.P, q.grank, damp, atol, btol, conlim, itnlim, wantse, q.T, q.R, q.V,
                                 q.sums));
@@ -317,11 +392,13 @@ extern "C" int lsqrhip_create_sharded(int m, int n, int64_t nnz, const int *irow
     const int ngpu_asked = ngpu;
     if (nnz > 0 && (!irow || !icol || !a)) return fail(LSQRHIP_ERR_SIZES, lsqrhip_error_string(LSQRHIP_ERR_SIZES));
     const int have = lsqrhip_device_count();
-    if (have < ngpu)
+    // test harness: more ranks than devices, exchanges as device copies inside the process (see fence_ranks)
+    const bool loopback = env_int("LSQRHIP_SHARD_LOOPBACK", 0) != 0 && have >= 1;
+    if (have < ngpu && !loopback)
         return fail(LSQRHIP_ERR_NO_DEVICE, "ngpu = " + std::to_string(ngpu) + " but this node shows " + std::to_string(have) +
                                                " usable gfx950 device(s)");
     ngpu = std::min(ngpu_asked, std::max(m, 1));  // never more row blocks than rows
-    if (ngpu > 1 && !rccl()) return fail(LSQRHIP_ERR_HIP, "librccl.so.1 could not be loaded");
+    if (ngpu > 1 && !loopback && !rccl()) return fail(LSQRHIP_ERR_HIP, "librccl.so.1 could not be loaded");
     // the reference's checks first (src/lsqr.f90:110-111), on the whole system
     for (int64_t k = 0; k < nnz; ++k) {
         if (irow[k] < 1 || irow[k] > m) return fail(LSQRHIP_ERR_IROW, lsqrhip_error_string(LSQRHIP_ERR_IROW));
@@ -357,6 +434,7 @@ extern "C" int lsqrhip_create_sharded(int m, int n, int64_t nnz, const int *irow
     g->n = n;
     g->chunk = ((int64_t)n + ngpu - 1) / ngpu;
     g->owned = true;
+    g->loopback = loopback;
     g->r.resize((size_t)ngpu);
     int rc = LSQRHIP_OK;
     {
@@ -373,7 +451,7 @@ extern "C" int lsqrhip_create_sharded(int m, int n, int64_t nnz, const int *irow
                     la[w] = a[k];
                     ++w;
                 }
-            g_device = dev0 + p;
+            g_device = loopback ? dev0 + p % have : dev0 + p;
             ShardRank &q = g->r[(size_t)p];
             q.grank = p;
             q.row0 = cut[(size_t)p];
@@ -384,7 +462,7 @@ extern "C" int lsqrhip_create_sharded(int m, int n, int64_t nnz, const int *irow
     if (rc == LSQRHIP_OK)
         for (ShardRank &q : g->r)
             if ((rc = alloc_rank_buffers(*g, q)) != LSQRHIP_OK) break;
-    if (rc == LSQRHIP_OK && ngpu > 1) {
+    if (rc == LSQRHIP_OK && ngpu > 1 && !loopback) {
         std::vector<int> devs;
         std::vector<ncclComm_t> comms((size_t)ngpu);
         for (ShardRank &q : g->r) devs.push_back(q.h->device);

@@ -105,15 +105,19 @@ def test_ez_driver_on_gpu_matches_oracle():
 
 
 @pytest.mark.gpu
-def test_sharded_initialize_from_fortran():
+@pytest.mark.parametrize("ngpu", [1, 3])
+def test_sharded_initialize_from_fortran(ngpu):
     """`initialize(..., ngpu=N)`: Fortran -> lsqrhip_create_sharded -> the C++ RCCL engine.  At ngpu = 1 on
-    a one-GPU box against the oracle; asking for more GPUs than the node has must `error stop`."""
+    a one-GPU box against the oracle (and at ngpu = 3 with the exchanges looped back inside the process,
+    LSQRHIP_SHARD_LOOPBACK=1: three ranks on the one device); asking for more GPUs than the node has must
+    `error stop`."""
     path = os.path.join(LIB, "test_sharded")
     assert os.path.exists(path), f"{path} missing: run __graft_entry__.build()"
-    p = subprocess.run([path, "1"], capture_output=True, text=True, timeout=300)
+    env = {**os.environ, "LSQRHIP_SHARD_LOOPBACK": "1" if ngpu > 1 else "0"}
+    p = subprocess.run([path, str(ngpu)], capture_output=True, text=True, timeout=300, env=env)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     out = p.stdout
-    assert "SHARDED TESTS PASSED ngpu=1" in out
+    assert f"SHARDED TESTS PASSED ngpu={ngpu}" in out
     readme = [l for l in out.splitlines() if l.startswith("README istop")][0]
     assert "istop= 1" in readme
     assert np.allclose(numbers(readme), [1.2424242424242424, -6.0606060606060594e-02, -4.0404040404040407e-02],
@@ -129,7 +133,8 @@ def test_sharded_initialize_from_fortran():
     assert np.max(np.abs(xs - want)) <= 1e-10 * np.linalg.norm(o.x, np.inf)
     import torch
     too_many = torch.cuda.device_count() + 1
-    p = subprocess.run([path, str(too_many)], capture_output=True, text=True, timeout=300)
+    env["LSQRHIP_SHARD_LOOPBACK"] = "0"
+    p = subprocess.run([path, str(too_many)], capture_output=True, text=True, timeout=300, env=env)
     assert p.returncode != 0 and "SHARDED TESTS PASSED" not in p.stdout
     assert "no usable MI355X" in (p.stdout + p.stderr) and f"ngpu = {too_many}" in (p.stdout + p.stderr)
 

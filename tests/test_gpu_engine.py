@@ -78,6 +78,66 @@ def test_single_process_sharded_handle_matches_oracle(name):
         check(lib().lsqrhip_destroy(h))
 
 
+@pytest.fixture
+def loopback():
+    import os
+    old = os.environ.get("LSQRHIP_SHARD_LOOPBACK")
+    os.environ["LSQRHIP_SHARD_LOOPBACK"] = "1"
+    yield
+    os.environ.pop("LSQRHIP_SHARD_LOOPBACK", None)
+    if old is not None:
+        os.environ["LSQRHIP_SHARD_LOOPBACK"] = old
+
+
+@pytest.mark.parametrize("ngpu", [2, 3, 8])
+@pytest.mark.parametrize("name", ["random_over_damped", "random_over_se", "random_under", "poisson_20x20_it50",
+                                  "shuffled_dups", "empty_rows_cols_it20", "powerlaw_small_it10", "b_zero", "zero_matrix",
+                                  "one_by_one", "itnlim_1"])
+def test_engine_with_several_ranks_on_one_gpu(loopback, name, ngpu):
+    """The whole C++ engine at world sizes 2, 3 and 8 on ONE device (LSQRHIP_SHARD_LOOPBACK=1: the three
+    exchanges become device copies between the ranks' buffers -- RCCL refuses ranks that share a GPU).  Stages,
+    row blocks, column slices (ragged: n not a multiple of the world; more ranks than rows), the rank-ordered
+    sums and the replicated scalar recurrences are the production code."""
+    p, o = CASES[name]
+    h = sharded_handle(p, ngpu)
+    try:
+        x, se, istop, itn, sc = solve_handle(h, p, o)
+        g = oracle.port().solve(p.m, p.n, p.irow, p.icol, p.a, p.b, **o)
+        assert (istop, itn) == (g.istop, g.itn)
+        nx = np.linalg.norm(g.x)
+        assert (np.linalg.norm(x - g.x) <= 1e-10 * nx) if nx > 0 else not x.any()
+        if g.itn > 0:
+            assert abs(sc[0] - g.anorm) <= 1e-10 * g.anorm
+            assert abs(sc[2] - g.rnorm) <= 1e-10 * g.rnorm or g.rnorm <= 1e-13 * np.linalg.norm(p.b)
+            assert abs(sc[4] - g.xnorm) <= 1e-10 * g.xnorm
+            if o["wantse"]:
+                assert np.linalg.norm(se - g.se) <= 1e-9 * np.linalg.norm(g.se)
+        x2, _, istop2, itn2, sc2 = solve_handle(h, p, o)       # repeats itself bit for bit
+        assert np.array_equal(x2, x) and (istop2, itn2, sc2) == (istop, itn, sc)
+        if p.nnz:
+            xp, yp = np.linspace(-1, 1, p.n), np.linspace(1, 2, p.m)
+            xx, yy = xp.copy(), yp.copy()
+            check(lib().lsqrhip_aprod(h, 2, xx.ctypes.data, yy.ctypes.data))
+            x_ref, _ = oracle.port().aprod(2, p.m, p.n, p.irow, p.icol, p.a, xp, yp)
+            assert np.max(np.abs(xx - x_ref)) <= 1e-13 * max(np.max(np.abs(x_ref)), 1.0)
+    finally:
+        check(lib().lsqrhip_destroy(h))
+
+
+def test_loopback_result_does_not_depend_on_the_world_size_beyond_rounding(loopback):
+    p, o = CASES["poisson_20x20_it50"]
+    xs = []
+    for ngpu in (1, 2, 5):
+        h = sharded_handle(p, ngpu)
+        try:
+            xs.append(solve_handle(h, p, o))
+        finally:
+            check(lib().lsqrhip_destroy(h))
+    for x, _, istop, itn, sc in xs[1:]:
+        assert (istop, itn) == xs[0][2:4]
+        assert np.linalg.norm(x - xs[0][0]) <= 1e-11 * np.linalg.norm(xs[0][0])
+
+
 def test_more_gpus_than_the_node_has_fails_loudly():
     p, _ = CASES["random_over_damped"]
     have = capi.device_count()
@@ -119,3 +179,44 @@ def test_one_rank_world_through_comm_init_and_shard_solve(name):
     s.atol, s.btol, s.conlim, s.itnlim = o["atol"], o["btol"], o["conlim"], o["itnlim"]
     r3 = s.solve(p.b, o["damp"])
     assert r3.istop == g.istop
+
+
+# ---- real RCCL, two ranks: only on a node with at least two GPUs (skipped on the one-GPU test boxes) ----
+def _two_gpus():
+    import torch
+    return torch.cuda.device_count() >= 2
+
+
+@pytest.mark.parametrize("name", ["random_over_se", "poisson_20x20_it50", "empty_rows_cols_it20"])
+def test_rccl_two_gpus_single_process(name):
+    if not _two_gpus():
+        pytest.skip("needs two GPUs (RCCL refuses ranks that share a device)")
+    p, o = CASES[name]
+    h = sharded_handle(p, 2)
+    try:
+        x, se, istop, itn, sc = solve_handle(h, p, o)
+        g = oracle.port().solve(p.m, p.n, p.irow, p.icol, p.a, p.b, **o)
+        assert (istop, itn) == (g.istop, g.itn)
+        assert np.linalg.norm(x - g.x) <= 1e-10 * np.linalg.norm(g.x)
+        if o["wantse"]:
+            assert np.linalg.norm(se - g.se) <= 1e-9 * np.linalg.norm(g.se)
+    finally:
+        check(lib().lsqrhip_destroy(h))
+
+
+def test_rccl_two_ranks_through_bench_launcher():
+    """`bench.py --gpus 2` starts its own two ranks (one process per GPU, RCCL), the C++ engine drives them."""
+    if not _two_gpus():
+        pytest.skip("needs two GPUs")
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {**os.environ, "LSQR_BENCH_STRONG_REF": "0"}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "2",
+                        "--workload", "random:200000:100000:20"], capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["world_size"] == 2 and line["steps"] == 20
+    assert line["result"]["itn"] == 20 and line["value"] > 0
