@@ -207,6 +207,7 @@ struct lsqrhip_handle_s {
     int amax_exp = 0;            // 2^amax_exp > max|a_ij| of THIS matrix (csb.h's bound on the products)
     int vgrid_m = 1, vgrid_n = 1;
     LsqrState *d_state = nullptr;
+    const void **h_bslot = nullptr;  // pinned: where this solve's b lies (k_start reads it through here: vec.h)
     LsqrState *h_state = nullptr;  // pinned; [1], [2] = per-batch snapshots of the look-ahead poll (solve_loop.h)
     SpmvCoef *d_unit = nullptr;    // (1,1,1): plain y += A x
     int *d_zero = nullptr;         // a stop flag that is never set
@@ -363,6 +364,7 @@ extern "C" int lsqrhip_destroy(lsqrhip_handle_t h)
     if (h->shard.live) (void)hipFree(h->shard.live);
     if (h->d_state) (void)hipFree(h->d_state);
     if (h->h_state) (void)hipHostFree(h->h_state);
+    if (h->h_bslot) (void)hipHostFree((void *)h->h_bslot);
     if (h->d_unit) (void)hipFree(h->d_unit);
     if (h->d_zero) (void)hipFree(h->d_zero);
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
@@ -939,6 +941,7 @@ static int alloc_workspace(H *h)
     HIPCHK(hipMemsetAsync(h->slots, 0, sizeof(NormSlot) * 4, s));
     HIPCHK(hipMalloc((void **)&h->d_state, sizeof(LsqrState)));
     HIPCHK(hipHostMalloc((void **)&h->h_state, 3 * sizeof(LsqrState)));
+    HIPCHK(hipHostMalloc((void **)&h->h_bslot, 64));
     for (hipEvent_t &e : h->ev_batch) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HIPCHK(hipMalloc((void **)&h->d_unit, sizeof(SpmvCoef)));
     HIPCHK(hipMalloc((void **)&h->d_zero, sizeof(int)));

@@ -155,11 +155,19 @@ __device__ __forceinline__ void s2_step(LsqrState *st, double alpha_new, bool sk
 
 // after the three Blue sums of b (vec.h k_sumsq3): beta = norm(b); u = b/beta     (src/lsqr.f90:597-617, 632-637)
 // `slot` (optional) receives (beta, 1/beta) for the first pipelined mode-1 launch.
+// `init` (optional): the solve's initial state in pinned host memory, copied into *st first (saves a copy node).
 template <bool REDUCE>
 __global__ __launch_bounds__(SC_BLOCK) void k_s_init1(const double *partials, int np, const double *pre,
-                                                      LsqrState *st, NormSlot *slot)
+                                                      LsqrState *st, NormSlot *slot, const LsqrState *init = nullptr)
 {
     __shared__ double red[SC_BLOCK / WAVE];
+    if (init != nullptr) {
+        static_assert(sizeof(LsqrState) % sizeof(int) == 0, "copied by words");
+        const int *src = reinterpret_cast<const int *>(init);
+        int *dst = reinterpret_cast<int *>(st);
+        for (int i = threadIdx.x; i < (int)(sizeof(LsqrState) / sizeof(int)); i += SC_BLOCK) dst[i] = src[i];
+        __syncthreads();
+    }
     const double beta = take_norm<REDUCE, true>(partials, np, pre, 1.0, red);  // norm(b): Blue's form
     if (threadIdx.x != 0) return;
     st->beta = beta;
@@ -183,14 +191,9 @@ __global__ __launch_bounds__(SC_BLOCK) void k_s_init1(const double *partials, in
 }
 
 // after sum(V^2): alpha = norm(A'u); v = V/alpha; arnorm; loop entry     (:638-653)
-template <bool REDUCE, bool BLUE = false>
-__global__ __launch_bounds__(SC_BLOCK) void k_s_init2(const double *partials, int np, const double *pre,
-                                                      LsqrState *st)
+__device__ __forceinline__ void s_init2_step(LsqrState *st, double nrm)
 {
-    __shared__ double red[SC_BLOCK / WAVE];
     const bool skipped = st->c2.skip != 0;
-    const double nrm = take_norm<REDUCE, BLUE>(partials, np, pre, st->ns_inv, red);
-    if (threadIdx.x != 0) return;
     const double beta = st->beta;
     const double alpha = skipped ? 0.0 : nrm;
     st->alpha = alpha;
@@ -212,6 +215,16 @@ __global__ __launch_bounds__(SC_BLOCK) void k_s_init2(const double *partials, in
     st->c1.sy = st->su;
     st->c1.cy = -alpha;
     st->c1.skip = 0;
+}
+
+template <bool REDUCE, bool BLUE = false>
+__global__ __launch_bounds__(SC_BLOCK) void k_s_init2(const double *partials, int np, const double *pre,
+                                                      LsqrState *st)
+{
+    __shared__ double red[SC_BLOCK / WAVE];
+    const double nrm = take_norm<REDUCE, BLUE>(partials, np, pre, st->ns_inv, red);
+    if (threadIdx.x != 0) return;
+    s_init2_step(st, nrm);
 }
 
 template <bool REDUCE, bool BLUE = false>
@@ -367,12 +380,37 @@ __global__ __launch_bounds__(SC_BLOCK) void k_s3(const double *partials, int np,
     s3_step(st, sum, first_of(x, xf32), log);
 }
 
+// k_s3 at the end of a batch, followed by the snapshot the host polls: the state as it now is -- settled by this
+// very kernel, or long stopped -- written straight into one of two slots in pinned host memory (alternating by
+// batch: the look-ahead poll has two batches in flight).  Replaces a device-to-host copy command behind the
+// batch (~13 us of gap + copy at the end of every batch of a short solve).
+template <bool REDUCE>
+__global__ __launch_bounds__(SC_BLOCK) void k_s3_snap(const double *partials, int np, const double *pre,
+                                                      LsqrState *st, const void *x, int xf32, double *log,
+                                                      LsqrState *snap)
+{
+    __shared__ double red[SC_BLOCK / WAVE];
+    if (st->stop == 0) {  // uniform
+        const double sum = take_sum<REDUCE>(partials, np, pre, red);
+        if (threadIdx.x == 0) s3_step(st, sum, first_of(x, xf32), log);
+    }
+    __syncthreads();
+    const int k = st->batch;
+    const int *src = reinterpret_cast<const int *>(st);
+    int *dst = reinterpret_cast<int *>(snap + (k & 1));
+    for (int i = threadIdx.x; i < (int)(sizeof(LsqrState) / sizeof(int)); i += SC_BLOCK) dst[i] = src[i];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) st->batch = k + 1;
+}
+
 // ---- riders -----------------------------------------------------------------------------
 // The same scalar steps executed by ONE spare workgroup of a long vector kernel (spmv.h):
 // the rider's inputs are complete when its host kernel starts and its outputs are first read
 // by a LATER kernel, so kernel-boundary ordering is all the synchronisation there is.
 struct Rider {
-    int kind;            // 0 none, 1 = steps 1+2 (pa = mode-1 partials, pb = mode-2 partials), 2 = step 3 (pa)
+    int kind;            // 0 none, 1 = steps 1+2 (pa = mode-1 partials, pb = mode-2 partials), 2 = step 3 (pa),
+                         // 3 = k_s_init2 (pa = the mode-2 partials of the start of the solve)
     int na, nb;
     const double *pa, *pb;
     LsqrState *st;
@@ -384,6 +422,12 @@ struct Rider {
 __device__ __forceinline__ void run_rider(const Rider &r, double *red)
 {
     LsqrState *st = r.st;
+    if (r.kind == 3) {   // (runs whatever the stop flag says, like the kernel it stands for)
+        const double sum = take_sum<true>(r.pa, r.na, nullptr, red);
+        if (threadIdx.x != 0) return;
+        s_init2_step(st, sqrt(sum) * st->ns_inv);
+        return;
+    }
     if (st->stop != 0) return;
     if (r.kind == 1) {
         const double sum1 = take_sum<true>(r.pa, r.na, nullptr, red);

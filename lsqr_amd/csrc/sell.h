@@ -220,7 +220,11 @@ __device__ __forceinline__ bool sell_prologue(const SpmvCoef *__restrict__ coef,
             slot_out->nrm = nrm;
             slot_out->scale = k.sx;
         }
-        if (UPD && upd.on) {  // x/w update of the previous iteration (vec.h UpdArgs)
+        if (UPD && upd.on == 2) {  // the first launch of a solve: w <- v / alpha  (src/lsqr.f90:641-644)
+            const XcdRange ur = xcd_range(upd.ugrid, nwg, wg);
+            for (int ub = (int)ur.first; ub < (int)ur.end; ub += (int)ur.stride)
+                winit_block<VT>((VT *)upd.w, (const VT *)upd.V, upd.n, k.sx, ub, upd.ugrid);
+        } else if (UPD && upd.on) {  // x/w update of the previous iteration (vec.h UpdArgs)
             const double beta = slot_in->nrm;
             double alpha = nrm, sv = k.sx;
             if (!(beta > 0.0)) {  // mode 2 was skipped (src/lsqr.f90:691): alpha, v unchanged

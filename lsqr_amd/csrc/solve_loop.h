@@ -402,9 +402,21 @@ static Rider rider_s3(H *h)  // step 3 of the iteration whose K4 ran last
     return r;
 }
 
+static Rider rider_init2(H *h)  // k_s_init2 of the start of a solve (alpha, arnorm, loop entry)
+{
+    Rider r{};
+    r.kind = 3;
+    r.pa = h->P2[0]; r.na = h->AT.out_grid;
+    r.st = h->d_state;
+    return r;
+}
+// The fused schedule (pipeline 2) is used when A is neither panelled nor in column-swept row blocks.
+static bool fused_schedule(const H *h) { return h->pipeline >= 2 && h->A.P <= 1 && !h->A.csb; }
+
 // mode-1 SpMV of iteration i: alpha from the mode-2 partials of iteration i-1
-// `fuse`: the launch also carries the x/w update of iteration i-1 (vec.h UpdArgs)
-static void launch_k1(H *h, int i, const Rider &rider, hipEvent_t e0, hipEvent_t e1, bool fuse = false)
+// `fuse`: 1 = the launch also carries the x/w update of iteration i-1; 2 = the first launch of a solve: it carries
+// w <- v / alpha instead (vec.h UpdArgs)
+static void launch_k1(H *h, int i, const Rider &rider, hipEvent_t e0, hipEvent_t e1, int fuse = 0)
 {
     const int par = i & 1, prev = par ^ 1;
     NormSlot *slotA = h->slots, *slotB = h->slots + 2;
@@ -415,7 +427,7 @@ static void launch_k1(H *h, int i, const Rider &rider, hipEvent_t e0, hipEvent_t
     a.unit_x = true;
     if (fuse) {
         UpdArgs &u = a.upd;
-        u.on = 1;
+        u.on = fuse;
         u.par = (i - 2) & 1;  // the rotation of iteration i-1 reads rhobar2 / phibar2 of iteration i-2
         u.ugrid = h->vgrid_n;
         u.x = h->X; u.w = h->W; u.se = h->SE; u.V = h->V; u.n = h->n;
@@ -440,7 +452,10 @@ static void launch_k2(H *h, int i, const Rider &rider, hipEvent_t e0, hipEvent_t
 
 // G iterations starting at global iteration i0 (1-based).  `ev`: 6 events per iteration
 // (begin/end of K1, K2, K4) or nullptr.
-static int launch_batch(H *h, int i0, int G, hipEvent_t *ev)
+// `solve_start`: the batch follows enqueue_solve_start directly; in the fused schedule its first mode-1 launch
+// then carries k_s_init2 (as a rider) and w <- v / alpha, which enqueue_solve_start leaves out.
+// `snap`: the batch ends with the state written to the pinned snapshot slots (scalar.h k_s3_snap).
+static int launch_batch(H *h, int i0, int G, hipEvent_t *ev, bool solve_start = false, bool snap = false)
 {
     if (!h->pipeline) {
         for (int j = 0; j < G; ++j) launch_iteration_seq(h, ev ? ev + 6 * j : nullptr);
@@ -450,14 +465,15 @@ static int launch_batch(H *h, int i0, int G, hipEvent_t *ev)
     hipStream_t s = h->stream;
     auto E = [&](int j, int k) -> hipEvent_t { return ev ? ev[6 * j + k] : nullptr; };
     const Rider none{};
-    launch_k1(h, i0, none, E(0, 0), E(0, 1));
-    launch_k2(h, i0, none, E(0, 2), E(0, 3));
     // pipeline 2: K4 rides inside K1 (fused update) -- two launches per iteration
-    const bool fuse = h->pipeline >= 2 && h->A.P <= 1 && !h->A.csb;
+    const bool fuse = fused_schedule(h);
+    if (solve_start && fuse) launch_k1(h, i0, rider_init2(h), E(0, 0), E(0, 1), 2);
+    else launch_k1(h, i0, none, E(0, 0), E(0, 1));
+    launch_k2(h, i0, none, E(0, 2), E(0, 3));
     for (int j = 1; j < G; ++j) {
         const int i = i0 + j;
         if (fuse) {
-            launch_k1(h, i, rider_s12(h, i - 1), E(j, 0), E(j, 1), true);  // K1(i) (+) S12(i-1) (+) K4(i-1)
+            launch_k1(h, i, rider_s12(h, i - 1), E(j, 0), E(j, 1), 1);  // K1(i) (+) S12(i-1) (+) K4(i-1)
         } else {
             launch_k1(h, i, rider_s12(h, i - 1), E(j, 0), E(j, 1));   // K1(i)  (+) S12(i-1)
             launch_update(h, h->P3, E(j - 1, 4), E(j - 1, 5));         // K4(i-1)
@@ -465,45 +481,75 @@ static int launch_batch(H *h, int i0, int G, hipEvent_t *ev)
         launch_k2(h, i, rider_s3(h), E(j, 2), E(j, 3));            // K2(i)  (+) S3(i-1)
     }
     const int il = i0 + G - 1;  // settle the last iteration of the batch with plain kernels
-    hipLaunchKernelGGL(k_s12, dim3(1), dim3(SC_BLOCK), 0, s, (const double *)h->P1[il & 1], h->A.out_grid,
-                       (const double *)h->P2[il & 1], h->AT.out_grid, st);
-    launch_update(h, h->P3, E(G - 1, 4), E(G - 1, 5));
-    hipLaunchKernelGGL(k_s3<true>, dim3(1), dim3(SC_BLOCK), 0, s, (const double *)h->P3, h->vgrid_n,
-                       (const double *)nullptr, st, (const void *)h->X, h->f32 ? 1 : 0, h->d_log);
+    if (fuse) {
+        // ... S12(il) (+) K4(il) in one launch: what K1(il + 1) would carry, without its product (scalar.h)
+        const int inext = il + 1, par = inext & 1, prev = par ^ 1;
+        NormSlot *slotA = h->slots, *slotB = h->slots + 2;
+        UpdArgs u{};
+        u.on = 1;
+        u.par = (inext - 2) & 1;
+        u.ugrid = h->vgrid_n;
+        u.x = h->X; u.w = h->W; u.se = h->SE; u.V = h->V; u.n = h->n;
+        u.st = st;
+        u.alpha_prev = &slotA[prev];
+        u.pout = h->P3;
+        const Rider r12 = rider_s12(h, il);
+        const dim3 grid(h->vgrid_n + 1);
+        auto kern = h->f32 ? k_update_lazy<float> : k_update_lazy<double>;
+        if (E(G - 1, 4))
+            hipExtLaunchKernelGGL(kern, grid, dim3(VEC_BLOCK), 0, s, E(G - 1, 4), E(G - 1, 5), 0,
+                                  (const double *)h->P2[prev], h->AT.out_grid, (const NormSlot *)&slotB[prev], u, r12,
+                                  h->nsc, (const int *)&st->stop);
+        else
+            hipLaunchKernelGGL(kern, grid, dim3(VEC_BLOCK), 0, s, (const double *)h->P2[prev], h->AT.out_grid,
+                               (const NormSlot *)&slotB[prev], u, r12, h->nsc, (const int *)&st->stop);
+    } else {
+        hipLaunchKernelGGL(k_s12, dim3(1), dim3(SC_BLOCK), 0, s, (const double *)h->P1[il & 1], h->A.out_grid,
+                           (const double *)h->P2[il & 1], h->AT.out_grid, st);
+        launch_update(h, h->P3, E(G - 1, 4), E(G - 1, 5));
+    }
+    if (snap) {
+        hipLaunchKernelGGL(k_s3_snap<true>, dim3(1), dim3(SC_BLOCK), 0, s, (const double *)h->P3, h->vgrid_n,
+                           (const double *)nullptr, st, (const void *)h->X, h->f32 ? 1 : 0, h->d_log, h->h_state + 1);
+        const int64_t bytes = (int64_t)(h->f32 ? sizeof(float) : sizeof(double)) * h->n;
+        hipLaunchKernelGGL(k_out_copy, dim3(vec_grid(bytes / 8)), dim3(VEC_BLOCK), 0, s, (const LsqrState *)st,
+                           (const void *)h->X, bytes);
+    } else
+        hipLaunchKernelGGL(k_s3<true>, dim3(1), dim3(SC_BLOCK), 0, s, (const double *)h->P3, h->vgrid_n,
+                           (const double *)nullptr, st, (const void *)h->X, h->f32 ? 1 : 0, h->d_log);
     return LSQRHIP_OK;
 }
 
-// The start of a solve on the handle's stream: initial state, u = b is already in U (solve_ez :242);
-// v = 0, x = 0, se = 0 (:621-630); beta = norm(u); u /= beta; v = A'u; alpha = norm(v); v /= alpha; w = v
-// (:632-644).  The mode-2 partials land in P2[0] and (beta, 1/beta) in slot B[0]: exactly what the first
-// lazy mode-1 launch (iteration 1: parity 1, previous parity 0) consumes.  Capturable.
-static int enqueue_solve_start(H *h, int wantse)
+// The start of a solve on the handle's stream (src/lsqr.f90:242, 621-644): u = b (from the address in the pinned
+// slot h->h_bslot), v = x = w = se = 0 and the Blue sums of b in one pass (k_start); beta = norm(u), u /= beta
+// (k_s_init1, which also brings the initial state over from pinned host memory); v = A'u.  Then alpha = norm(v),
+// v /= alpha, w = v: as k_s_init2 + k_copy_scale here, or -- fused schedule, `lean` -- carried by the first mode-1
+// launch of the batch that follows (launch_batch solve_start).  The mode-2 partials land in P2[0] and
+// (beta, 1/beta) in slot B[0]: exactly what the first lazy mode-1 launch (iteration 1: parity 1, previous
+// parity 0) consumes.  Capturable: nothing here depends on the caller's addresses.
+static int enqueue_solve_start(H *h, int wantse, bool lean)
 {
     hipStream_t s = h->stream;
     const int m = h->m, n = h->n;
     LsqrState *st = h->d_state;
-    const size_t esz = h->f32 ? sizeof(float) : sizeof(double);
-    HIPCHK(hipMemcpyAsync(h->d_state, h->h_state, sizeof(LsqrState), hipMemcpyHostToDevice, s));
-    if (n > 0) {
-        HIPCHK(hipMemsetAsync(h->V, 0, esz * (size_t)n, s));
-        HIPCHK(hipMemsetAsync(h->X, 0, esz * (size_t)n, s));
-        HIPCHK(hipMemsetAsync(h->W, 0, esz * (size_t)n, s));
-        if (wantse) HIPCHK(hipMemsetAsync(h->SE, 0, esz * (size_t)n, s));
-    }
+    const int g = std::max(h->vgrid_m, h->vgrid_n);
     if (h->f32)
-        hipLaunchKernelGGL(k_sumsq3<float>, dim3(h->vgrid_m), dim3(VEC_BLOCK), 0, s, (const float *)h->U, (int64_t)m,
-                           h->partials);
+        hipLaunchKernelGGL(k_start<float>, dim3(g), dim3(VEC_BLOCK), 0, s, (const void *const *)h->h_bslot, (float *)h->U,
+                           (int64_t)m, h->vgrid_m, (float *)h->V, (float *)h->X, (float *)nullptr,
+                           wantse ? (float *)h->SE : (float *)nullptr, (int64_t)n, h->partials);
     else
-        hipLaunchKernelGGL(k_sumsq3<double>, dim3(h->vgrid_m), dim3(VEC_BLOCK), 0, s, (const double *)h->U, (int64_t)m,
-                           h->partials);
+        hipLaunchKernelGGL(k_start<double>, dim3(g), dim3(VEC_BLOCK), 0, s, (const void *const *)h->h_bslot, h->U,
+                           (int64_t)m, h->vgrid_m, h->V, h->X, (double *)nullptr, wantse ? h->SE : (double *)nullptr,
+                           (int64_t)n, h->partials);
     hipLaunchKernelGGL(k_s_init1<true>, dim3(1), dim3(SC_BLOCK), 0, s, (const double *)h->partials, h->vgrid_m,
-                       (const double *)nullptr, st, h->slots + 2);
+                       (const double *)nullptr, st, h->slots + 2, (const LsqrState *)h->h_state);
     {
         SpmvArgs a;
         a.c = &h->AT; a.x = h->U; a.y = h->V; a.coef = &st->c2; a.stop = h->d_zero; a.pout = h->P2[0]; a.stream = s;
         a.unit_x = true;
         launch_spmv_args(h, a);
     }
+    if (lean) return LSQRHIP_OK;
     hipLaunchKernelGGL(k_s_init2<true>, dim3(1), dim3(SC_BLOCK), 0, s, (const double *)h->P2[0], h->AT.out_grid,
                        (const double *)nullptr, st);
     if (h->f32)
@@ -522,8 +568,10 @@ static int capture_graph(H *h, int G, bool with_start, int wantse, hipGraphExec_
 {
     hipGraph_t g = nullptr;
     HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-    int rc = with_start ? enqueue_solve_start(h, wantse) : LSQRHIP_OK;
-    if (rc == LSQRHIP_OK) rc = launch_batch(h, 1, G, nullptr);  // parity of iteration 1; G is even when riders are on
+    int rc = with_start ? enqueue_solve_start(h, wantse, fused_schedule(h)) : LSQRHIP_OK;
+    // (parity of iteration 1; G is even with riders.)  Graph batches are what the look-ahead poll launches: they
+    // end with the snapshot.  The plain poll (poll_ahead = 0) reads slot 0 and copies the state itself.
+    if (rc == LSQRHIP_OK) rc = launch_batch(h, 1, G, nullptr, with_start, h->pipeline != 0);
     hipError_t e = hipStreamEndCapture(h->stream, &g);
     RET(rc);
     if (e != hipSuccess) return fail(LSQRHIP_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
@@ -575,7 +623,7 @@ static int prepare_log(H *h, int itnlim, int want_log)
 
 // initial state (src/lsqr.f90:597-617)
 static int upload_initial_state(H *h, double damp, double atol, double btol, double conlim, int itnlim, int wantse,
-                                int want_log)
+                                int want_log, void *xout = nullptr)
 {
     LsqrState init;
     std::memset(&init, 0, sizeof(init));
@@ -594,19 +642,21 @@ static int upload_initial_state(H *h, double damp, double atol, double btol, dou
     init.su = init.sv = 1.0;
     init.ns_inv = h->nsc.inv;
     init.wp32 = h->f32 ? 1 : 0;
+    init.xout = xout;
     init.c1.skip = init.c2.skip = init.c2p.skip = 1;
     *h->h_state = init;   // enqueue_solve_start (or the caller) copies it to the device
     return LSQRHIP_OK;
 }
 
 // epilogue: se (:857-865), istop 2 -> 3 (:871), outputs.  h->h_state holds the settled state.
-static int finish_solve(H *h, int wantse, int want_log, double *x, double *se, bool out_on_device, int *istop,
-                        int *itn, double *anorm, double *acond, double *rnorm, double *arnorm, double *xnorm,
-                        bool timed, std::chrono::steady_clock::time_point t_host0)
+// The copies out (and k_se_finish): everything of the epilogue that needs no host knowledge of the final state.
+// Enqueued behind the loop -- or, when a batch is the last one a solve can have, right behind that batch, before
+// the host has seen its outcome: kernels past the stop change nothing, so x and se are final either way, and
+// the host then waits once instead of twice.
+static int enqueue_outputs(H *h, int wantse, double *x, double *se, bool out_on_device)
 {
     hipStream_t s = h->stream;
     const int n = h->n;
-    lsqrhip_timing_t &tm = h->timing;
     const size_t esz = h->f32 ? sizeof(float) : sizeof(double);   // x, se: float arrays for a REAL32 handle
     if (wantse && n > 0) {
         if (h->f32)
@@ -616,16 +666,40 @@ static int finish_solve(H *h, int wantse, int want_log, double *x, double *se, b
             hipLaunchKernelGGL(k_se_finish<double>, dim3(h->vgrid_n), dim3(VEC_BLOCK), 0, s, h->SE, (int64_t)n,
                                (const LsqrState *)h->d_state);
     }
-    const hipMemcpyKind out_kind = out_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
-    if (n > 0) HIPCHK(hipMemcpyAsync(x, h->X, esz * (size_t)n, out_kind, s));
-    if (wantse && n > 0) HIPCHK(hipMemcpyAsync(se, h->SE, esz * (size_t)n, out_kind, s));
+    if (out_on_device) {  // a kernel of our own: starts ~6 us sooner behind the loop than a copy command does
+        const int g = vec_grid((int64_t)(esz * (size_t)n / 8));
+        if (n > 0)
+            hipLaunchKernelGGL(k_copy_bytes, dim3(g), dim3(VEC_BLOCK), 0, s, (const void *)h->X, (void *)x,
+                               (int64_t)(esz * (size_t)n));
+        if (wantse && n > 0)
+            hipLaunchKernelGGL(k_copy_bytes, dim3(g), dim3(VEC_BLOCK), 0, s, (const void *)h->SE, (void *)se,
+                               (int64_t)(esz * (size_t)n));
+        HIPCHK(hipGetLastError());
+        return LSQRHIP_OK;
+    }
+    if (n > 0) HIPCHK(hipMemcpyAsync(x, h->X, esz * (size_t)n, hipMemcpyDeviceToHost, s));
+    if (wantse && n > 0) HIPCHK(hipMemcpyAsync(se, h->SE, esz * (size_t)n, hipMemcpyDeviceToHost, s));
+    return LSQRHIP_OK;
+}
+
+// `outputs_done`: 0 = not enqueued yet; 1 = enqueued, the stream may still be running them; 2 = enqueued AND the
+// host has already waited for them.
+static int finish_solve(H *h, int wantse, int want_log, double *x, double *se, bool out_on_device, int *istop,
+                        int *itn, double *anorm, double *acond, double *rnorm, double *arnorm, double *xnorm,
+                        bool timed, std::chrono::steady_clock::time_point t_host0, int outputs_done = 0)
+{
+    hipStream_t s = h->stream;
+    lsqrhip_timing_t &tm = h->timing;
+    if (!outputs_done) RET(enqueue_outputs(h, wantse, x, se, out_on_device));
     const LsqrState &r = *h->h_state;
+    bool need_sync = outputs_done != 2;
     if (want_log && r.itn > 0) {
+        need_sync = true;
         h->log_count = std::min(r.log_count, h->log_cap);
         h->h_log.resize((size_t)h->log_count * LOG_STRIDE);
         HIPCHK(hipMemcpyAsync(h->h_log.data(), h->d_log, sizeof(double) * h->h_log.size(), hipMemcpyDeviceToHost, s));
     }
-    HIPCHK(hipStreamSynchronize(s));
+    if (need_sync) HIPCHK(hipStreamSynchronize(s));
     float loop_ms = 0;
     (void)hipEventElapsedTime(&loop_ms, h->ev_loop0, h->ev_loop1);
     tm.loop_ms = loop_ms;
@@ -674,23 +748,25 @@ static int solve_core(H *h, const double *b, bool b_on_device, double damp, doub
     const int m = h->m, n = h->n;
     LsqrState *st = h->d_state;
 
-    RET(prepare_log(h, itnlim, want_log));
-    RET(upload_initial_state(h, damp, atol, btol, conlim, itnlim, wantse, want_log));
-
     int G = std::max(1, h->graph_iters);
     if (h->pipeline) G = (G + 1) & ~1;  // even: parity-consistent batches
     const bool timed = h->time_kernels != 0;
-    const bool fused_update = h->pipeline >= 2 && h->A.P <= 1 && !h->A.csb;
+    const bool fused_update = fused_schedule(h);
     const bool graph = h->use_graph != 0 && !timed;
+    // x of a device-resident solve is copied out by the batch that raises the stop flag (vec.h k_out_copy)
+    const bool dev_out = graph && h->poll_ahead && h->pipeline != 0 && out_on_device && !wantse && h->n > 0;
+    RET(prepare_log(h, itnlim, want_log));
+    RET(upload_initial_state(h, damp, atol, btol, conlim, itnlim, wantse, want_log, dev_out ? (void *)x : nullptr));
+
     if (graph) RET(ensure_graph(h, G, wantse));   // before anything of THIS solve is enqueued (capture)
 
-    // u = b (solve_ez :242); then the start of the solve (enqueue_solve_start), eagerly or as the head of
-    // the first graph
-    if (m > 0)
-        HIPCHK(hipMemcpyAsync(h->U, b, (h->f32 ? sizeof(float) : sizeof(double)) * (size_t)m,
-                              b_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
+    // u = b (solve_ez :242): k_start reads b through the pinned slot -- a device b where it lies, a host b after
+    // its upload into U; then the start of the solve (enqueue_solve_start), eagerly or as the head of the first graph
+    if (m > 0 && !b_on_device)
+        HIPCHK(hipMemcpyAsync(h->U, b, (h->f32 ? sizeof(float) : sizeof(double)) * (size_t)m, hipMemcpyHostToDevice, s));
+    *h->h_bslot = (m > 0 && b_on_device) ? (const void *)b : (const void *)h->U;
     if (!graph) {
-        RET(enqueue_solve_start(h, wantse));
+        RET(enqueue_solve_start(h, wantse, fused_schedule(h)));
         HIPCHK(hipGetLastError());
     }
 
@@ -716,9 +792,21 @@ static int solve_core(H *h, const double *b, bool b_on_device, double damp, doub
         // the wait, the check and the next graph launch (~80 us per batch of 50 at config 2)
         // overlap device work.  Never beyond itnlim; after a stop inside batch k the kernels of
         // batch k+1 return at their first instruction (stop flag) and change nothing.
+        int64_t outputs_in = -1;   // the batch the outputs were enqueued behind (enqueue_outputs), if any
+        bool loop1 = false;
         auto enqueue = [&](int64_t k) -> int {
             HIPCHK(hipGraphLaunch(k == 0 ? h->gexec_first : h->gexec, s));
-            HIPCHK(hipMemcpyAsync(h->h_state + 1 + (k & 1), st, sizeof(LsqrState), hipMemcpyDeviceToHost, s));
+            // the snapshot in h_state[1 + (k & 1)]: written by the batch's last kernel itself (k_s3_snap), or copied
+            if (!h->pipeline)
+                HIPCHK(hipMemcpyAsync(h->h_state + 1 + (k & 1), st, sizeof(LsqrState), hipMemcpyDeviceToHost, s));
+            if ((k + 1) * G >= (int64_t)itnlim) {   // no batch can follow this one
+                HIPCHK(hipEventRecord(h->ev_loop1, s));
+                loop1 = true;
+                if (!dev_out) {
+                    RET(enqueue_outputs(h, wantse, x, se, out_on_device));
+                    outputs_in = k;
+                }
+            }
             HIPCHK(hipEventRecord(h->ev_batch[k & 1], s));
             return LSQRHIP_OK;
         };
@@ -737,6 +825,13 @@ static int solve_core(H *h, const double *b, bool b_on_device, double damp, doub
         // the settled state: the snapshot taken behind the stopping batch (a batch enqueued past the stop
         // returns at its stop-flag tests and has not touched it)
         *h->h_state = h->h_state[1 + (stopped_in & 1)];
+        if (!loop1) HIPCHK(hipEventRecord(h->ev_loop1, s));
+        if (dev_out)   // x was copied by the batch whose snapshot showed the stop, and that batch's event has been
+                       // waited for; a batch enqueued behind it (look-ahead) repeats the copy: wait for that one too
+            return finish_solve(h, wantse, want_log, x, se, out_on_device, istop, itn, anorm, acond, rnorm, arnorm,
+                                xnorm, timed, t_host0, (stopped_in + 1) * G < (int64_t)itnlim ? 1 : 2);
+        return finish_solve(h, wantse, want_log, x, se, out_on_device, istop, itn, anorm, acond, rnorm, arnorm, xnorm,
+                            timed, t_host0, outputs_in < 0 ? 0 : (outputs_in == stopped_in ? 2 : 1));
     } else {
         for (int64_t batch = 0;; ++batch) {
             if (batch > max_batches)
@@ -744,7 +839,7 @@ static int solve_core(H *h, const double *b, bool b_on_device, double damp, doub
             if (graph) {
                 HIPCHK(hipGraphLaunch(batch == 0 ? h->gexec_first : h->gexec, s));
             } else {
-                RET(launch_batch(h, 1 + (int)(batch * G), G, timed ? h->ev.data() : nullptr));
+                RET(launch_batch(h, 1 + (int)(batch * G), G, timed ? h->ev.data() : nullptr, batch == 0));
                 HIPCHK(hipGetLastError());
             }
             HIPCHK(hipMemcpyAsync(h->h_state, st, sizeof(LsqrState), hipMemcpyDeviceToHost, s));

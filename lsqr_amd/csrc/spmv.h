@@ -282,7 +282,11 @@ __global__ __launch_bounds__(SPMV_BLOCK, XL ? 2 : 8) void k_spmv_fused(
             slot_out->nrm = nrm;
             slot_out->scale = sx;
         }
-        if (UPD && upd.on) {  // x/w update of the previous iteration (vec.h UpdArgs)
+        if (UPD && upd.on == 2) {  // the first launch of a solve: w <- v / alpha  (src/lsqr.f90:641-644)
+            const XcdRange ur = xcd_range(upd.ugrid, nwg, wg);
+            for (int ub = (int)ur.first; ub < (int)ur.end; ub += (int)ur.stride)
+                winit_block<VT>((VT *)upd.w, (const VT *)upd.V, upd.n, sx, ub, upd.ugrid);
+        } else if (UPD && upd.on) {  // x/w update of the previous iteration (vec.h UpdArgs)
             const double beta = slot_in->nrm;
             double alpha = nrm, sv = sx;
             if (!(beta > 0.0)) {  // mode 2 was skipped (src/lsqr.f90:691): alpha, v unchanged
@@ -590,6 +594,37 @@ __global__ __launch_bounds__(SPMV_BLOCK) void k_panel_combine(
     }
     const double tot = block_sum<SPMV_BLOCK>(sq, red);
     if (threadIdx.x == 0) partials[blockIdx.x] = tot;
+}
+
+// The tail of a batch in the fused schedule: the x/w update of the batch's last iteration with the rotation
+// taken lazily, exactly as the next mode-1 launch would take it (sell.h sell_prologue / spmv.h: alpha from the
+// mode-2 partials, beta from the slot the mode-2 launch published, rhobar / phibar by parity), and steps 1+2 of
+// that iteration as the rider (block 0) -- one launch where k_s12 and then k_update ran.  Same functions on the
+// same inputs: the same bits.
+template <typename VT>
+__global__ __launch_bounds__(VEC_BLOCK) void k_update_lazy(const double *__restrict__ pin, int npin,
+                                                           const NormSlot *__restrict__ slot_in, UpdArgs upd, Rider rider,
+                                                           NScale nsc, const int *__restrict__ stop)
+{
+    __shared__ double red[VEC_BLOCK / WAVE + 1];
+    const int wg = (int)blockIdx.x - 1;
+    if (wg < 0) {
+        run_rider(rider, red);
+        return;
+    }
+    if (*stop != 0) return;
+    const double nrm = sqrt(block_sum_all<VEC_BLOCK>(pin, npin, red)) * nsc.inv;
+    const double beta = slot_in->nrm;
+    double alpha = nrm, sv = nrm > 0.0 ? 1.0 / nrm : 1.0;
+    if (!(beta > 0.0)) {  // mode 2 was skipped (src/lsqr.f90:691): alpha, v unchanged
+        alpha = upd.alpha_prev->nrm;
+        sv = upd.alpha_prev->scale;
+    }
+    const LsqrState *ust = upd.st;
+    const Rot rt = rot_step(ust->rhobar2[upd.par], ust->phibar2[upd.par], ust->damp, ust->damped, alpha, beta);
+    const double tot = update_block<VT>((VT *)upd.x, (VT *)upd.w, (const VT *)upd.V, (VT *)upd.se, upd.n, rt.t1, rt.t2,
+                                        rt.t3, sv, ust->wantse != 0, wg, upd.ugrid, red);
+    if (threadIdx.x == 0) upd.pout[wg] = tot;
 }
 
 }  // namespace lsqrhip

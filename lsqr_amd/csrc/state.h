@@ -48,6 +48,8 @@ struct LsqrState {
     double damp, atol, btol, ctol;
     // Golub-Kahan scalars ----------------------------------------------------
     double alpha, beta;
+    void *xout;     // device address x goes to when the stop flag rises (vec.h k_out_copy), or null
+    int batch;      // batches settled so far in this solve (k_s3 with a snapshot: which of the two host slots is next)
     int wp32;       // REAL32 handle: the "1 + test <= 1" stops are taken in real32 like the reference's REAL32 build
     double ns_inv;  // fused norms are sqrt(sum of (y * ns)^2) * ns_inv, ns a power of two (scalar.h "range-safe norms")
     double su;  // pending scale of U: u = U * su   (1/beta, or 1 when beta == 0)

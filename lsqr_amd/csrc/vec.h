@@ -101,8 +101,30 @@ __global__ __launch_bounds__(VEC_BLOCK) void k_update(
     if (threadIdx.x == 0) partials[blockIdx.x] = tot;
 }
 
+// w <- V * sv, the first w of the recurrence (src/lsqr.f90:641-644), in update_block's decomposition: what the
+// FIRST lazy mode-1 launch of a solve carries in place of an x/w update (UpdArgs.on == 2).  The values are
+// k_copy_scale's, bit for bit.
+template <typename VT>
+__device__ __forceinline__ void winit_block(VT *__restrict__ w, const VT *__restrict__ V, int64_t n, double sv, int ub,
+                                            int ugrid)
+{
+    typedef typename Vec2<VT>::type V2T;
+    const int64_t n2 = n >> 1;
+    const int64_t stride = (int64_t)ugrid * VEC_BLOCK;
+    V2T *w2 = reinterpret_cast<V2T *>(w);
+    const V2T *V2 = reinterpret_cast<const V2T *>(V);
+    for (int64_t i = (int64_t)ub * VEC_BLOCK + threadIdx.x; i < n2; i += stride) {
+        const V2T vv = V2[i];
+        V2T wn;
+        wn.x = (VT)((double)vv.x * sv);
+        wn.y = (VT)((double)vv.y * sv);
+        w2[i] = wn;
+    }
+    if ((n & 1) && ub == 0 && threadIdx.x == 0) w[n - 1] = (VT)((double)V[n - 1] * sv);
+}
+
 // The x/w update of the PREVIOUS iteration carried by a lazy mode-1 SpMV launch ("fused
-// update", solve_loop.h).  on = 0: nothing to do.
+// update", solve_loop.h).  on = 0: nothing to do; on = 2: the first launch of a solve, w <- V sv instead.
 struct UpdArgs {
     int on;
     int par;      // parity of the rotation inputs: st->rhobar2[par], st->phibar2[par]
@@ -166,6 +188,76 @@ __global__ __launch_bounds__(VEC_BLOCK) void k_sumsq3(const VT *__restrict__ x, 
     }
 }
 
+// The start of a solve in ONE pass (src/lsqr.f90:242, 621-637): u = b, v = x (= se) = 0 -- w is written whole by
+// whoever forms the first w = v / alpha (k_copy_scale or winit_block), W may be null -- and the three Blue
+// sums of b with k_sumsq3's decomposition over g = sgrid workgroups (same partials, bit for bit); the grid
+// may be larger (zeroing n >> m elements).  b arrives through a slot in pinned host memory so that the launch
+// can sit in a captured graph whatever address the caller passes; b == U (host b, already copied in): no store.
+template <typename VT>
+__global__ __launch_bounds__(VEC_BLOCK) void k_start(const void *const *__restrict__ bslot, VT *__restrict__ U, int64_t m,
+                                                     int sgrid, VT *__restrict__ V, VT *__restrict__ X,
+                                                     VT *__restrict__ W, VT *__restrict__ SE, int64_t n,
+                                                     double *__restrict__ partials)
+{
+    typedef typename Vec2<VT>::type V2T;
+    __shared__ double red[VEC_BLOCK / WAVE];
+    __shared__ const void *bsh;
+    // (the slot is read FIRST, by one lane of the workgroups that need it, and looked at LAST: a read across
+    // PCIe, hidden behind the zeroing)
+    const void *braw = nullptr;
+    if (threadIdx.x == 0 && (int)blockIdx.x < sgrid) braw = *bslot;
+    {   // zeros: every workgroup of the launch
+        const int64_t n2 = n >> 1;
+        const int64_t stride = (int64_t)gridDim.x * VEC_BLOCK;
+        V2T z;
+        z.x = (VT)0;
+        z.y = (VT)0;
+        V2T *v2 = reinterpret_cast<V2T *>(V), *x2 = reinterpret_cast<V2T *>(X), *w2 = reinterpret_cast<V2T *>(W);
+        V2T *s2 = reinterpret_cast<V2T *>(SE);
+        for (int64_t i = (int64_t)blockIdx.x * VEC_BLOCK + threadIdx.x; i < n2; i += stride) {
+            v2[i] = z;
+            x2[i] = z;
+            if (W != nullptr) w2[i] = z;
+            if (SE != nullptr) s2[i] = z;
+        }
+        if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+            V[n - 1] = (VT)0;
+            X[n - 1] = (VT)0;
+            if (W != nullptr) W[n - 1] = (VT)0;
+            if (SE != nullptr) SE[n - 1] = (VT)0;
+        }
+    }
+    if ((int)blockIdx.x >= sgrid) return;
+    if (threadIdx.x == 0) bsh = braw;
+    __syncthreads();
+    const VT *b = static_cast<const VT *>(bsh);
+    const bool store = b != U;
+    Blue3 a{0.0, 0.0, 0.0};
+    const int64_t m2 = m >> 1;
+    const int64_t stride = (int64_t)sgrid * VEC_BLOCK;
+    const V2T *b2 = reinterpret_cast<const V2T *>(b);
+    V2T *u2 = reinterpret_cast<V2T *>(U);
+    for (int64_t i = (int64_t)blockIdx.x * VEC_BLOCK + threadIdx.x; i < m2; i += stride) {
+        const V2T v = b2[i];
+        if (store) u2[i] = v;
+        blue_add(a, (double)v.x);
+        blue_add(a, (double)v.y);
+    }
+    if ((m & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        const VT v = b[m - 1];
+        if (store) U[m - 1] = v;
+        blue_add(a, (double)v);
+    }
+    const double t0 = block_sum<VEC_BLOCK>(a.sml, red);
+    const double t1 = block_sum<VEC_BLOCK>(a.med, red);
+    const double t2 = block_sum<VEC_BLOCK>(a.big, red);
+    if (threadIdx.x == 0) {
+        partials[blockIdx.x] = t0;
+        partials[sgrid + blockIdx.x] = t1;
+        partials[2 * sgrid + blockIdx.x] = t2;
+    }
+}
+
 // out[0..2] = the three planes of k_sumsq3 reduced in fixed order (one workgroup): what the row-sharded
 // solve all-reduces for norm(b)
 __global__ __launch_bounds__(VEC_BLOCK) void k_reduce_partials3(const double *__restrict__ partials, int np,
@@ -190,6 +282,52 @@ __global__ __launch_bounds__(VEC_BLOCK) void k_copy(const double *__restrict__ x
 {
     const int64_t stride = (int64_t)gridDim.x * VEC_BLOCK;
     for (int64_t i = (int64_t)blockIdx.x * VEC_BLOCK + threadIdx.x; i < n; i += stride) y[i] = x[i];
+}
+
+// y <- x, `bytes` bytes: 16 at a time when both addresses allow it, else 4 (vectors of float / double)
+__global__ __launch_bounds__(VEC_BLOCK) void k_copy_bytes(const void *__restrict__ x, void *__restrict__ y, int64_t bytes)
+{
+    const int64_t stride = (int64_t)gridDim.x * VEC_BLOCK;
+    const int64_t t = (int64_t)blockIdx.x * VEC_BLOCK + threadIdx.x;
+    if ((((uintptr_t)x | (uintptr_t)y) & 15) == 0) {
+        const int64_t n16 = bytes >> 4;
+        const uint4 *a = static_cast<const uint4 *>(x);
+        uint4 *b = static_cast<uint4 *>(y);
+        for (int64_t i = t; i < n16; i += stride) b[i] = a[i];
+        const unsigned *a4 = static_cast<const unsigned *>(x);
+        unsigned *b4 = static_cast<unsigned *>(y);
+        for (int64_t i = (n16 << 2) + t; i < (bytes >> 2); i += stride) b4[i] = a4[i];
+    } else {
+        const unsigned *a4 = static_cast<const unsigned *>(x);
+        unsigned *b4 = static_cast<unsigned *>(y);
+        for (int64_t i = t; i < (bytes >> 2); i += stride) b4[i] = a4[i];
+    }
+}
+
+// The copy out of x at the end of a device-resident solve, as the last node of every graph batch: does nothing
+// until the stop flag is up (k_s3 raises it at itnlim at the latest), then x is final and goes to the address
+// the solve was given (LsqrState.xout; null: the host copies).  No host round trip between the last
+// iteration and the copy.
+__global__ __launch_bounds__(VEC_BLOCK) void k_out_copy(const LsqrState *__restrict__ st, const void *__restrict__ X,
+                                                        int64_t bytes)
+{
+    if (st->stop == 0 || st->xout == nullptr) return;
+    void *y = st->xout;
+    const int64_t stride = (int64_t)gridDim.x * VEC_BLOCK;
+    const int64_t t = (int64_t)blockIdx.x * VEC_BLOCK + threadIdx.x;
+    if ((((uintptr_t)X | (uintptr_t)y) & 15) == 0) {
+        const int64_t n16 = bytes >> 4;
+        const uint4 *a = static_cast<const uint4 *>(X);
+        uint4 *b = static_cast<uint4 *>(y);
+        for (int64_t i = t; i < n16; i += stride) b[i] = a[i];
+        const unsigned *a4 = static_cast<const unsigned *>(X);
+        unsigned *b4 = static_cast<unsigned *>(y);
+        for (int64_t i = (n16 << 2) + t; i < (bytes >> 2); i += stride) b4[i] = a4[i];
+    } else {
+        const unsigned *a4 = static_cast<const unsigned *>(X);
+        unsigned *b4 = static_cast<unsigned *>(y);
+        for (int64_t i = t; i < (bytes >> 2); i += stride) b4[i] = a4[i];
+    }
 }
 
 __global__ __launch_bounds__(VEC_BLOCK) void k_fill(double *__restrict__ x, int64_t n, double a)
