@@ -915,6 +915,21 @@ static void choose_panels(int rows, int cols, int64_t nnz, double mean_dev, int 
     *pw = (int)width;
 }
 
+// Column-swept row blocks (csb.h) are the layout of every matrix whose columns are scattered and which has
+// enough nonzeros to keep 256 sweeping workgroups busy.  Measured against what the other rules would pick
+// (profiles/r02/perf_csb_vs_xl.txt, perf_csb_small.txt; us per mode-1 product, other / CSB): 4M x 1M at 200 /
+// 300 / 600 / 1000 per row (LDS panels) 3991 / 1744, 4575 / 2564, 6707 / 5041, 10109 / 8497; 1M x 1M x 500
+// 1525 / 1040; 1M x 50k x 30 (row windows: x fits L2) 167 / 99, its transpose (LDS panels) 167 / 80; 2M x 500k
+// x 10 145 / 83; 100k^2 x 100 53 / 45; 50k^2 x 100 29 / 26; 20k^2 x 200 24 / 20; 200k^2 x 50 53 / 56 (a tie);
+// but 300k^2 x 8 = 2.4 M nonzeros 18 / 52: below ~4 M nonzeros the sweep is all fixed cost.
+static bool csb_rule(int cols, int64_t nnz, double mean_dev)
+{
+    const int64_t kb = std::max(64, env_int("LSQRHIP_PANEL_KB", 2048));
+    const double width = (double)((kb * 1024 / 8 + 1023) & ~(int64_t)1023);
+    const bool scattered = mean_dev >= std::min(0.25 * width, (double)cols / 8.0);   // (uniform columns: cols / 3)
+    return scattered && nnz >= (4ll << 20);
+}
+
 // work vectors, partial buffers, state: everything a solve needs besides the operator
 static int alloc_workspace(H *h)
 {
@@ -1025,10 +1040,11 @@ static int finish_create(H *h, const int *d_irow, const int *d_icol, const doubl
     unsigned long long *bufA = sA.as<unsigned long long>(), *bufB = sB.as<unsigned long long>();
     unsigned *hist = sH.as<unsigned>();
     int *d_flags = sF.as<int>();
-    // locality of the column pattern (only looked at when a vector exceeds L2; indices that are
-    // out of range are caught by the build below, the measure merely becomes meaningless)
+    // locality of the column pattern (only looked at when a vector exceeds L2 or the matrix is large enough
+    // for column-swept row blocks; indices that are out of range are caught by the build below, the measure
+    // merely becomes meaningless)
     double mean_dev = 0.0;
-    if (nnz > 0 && env_int("LSQRHIP_PANELS", -1) != 0 && std::max(h->m, h->n) > 600000) {
+    if (nnz > 0 && env_int("LSQRHIP_PANELS", -1) != 0 && (std::max(h->m, h->n) > 600000 || nnz >= (4ll << 20))) {
         unsigned long long *d_dev = (unsigned long long *)hist, dev = 0;
         HIPCHK(hipMemsetAsync(d_dev, 0, sizeof(dev), s));
         const int g = (int)std::min<int64_t>(std::max<int64_t>((nnz + 255) / 256, 1), 4096);
@@ -1063,12 +1079,16 @@ static int finish_create(H *h, const int *d_irow, const int *d_icol, const doubl
     int pa = 1, pwa = h->n, pt = 1, pwt = h->m, xa = 0, xt = 0;
     choose_panels(h->m, h->n, nnz, mean_dev, &pa, &pwa, &xa);                         // mode 1 gathers V (n)
     choose_panels(h->n, h->m, nnz, mean_dev * (double)std::max(h->m, 1) / (double)std::max(h->n, 1), &pt, &pwt, &xt);  // mode 2 gathers U (m)
-    // Column-swept row blocks (csb.h) wherever the L2 column panels would have been chosen.
-    //   LSQRHIP_CSB   0 never | 1 for every matrix (tests) | unset: instead of L2 panels
+    // Column-swept row blocks (csb.h) for scattered columns (csb_rule); a matrix the build declines (a block too
+    // empty for 18-bit local columns) falls through to the panels / row windows chosen above.
+    //   LSQRHIP_CSB   0 never | 1 for every matrix (tests) | 2 only instead of L2 panels (r02's first rule) | unset: csb_rule
     const int cmode = env_int("LSQRHIP_CSB", -1);
+    const double dev_t = mean_dev * (double)std::max(h->m, 1) / (double)std::max(h->n, 1);
     // (a REAL32 handle has no panel kernels: scattered columns always go to the column-swept blocks)
-    const bool csb_a = cmode == 1 || (cmode != 0 && pa > 1 && (xa == 0 || h->f32)) || (h->f32 && pa > 1);
-    const bool csb_t = cmode == 1 || (cmode != 0 && pt > 1 && (xt == 0 || h->f32)) || (h->f32 && pt > 1);
+    const bool csb_a = cmode == 1 || (cmode == 2 && pa > 1 && xa == 0) || (cmode < 0 && csb_rule(h->n, nnz, mean_dev)) ||
+                       (h->f32 && pa > 1);
+    const bool csb_t = cmode == 1 || (cmode == 2 && pt > 1 && xt == 0) || (cmode < 0 && csb_rule(h->m, nnz, dev_t)) ||
+                       (h->f32 && pt > 1);
     const bool t_first = env_int("LSQRHIP_BUILD_T_FIRST", 0) != 0;   // (experiment: does allocation order show?)
     if (csb_t && t_first) RET(build_csb(s, d_icol, d_irow, d_a, nnz, h->n, h->m, LSQRHIP_ERR_ICOL, LSQRHIP_ERR_IROW, bufA, bufB, hist, d_flags, h->AT));
     if (csb_a) RET(build_csb(s, d_irow, d_icol, d_a, nnz, h->m, h->n, LSQRHIP_ERR_IROW, LSQRHIP_ERR_ICOL, bufA, bufB, hist, d_flags, h->A));
