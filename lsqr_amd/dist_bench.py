@@ -42,15 +42,51 @@ def run_distributed(args):
     row0, nrows = blocks[rank]
     prob = devgen.generate(spec, row0, nrows)
     # the loop itself -- kernels and RCCL calls -- runs in C++ (csrc/shard_engine.h); LSQR_DIST_ENGINE=python
-    # selects the stage-by-stage driver over torch.distributed instead (same arithmetic)
+    # selects the stage-by-stage driver over torch.distributed instead (same stages, same arithmetic).
+    # The C++ engine's RCCL calls could only be exercised at world = 1 and through the in-process loopback
+    # while this was written (one-GPU boxes), so at world > 1 it is first checked against the Python driver
+    # on a 4-iteration solve -- the two must agree to rounding -- and any failure or disagreement, on any
+    # rank, falls back to the Python driver for the timed run (reported in config.engine).
     engine = os.environ.get("LSQR_DIST_ENGINE", "c++")
-    if engine == "python":
-        be = HipShardBackend(prob.solver, cfg["m"], world, rank)
-        drv = ShardedLSQR(be, comm, poll_every=min(16, max(1, K)))
-    else:
-        be = None
-        drv = EngineSolver(prob.solver, row0, cfg["m"], world, rank)
     kw = dict(damp=cfg["damp"], atol=0.0, btol=0.0, conlim=0.0)
+    be, drv, engine_note = None, None, None
+
+    def python_driver():
+        b = HipShardBackend(prob.solver, cfg["m"], world, rank)
+        return b, ShardedLSQR(b, comm, poll_every=min(16, max(1, K)))
+
+    if engine != "python":
+        ok = 1
+        try:
+            if os.environ.get("LSQR_DIST_TEST_ENGINE_FAILURE") == "1":   # (tests: the fall-back path)
+                raise RuntimeError("LSQR_DIST_TEST_ENGINE_FAILURE")
+            drv = EngineSolver(prob.solver, row0, cfg["m"], world, rank)
+            if world > 1:
+                r_eng = drv.solve(prob.d_b.ptr.value, itnlim=4, **kw)
+        except Exception as e:  # noqa: BLE001  (RCCL missing / refusing: report and use the other driver)
+            engine_note, ok, drv = f"c++ engine failed: {e!r}", 0, None
+        if world > 1:
+            flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
+                be, pdrv = python_driver()
+                r_py = pdrv.solve(prob.d_b.ptr.value, itnlim=4, **kw)
+                same = (r_eng.itn == r_py.itn and abs(r_eng.rnorm - r_py.rnorm) <= 1e-12 * abs(r_py.rnorm)
+                        and abs(r_eng.anorm - r_py.anorm) <= 1e-12 * abs(r_py.anorm))
+                flag = torch.tensor([1 if same else 0], dtype=torch.int32, device="cuda")
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                if int(flag.item()) == 1:
+                    be.close()
+                    be = None
+                else:
+                    engine_note = (f"c++ engine disagreed with the python driver after 4 iterations "
+                                   f"(rnorm {r_eng.rnorm!r} vs {r_py.rnorm!r}): python driver used")
+                    drv, engine = pdrv, "python"
+            else:
+                drv = None
+    if drv is None:
+        be, drv = python_driver()
+        engine = "python"
 
     if W > 0:
         drv.solve(prob.d_b.ptr.value, itnlim=W, **kw)
@@ -142,7 +178,7 @@ def run_distributed(args):
                            {"allreduce_scalars": "1 + 2 doubles (all-gather + rank-ordered sum)",
                             "reduce_scatter_bytes_out_per_gpu": 8 * cfg["n"] * (world - 1) // world,
                             "allgather_bytes_in_per_gpu": 8 * cfg["n"] * (world - 1) // world},
-                       "backend": "nccl (RCCL over xGMI)", "engine": engine, "world_size": dist.get_world_size(),
+                       "backend": "nccl (RCCL over xGMI)", "engine": engine, "engine_note": engine_note, "world_size": dist.get_world_size(),
                        "restarts": restarts},
             "result": {"istop": r.istop, "itn": r.itn, "anorm": r.anorm, "rnorm": r.rnorm},
             "roofline": {"bound": "hbm", "kernel": f"{kname} (aprod mode 1, local row block, rank 0)",

@@ -220,3 +220,25 @@ def test_rccl_two_ranks_through_bench_launcher():
     line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["config"]["world_size"] == 2 and line["steps"] == 20
     assert line["result"]["itn"] == 20 and line["value"] > 0
+
+
+@pytest.mark.parametrize("fail", ["0", "1"])
+def test_bench_distributed_leg_at_world_one_and_its_fallback(fail):
+    """bench.py's N > 1 leg forced at world = 1 (one rank over RCCL): the C++ engine by default, and the
+    stage-by-stage Python driver when the engine cannot be used (here: a simulated failure)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {**os.environ, "LSQR_BENCH_FORCE_DIST": "1", "LSQR_BENCH_STRONG_REF": "0",
+           "LSQR_DIST_TEST_ENGINE_FAILURE": fail}
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nproc-per-node", "1", "--master-addr",
+                        "127.0.0.1", "--master-port", "29541" if fail == "0" else "29542", os.path.join(root, "bench.py"),
+                        "--gpus", "1", "--steps", "12", "--warmup", "2", "--workload", "random:200000:100000:20"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["steps"] == 12 and line["result"]["itn"] == 12
+    assert line["config"]["engine"] == ("c++" if fail == "0" else "python")
+    assert (line["config"]["engine_note"] is None) == (fail == "0")
