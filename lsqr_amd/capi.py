@@ -159,6 +159,12 @@ class DeviceBuffer:
         check(lib().lsqrhip_dev_upload(buf.ptr, _ptr(a), a.nbytes))
         return buf
 
+    def copy_from(self, a: np.ndarray) -> None:
+        a = np.ascontiguousarray(a)
+        if a.nbytes > self.nbytes:
+            raise ValueError("array larger than the device buffer")
+        check(lib().lsqrhip_dev_upload(self.ptr, _ptr(a), a.nbytes))
+
     def to_array(self, dtype, count: int) -> np.ndarray:
         out = np.empty(count, dtype=dtype)
         check(lib().lsqrhip_dev_download(_ptr(out), self.ptr, out.nbytes))

@@ -1089,10 +1089,8 @@ static int finish_create(H *h, const int *d_irow, const int *d_icol, const doubl
                        (h->f32 && pa > 1);
     const bool csb_t = cmode == 1 || (cmode == 2 && pt > 1 && xt == 0) || (cmode < 0 && csb_rule(h->m, nnz, dev_t)) ||
                        (h->f32 && pt > 1);
-    const bool t_first = env_int("LSQRHIP_BUILD_T_FIRST", 0) != 0;   // (experiment: does allocation order show?)
-    if (csb_t && t_first) RET(build_csb(s, d_icol, d_irow, d_a, nnz, h->n, h->m, LSQRHIP_ERR_ICOL, LSQRHIP_ERR_IROW, bufA, bufB, hist, d_flags, h->AT));
     if (csb_a) RET(build_csb(s, d_irow, d_icol, d_a, nnz, h->m, h->n, LSQRHIP_ERR_IROW, LSQRHIP_ERR_ICOL, bufA, bufB, hist, d_flags, h->A));
-    if (csb_t && !t_first) RET(build_csb(s, d_icol, d_irow, d_a, nnz, h->n, h->m, LSQRHIP_ERR_ICOL, LSQRHIP_ERR_IROW, bufA, bufB, hist, d_flags, h->AT));
+    if (csb_t) RET(build_csb(s, d_icol, d_irow, d_a, nnz, h->n, h->m, LSQRHIP_ERR_ICOL, LSQRHIP_ERR_IROW, bufA, bufB, hist, d_flags, h->AT));
     if (h->f32) {  // ... and row windows over the whole x where a block was too empty for them
         if (!h->A.csb) { pa = 1; pwa = h->n; xa = 0; }
         if (!h->AT.csb) { pt = 1; pwt = h->m; xt = 0; }

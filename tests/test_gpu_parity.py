@@ -463,3 +463,36 @@ def test_unsorted_and_sorted_coo_give_same_matrix():
     # shuffled input: bit-exact against the reference run on the same shuffled triplets
     _, yr = oracle.port().aprod(1, q.m, q.n, q.irow, q.icol, q.a, xp, np.zeros(q.m))
     assert np.array_equal(y2, yr)
+
+
+@pytest.mark.parametrize("name", ["poisson_20x20_it50", "random_over_se", "illcond_conlim", "itnlim_1", "b_zero",
+                                  "zero_matrix", "one_by_one"])
+def test_device_resident_solve_copies_x_out_in_graph(name):
+    """lsqrhip_solve_device: x is copied to the caller's device array by the batch that raises the stop flag
+    (vec.h k_out_copy), b is read where it lies through the pinned slot (k_start).  Whatever the batch size
+    and wherever the stop falls -- mid-batch with a look-ahead batch behind it, at a boundary, at iteration 0 --
+    the outputs must be those of the host-vector solve, bit for bit, and the caller's b must be untouched."""
+    from lsqr_amd import capi
+    p, o = CASES[name]
+    s = make(p, o)
+    ref = s.solve(p.b, o["damp"], wantse=o["wantse"])
+    d_b = capi.DeviceBuffer.from_array(np.ascontiguousarray(p.b, np.float64))
+    d_x = capi.DeviceBuffer(8 * max(p.n, 1))
+    d_se = capi.DeviceBuffer(8 * max(p.n, 1))
+    poison = np.full(max(p.n, 1), np.nan)
+    for gi in (2, 6, max(2, ref.itn), max(2, ref.itn + 1), 64):
+        for pa in (1, 0):
+            for use_graph in (1, 0):
+                s.set_option("graph", use_graph)
+                s.set_option("graph_iters", gi)
+                s.set_option("poll_ahead", pa)
+                d_x.copy_from(poison)                                  # stale contents must be overwritten
+                r = s.solve_device(d_b.ptr.value, d_x.ptr.value, o["damp"])
+                assert (r.istop, r.itn, r.anorm, r.rnorm, r.xnorm) == \
+                       (ref.istop, ref.itn, ref.anorm, ref.rnorm, ref.xnorm), (gi, pa, use_graph)
+                assert np.array_equal(d_x.to_array(np.float64, p.n), ref.x), (gi, pa, use_graph)
+                if o["wantse"]:
+                    r = s.solve_device(d_b.ptr.value, d_x.ptr.value, o["damp"], d_se.ptr.value)
+                    assert np.array_equal(d_x.to_array(np.float64, p.n), ref.x)
+                    assert np.array_equal(d_se.to_array(np.float64, p.n), ref.se)
+    assert np.array_equal(d_b.to_array(np.float64, p.m), p.b)
