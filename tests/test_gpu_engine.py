@@ -11,6 +11,7 @@ import pytest
 import oracle
 from cases import build_cases
 from lsqr_amd import capi
+from lsqr_amd import problems as P
 from lsqr_amd.capi import check, lib
 from lsqr_amd.dist import EngineSolver
 from lsqr_amd.solver import lsqr_solver_ez
@@ -242,3 +243,31 @@ def test_bench_distributed_leg_at_world_one_and_its_fallback(fail):
     assert line["n_gpus"] == 1 and line["steps"] == 12 and line["result"]["itn"] == 12
     assert line["config"]["engine"] == ("c++" if fail == "0" else "python")
     assert (line["config"]["engine_note"] is None) == (fail == "0")
+
+
+@pytest.mark.parametrize("csb", ["0", "1"])
+def test_loopback_eight_ranks_on_a_larger_system_agree_with_one_gpu(loopback, csb):
+    """400k x 150k random, 12 per row (4.8 M nonzeros), damped: eight ranks on one device (loopback exchanges)
+    against the ordinary single-handle solve of the same triplets -- same istop and itn, x to 1e-10 -- with
+    the ranks' blocks in row windows and, forced, in column-swept row blocks (column splits, exact sums)."""
+    import os
+    p = P.random_rows(400_000, 150_000, 12, damp=1e-2, seed=5)
+    o = dict(damp=p.damp, atol=1e-9, btol=1e-9, conlim=0.0, itnlim=60, wantse=True)
+    s1 = lsqr_solver_ez().initialize(p.m, p.n, p.a, p.irow, p.icol, atol=o["atol"], btol=o["btol"], itnlim=o["itnlim"])
+    ref = s1.solve(p.b, p.damp, wantse=True)
+    old = os.environ.get("LSQRHIP_CSB")
+    os.environ["LSQRHIP_CSB"] = csb
+    try:
+        h = sharded_handle(p, 8)
+    finally:
+        os.environ.pop("LSQRHIP_CSB", None)
+        if old is not None:
+            os.environ["LSQRHIP_CSB"] = old
+    try:
+        x, se, istop, itn, sc = solve_handle(h, p, o)
+        assert (istop, itn) == (ref.istop, ref.itn)
+        assert np.linalg.norm(x - ref.x) <= 1e-10 * np.linalg.norm(ref.x)
+        assert np.linalg.norm(se - ref.se) <= 1e-9 * np.linalg.norm(ref.se)
+        assert abs(sc[0] - ref.anorm) <= 1e-10 * ref.anorm and abs(sc[2] - ref.rnorm) <= 1e-10 * ref.rnorm
+    finally:
+        check(lib().lsqrhip_destroy(h))
