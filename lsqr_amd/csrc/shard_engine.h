@@ -200,13 +200,20 @@ static int loop_copy(ShardRank &dst, double *d, const double *s, size_t count)
     return LSQRHIP_OK;
 }
 
-static int ex_scalars(ShardGroup &g, int k)  // sums[0..k) <- sum over ranks, in rank order, same bits everywhere
+// sums[0..k) <- sum over ranks, in rank order, same bits everywhere.  `with_v`: the in-place all-gather of the v
+// slices rides in the same RCCL group (one collective latency instead of two: after ST_VCOMBINE the slices are
+// final -- the update that follows only reads them).
+static int ex_scalars(ShardGroup &g, int k, bool with_v = false)
 {
     Rccl *rc = rccl();
+    const size_t c = (size_t)g.chunk;
     if (g.P > 1 && g.loopback) {
         RET(fence_ranks(g));
         for (ShardRank &q : g.r)
-            for (ShardRank &p : g.r) RET(loop_copy(q, q.gath + 4 * (size_t)p.grank, p.sums, 4));
+            for (ShardRank &p : g.r) {
+                RET(loop_copy(q, q.gath + 4 * (size_t)p.grank, p.sums, 4));
+                if (with_v && &p != &q) RET(loop_copy(q, q.V + (size_t)p.grank * c, p.V + (size_t)p.grank * c, c));
+            }
         RET(fence_ranks(g));
         for (ShardRank &q : g.r) {
             HIPCHK(hipSetDevice(q.h->device));
@@ -216,7 +223,11 @@ static int ex_scalars(ShardGroup &g, int k)  // sums[0..k) <- sum over ranks, in
     }
     if (g.P > 1) {
         NCCLCHK(rc->GroupStart());
-        for (ShardRank &q : g.r) NCCLCHK(rc->AllGather(q.sums, q.gath, 4, ncclDouble, q.comm, q.h->stream));
+        for (ShardRank &q : g.r) {
+            NCCLCHK(rc->AllGather(q.sums, q.gath, 4, ncclDouble, q.comm, q.h->stream));
+            if (with_v && c > 0)
+                NCCLCHK(rc->AllGather(q.V + (size_t)q.grank * c, q.V, c, ncclDouble, q.comm, q.h->stream));
+        }
         NCCLCHK(rc->GroupEnd());
         for (ShardRank &q : g.r) {
             HIPCHK(hipSetDevice(q.h->device));
@@ -324,9 +335,8 @@ static int run_group(ShardGroup &g, double damp, double atol, double btol, doubl
             RET(stage_all(g, ST_S1_ATU));
             RET(ex_scatter(g));
             RET(stage_all(g, ST_VCOMBINE));
-            RET(ex_scalars(g, 2));
+            RET(ex_scalars(g, 2, true));    // alpha^2, dknorm^2 and the v slices in one group
             RET(stage_all(g, ST_UPDATE));
-            RET(ex_gather(g, false, false));
         }
         launched += batch;
         RET(poll());
