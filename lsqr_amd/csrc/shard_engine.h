@@ -113,11 +113,7 @@ struct ShardRank {
 struct ShardGroup {
     int P = 1;                     // world size
     int m = 0, n = 0;
-    int64_t chunk = 0;             // slice capacity (sum of the piece lengths)
-    int64_t nfull = 0;             // length of the natural-order buffers T, V, xfull, sefull
-    int G = 1;                     // pieces per slice (shard_api.h SliceMap); group g = piece g of every slice
-    std::vector<int64_t> bounds;   // [G + 1] natural bounds of the groups
-    std::vector<int64_t> pl, loc0; // [G] piece length and local offset of every group
+    int64_t chunk = 0;
     std::vector<ShardRank> r;      // the ranks driven by this process
     bool owned = false;            // sub-handles belong to the group (single-process form)
     bool loopback = false;         // exchanges by device copies inside this process instead of RCCL (all ranks are local)
@@ -158,61 +154,12 @@ static void release_groups(H *h)
     }
 }
 
-// The slice geometry of the group: G pieces cut at `bounds` (G + 1 values, multiples of P but the last), or one
-// contiguous slice per rank (G <= 1).  Too few columns for pieces: one slice.
-static void set_geometry(ShardGroup &g, int G, const int64_t *bounds)
-{
-    if (G > 1 && (int64_t)g.n < (int64_t)G * g.P * 4) G = 1;
-    g.bounds.clear(); g.pl.clear(); g.loc0.clear();
-    if (G <= 1) {
-        const int64_t c = ((int64_t)g.n + g.P - 1) / g.P;
-        g.G = 1;
-        g.bounds = {0, c * g.P};
-        g.pl = {c};
-        g.loc0 = {0};
-        g.chunk = c;
-        g.nfull = c * g.P;
-        return;
-    }
-    g.G = G;
-    int64_t loc = 0, end = 0;
-    for (int k = 0; k < G; ++k) {
-        const int64_t span = bounds[k + 1] - bounds[k];
-        const int64_t p = (span + g.P - 1) / g.P;
-        g.bounds.push_back(bounds[k]);
-        g.pl.push_back(p);
-        g.loc0.push_back(loc);
-        loc += p;
-        end = bounds[k] + p * g.P;
-    }
-    g.bounds.push_back(bounds[G]);
-    g.chunk = loc;
-    g.nfull = std::max<int64_t>(end, g.n);
-}
-
-// G equal groups (test hook LSQRHIP_SHARD_PIECES, and the default when the product's launches give no bounds)
-static void uniform_geometry(ShardGroup &g, int G)
-{
-    G = std::min(std::max(G, 1), SHARD_MAX_PIECES);
-    std::vector<int64_t> b((size_t)G + 1, 0);
-    const int64_t per = (((int64_t)g.n + G - 1) / G + g.P - 1) / g.P * g.P;   // a multiple of P
-    for (int k = 1; k <= G; ++k) b[(size_t)k] = std::min<int64_t>(per * k, ((int64_t)g.n + g.P - 1) / g.P * g.P);
-    b[(size_t)G] = std::max<int64_t>(b[(size_t)G], g.n);
-    for (int k = 1; k <= G; ++k)
-        if (b[(size_t)k] <= b[(size_t)k - 1] && k < G) {   // degenerate (tiny n): one slice
-            set_geometry(g, 1, nullptr);
-            return;
-        }
-    set_geometry(g, G, b.data());
-}
-
 static int alloc_rank_buffers(ShardGroup &g, ShardRank &k)
 {
     k.dev = k.h->device;
     HIPCHK(hipSetDevice(k.h->device));
-    const size_t full = (size_t)std::max<int64_t>(g.nfull, 1);
-    for (double **pp : {&k.T, &k.V, &k.xfull, &k.sefull}) HIPCHK(hipMalloc((void **)pp, sizeof(double) * full));
-    HIPCHK(hipMalloc((void **)&k.R, sizeof(double) * (size_t)std::max<int64_t>(g.chunk * g.P, 1)));
+    const size_t full = (size_t)std::max<int64_t>(g.chunk * g.P, 1);
+    for (double **pp : {&k.T, &k.R, &k.V, &k.xfull, &k.sefull}) HIPCHK(hipMalloc((void **)pp, sizeof(double) * full));
     HIPCHK(hipMalloc((void **)&k.sums, sizeof(double) * 4));
     HIPCHK(hipMalloc((void **)&k.gath, sizeof(double) * 4 * (size_t)g.P));
     HIPCHK(hipMalloc((void **)&k.bloc, sizeof(double) * (size_t)std::max(k.h->m, 1)));
@@ -259,16 +206,13 @@ static int loop_copy(ShardRank &dst, double *d, const double *s, size_t count)
 static int ex_scalars(ShardGroup &g, int k, bool with_v = false)
 {
     Rccl *rc = rccl();
+    const size_t c = (size_t)g.chunk;
     if (g.P > 1 && g.loopback) {
         RET(fence_ranks(g));
         for (ShardRank &q : g.r)
             for (ShardRank &p : g.r) {
                 RET(loop_copy(q, q.gath + 4 * (size_t)p.grank, p.sums, 4));
-                if (with_v && &p != &q)
-                    for (int k = 0; k < g.G; ++k) {
-                        const size_t o = (size_t)(g.bounds[(size_t)k] + p.grank * g.pl[(size_t)k]);
-                        RET(loop_copy(q, q.V + o, p.V + o, (size_t)g.pl[(size_t)k]));
-                    }
+                if (with_v && &p != &q) RET(loop_copy(q, q.V + (size_t)p.grank * c, p.V + (size_t)p.grank * c, c));
             }
         RET(fence_ranks(g));
         for (ShardRank &q : g.r) {
@@ -281,10 +225,8 @@ static int ex_scalars(ShardGroup &g, int k, bool with_v = false)
         NCCLCHK(rc->GroupStart());
         for (ShardRank &q : g.r) {
             NCCLCHK(rc->AllGather(q.sums, q.gath, 4, ncclDouble, q.comm, q.h->stream));
-            for (int k = 0; with_v && k < g.G; ++k)   // in place, group by group
-                if (g.pl[(size_t)k] > 0)
-                    NCCLCHK(rc->AllGather(q.V + g.bounds[(size_t)k] + q.grank * g.pl[(size_t)k], q.V + g.bounds[(size_t)k],
-                                          (size_t)g.pl[(size_t)k], ncclDouble, q.comm, q.h->stream));
+            if (with_v && c > 0)
+                NCCLCHK(rc->AllGather(q.V + (size_t)q.grank * c, q.V, c, ncclDouble, q.comm, q.h->stream));
         }
         NCCLCHK(rc->GroupEnd());
         for (ShardRank &q : g.r) {
@@ -295,33 +237,34 @@ static int ex_scalars(ShardGroup &g, int k, bool with_v = false)
     return LSQRHIP_OK;
 }
 
-// Piece (group k, slice q) of every rank's T -> rank q's R[rank][loc0[k] ..): the direct reduce-scatter of the
-// groups [k0, k1).
-static int ex_scatter(ShardGroup &g, int k0 = 0, int k1 = -1)
+static int ex_scatter(ShardGroup &g)  // slice q of every rank's T -> rank q's R[rank]
 {
     Rccl *rc = rccl();
-    if (k1 < 0) k1 = g.G;
-    if (g.chunk == 0) return LSQRHIP_OK;
-    auto src = [&](ShardRank &from, int k, int to) { return from.T + g.bounds[(size_t)k] + (int64_t)to * g.pl[(size_t)k]; };
-    auto dst = [&](ShardRank &at, int k, int from) { return at.R + (int64_t)from * g.chunk + g.loc0[(size_t)k]; };
-    if (g.P == 1 || g.loopback) {
-        if (g.P > 1) RET(fence_ranks(g));
-        for (int k = k0; k < k1; ++k)
-            for (ShardRank &q : g.r)
-                for (ShardRank &p : g.r) RET(loop_copy(q, dst(q, k, p.grank), src(p, k, q.grank), (size_t)g.pl[(size_t)k]));
-        return g.P > 1 ? fence_ranks(g) : LSQRHIP_OK;
-    }
-    // the rank's own pieces never leave the device; the others go to their owners over all links at once
-    for (int k = k0; k < k1; ++k)
-        for (ShardRank &q : g.r) RET(loop_copy(q, dst(q, k, q.grank), src(q, k, q.grank), (size_t)g.pl[(size_t)k]));
-    NCCLCHK(rc->GroupStart());
-    for (int k = k0; k < k1; ++k)
+    const size_t c = (size_t)g.chunk;
+    if (g.P == 1 || c == 0) {
         for (ShardRank &q : g.r)
-            for (int peer = 0; peer < g.P; ++peer) {
-                if (peer == q.grank || g.pl[(size_t)k] == 0) continue;
-                NCCLCHK(rc->Send(src(q, k, peer), (size_t)g.pl[(size_t)k], ncclDouble, peer, q.comm, q.h->stream));
-                NCCLCHK(rc->Recv(dst(q, k, peer), (size_t)g.pl[(size_t)k], ncclDouble, peer, q.comm, q.h->stream));
-            }
+            if (c) HIPCHK(hipMemcpyAsync(q.R, q.T, sizeof(double) * c, hipMemcpyDeviceToDevice, q.h->stream));
+        return LSQRHIP_OK;
+    }
+    if (g.loopback) {
+        RET(fence_ranks(g));
+        for (ShardRank &q : g.r)
+            for (ShardRank &p : g.r) RET(loop_copy(q, q.R + (size_t)p.grank * c, p.T + (size_t)q.grank * c, c));
+        return fence_ranks(g);
+    }
+    // the rank's own slice never leaves the device; the others go to their owners over all links at once
+    for (ShardRank &q : g.r) {
+        HIPCHK(hipSetDevice(q.h->device));
+        HIPCHK(hipMemcpyAsync(q.R + (size_t)q.grank * c, q.T + (size_t)q.grank * c, sizeof(double) * c,
+                              hipMemcpyDeviceToDevice, q.h->stream));
+    }
+    NCCLCHK(rc->GroupStart());
+    for (ShardRank &q : g.r)
+        for (int peer = 0; peer < g.P; ++peer) {
+            if (peer == q.grank) continue;
+            NCCLCHK(rc->Send(q.T + (size_t)peer * c, c, ncclDouble, peer, q.comm, q.h->stream));
+            NCCLCHK(rc->Recv(q.R + (size_t)peer * c, c, ncclDouble, peer, q.comm, q.h->stream));
+        }
     NCCLCHK(rc->GroupEnd());
     return LSQRHIP_OK;
 }
@@ -329,31 +272,26 @@ static int ex_scatter(ShardGroup &g, int k0 = 0, int k1 = -1)
 static int ex_gather(ShardGroup &g, bool x_too, bool se_too)  // in-place all-gather of the column slices
 {
     Rccl *rc = rccl();
-    if (g.P == 1 || g.chunk == 0) return LSQRHIP_OK;
+    const size_t c = (size_t)g.chunk;
+    if (g.P == 1 || c == 0) return LSQRHIP_OK;
     if (g.loopback) {
         RET(fence_ranks(g));
         for (ShardRank &q : g.r)
             for (ShardRank &p : g.r) {
                 if (&p == &q) continue;
-                for (int k = 0; k < g.G; ++k) {
-                    const size_t o = (size_t)(g.bounds[(size_t)k] + p.grank * g.pl[(size_t)k]), c = (size_t)g.pl[(size_t)k];
-                    if (!x_too) RET(loop_copy(q, q.V + o, p.V + o, c));
-                    if (x_too) RET(loop_copy(q, q.xfull + o, p.xfull + o, c));
-                    if (se_too) RET(loop_copy(q, q.sefull + o, p.sefull + o, c));
-                }
+                const size_t o = (size_t)p.grank * c;
+                if (!x_too) RET(loop_copy(q, q.V + o, p.V + o, c));
+                if (x_too) RET(loop_copy(q, q.xfull + o, p.xfull + o, c));
+                if (se_too) RET(loop_copy(q, q.sefull + o, p.sefull + o, c));
             }
         return fence_ranks(g);
     }
     NCCLCHK(rc->GroupStart());
-    for (ShardRank &q : g.r)
-        for (int k = 0; k < g.G; ++k) {
-            const size_t c = (size_t)g.pl[(size_t)k];
-            if (c == 0) continue;
-            const int64_t b0 = g.bounds[(size_t)k], mine = b0 + q.grank * g.pl[(size_t)k];
-            if (!x_too) NCCLCHK(rc->AllGather(q.V + mine, q.V + b0, c, ncclDouble, q.comm, q.h->stream));
-            if (x_too) NCCLCHK(rc->AllGather(q.xfull + mine, q.xfull + b0, c, ncclDouble, q.comm, q.h->stream));
-            if (se_too) NCCLCHK(rc->AllGather(q.sefull + mine, q.sefull + b0, c, ncclDouble, q.comm, q.h->stream));
-        }
+    for (ShardRank &q : g.r) {
+        if (!x_too) NCCLCHK(rc->AllGather(q.V + (size_t)q.grank * c, q.V, c, ncclDouble, q.comm, q.h->stream));
+        if (x_too) NCCLCHK(rc->AllGather(q.xfull + (size_t)q.grank * c, q.xfull, c, ncclDouble, q.comm, q.h->stream));
+        if (se_too) NCCLCHK(rc->AllGather(q.sefull + (size_t)q.grank * c, q.sefull, c, ncclDouble, q.comm, q.h->stream));
+    }
     NCCLCHK(rc->GroupEnd());
     return LSQRHIP_OK;
 }
@@ -369,7 +307,6 @@ static int run_group(ShardGroup &g, double damp, double atol, double btol, doubl
                      int *istop, int *itn, double *anorm, double *acond, double *rnorm, double *arnorm, double *xnorm)
 {
     if (g.P > 1 && !g.loopback && !rccl()) return fail(LSQRHIP_ERR_HIP, "librccl.so.1 could not be loaded");
-    for (ShardRank &q : g.r) RET(lsqrhip_shard_set_pieces(q.h, g.G, g.G > 1 ? g.bounds.data() : nullptr));
     for (ShardRank &q : g.r)
         RET(lsqrhip_shard_begin(q.h, q.bloc, g.m, g.P, q.grank, damp, atol, btol, conlim, itnlim, wantse, q.T, q.R, q.V,
                                 q.sums));
@@ -505,7 +442,7 @@ extern "C" int lsqrhip_create_sharded(int m, int n, int64_t nnz, const int *irow
     g->P = ngpu;
     g->m = m;
     g->n = n;
-    uniform_geometry(*g, env_int("LSQRHIP_SHARD_PIECES", 1));
+    g->chunk = ((int64_t)n + ngpu - 1) / ngpu;
     g->owned = true;
     g->loopback = loopback;
     g->r.resize((size_t)ngpu);
@@ -621,7 +558,7 @@ extern "C" int lsqrhip_shard_comm_init(lsqrhip_handle_t h, int world, int rank, 
     g->P = world;
     g->m = (int)m_global;
     g->n = h->n;
-    uniform_geometry(*g, env_int("LSQRHIP_SHARD_PIECES", 1));
+    g->chunk = ((int64_t)h->n + world - 1) / world;
     g->owned = false;
     g->r.resize(1);
     ShardRank &q = g->r[0];

@@ -90,23 +90,11 @@ def loopback():
         os.environ["LSQRHIP_SHARD_LOOPBACK"] = old
 
 
-@pytest.fixture(params=[1, 3, 8])
-def pieces(request):
-    """Slices in 1, 3 or 8 pieces (shard_api.h SliceMap; LSQRHIP_SHARD_PIECES: equal groups)."""
-    import os
-    old = os.environ.get("LSQRHIP_SHARD_PIECES")
-    os.environ["LSQRHIP_SHARD_PIECES"] = str(request.param)
-    yield request.param
-    os.environ.pop("LSQRHIP_SHARD_PIECES", None)
-    if old is not None:
-        os.environ["LSQRHIP_SHARD_PIECES"] = old
-
-
 @pytest.mark.parametrize("ngpu", [2, 3, 8])
 @pytest.mark.parametrize("name", ["random_over_damped", "random_over_se", "random_under", "poisson_20x20_it50",
                                   "shuffled_dups", "empty_rows_cols_it20", "powerlaw_small_it10", "b_zero", "zero_matrix",
                                   "one_by_one", "itnlim_1"])
-def test_engine_with_several_ranks_on_one_gpu(loopback, pieces, name, ngpu):
+def test_engine_with_several_ranks_on_one_gpu(loopback, name, ngpu):
     """The whole C++ engine at world sizes 2, 3 and 8 on ONE device (LSQRHIP_SHARD_LOOPBACK=1: the three
     exchanges become device copies between the ranks' buffers -- RCCL refuses ranks that share a GPU).  Stages,
     row blocks, column slices (ragged: n not a multiple of the world; more ranks than rows), the rank-ordered
@@ -258,7 +246,7 @@ def test_bench_distributed_leg_at_world_one_and_its_fallback(fail):
 
 
 @pytest.mark.parametrize("csb", ["0", "1"])
-def test_loopback_eight_ranks_on_a_larger_system_agree_with_one_gpu(loopback, pieces, csb):
+def test_loopback_eight_ranks_on_a_larger_system_agree_with_one_gpu(loopback, csb):
     """400k x 150k random, 12 per row (4.8 M nonzeros), damped: eight ranks on one device (loopback exchanges)
     against the ordinary single-handle solve of the same triplets -- same istop and itn, x to 1e-10 -- with
     the ranks' blocks in row windows and, forced, in column-swept row blocks (column splits, exact sums)."""
