@@ -312,14 +312,6 @@ int lsqrhip_shard_begin(lsqrhip_handle_t h, const double *d_b_local, int64_t m_g
                         double damp, double atol, double btol, double conlim, int itnlim, int wantse, double *d_T,
                         double *d_R, double *d_V, double *d_sums);
 int lsqrhip_shard_stage(lsqrhip_handle_t h, int stage);
-/* Optional, before lsqrhip_shard_begin: cut every rank's column slice into G <= 8 pieces.  bounds[0..G]:
- * 0 = c_0 < c_1 < .. < c_G, every c_g (g < G) a multiple of the world size, c_G >= n; piece g of rank q is the
- * q-th world-th of [c_g, c_{g+1}).  The same bounds on every rank.  The natural-order buffers T, V (and the x,
- * se passed to lsqrhip_shard_end) then hold c_{G-1} + world * ceil((c_G - c_{G-1}) / world) >= n elements, R
- * world * (sum of the piece lengths).  With pieces cut where the mode-2 product's launches end, the exchange
- * of group g can travel while the product of group g + 1 runs (shard_engine.h does this).  G <= 1: the plain
- * contiguous slices [q chunk, (q+1) chunk), chunk = ceil(n / world) (the default). */
-int lsqrhip_shard_set_pieces(lsqrhip_handle_t h, int G, const int64_t *bounds);
 /* d_out[0..chunk) = sum_{r < nchunks} d_in[r*chunk + i], in rank order (asynchronous on the
  * handle's stream). */
 int lsqrhip_sum_chunks(lsqrhip_handle_t h, const double *d_in, int nchunks, int64_t chunk, double *d_out);

@@ -29,7 +29,7 @@ EXPORTS = [
     "lsqrhip_log_extras", "lsqrhip_dnrm2", "lsqrhip_ddot", "lsqrhip_dscal", "lsqrhip_dcopy",
     "lsqrhip_last_timing", "lsqrhip_bench_kernel", "lsqrhip_set_option", "lsqrhip_get_option", "lsqrhip_set_stream", "lsqrhip_dev_alloc",
     "lsqrhip_dev_free", "lsqrhip_dev_upload", "lsqrhip_dev_download", "lsqrhip_dev_sync",
-    "lsqrhip_shard_begin", "lsqrhip_shard_set_pieces", "lsqrhip_shard_stage", "lsqrhip_shard_poll", "lsqrhip_shard_end", "lsqrhip_sum_chunks",
+    "lsqrhip_shard_begin", "lsqrhip_shard_stage", "lsqrhip_shard_poll", "lsqrhip_shard_end", "lsqrhip_sum_chunks",
     "lsqrhip_create_f32", "lsqrhip_solve_f32", "lsqrhip_aprod_f32", "lsqrhip_solve_device_f32",
     "lsqrhip_aprod_device_f32",
     "lsqrhip_create_sharded", "lsqrhip_rccl_unique_id", "lsqrhip_shard_comm_init", "lsqrhip_shard_solve",
@@ -118,7 +118,6 @@ def lib() -> C.CDLL:
     L.lsqrhip_sum_chunks.argtypes = [vp, vp, i32, i64, vp]
     L.lsqrhip_shard_poll.argtypes = [vp, vp]
     L.lsqrhip_shard_end.argtypes = [vp, vp, vp] + [vp] * 7
-    L.lsqrhip_shard_set_pieces.argtypes = [vp, i32, vp]
     L.lsqrhip_gen_count.restype = i64
     L.lsqrhip_gen_count.argtypes = [i32, i64, i64, i64, i64, i64, i64]
     L.lsqrhip_gen_coo.argtypes = [i32, C.c_uint64, i64, i64, i64, i64, i64, i64, vp, vp, vp, vp, vp, vp]

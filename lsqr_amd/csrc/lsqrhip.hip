@@ -172,32 +172,10 @@ struct Csr {
 
 // One rank's view of a row-sharded solve (shard_api.h): its place in the world, the caller-owned
 // exchange buffers of the current solve, and two device words of its own.
-// A rank's column slice as G <= 8 pieces of the natural order: the n columns are cut at common bounds
-// 0 = c_0 < c_1 < ... < c_G (multiples of P but the last, which is >= n), and piece g of rank q is the q-th
-// P-th of [c_g, c_{g+1}).  G = 1 is the plain contiguous slice [q chunk, (q+1) chunk).  With G > 1 group g of
-// every slice is complete as soon as the mode-2 product has swept the rows below c_{g+1}: its reduce-scatter
-// can travel while the product goes on (shard_engine.h).
-constexpr int SHARD_MAX_PIECES = 8;
-struct SliceMap {
-    int G = 1;
-    int64_t n = 0;                              // natural indices >= n do not exist
-    int64_t loc0[SHARD_MAX_PIECES + 1] = {0};   // local offset of piece g; loc0[G] = chunk (slice capacity)
-    int64_t nat0[SHARD_MAX_PIECES] = {0};       // natural index of piece g's first element
-    __host__ __device__ int64_t nat(int64_t l) const
-    {
-        int g = 0;
-        while (g + 1 < G && l >= loc0[g + 1]) ++g;
-        return nat0[g] + (l - loc0[g]);
-    }
-};
-
 struct ShardCtx {
     int P = 1, rank = 0;
-    int64_t chunk = 0;            // slice capacity: ceil(n / P) for one piece, the sum of the piece lengths otherwise
-    int64_t nfull = 0;            // length of the natural-order buffers T, V (>= n: the last group is padded)
-    SliceMap map;                 // local index <-> natural index of this rank's slice
-    int G_req = 0;                // pieces asked for by lsqrhip_shard_set_pieces (0: one contiguous slice)
-    int64_t bounds_req[SHARD_MAX_PIECES + 1] = {0};
+    int64_t chunk = 0;            // ceil(n / P): columns per slice
+    int64_t my0 = 0, mylen = 0;   // this rank's column slice [my0, my0 + mylen)
     double *T = nullptr, *R = nullptr, *V = nullptr, *sums = nullptr;  // caller-owned: P*chunk, P*chunk, P*chunk, 4
     double *wsq = nullptr;        // [1] this rank's sum of w_q^2 (owned)
     int *live = nullptr;          // [1] "this iteration runs" (owned)

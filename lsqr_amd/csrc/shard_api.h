@@ -28,9 +28,8 @@ namespace lsqrhip {
 
 // Vq_i <- cy (Vq_i sy) + (R[0][i] + R[1][i] + ... + R[P-1][i])   (rank order); partials of sum (Vq ns)^2.
 // R[r] = slice q of rank r's T (what the all-to-all delivered), each `chunk` long; i < len <= chunk.
-// (local element i of the slice sits at V[map.nat(i)] in the natural order; elements past n do not exist)
-__global__ __launch_bounds__(VEC_BLOCK) void k_rs_combine(double *__restrict__ V, const double *__restrict__ R,
-                                                          int P, int64_t chunk, SliceMap map,
+__global__ __launch_bounds__(VEC_BLOCK) void k_rs_combine(double *__restrict__ Vq, const double *__restrict__ R,
+                                                          int P, int64_t chunk, int64_t len,
                                                           const SpmvCoef *__restrict__ coef,
                                                           const int *__restrict__ stop,
                                                           double *__restrict__ partials, NScale nsc)
@@ -40,13 +39,11 @@ __global__ __launch_bounds__(VEC_BLOCK) void k_rs_combine(double *__restrict__ V
     __shared__ double red[VEC_BLOCK / WAVE];
     double s = 0.0;
     const int64_t stride = (int64_t)gridDim.x * VEC_BLOCK;
-    for (int64_t i = (int64_t)blockIdx.x * VEC_BLOCK + threadIdx.x; i < chunk; i += stride) {
-        const int64_t j = map.nat(i);
-        if (j >= map.n) continue;
+    for (int64_t i = (int64_t)blockIdx.x * VEC_BLOCK + threadIdx.x; i < len; i += stride) {
         double t = R[i];
         for (int r = 1; r < P; ++r) t = t + R[(int64_t)r * chunk + i];
-        const double v = cy * (V[j] * sy) + t;
-        V[j] = v;
+        const double v = cy * (Vq[i] * sy) + t;
+        Vq[i] = v;
         const double vs = v * nsc.s;
         s += vs * vs;
     }
@@ -71,8 +68,8 @@ __global__ __launch_bounds__(VEC_BLOCK) void k_sum_chunks(double *__restrict__ o
 // folded in), gated by `live` (set by k_shard_s2 in the SAME iteration: the stop flag that k_shard_s3
 // raises afterwards must not hide the last update).  partials = sum of w_new^2 (next iteration's dknorm).
 __global__ __launch_bounds__(VEC_BLOCK) void k_update_slice(double *__restrict__ x, double *__restrict__ w,
-                                                            const double *__restrict__ V, double *__restrict__ se,
-                                                            int64_t chunk, SliceMap map, const LsqrState *__restrict__ st,
+                                                            const double *__restrict__ Vq, double *__restrict__ se,
+                                                            int64_t len, const LsqrState *__restrict__ st,
                                                             const int *__restrict__ live,
                                                             double *__restrict__ partials)
 {
@@ -82,12 +79,10 @@ __global__ __launch_bounds__(VEC_BLOCK) void k_update_slice(double *__restrict__
     __shared__ double red[VEC_BLOCK / WAVE];
     double s = 0.0;
     const int64_t stride = (int64_t)gridDim.x * VEC_BLOCK;
-    for (int64_t i = (int64_t)blockIdx.x * VEC_BLOCK + threadIdx.x; i < chunk; i += stride) {
-        const int64_t j = map.nat(i);
-        if (j >= map.n) continue;
+    for (int64_t i = (int64_t)blockIdx.x * VEC_BLOCK + threadIdx.x; i < len; i += stride) {
         const double t = w[i];
         x[i] = t1 * t + x[i];
-        const double wn = t2 * t + V[j] * sv;
+        const double wn = t2 * t + Vq[i] * sv;
         w[i] = wn;
         if (wantse) {
             const double d = (t3 * t) * (t3 * t);
@@ -100,8 +95,8 @@ __global__ __launch_bounds__(VEC_BLOCK) void k_update_slice(double *__restrict__
 }
 
 // w_q <- V_q sv (first w, src/lsqr.f90:641-644); partials of sum w_q^2
-__global__ __launch_bounds__(VEC_BLOCK) void k_init_w_slice(double *__restrict__ w, const double *__restrict__ V,
-                                                            int64_t chunk, SliceMap map, const LsqrState *__restrict__ st,
+__global__ __launch_bounds__(VEC_BLOCK) void k_init_w_slice(double *__restrict__ w, const double *__restrict__ Vq,
+                                                            int64_t len, const LsqrState *__restrict__ st,
                                                             double *__restrict__ partials)
 {
     const double sv = st->sv;
@@ -109,26 +104,13 @@ __global__ __launch_bounds__(VEC_BLOCK) void k_init_w_slice(double *__restrict__
     double s = 0.0;
     const int64_t stride = (int64_t)gridDim.x * VEC_BLOCK;
     if (st->stop == 0)
-        for (int64_t i = (int64_t)blockIdx.x * VEC_BLOCK + threadIdx.x; i < chunk; i += stride) {
-            const int64_t j = map.nat(i);
-            if (j >= map.n) continue;
-            const double wn = V[j] * sv;
+        for (int64_t i = (int64_t)blockIdx.x * VEC_BLOCK + threadIdx.x; i < len; i += stride) {
+            const double wn = Vq[i] * sv;
             w[i] = wn;
             s += wn * wn;
         }
     const double tot = block_sum<VEC_BLOCK>(s, red);
     if (threadIdx.x == 0) partials[blockIdx.x] = tot;
-}
-
-// out[map.nat(i)] <- in[i]: a slice (x_q, se_q) written at its places of a natural-order vector
-__global__ __launch_bounds__(VEC_BLOCK) void k_slice_to_natural(double *__restrict__ out, const double *__restrict__ in,
-                                                                int64_t chunk, SliceMap map)
-{
-    const int64_t stride = (int64_t)gridDim.x * VEC_BLOCK;
-    for (int64_t i = (int64_t)blockIdx.x * VEC_BLOCK + threadIdx.x; i < chunk; i += stride) {
-        const int64_t j = map.nat(i);
-        if (j < map.n) out[j] = in[i];
-    }
 }
 
 // sums[0] <- the np partials of sum (V_q ns)^2 in fixed order, sums[1] <- *wsq (this rank's sum of w_q^2)
@@ -166,55 +148,6 @@ __global__ void k_shard_s3(const double *__restrict__ sums, LsqrState *st, const
 
 }  // namespace lsqrhip
 
-// The slice geometry of rank `rank` of P for n columns.  G <= 1: one contiguous slice of ceil(n / P).  Else
-// `bounds` = c_0 .. c_G with c_0 = 0, c_g multiples of P (g < G), c_G >= n: piece g is the rank-th P-th of
-// [c_g, c_{g+1}) (the last group rounded up to a multiple of P).
-static int shard_geometry(int n, int P, int rank, int G, const int64_t *bounds, SliceMap *map, int64_t *chunk,
-                          int64_t *nfull)
-{
-    SliceMap mp;
-    mp.n = n;
-    if (G <= 1) {
-        const int64_t c = ((int64_t)n + P - 1) / P;
-        mp.G = 1;
-        mp.loc0[0] = 0;
-        mp.loc0[1] = c;
-        mp.nat0[0] = (int64_t)rank * c;
-        *chunk = c;
-        *nfull = c * P;
-    } else {
-        if (G > SHARD_MAX_PIECES || bounds[0] != 0 || bounds[G] < n) return fail(LSQRHIP_ERR_ARG, "bad slice bounds");
-        mp.G = G;
-        int64_t loc = 0, end = 0;
-        for (int g = 0; g < G; ++g) {
-            const int64_t span = bounds[g + 1] - bounds[g];
-            if (span < 0 || (g + 1 < G && span % P != 0)) return fail(LSQRHIP_ERR_ARG, "slice bounds must be multiples of P");
-            const int64_t pl = (span + P - 1) / P;
-            mp.loc0[g] = loc;
-            mp.nat0[g] = bounds[g] + (int64_t)rank * pl;
-            loc += pl;
-            end = bounds[g] + pl * P;
-        }
-        mp.loc0[G] = loc;
-        *chunk = loc;
-        *nfull = std::max<int64_t>(end, n);
-    }
-    *map = mp;
-    return LSQRHIP_OK;
-}
-
-// Ask for a slice in G pieces cut at `bounds` (G + 1 values) from the next lsqrhip_shard_begin on; G <= 1: the
-// plain contiguous slices.  Every rank of a world must use the same bounds.  The caller's T and V then hold
-// lsqrhip_shard_nfull elements, R world * lsqrhip_shard_chunk.
-extern "C" int lsqrhip_shard_set_pieces(lsqrhip_handle_t h, int G, const int64_t *bounds)
-{
-    if (!h) return fail(LSQRHIP_ERR_NOT_INIT, lsqrhip_error_string(LSQRHIP_ERR_NOT_INIT));
-    if (G > SHARD_MAX_PIECES || (G > 1 && !bounds)) return fail(LSQRHIP_ERR_ARG, "bad number of pieces");
-    h->shard.G_req = G > 1 ? G : 0;
-    for (int g = 0; g <= G && G > 1; ++g) h->shard.bounds_req[g] = bounds[g];
-    return LSQRHIP_OK;
-}
-
 // stage ids (keep in sync with lsqr_amd/dist.py)
 enum {
     ST_SUMSQ_B = 0,        // sums[0..2] = Blue's sums of b_p^2                       -> all-reduce sums[0..2]
@@ -241,7 +174,9 @@ extern "C" int lsqrhip_shard_begin(lsqrhip_handle_t h, const double *d_b_local, 
     ShardCtx &c = h->shard;
     c.P = world;
     c.rank = rank;
-    RET(shard_geometry(h->n, world, rank, c.G_req, c.bounds_req, &c.map, &c.chunk, &c.nfull));
+    c.chunk = ((int64_t)h->n + world - 1) / world;
+    c.my0 = std::min<int64_t>((int64_t)rank * c.chunk, h->n);
+    c.mylen = std::min<int64_t>(c.chunk, (int64_t)h->n - c.my0);
     c.T = d_T; c.R = d_R; c.V = d_V; c.sums = d_sums;
     c.wantse = wantse;
     if (!c.wsq) HIPCHK(hipMalloc((void **)&c.wsq, sizeof(double)));
@@ -264,14 +199,14 @@ extern "C" int lsqrhip_shard_begin(lsqrhip_handle_t h, const double *d_b_local, 
     init.c1.skip = init.c2.skip = init.c2p.skip = 1;
     *h->h_state = init;
     HIPCHK(hipMemcpyAsync(h->d_state, h->h_state, sizeof(LsqrState), hipMemcpyHostToDevice, s));
-    const size_t m = (size_t)h->m, full = (size_t)c.nfull, rfull = (size_t)(c.chunk * world);
-    const size_t sl = std::min((size_t)std::max<int64_t>(c.chunk, 0), (size_t)std::max(h->n, 1));
+    const size_t m = (size_t)h->m, full = (size_t)(c.chunk * world);
+    const size_t sl = std::min((size_t)std::max<int64_t>(c.chunk, 0), (size_t)h->n);
     if (m > 0) HIPCHK(hipMemcpyAsync(h->U, d_b_local, sizeof(double) * m, hipMemcpyDeviceToDevice, s));
     if (full > 0) {
         HIPCHK(hipMemsetAsync(c.V, 0, sizeof(double) * full, s));
         HIPCHK(hipMemsetAsync(c.T, 0, sizeof(double) * full, s));
+        HIPCHK(hipMemsetAsync(c.R, 0, sizeof(double) * full, s));
     }
-    if (rfull > 0) HIPCHK(hipMemsetAsync(c.R, 0, sizeof(double) * rfull, s));
     if (sl > 0) {   // x_q, w_q, se_q live at the start of the handle's n-vectors
         HIPCHK(hipMemsetAsync(h->X, 0, sizeof(double) * sl, s));
         HIPCHK(hipMemsetAsync(h->W, 0, sizeof(double) * sl, s));
@@ -293,8 +228,9 @@ extern "C" int lsqrhip_shard_stage(lsqrhip_handle_t h, int stage)
     LsqrState *st = h->d_state;
     ShardCtx &c = h->shard;
     double *T = c.T, *sums = c.sums;
+    double *Vq = c.V + c.my0;
     const int64_t m = h->m;
-    const int gq = vec_grid(2 * std::max<int64_t>(c.chunk, 1));
+    const int gq = vec_grid(2 * std::max<int64_t>(c.mylen, 1));
     switch (stage) {
     case ST_SUMSQ_B:
         hipLaunchKernelGGL(k_sumsq3, dim3(h->vgrid_m), dim3(VEC_BLOCK), 0, s, (const double *)h->U, m, h->partials);
@@ -307,7 +243,7 @@ extern "C" int lsqrhip_shard_stage(lsqrhip_handle_t h, int stage)
         launch_spmv(h, h->AT, h->U, T, &st->c2p, h->d_zero, nullptr, nullptr, true);
         break;
     case ST_INIT_V:
-        hipLaunchKernelGGL(k_rs_combine, dim3(gq), dim3(VEC_BLOCK), 0, s, c.V, (const double *)c.R, c.P, c.chunk, c.map,
+        hipLaunchKernelGGL(k_rs_combine, dim3(gq), dim3(VEC_BLOCK), 0, s, Vq, (const double *)c.R, c.P, c.chunk, c.mylen,
                            (const SpmvCoef *)&st->c2, (const int *)h->d_zero, h->partials, h->nsc);
         hipLaunchKernelGGL(k_shard_sums, dim3(1), dim3(VEC_BLOCK), 0, s, (const double *)h->partials, gq,
                            (const double *)c.wsq, sums, (const SpmvCoef *)&st->c2);
@@ -315,7 +251,7 @@ extern "C" int lsqrhip_shard_stage(lsqrhip_handle_t h, int stage)
     case ST_INIT_W:
         hipLaunchKernelGGL((k_s_init2<false>), dim3(1), dim3(SC_BLOCK), 0, s, (const double *)h->partials, 0,
                            (const double *)sums, st);
-        hipLaunchKernelGGL(k_init_w_slice, dim3(gq), dim3(VEC_BLOCK), 0, s, h->W, (const double *)c.V, c.chunk, c.map,
+        hipLaunchKernelGGL(k_init_w_slice, dim3(gq), dim3(VEC_BLOCK), 0, s, h->W, (const double *)Vq, c.mylen,
                            (const LsqrState *)st, h->partials);
         hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(VEC_BLOCK), 0, s, (const double *)h->partials, gq, c.wsq);
         break;
@@ -330,7 +266,7 @@ extern "C" int lsqrhip_shard_stage(lsqrhip_handle_t h, int stage)
         launch_spmv(h, h->AT, h->U, T, &st->c2p, &st->stop, nullptr, nullptr, true);
         break;
     case ST_VCOMBINE:
-        hipLaunchKernelGGL(k_rs_combine, dim3(gq), dim3(VEC_BLOCK), 0, s, c.V, (const double *)c.R, c.P, c.chunk, c.map,
+        hipLaunchKernelGGL(k_rs_combine, dim3(gq), dim3(VEC_BLOCK), 0, s, Vq, (const double *)c.R, c.P, c.chunk, c.mylen,
                            (const SpmvCoef *)&st->c2, (const int *)&st->stop, h->partials, h->nsc);
         hipLaunchKernelGGL(k_shard_sums, dim3(1), dim3(VEC_BLOCK), 0, s, (const double *)h->partials, gq,
                            (const double *)c.wsq, sums, (const SpmvCoef *)&st->c2);
@@ -339,8 +275,8 @@ extern "C" int lsqrhip_shard_stage(lsqrhip_handle_t h, int stage)
         hipLaunchKernelGGL(k_shard_s2, dim3(1), dim3(1), 0, s, (const double *)sums, st, c.live);
         hipLaunchKernelGGL(k_shard_s3, dim3(1), dim3(1), 0, s, (const double *)sums, st, (const int *)c.live,
                            (const double *)h->X, h->d_log);
-        hipLaunchKernelGGL(k_update_slice, dim3(gq), dim3(VEC_BLOCK), 0, s, h->X, h->W, (const double *)c.V, h->SE,
-                           c.chunk, c.map, (const LsqrState *)st, (const int *)c.live, h->partials);
+        hipLaunchKernelGGL(k_update_slice, dim3(gq), dim3(VEC_BLOCK), 0, s, h->X, h->W, (const double *)Vq, h->SE,
+                           c.mylen, (const LsqrState *)st, (const int *)c.live, h->partials);
         hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(VEC_BLOCK), 0, s, (const double *)h->partials, gq, c.wsq);
         break;
     default:
@@ -385,16 +321,13 @@ extern "C" int lsqrhip_shard_end(lsqrhip_handle_t h, double *d_x, double *d_se, 
     HIPCHK(hipSetDevice(h->device));
     hipStream_t s = h->stream;
     ShardCtx &c = h->shard;
-    const size_t len = (size_t)std::min<int64_t>(std::max<int64_t>(c.chunk, 0), std::max(h->n, 1));
-    const int gq = vec_grid(2 * std::max<int64_t>(c.chunk, 1));
-    if (c.wantse && len > 0)   // (slice elements past n are zeros and stay zeros)
+    const size_t len = (size_t)std::max<int64_t>(c.mylen, 0);
+    if (c.wantse && len > 0)
         hipLaunchKernelGGL(k_se_finish, dim3(vec_grid(2 * (int64_t)len)), dim3(VEC_BLOCK), 0, s, h->SE, (int64_t)len,
                            (const LsqrState *)h->d_state);
-    if (d_x && len > 0)
-        hipLaunchKernelGGL(k_slice_to_natural, dim3(gq), dim3(VEC_BLOCK), 0, s, d_x, (const double *)h->X, c.chunk, c.map);
+    if (d_x && len > 0) HIPCHK(hipMemcpyAsync(d_x + c.my0, h->X, sizeof(double) * len, hipMemcpyDeviceToDevice, s));
     if (d_se && c.wantse && len > 0)
-        hipLaunchKernelGGL(k_slice_to_natural, dim3(gq), dim3(VEC_BLOCK), 0, s, d_se, (const double *)h->SE, c.chunk, c.map);
-    HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(d_se + c.my0, h->SE, sizeof(double) * len, hipMemcpyDeviceToDevice, s));
     HIPCHK(hipMemcpyAsync(h->h_state, h->d_state, sizeof(LsqrState), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     const LsqrState &r = *h->h_state;
