@@ -398,7 +398,7 @@ def run_single(args):
         "result": {"istop": r.istop, "itn": r.itn, "anorm": r.anorm, "rnorm": r.rnorm},
     }
     if not args.no_roofline:
-        reps = min(max(K, 100), 1000) if facts["nnz"] < 50_000_000 else (100 if facts["nnz"] < 200_000_000 else 10)
+        reps = min(max(K, 500), 1000) if facts["nnz"] < 50_000_000 else (100 if facts["nnz"] < 200_000_000 else 10)
         roof, kernels, (alg1, alg2, lay1, lay2) = product_roofline(s, facts, reps, tr(spec, {}))
         if roof["traffic"] is None:
             roof["traffic_note"] = traffic_note
