@@ -7,42 +7,53 @@
 //
 //     y_i  <-  cy * (y_i * sy)  +  sum_j A_ij * (x_j * sx)        partial += (y_i * ns)^2
 //
-// Why.  With scattered columns every gathered x_j is an L1 miss, and a CU retires only ~0.3 misses
-// per clock from L2 (64 outstanding lines / ~220 cycles) and a third of that from beyond
-// (scripts/gather_roof.hip).  Column PANELS (spmv.h) bring the gathers into L2 but pay for it with
-// row pointers per (row, panel), per-panel row sums Z written and re-read, and a combine launch:
-// 1.6x the algorithmic bytes at config 4, 18.6 % of the HBM roofline.  Here instead:
+// Why.  With scattered columns every gathered x_j is an L1 miss, and a CU keeps only ~64 cache lines in
+// flight: ~0.3 misses per clock from L2 (~220 cycles), a third of that from beyond (scripts/gather_roof.hip),
+// and the (value, index) stream from HBM competes for the same slots.  Column PANELS (spmv.h) bring the
+// gathers into L2 but pay for it with row pointers per (row, panel), per-panel row sums Z written and
+// re-read, and a combine launch: 1.6x the algorithmic bytes at config 4.  Here instead:
 //
-//   * rows are cut into blocks of R <= 10112 rows, and the nonzeros of a block are stored SORTED BY
+//   * rows are cut into blocks of R <= 20352 rows, and the nonzeros of a block are stored SORTED BY
 //     COLUMN: one 1024-thread workgroup (one per CU) sweeps x from left to right while it streams
 //     its block -- 8-byte value + 4-byte (local row | local column) = 12 bytes per nonzero, the
 //     algorithmic minimum, and no row pointers at all.  All workgroups sweep at the same pace, so
-//     the part of x they are gathering from is in L2 (scripts/csb_roof.hip: the sweep sustains the
-//     L2-resident gather rate with an x of any size, and the 64 lanes of a gather touch
-//     neighbouring lines: 176 / 215 / 476 G nonzeros/s at 0.08 / 0.1 / 0.8 nonzeros per column and block).
-//   * the block's row sums are accumulated IN LDS with ds_add_f64 (measured free beside the
-//     gathers).  Floating-point adds in an order nobody controls would not be reproducible, so each
-//     product is first split EXACTLY into two parts on fixed binary grids,
-//         hi = the multiple of q0 nearest p,     lo = the multiple of q1 nearest p - hi,
-//     with q0 = 2^(E+H-53), q1 = q0 * 2^(H-54): 2^E bounds |p| (max|a| * max|x sx|), 2^(H-1) bounds
-//     the nonzeros of a row.  Sums of such multiples stay below 2^53 grid steps, so every ds_add_f64
-//     is exact and the result does not depend on the order of the adds -- nor on R, the grid or
-//     which workgroup took which block: bit-reproducible by construction.  What is dropped is
-//     below q1/2 = 2^(E+2H-108) per product: with rows of <= 2^14 nonzeros 80 bits below the
-//     largest possible product, i.e. the row sum is (far) more accurate than the reference's
-//     left-to-right sum, and agrees with it to rounding.
+//     the part of x they are gathering from is in L2, and the 64 lanes of a gather touch neighbouring
+//     lines: what a product costs is the number of LINES of x a block touches, i.e. it falls with
+//     R d / n, the nonzeros a block holds per column -- hence R as large as the LDS allows.
+//   * the block's row sums are accumulated IN LDS, one 64-bit INTEGER per row (ds_add_u64).  Floating-
+//     point adds in an order nobody controls would not be reproducible; integer adds are exact and
+//     order-free by nature.  Each product p is rounded once to the fixed binary grid
+//         g = 2^(eb - 61),      2^eb > B >= |sum_j A_ij (x_j sx)| for every row i,
+//     q = rint(p / g) is added, and y's new part is (double)(sum of the q) * g: ONE more rounding.
+//     The bound B: for the solver's own unit vectors (|x sx|_2 <= 1) Cauchy-Schwarz gives
+//     B = max_i |a_i|_2; for caller vectors B = max_i |a_i|_1 * max|x sx| (a k_amax pass).  Both row
+//     norms are taken at build time (integer sums: deterministic).  Only the FINAL sum has to fit --
+//     two's-complement adds wrap, so partial sums in any order may overflow on the way -- and it
+//     does with two bits to spare whatever the row length.  So the result does not depend on the
+//     order of the adds, on R, on the launch shape, on which workgroup took which block or on column
+//     splits: bit-reproducible by construction.  Accuracy: each product is off by <= g/2 = 2^-62 B,
+//     i.e. a row of k nonzeros by <= k 2^-62 B (typically sqrt(k) 2^-63 B) where the reference's
+//     left-to-right sum is off by up to k 2^-53 |a_i|'|x|: for rows whose products are of the size
+//     the bound allows this is ~500 times closer to the exact sum, normwise always at least as close.
+//     (r02 kept two parts per row, 12-16 bytes: 9766-13021 rows per block at config 4; 8 bytes per
+//     row give 19532 -- 50 % more nonzeros per column of x in every sweep and 2 rounds instead of 3.)
+//   * a product beyond the bound or not finite (inf / NaN in x: never in a solve that has not
+//     already failed) cannot enter an integer sum: the sweep leaves it out and raises a flag, and
+//     the block's epilogue then reads the stream a second time, adds ONLY those products as doubles
+//     and patches the rows concerned -- inf and NaN come out as IEEE addition gives them, like the
+//     reference's (tests/test_gpu_csb.py::test_non_finite_and_huge_x_as_the_reference).
 //   * the epilogue of a block forms y_i, the block's partial of sum (y ns)^2 (one per BLOCK, so the
 //     fixed-order reduction is independent of the launch shape) and clears the accumulators.
 //
-// Layout (built once by csb_build below from the COO triplets, stable LSD radix sorts of csr_build.h):
+// Layout (built once by build_csb from the COO triplets, stable LSD radix sorts of csr_build.h):
 //   block b = rows [rstart[b], rstart[b+1]): at most R rows, cut so that every block holds about the
 //   same number of NONZEROS (equal sweeps: workgroups that start together must stay within ~1 % of
 //   each other's column for the x they gather to be in L2 -- with equal ROW counts a square random
 //   matrix's transpose, whose rows are Poisson(100) long, ran 16 % slower than the matrix itself);
 //   its nonzeros sorted by column (ties: COO order), padded to whole chunks of 256 (pad = value 0
 //   aimed at a dummy accumulator);
-//   cptr[b] = first chunk of block b; val[k], idx[k] = lrow << 18 | (col - cbase[k / 256]);
-//   cbase[c] = column of the first nonzero of chunk c.  A chunk spans < 2^18 columns or the build
+//   cptr[b] = first chunk of block b; val[k], idx[k] = lrow << 17 | (col - cbase[k / 256]);
+//   cbase[c] = column of the first nonzero of chunk c.  A chunk spans < 2^17 columns or the build
 //   gives up (an almost empty block: such a matrix keeps the panel layout).
 #pragma once
 
@@ -57,14 +68,14 @@ constexpr int CSB_BLOCK = 1024;
 constexpr int CSB_WAVES = CSB_BLOCK / WAVE;
 constexpr int CSB_U = 4;                         // nonzeros per lane and step
 constexpr int CSB_CHUNK = CSB_U * WAVE;          // 256: what one wave takes per step
-constexpr int CSB_RMAX = 10112;                  // rows per block: 2 accumulators of 8 bytes in 160 KB of LDS
-constexpr int CSB_RMAX32 = 13504;                // ... with the low parts as 32-bit integers (12 bytes per row)
-constexpr int CSB_LO32_MAXH = 10;                // that form is used for rows of <= 512 nonzeros
-constexpr int CSB_LDS_BYTES = (CSB_RMAX + 64) * 16;
-static_assert((CSB_RMAX32 + 64) * 12 <= CSB_LDS_BYTES, "both accumulator forms share one LDS array");
-constexpr int CSB_LCOL_BITS = 18;
+constexpr int CSB_RMAX = 20352;                  // rows per block: one 8-byte accumulator each in 160 KB of LDS
+constexpr int CSB_NACC = CSB_RMAX + 64;          // + the padding's dummy accumulator (index R)
+static_assert(CSB_NACC * 8 + (CSB_WAVES + 2) * 8 + 16 <= 160 * 1024, "accumulators + reduction scratch fit the LDS");
+constexpr int CSB_LCOL_BITS = 17;
 constexpr unsigned CSB_LCOL_MASK = (1u << CSB_LCOL_BITS) - 1u;
+static_assert(CSB_NACC <= (1 << (32 - CSB_LCOL_BITS)), "local rows fit the index word");
 constexpr int CSB_GRID = 256;                    // one workgroup per CU
+constexpr int CSB_NORM_FRAC = 32;                // build: row norms as integer sums of |a| 2^(32 - ea), a^2 2^(32 - 2 ea)
 // The (value, index) stream is read once: loaded non-temporal so that it does not push the part of x the
 // XCD's workgroups are gathering from out of L2 (PMC before: 15 % of the gathers missed L2, 2.6x the
 // layout's bytes fetched; config 4 4.80 -> 4.20 ms, config 3 at 100 per row 956 -> 900 us).
@@ -79,13 +90,18 @@ struct CsbMat {
     const long long *cptr;  // [nrb + 1], in chunks
     const int *rstart;      // [nrb + 1] first row of each block (blocks are cut by NONZEROS, at most R rows each)
     int nrb, R, rows, cols; // R = the dummy accumulator's index = rows per block at most
-    int ea;  // 2^ea > max|a_ij|
-    int H;   // 2^(H-1) >= nonzeros of the longest row, H >= 3
+    int e1;  // 2^e1 > max_i sum_j |a_ij|          (bound on a row sum for |x sx| <= 1 elementwise)
+    int e2;  // 2^e2 > max_i sqrt(sum_j a_ij^2)    (bound on a row sum for |x sx|_2 <= 1)
     int b0, b1;  // the row blocks of THIS launch: [b0, b1)
     int S;       // column splits: S workgroups share a row block, each sweeping 1/S of its chunks (see below)
-    double *zhi, *zlo;  // S > 1: the splits' exact partial sums, [S][rows] each
-    double *q1out;      // S > 1: this launch's q1 for k_csb_combine
+    long long *z;   // S > 1: the splits' exact integer sums, [S][rows]
+    int *bad;       // S > 1: [nrb] a split of the block left a product out (beyond the bound / not finite)
+    double *gout;   // S > 1: this product's grid step g for k_csb_combine
+    int *prog;      // pacing: [8][64] progress words, one per workgroup, grouped by blockIdx & 7 (see "pacing")
+    int pace;       // pacing: steps a wave may be ahead of the slowest workgroup of its group (0 = off)
 };
+constexpr int CSB_PROG_WORDS = 8 * 64;
+constexpr int CSB_PROG_DONE = 0x7fffffff;
 
 // ---------------------------------------------------------------------------------------------
 // build
@@ -110,17 +126,41 @@ __global__ __launch_bounds__(256) void k_csb_pack_col(const int *__restrict__ ro
     if (uns) atomicOr(&flags[1], 1);
 }
 
-// pos1[i] = original position of the i-th nonzero in column order; cnt[row] += 1
+// pos1[i] = original position of the i-th nonzero in column order; cnt[row] += 1; and the row norms behind
+// the bound on a row sum (header): n1[row] += ceil(|a| 2^(32 - ea)), n2[row] += ceil(a^2 2^(32 - 2 ea)) with
+// 2^ea > max|a| -- integer sums, so the bounds do not depend on the order of the atomics.  (A value that is
+// not finite counts as 2^ea: its products are left to the outlier pass anyway.)
 __global__ __launch_bounds__(256) void k_csb_pos(const unsigned long long *__restrict__ sorted, int64_t nnz,
-                                                 const int *__restrict__ rowk, unsigned *__restrict__ pos1,
-                                                 int *__restrict__ cnt)
+                                                 const int *__restrict__ rowk, const double *__restrict__ a, double sc,
+                                                 unsigned *__restrict__ pos1, int *__restrict__ cnt,
+                                                 unsigned long long *__restrict__ n1, unsigned long long *__restrict__ n2)
 {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const double one = (double)(1ull << CSB_NORM_FRAC);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nnz; i += stride) {
         const unsigned p = (unsigned)(sorted[i] & 0xffffffffull);
         pos1[i] = p;
-        atomicAdd(&cnt[rowk[p] - 1], 1);
+        const int r = rowk[p] - 1;
+        atomicAdd(&cnt[r], 1);
+        double t = fabs(a[p]) * sc;      // in [0, 1)
+        t = t < 1.0 ? t : 1.0;           // (inf, NaN -> 1)
+        atomicAdd(&n1[r], (unsigned long long)ceil(t * one));
+        atomicAdd(&n2[r], (unsigned long long)ceil(t * t * one));
     }
+}
+
+__global__ __launch_bounds__(256) void k_csb_maxu64(const unsigned long long *__restrict__ a, int64_t n,
+                                                    unsigned long long *__restrict__ out)
+{
+    unsigned long long m = 0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) m = a[i] > m ? a[i] : m;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long o = __shfl_xor(m, off, WAVE);
+        m = o > m ? o : m;
+    }
+    if ((threadIdx.x & (WAVE - 1)) == 0 && m > 0) atomicMax(out, m);
 }
 
 __global__ __launch_bounds__(256) void k_csb_maxint(const int *__restrict__ a, int64_t n, int *__restrict__ out)
@@ -152,7 +192,7 @@ __global__ __launch_bounds__(256) void k_csb_pack_rb(const int *__restrict__ row
 }
 
 // One workgroup per chunk: element t of chunk c of block b is the (c - cptr[b]) * 256 + t -th nonzero
-// of the block in column order, or padding.  flags[3] |= 1 if a chunk spans 2^18 columns or more.
+// of the block in column order, or padding.  flags[3] |= 1 if a chunk spans 2^17 columns or more.
 __global__ __launch_bounds__(CSB_CHUNK) void k_csb_fill(const unsigned long long *__restrict__ sorted2,
                                                         const unsigned *__restrict__ pos1,
                                                         const int *__restrict__ rowk, const int *__restrict__ colk,
@@ -203,29 +243,135 @@ __global__ __launch_bounds__(CSB_CHUNK) void k_csb_fill(const unsigned long long
 // product
 // ---------------------------------------------------------------------------------------------
 struct CsbX {
-    const double *xmax;  // partials of max|x| (vec.h k_amax), or null: |x sx| <= 1 is known
+    const double *xmax;  // partials of max|x| (vec.h k_amax), or null: |x sx|_2 <= 1 is known
     int nxmax;
 };
 
-// LO32 = false: hi and lo parts both as doubles on the grids q0, q1 of the header (any row length).
-// LO32 = true (rows of <= 512 nonzeros, H <= 10): the low part as a 32-bit INTEGER count of steps of
-// q1' = q0 / 2^(31-H) -- |lo| <= q0/2 is at most 2^(30-H) steps, 2^(H-1) of them stay below 2^31 --
-// accumulated with ds_add_u32 (integer adds are exact and order-free by nature).  12 bytes per row
-// instead of 16: a third more rows per block, i.e. a third more nonzeros per column of x in every sweep
-// (config 4: 13021 instead of 9766 rows per block).  Dropped per product: < q1'/2 = 2^(E+2H-85).
-template <bool LO32, typename VT = double>
+// sx, sy, cy of this launch: explicit (coef) or lazy from the previous kernel's partials (pin) -- the
+// 256-thread fixed-order reduction of the other kernels, bit for bit.  `nrm` is the lazy norm.
+struct CsbCoef {
+    double sx, sy, cy, nrm;
+    bool skip;
+};
+__device__ __forceinline__ CsbCoef csb_coef(const SpmvCoef *__restrict__ coef, const double *__restrict__ pin, int npin,
+                                            const NormSlot *__restrict__ slot_in, int skip_if_zero, NScale nsc,
+                                            double *red)
+{
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1);
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    CsbCoef c{1.0, 1.0, 1.0, 0.0, false};
+    if (pin != nullptr) {
+        double s = 0.0;
+        if (tid < SC_BLOCK && npin > 0) s = strided_sum<SC_BLOCK>(pin, npin);
+        s = wave_sum(s);
+        if (tid < SC_BLOCK && lane == 0) red[w] = s;
+        __syncthreads();
+        if (tid == 0) {
+            double r = 0.0;
+#pragma unroll
+            for (int i = 0; i < SC_BLOCK / WAVE; ++i) r += red[i];
+            red[CSB_WAVES] = r;
+        }
+        __syncthreads();
+        c.nrm = sqrt(red[CSB_WAVES]) * nsc.inv;
+        __syncthreads();
+        c.skip = skip_if_zero && !(c.nrm > 0.0);   // mode 2 is skipped when beta == 0 (:691)
+        c.sx = c.nrm > 0.0 ? 1.0 / c.nrm : 1.0;
+        c.cy = -c.nrm;
+        c.sy = slot_in->scale;
+    } else {
+        c.skip = coef->skip != 0;
+        c.sx = coef->sx;
+        c.sy = coef->sy;
+        c.cy = coef->cy;
+    }
+    return c;
+}
+
+// 2^eb > the bound on |row sum| of this launch (header); every thread gets the same value.
+__device__ __forceinline__ int csb_bound_exp(const CsbMat &A, CsbX xb, double sx, double *red)
+{
+    int eb = A.e2;   // |x sx|_2 <= 1: the solver's own unit vectors
+    if (xb.xmax != nullptr) {
+        const int tid = threadIdx.x, lane = tid & (WAVE - 1);
+        const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+        double m = 0.0;
+        for (int i = tid; i < xb.nxmax; i += CSB_BLOCK) m = fmax(m, xb.xmax[i]);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off, WAVE));
+        if (lane == 0) red[w] = m;
+        __syncthreads();
+        m = red[0];
+#pragma unroll
+        for (int i = 1; i < CSB_WAVES; ++i) m = fmax(m, red[i]);
+        __syncthreads();
+        const double bound = m * fabs(sx);
+        int ex = 0;
+        if (bound > 0.0 && bound < 1.0e308) (void)frexp(bound, &ex);  // bound < 2^ex
+        eb = A.e1 + ex;
+    }
+    eb = eb > 1020 ? 1020 : eb;      // 2^eb and 2^(61 - eb) must stay finite and normal
+    eb = eb < -960 ? -960 : eb;
+    return eb;
+}
+
+// Rows that were sent a product beyond the bound or not finite.  The sweep left those products out (an
+// integer sum cannot hold them); here the chunks [c0, c1) of the block are read once more, ONLY those
+// products are added -- as doubles, in LDS (`accd`: the block's accumulators, all zero on entry and on
+// exit) -- and the rows concerned are patched in y: inf and NaN come out as IEEE addition gives them,
+// which is what the reference's row sum does with them.  Reached when x (or A) holds inf / NaN or
+// |x| is not what the bound was taken from; never by a healthy solve.
+template <typename VT>
+__device__ void csb_add_outliers(const CsbMat &A, const VT *__restrict__ aval, long long c0, long long c1,
+                                 const VT *__restrict__ x, double sx, double pmax, double *accd,
+                                 VT *__restrict__ y, int row0, int nr)
+{
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1);
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (long long c = c0 + w; c < c1; c += CSB_WAVES) {
+        const int base = A.cbase[c];
+        const long long k = c * CSB_CHUNK + lane;
+#pragma unroll
+        for (int j = 0; j < CSB_U; ++j) {
+            const unsigned i = A.idx[k + j * WAVE];
+            const double p = (double)aval[k + j * WAVE] * ((double)x[base + (int)(i & CSB_LCOL_MASK)] * sx);
+            const int r = (int)(i >> CSB_LCOL_BITS);
+            if (!(fabs(p) < pmax) && r < nr) atomicAdd(&accd[r], p);
+        }
+    }
+    __syncthreads();
+    for (int r = tid; r < nr; r += CSB_BLOCK) {
+        const double v = accd[r];
+        if (v != 0.0) {   // (true for NaN)
+            y[row0 + r] = (VT)((double)y[row0 + r] + v);
+            accd[r] = 0.0;
+        }
+    }
+    __syncthreads();
+}
+
+// the block's partial of sum (y ns)^2 from y as stored, with the epilogue's thread -> row mapping and reduction
+template <typename VT>
+__device__ __forceinline__ double csb_sumsq_rows(const VT *__restrict__ y, int row0, int nr, NScale nsc)
+{
+    double sq = 0.0;
+    for (int r = threadIdx.x; r < nr; r += CSB_BLOCK) {
+        const double ys = (double)y[row0 + r] * nsc.s;
+        sq += ys * ys;
+    }
+    return sq;
+}
+
+template <typename VT = double>
 __global__ __launch_bounds__(CSB_BLOCK, 1) void k_spmv_csb(
     CsbMat A, const VT *__restrict__ x, VT *__restrict__ y, const SpmvCoef *__restrict__ coef,
     const int *__restrict__ stop, double *__restrict__ partials, const double *__restrict__ pin, int npin,
     const NormSlot *__restrict__ slot_in, NormSlot *__restrict__ slot_out, int skip_if_zero, Rider rider, CsbX xb,
     NScale nsc)
 {
-    __shared__ double acc_raw[CSB_LDS_BYTES / 8];
+    __shared__ unsigned long long acc[CSB_NACC];
     __shared__ double red[CSB_WAVES + 2];
-    constexpr int NR = LO32 ? CSB_RMAX32 + 64 : CSB_RMAX + 64;
-    double *const acc_hi = acc_raw;
-    double *const acc_lo = acc_raw + NR;                              // LO32 = false
-    int *const acc_li = reinterpret_cast<int *>(acc_raw + NR);        // LO32 = true
+    __shared__ int s_bad;
     const int tid = threadIdx.x;
     const int lane = tid & (WAVE - 1);
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -240,86 +386,43 @@ __global__ __launch_bounds__(CSB_BLOCK, 1) void k_spmv_csb(
     if (*stop != 0) return;
     const VT *__restrict__ aval = static_cast<const VT *>(A.val);
 
-    double sx, sy, cy;
-    if (pin != nullptr) {
-        // the 256-thread fixed-order reduction of the other kernels, bit for bit
-        double s = 0.0;
-        if (tid < SC_BLOCK && npin > 0) s = strided_sum<SC_BLOCK>(pin, npin);
-        s = wave_sum(s);
-        if (tid < SC_BLOCK && lane == 0) red[w] = s;
-        __syncthreads();
-        if (tid == 0) {
-            double r = 0.0;
-#pragma unroll
-            for (int i = 0; i < SC_BLOCK / WAVE; ++i) r += red[i];
-            red[CSB_WAVES] = r;
-        }
-        __syncthreads();
-        const double nrm = sqrt(red[CSB_WAVES]) * nsc.inv;
-        __syncthreads();
-        if (skip_if_zero && !(nrm > 0.0)) {  // mode 2 is skipped when beta == 0 (:691)
-            if (wg == 0 && tid == 0) {
-                slot_out->nrm = nrm;
-                slot_out->scale = 1.0;
-            }
-            return;
-        }
-        sx = nrm > 0.0 ? 1.0 / nrm : 1.0;
-        cy = -nrm;
-        sy = slot_in->scale;
-        if (wg == 0 && tid == 0) {
-            slot_out->nrm = nrm;
-            slot_out->scale = sx;
-        }
-    } else {
-        if (coef->skip != 0) return;
-        sx = coef->sx;
-        sy = coef->sy;
-        cy = coef->cy;
+    const CsbCoef co = csb_coef(coef, pin, npin, slot_in, skip_if_zero, nsc, red);
+    if (pin != nullptr && wg == 0 && tid == 0) {
+        slot_out->nrm = co.nrm;
+        slot_out->scale = co.skip ? 1.0 : co.sx;
     }
+    if (co.skip) return;
+    const double sx = co.sx, sy = co.sy, cy = co.cy;
 
-    // the binary grids of this launch: 2^E bounds |a_ij * (x_j sx)|
-    int ex = 1;  // |x sx| <= 1 (+ rounding) for the solver's own unit vectors
-    if (xb.xmax != nullptr) {
-        double m = 0.0;
-        for (int i = tid; i < xb.nxmax; i += CSB_BLOCK) m = fmax(m, xb.xmax[i]);
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off, WAVE));
-        if (lane == 0) red[w] = m;
-        __syncthreads();
-        m = red[0];
-#pragma unroll
-        for (int i = 1; i < CSB_WAVES; ++i) m = fmax(m, red[i]);
-        __syncthreads();
-        const double bound = m * fabs(sx);
-        ex = 0;
-        if (bound > 0.0 && bound < 1.0e308) (void)frexp(bound, &ex);  // bound < 2^ex
-    }
-    int E = A.ea + ex;
-    E = E > 1020 - A.H ? 1020 - A.H : E;                        // C0 must stay finite
-    E = E < 108 - 2 * A.H - 1020 ? 108 - 2 * A.H - 1020 : E;    // q1 must stay normal
-    const double C0 = ldexp(1.5, E + A.H - 1);        // 1.5 * 2^52 * q0
-    const int e1 = LO32 ? E + 2 * A.H - 84 : E + 2 * A.H - 107;   // q1 = 2^e1
-    const double C1 = ldexp(1.5, e1 + 52);            // 1.5 * 2^52 * q1
-    const long long C1bits = __double_as_longlong(C1);
-    const double q1 = ldexp(1.0, e1);
-    const double pmax = ldexp(1.0, E);
+    // the binary grid of this launch
+    const int eb = csb_bound_exp(A, xb, sx, red);
+    const double pmax = ldexp(1.0, eb);          // a product is in range below this
+    const double ginv = ldexp(1.0, 61 - eb);     // 1 / g
+    const double g = ldexp(1.0, eb - 61);
 
-    for (int i = tid; i < NR; i += CSB_BLOCK) {
-        acc_hi[i] = 0.0;
-        if (LO32) acc_li[i] = 0;
-        else acc_lo[i] = 0.0;
-    }
+    for (int i = tid; i < CSB_NACC; i += CSB_BLOCK) acc[i] = 0ull;
+    if (tid == 0) s_bad = 0;
     __syncthreads();
 
-    if (A.S > 1 && wg == 0 && tid == 0) *A.q1out = q1;
+    if (A.S > 1 && wg == 0 && tid == 0) *A.gout = g;
     // Column splits (few rows: fewer row blocks than CUs).  S workgroups share a block, each sweeping a
-    // contiguous S-th of its column-sorted chunks into accumulators of its own; their hi / lo sums go to
-    // zhi / zlo and k_csb_combine adds them -- sums on the grids are exact, so the result is bit for bit
-    // what ONE workgroup would have produced.  A block of R rows then still holds R d / n nonzeros per
-    // column although 256 / S blocks cover the matrix: R can stay large (one rank's block of config 4 at
-    // N = 8: 9766 instead of 4883 rows per block).
+    // contiguous S-th of its column-sorted chunks into accumulators of its own; their integer sums go to
+    // z and k_csb_combine adds them -- exact, so the result is bit for bit what ONE workgroup would have
+    // produced.  A block of R rows then still holds R d / n nonzeros per column although 256 / S blocks
+    // cover the matrix: R can stay large (one rank's block of config 4 at N = 8).
     const int nunits = (A.b1 - A.b0) * A.S;
+    // Pacing.  The workgroups of an XCD (blockIdx & 7 under the observed round-robin placement -- speed only)
+    // sweep the same columns, and an x line stays in their L2 for well under a percent of a sweep: a workgroup
+    // that runs ahead pays its gathers from the Infinity Cache, one that falls behind as well, and once apart
+    // they never meet again (PMC: 29 % of the gather requests missed L2).  So wave 0 of every workgroup
+    // publishes the steps it has done, and every wave looks at its group's 256-byte line once per step -- the
+    // load is issued behind the step's gathers and read a step later, when it has long returned: a wave's loads
+    // return in order, and a flag that is waited for at once drains the wave's whole pipeline (r02's attempt) --
+    // and sleeps while it is more than `pace` steps ahead of the slowest.  Only with one unit per workgroup and
+    // splits that put one column range on an XCD; bounded spins: placement or a missing peer cannot hang it.
+    const bool paced = A.pace > 0 && nunits <= nwg && nwg >= 16 && (8 % A.S) == 0;
+    int *const pgroup = A.prog + ((int)blockIdx.x & 7) * 64;
+    int *const pmine = pgroup + (((int)blockIdx.x >> 3) & 63);
     for (int u = wg; u < nunits; u += nwg) {
         const int b = A.b0 + u / A.S, sp = u % A.S;
         const long long cb0 = A.cptr[b], cb1 = A.cptr[b + 1];
@@ -329,6 +432,7 @@ __global__ __launch_bounds__(CSB_BLOCK, 1) void k_spmv_csb(
         double av[CSB_U], bv[CSB_U];
         unsigned iv[CSB_U], jv[CSB_U];
         int cb = 0, cbn = 0;
+        bool outlier = false;
         const long long clast = c1 > c0 ? c1 - 1 : c0;
         auto issue = [&](long long c, double (&a)[CSB_U], unsigned (&i)[CSB_U], int &base) {
             const long long cc = c < clast ? c : clast;
@@ -345,25 +449,33 @@ __global__ __launch_bounds__(CSB_BLOCK, 1) void k_spmv_csb(
                 }
             }
         };
+        int step = 0, seen = CSB_PROG_DONE;   // seen: the group's line as loaded one step ago (this lane's word)
         auto work = [&](const double (&a)[CSB_U], const unsigned (&i)[CSB_U], int base) {
+            if (paced) {
+                int slowest = seen;
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) slowest = min(slowest, __shfl_xor(slowest, off, WAVE));
+                for (int spin = 0; step > slowest + A.pace && spin < 4096; ++spin) {   // ahead: let the others catch up
+                    __builtin_amdgcn_s_sleep(16);
+                    slowest = __hip_atomic_load(&pgroup[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) slowest = min(slowest, __shfl_xor(slowest, off, WAVE));
+                }
+                if (w == 0 && lane == 0) __hip_atomic_store(pmine, step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             double xv[CSB_U];
 #pragma unroll
             for (int j = 0; j < CSB_U; ++j) xv[j] = (double)x[base + (int)(i[j] & CSB_LCOL_MASK)];
+            if (paced) seen = __hip_atomic_load(&pgroup[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ++step;
 #pragma unroll
             for (int j = 0; j < CSB_U; ++j) {
                 const double p = a[j] * (xv[j] * sx);
                 const int r = (int)(i[j] >> CSB_LCOL_BITS);
-                double hi = (p + C0) - C0;
-                const double t1 = (p - hi) + C1;       // C1 + (steps of q1): the steps sit in the low mantissa bits
-                const bool out = !(fabs(p) <= pmax);   // beyond the bound (or not finite): added as it is
-                if (out) hi = p;
-                atomicAdd(&acc_hi[r], hi);
-                if (LO32) {
-                    const int steps = out ? 0 : (int)(__double_as_longlong(t1) - C1bits);
-                    atomicAdd(&acc_li[r], steps);
-                } else {
-                    atomicAdd(&acc_lo[r], out ? 0.0 : t1 - C1);
-                }
+                const bool out = !(fabs(p) < pmax);   // beyond the bound (or not finite): left to the outlier pass
+                outlier |= out;
+                const long long q = __double2ll_rn(p * ginv);
+                atomicAdd(&acc[r], out ? 0ull : (unsigned long long)q);
             }
         };
         if (c0 + w < c1) {
@@ -377,43 +489,46 @@ __global__ __launch_bounds__(CSB_BLOCK, 1) void k_spmv_csb(
                 }
             }
         }
+        if (paced && w == 0 && lane == 0)
+            __hip_atomic_store(pmine, CSB_PROG_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (outlier) s_bad = 1;
         __syncthreads();
         // epilogue of the block: y, its partial of sum (y ns)^2, accumulators cleared
         const int row0 = A.rstart[b];
         const int nr = A.rstart[b + 1] - row0;
-        double sq = 0.0;
-        if (A.S > 1) {  // a split: the exact sums as they are (integer steps of q1 as doubles when LO32)
-            double *zh = A.zhi + (size_t)sp * A.rows + row0, *zl = A.zlo + (size_t)sp * A.rows + row0;
+        const bool bad = s_bad != 0;
+        __syncthreads();   // (everyone has read the flag: it may be lowered)
+        if (A.S > 1) {  // a split: the exact sums as they are
+            long long *zs = A.z + (size_t)sp * A.rows + row0;
             for (int r = tid; r < nr; r += CSB_BLOCK) {
-                zh[r] = acc_hi[r];
-                zl[r] = LO32 ? (double)acc_li[r] : acc_lo[r];
-                acc_hi[r] = 0.0;
-                if (LO32) acc_li[r] = 0;
-                else acc_lo[r] = 0.0;
+                zs[r] = (long long)acc[r];
+                acc[r] = 0ull;
             }
             if (tid == 0) {
-                acc_hi[A.R] = 0.0;
-                if (LO32) acc_li[A.R] = 0;
-                else acc_lo[A.R] = 0.0;
+                acc[A.R] = 0ull;
+                s_bad = 0;
+                if (bad) atomicOr(&A.bad[b], 1);
             }
             __syncthreads();
             continue;
         }
+        double sq = 0.0;
         for (int r = tid; r < nr; r += CSB_BLOCK) {
-            const double hi = acc_hi[r];
-            const double lo = LO32 ? (double)acc_li[r] * q1 : acc_lo[r];
-            acc_hi[r] = 0.0;
-            if (LO32) acc_li[r] = 0;
-            else acc_lo[r] = 0.0;
-            const VT yn = (VT)(cy * ((double)y[row0 + r] * sy) + (hi + lo));
+            const double sum = (double)(long long)acc[r] * g;
+            acc[r] = 0ull;
+            const VT yn = (VT)(cy * ((double)y[row0 + r] * sy) + sum);
             y[row0 + r] = yn;
             const double ys = (double)yn * nsc.s;
             sq += ys * ys;
         }
         if (tid == 0) {  // the padding's dummy accumulator
-            acc_hi[A.R] = 0.0;
-            if (LO32) acc_li[A.R] = 0;
-            else acc_lo[A.R] = 0.0;
+            acc[A.R] = 0ull;
+            s_bad = 0;
+        }
+        if (bad) {  // uniform
+            __syncthreads();
+            csb_add_outliers<VT>(A, aval, c0, c1, x, sx, pmax, reinterpret_cast<double *>(acc), y, row0, nr);
+            sq = csb_sumsq_rows<VT>(y, row0, nr, nsc);
         }
         sq = wave_sum(sq);
         if (lane == 0) red[w] = sq;
@@ -431,56 +546,45 @@ __global__ __launch_bounds__(CSB_BLOCK, 1) void k_spmv_csb(
 // The second launch of a column-split product: y and the blocks' partials of sum (y ns)^2 from the
 // splits' exact sums.  One workgroup per row block with the thread -> row mapping and the reduction of
 // k_spmv_csb's own epilogue, so y AND the partials are bit for bit those of the unsplit kernel.
-template <bool LO32, typename VT = double>
+template <typename VT = double>
 __global__ __launch_bounds__(CSB_BLOCK) void k_csb_combine(
-    CsbMat A, VT *__restrict__ y, const SpmvCoef *__restrict__ coef, const int *__restrict__ stop,
-    double *__restrict__ partials, const double *__restrict__ pin, int npin, const NormSlot *__restrict__ slot_in,
-    int skip_if_zero, NScale nsc)
+    CsbMat A, const VT *__restrict__ x, VT *__restrict__ y, const SpmvCoef *__restrict__ coef,
+    const int *__restrict__ stop, double *__restrict__ partials, const double *__restrict__ pin, int npin,
+    const NormSlot *__restrict__ slot_in, int skip_if_zero, NScale nsc)
 {
+    __shared__ double accd[CSB_NACC];   // the outlier pass only (all zero otherwise)
     __shared__ double red[CSB_WAVES + 2];
     const int tid = threadIdx.x, lane = tid & (WAVE - 1);
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (*stop != 0) return;
-    double sy, cy;
-    if (pin != nullptr) {
-        double s = 0.0;
-        if (tid < SC_BLOCK && npin > 0) s = strided_sum<SC_BLOCK>(pin, npin);
-        s = wave_sum(s);
-        if (tid < SC_BLOCK && lane == 0) red[w] = s;
-        __syncthreads();
-        if (tid == 0) {
-            double r = 0.0;
-#pragma unroll
-            for (int i = 0; i < SC_BLOCK / WAVE; ++i) r += red[i];
-            red[CSB_WAVES] = r;
-        }
-        __syncthreads();
-        const double nrm = sqrt(red[CSB_WAVES]) * nsc.inv;
-        __syncthreads();
-        if (skip_if_zero && !(nrm > 0.0)) return;
-        cy = -nrm;
-        sy = slot_in->scale;
-    } else {
-        if (coef->skip != 0) return;
-        sy = coef->sy;
-        cy = coef->cy;
-    }
-    const double q1 = *A.q1out;
+    const CsbCoef co = csb_coef(coef, pin, npin, slot_in, skip_if_zero, nsc, red);
+    if (co.skip) return;
+    const double sx = co.sx, sy = co.sy, cy = co.cy;
+    const double g = *A.gout;
+    const VT *__restrict__ aval = static_cast<const VT *>(A.val);
+    bool cleared = false;
     for (int b = blockIdx.x; b < A.nrb; b += gridDim.x) {
         const int row0 = A.rstart[b];
         const int nr = A.rstart[b + 1] - row0;
         double sq = 0.0;
         for (int r = tid; r < nr; r += CSB_BLOCK) {
-            double hi = A.zhi[row0 + r], lo = A.zlo[row0 + r];
-            for (int sp = 1; sp < A.S; ++sp) {
-                hi = hi + A.zhi[(size_t)sp * A.rows + row0 + r];
-                lo = lo + A.zlo[(size_t)sp * A.rows + row0 + r];
-            }
-            if (LO32) lo = lo * q1;
-            const VT yn = (VT)(cy * ((double)y[row0 + r] * sy) + (hi + lo));
+            long long s = A.z[row0 + r];
+            for (int sp = 1; sp < A.S; ++sp) s += A.z[(size_t)sp * A.rows + row0 + r];
+            const double sum = (double)s * g;
+            const VT yn = (VT)(cy * ((double)y[row0 + r] * sy) + sum);
             y[row0 + r] = yn;
             const double ys = (double)yn * nsc.s;
             sq += ys * ys;
+        }
+        if (A.bad[b] != 0) {  // uniform: a split of this block left products out (k_spmv_csb "outlier")
+            if (!cleared) {
+                for (int i = tid; i < CSB_NACC; i += CSB_BLOCK) accd[i] = 0.0;
+                cleared = true;
+            }
+            __syncthreads();   // (y of this block is written; accd is zero)
+            csb_add_outliers<VT>(A, aval, A.cptr[b], A.cptr[b + 1], x, sx, g * 0x1p61, accd, y, row0, nr);
+            sq = csb_sumsq_rows<VT>(y, row0, nr, nsc);
+            if (tid == 0) A.bad[b] = 0;
         }
         sq = wave_sum(sq);
         if (lane == 0) red[w] = sq;

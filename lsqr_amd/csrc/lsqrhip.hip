@@ -159,15 +159,16 @@ struct Csr {
     // column-swept row blocks (csb.h), used instead of everything above when `csb` is set
     int csb = 0;
     double *cval = nullptr;       // [nchunks * 256] values, each block sorted by column, padded to whole chunks
-    unsigned *cidx = nullptr;     // [nchunks * 256] local row << 18 | column - cbase[chunk]
+    unsigned *cidx = nullptr;     // [nchunks * 256] local row << 17 | column - cbase[chunk]
     int *ccb = nullptr;           // [nchunks] first column of each chunk
     long long *cptr = nullptr;    // [nrb + 1] first chunk of each row block
     int *crs = nullptr;           // [nrb + 1] first row of each row block
     int64_t nchunks = 0;
-    int nrb = 0, R = 0, H = 3;
-    int lo32 = 0;                 // low parts of the row sums as 32-bit integers (csb.h)
+    int nrb = 0, R = 0;
+    int e1 = 0, e2 = 0;           // 2^e1 > max row 1-norm, 2^e2 > max row 2-norm: csb.h's bounds on a row sum
     int S = 1;                    // column splits per row block (csb.h): S workgroups share a block
-    double *zsplit = nullptr;     // S > 1: [2][S][rows] exact partial sums of the splits
+    long long *zsplit = nullptr;  // S > 1: [S][rows] exact integer sums of the splits
+    int *cbad = nullptr;          // S > 1: [nrb] "a split left a product out" flags (csb.h outlier pass)
 };
 
 // One rank's view of a row-sharded solve (shard_api.h): its place in the world, the caller-owned
@@ -202,6 +203,7 @@ struct lsqrhip_handle_s {
     double *Z = nullptr;         // per-panel row sums of a panelled product (max over A, A')
     double *partials = nullptr;  // 3 * SPMV_MAX_GRID (three planes for Blue's norm of b, vec.h k_sumsq3)
     double *xmax_part = nullptr; // VEC_MAX_GRID partials of max|x| for csb.h products on caller vectors
+    int *csb_prog = nullptr;     // csb.h pacing: one progress word per workgroup (CSB_PROG_WORDS, all "done" between launches)
     NScale nsc{1.0, 1.0};        // fused norms: sum of (y * nsc.s)^2, sqrt(sum) * nsc.inv (scalar.h "range-safe norms")
     int norm_exp = 0;            // nsc.s = 2^-norm_exp (option "norm_exp": ranks of a sharded solve agree on one)
     int amax_exp = 0;            // 2^amax_exp > max|a_ij| of THIS matrix (csb.h's bound on the products)
@@ -262,6 +264,11 @@ struct DevScratch {
         if (p) (void)hipFree(p);
     }
     hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes > 0 ? bytes : 1); }
+    void free_now()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+    }
     template <typename T>
     T *as() const
     {
@@ -315,6 +322,7 @@ static void free_csr(Csr &c)
     if (c.cptr) (void)hipFree(c.cptr);
     if (c.crs) (void)hipFree(c.crs);
     if (c.zsplit) (void)hipFree(c.zsplit);
+    if (c.cbad) (void)hipFree(c.cbad);
     c = Csr();
 }
 
@@ -360,6 +368,7 @@ extern "C" int lsqrhip_destroy(lsqrhip_handle_t h)
                       h->opY})
         if (p) (void)hipFree(p);
     if (h->op_free) h->op_free(h->op_user);
+    if (h->csb_prog) (void)hipFree(h->csb_prog);
     if (h->shard.wsq) (void)hipFree(h->shard.wsq);
     if (h->shard.live) (void)hipFree(h->shard.live);
     if (h->d_state) (void)hipFree(h->d_state);
@@ -720,19 +729,23 @@ static unsigned long long *radix_sort_words(hipStream_t s, unsigned long long *i
 //   LSQRHIP_CSB_R  rows per block (test hook; default: as many as the LDS holds, cut so that the
 //                  blocks divide evenly among the 256 workgroups)
 static int build_csb(hipStream_t s, const int *rowk, const int *colk, const double *d_a, int64_t nnz, int rows,
-                     int cols, int bad_code, int bad_code_other, unsigned long long *bufA,
+                     int cols, int ea, int bad_code, int bad_code_other, unsigned long long *bufA,
                      unsigned long long *bufB, unsigned *hist, int *d_flags, Csr &out)
 {
     if (rows <= 0 || cols <= 0) return LSQRHIP_OK;
     const int g = (int)std::min<int64_t>(std::max<int64_t>((nnz + 255) / 256, 1), 4096);
     HIPCHK(hipMemsetAsync(d_flags, 0, 4 * sizeof(int), s));
     int got[4] = {0, 0, 0, 0};
-    DevScratch s_pos, s_cnt, s_rbs;
+    DevScratch s_pos, s_cnt, s_rbs, s_nrm;
     HIPCHK(s_pos.alloc(sizeof(unsigned) * (size_t)std::max<int64_t>(nnz, 1)));
     HIPCHK(s_cnt.alloc(sizeof(int) * ((size_t)rows + 1)));
     HIPCHK(hipMemsetAsync(s_cnt.p, 0, sizeof(int) * ((size_t)rows + 1), s));
+    // row 1-norms and squared 2-norms as integer sums (csb.h k_csb_pos), then two words for their maxima
+    HIPCHK(s_nrm.alloc(sizeof(unsigned long long) * (2 * (size_t)rows + 2)));
+    HIPCHK(hipMemsetAsync(s_nrm.p, 0, sizeof(unsigned long long) * (2 * (size_t)rows + 2), s));
     unsigned long long *sorted1 = bufA;
     int maxrow = 0;
+    unsigned long long nmax[2] = {0, 0};
     if (nnz > 0) {
         hipLaunchKernelGGL(k_csb_pack_col, dim3(g), dim3(256), 0, s, rowk, colk, nnz, rows, cols, bufA, d_flags);
         HIPCHK(hipGetLastError());
@@ -741,72 +754,97 @@ static int build_csb(hipStream_t s, const int *rowk, const int *colk, const doub
         if (got[0]) return fail(bad_code, lsqrhip_error_string(bad_code));
         if (got[2]) return fail(bad_code_other, lsqrhip_error_string(bad_code_other));
         if (got[1]) sorted1 = radix_sort_words(s, bufA, bufB, nnz, bits_for(cols), hist);
-        hipLaunchKernelGGL(k_csb_pos, dim3(g), dim3(256), 0, s, (const unsigned long long *)sorted1, nnz, rowk,
-                           s_pos.as<unsigned>(), s_cnt.as<int>());
-        // the longest row: how many products one accumulator may receive
+        unsigned long long *n1 = s_nrm.as<unsigned long long>(), *n2 = n1 + rows, *nm = n2 + rows;
+        hipLaunchKernelGGL(k_csb_pos, dim3(g), dim3(256), 0, s, (const unsigned long long *)sorted1, nnz, rowk, d_a,
+                           std::ldexp(1.0, -ea), s_pos.as<unsigned>(), s_cnt.as<int>(), n1, n2);
+        // the longest row (how even the rows are), the largest row norms (the bounds on a row sum)
         HIPCHK(hipMemsetAsync(d_flags, 0, 4 * sizeof(int), s));
-        hipLaunchKernelGGL(k_csb_maxint, dim3((unsigned)std::min<int64_t>(((int64_t)rows + 255) / 256, 2048)), dim3(256), 0,
-                           s, (const int *)s_cnt.as<int>(), (int64_t)rows, d_flags);
+        const dim3 gr((unsigned)std::min<int64_t>(((int64_t)rows + 255) / 256, 2048));
+        hipLaunchKernelGGL(k_csb_maxint, gr, dim3(256), 0, s, (const int *)s_cnt.as<int>(), (int64_t)rows, d_flags);
+        hipLaunchKernelGGL(k_csb_maxu64, gr, dim3(256), 0, s, (const unsigned long long *)n1, (int64_t)rows, nm);
+        hipLaunchKernelGGL(k_csb_maxu64, gr, dim3(256), 0, s, (const unsigned long long *)n2, (int64_t)rows, nm + 1);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(got, d_flags, sizeof(got), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(nmax, nm, sizeof(nmax), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
         maxrow = got[0];
     }
-    const int H = std::max(3, bits_for(std::max(maxrow, 1)) + 1);
-    // rows of <= 512 nonzeros: the low part of the sums as 32-bit integers, a third more rows per block
-    // (csb.h "accumulators"); LSQRHIP_CSB_LO32=0 keeps 8-byte low parts
-    const bool lo32 = H <= CSB_LO32_MAXH && env_int("LSQRHIP_CSB_LO32", 1) != 0;
-    const int rmax = lo32 ? CSB_RMAX32 : CSB_RMAX;
-    // Fewer rows than 256 full blocks: S workgroups share a block (column splits, csb.h) so that blocks
-    // stay tall -- what counts is R d / n, the nonzeros a block holds per column of x.
-    //   LSQRHIP_CSB_S  splits per block (test hook; default: as many as keep R <= rmax, at most 8)
-    // (blocks are cut by nonzeros, so where rows are short a block takes more rows than the mean: the mean
-    // stays a little below what the LDS holds -- 3 % for near-uniform rows, 15 % for skewed ones)
-    const int rfill = lo32 ? (int)(0.97 * rmax) : (int)(0.85 * rmax);
-    int S = env_int("LSQRHIP_CSB_S", 0);
-    if (S <= 0) {
-        S = (int)std::min<int64_t>(8, std::max<int64_t>(1, (int64_t)rfill * CSB_GRID / std::max(rows, 1)));
-        if ((int64_t)rows * S < (int64_t)CSB_GRID * 512) S = 1;   // small systems: not worth a second launch
-    }
-    S = std::min(S, 8);
-    int R = env_int("LSQRHIP_CSB_R", 0);
-    if (R <= 0) {
-        if (S > 1) {
-            const int nb = std::max(1, CSB_GRID / S);       // S * nb <= 256 units: one per CU, no second pass
-            R = (int)(((int64_t)rows + nb - 1) / nb);
-        } else {
-            const int64_t k = ((int64_t)rows + (int64_t)CSB_GRID * rfill - 1) / ((int64_t)CSB_GRID * rfill);
-            R = (int)(((int64_t)rows + CSB_GRID * k - 1) / (CSB_GRID * k));
-            R = std::max(R, std::min(rows, 512));  // small systems: a few whole blocks rather than 256 slivers
-        }
-    }
-    R = std::min(std::max(R, 1), rmax);
-    // Blocks of at most R rows holding about the same number of nonzeros: the boundaries from the row counts.
-    std::vector<int> rstart;
-    {
-        std::vector<int> cnt((size_t)rows);
-        HIPCHK(hipMemcpy(cnt.data(), s_cnt.p, sizeof(int) * (size_t)rows, hipMemcpyDeviceToHost));
-        const int nb0 = (rows + R - 1) / R;                       // blocks if they were cut by rows
-        const double target = (double)nnz / (double)nb0;         // nonzeros per block
-        // rows per block may exceed the mean where rows are short, up to what the LDS holds -- unless the
-        // block size was asked for (LSQRHIP_CSB_R: then blocks are exactly R rows, as the tests expect)
-        const int cap = env_int("LSQRHIP_CSB_R", 0) > 0 ? R : rmax;
-        rstart.push_back(0);
+    s_nrm.free_now();
+    // max_i sum_j |a_ij| < 2^e1 and max_i sqrt(sum_j a_ij^2) < 2^e2 from the integer maxima (all integer
+    // arithmetic: the same exponents on every build of the same matrix)
+    auto bits_u64 = [](unsigned long long v) { int b = 0; while (v) { ++b; v >>= 1; } return b; };   // v < 2^b
+    const int e1 = ea - CSB_NORM_FRAC + bits_u64(nmax[0]);
+    const int b2 = bits_u64(nmax[1]) - CSB_NORM_FRAC;                     // sum a^2 < 2^(b2 + 2 ea)
+    const int e2 = ea + (b2 >= 0 ? (b2 + 1) / 2 : -((-b2) / 2));          // ceil(b2 / 2)
+    // near-uniform rows (the longest <= 512): blocks cut by nonzeros stay close to the mean row count
+    const bool even_rows = maxrow <= 512;
+    const int rmax = CSB_RMAX;
+    // Blocks of at most rmax rows, cut so that every block holds about the same number of NONZEROS and so that
+    // every launch ("round") of 256 workgroups has one whole block, or one column split of a block, per CU:
+    //   * enough rows for 256 full blocks: 256 k blocks, k the smallest for which the cut stays within them
+    //     (blocks are cut by nonzeros, so where rows are short a block takes more rows than the mean; when that
+    //     runs into what the LDS holds the surplus moves to later blocks -- and if it does not fit, k grows);
+    //   * fewer rows: S workgroups share a block (column splits, csb.h) so that blocks stay tall -- what counts
+    //     is R d / n, the nonzeros a block holds per column of x.
+    //   LSQRHIP_CSB_S  splits per block (test hook; default: as many as keep blocks within rmax rows, at most 8)
+    //   LSQRHIP_CSB_R  rows per block, exactly (test hook)
+    std::vector<int> cnt((size_t)rows);
+    HIPCHK(hipMemcpy(cnt.data(), s_cnt.p, sizeof(int) * (size_t)rows, hipMemcpyDeviceToHost));
+    // nb blocks by cumulative nonzeros (block k ends where the running count reaches k / nb of the total), none
+    // longer than `cap` rows; or, by_rows, blocks of exactly `cap` rows
+    auto cut = [&](int nb, int cap, bool by_rows) {
+        std::vector<int> rs;
+        rs.push_back(0);
+        const double target = (double)nnz / (double)std::max(nb, 1);
         double acc = 0.0;
         int inblk = 0;
-        const bool by_nnz = env_int("LSQRHIP_CSB_R", 0) <= 0 && nnz > 0;
         for (int r = 0; r < rows; ++r) {
             acc += cnt[(size_t)r];
             ++inblk;
             const bool full = inblk >= cap;
-            const bool enough = by_nnz ? acc >= target * (double)rstart.size() && inblk >= 1 : inblk >= R;
+            const bool enough = !by_rows && acc >= target * (double)rs.size();
             if ((full || enough) && r + 1 < rows) {
-                rstart.push_back(r + 1);
+                rs.push_back(r + 1);
                 inblk = 0;
             }
         }
-        rstart.push_back(rows);
+        rs.push_back(rows);
+        return rs;
+    };
+    const int rfill = even_rows ? (int)(0.97 * rmax) : (int)(0.9 * rmax);
+    int S = env_int("LSQRHIP_CSB_S", 0);
+    const bool s_forced = S > 0;
+    if (!s_forced) {
+        S = (int)std::min<int64_t>(8, std::max<int64_t>(1, (int64_t)rfill * CSB_GRID / std::max(rows, 1)));
+        if ((int64_t)rows * S < (int64_t)CSB_GRID * 512) S = 1;   // small systems: not worth a second launch
     }
+    S = std::min(S, 8);
+    std::vector<int> rstart;
+    const int r_forced = env_int("LSQRHIP_CSB_R", 0);
+    if (r_forced > 0 || nnz <= 0) {
+        const int R = std::min(std::max(r_forced > 0 ? r_forced : rmax, 1), rmax);
+        rstart = cut(0, R, true);
+    } else {
+        for (;; --S) {       // column splits: 256 / S blocks, one unit per CU and no second pass
+            if (S <= 1) break;
+            const int nb = std::max(1, CSB_GRID / S);
+            if ((int64_t)nb * rmax < rows) continue;
+            rstart = cut(nb, rmax, false);
+            if ((int)rstart.size() - 1 <= nb || s_forced) break;
+        }
+        if (S <= 1) {
+            S = 1;
+            const int kmin = (int)std::max<int64_t>(1, ((int64_t)rows + (int64_t)CSB_GRID * rmax - 1) / ((int64_t)CSB_GRID * rmax));
+            for (int k = kmin;; ++k) {
+                // (small systems: a few whole blocks of >= 512 rows rather than 256 slivers)
+                const int nb = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)CSB_GRID * k, ((int64_t)rows + 511) / 512));
+                rstart = cut(nb, rmax, false);
+                if ((int)rstart.size() - 1 <= CSB_GRID * k || k >= kmin + 4) break;
+            }
+        }
+    }
+    cnt.clear();
+    cnt.shrink_to_fit();
     const int nrb = (int)rstart.size() - 1;
     if (nrb > SPMV_MAX_GRID) return LSQRHIP_OK;  // one partial of sum(y^2) per block
     DevScratch s_rst;
@@ -861,10 +899,14 @@ static int build_csb(hipStream_t s, const int *rowk, const int *colk, const doub
     out.nstored = (int64_t)nchunks * CSB_CHUNK;
     out.nrb = nrb;
     out.R = rmax;   // the dummy accumulator's index (blocks hold at most this many rows)
-    out.H = H;
-    out.lo32 = lo32 ? 1 : 0;
+    out.e1 = e1;
+    out.e2 = e2;
     out.S = S;
-    if (S > 1) HIPCHK(hipMalloc((void **)&out.zsplit, sizeof(double) * 2 * (size_t)S * (size_t)rows));
+    if (S > 1) {
+        HIPCHK(hipMalloc((void **)&out.zsplit, sizeof(long long) * (size_t)S * (size_t)rows));
+        HIPCHK(hipMalloc((void **)&out.cbad, sizeof(int) * (size_t)nrb));
+        HIPCHK(hipMemsetAsync(out.cbad, 0, sizeof(int) * (size_t)nrb, s));
+    }
     out.grid = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)nrb * S, CSB_GRID));  // workgroups per launch
     out.out_grid = nrb;
     out.nblk = nrb;
@@ -943,6 +985,11 @@ static int alloc_workspace(H *h)
     HIPCHK(hipMalloc((void **)&h->SE, esz * n1));
     HIPCHK(hipMalloc((void **)&h->partials, sizeof(double) * 3 * SPMV_MAX_GRID));
     HIPCHK(hipMalloc((void **)&h->xmax_part, sizeof(double) * VEC_MAX_GRID));
+    {
+        std::vector<int> done(CSB_PROG_WORDS, CSB_PROG_DONE);
+        HIPCHK(hipMalloc((void **)&h->csb_prog, sizeof(int) * CSB_PROG_WORDS));
+        HIPCHK(hipMemcpy(h->csb_prog, done.data(), sizeof(int) * CSB_PROG_WORDS, hipMemcpyHostToDevice));
+    }
     {
         const int64_t zn = std::max<int64_t>(h->A.P > 1 ? h->A.rows_v : 0, h->AT.P > 1 ? h->AT.rows_v : 0);
         if (zn > 0) HIPCHK(hipMalloc((void **)&h->Z, sizeof(double) * (size_t)zn));
@@ -1089,8 +1136,8 @@ static int finish_create(H *h, const int *d_irow, const int *d_icol, const doubl
                        (h->f32 && pa > 1);
     const bool csb_t = cmode == 1 || (cmode == 2 && pt > 1 && xt == 0) || (cmode < 0 && csb_rule(h->m, nnz, dev_t)) ||
                        (h->f32 && pt > 1);
-    if (csb_a) RET(build_csb(s, d_irow, d_icol, d_a, nnz, h->m, h->n, LSQRHIP_ERR_IROW, LSQRHIP_ERR_ICOL, bufA, bufB, hist, d_flags, h->A));
-    if (csb_t) RET(build_csb(s, d_icol, d_irow, d_a, nnz, h->n, h->m, LSQRHIP_ERR_ICOL, LSQRHIP_ERR_IROW, bufA, bufB, hist, d_flags, h->AT));
+    if (csb_a) RET(build_csb(s, d_irow, d_icol, d_a, nnz, h->m, h->n, h->amax_exp, LSQRHIP_ERR_IROW, LSQRHIP_ERR_ICOL, bufA, bufB, hist, d_flags, h->A));
+    if (csb_t) RET(build_csb(s, d_icol, d_irow, d_a, nnz, h->n, h->m, h->amax_exp, LSQRHIP_ERR_ICOL, LSQRHIP_ERR_IROW, bufA, bufB, hist, d_flags, h->AT));
     if (h->f32) {  // ... and row windows over the whole x where a block was too empty for them
         if (!h->A.csb) { pa = 1; pwa = h->n; xa = 0; }
         if (!h->AT.csb) { pt = 1; pwt = h->m; xt = 0; }
@@ -1627,6 +1674,9 @@ extern "C" int lsqrhip_set_option(lsqrhip_handle_t h, const char *name, int64_t 
     else if (k == "pipeline") h->pipeline = value < 0 ? 0 : (value > 2 ? 2 : (int)value);
     else if (k == "norm_exp") {  // the ranks of a row-sharded solve must scale their sums of squares alike
         if (value < -1000 || value > 1000) return fail(LSQRHIP_ERR_ARG, "norm_exp must be in [-1000, 1000]");
+        // captured kernel nodes hold the scale BY VALUE (SpmvArgs.nsc, k_update_lazy): batches captured under
+        // another exponent would sum (y * old scale)^2 and rescale by the new one -- they are rebuilt
+        if ((int)value != h->norm_exp) h->graph_dirty = true;
         h->norm_exp = (int)value;
         h->nsc.s = std::ldexp(1.0, -(int)value);
         h->nsc.inv = std::ldexp(1.0, (int)value);
@@ -1654,6 +1704,12 @@ extern "C" int lsqrhip_get_option(lsqrhip_handle_t h, const char *name, int64_t 
             *value = (rounds ? std::max(1, (c.nrb + step - 1) / step) : 1) + (c.S > 1 ? 1 : 0);
         }
         else *value = c.P > 1 ? 2 : 1;
+    } else if (k == "csb_blocks_mode1" || k == "csb_blocks_mode2") {  // row blocks of a column-swept layout (0: another layout)
+        const Csr &c = k == "csb_blocks_mode1" ? h->A : h->AT;
+        *value = c.csb ? c.nrb : 0;
+    } else if (k == "csb_splits_mode1" || k == "csb_splits_mode2") {
+        const Csr &c = k == "csb_splits_mode1" ? h->A : h->AT;
+        *value = c.csb ? c.S : 0;
     } else return fail(LSQRHIP_ERR_ARG, "unknown option: " + k);
     return LSQRHIP_OK;
 }

@@ -223,9 +223,9 @@ static void launch_csb(H *h, const SpmvArgs &a)
     static const int rounds = env_int("LSQRHIP_CSB_ROUNDS", 1);
     const int S = std::max(c.S, 1);
     const int step = rounds ? std::max(1, c.grid / S) : std::max(c.nrb, 1);   // row blocks per launch
-    double *zhi = c.zsplit, *zlo = c.zsplit ? c.zsplit + (size_t)S * c.rows : nullptr;
-    CsbMat A{c.cval, c.cidx, c.ccb, c.cptr, c.crs, c.nrb, c.R, c.rows, c.cols, h->amax_exp, c.H, 0, 0, S, zhi, zlo,
-             h->d_scalar + 3};
+    static const int pace = env_int("LSQRHIP_CSB_PACE", 0);
+    CsbMat A{c.cval, c.cidx, c.ccb, c.cptr, c.crs, c.nrb, c.R, c.rows, c.cols, c.e1, c.e2, 0, 0, S, c.zsplit, c.cbad,
+             h->d_scalar + 3, h->csb_prog, pace};
     for (int b0 = 0; b0 < c.nrb || b0 == 0; b0 += step) {
         const int b1 = std::min(c.nrb, b0 + step);
         const bool first = b0 == 0, last = b1 >= c.nrb;
@@ -234,24 +234,23 @@ static void launch_csb(H *h, const SpmvArgs &a)
         Rider rider = first ? a.rider : Rider{};
         const dim3 grid(std::max(1, std::min(c.grid, (b1 - b0) * S)) + (rider.kind != 0 ? 1 : 0));
         hipEvent_t e0 = first ? a.e0 : nullptr, e1 = (last && S == 1) ? a.e1 : nullptr;
-        auto kern = c.lo32 ? k_spmv_csb<true, VT> : k_spmv_csb<false, VT>;
         if (e0 == nullptr && e1 == nullptr)
-            hipLaunchKernelGGL(kern, grid, dim3(CSB_BLOCK), 0, a.stream, A, x, y, a.coef, a.stop, a.pout, a.pin,
-                               a.npin, a.slot_in, a.slot_out, a.skip_if_zero, rider, xb, a.nsc);
+            hipLaunchKernelGGL(k_spmv_csb<VT>, grid, dim3(CSB_BLOCK), 0, a.stream, A, x, y, a.coef, a.stop, a.pout,
+                               a.pin, a.npin, a.slot_in, a.slot_out, a.skip_if_zero, rider, xb, a.nsc);
         else
-            hipExtLaunchKernelGGL(kern, grid, dim3(CSB_BLOCK), 0, a.stream, e0, e1, 0, A, x, y, a.coef, a.stop,
-                                  a.pout, a.pin, a.npin, a.slot_in, a.slot_out, a.skip_if_zero, rider, xb, a.nsc);
+            hipExtLaunchKernelGGL(k_spmv_csb<VT>, grid, dim3(CSB_BLOCK), 0, a.stream, e0, e1, 0, A, x, y, a.coef,
+                                  a.stop, a.pout, a.pin, a.npin, a.slot_in, a.slot_out, a.skip_if_zero, rider, xb,
+                                  a.nsc);
         if (last) break;
     }
     if (S > 1) {  // the splits' sums -> y and the blocks' partials (csb.h k_csb_combine)
-        auto comb = c.lo32 ? k_csb_combine<true, VT> : k_csb_combine<false, VT>;
         const dim3 grid(std::max(1, std::min(c.nrb, 2 * CSB_GRID)));
         if (a.e1 == nullptr)
-            hipLaunchKernelGGL(comb, grid, dim3(CSB_BLOCK), 0, a.stream, A, y, a.coef, a.stop, a.pout, a.pin, a.npin,
-                               a.slot_in, a.skip_if_zero, a.nsc);
+            hipLaunchKernelGGL(k_csb_combine<VT>, grid, dim3(CSB_BLOCK), 0, a.stream, A, x, y, a.coef, a.stop, a.pout,
+                               a.pin, a.npin, a.slot_in, a.skip_if_zero, a.nsc);
         else
-            hipExtLaunchKernelGGL(comb, grid, dim3(CSB_BLOCK), 0, a.stream, nullptr, a.e1, 0, A, y, a.coef, a.stop,
-                                  a.pout, a.pin, a.npin, a.slot_in, a.skip_if_zero, a.nsc);
+            hipExtLaunchKernelGGL(k_csb_combine<VT>, grid, dim3(CSB_BLOCK), 0, a.stream, nullptr, a.e1, 0, A, x, y,
+                                  a.coef, a.stop, a.pout, a.pin, a.npin, a.slot_in, a.skip_if_zero, a.nsc);
     }
 }
 

@@ -1,0 +1,16 @@
+#!/usr/bin/env python3
+"""13 mode-1 products, then 13 mode-2 products of one generated workload (3 warm + 10 each): the program
+scripts/pmc_csb.sh runs under rocprofv3 --pmc.  usage: pmc_products.py SPEC"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from lsqr_amd import devgen
+spec = sys.argv[1]
+dp = devgen.generate(spec)
+s = dp.solver
+g = s.get_option
+print("LAYOUT", spec, "launches", g("launches_mode1"), g("launches_mode2"), "blocks", g("csb_blocks_mode1"),
+      g("csb_blocks_mode2"), "splits", g("csb_splits_mode1"), g("csb_splits_mode2"), "bytes", s.info()["csr_bytes"],
+      s.info()["csrt_bytes"], flush=True)
+t1 = s.bench_kernel(1, 10)
+t2 = s.bench_kernel(2, 10)
+print("TIMES_MS", round(t1, 4), round(t2, 4), flush=True)

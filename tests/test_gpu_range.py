@@ -106,3 +106,33 @@ def test_operator_handle_norms_are_range_safe():
         assert (r.istop, r.itn) == (o.istop, o.itn)
         assert xerr(r.x, o.x) <= 1e-10
         assert abs(r.anorm - o.anorm) <= 1e-10 * o.anorm and abs(r.rnorm - o.rnorm) <= 1e-10 * o.rnorm
+
+
+@pytest.mark.parametrize("layout", [{}, {"LSQRHIP_CSB": "1"}])
+def test_changing_the_norm_exponent_rebuilds_the_captured_batches(layout):
+    """The power-of-two scale of the fused norms travels BY VALUE in every captured kernel node, while the
+    scalar steps read its inverse from the state of the solve: a handle that has solved through its graphs
+    and is then given another exponent (the ranks of a sharded solve agree on one, `norm_exp`) must capture
+    them again -- otherwise beta and alpha come out wrong by 2^(e' - e) without any error."""
+    p = P.random_rows(3000, 800, 8, seed=4, damp=1e-3)
+    kw = dict(atol=1e-9, btol=1e-9, itnlim=200)
+    old = {k: os.environ.get(k) for k in layout}
+    os.environ.update(layout)
+    try:
+        s = lsqr_solver_ez().initialize(p.m, p.n, p.a, p.irow, p.icol, **kw)
+        r0 = s.solve(p.b, p.damp)                                  # captures the batches under the build's exponent
+        e = s.get_option("norm_exp")
+        for de in (3, -3, 40):
+            s.set_option("norm_exp", e + de)
+            r = s.solve(p.b, p.damp)
+            f = lsqr_solver_ez().initialize(p.m, p.n, p.a, p.irow, p.icol, **kw)
+            f.set_option("norm_exp", e + de)                       # a fresh handle: captured under the new exponent
+            g = f.solve(p.b, p.damp)
+            assert (r.istop, r.itn) == (g.istop, g.itn) == (r0.istop, r0.itn)
+            assert np.array_equal(r.x, g.x) and (r.anorm, r.rnorm, r.xnorm) == (g.anorm, g.rnorm, g.xnorm)
+            assert xerr(r.x, r0.x) <= 1e-12                         # (a power-of-two scale: the same norms to rounding)
+    finally:
+        for k, v in old.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v
