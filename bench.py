@@ -126,15 +126,20 @@ class _Env:
                 os.environ[k] = v
 
 
-def build_workload(spec: str, env=None, itnlim=100):
-    """(solver, d_b, facts) with the matrix resident in HBM; small systems also keep the host copy."""
+def build_workload(spec: str, env=None, itnlim=100, rows=None):
+    """(solver, d_b, facts) with the matrix resident in HBM; small systems also keep the host copy.
+    `rows` = (row0, nrows): only that row block of the system (one rank's share of a sharded solve)."""
     from lsqr_amd import capi, devgen
     from lsqr_amd.solver import lsqr_solver_ez
     cfg = devgen.parse_spec(spec)
     nnz_est = cfg["m"] * (5 if cfg["kind"] == "poisson2d" else cfg.get("per_row", 30))
     host = None
     with _Env(env):
-        if nnz_est <= 60_000_000 and not env:       # the host copy only exists for the CPU baseline
+        if rows is not None:
+            dp = devgen.generate(spec, int(rows[0]), int(rows[1]), itnlim=itnlim)
+            s, d_b = dp.solver, dp.d_b
+            facts = dict(name=f"{spec} rows {rows[0]}..{rows[0] + rows[1]}", m=dp.nrows, n=dp.n, nnz=dp.nnz, damp=dp.damp)
+        elif nnz_est <= 60_000_000 and not env:     # the host copy only exists for the CPU baseline
             host = make_problem(spec)
             s = lsqr_solver_ez().initialize(host.m, host.n, host.a, host.irow, host.icol, itnlim=itnlim)
             d_b = capi.DeviceBuffer.from_array(host.b)
@@ -175,7 +180,6 @@ def product_roofline(s, facts, reps, traffic=None):
     layout, kname = describe_layout(info)
     ach = lay1 / (avg1 * 1e-3) / 1e9
     frac = ach / HBM_PEAK_GBS
-    assert frac <= 1.0, ("a roofline fraction above 1 is not a fraction", frac)
     wset = info["csr_bytes"] + info["csrt_bytes"] + 8 * (m + 4 * n)
     lpp = s.get_option("launches_mode1")
     roof = {"bound": "hbm", "kernel": f"{kname} (aprod mode 1)", "achieved": ach, "peak": HBM_PEAK_GBS,
@@ -192,6 +196,9 @@ def product_roofline(s, facts, reps, traffic=None):
             "resident": ("infinity cache (iteration working set %.0f MB < 256 MB: 'HBM' bytes are fabric requests "
                          "that may be served on-die)" % (wset / 1e6)) if wset < INFINITY_CACHE else
                         "hbm (iteration working set %.1f GB)" % (wset / 1e9)}
+    if frac > 1.0:      # physical bytes faster than HBM can deliver them: the working set is served by a cache
+        roof["bound"] = "cache"
+        roof["frac_exceeds_hbm_peak"] = True
     if traffic:
         roof["traffic"] = traffic.get("bytes_per_launch")
         roof["traffic_detail"] = traffic
@@ -277,14 +284,15 @@ def side_workload(spec, env, note, K, traffic):
 # ---------------------------------------------------------------------------------------------
 def pmc_child(counter: str):
     """Runs under `rocprofv3 --pmc COUNTER`: builds each workload of the plan (stdin: JSON list of
-    [spec, env]) and launches its mode-1 product 3 + reps times; prints the launch manifest."""
+    [spec, env] or [spec, env, row0, nrows]) and launches its mode-1 product 3 + reps times; prints the
+    launch manifest."""
     plan = json.loads(sys.stdin.read())
     manifest = []
-    for spec, env in plan:
-        s, d_b, facts, _ = build_workload(spec, env)
+    for spec, env, *rows in plan:
+        s, d_b, facts, _ = build_workload(spec, env, rows=rows or None)
         reps = 10 if facts["nnz"] < 200_000_000 else 4
         s.bench_kernel(1, reps)
-        manifest.append({"spec": spec, "env": env, "launches": 3 + reps,
+        manifest.append({"spec": spec, "env": env, "rows": rows, "launches": 3 + reps,
                          "kernels_per_product": s.get_option("launches_mode1")})
         del s, d_b
     print("PMC_MANIFEST " + json.dumps(manifest), flush=True)
@@ -329,7 +337,8 @@ def live_traffic(plan, timeout=600):
                     return {}, f"PMC pass {counter}: {len(rows)} product dispatches, manifest wants more"
                 live = vals[3 * mf["kernels_per_product"]:]          # skip the 3 warm launches
                 per_launch = sum(live) / (len(live) / mf["kernels_per_product"])
-                sums.setdefault((mf["spec"], json.dumps(mf["env"], sort_keys=True)), {})[counter] = per_launch
+                sums.setdefault((mf["spec"], json.dumps(mf["env"], sort_keys=True), tuple(mf.get("rows") or ())),
+                                {})[counter] = per_launch
             if pos != len(rows):
                 return {}, f"PMC pass {counter}: {len(rows) - pos} unexpected product dispatches"
         except Exception as e:      # noqa: BLE001
@@ -364,7 +373,7 @@ def run_single(args):
         traffic, traffic_note = live_traffic(plan)
 
     def tr(sp, env):
-        return traffic.get((sp, json.dumps(env or {}, sort_keys=True)))
+        return traffic.get((sp, json.dumps(env or {}, sort_keys=True), ()))
 
     import torch
     from lsqr_amd import capi

@@ -14,6 +14,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "liblsqrhip.so")
+if os.environ.get("LSQRHIP_LIB"):      # measurement scripts only (scripts/): another in-tree build of the same sources
+    LIB_PATH = os.path.join(_HERE, "lib", os.path.basename(os.environ["LSQRHIP_LIB"]))
 
 LOG_STRIDE = 14
 

@@ -97,11 +97,7 @@ struct CsbMat {
     long long *z;   // S > 1: the splits' exact integer sums, [S][rows]
     int *bad;       // S > 1: [nrb] a split of the block left a product out (beyond the bound / not finite)
     double *gout;   // S > 1: this product's grid step g for k_csb_combine
-    int *prog;      // pacing: [8][64] progress words, one per workgroup, grouped by blockIdx & 7 (see "pacing")
-    int pace;       // pacing: steps a wave may be ahead of the slowest workgroup of its group (0 = off)
 };
-constexpr int CSB_PROG_WORDS = 8 * 64;
-constexpr int CSB_PROG_DONE = 0x7fffffff;
 
 // ---------------------------------------------------------------------------------------------
 // build
@@ -411,18 +407,6 @@ __global__ __launch_bounds__(CSB_BLOCK, 1) void k_spmv_csb(
     // produced.  A block of R rows then still holds R d / n nonzeros per column although 256 / S blocks
     // cover the matrix: R can stay large (one rank's block of config 4 at N = 8).
     const int nunits = (A.b1 - A.b0) * A.S;
-    // Pacing.  The workgroups of an XCD (blockIdx & 7 under the observed round-robin placement -- speed only)
-    // sweep the same columns, and an x line stays in their L2 for well under a percent of a sweep: a workgroup
-    // that runs ahead pays its gathers from the Infinity Cache, one that falls behind as well, and once apart
-    // they never meet again (PMC: 29 % of the gather requests missed L2).  So wave 0 of every workgroup
-    // publishes the steps it has done, and every wave looks at its group's 256-byte line once per step -- the
-    // load is issued behind the step's gathers and read a step later, when it has long returned: a wave's loads
-    // return in order, and a flag that is waited for at once drains the wave's whole pipeline (r02's attempt) --
-    // and sleeps while it is more than `pace` steps ahead of the slowest.  Only with one unit per workgroup and
-    // splits that put one column range on an XCD; bounded spins: placement or a missing peer cannot hang it.
-    const bool paced = A.pace > 0 && nunits <= nwg && nwg >= 16 && (8 % A.S) == 0;
-    int *const pgroup = A.prog + ((int)blockIdx.x & 7) * 64;
-    int *const pmine = pgroup + (((int)blockIdx.x >> 3) & 63);
     for (int u = wg; u < nunits; u += nwg) {
         const int b = A.b0 + u / A.S, sp = u % A.S;
         const long long cb0 = A.cptr[b], cb1 = A.cptr[b + 1];
@@ -449,25 +433,10 @@ __global__ __launch_bounds__(CSB_BLOCK, 1) void k_spmv_csb(
                 }
             }
         };
-        int step = 0, seen = CSB_PROG_DONE;   // seen: the group's line as loaded one step ago (this lane's word)
         auto work = [&](const double (&a)[CSB_U], const unsigned (&i)[CSB_U], int base) {
-            if (paced) {
-                int slowest = seen;
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) slowest = min(slowest, __shfl_xor(slowest, off, WAVE));
-                for (int spin = 0; step > slowest + A.pace && spin < 4096; ++spin) {   // ahead: let the others catch up
-                    __builtin_amdgcn_s_sleep(16);
-                    slowest = __hip_atomic_load(&pgroup[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-                    for (int off = 32; off > 0; off >>= 1) slowest = min(slowest, __shfl_xor(slowest, off, WAVE));
-                }
-                if (w == 0 && lane == 0) __hip_atomic_store(pmine, step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
             double xv[CSB_U];
 #pragma unroll
             for (int j = 0; j < CSB_U; ++j) xv[j] = (double)x[base + (int)(i[j] & CSB_LCOL_MASK)];
-            if (paced) seen = __hip_atomic_load(&pgroup[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            ++step;
 #pragma unroll
             for (int j = 0; j < CSB_U; ++j) {
                 const double p = a[j] * (xv[j] * sx);
@@ -489,8 +458,6 @@ __global__ __launch_bounds__(CSB_BLOCK, 1) void k_spmv_csb(
                 }
             }
         }
-        if (paced && w == 0 && lane == 0)
-            __hip_atomic_store(pmine, CSB_PROG_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (outlier) s_bad = 1;
         __syncthreads();
         // epilogue of the block: y, its partial of sum (y ns)^2, accumulators cleared

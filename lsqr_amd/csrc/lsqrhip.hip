@@ -103,13 +103,18 @@ extern "C" int lsqrhip_set_device(int device)
     return LSQRHIP_OK;
 }
 
+// The device of the handles THIS thread creates next, when >= 0 (lsqrhip_create_sharded places its row blocks
+// with it); otherwise the process-wide selection of lsqrhip_set_device.
+static thread_local int t_device_override = -1;
+static int target_device() { return t_device_override >= 0 ? t_device_override : g_device.load(); }
+
 static int use_device()
 {
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0)
         return fail(LSQRHIP_ERR_NO_DEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
-    const int dev = g_device.load();
+    const int dev = target_device();
     if (dev >= n) return fail(LSQRHIP_ERR_NO_DEVICE, "selected device index out of range");
     hipDeviceProp_t p;
     HIPCHK(hipGetDeviceProperties(&p, dev));
@@ -181,6 +186,8 @@ struct ShardCtx {
     double *wsq = nullptr;        // [1] this rank's sum of w_q^2 (owned)
     int *live = nullptr;          // [1] "this iteration runs" (owned)
     int wantse = 0;
+    int want_log = 0;             // option "shard_log": this rank keeps the iteration log of the next sharded solves
+                                  // (rank 0's business: the scalars are replicated and x(1) lies on its slice)
     bool active = false;
 };
 
@@ -203,7 +210,6 @@ struct lsqrhip_handle_s {
     double *Z = nullptr;         // per-panel row sums of a panelled product (max over A, A')
     double *partials = nullptr;  // 3 * SPMV_MAX_GRID (three planes for Blue's norm of b, vec.h k_sumsq3)
     double *xmax_part = nullptr; // VEC_MAX_GRID partials of max|x| for csb.h products on caller vectors
-    int *csb_prog = nullptr;     // csb.h pacing: one progress word per workgroup (CSB_PROG_WORDS, all "done" between launches)
     NScale nsc{1.0, 1.0};        // fused norms: sum of (y * nsc.s)^2, sqrt(sum) * nsc.inv (scalar.h "range-safe norms")
     int norm_exp = 0;            // nsc.s = 2^-norm_exp (option "norm_exp": ranks of a sharded solve agree on one)
     int amax_exp = 0;            // 2^amax_exp > max|a_ij| of THIS matrix (csb.h's bound on the products)
@@ -228,6 +234,8 @@ struct lsqrhip_handle_s {
     int gexec_first_wantse = -1;
     int gexec_iters = 0;
     bool graph_dirty = true;
+    int graph_epoch = 0;  // bumped by whatever invalidates captured kernel nodes (log buffer moved, norm_exp changed): the
+                          // sharded engine's graphs (shard_engine.h) are rebuilt when it differs from the one they were captured at
     std::vector<hipEvent_t> ev;
     hipEvent_t ev_loop0 = nullptr, ev_loop1 = nullptr;
     lsqrhip_timing_t timing{};
@@ -328,8 +336,8 @@ static void free_csr(Csr &c)
 
 static void release_groups(H *h);  // shard_engine.h
 static int solve_group_host(H *h, const double *b, double damp, double atol, double btol, double conlim, int itnlim,
-                            int wantse, double *x, double *se, int *istop, int *itn, double *anorm, double *acond,
-                            double *rnorm, double *arnorm, double *xnorm);
+                            int wantse, int want_log, double *x, double *se, int *istop, int *itn, double *anorm,
+                            double *acond, double *rnorm, double *arnorm, double *xnorm);
 static int aprod_group_host(H *h, int mode, double *x, double *y);
 
 static H *lsqrhip_group_rank0(H *h);
@@ -368,7 +376,6 @@ extern "C" int lsqrhip_destroy(lsqrhip_handle_t h)
                       h->opY})
         if (p) (void)hipFree(p);
     if (h->op_free) h->op_free(h->op_user);
-    if (h->csb_prog) (void)hipFree(h->csb_prog);
     if (h->shard.wsq) (void)hipFree(h->shard.wsq);
     if (h->shard.live) (void)hipFree(h->shard.live);
     if (h->d_state) (void)hipFree(h->d_state);
@@ -986,11 +993,6 @@ static int alloc_workspace(H *h)
     HIPCHK(hipMalloc((void **)&h->partials, sizeof(double) * 3 * SPMV_MAX_GRID));
     HIPCHK(hipMalloc((void **)&h->xmax_part, sizeof(double) * VEC_MAX_GRID));
     {
-        std::vector<int> done(CSB_PROG_WORDS, CSB_PROG_DONE);
-        HIPCHK(hipMalloc((void **)&h->csb_prog, sizeof(int) * CSB_PROG_WORDS));
-        HIPCHK(hipMemcpy(h->csb_prog, done.data(), sizeof(int) * CSB_PROG_WORDS, hipMemcpyHostToDevice));
-    }
-    {
         const int64_t zn = std::max<int64_t>(h->A.P > 1 ? h->A.rows_v : 0, h->AT.P > 1 ? h->AT.rows_v : 0);
         if (zn > 0) HIPCHK(hipMalloc((void **)&h->Z, sizeof(double) * (size_t)zn));
     }
@@ -1170,7 +1172,7 @@ static int new_handle(int m, int n, int64_t nnz, H **out)
     if (nnz >= (1ll << 32)) return fail(LSQRHIP_ERR_TOO_LARGE, lsqrhip_error_string(LSQRHIP_ERR_TOO_LARGE));
     RET(use_device());
     H *h = new H();
-    h->device = g_device.load();
+    h->device = target_device();
     h->m = m;
     h->n = n;
     h->nnz = nnz;
@@ -1405,6 +1407,7 @@ static int dev_dot(H *h, int64_t n, const double *d_x, const double *d_y, double
 
 extern "C" int lsqrhip_dnrm2(lsqrhip_handle_t h, int64_t n, const double *d_x, double *result)
 {
+    if (h && h->group) return fail(LSQRHIP_ERR_ARG, "not available on a handle sharded over several GPUs (lsqrhip_create_sharded)");
     if (!h || !result) return fail(LSQRHIP_ERR_NOT_INIT, lsqrhip_error_string(LSQRHIP_ERR_NOT_INIT));
     HIPCHK(hipSetDevice(h->device));
     // Stand-alone dnrm2 (src/lsqrblas.f90:123-159 is a scaled sum of squares): two passes, the
@@ -1442,6 +1445,7 @@ extern "C" int lsqrhip_dnrm2(lsqrhip_handle_t h, int64_t n, const double *d_x, d
 
 extern "C" int lsqrhip_ddot(lsqrhip_handle_t h, int64_t n, const double *d_x, const double *d_y, double *result)
 {
+    if (h && h->group) return fail(LSQRHIP_ERR_ARG, "not available on a handle sharded over several GPUs (lsqrhip_create_sharded)");
     if (!h || !result) return fail(LSQRHIP_ERR_NOT_INIT, lsqrhip_error_string(LSQRHIP_ERR_NOT_INIT));
     HIPCHK(hipSetDevice(h->device));
     return dev_dot(h, n, d_x, d_y, result);
@@ -1449,6 +1453,7 @@ extern "C" int lsqrhip_ddot(lsqrhip_handle_t h, int64_t n, const double *d_x, co
 
 extern "C" int lsqrhip_dscal(lsqrhip_handle_t h, int64_t n, double da, double *d_x)
 {
+    if (h && h->group) return fail(LSQRHIP_ERR_ARG, "not available on a handle sharded over several GPUs (lsqrhip_create_sharded)");
     if (!h) return fail(LSQRHIP_ERR_NOT_INIT, lsqrhip_error_string(LSQRHIP_ERR_NOT_INIT));
     if (n <= 0) return LSQRHIP_OK;
     HIPCHK(hipSetDevice(h->device));
@@ -1460,6 +1465,7 @@ extern "C" int lsqrhip_dscal(lsqrhip_handle_t h, int64_t n, double da, double *d
 
 extern "C" int lsqrhip_dcopy(lsqrhip_handle_t h, int64_t n, const double *d_x, double *d_y)
 {
+    if (h && h->group) return fail(LSQRHIP_ERR_ARG, "not available on a handle sharded over several GPUs (lsqrhip_create_sharded)");
     if (!h) return fail(LSQRHIP_ERR_NOT_INIT, lsqrhip_error_string(LSQRHIP_ERR_NOT_INIT));
     if (n <= 0) return LSQRHIP_OK;
     HIPCHK(hipSetDevice(h->device));
@@ -1487,6 +1493,7 @@ struct DevVec {
 
 extern "C" int lsqrhip_acheck(lsqrhip_handle_t h, double eps, int *inform, double *relerr)
 {
+    if (h && h->group) return fail(LSQRHIP_ERR_ARG, "not available on a handle sharded over several GPUs (lsqrhip_create_sharded)");
     if (!h || !inform) return fail(LSQRHIP_ERR_NOT_INIT, lsqrhip_error_string(LSQRHIP_ERR_NOT_INIT));
     NOT_F32(h);
     HIPCHK(hipSetDevice(h->device));
@@ -1519,6 +1526,7 @@ extern "C" int lsqrhip_acheck(lsqrhip_handle_t h, double eps, int *inform, doubl
 extern "C" int lsqrhip_xcheck(lsqrhip_handle_t h, double anorm, double damp, double eps, const double *b,
                               const double *x, double *u, double *v, double *w, int *inform, double *tests)
 {
+    if (h && h->group) return fail(LSQRHIP_ERR_ARG, "not available on a handle sharded over several GPUs (lsqrhip_create_sharded)");
     if (!h || !inform || !tests) return fail(LSQRHIP_ERR_NOT_INIT, lsqrhip_error_string(LSQRHIP_ERR_NOT_INIT));
     NOT_F32(h);
     HIPCHK(hipSetDevice(h->device));
@@ -1582,6 +1590,7 @@ extern "C" int lsqrhip_xcheck(lsqrhip_handle_t h, double anorm, double damp, dou
 // ---------------------------------------------------------------------------
 extern "C" int lsqrhip_bench_kernel(lsqrhip_handle_t h, int which, int reps, double *avg_ms)
 {
+    if (h && h->group) return fail(LSQRHIP_ERR_ARG, "not available on a handle sharded over several GPUs (lsqrhip_create_sharded)");
     if (!h || !avg_ms || reps < 1 || which < 1 || which > 3) return fail(LSQRHIP_ERR_ARG, "bad bench_kernel arguments");
     if (h->op && which != 3) return fail(LSQRHIP_ERR_ARG, "operator handles have no SpMV kernel to time");
     HIPCHK(hipSetDevice(h->device));
@@ -1630,11 +1639,15 @@ extern "C" int lsqrhip_bench_kernel(lsqrhip_handle_t h, int which, int reps, dou
 // ---------------------------------------------------------------------------
 // log, timing, options, memory helpers
 // ---------------------------------------------------------------------------
-extern "C" int lsqrhip_log_count(lsqrhip_handle_t h) { return h ? h->log_count : 0; }
+// (a handle sharded over several GPUs by this process keeps its log on rank 0's sub-handle: shard_engine.h)
+static H *log_owner(H *h);
+
+extern "C" int lsqrhip_log_count(lsqrhip_handle_t h) { return h ? log_owner(h)->log_count : 0; }
 
 extern "C" int lsqrhip_log_fetch(lsqrhip_handle_t h, int first, int count, double *records)
 {
     if (!h || !records) return fail(LSQRHIP_ERR_ARG, "null handle or buffer");
+    h = log_owner(h);
     if (first < 0 || count < 0 || first + count > h->log_count) return fail(LSQRHIP_ERR_ARG, "log range out of bounds");
     std::memcpy(records, h->h_log.data() + (size_t)first * LOG_STRIDE, sizeof(double) * LOG_STRIDE * (size_t)count);
     return LSQRHIP_OK;
@@ -1642,6 +1655,7 @@ extern "C" int lsqrhip_log_fetch(lsqrhip_handle_t h, int first, int count, doubl
 
 extern "C" int lsqrhip_log_extras(lsqrhip_handle_t h, double *out)
 {
+    if (h) h = log_owner(h);
     if (!h || !out || !h->h_state) return fail(LSQRHIP_ERR_ARG, "null handle or buffer");
     const LsqrState &r = *h->h_state;
     out[0] = r.bnorm;
@@ -1672,11 +1686,15 @@ extern "C" int lsqrhip_set_option(lsqrhip_handle_t h, const char *name, int64_t 
     else if (k == "poll_ahead") h->poll_ahead = value != 0;
     else if (k == "op_batch") h->op_batch = value < 1 ? 1 : (int)value;
     else if (k == "pipeline") h->pipeline = value < 0 ? 0 : (value > 2 ? 2 : (int)value);
+    else if (k == "shard_log") h->shard.want_log = value != 0;   // (rank 0 of a one-process-per-GPU world)
     else if (k == "norm_exp") {  // the ranks of a row-sharded solve must scale their sums of squares alike
         if (value < -1000 || value > 1000) return fail(LSQRHIP_ERR_ARG, "norm_exp must be in [-1000, 1000]");
         // captured kernel nodes hold the scale BY VALUE (SpmvArgs.nsc, k_update_lazy): batches captured under
         // another exponent would sum (y * old scale)^2 and rescale by the new one -- they are rebuilt
-        if ((int)value != h->norm_exp) h->graph_dirty = true;
+        if ((int)value != h->norm_exp) {
+            h->graph_dirty = true;
+            ++h->graph_epoch;
+        }
         h->norm_exp = (int)value;
         h->nsc.s = std::ldexp(1.0, -(int)value);
         h->nsc.inv = std::ldexp(1.0, (int)value);
@@ -1695,7 +1713,7 @@ extern "C" int lsqrhip_get_option(lsqrhip_handle_t h, const char *name, int64_t 
     else if (k == "op_batch") *value = h->op_batch;
     else if (k == "pipeline") *value = h->pipeline;
     else if (k == "norm_exp") *value = h->norm_exp;
-    else if (k == "log_truncated") *value = h->h_state ? h->h_state->log_truncated : 0;  // of the last solve
+    else if (k == "log_truncated") *value = log_owner(h)->h_state ? log_owner(h)->h_state->log_truncated : 0;  // of the last solve
     else if (k == "launches_mode1" || k == "launches_mode2") {  // kernel launches one product takes (profiling)
         const Csr &c = k == "launches_mode1" ? h->A : h->AT;
         static const int rounds = env_int("LSQRHIP_CSB_ROUNDS", 1);

@@ -167,7 +167,7 @@ extern "C" int lsqrhip_shard_begin(lsqrhip_handle_t h, const double *d_b_local, 
     if (!h) return fail(LSQRHIP_ERR_NOT_INIT, lsqrhip_error_string(LSQRHIP_ERR_NOT_INIT));
     if (!d_T || !d_R || !d_V || !d_sums || (!d_b_local && h->m > 0)) return fail(LSQRHIP_ERR_ARG, "null shard buffer");
     if (world < 1 || rank < 0 || rank >= world) return fail(LSQRHIP_ERR_ARG, "bad world / rank");
-    if (h->op) return fail(LSQRHIP_ERR_ARG, "the row-sharded solve needs a matrix handle, not an operator");
+    if (h->op || h->group) return fail(LSQRHIP_ERR_ARG, "the row-sharded stages need a matrix handle, not an operator or a sharded parent");
     if (h->f32) return fail(LSQRHIP_ERR_ARG, "the row-sharded solve is binary64 only (not a REAL32 handle)");
     HIPCHK(hipSetDevice(h->device));
     hipStream_t s = h->stream;
@@ -181,12 +181,14 @@ extern "C" int lsqrhip_shard_begin(lsqrhip_handle_t h, const double *d_b_local, 
     c.wantse = wantse;
     if (!c.wsq) HIPCHK(hipMalloc((void **)&c.wsq, sizeof(double)));
     if (!c.live) HIPCHK(hipMalloc((void **)&c.live, sizeof(int)));
-    RET(prepare_log(h, itnlim, 0));
+    RET(prepare_log(h, itnlim, c.want_log));
     LsqrState init;
     std::memset(&init, 0, sizeof(init));
     init.itnlim = itnlim;
     init.damped = damp > 0.0;
     init.wantse = wantse != 0;
+    init.want_log = c.want_log != 0;   // the reference's log (src/lsqr.f90:813-837) from this rank's records
+    init.log_cap = h->log_cap;
     init.m = (int)m_global;  // se finish uses the GLOBAL row count (src/lsqr.f90:857-861)
     init.n = h->n;
     init.damp = damp;
@@ -273,11 +275,13 @@ extern "C" int lsqrhip_shard_stage(lsqrhip_handle_t h, int stage)
         break;
     case ST_UPDATE:
         hipLaunchKernelGGL(k_shard_s2, dim3(1), dim3(1), 0, s, (const double *)sums, st, c.live);
-        hipLaunchKernelGGL(k_shard_s3, dim3(1), dim3(1), 0, s, (const double *)sums, st, (const int *)c.live,
-                           (const double *)h->X, h->d_log);
         hipLaunchKernelGGL(k_update_slice, dim3(gq), dim3(VEC_BLOCK), 0, s, h->X, h->W, (const double *)Vq, h->SE,
                            c.mylen, (const LsqrState *)st, (const int *)c.live, h->partials);
         hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(VEC_BLOCK), 0, s, (const double *)h->partials, gq, c.wsq);
+        // step 3 AFTER the update, as in the reference (src/lsqr.f90:729-745, then :751-837): the x(1) of the
+        // iteration log is the updated one; both are gated by `live`, which step 2 set for this iteration
+        hipLaunchKernelGGL(k_shard_s3, dim3(1), dim3(1), 0, s, (const double *)sums, st, (const int *)c.live,
+                           (const double *)h->X, h->d_log);
         break;
     default:
         return fail(LSQRHIP_ERR_ARG, "unknown shard stage");
@@ -331,6 +335,11 @@ extern "C" int lsqrhip_shard_end(lsqrhip_handle_t h, double *d_x, double *d_se, 
     HIPCHK(hipMemcpyAsync(h->h_state, h->d_state, sizeof(LsqrState), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     const LsqrState &r = *h->h_state;
+    if (c.want_log && r.itn > 0) {   // as finish_solve does for the one-GPU path
+        h->log_count = std::min(r.log_count, h->log_cap);
+        h->h_log.resize((size_t)h->log_count * LOG_STRIDE);
+        HIPCHK(hipMemcpy(h->h_log.data(), h->d_log, sizeof(double) * h->h_log.size(), hipMemcpyDeviceToHost));
+    }
     int is = r.istop;
     if (r.damped && is == 2) is = 3;
     if (istop) *istop = is;

@@ -119,13 +119,20 @@ struct ShardGroup {
     bool loopback = false;         // exchanges by device copies inside this process instead of RCCL (all ranks are local)
     std::vector<hipEvent_t> ev;    // loopback: one event per rank
     int poll_every = 16;
+    // one captured batch of `poll_every` iterations -- stages AND exchanges of every local rank (capture_group_batch)
+    hipGraphExec_t gexec = nullptr;
+    std::vector<int> gexec_epoch;  // the ranks' graph_epoch at capture
+    int graph_state = 0;           // 0 not tried, 1 in use, -1 capture failed once: eager launches from then on
 };
 
 static H *lsqrhip_group_rank0(H *h) { return h->group->r[0].h; }
+static H *log_owner(H *h) { return h->group && !h->group->r.empty() && h->group->r[0].h ? h->group->r[0].h : h; }
 
 static void free_group(ShardGroup *g)
 {
     if (!g) return;
+    if (g->gexec) (void)hipGraphExecDestroy(g->gexec);
+
     for (size_t i = 0; i < g->ev.size(); ++i) {
         (void)hipSetDevice(g->r[i].dev >= 0 ? g->r[i].dev : 0);
         if (g->ev[i]) (void)hipEventDestroy(g->ev[i]);
@@ -302,6 +309,68 @@ static int stage_all(ShardGroup &g, int st)
     return LSQRHIP_OK;
 }
 
+// `count` iterations: the stages of every local rank and the three exchanges of each iteration, all asynchronous
+static int enqueue_iterations(ShardGroup &g, int count)
+{
+    for (int k = 0; k < count; ++k) {
+        RET(stage_all(g, ST_MODE1));
+        RET(ex_scalars(g, 1));
+        RET(stage_all(g, ST_S1_ATU));
+        RET(ex_scatter(g));
+        RET(stage_all(g, ST_VCOMBINE));
+        RET(ex_scalars(g, 2, true));    // alpha^2, dknorm^2 and the v slices in one group
+        RET(stage_all(g, ST_UPDATE));
+    }
+    return LSQRHIP_OK;
+}
+
+// One hipGraph per batch of `poll_every` iterations, as solve_loop.h does for one GPU: ~14 launches, 2 copies and
+// 3 exchanges per iteration become one graph launch per batch (iterations past the stop are no-ops: every kernel
+// looks at the flag first).  Only for a group with ONE local rank -- a world of 1, or one rank of a
+// one-process-per-GPU world: the capture is a plain single-stream capture.  (Forking the other ranks' streams of
+// the loopback harness into the capture and joining them back crashed inside the HIP runtime on ROCm 7.2 -- several
+// ranks in one process stay eager, as does one process driving several devices over RCCL.)
+//   LSQRHIP_SHARD_GRAPH   0 never | 1 also with RCCL between processes (RCCL's kernels are captured like any
+//                         others) | unset: only where no RCCL call is involved (world of 1) -- the RCCL form stays
+//                         eager until a multi-GPU node has run it captured (tests/test_gpu_engine.py::test_rccl_*)
+static bool group_graph_wanted(const ShardGroup &g)
+{
+    const int mode = env_int("LSQRHIP_SHARD_GRAPH", -1);   // (read at every solve: the tests switch it)
+    if (mode == 0 || g.graph_state < 0 || g.r.size() != 1) return false;
+    return g.P == 1 || mode == 1;
+}
+
+static int capture_group_batch(ShardGroup &g)
+{
+    ShardRank &q0 = g.r[0];
+    hipStream_t s0 = q0.h->stream;
+    HIPCHK(hipSetDevice(q0.h->device));
+    if (g.gexec) {
+        (void)hipGraphExecDestroy(g.gexec);
+        g.gexec = nullptr;
+    }
+    HIPCHK(hipStreamSynchronize(s0));
+    hipError_t e = hipStreamBeginCapture(s0, hipStreamCaptureModeRelaxed);
+    if (e != hipSuccess) return fail(LSQRHIP_ERR_HIP, std::string("hipStreamBeginCapture: ") + hipGetErrorString(e));
+    const int rc = enqueue_iterations(g, g.poll_every);
+    hipGraph_t graph = nullptr;
+    e = hipStreamEndCapture(s0, &graph);
+    if (e != hipSuccess || rc != LSQRHIP_OK) {
+        if (graph) (void)hipGraphDestroy(graph);
+        (void)hipGetLastError();
+        return fail(LSQRHIP_ERR_HIP, std::string("capture of a sharded batch failed: ") +
+                                         (e != hipSuccess ? hipGetErrorString(e) : g_last_error.c_str()));
+    }
+    e = hipGraphInstantiate(&g.gexec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (e != hipSuccess) {
+        g.gexec = nullptr;
+        return fail(LSQRHIP_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
+    }
+    g.gexec_epoch.assign(1, q0.h->graph_epoch);
+    return LSQRHIP_OK;
+}
+
 // The loop.  b: every local rank's block is in q.bloc.  Outputs: x (and se) replicated in q.xfull / q.sefull.
 static int run_group(ShardGroup &g, double damp, double atol, double btol, double conlim, int itnlim, int wantse,
                      int *istop, int *itn, double *anorm, double *acond, double *rnorm, double *arnorm, double *xnorm)
@@ -324,21 +393,31 @@ static int run_group(ShardGroup &g, double damp, double atol, double btol, doubl
         return LSQRHIP_OK;
     };
     RET(poll());
+    // batches: one graph launch each where the exchanges can be captured (group_graph_wanted), else eager
+    bool graph = group_graph_wanted(g);
+    if (graph) {
+        bool stale = g.gexec == nullptr || g.gexec_epoch.size() != g.r.size();
+        for (size_t i = 0; !stale && i < g.r.size(); ++i) stale = g.gexec_epoch[i] != g.r[i].h->graph_epoch;
+        if (stale && capture_group_batch(g) != LSQRHIP_OK) {   // never fatal: the eager form is always there
+            g.graph_state = -1;
+            graph = false;
+        } else {
+            g.graph_state = 1;
+        }
+    }
     int64_t launched = 0;
     while (!st3[0]) {
         if (launched > (int64_t)itnlim + g.poll_every)
             return fail(LSQRHIP_ERR_HIP, "sharded iteration loop did not terminate (device state not advancing)");
-        const int batch = (int)std::min<int64_t>(g.poll_every, std::max<int64_t>(1, (int64_t)itnlim - launched));
-        for (int k = 0; k < batch; ++k) {
-            RET(stage_all(g, ST_MODE1));
-            RET(ex_scalars(g, 1));
-            RET(stage_all(g, ST_S1_ATU));
-            RET(ex_scatter(g));
-            RET(stage_all(g, ST_VCOMBINE));
-            RET(ex_scalars(g, 2, true));    // alpha^2, dknorm^2 and the v slices in one group
-            RET(stage_all(g, ST_UPDATE));
+        if (graph) {
+            HIPCHK(hipSetDevice(g.r[0].h->device));
+            HIPCHK(hipGraphLaunch(g.gexec, g.r[0].h->stream));
+            launched += g.poll_every;
+        } else {
+            const int batch = (int)std::min<int64_t>(g.poll_every, std::max<int64_t>(1, (int64_t)itnlim - launched));
+            RET(enqueue_iterations(g, batch));
+            launched += batch;
         }
-        launched += batch;
         RET(poll());
     }
     for (ShardRank &q : g.r) {
@@ -407,16 +486,20 @@ extern "C" int lsqrhip_create_sharded(int m, int n, int64_t nnz, const int *irow
     if (have < ngpu && !loopback)
         return fail(LSQRHIP_ERR_NO_DEVICE, "ngpu = " + std::to_string(ngpu) + " but this node shows " + std::to_string(have) +
                                                " usable gfx950 device(s)");
+    if (!loopback && g_device.load() + ngpu > have)   // blocks go to devices [selected, selected + ngpu)
+        return fail(LSQRHIP_ERR_NO_DEVICE, "ngpu = " + std::to_string(ngpu) + " starting at the selected device " +
+                                               std::to_string(g_device.load()) + " exceeds the " + std::to_string(have) +
+                                               " device(s) of this node (lsqrhip_set_device)");
     ngpu = std::min(ngpu_asked, std::max(m, 1));  // never more row blocks than rows
     if (ngpu > 1 && !loopback && !rccl()) return fail(LSQRHIP_ERR_HIP, "librccl.so.1 could not be loaded");
-    // the reference's checks first (src/lsqr.f90:110-111), on the whole system
+    // One pass over the triplets: the reference's checks (src/lsqr.f90:110-111) on the whole system, and the row
+    // counts.  Then contiguous row blocks balanced by nonzeros (+1 per row: a row costs work even when empty).
+    std::vector<int64_t> cum((size_t)m + 1, 0);
     for (int64_t k = 0; k < nnz; ++k) {
         if (irow[k] < 1 || irow[k] > m) return fail(LSQRHIP_ERR_IROW, lsqrhip_error_string(LSQRHIP_ERR_IROW));
         if (icol[k] < 1 || icol[k] > n) return fail(LSQRHIP_ERR_ICOL, lsqrhip_error_string(LSQRHIP_ERR_ICOL));
+        cum[(size_t)irow[k]] += 1;
     }
-    // contiguous row blocks balanced by nonzeros (+1 per row: a row costs work even when empty)
-    std::vector<int64_t> cum((size_t)m + 1, 0);
-    for (int64_t k = 0; k < nnz; ++k) cum[(size_t)irow[k]] += 1;
     for (int r = 0; r < m; ++r) cum[(size_t)r + 1] += cum[(size_t)r] + 1;
     std::vector<int> cut((size_t)ngpu + 1, 0);
     cut[(size_t)ngpu] = m;
@@ -426,12 +509,40 @@ extern "C" int lsqrhip_create_sharded(int m, int n, int64_t nnz, const int *irow
         r = std::min(std::max(r, cut[(size_t)p - 1] + (m >= ngpu ? 1 : 0)), m - (m >= ngpu ? ngpu - p : 0));
         cut[(size_t)p] = std::max(r, cut[(size_t)p - 1]);
     }
-    std::vector<int> owner((size_t)m + 1, 0);
+    // nonzeros of block p = what cum says of its rows, less the +1 per row
+    std::vector<int64_t> first((size_t)ngpu + 1, 0);
     for (int p = 0; p < ngpu; ++p)
-        for (int r = cut[(size_t)p]; r < cut[(size_t)p + 1]; ++r) owner[(size_t)r] = p;
-    std::vector<int64_t> cnt((size_t)ngpu + 1, 0);
-    for (int64_t k = 0; k < nnz; ++k) cnt[(size_t)owner[(size_t)irow[k] - 1] + 1] += 1;
-    for (int p = 0; p < ngpu; ++p) cnt[(size_t)p + 1] += cnt[(size_t)p];
+        first[(size_t)p + 1] = first[(size_t)p] + (cum[(size_t)cut[(size_t)p + 1]] - cum[(size_t)cut[(size_t)p]]) -
+                               (cut[(size_t)p + 1] - cut[(size_t)p]);
+    cum.clear();
+    cum.shrink_to_fit();
+    std::vector<unsigned char> owner8;
+    std::vector<int> owner;
+    // (a byte per row suffices for any node; the int form is for the loopback harness with > 255 ranks)
+    if (ngpu <= 255) owner8.assign((size_t)std::max(m, 1), 0);
+    else owner.assign((size_t)std::max(m, 1), 0);
+    for (int p = 0; p < ngpu; ++p)
+        for (int r = cut[(size_t)p]; r < cut[(size_t)p + 1]; ++r) {
+            if (ngpu <= 255) owner8[(size_t)r] = (unsigned char)p;
+            else owner[(size_t)r] = p;
+        }
+    // ... and ONE pass that files every triplet under its block, COO order kept inside each (the reference's
+    // row sums are formed in that order, src/lsqr.f90:168-172): O(nnz) host work whatever ngpu is
+    std::vector<int> lr((size_t)std::max<int64_t>(nnz, 1)), lc((size_t)std::max<int64_t>(nnz, 1));
+    std::vector<double> la((size_t)std::max<int64_t>(nnz, 1));
+    {
+        std::vector<int64_t> pos(first.begin(), first.end() - 1);
+        for (int64_t k = 0; k < nnz; ++k) {
+            const int r = irow[k] - 1;
+            const int p = ngpu <= 255 ? (int)owner8[(size_t)r] : owner[(size_t)r];
+            const int64_t w = pos[(size_t)p]++;
+            lr[(size_t)w] = irow[k] - cut[(size_t)p];
+            lc[(size_t)w] = icol[k];
+            la[(size_t)w] = a[k];
+        }
+    }
+    owner8.clear(); owner8.shrink_to_fit();
+    owner.clear(); owner.shrink_to_fit();
 
     H *h = nullptr;
     const int dev0 = g_device.load();
@@ -447,28 +558,19 @@ extern "C" int lsqrhip_create_sharded(int m, int n, int64_t nnz, const int *irow
     g->loopback = loopback;
     g->r.resize((size_t)ngpu);
     int rc = LSQRHIP_OK;
-    {
-        std::vector<int> lr, lc;
-        std::vector<double> la;
-        for (int p = 0; p < ngpu && rc == LSQRHIP_OK; ++p) {
-            const size_t np = (size_t)(cnt[(size_t)p + 1] - cnt[(size_t)p]);
-            lr.resize(np); lc.resize(np); la.resize(np);
-            size_t w = 0;
-            for (int64_t k = 0; k < nnz; ++k)   // COO order kept inside the block
-                if (owner[(size_t)irow[k] - 1] == p) {
-                    lr[w] = irow[k] - cut[(size_t)p];
-                    lc[w] = icol[k];
-                    la[w] = a[k];
-                    ++w;
-                }
-            g_device = loopback ? dev0 + p % have : dev0 + p;
-            ShardRank &q = g->r[(size_t)p];
-            q.grank = p;
-            q.row0 = cut[(size_t)p];
-            rc = lsqrhip_create(cut[(size_t)p + 1] - cut[(size_t)p], n, (int64_t)np, lr.data(), lc.data(), la.data(), &q.h);
-        }
+    for (int p = 0; p < ngpu && rc == LSQRHIP_OK; ++p) {
+        const int64_t f = first[(size_t)p], np = first[(size_t)p + 1] - f;
+        ShardRank &q = g->r[(size_t)p];
+        q.grank = p;
+        q.row0 = cut[(size_t)p];
+        // the block's device, for this thread's create only (never through the process-wide selection)
+        t_device_override = loopback ? dev0 + p % have : dev0 + p;
+        rc = lsqrhip_create(cut[(size_t)p + 1] - cut[(size_t)p], n, np, lr.data() + f, lc.data() + f, la.data() + f, &q.h);
+        t_device_override = -1;
     }
-    g_device = dev0;
+    lr.clear(); lr.shrink_to_fit();
+    lc.clear(); lc.shrink_to_fit();
+    la.clear(); la.shrink_to_fit();
     if (rc == LSQRHIP_OK)
         for (ShardRank &q : g->r)
             if ((rc = alloc_rank_buffers(*g, q)) != LSQRHIP_OK) break;
@@ -495,12 +597,14 @@ extern "C" int lsqrhip_create_sharded(int m, int n, int64_t nnz, const int *irow
 
 // lsqrhip_solve on a sharded handle: b is cut into the row blocks, x (se) come back whole.
 static int solve_group_host(H *h, const double *b, double damp, double atol, double btol, double conlim, int itnlim,
-                            int wantse, double *x, double *se, int *istop, int *itn, double *anorm, double *acond,
-                            double *rnorm, double *arnorm, double *xnorm)
+                            int wantse, int want_log, double *x, double *se, int *istop, int *itn, double *anorm,
+                            double *acond, double *rnorm, double *arnorm, double *xnorm)
 {
     ShardGroup &g = *h->group;
     if (!istop || (!x && g.n > 0) || (!b && g.m > 0)) return fail(LSQRHIP_ERR_ARG, "null b, x or istop");
     if (wantse && !se) return fail(LSQRHIP_ERR_ARG, "wantse set but se is null");
+    // the iteration log: rank 0 keeps the records (replicated scalars; x(1) is the first entry of its slice)
+    for (ShardRank &q : g.r) q.h->shard.want_log = (want_log != 0 && &q == &g.r[0]) ? 1 : 0;
     for (ShardRank &q : g.r) {
         HIPCHK(hipSetDevice(q.h->device));
         if (q.h->m > 0)
@@ -549,7 +653,8 @@ extern "C" int lsqrhip_rccl_unique_id(char *out128)
 extern "C" int lsqrhip_shard_comm_init(lsqrhip_handle_t h, int world, int rank, int64_t row0, int64_t m_global,
                                        const char *id128)
 {
-    if (!h || h->op || h->group) return fail(LSQRHIP_ERR_ARG, "needs a matrix handle that is not yet part of a group");
+    if (!h || h->op || h->group || h->mp)
+        return fail(LSQRHIP_ERR_ARG, "needs a matrix handle that is not yet part of a group or a world");
     if (world < 1 || rank < 0 || rank >= world) return fail(LSQRHIP_ERR_ARG, "bad world / rank");
     if (world > 1 && !id128) return fail(LSQRHIP_ERR_ARG, "null unique id");
     if (world > 1 && !rccl()) return fail(LSQRHIP_ERR_HIP, "librccl.so.1 could not be loaded");

@@ -223,9 +223,8 @@ static void launch_csb(H *h, const SpmvArgs &a)
     static const int rounds = env_int("LSQRHIP_CSB_ROUNDS", 1);
     const int S = std::max(c.S, 1);
     const int step = rounds ? std::max(1, c.grid / S) : std::max(c.nrb, 1);   // row blocks per launch
-    static const int pace = env_int("LSQRHIP_CSB_PACE", 0);
     CsbMat A{c.cval, c.cidx, c.ccb, c.cptr, c.crs, c.nrb, c.R, c.rows, c.cols, c.e1, c.e2, 0, 0, S, c.zsplit, c.cbad,
-             h->d_scalar + 3, h->csb_prog, pace};
+             h->d_scalar + 3};
     for (int b0 = 0; b0 < c.nrb || b0 == 0; b0 += step) {
         const int b1 = std::min(c.nrb, b0 + step);
         const bool first = b0 == 0, last = b1 >= c.nrb;
@@ -614,6 +613,7 @@ static int prepare_log(H *h, int itnlim, int want_log)
             HIPCHK(hipMalloc((void **)&h->d_log, sizeof(double) * LOG_STRIDE * (size_t)cap));
             h->log_cap = cap;
             h->graph_dirty = true;
+            ++h->graph_epoch;
         }
     }
     h->log_count = 0;
@@ -733,8 +733,8 @@ static int solve_core(H *h, const double *b, bool b_on_device, double damp, doub
     if (h->group) {  // a system sharded over several GPUs by this process (shard_engine.h)
         if (b_on_device || out_on_device)
             return fail(LSQRHIP_ERR_ARG, "a sharded handle takes host vectors (its devices each hold a row block)");
-        return solve_group_host(h, b, damp, atol, btol, conlim, itnlim, wantse, x, se, istop, itn, anorm, acond, rnorm,
-                                arnorm, xnorm);
+        return solve_group_host(h, b, damp, atol, btol, conlim, itnlim, wantse, want_log, x, se, istop, itn, anorm, acond,
+                                rnorm, arnorm, xnorm);
     }
     if (!istop || (!x && h->n > 0) || (!b && h->m > 0)) return fail(LSQRHIP_ERR_ARG, "null b, x or istop");
     if (wantse && !se) return fail(LSQRHIP_ERR_ARG, "wantse set but se is null");

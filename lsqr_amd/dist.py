@@ -295,15 +295,34 @@ class EngineSolver:
         solver._need()
         self.capi, self.torch, self.solver = capi, torch, solver
         self.n, self.world, self.rank = solver.n, int(world), int(rank)
-        ident = [None]
+        # Every rank takes part in every collective of this handshake whatever happened to it locally: a rank
+        # that raised on its own would leave its peers blocked in the broadcast (or in the all-reduce of the
+        # caller's fall-back logic).  Failures are agreed on and then raised by ALL ranks.
+        ident, err = [None], None
         if world > 1:
             if rank == 0:
-                buf = C.create_string_buffer(128)
-                capi.check(capi.lib().lsqrhip_rccl_unique_id(buf))
-                ident = [bytes(buf.raw)]
-            dist.broadcast_object_list(ident, src=0, group=group)
-        capi.check(capi.lib().lsqrhip_shard_comm_init(solver._h, self.world, self.rank, int(row0), int(m_global),
-                                                      ident[0] if world > 1 else None))
+                try:
+                    buf = C.create_string_buffer(128)
+                    capi.check(capi.lib().lsqrhip_rccl_unique_id(buf))
+                    ident = [bytes(buf.raw)]
+                except Exception as e:  # noqa: BLE001
+                    err = e
+            dist.broadcast_object_list(ident, src=0, group=group)      # None: rank 0 has no id
+            if ident[0] is None:
+                raise err or capi.LsqrHipError(capi.ERR_HIP, "rank 0 could not obtain an RCCL unique id")
+        ok = 1
+        try:
+            capi.check(capi.lib().lsqrhip_shard_comm_init(solver._h, self.world, self.rank, int(row0), int(m_global),
+                                                          ident[0] if world > 1 else None))
+        except Exception as e:  # noqa: BLE001
+            ok, err = 0, e
+        if world > 1:
+            flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+            if int(flag.item()) == 0:
+                raise err or capi.LsqrHipError(capi.ERR_HIP, "lsqrhip_shard_comm_init failed on another rank")
+        elif not ok:
+            raise err
         self.d_x = capi.DeviceBuffer(8 * max(self.n, 1))
         self.d_se = None
 

@@ -13,6 +13,61 @@ import os
 import time
 
 DEFAULT_SPEC = "random:10000000:10000000:100"
+CPU_SAMPLE_NNZ = 20_000_000     # the CPU baseline runs a scaled-down instance of the same generator (~10-20 s)
+
+# keys of the one JSON line (tests/test_capi_cpu.py holds both line shapes to their key sets)
+LINE_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+             "vs_baseline", "dtype", "data", "config", "result", "roofline", "cpu_baseline")
+ROOFLINE_KEYS = ("bound", "achieved", "peak", "unit", "frac", "traffic")
+CPU_BASELINE_KEYS = ("value", "unit", "cores", "kind", "sample")
+
+
+def cpu_sample_spec(cfg: dict) -> str:
+    """The same generator at a size the reference's single-threaded CPU path finishes in seconds: rows and
+    columns divided by the same factor, nonzeros per row kept (per-iteration cost is linear in nnz)."""
+    if cfg["kind"] != "random":
+        return ""
+    f = max(1, int(round(cfg["m"] * cfg["per_row"] / CPU_SAMPLE_NNZ)))
+    return f"random:{max(cfg['m'] // f, 1)}:{max(cfg['n'] // f, 1)}:{cfg['per_row']}"
+
+
+def cpu_baseline_scaled(spec: str, nnz_full: int, iters: int = 20):
+    """`cpu_baseline` of the N > 1 line: oracle/_ref (or the C port) on a scaled-down instance of the SAME
+    generator, one core; `value` is the measured rate scaled linearly in nnz to the full workload (an
+    iteration of LSQR is O(nnz)); the raw sample is quoted beside it."""
+    import time as _t
+
+    import oracle
+
+    from . import devgen
+    cfg = devgen.parse_spec(spec)
+    sspec = cpu_sample_spec(cfg)
+    if not sspec:
+        return None
+    irow, icol, a, b = devgen.download_coo(sspec)      # generated in HBM (bit-identical to lsqr_amd.problems), copied out
+    sc = devgen.parse_spec(sspec)
+    rf = oracle.ref()
+    eng, kind = (rf, "reference") if rf is not None else (oracle.port(), "port")
+    t0 = _t.perf_counter()
+    r = eng.solve(sc["m"], sc["n"], irow, icol, a, b, damp=sc["damp"], itnlim=iters)
+    dt = _t.perf_counter() - t0
+    rate = r.itn / dt
+    return {"value": rate * len(a) / nnz_full, "unit": "it/s", "cores": 1, "kind": kind,
+            "value_is": "the sample's measured rate scaled by nnz(sample) / nnz(workload): LSQR's iteration is O(nnz)",
+            "sample_value": rate, "sample_nnz": int(len(a)),
+            "sample": f"{sspec} (same generator and seed, rows and columns scaled down, {len(a)} nonzeros): {r.itn} "
+                      f"iterations in {dt:.2f} s, "
+                      f"{'oracle/_ref (reference compiled with amdflang -O2)' if kind == 'reference' else 'oracle C port'}"}
+
+
+def rank0_block_traffic(spec: str, row0: int, nrows: int):
+    """HBM bytes per mode-1 product of rank 0's row block from rocprofv3 PMC passes run as child processes of
+    rank 0 (bench.py live_traffic), BEFORE this process joins the world (the other ranks wait in the
+    rendezvous meanwhile).  (traffic dict or None, note)"""
+    import bench
+    plan = [[spec, {}, int(row0), int(nrows)]]
+    traffic, note = bench.live_traffic(plan)
+    return traffic.get((spec, "{}", (int(row0), int(nrows)))), note
 
 
 def run_distributed(args):
@@ -28,6 +83,15 @@ def run_distributed(args):
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py: no MI355X visible; the HIP path has no CPU fallback")
+    spec = DEFAULT_SPEC if args.workload == "auto" else args.workload
+    cfg = devgen.parse_spec(spec)
+    blocks = partition_rows(cfg["m"], world, devgen.row_weights(cfg))
+    traffic, traffic_note = None, "--traffic off"
+    if rank == 0 and args.traffic == "live" and not args.no_roofline:
+        try:
+            traffic, traffic_note = rank0_block_traffic(spec, *blocks[0])
+        except Exception as e:  # noqa: BLE001  (never fail the measurement over its annotation)
+            traffic, traffic_note = None, f"PMC passes failed: {e!r}"
     torch.cuda.set_device(local)
     capi.check(capi.lib().lsqrhip_set_device(local))
     dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
@@ -35,10 +99,7 @@ def run_distributed(args):
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)")
 
-    spec = DEFAULT_SPEC if args.workload == "auto" else args.workload
-    cfg = devgen.parse_spec(spec)
     K, W = args.steps, args.warmup
-    blocks = partition_rows(cfg["m"], world, devgen.row_weights(cfg))
     row0, nrows = blocks[rank]
     prob = devgen.generate(spec, row0, nrows)
     # the loop itself -- kernels and RCCL calls -- runs in C++ (csrc/shard_engine.h); LSQR_DIST_ENGINE=python
@@ -57,14 +118,23 @@ def run_distributed(args):
 
     if engine != "python":
         ok = 1
+        # A rank that hangs inside RCCL (a peer died in ncclCommInitRank, a send without its receive) cannot be
+        # recovered in-process: the watchdog ends THIS process with a non-zero code and the launcher tears the job
+        # down -- no restart, no exec from a process that holds the GPU.
+        import threading
+        watchdog = threading.Timer(float(os.environ.get("LSQR_DIST_PROBE_TIMEOUT", "600")), lambda: os._exit(3))
+        watchdog.daemon = True
+        watchdog.start()
         try:
             if os.environ.get("LSQR_DIST_TEST_ENGINE_FAILURE") == "1":   # (tests: the fall-back path)
                 raise RuntimeError("LSQR_DIST_TEST_ENGINE_FAILURE")
-            drv = EngineSolver(prob.solver, row0, cfg["m"], world, rank)
+            drv = EngineSolver(prob.solver, row0, cfg["m"], world, rank)   # (its handshake is collective-safe: dist.py)
             if world > 1:
                 r_eng = drv.solve(prob.d_b.ptr.value, itnlim=4, **kw)
         except Exception as e:  # noqa: BLE001  (RCCL missing / refusing: report and use the other driver)
             engine_note, ok, drv = f"c++ engine failed: {e!r}", 0, None
+        finally:
+            watchdog.cancel()
         if world > 1:
             flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
@@ -155,6 +225,13 @@ def run_distributed(args):
         except Exception as e:  # e.g. not enough HBM for the whole matrix: report, do not fail the run
             ref = {"error": repr(e)}
 
+    cpu = None
+    if rank == 0 and args.cpu_iters > 0:
+        try:
+            cpu = cpu_baseline_scaled(spec, nnz_total)
+        except Exception as e:  # noqa: BLE001
+            cpu = {"error": repr(e)}
+
     # RCCL (NCCL_DEBUG=VERSION on the GPU boxes) writes its banner to STDOUT through C stdio,
     # which sits in a buffer until the process exits -- i.e. after the JSON line.  Drain every
     # rank's C buffers first so that the JSON line is the last thing this job prints on stdout.
@@ -182,11 +259,14 @@ def run_distributed(args):
                        "restarts": restarts},
             "result": {"istop": r.istop, "itn": r.itn, "anorm": r.anorm, "rnorm": r.rnorm},
             "roofline": {"bound": "hbm", "kernel": f"{kname} (aprod mode 1, local row block, rank 0)",
-                         "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": None,
+                         "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
+                         "traffic": traffic.get("bytes_per_launch") if traffic else None,
+                         "traffic_detail": traffic, "traffic_note": traffic_note,
                          "bytes_per_launch": lay1, "avg_launch_us": avg1 * 1e3, "launches": reps,
                          "bytes_are": "the layout in use: matrix as stored + x once + y read and written (physical)",
                          "effective_gbps": b1 / (avg1 * 1e-3) / 1e9, "effective_bytes_per_launch": b1},
         }
+        out["cpu_baseline"] = cpu
         if ref is not None:
             out["strong_scaling_ref"] = ref
             if "value" in ref:

@@ -45,7 +45,7 @@ module lsqr_module
       integer  :: nout = 0
       type(c_ptr) :: handle = c_null_ptr   !< lsqrhip_handle_t (reference-counted, see assignment)
       logical  :: io32 = .false.           !< REAL32 build, one GPU: a handle of lsqrhip_create_f32 (real32 on the device)
-      logical  :: sharded = .false.        !< rows cut over several GPUs (`initialize(..., ngpu=)`): no iteration log
+      logical  :: sharded = .false.        !< rows cut over several GPUs (`initialize(..., ngpu=)`)
    contains
       procedure, public :: initialize => initialize_ez
       procedure, public :: solve => solve_ez
@@ -368,7 +368,7 @@ contains
 
       if (.not. c_associated(me%handle)) call check(4_c_int)
       wantse = merge(1_c_int, 0_c_int, present(se))
-      want_log = merge(1_c_int, 0_c_int, me%nout /= 0 .and. .not. me%sharded)
+      want_log = merge(1_c_int, 0_c_int, me%nout /= 0)   ! (sharded: rank 0 keeps the records, the scalars are replicated)
       if (me%io32) then
          allocate (xf(max(me%n, 1)), sef(max(me%n, 1)), bf(max(me%m, 1)))
          bf(1:me%m) = real(b, c_float)
@@ -393,7 +393,7 @@ contains
       if (present(rnorm)) rnorm = rnorm_
       if (present(arnorm)) arnorm = arnorm_
       if (present(xnorm)) xnorm = xnorm_
-      if (me%nout /= 0 .and. .not. me%sharded) &
+      if (me%nout /= 0) &
          call print_device_log(me, damp, present(se), int(istop_), int(itn_), real(anorm_, wp), &
                                               real(acond_, wp), real(rnorm_, wp), real(arnorm_, wp), real(xnorm_, wp))
    end subroutine solve_ez

@@ -9,7 +9,7 @@ import oracle
 from lsqr_amd.solver import lsqr_solver_ez
 
 KNOBS = ["LSQRHIP_SELL", "LSQRHIP_SELLP", "LSQRHIP_VAL8", "LSQRHIP_COL16", "LSQRHIP_PANELS", "LSQRHIP_PANEL_KB",
-         "LSQRHIP_XLDS", "LSQRHIP_XLDS_COLS", "LSQRHIP_OFF64", "LSQRHIP_SKEW", "LSQRHIP_TUNE", "LSQRHIP_CSB", "LSQRHIP_CSB_R", "LSQRHIP_CSB_LO32", "LSQRHIP_CSB_S"]
+         "LSQRHIP_XLDS", "LSQRHIP_XLDS_COLS", "LSQRHIP_OFF64", "LSQRHIP_SKEW", "LSQRHIP_TUNE", "LSQRHIP_CSB", "LSQRHIP_CSB_R", "LSQRHIP_CSB_S"]
 LAYOUTS = [
     {},                                                                        # whatever the build chooses
     {"LSQRHIP_SELL": "0"},
@@ -20,7 +20,6 @@ LAYOUTS = [
     {"LSQRHIP_SELL": "1", "LSQRHIP_SELLP": "0"},
     {"LSQRHIP_CSB": "1"},                                                      # column-swept row blocks (csb.h)
     {"LSQRHIP_CSB": "1", "LSQRHIP_CSB_R": "37"},                               # ... in many small blocks, ragged last one
-    {"LSQRHIP_CSB": "1", "LSQRHIP_CSB_LO32": "0"},                             # ... 8-byte low parts whatever the row lengths
     {"LSQRHIP_CSB": "1", "LSQRHIP_CSB_R": "129", "LSQRHIP_CSB_S": "3"},        # ... three workgroups per block (column splits)
 ]
 

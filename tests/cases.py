@@ -89,3 +89,30 @@ def build_cases():
 
 
 TRUNCATED_TWINS = ["illcond_conlim_it10", "powerlaw_small_it10", "poisson_48x37_it100", "empty_rows_cols_it20"]
+
+
+def assert_log_lines_match(got, want, min_records):
+    """An iteration log (list of lines) against the reference's own log of the same run: text lines equal
+    (5-digit scalars of the exit block may round apart), every printed iteration the same, x(1) and rnorm to
+    their 10 printed digits, test1, test2, anorm, acond to their 3, phi, dknorm, dxk, alfa_opt to their 2."""
+    import re
+
+    import numpy as np
+    assert len(got) == len(want)
+    num = re.compile(r"[-+]?\d\.\d+E[-+]\d+")
+    nrec = 0
+    for a, b in zip(got, want):
+        if not re.match(r"^\s+\d+\s+[-+]?\d\.\d{9}E", b):          # not an iteration record: text must be equal
+            if a != b:                                                 # (exit block: 5-digit scalars may round apart)
+                va, vb = [float(t) for t in num.findall(a)], [float(t) for t in num.findall(b)]
+                assert num.sub("#", a) == num.sub("#", b) and np.allclose(va, vb, rtol=2e-5, atol=0)
+            continue
+        nrec += 1
+        assert a[:6] == b[:6]                                          # the same iteration is printed
+        va, vb = [float(t) for t in num.findall(a)], [float(t) for t in num.findall(b)]
+        assert len(va) == len(vb)
+        digits = [10, 10, 3, 3, 3, 3, 2, 2, 2, 2]
+        for k, (x1, x2) in enumerate(zip(va, vb)):
+            tol = 1.01 * 10.0 ** (1 - digits[k])                       # one unit of the last printed digit
+            assert abs(x1 - x2) <= tol * max(abs(x2), 1e-300), (a, b, k)
+    assert nrec >= min_records

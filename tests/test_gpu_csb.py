@@ -1,7 +1,7 @@
 """Column-swept row blocks (csrc/csb.h): the layout of scattered matrices whose x exceeds L2.
 
 Forced on at test scale (LSQRHIP_CSB=1) and checked against the oracle for both aprod modes and
-for solves; the exact two-part sums make every result independent of the blocking, so products
+for solves; the exact integer sums make every result independent of the blocking, so products
 under different block sizes must agree BIT FOR BIT; a matrix whose blocks are too empty for 18-bit
 local columns must fall back to another layout; non-finite x must come out as the reference's."""
 import os
@@ -20,7 +20,7 @@ CASES = build_cases()
 
 @pytest.fixture
 def csb_env():
-    keys = ("LSQRHIP_CSB", "LSQRHIP_CSB_R", "LSQRHIP_CSB_LO32", "LSQRHIP_CSB_S")
+    keys = ("LSQRHIP_CSB", "LSQRHIP_CSB_R", "LSQRHIP_CSB_S")
     old = {k: os.environ.get(k) for k in keys}
     os.environ["LSQRHIP_CSB"] = "1"
 
@@ -84,10 +84,10 @@ def test_products_and_solve_match_oracle(csb_env, name, R):
         assert abs(r.rnorm - g.rnorm) <= 1e-10 * g.rnorm or g.rnorm <= 1e-13 * np.linalg.norm(p.b)
 
 
-@pytest.mark.parametrize("kind", ["powerlaw rows of 2500 (8-byte low parts)", "rows of 9 (32-bit integer low parts)"])
+@pytest.mark.parametrize("kind", ["powerlaw rows of 2500", "rows of 9"])
 def test_results_do_not_depend_on_the_blocking_bit_for_bit(csb_env, kind):
-    """Every product is split exactly onto two fixed binary grids and the sums on those grids are
-    exact, so the order of the adds -- and with it the block size, the column splits, the launch shape,
+    """Every product is rounded once onto a fixed binary grid and the sums on that grid are 64-bit integer
+    sums: exact, so the order of the adds -- and with it the block size, the column splits, the launch shape,
     which wave took which chunk -- cannot change a bit of y.  A solve inherits that up to its partial sums of y^2
     (one per block, reduced in block order): identical blockings repeat exactly."""
     if kind.startswith("powerlaw"):

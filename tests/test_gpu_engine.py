@@ -271,3 +271,89 @@ def test_loopback_eight_ranks_on_a_larger_system_agree_with_one_gpu(loopback, cs
         assert abs(sc[0] - ref.anorm) <= 1e-10 * ref.anorm and abs(sc[2] - ref.rnorm) <= 1e-10 * ref.rnorm
     finally:
         check(lib().lsqrhip_destroy(h))
+
+
+@pytest.mark.parametrize("name", ["poisson_48x37_it100", "empty_rows_cols_it20", "illcond_conlim_it10"])
+@pytest.mark.parametrize("ngpu", [1, 3])
+def test_sharded_solve_keeps_the_iteration_log(loopback, name, ngpu):
+    """`nout /= 0` on a sharded handle (reference src/lsqr.f90:589-595, 813-837, 872-880): the scalars of the
+    iteration are replicated and x(1) is the first entry of rank 0's column slice, so rank 0's records ARE the
+    reference's log.  On the truncated twins (the reference's own drift < 1e-11 there) the text formatted from a
+    3-rank solve must match the reference's own log of the run line for line to the printed digits, and the
+    records of the one-GPU path to rounding."""
+    import os
+    from types import SimpleNamespace
+
+    from cases import assert_log_lines_match
+    from lsqr_amd.logfmt import format_log
+    p, o = CASES[name]
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"log_{name}.txt")
+    h = sharded_handle(p, ngpu)
+    try:
+        x, se = np.zeros(max(p.n, 1)), np.zeros(max(p.n, 1))
+        istop, itn = C.c_int(), C.c_int()
+        sc = [C.c_double() for _ in range(5)]
+        b = np.ascontiguousarray(p.b, np.float64)
+        check(lib().lsqrhip_solve(h, b.ctypes.data, o["damp"], o["atol"], o["btol"], o["conlim"], o["itnlim"], 0, 1,
+                                  x.ctypes.data, None, C.addressof(istop), C.addressof(itn),
+                                  *[C.addressof(s) for s in sc]))
+        k = lib().lsqrhip_log_count(h)
+        rec = np.zeros((k, capi.LOG_STRIDE))
+        check(lib().lsqrhip_log_fetch(h, 0, k, rec.ctypes.data))
+        ex = np.zeros(6)
+        check(lib().lsqrhip_log_extras(h, ex.ctypes.data))
+    finally:
+        check(lib().lsqrhip_destroy(h))
+    assert k > 0 and int(rec[-1][0]) == itn.value
+    res = SimpleNamespace(istop=istop.value, itn=itn.value, anorm=sc[0].value, acond=sc[1].value, rnorm=sc[2].value,
+                          arnorm=sc[3].value, xnorm=sc[4].value)
+    text = format_log(p.m, p.n, o["damp"], False, o["atol"], o["btol"], o["conlim"], o["itnlim"], rec, res,
+                      bnorm=ex[0], dxmax=ex[1], maxdx=int(ex[2]), test2_0=ex[5], beta0=ex[4])
+    assert_log_lines_match(text.splitlines(), open(gold).read().splitlines(), min(itn.value, 10))
+    # ... and against the records of the one-GPU path (another order of the partial sums: rounding apart)
+    s = lsqr_solver_ez().initialize(p.m, p.n, p.a, p.irow, p.icol, atol=o["atol"], btol=o["btol"], conlim=o["conlim"],
+                                    itnlim=o["itnlim"], nout=os.devnull)
+    s.solve(p.b, o["damp"])
+    one = s.log_records()
+    assert one.shape == rec.shape and np.array_equal(one[:, 0], rec[:, 0]) and np.array_equal(one[:, 11], rec[:, 11])
+    assert np.allclose(rec[:, 1:7], one[:, 1:7], rtol=1e-8, atol=0)
+    # a solve without the log leaves none behind
+    h = sharded_handle(p, ngpu)
+    try:
+        solve_handle(h, p, dict(o, wantse=False))
+        assert lib().lsqrhip_log_count(h) == 0
+    finally:
+        check(lib().lsqrhip_destroy(h))
+
+
+@pytest.mark.parametrize("ngpu", [1, 3])
+def test_captured_batches_and_eager_launches_agree_bitwise(loopback, ngpu):
+    """With one local rank the engine runs its iterations as one hipGraph per batch of 16 (stages and local
+    exchanges captured from the rank's stream); LSQRHIP_SHARD_GRAPH=0 enqueues the same launches one by one, as
+    groups of several ranks in one process always do.  Same kernels on the same inputs in the same order:
+    identical bits, for a run that stops inside a batch, one that ends on a batch boundary and one shorter than
+    a batch -- and a captured batch is reused by the next solve."""
+    import os
+    p, o = CASES["poisson_20x20_it50"]
+    for itnlim in (50, 32, 5):
+        oo = dict(o, itnlim=itnlim)
+        res = {}
+        for mode in ("0", None):
+            old = os.environ.pop("LSQRHIP_SHARD_GRAPH", None)
+            if mode is not None:
+                os.environ["LSQRHIP_SHARD_GRAPH"] = mode
+            try:
+                h = sharded_handle(p, ngpu)
+                try:
+                    a = solve_handle(h, p, oo)
+                    b = solve_handle(h, p, oo)
+                finally:
+                    check(lib().lsqrhip_destroy(h))
+            finally:
+                os.environ.pop("LSQRHIP_SHARD_GRAPH", None)
+                if old is not None:
+                    os.environ["LSQRHIP_SHARD_GRAPH"] = old
+            assert np.array_equal(a[0], b[0]) and a[2:] == b[2:]
+            res[mode] = a
+        assert np.array_equal(res["0"][0], res[None][0]) and res["0"][2:] == res[None][2:]
+        assert res[None][3] == itnlim

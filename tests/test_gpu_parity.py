@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 
 import oracle
-from cases import TRUNCATED_TWINS, build_cases
+from cases import TRUNCATED_TWINS, assert_log_lines_match, build_cases
 from golden.gen_golden import blas_vectors
 from lsqr_amd import capi, problems as P
 from lsqr_amd.capi import LsqrHipError
@@ -358,24 +358,7 @@ def test_truncated_twins_hold_the_strict_tolerance(name, tmp_path):
         assert rel(r.xnorm, fh(g["xnorm"])) <= TOL and rel(r.acond, fh(g["acond"])) <= 1e-9
     got = open(path).read().splitlines()
     want = open(os.path.join(GOLD, f"log_{name}.txt")).read().splitlines()
-    assert len(got) == len(want)
-    num = re.compile(r"[-+]?\d\.\d+E[-+]\d+")
-    nrec = 0
-    for a, b in zip(got, want):
-        if not re.match(r"^\s+\d+\s+[-+]?\d\.\d{9}E", b):          # not an iteration record: text must be equal
-            if a != b:                                                 # (exit block: 5-digit scalars may round apart)
-                va, vb = [float(t) for t in num.findall(a)], [float(t) for t in num.findall(b)]
-                assert num.sub("#", a) == num.sub("#", b) and np.allclose(va, vb, rtol=2e-5, atol=0)
-            continue
-        nrec += 1
-        assert a[:6] == b[:6]                                          # the same iteration is printed
-        va, vb = [float(t) for t in num.findall(a)], [float(t) for t in num.findall(b)]
-        assert len(va) == len(vb)
-        digits = [10, 10, 3, 3, 3, 3, 2, 2, 2, 2]
-        for k, (x1, x2) in enumerate(zip(va, vb)):
-            tol = 1.01 * 10.0 ** (1 - digits[k])                       # one unit of the last printed digit
-            assert abs(x1 - x2) <= tol * max(abs(x2), 1e-300), (a, b, k)
-    assert nrec >= min(g["itn"], 10)
+    assert_log_lines_match(got, want, min(g["itn"], 10))
 
 
 def test_log_holds_every_line_of_a_run_that_lingers_near_convergence(tmp_path):
