@@ -276,6 +276,12 @@ int lsqrhip_dev_sync(void);
  *     ngpu is clamped to the number of rows; more devices than the node has -> LSQRHIP_ERR_NO_DEVICE. */
 int lsqrhip_create_sharded(int m, int n, int64_t nnz, const int *irow, const int *icol, const double *a, int ngpu,
                            lsqrhip_handle_t *out);
+/*     The same for a host built with wp = real32 (src/lsqr_kinds.F90:16-17; lsqr_amd/fortran -DREAL32 with ngpu=):
+ *     real32 storage in every row block and real32 slices on the links (half the bytes of both exchanges), binary64
+ *     registers; the handle then works with lsqrhip_solve_f32 / lsqrhip_aprod_f32 (float host vectors).
+ *     LSQRHIP_REAL32_MIXED=1: binary64 on the devices, real32 at the boundary only. */
+int lsqrhip_create_sharded_f32(int m, int n, int64_t nnz, const int *irow, const int *icol, const float *a, int ngpu,
+                               lsqrhip_handle_t *out);
 
 /* (2) one process PER GPU (bench.py --gpus N under torch.distributed.run): every rank creates an
  *     ordinary handle from its own row block (rows renumbered from 1, all n columns), rank 0 obtains a

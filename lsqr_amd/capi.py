@@ -34,7 +34,7 @@ EXPORTS = [
     "lsqrhip_shard_begin", "lsqrhip_shard_stage", "lsqrhip_shard_poll", "lsqrhip_shard_end", "lsqrhip_sum_chunks",
     "lsqrhip_create_f32", "lsqrhip_solve_f32", "lsqrhip_aprod_f32", "lsqrhip_solve_device_f32",
     "lsqrhip_aprod_device_f32",
-    "lsqrhip_create_sharded", "lsqrhip_rccl_unique_id", "lsqrhip_shard_comm_init", "lsqrhip_shard_solve",
+    "lsqrhip_create_sharded", "lsqrhip_create_sharded_f32", "lsqrhip_rccl_unique_id", "lsqrhip_shard_comm_init", "lsqrhip_shard_solve",
     "lsqrhip_gen_count", "lsqrhip_gen_coo",
     "lsqrhip_create_operator", "lsqrhip_lstp_create", "lsqrhip_lstp_vectors",
 ]
@@ -113,6 +113,7 @@ def lib() -> C.CDLL:
     L.lsqrhip_dev_download.argtypes = [vp, vp, i64]
     L.lsqrhip_shard_begin.argtypes = [vp, vp, i64, i32, i32, f64, f64, f64, f64, i32, i32, vp, vp, vp, vp]
     L.lsqrhip_create_sharded.argtypes = [i32, i32, i64, vp, vp, vp, i32, C.POINTER(vp)]
+    L.lsqrhip_create_sharded_f32.argtypes = [i32, i32, i64, vp, vp, vp, i32, C.POINTER(vp)]
     L.lsqrhip_rccl_unique_id.argtypes = [vp]
     L.lsqrhip_shard_comm_init.argtypes = [vp, i32, i32, i64, i64, vp]
     L.lsqrhip_shard_solve.argtypes = [vp, vp, f64, f64, f64, f64, i32, i32, vp, vp] + [vp] * 7

@@ -83,57 +83,6 @@ __device__ __forceinline__ double block_sum_all(const double *__restrict__ p, in
     return out;
 }
 
-// block_sum_all with two places for the caller's own loads: `pre()` runs right after this thread's loads of the
-// partials have been ISSUED (loads queued there return behind them, so the sum never waits for them), `mid()`
-// between the two barriers of the cross-wave step.  Same loads, same adds, same order: the same bits.
-struct NoHook {
-    __device__ __forceinline__ void operator()() const {}
-};
-template <int BLOCK, int K, typename Pre>
-__device__ __forceinline__ double strided_sum_k_hook(const double *__restrict__ p, int np, Pre &pre)
-{
-    const int t = threadIdx.x;
-    const int last = np > 0 ? np - 1 : 0;
-    double v[K];
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-        const int i = t + k * BLOCK;
-        v[k] = p[i < last ? i : last];
-    }
-    pre();
-    double s = 0.0;
-#pragma unroll
-    for (int k = 0; k < K; ++k)
-        if (t + k * BLOCK < np) s += v[k];
-    for (int i = t + K * BLOCK; i < np; i += BLOCK) s += p[i];
-    return s;
-}
-template <int BLOCK, typename Pre, typename Mid>
-__device__ __forceinline__ double block_sum_all_hooks(const double *__restrict__ p, int np, double *lds, Pre &pre, Mid &mid)
-{
-    double s = 0.0;
-    if (np <= 0) pre();
-    else if (np <= 2 * BLOCK) s = strided_sum_k_hook<BLOCK, 2>(p, np, pre);
-    else if (np <= 4 * BLOCK) s = strided_sum_k_hook<BLOCK, 4>(p, np, pre);
-    else s = strided_sum_k_hook<BLOCK, 8>(p, np, pre);
-    const int lane = threadIdx.x & (WAVE - 1), wid = threadIdx.x >> 6;
-    s = wave_sum(s);
-    __syncthreads();
-    if (lane == 0) lds[wid] = s;
-    __syncthreads();
-    mid();
-    if (threadIdx.x == 0) {
-        double r = 0.0;
-#pragma unroll
-        for (int i = 0; i < BLOCK / WAVE; ++i) r += lds[i];
-        lds[BLOCK / WAVE] = r;
-    }
-    __syncthreads();
-    const double out = lds[BLOCK / WAVE];
-    __syncthreads();
-    return out;
-}
-
 // Blue's range-safe sum of squares (constants of LAPACK 3.10's dnrm2); see scalar.h "range-safe norms".
 constexpr double BLUE_TSML = 0x1p-511, BLUE_TBIG = 0x1p486, BLUE_SSML = 0x1p537, BLUE_SBIG = 0x1p-538;
 

@@ -25,16 +25,18 @@
 //     order-free by nature.  Each product p is rounded once to the fixed binary grid
 //         g = 2^(eb - 61),      2^eb > B >= |sum_j A_ij (x_j sx)| for every row i,
 //     q = rint(p / g) is added, and y's new part is (double)(sum of the q) * g: ONE more rounding.
-//     The bound B: for the solver's own unit vectors (|x sx|_2 <= 1) Cauchy-Schwarz gives
-//     B = max_i |a_i|_2; for caller vectors B = max_i |a_i|_1 * max|x sx| (a k_amax pass).  Both row
-//     norms are taken at build time (integer sums: deterministic).  Only the FINAL sum has to fit --
-//     two's-complement adds wrap, so partial sums in any order may overflow on the way -- and it
-//     does with two bits to spare whatever the row length.  So the result does not depend on the
-//     order of the adds, on R, on the launch shape, on which workgroup took which block or on column
-//     splits: bit-reproducible by construction.  Accuracy: each product is off by <= g/2 = 2^-62 B,
-//     i.e. a row of k nonzeros by <= k 2^-62 B (typically sqrt(k) 2^-63 B) where the reference's
-//     left-to-right sum is off by up to k 2^-53 |a_i|'|x|: for rows whose products are of the size
-//     the bound allows this is ~500 times closer to the exact sum, normwise always at least as close.
+//     The bound: B = max_i sum_j |a_ij| * max_j |x_j sx| -- the largest row 1-norm, taken at build time as an
+//     integer sum (deterministic), times the largest entry of the vector, taken by a k_amax pass over x before
+//     every product (0.4 % of a config-4 product).  It holds whatever the matrix looks like -- in particular with
+//     DUPLICATE (i, j) entries, which the reference sums like any others: the first form of this bound,
+//     |a_i|_2 |x|_2 for the solver's unit vectors, is wrong with duplicates (185 equal entries on one (i, j)
+//     weigh 185, not sqrt(185): the sums wrapped on such a system, tests/test_gpu_fuzz.py) -- and for vectors
+//     without outliers it is also the tighter one (config 4: 60 * 1.6e-3 against 6.5).  Only the FINAL sum has to
+//     fit -- two's-complement adds wrap, so partial sums in any order may overflow on the way -- and it does
+//     with two bits to spare whatever the row length.  So the result does not depend on the order of the adds,
+//     on R, on the launch shape, on which workgroup took which block or on column splits: bit-reproducible by
+//     construction.  Accuracy: each product is off by <= g/2 = 2^-62 B, i.e. a row of k nonzeros by <= k 2^-62 B
+//     (typically sqrt(k) 2^-63 B) where the reference's left-to-right sum is off by up to k 2^-53 |a_i|'|x|.
 //     (r02 kept two parts per row, 12-16 bytes: 9766-13021 rows per block at config 4; 8 bytes per
 //     row give 19532 -- 50 % more nonzeros per column of x in every sweep and 2 rounds instead of 3.)
 //   * a product beyond the bound or not finite (inf / NaN in x: never in a solve that has not
@@ -75,7 +77,7 @@ constexpr int CSB_LCOL_BITS = 17;
 constexpr unsigned CSB_LCOL_MASK = (1u << CSB_LCOL_BITS) - 1u;
 static_assert(CSB_NACC <= (1 << (32 - CSB_LCOL_BITS)), "local rows fit the index word");
 constexpr int CSB_GRID = 256;                    // one workgroup per CU
-constexpr int CSB_NORM_FRAC = 32;                // build: row norms as integer sums of |a| 2^(32 - ea), a^2 2^(32 - 2 ea)
+constexpr int CSB_NORM_FRAC = 32;                // build: row 1-norms as integer sums of ceil(|a| 2^(32 - ea))
 // The (value, index) stream is read once: loaded non-temporal so that it does not push the part of x the
 // XCD's workgroups are gathering from out of L2 (PMC before: 15 % of the gathers missed L2, 2.6x the
 // layout's bytes fetched; config 4 4.80 -> 4.20 ms, config 3 at 100 per row 956 -> 900 us).
@@ -90,8 +92,7 @@ struct CsbMat {
     const long long *cptr;  // [nrb + 1], in chunks
     const int *rstart;      // [nrb + 1] first row of each block (blocks are cut by NONZEROS, at most R rows each)
     int nrb, R, rows, cols; // R = the dummy accumulator's index = rows per block at most
-    int e1;  // 2^e1 > max_i sum_j |a_ij|          (bound on a row sum for |x sx| <= 1 elementwise)
-    int e2;  // 2^e2 > max_i sqrt(sum_j a_ij^2)    (bound on a row sum for |x sx|_2 <= 1)
+    int e1;  // 2^e1 > max_i sum_j |a_ij|: with max|x sx| the bound on a row sum
     int b0, b1;  // the row blocks of THIS launch: [b0, b1)
     int S;       // column splits: S workgroups share a row block, each sweeping 1/S of its chunks (see below)
     long long *z;   // S > 1: the splits' exact integer sums, [S][rows]
@@ -122,14 +123,14 @@ __global__ __launch_bounds__(256) void k_csb_pack_col(const int *__restrict__ ro
     if (uns) atomicOr(&flags[1], 1);
 }
 
-// pos1[i] = original position of the i-th nonzero in column order; cnt[row] += 1; and the row norms behind
-// the bound on a row sum (header): n1[row] += ceil(|a| 2^(32 - ea)), n2[row] += ceil(a^2 2^(32 - 2 ea)) with
-// 2^ea > max|a| -- integer sums, so the bounds do not depend on the order of the atomics.  (A value that is
-// not finite counts as 2^ea: its products are left to the outlier pass anyway.)
+// pos1[i] = original position of the i-th nonzero in column order; cnt[row] += 1; and the row 1-norms behind
+// the bound on a row sum (header): n1[row] += ceil(|a| 2^(32 - ea)) with 2^ea > max|a| -- an integer sum, so the
+// bound does not depend on the order of the atomics.  (A value that is not finite counts as 2^ea: its products
+// are left to the outlier pass anyway.)
 __global__ __launch_bounds__(256) void k_csb_pos(const unsigned long long *__restrict__ sorted, int64_t nnz,
                                                  const int *__restrict__ rowk, const double *__restrict__ a, double sc,
                                                  unsigned *__restrict__ pos1, int *__restrict__ cnt,
-                                                 unsigned long long *__restrict__ n1, unsigned long long *__restrict__ n2)
+                                                 unsigned long long *__restrict__ n1)
 {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const double one = (double)(1ull << CSB_NORM_FRAC);
@@ -141,7 +142,6 @@ __global__ __launch_bounds__(256) void k_csb_pos(const unsigned long long *__res
         double t = fabs(a[p]) * sc;      // in [0, 1)
         t = t < 1.0 ? t : 1.0;           // (inf, NaN -> 1)
         atomicAdd(&n1[r], (unsigned long long)ceil(t * one));
-        atomicAdd(&n2[r], (unsigned long long)ceil(t * t * one));
     }
 }
 
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(CSB_CHUNK) void k_csb_fill(const unsigned long long
 // product
 // ---------------------------------------------------------------------------------------------
 struct CsbX {
-    const double *xmax;  // partials of max|x| (vec.h k_amax), or null: |x sx|_2 <= 1 is known
+    const double *xmax;  // partials of max|x| (vec.h k_amax over the vector this product gathers from)
     int nxmax;
 };
 
@@ -284,28 +284,26 @@ __device__ __forceinline__ CsbCoef csb_coef(const SpmvCoef *__restrict__ coef, c
     return c;
 }
 
-// 2^eb > the bound on |row sum| of this launch (header); every thread gets the same value.
+// 2^eb > the bound on |row sum| of this launch (header): the largest row 1-norm times max|x sx|, the latter from
+// the partials of the k_amax pass that precedes every product; every thread gets the same value.
 __device__ __forceinline__ int csb_bound_exp(const CsbMat &A, CsbX xb, double sx, double *red)
 {
-    int eb = A.e2;   // |x sx|_2 <= 1: the solver's own unit vectors
-    if (xb.xmax != nullptr) {
-        const int tid = threadIdx.x, lane = tid & (WAVE - 1);
-        const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-        double m = 0.0;
-        for (int i = tid; i < xb.nxmax; i += CSB_BLOCK) m = fmax(m, xb.xmax[i]);
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1);
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    double m = 0.0;
+    for (int i = tid; i < xb.nxmax; i += CSB_BLOCK) m = fmax(m, xb.xmax[i]);
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off, WAVE));
-        if (lane == 0) red[w] = m;
-        __syncthreads();
-        m = red[0];
+    for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off, WAVE));
+    if (lane == 0) red[w] = m;
+    __syncthreads();
+    m = red[0];
 #pragma unroll
-        for (int i = 1; i < CSB_WAVES; ++i) m = fmax(m, red[i]);
-        __syncthreads();
-        const double bound = m * fabs(sx);
-        int ex = 0;
-        if (bound > 0.0 && bound < 1.0e308) (void)frexp(bound, &ex);  // bound < 2^ex
-        eb = A.e1 + ex;
-    }
+    for (int i = 1; i < CSB_WAVES; ++i) m = fmax(m, red[i]);
+    __syncthreads();
+    const double bound = m * fabs(sx);
+    int ex = 0;
+    if (bound > 0.0 && bound < 1.0e308) (void)frexp(bound, &ex);  // bound < 2^ex
+    int eb = A.e1 + ex;
     eb = eb > 1020 ? 1020 : eb;      // 2^eb and 2^(61 - eb) must stay finite and normal
     eb = eb < -960 ? -960 : eb;
     return eb;

@@ -170,7 +170,7 @@ struct Csr {
     int *crs = nullptr;           // [nrb + 1] first row of each row block
     int64_t nchunks = 0;
     int nrb = 0, R = 0;
-    int e1 = 0, e2 = 0;           // 2^e1 > max row 1-norm, 2^e2 > max row 2-norm: csb.h's bounds on a row sum
+    int e1 = 0;                   // 2^e1 > the largest row 1-norm: csb.h's bound on a row sum, with max|x|
     int S = 1;                    // column splits per row block (csb.h): S workgroups share a block
     long long *zsplit = nullptr;  // S > 1: [S][rows] exact integer sums of the splits
     int *cbad = nullptr;          // S > 1: [nrb] "a split left a product out" flags (csb.h outlier pass)
@@ -339,6 +339,7 @@ static int solve_group_host(H *h, const double *b, double damp, double atol, dou
                             int wantse, int want_log, double *x, double *se, int *istop, int *itn, double *anorm,
                             double *acond, double *rnorm, double *arnorm, double *xnorm);
 static int aprod_group_host(H *h, int mode, double *x, double *y);
+static int aprod_group_host_f32(H *h, int mode, float *x, float *y);
 
 static H *lsqrhip_group_rank0(H *h);
 
@@ -747,9 +748,9 @@ static int build_csb(hipStream_t s, const int *rowk, const int *colk, const doub
     HIPCHK(s_pos.alloc(sizeof(unsigned) * (size_t)std::max<int64_t>(nnz, 1)));
     HIPCHK(s_cnt.alloc(sizeof(int) * ((size_t)rows + 1)));
     HIPCHK(hipMemsetAsync(s_cnt.p, 0, sizeof(int) * ((size_t)rows + 1), s));
-    // row 1-norms and squared 2-norms as integer sums (csb.h k_csb_pos), then two words for their maxima
-    HIPCHK(s_nrm.alloc(sizeof(unsigned long long) * (2 * (size_t)rows + 2)));
-    HIPCHK(hipMemsetAsync(s_nrm.p, 0, sizeof(unsigned long long) * (2 * (size_t)rows + 2), s));
+    // row 1-norms as integer sums (csb.h k_csb_pos), then one word for their maximum
+    HIPCHK(s_nrm.alloc(sizeof(unsigned long long) * ((size_t)rows + 2)));
+    HIPCHK(hipMemsetAsync(s_nrm.p, 0, sizeof(unsigned long long) * ((size_t)rows + 2), s));
     unsigned long long *sorted1 = bufA;
     int maxrow = 0;
     unsigned long long nmax[2] = {0, 0};
@@ -761,15 +762,14 @@ static int build_csb(hipStream_t s, const int *rowk, const int *colk, const doub
         if (got[0]) return fail(bad_code, lsqrhip_error_string(bad_code));
         if (got[2]) return fail(bad_code_other, lsqrhip_error_string(bad_code_other));
         if (got[1]) sorted1 = radix_sort_words(s, bufA, bufB, nnz, bits_for(cols), hist);
-        unsigned long long *n1 = s_nrm.as<unsigned long long>(), *n2 = n1 + rows, *nm = n2 + rows;
+        unsigned long long *n1 = s_nrm.as<unsigned long long>(), *nm = n1 + rows;
         hipLaunchKernelGGL(k_csb_pos, dim3(g), dim3(256), 0, s, (const unsigned long long *)sorted1, nnz, rowk, d_a,
-                           std::ldexp(1.0, -ea), s_pos.as<unsigned>(), s_cnt.as<int>(), n1, n2);
-        // the longest row (how even the rows are), the largest row norms (the bounds on a row sum)
+                           std::ldexp(1.0, -ea), s_pos.as<unsigned>(), s_cnt.as<int>(), n1);
+        // the longest row (how even the rows are), the largest row 1-norm (the bound on a row sum)
         HIPCHK(hipMemsetAsync(d_flags, 0, 4 * sizeof(int), s));
         const dim3 gr((unsigned)std::min<int64_t>(((int64_t)rows + 255) / 256, 2048));
         hipLaunchKernelGGL(k_csb_maxint, gr, dim3(256), 0, s, (const int *)s_cnt.as<int>(), (int64_t)rows, d_flags);
         hipLaunchKernelGGL(k_csb_maxu64, gr, dim3(256), 0, s, (const unsigned long long *)n1, (int64_t)rows, nm);
-        hipLaunchKernelGGL(k_csb_maxu64, gr, dim3(256), 0, s, (const unsigned long long *)n2, (int64_t)rows, nm + 1);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(got, d_flags, sizeof(got), hipMemcpyDeviceToHost, s));
         HIPCHK(hipMemcpyAsync(nmax, nm, sizeof(nmax), hipMemcpyDeviceToHost, s));
@@ -777,12 +777,10 @@ static int build_csb(hipStream_t s, const int *rowk, const int *colk, const doub
         maxrow = got[0];
     }
     s_nrm.free_now();
-    // max_i sum_j |a_ij| < 2^e1 and max_i sqrt(sum_j a_ij^2) < 2^e2 from the integer maxima (all integer
-    // arithmetic: the same exponents on every build of the same matrix)
+    // max_i sum_j |a_ij| < 2^e1 from the integer maximum (integer arithmetic: the same exponent on every build
+    // of the same matrix)
     auto bits_u64 = [](unsigned long long v) { int b = 0; while (v) { ++b; v >>= 1; } return b; };   // v < 2^b
     const int e1 = ea - CSB_NORM_FRAC + bits_u64(nmax[0]);
-    const int b2 = bits_u64(nmax[1]) - CSB_NORM_FRAC;                     // sum a^2 < 2^(b2 + 2 ea)
-    const int e2 = ea + (b2 >= 0 ? (b2 + 1) / 2 : -((-b2) / 2));          // ceil(b2 / 2)
     // near-uniform rows (the longest <= 512): blocks cut by nonzeros stay close to the mean row count
     const bool even_rows = maxrow <= 512;
     const int rmax = CSB_RMAX;
@@ -907,7 +905,6 @@ static int build_csb(hipStream_t s, const int *rowk, const int *colk, const doub
     out.nrb = nrb;
     out.R = rmax;   // the dummy accumulator's index (blocks hold at most this many rows)
     out.e1 = e1;
-    out.e2 = e2;
     out.S = S;
     if (S > 1) {
         HIPCHK(hipMalloc((void **)&out.zsplit, sizeof(long long) * (size_t)S * (size_t)rows));
@@ -1867,6 +1864,7 @@ extern "C" int lsqrhip_aprod_f32(lsqrhip_handle_t h, int mode, float *x, float *
     if (!h) return fail(LSQRHIP_ERR_NOT_INIT, lsqrhip_error_string(LSQRHIP_ERR_NOT_INIT));
     if (!h->io32) return fail(LSQRHIP_ERR_ARG, "not a handle of lsqrhip_create_f32");
     if (mode != 1 && mode != 2) return fail(LSQRHIP_ERR_MODE, lsqrhip_error_string(LSQRHIP_ERR_MODE));
+    if (h->group && h->f32) return aprod_group_host_f32(h, mode, x, y);   // REAL32 blocks on several devices
     if (!h->f32) {  // mixed mode
         std::vector<double> xd((size_t)std::max(h->n, 1)), yd((size_t)std::max(h->m, 1));
         for (int j = 0; j < h->n; ++j) xd[(size_t)j] = (double)x[j];

@@ -197,15 +197,15 @@ struct SellCoef {
 // What every workgroup of a sliced-ELL product does before its rows: the lazy coefficients from
 // the previous kernel's partial sums (spmv.h) and, with UPD, its share of the x/w update of the
 // previous iteration (vec.h UpdArgs).  false = this product is skipped.
-template <bool UPD, typename VT, typename Pre = NoHook, typename Mid = NoHook>
+template <bool UPD, typename VT>
 __device__ __forceinline__ bool sell_prologue(const SpmvCoef *__restrict__ coef, const double *__restrict__ pin, int npin,
                                               const NormSlot *__restrict__ slot_in, NormSlot *__restrict__ slot_out,
                                               int skip_if_zero, const UpdArgs &upd, int nwg, int wg, double *red,
-                                              SellCoef &k, const NScale nsc, Pre pre = Pre(), Mid mid = Mid())
+                                              SellCoef &k, const NScale nsc)
 {
     const int tid = threadIdx.x;
     if (pin != nullptr) {  // lazy coefficients (spmv.h)
-        const double nrm = sqrt(block_sum_all_hooks<SELL_BLOCK>(pin, npin, red, pre, mid)) * nsc.inv;
+        const double nrm = sqrt(block_sum_all<SELL_BLOCK>(pin, npin, red)) * nsc.inv;
         if (skip_if_zero && !(nrm > 0.0)) {  // mode 2 is skipped when beta == 0 (:691)
             if (wg == 0 && tid == 0) {
                 slot_out->nrm = nrm;
@@ -245,8 +245,6 @@ __device__ __forceinline__ bool sell_prologue(const SpmvCoef *__restrict__ coef,
         }
         return true;
     }
-    pre();
-    mid();
     if (coef->skip != 0) return false;
     k.sx = coef->sx;
     k.sy = coef->sy;
@@ -434,20 +432,16 @@ __device__ __forceinline__ double sellp_add(double sum, const uint4 q, int k0, i
 
 // A launch at BASELINE configs[1] lives ~8 us, and what a workgroup does in it is a CHAIN of dependent round
 // trips: stop flag -> dictionary -> the previous kernel's partial sums (the lazy norm: two trips and two
-// barriers) -> slice descriptor -> record -> gathered x -> y.  Two things were tried in round 3
-// (profiles/r03/config2_early_loads.txt):
-//   * the dictionary's load, the stop flag's and the first descriptor's are requested together at the top
-//     (one round trip instead of three): kept, 39.2k -> 40.0k iterations/s at K = 2000;
-//   * SELLP_EARLY: also the first slice's record, y and gathered x requested BEFORE the prologue, so that they
-//     land while it runs.  The product alone (explicit coefficients, back to back) gains 0.4 us of 8.1 -- but
-//     inside the solve the iteration LOSES 1 us (38.1k): every workgroup's partial-sum loads now queue behind
-//     40 MB of product requests, right behind a kernel boundary that is still writing the previous kernel's
-//     output back, and the prologue -- which the update of the mode-1 launch and every row sum wait for -- ends
-//     later than before.  Off.
-#ifndef SELLP_EARLY
-#define SELLP_EARLY 0
-#endif
-
+// barriers) -> slice descriptor -> record -> gathered x -> y.  Round 3 (profiles/r03/config2_early_loads.txt):
+//   * the dictionary's load and the stop flag's are requested together at the top (one round trip instead of two)
+//     and the dictionary is stored to LDS just before the prologue's barrier: kept, 39.5k -> 40.7k iterations/s
+//     at K = 2000, 33.0k -> 33.8k at K = 20;
+//   * ALSO requesting the first slice's record, y and gathered x before the prologue (so that they land while it
+//     runs) makes the product alone 0.4 us faster and the solve 1 us per iteration SLOWER, whether they are
+//     queued before or behind the prologue's own loads: 1536 workgroups' partial-sum loads then share the memory
+//     system with 40 MB of product requests right behind a kernel boundary that is still writing the previous
+//     kernel's output back, and the prologue -- which the fused update and every row sum wait for -- ends
+//     later.  Not kept.
 template <bool UPD, typename VT = double>
 __global__ __launch_bounds__(SELL_BLOCK, 6) void k_spmv_sellp(
     const unsigned *__restrict__ roff, const uint4 *__restrict__ rec, const int *__restrict__ cbaseS,
@@ -466,52 +460,16 @@ __global__ __launch_bounds__(SELL_BLOCK, 6) void k_spmv_sellp(
         return;
     }
     const int tid = threadIdx.x;
-    const double dict_mine = dict[tid];  // (requested here, stored below: its wait rides with the record's)
+    const double dict_mine = dict[tid];  // (requested here, stored below: one round trip with the stop flag's)
     const int lane = tid & (WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: the slice descriptors arrive in SGPRs
     const XcdRange xr = xcd_range(nblk, nwg, wg);
 
-    // the first slice of this wave, requested ahead of the prologue
-    const int s0 = (int)(xr.first * SELL_SLICES) + wave;
-    const bool early = SELLP_EARLY && xr.first < xr.end && s0 < nslices;
-    unsigned e_o0 = 0;
-    int e_nch = 0, e_cb = 0;
-    double e_y0 = 0.0;
-    uint4 e_q = make_uint4(0u, 0u, 0u, 0u);
-    double e_xv[SELLP_K] = {0.0, 0.0, 0.0, 0.0, 0.0};
-    if (early) {   // the descriptor (scalar loads: they share the round trip of the stop flag and the dictionary)
-        e_o0 = roff[s0];
-        e_nch = (int)((roff[s0 + 1] - e_o0) >> 6);
-        e_cb = cbaseS[s0];
-    }
-    auto request_record = [&]() {
-        if (early) {
-            const int r = s0 * WAVE + lane;
-            e_y0 = (double)y[r < rows ? r : rows - 1];
-            if (e_nch > 0) e_q = rec[(size_t)e_o0 + lane];
-        }
-    };
-    auto request_x = [&]() {
-        if (early && e_nch > 0) {
-            int c[SELLP_K];
-            sellp_cols(e_q, e_cb, c);
-#pragma unroll
-            for (int t = 0; t < SELLP_K; ++t) e_xv[t] = (double)x[c[t]];
-        }
-    };
-    if (SELLP_EARLY == 1) request_record();
+    if (*stop != 0) return;   // (its load shares the dictionary's round trip)
     sdict[tid] = dict_mine;   // visible after the barrier below
-    if (SELLP_EARLY == 1) request_x();
-    if (*stop != 0) return;   // (tested after the requests above so that its load shares their round trip)
 
     SellCoef kc;
-    bool go;
-    if (SELLP_EARLY == 2)   // record and y behind the partial sums' loads, gathered x between the reduction's barriers
-        go = sell_prologue<UPD, VT>(coef, pin, npin, slot_in, slot_out, skip_if_zero, upd, nwg, wg, red, kc, nsc,
-                                    request_record, request_x);
-    else
-        go = sell_prologue<UPD, VT>(coef, pin, npin, slot_in, slot_out, skip_if_zero, upd, nwg, wg, red, kc, nsc);
-    if (!go) return;
+    if (!sell_prologue<UPD, VT>(coef, pin, npin, slot_in, slot_out, skip_if_zero, upd, nwg, wg, red, kc, nsc)) return;
     const double sx = kc.sx, sy = kc.sy, cy = kc.cy;
     __syncthreads();
 
@@ -519,24 +477,15 @@ __global__ __launch_bounds__(SELL_BLOCK, 6) void k_spmv_sellp(
     for (int64_t b = xr.first; b < xr.end; b += xr.stride) {
         const int s = (int)(b * SELL_SLICES) + wave;
         if (s >= nslices) continue;
-        const bool pre = early && b == xr.first;
-        const unsigned o0 = pre ? e_o0 : roff[s];
-        const int nch = pre ? e_nch : (int)((roff[s + 1] - o0) >> 6);
-        const int cb = pre ? e_cb : cbaseS[s];
+        const unsigned o0 = roff[s];
+        const int nch = (int)((roff[s + 1] - o0) >> 6);
+        const int cb = cbaseS[s];
         const int r = s * WAVE + lane;
         const bool active = r < rows;
-        const double y0 = pre ? e_y0 : (double)y[active ? r : rows - 1];
+        const double y0 = (double)y[active ? r : rows - 1];
         const uint4 *__restrict__ p = rec + (size_t)o0 + lane;
         double sum = 0.0;
-        if (pre) {
-            if (nch > 0) sum = sellp_sum(sum, e_q, 0, e_xv, sdict, sx);
-            for (int j = 1; j < nch; j += 2) {  // (rows of more than 5 nonzeros: the other records as below)
-                const uint4 qa = p[(size_t)j * 64];
-                const uint4 qb = p[(size_t)min(j + 1, nch - 1) * 64];
-                sum = sellp_add<VT>(sum, qa, SELLP_K * j, cb, sdict, x, sx);
-                if (j + 1 < nch) sum = sellp_add<VT>(sum, qb, SELLP_K * (j + 1), cb, sdict, x, sx);
-            }
-        } else if (nch == 1) {
+        if (nch == 1) {
             sum = sellp_add<VT>(sum, p[0], 0, cb, sdict, x, sx);
         } else {
             for (int j = 0; j < nch; j += 2) {  // two records in flight; the second one clamped, not branched on

@@ -28,7 +28,8 @@ namespace lsqrhip {
 
 // Vq_i <- cy (Vq_i sy) + (R[0][i] + R[1][i] + ... + R[P-1][i])   (rank order); partials of sum (Vq ns)^2.
 // R[r] = slice q of rank r's T (what the all-to-all delivered), each `chunk` long; i < len <= chunk.
-__global__ __launch_bounds__(VEC_BLOCK) void k_rs_combine(double *__restrict__ Vq, const double *__restrict__ R,
+template <typename VT>
+__global__ __launch_bounds__(VEC_BLOCK) void k_rs_combine(VT *__restrict__ Vq, const VT *__restrict__ R,
                                                           int P, int64_t chunk, int64_t len,
                                                           const SpmvCoef *__restrict__ coef,
                                                           const int *__restrict__ stop,
@@ -40,11 +41,11 @@ __global__ __launch_bounds__(VEC_BLOCK) void k_rs_combine(double *__restrict__ V
     double s = 0.0;
     const int64_t stride = (int64_t)gridDim.x * VEC_BLOCK;
     for (int64_t i = (int64_t)blockIdx.x * VEC_BLOCK + threadIdx.x; i < len; i += stride) {
-        double t = R[i];
-        for (int r = 1; r < P; ++r) t = t + R[(int64_t)r * chunk + i];
-        const double v = cy * (Vq[i] * sy) + t;
+        double t = (double)R[i];
+        for (int r = 1; r < P; ++r) t = t + (double)R[(int64_t)r * chunk + i];
+        const VT v = (VT)(cy * ((double)Vq[i] * sy) + t);
         Vq[i] = v;
-        const double vs = v * nsc.s;
+        const double vs = (double)v * nsc.s;
         s += vs * vs;
     }
     const double tot = block_sum<VEC_BLOCK>(s, red);
@@ -67,8 +68,9 @@ __global__ __launch_bounds__(VEC_BLOCK) void k_sum_chunks(double *__restrict__ o
 // The x / w / se update on this rank's column slice (src/lsqr.f90:729-745 with the dscal of :697
 // folded in), gated by `live` (set by k_shard_s2 in the SAME iteration: the stop flag that k_shard_s3
 // raises afterwards must not hide the last update).  partials = sum of w_new^2 (next iteration's dknorm).
-__global__ __launch_bounds__(VEC_BLOCK) void k_update_slice(double *__restrict__ x, double *__restrict__ w,
-                                                            const double *__restrict__ Vq, double *__restrict__ se,
+template <typename VT>
+__global__ __launch_bounds__(VEC_BLOCK) void k_update_slice(VT *__restrict__ x, VT *__restrict__ w,
+                                                            const VT *__restrict__ Vq, VT *__restrict__ se,
                                                             int64_t len, const LsqrState *__restrict__ st,
                                                             const int *__restrict__ live,
                                                             double *__restrict__ partials)
@@ -80,22 +82,23 @@ __global__ __launch_bounds__(VEC_BLOCK) void k_update_slice(double *__restrict__
     double s = 0.0;
     const int64_t stride = (int64_t)gridDim.x * VEC_BLOCK;
     for (int64_t i = (int64_t)blockIdx.x * VEC_BLOCK + threadIdx.x; i < len; i += stride) {
-        const double t = w[i];
-        x[i] = t1 * t + x[i];
-        const double wn = t2 * t + Vq[i] * sv;
+        const double t = (double)w[i];
+        x[i] = (VT)(t1 * t + (double)x[i]);
+        const VT wn = (VT)(t2 * t + (double)Vq[i] * sv);
         w[i] = wn;
         if (wantse) {
             const double d = (t3 * t) * (t3 * t);
-            se[i] = d + se[i];
+            se[i] = (VT)(d + (double)se[i]);
         }
-        s += wn * wn;
+        s += (double)wn * (double)wn;
     }
     const double tot = block_sum<VEC_BLOCK>(s, red);
     if (threadIdx.x == 0) partials[blockIdx.x] = tot;
 }
 
 // w_q <- V_q sv (first w, src/lsqr.f90:641-644); partials of sum w_q^2
-__global__ __launch_bounds__(VEC_BLOCK) void k_init_w_slice(double *__restrict__ w, const double *__restrict__ Vq,
+template <typename VT>
+__global__ __launch_bounds__(VEC_BLOCK) void k_init_w_slice(VT *__restrict__ w, const VT *__restrict__ Vq,
                                                             int64_t len, const LsqrState *__restrict__ st,
                                                             double *__restrict__ partials)
 {
@@ -105,9 +108,9 @@ __global__ __launch_bounds__(VEC_BLOCK) void k_init_w_slice(double *__restrict__
     const int64_t stride = (int64_t)gridDim.x * VEC_BLOCK;
     if (st->stop == 0)
         for (int64_t i = (int64_t)blockIdx.x * VEC_BLOCK + threadIdx.x; i < len; i += stride) {
-            const double wn = Vq[i] * sv;
+            const VT wn = (VT)((double)Vq[i] * sv);
             w[i] = wn;
-            s += wn * wn;
+            s += (double)wn * (double)wn;
         }
     const double tot = block_sum<VEC_BLOCK>(s, red);
     if (threadIdx.x == 0) partials[blockIdx.x] = tot;
@@ -140,10 +143,11 @@ __global__ void k_shard_s2(const double *__restrict__ sums, LsqrState *st, int *
 
 // step 3 on all-reduced sums: dknorm^2 = t3^2 * sum of the previous w^2
 __global__ void k_shard_s3(const double *__restrict__ sums, LsqrState *st, const int *__restrict__ live,
-                           const double *__restrict__ x, double *__restrict__ log)
+                           const void *__restrict__ x, int f32, double *__restrict__ log)
 {
     if (*live == 0) return;
-    s3_step(st, (st->t3 * st->t3) * sums[1], x != nullptr ? x[0] : 0.0, log);
+    const double x1 = x == nullptr ? 0.0 : (f32 ? (double)static_cast<const float *>(x)[0] : static_cast<const double *>(x)[0]);
+    s3_step(st, (st->t3 * st->t3) * sums[1], x1, log);
 }
 
 }  // namespace lsqrhip
@@ -168,7 +172,6 @@ extern "C" int lsqrhip_shard_begin(lsqrhip_handle_t h, const double *d_b_local, 
     if (!d_T || !d_R || !d_V || !d_sums || (!d_b_local && h->m > 0)) return fail(LSQRHIP_ERR_ARG, "null shard buffer");
     if (world < 1 || rank < 0 || rank >= world) return fail(LSQRHIP_ERR_ARG, "bad world / rank");
     if (h->op || h->group) return fail(LSQRHIP_ERR_ARG, "the row-sharded stages need a matrix handle, not an operator or a sharded parent");
-    if (h->f32) return fail(LSQRHIP_ERR_ARG, "the row-sharded solve is binary64 only (not a REAL32 handle)");
     HIPCHK(hipSetDevice(h->device));
     hipStream_t s = h->stream;
     ShardCtx &c = h->shard;
@@ -198,27 +201,67 @@ extern "C" int lsqrhip_shard_begin(lsqrhip_handle_t h, const double *d_b_local, 
     init.cs2 = -1.0;
     init.su = init.sv = 1.0;
     init.ns_inv = h->nsc.inv;
+    init.wp32 = h->f32 ? 1 : 0;
     init.c1.skip = init.c2.skip = init.c2p.skip = 1;
     *h->h_state = init;
     HIPCHK(hipMemcpyAsync(h->d_state, h->h_state, sizeof(LsqrState), hipMemcpyHostToDevice, s));
+    // (a REAL32 handle: b, the exchange buffers T, R, V and the slices are float arrays -- half the bytes on the links)
+    const size_t esz = h->f32 ? sizeof(float) : sizeof(double);
     const size_t m = (size_t)h->m, full = (size_t)(c.chunk * world);
     const size_t sl = std::min((size_t)std::max<int64_t>(c.chunk, 0), (size_t)h->n);
-    if (m > 0) HIPCHK(hipMemcpyAsync(h->U, d_b_local, sizeof(double) * m, hipMemcpyDeviceToDevice, s));
+    if (m > 0) HIPCHK(hipMemcpyAsync(h->U, d_b_local, esz * m, hipMemcpyDeviceToDevice, s));
     if (full > 0) {
-        HIPCHK(hipMemsetAsync(c.V, 0, sizeof(double) * full, s));
-        HIPCHK(hipMemsetAsync(c.T, 0, sizeof(double) * full, s));
-        HIPCHK(hipMemsetAsync(c.R, 0, sizeof(double) * full, s));
+        HIPCHK(hipMemsetAsync(c.V, 0, esz * full, s));
+        HIPCHK(hipMemsetAsync(c.T, 0, esz * full, s));
+        HIPCHK(hipMemsetAsync(c.R, 0, esz * full, s));
     }
     if (sl > 0) {   // x_q, w_q, se_q live at the start of the handle's n-vectors
-        HIPCHK(hipMemsetAsync(h->X, 0, sizeof(double) * sl, s));
-        HIPCHK(hipMemsetAsync(h->W, 0, sizeof(double) * sl, s));
-        if (wantse) HIPCHK(hipMemsetAsync(h->SE, 0, sizeof(double) * sl, s));
+        HIPCHK(hipMemsetAsync(h->X, 0, esz * sl, s));
+        HIPCHK(hipMemsetAsync(h->W, 0, esz * sl, s));
+        if (wantse) HIPCHK(hipMemsetAsync(h->SE, 0, esz * sl, s));
     }
     HIPCHK(hipMemsetAsync(d_sums, 0, 4 * sizeof(double), s));
     HIPCHK(hipMemsetAsync(c.wsq, 0, sizeof(double), s));
     HIPCHK(hipMemsetAsync(c.live, 0, sizeof(int), s));
     c.active = true;
     return LSQRHIP_OK;
+}
+
+// the kernels of a stage that touch the vectors, for binary64 and REAL32 handles alike
+template <typename VT>
+static void shard_stage_vec(H *h, int stage)
+{
+    hipStream_t s = h->stream;
+    LsqrState *st = h->d_state;
+    ShardCtx &c = h->shard;
+    VT *Vq = reinterpret_cast<VT *>(c.V) + c.my0;
+    const VT *R = reinterpret_cast<const VT *>(c.R);
+    VT *X = reinterpret_cast<VT *>(h->X), *W = reinterpret_cast<VT *>(h->W), *SE = reinterpret_cast<VT *>(h->SE);
+    const int gq = vec_grid(2 * std::max<int64_t>(c.mylen, 1));
+    switch (stage) {
+    case ST_SUMSQ_B:
+        hipLaunchKernelGGL(k_sumsq3<VT>, dim3(h->vgrid_m), dim3(VEC_BLOCK), 0, s, (const VT *)reinterpret_cast<VT *>(h->U),
+                           (int64_t)h->m, h->partials);
+        break;
+    case ST_INIT_V:
+        hipLaunchKernelGGL(k_rs_combine<VT>, dim3(gq), dim3(VEC_BLOCK), 0, s, Vq, R, c.P, c.chunk, c.mylen,
+                           (const SpmvCoef *)&st->c2, (const int *)h->d_zero, h->partials, h->nsc);
+        break;
+    case ST_INIT_W:
+        hipLaunchKernelGGL(k_init_w_slice<VT>, dim3(gq), dim3(VEC_BLOCK), 0, s, W, (const VT *)Vq, c.mylen,
+                           (const LsqrState *)st, h->partials);
+        break;
+    case ST_VCOMBINE:
+        hipLaunchKernelGGL(k_rs_combine<VT>, dim3(gq), dim3(VEC_BLOCK), 0, s, Vq, R, c.P, c.chunk, c.mylen,
+                           (const SpmvCoef *)&st->c2, (const int *)&st->stop, h->partials, h->nsc);
+        break;
+    case ST_UPDATE:
+        hipLaunchKernelGGL(k_update_slice<VT>, dim3(gq), dim3(VEC_BLOCK), 0, s, X, W, (const VT *)Vq, SE, c.mylen,
+                           (const LsqrState *)st, (const int *)c.live, h->partials);
+        break;
+    default:
+        break;
+    }
 }
 
 // Enqueue one stage on the handle's stream (asynchronous).
@@ -229,13 +272,15 @@ extern "C" int lsqrhip_shard_stage(lsqrhip_handle_t h, int stage)
     hipStream_t s = h->stream;
     LsqrState *st = h->d_state;
     ShardCtx &c = h->shard;
-    double *T = c.T, *sums = c.sums;
-    double *Vq = c.V + c.my0;
-    const int64_t m = h->m;
+    double *T = c.T, *sums = c.sums;   // (T, V: float arrays in disguise for a REAL32 handle, like U, V, W, X)
     const int gq = vec_grid(2 * std::max<int64_t>(c.mylen, 1));
+    auto vec = [&](int st_) {
+        if (h->f32) shard_stage_vec<float>(h, st_);
+        else shard_stage_vec<double>(h, st_);
+    };
     switch (stage) {
     case ST_SUMSQ_B:
-        hipLaunchKernelGGL(k_sumsq3, dim3(h->vgrid_m), dim3(VEC_BLOCK), 0, s, (const double *)h->U, m, h->partials);
+        vec(stage);
         hipLaunchKernelGGL(k_reduce_partials3, dim3(1), dim3(VEC_BLOCK), 0, s, (const double *)h->partials,
                            h->vgrid_m, sums);
         break;
@@ -245,16 +290,14 @@ extern "C" int lsqrhip_shard_stage(lsqrhip_handle_t h, int stage)
         launch_spmv(h, h->AT, h->U, T, &st->c2p, h->d_zero, nullptr, nullptr, true);
         break;
     case ST_INIT_V:
-        hipLaunchKernelGGL(k_rs_combine, dim3(gq), dim3(VEC_BLOCK), 0, s, Vq, (const double *)c.R, c.P, c.chunk, c.mylen,
-                           (const SpmvCoef *)&st->c2, (const int *)h->d_zero, h->partials, h->nsc);
+        vec(stage);
         hipLaunchKernelGGL(k_shard_sums, dim3(1), dim3(VEC_BLOCK), 0, s, (const double *)h->partials, gq,
                            (const double *)c.wsq, sums, (const SpmvCoef *)&st->c2);
         break;
     case ST_INIT_W:
         hipLaunchKernelGGL((k_s_init2<false>), dim3(1), dim3(SC_BLOCK), 0, s, (const double *)h->partials, 0,
                            (const double *)sums, st);
-        hipLaunchKernelGGL(k_init_w_slice, dim3(gq), dim3(VEC_BLOCK), 0, s, h->W, (const double *)Vq, c.mylen,
-                           (const LsqrState *)st, h->partials);
+        vec(stage);
         hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(VEC_BLOCK), 0, s, (const double *)h->partials, gq, c.wsq);
         break;
     case ST_MODE1:
@@ -268,20 +311,18 @@ extern "C" int lsqrhip_shard_stage(lsqrhip_handle_t h, int stage)
         launch_spmv(h, h->AT, h->U, T, &st->c2p, &st->stop, nullptr, nullptr, true);
         break;
     case ST_VCOMBINE:
-        hipLaunchKernelGGL(k_rs_combine, dim3(gq), dim3(VEC_BLOCK), 0, s, Vq, (const double *)c.R, c.P, c.chunk, c.mylen,
-                           (const SpmvCoef *)&st->c2, (const int *)&st->stop, h->partials, h->nsc);
+        vec(stage);
         hipLaunchKernelGGL(k_shard_sums, dim3(1), dim3(VEC_BLOCK), 0, s, (const double *)h->partials, gq,
                            (const double *)c.wsq, sums, (const SpmvCoef *)&st->c2);
         break;
     case ST_UPDATE:
         hipLaunchKernelGGL(k_shard_s2, dim3(1), dim3(1), 0, s, (const double *)sums, st, c.live);
-        hipLaunchKernelGGL(k_update_slice, dim3(gq), dim3(VEC_BLOCK), 0, s, h->X, h->W, (const double *)Vq, h->SE,
-                           c.mylen, (const LsqrState *)st, (const int *)c.live, h->partials);
+        vec(stage);
         hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(VEC_BLOCK), 0, s, (const double *)h->partials, gq, c.wsq);
         // step 3 AFTER the update, as in the reference (src/lsqr.f90:729-745, then :751-837): the x(1) of the
         // iteration log is the updated one; both are gated by `live`, which step 2 set for this iteration
         hipLaunchKernelGGL(k_shard_s3, dim3(1), dim3(1), 0, s, (const double *)sums, st, (const int *)c.live,
-                           (const double *)h->X, h->d_log);
+                           (const void *)h->X, h->f32 ? 1 : 0, h->d_log);
         break;
     default:
         return fail(LSQRHIP_ERR_ARG, "unknown shard stage");
@@ -295,6 +336,7 @@ extern "C" int lsqrhip_shard_stage(lsqrhip_handle_t h, int stage)
 extern "C" int lsqrhip_sum_chunks(lsqrhip_handle_t h, const double *d_in, int nchunks, int64_t chunk, double *d_out)
 {
     if (!h || !d_in || !d_out || nchunks < 1 || chunk < 0) return fail(LSQRHIP_ERR_ARG, "bad sum_chunks arguments");
+    if (h->f32) return fail(LSQRHIP_ERR_ARG, "lsqrhip_sum_chunks sums binary64 vectors (not for a REAL32 handle)");
     HIPCHK(hipSetDevice(h->device));
     if (chunk > 0)
         hipLaunchKernelGGL(k_sum_chunks, dim3(vec_grid(2 * chunk)), dim3(VEC_BLOCK), 0, h->stream, d_out, d_in, nchunks,
@@ -326,12 +368,19 @@ extern "C" int lsqrhip_shard_end(lsqrhip_handle_t h, double *d_x, double *d_se, 
     hipStream_t s = h->stream;
     ShardCtx &c = h->shard;
     const size_t len = (size_t)std::max<int64_t>(c.mylen, 0);
-    if (c.wantse && len > 0)
-        hipLaunchKernelGGL(k_se_finish, dim3(vec_grid(2 * (int64_t)len)), dim3(VEC_BLOCK), 0, s, h->SE, (int64_t)len,
-                           (const LsqrState *)h->d_state);
-    if (d_x && len > 0) HIPCHK(hipMemcpyAsync(d_x + c.my0, h->X, sizeof(double) * len, hipMemcpyDeviceToDevice, s));
+    const size_t esz = h->f32 ? sizeof(float) : sizeof(double);
+    if (c.wantse && len > 0) {
+        if (h->f32)
+            hipLaunchKernelGGL(k_se_finish<float>, dim3(vec_grid(2 * (int64_t)len)), dim3(VEC_BLOCK), 0, s, (float *)h->SE,
+                               (int64_t)len, (const LsqrState *)h->d_state);
+        else
+            hipLaunchKernelGGL(k_se_finish<double>, dim3(vec_grid(2 * (int64_t)len)), dim3(VEC_BLOCK), 0, s, h->SE,
+                               (int64_t)len, (const LsqrState *)h->d_state);
+    }
+    if (d_x && len > 0)
+        HIPCHK(hipMemcpyAsync((char *)d_x + esz * (size_t)c.my0, h->X, esz * len, hipMemcpyDeviceToDevice, s));
     if (d_se && c.wantse && len > 0)
-        HIPCHK(hipMemcpyAsync(d_se + c.my0, h->SE, sizeof(double) * len, hipMemcpyDeviceToDevice, s));
+        HIPCHK(hipMemcpyAsync((char *)d_se + esz * (size_t)c.my0, h->SE, esz * len, hipMemcpyDeviceToDevice, s));
     HIPCHK(hipMemcpyAsync(h->h_state, h->d_state, sizeof(LsqrState), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     const LsqrState &r = *h->h_state;

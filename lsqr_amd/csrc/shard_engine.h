@@ -22,6 +22,7 @@
 #pragma once
 
 #include <dlfcn.h>
+#include <memory>
 #include <rccl/rccl.h>
 
 namespace lsqrhip {
@@ -100,6 +101,15 @@ static Rccl *rccl()
             return fail(LSQRHIP_ERR_HIP, std::string(#expr) + ": " + rccl()->GetErrorString(_r)); \
     } while (0)
 
+static int create_block(int m, int n, int64_t nnz, const int *irow, const int *icol, const double *a, lsqrhip_handle_t *h)
+{
+    return lsqrhip_create(m, n, nnz, irow, icol, a, h);
+}
+static int create_block(int m, int n, int64_t nnz, const int *irow, const int *icol, const float *a, lsqrhip_handle_t *h)
+{
+    return lsqrhip_create_f32(m, n, nnz, irow, icol, a, h);
+}
+
 struct ShardRank {
     H *h = nullptr;          // this rank's matrix handle (owned by the group when `owned`)
     int dev = -1;            // its device
@@ -114,6 +124,7 @@ struct ShardGroup {
     int P = 1;                     // world size
     int m = 0, n = 0;
     int64_t chunk = 0;
+    size_t esz = sizeof(double);   // bytes per vector element: 4 for REAL32 handles (T, R, V, x, se, b are float arrays then)
     std::vector<ShardRank> r;      // the ranks driven by this process
     bool owned = false;            // sub-handles belong to the group (single-process form)
     bool loopback = false;         // exchanges by device copies inside this process instead of RCCL (all ranks are local)
@@ -165,11 +176,12 @@ static int alloc_rank_buffers(ShardGroup &g, ShardRank &k)
 {
     k.dev = k.h->device;
     HIPCHK(hipSetDevice(k.h->device));
+    g.esz = k.h->f32 ? sizeof(float) : sizeof(double);
     const size_t full = (size_t)std::max<int64_t>(g.chunk * g.P, 1);
-    for (double **pp : {&k.T, &k.R, &k.V, &k.xfull, &k.sefull}) HIPCHK(hipMalloc((void **)pp, sizeof(double) * full));
+    for (double **pp : {&k.T, &k.R, &k.V, &k.xfull, &k.sefull}) HIPCHK(hipMalloc((void **)pp, g.esz * full));
     HIPCHK(hipMalloc((void **)&k.sums, sizeof(double) * 4));
     HIPCHK(hipMalloc((void **)&k.gath, sizeof(double) * 4 * (size_t)g.P));
-    HIPCHK(hipMalloc((void **)&k.bloc, sizeof(double) * (size_t)std::max(k.h->m, 1)));
+    HIPCHK(hipMalloc((void **)&k.bloc, g.esz * (size_t)std::max(k.h->m, 1)));
     return LSQRHIP_OK;
 }
 
@@ -199,13 +211,15 @@ static int fence_ranks(ShardGroup &g)  // every rank's stream waits for all that
     return LSQRHIP_OK;
 }
 
-static int loop_copy(ShardRank &dst, double *d, const double *s, size_t count)
+static int loop_copy(ShardRank &dst, void *d, const void *s, size_t bytes)
 {
-    if (!count) return LSQRHIP_OK;
+    if (!bytes) return LSQRHIP_OK;
     HIPCHK(hipSetDevice(dst.h->device));
-    HIPCHK(hipMemcpyAsync(d, s, sizeof(double) * count, hipMemcpyDeviceToDevice, dst.h->stream));
+    HIPCHK(hipMemcpyAsync(d, s, bytes, hipMemcpyDeviceToDevice, dst.h->stream));
     return LSQRHIP_OK;
 }
+// element i of a vector buffer (binary64 or REAL32 elements)
+static inline char *at(double *base, size_t i, size_t esz) { return reinterpret_cast<char *>(base) + i * esz; }
 
 // sums[0..k) <- sum over ranks, in rank order, same bits everywhere.  `with_v`: the in-place all-gather of the v
 // slices rides in the same RCCL group (one collective latency instead of two: after ST_VCOMBINE the slices are
@@ -214,12 +228,14 @@ static int ex_scalars(ShardGroup &g, int k, bool with_v = false)
 {
     Rccl *rc = rccl();
     const size_t c = (size_t)g.chunk;
+    const ncclDataType_t vtype = g.esz == sizeof(float) ? ncclFloat : ncclDouble;
     if (g.P > 1 && g.loopback) {
         RET(fence_ranks(g));
         for (ShardRank &q : g.r)
             for (ShardRank &p : g.r) {
-                RET(loop_copy(q, q.gath + 4 * (size_t)p.grank, p.sums, 4));
-                if (with_v && &p != &q) RET(loop_copy(q, q.V + (size_t)p.grank * c, p.V + (size_t)p.grank * c, c));
+                RET(loop_copy(q, q.gath + 4 * (size_t)p.grank, p.sums, 4 * sizeof(double)));
+                if (with_v && &p != &q)
+                    RET(loop_copy(q, at(q.V, (size_t)p.grank * c, g.esz), at(p.V, (size_t)p.grank * c, g.esz), c * g.esz));
             }
         RET(fence_ranks(g));
         for (ShardRank &q : g.r) {
@@ -233,7 +249,7 @@ static int ex_scalars(ShardGroup &g, int k, bool with_v = false)
         for (ShardRank &q : g.r) {
             NCCLCHK(rc->AllGather(q.sums, q.gath, 4, ncclDouble, q.comm, q.h->stream));
             if (with_v && c > 0)
-                NCCLCHK(rc->AllGather(q.V + (size_t)q.grank * c, q.V, c, ncclDouble, q.comm, q.h->stream));
+                NCCLCHK(rc->AllGather(at(q.V, (size_t)q.grank * c, g.esz), q.V, c, vtype, q.comm, q.h->stream));
         }
         NCCLCHK(rc->GroupEnd());
         for (ShardRank &q : g.r) {
@@ -247,30 +263,31 @@ static int ex_scalars(ShardGroup &g, int k, bool with_v = false)
 static int ex_scatter(ShardGroup &g)  // slice q of every rank's T -> rank q's R[rank]
 {
     Rccl *rc = rccl();
-    const size_t c = (size_t)g.chunk;
+    const size_t c = (size_t)g.chunk, e = g.esz;
+    const ncclDataType_t vtype = e == sizeof(float) ? ncclFloat : ncclDouble;
     if (g.P == 1 || c == 0) {
         for (ShardRank &q : g.r)
-            if (c) HIPCHK(hipMemcpyAsync(q.R, q.T, sizeof(double) * c, hipMemcpyDeviceToDevice, q.h->stream));
+            if (c) HIPCHK(hipMemcpyAsync(q.R, q.T, e * c, hipMemcpyDeviceToDevice, q.h->stream));
         return LSQRHIP_OK;
     }
     if (g.loopback) {
         RET(fence_ranks(g));
         for (ShardRank &q : g.r)
-            for (ShardRank &p : g.r) RET(loop_copy(q, q.R + (size_t)p.grank * c, p.T + (size_t)q.grank * c, c));
+            for (ShardRank &p : g.r) RET(loop_copy(q, at(q.R, (size_t)p.grank * c, e), at(p.T, (size_t)q.grank * c, e), c * e));
         return fence_ranks(g);
     }
     // the rank's own slice never leaves the device; the others go to their owners over all links at once
     for (ShardRank &q : g.r) {
         HIPCHK(hipSetDevice(q.h->device));
-        HIPCHK(hipMemcpyAsync(q.R + (size_t)q.grank * c, q.T + (size_t)q.grank * c, sizeof(double) * c,
+        HIPCHK(hipMemcpyAsync(at(q.R, (size_t)q.grank * c, e), at(q.T, (size_t)q.grank * c, e), e * c,
                               hipMemcpyDeviceToDevice, q.h->stream));
     }
     NCCLCHK(rc->GroupStart());
     for (ShardRank &q : g.r)
         for (int peer = 0; peer < g.P; ++peer) {
             if (peer == q.grank) continue;
-            NCCLCHK(rc->Send(q.T + (size_t)peer * c, c, ncclDouble, peer, q.comm, q.h->stream));
-            NCCLCHK(rc->Recv(q.R + (size_t)peer * c, c, ncclDouble, peer, q.comm, q.h->stream));
+            NCCLCHK(rc->Send(at(q.T, (size_t)peer * c, e), c, vtype, peer, q.comm, q.h->stream));
+            NCCLCHK(rc->Recv(at(q.R, (size_t)peer * c, e), c, vtype, peer, q.comm, q.h->stream));
         }
     NCCLCHK(rc->GroupEnd());
     return LSQRHIP_OK;
@@ -279,7 +296,8 @@ static int ex_scatter(ShardGroup &g)  // slice q of every rank's T -> rank q's R
 static int ex_gather(ShardGroup &g, bool x_too, bool se_too)  // in-place all-gather of the column slices
 {
     Rccl *rc = rccl();
-    const size_t c = (size_t)g.chunk;
+    const size_t c = (size_t)g.chunk, e = g.esz;
+    const ncclDataType_t vtype = e == sizeof(float) ? ncclFloat : ncclDouble;
     if (g.P == 1 || c == 0) return LSQRHIP_OK;
     if (g.loopback) {
         RET(fence_ranks(g));
@@ -287,17 +305,18 @@ static int ex_gather(ShardGroup &g, bool x_too, bool se_too)  // in-place all-ga
             for (ShardRank &p : g.r) {
                 if (&p == &q) continue;
                 const size_t o = (size_t)p.grank * c;
-                if (!x_too) RET(loop_copy(q, q.V + o, p.V + o, c));
-                if (x_too) RET(loop_copy(q, q.xfull + o, p.xfull + o, c));
-                if (se_too) RET(loop_copy(q, q.sefull + o, p.sefull + o, c));
+                if (!x_too) RET(loop_copy(q, at(q.V, o, e), at(p.V, o, e), c * e));
+                if (x_too) RET(loop_copy(q, at(q.xfull, o, e), at(p.xfull, o, e), c * e));
+                if (se_too) RET(loop_copy(q, at(q.sefull, o, e), at(p.sefull, o, e), c * e));
             }
         return fence_ranks(g);
     }
     NCCLCHK(rc->GroupStart());
     for (ShardRank &q : g.r) {
-        if (!x_too) NCCLCHK(rc->AllGather(q.V + (size_t)q.grank * c, q.V, c, ncclDouble, q.comm, q.h->stream));
-        if (x_too) NCCLCHK(rc->AllGather(q.xfull + (size_t)q.grank * c, q.xfull, c, ncclDouble, q.comm, q.h->stream));
-        if (se_too) NCCLCHK(rc->AllGather(q.sefull + (size_t)q.grank * c, q.sefull, c, ncclDouble, q.comm, q.h->stream));
+        const size_t o = (size_t)q.grank * c;
+        if (!x_too) NCCLCHK(rc->AllGather(at(q.V, o, e), q.V, c, vtype, q.comm, q.h->stream));
+        if (x_too) NCCLCHK(rc->AllGather(at(q.xfull, o, e), q.xfull, c, vtype, q.comm, q.h->stream));
+        if (se_too) NCCLCHK(rc->AllGather(at(q.sefull, o, e), q.sefull, c, vtype, q.comm, q.h->stream));
     }
     NCCLCHK(rc->GroupEnd());
     return LSQRHIP_OK;
@@ -471,8 +490,11 @@ static int agree_norm_exp(ShardGroup &g)
 // ---------------------------------------------------------------------------------------------------
 // one process, ngpu devices
 // ---------------------------------------------------------------------------------------------------
-extern "C" int lsqrhip_create_sharded(int m, int n, int64_t nnz, const int *irow, const int *icol, const double *a,
-                                      int ngpu, lsqrhip_handle_t *out)
+// AT = double: binary64 sub-handles (lsqrhip_create); AT = float: REAL32 sub-handles (lsqrhip_create_f32: real32
+// storage on the devices and real32 slices on the links, or binary64 with LSQRHIP_REAL32_MIXED=1)
+template <typename AT>
+static int create_sharded_T(int m, int n, int64_t nnz, const int *irow, const int *icol, const AT *a, int ngpu,
+                            lsqrhip_handle_t *out)
 {
     if (!out) return fail(LSQRHIP_ERR_ARG, "null handle pointer");
     *out = nullptr;
@@ -528,8 +550,10 @@ extern "C" int lsqrhip_create_sharded(int m, int n, int64_t nnz, const int *irow
         }
     // ... and ONE pass that files every triplet under its block, COO order kept inside each (the reference's
     // row sums are formed in that order, src/lsqr.f90:168-172): O(nnz) host work whatever ngpu is
-    std::vector<int> lr((size_t)std::max<int64_t>(nnz, 1)), lc((size_t)std::max<int64_t>(nnz, 1));
-    std::vector<double> la((size_t)std::max<int64_t>(nnz, 1));
+    // (uninitialised storage: value-initialising 16 bytes per nonzero first would cost as much as the pass itself)
+    const size_t cap = (size_t)std::max<int64_t>(nnz, 1);
+    std::unique_ptr<int[]> lr(new int[cap]), lc(new int[cap]);
+    std::unique_ptr<AT[]> la(new AT[cap]);
     {
         std::vector<int64_t> pos(first.begin(), first.end() - 1);
         for (int64_t k = 0; k < nnz; ++k) {
@@ -565,12 +589,12 @@ extern "C" int lsqrhip_create_sharded(int m, int n, int64_t nnz, const int *irow
         q.row0 = cut[(size_t)p];
         // the block's device, for this thread's create only (never through the process-wide selection)
         t_device_override = loopback ? dev0 + p % have : dev0 + p;
-        rc = lsqrhip_create(cut[(size_t)p + 1] - cut[(size_t)p], n, np, lr.data() + f, lc.data() + f, la.data() + f, &q.h);
+        rc = create_block(cut[(size_t)p + 1] - cut[(size_t)p], n, np, lr.get() + f, lc.get() + f, la.get() + f, &q.h);
         t_device_override = -1;
     }
-    lr.clear(); lr.shrink_to_fit();
-    lc.clear(); lc.shrink_to_fit();
-    la.clear(); la.shrink_to_fit();
+    lr.reset();
+    lc.reset();
+    la.reset();
     if (rc == LSQRHIP_OK)
         for (ShardRank &q : g->r)
             if ((rc = alloc_rank_buffers(*g, q)) != LSQRHIP_OK) break;
@@ -591,8 +615,22 @@ extern "C" int lsqrhip_create_sharded(int m, int n, int64_t nnz, const int *irow
         return rc;
     }
     (void)hipSetDevice(dev0);
+    h->io32 = sizeof(AT) == sizeof(float);
+    h->f32 = h->io32 && !g->r.empty() && g->r[0].h->f32;   // (false in the mixed mode: binary64 on the devices)
     *out = h;
     return LSQRHIP_OK;
+}
+
+extern "C" int lsqrhip_create_sharded(int m, int n, int64_t nnz, const int *irow, const int *icol, const double *a,
+                                      int ngpu, lsqrhip_handle_t *out)
+{
+    return create_sharded_T<double>(m, n, nnz, irow, icol, a, ngpu, out);
+}
+
+extern "C" int lsqrhip_create_sharded_f32(int m, int n, int64_t nnz, const int *irow, const int *icol, const float *a,
+                                          int ngpu, lsqrhip_handle_t *out)
+{
+    return create_sharded_T<float>(m, n, nnz, irow, icol, a, ngpu, out);
 }
 
 // lsqrhip_solve on a sharded handle: b is cut into the row blocks, x (se) come back whole.
@@ -605,36 +643,46 @@ static int solve_group_host(H *h, const double *b, double damp, double atol, dou
     if (wantse && !se) return fail(LSQRHIP_ERR_ARG, "wantse set but se is null");
     // the iteration log: rank 0 keeps the records (replicated scalars; x(1) is the first entry of its slice)
     for (ShardRank &q : g.r) q.h->shard.want_log = (want_log != 0 && &q == &g.r[0]) ? 1 : 0;
+    // (b, x, se: float arrays in disguise for a REAL32 group -- lsqrhip_solve_f32 -- like the vectors on the devices)
     for (ShardRank &q : g.r) {
         HIPCHK(hipSetDevice(q.h->device));
         if (q.h->m > 0)
-            HIPCHK(hipMemcpyAsync(q.bloc, b + q.row0, sizeof(double) * (size_t)q.h->m, hipMemcpyHostToDevice, q.h->stream));
+            HIPCHK(hipMemcpyAsync(q.bloc, reinterpret_cast<const char *>(b) + g.esz * (size_t)q.row0, g.esz * (size_t)q.h->m,
+                                  hipMemcpyHostToDevice, q.h->stream));
     }
     RET(run_group(g, damp, atol, btol, conlim, itnlim, wantse, istop, itn, anorm, acond, rnorm, arnorm, xnorm));
     ShardRank &q0 = g.r[0];
     HIPCHK(hipSetDevice(q0.h->device));
-    if (g.n > 0) HIPCHK(hipMemcpy(x, q0.xfull, sizeof(double) * (size_t)g.n, hipMemcpyDeviceToHost));
-    if (wantse && g.n > 0) HIPCHK(hipMemcpy(se, q0.sefull, sizeof(double) * (size_t)g.n, hipMemcpyDeviceToHost));
+    if (g.n > 0) HIPCHK(hipMemcpy(x, q0.xfull, g.esz * (size_t)g.n, hipMemcpyDeviceToHost));
+    if (wantse && g.n > 0) HIPCHK(hipMemcpy(se, q0.sefull, g.esz * (size_t)g.n, hipMemcpyDeviceToHost));
     return LSQRHIP_OK;
 }
 
 // lsqrhip_aprod on a sharded handle (host vectors): the blocks one after the other
-static int aprod_group_host(H *h, int mode, double *x, double *y)
+static int aprod_block(H *h, int mode, double *x, double *y) { return lsqrhip_aprod(h, mode, x, y); }
+static int aprod_block(H *h, int mode, float *x, float *y) { return lsqrhip_aprod_f32(h, mode, x, y); }
+
+template <typename VT>
+static int aprod_group_host_T(H *h, int mode, VT *x, VT *y)
 {
     ShardGroup &g = *h->group;
     if (mode == 1) {
-        for (ShardRank &q : g.r) RET(lsqrhip_aprod(q.h, 1, x, y + q.row0));
+        for (ShardRank &q : g.r) RET(aprod_block(q.h, 1, x, y + q.row0));
         return LSQRHIP_OK;
     }
-    std::vector<double> t((size_t)std::max(g.n, 1)), acc((size_t)std::max(g.n, 1), 0.0);
+    std::vector<VT> t((size_t)std::max(g.n, 1));
+    std::vector<double> acc((size_t)std::max(g.n, 1), 0.0);
     for (ShardRank &q : g.r) {   // x += sum_p A_p' y_p, partial products added in rank order
-        std::fill(t.begin(), t.end(), 0.0);
-        RET(lsqrhip_aprod(q.h, 2, t.data(), y + q.row0));
-        for (int j = 0; j < g.n; ++j) acc[(size_t)j] = &q == &g.r[0] ? t[(size_t)j] : acc[(size_t)j] + t[(size_t)j];
+        std::fill(t.begin(), t.end(), (VT)0);
+        RET(aprod_block(q.h, 2, t.data(), y + q.row0));
+        for (int j = 0; j < g.n; ++j)
+            acc[(size_t)j] = &q == &g.r[0] ? (double)t[(size_t)j] : acc[(size_t)j] + (double)t[(size_t)j];
     }
-    for (int j = 0; j < g.n; ++j) x[j] = x[j] + acc[(size_t)j];
+    for (int j = 0; j < g.n; ++j) x[j] = (VT)((double)x[j] + acc[(size_t)j]);
     return LSQRHIP_OK;
 }
+static int aprod_group_host(H *h, int mode, double *x, double *y) { return aprod_group_host_T<double>(h, mode, x, y); }
+static int aprod_group_host_f32(H *h, int mode, float *x, float *y) { return aprod_group_host_T<float>(h, mode, x, y); }
 
 // ---------------------------------------------------------------------------------------------------
 // one process per GPU
@@ -697,10 +745,10 @@ extern "C" int lsqrhip_shard_solve(lsqrhip_handle_t h, const double *d_b_local, 
     HIPCHK(hipSetDevice(h->device));
     if (h->m > 0) {
         if (!d_b_local) return fail(LSQRHIP_ERR_ARG, "null b");
-        HIPCHK(hipMemcpyAsync(q.bloc, d_b_local, sizeof(double) * (size_t)h->m, hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(q.bloc, d_b_local, g.esz * (size_t)h->m, hipMemcpyDeviceToDevice, h->stream));
     }
     RET(run_group(g, damp, atol, btol, conlim, itnlim, wantse, istop, itn, anorm, acond, rnorm, arnorm, xnorm));
-    if (d_x && g.n > 0) HIPCHK(hipMemcpy(d_x, q.xfull, sizeof(double) * (size_t)g.n, hipMemcpyDeviceToDevice));
-    if (d_se && wantse && g.n > 0) HIPCHK(hipMemcpy(d_se, q.sefull, sizeof(double) * (size_t)g.n, hipMemcpyDeviceToDevice));
+    if (d_x && g.n > 0) HIPCHK(hipMemcpy(d_x, q.xfull, g.esz * (size_t)g.n, hipMemcpyDeviceToDevice));
+    if (d_se && wantse && g.n > 0) HIPCHK(hipMemcpy(d_se, q.sefull, g.esz * (size_t)g.n, hipMemcpyDeviceToDevice));
     return LSQRHIP_OK;
 }

@@ -200,21 +200,18 @@ static void launch_xl(const SpmvArgs &a, double *z)
     else launch_xl_C<OffT, V8, false>(a, z);
 }
 
-// column-swept row blocks (csb.h).  A product on caller vectors first needs max|x| (the bound on
-// the products that fixes the binary grids of the exact sums); the solver's own vectors are unit.
+// column-swept row blocks (csb.h)
 template <typename VT>
 static void launch_csb(H *h, const SpmvArgs &a)
 {
     const Csr &c = *a.c;
     const VT *x = reinterpret_cast<const VT *>(a.x);
     VT *y = reinterpret_cast<VT *>(a.y);
-    CsbX xb{nullptr, 0};
-    if (!a.unit_x) {
-        const int g = vec_grid(2 * (int64_t)c.cols);
-        hipLaunchKernelGGL(k_amax<VT>, dim3(g), dim3(VEC_BLOCK), 0, a.stream, x, (int64_t)c.cols, h->xmax_part);
-        xb.xmax = h->xmax_part;
-        xb.nxmax = g;
-    }
+    // max|x| first (the bound on a row sum that fixes the grid of the exact sums, csb.h): one pass over the vector
+    // the product gathers from -- the solver's own vectors too (a bound from |x|_2 = 1 alone does not survive
+    // duplicate entries, and is the looser one besides)
+    CsbX xb{h->xmax_part, vec_grid(2 * (int64_t)c.cols)};
+    hipLaunchKernelGGL(k_amax<VT>, dim3(xb.nxmax), dim3(VEC_BLOCK), 0, a.stream, x, (int64_t)c.cols, h->xmax_part);
     // One launch per ROUND of row blocks (256 at a time, one per CU).  Every workgroup sweeps x from its
     // first to its last column; workgroups that start a sweep together stay close enough for the part of x
     // they gather from to sit in their XCD's L2, and a kernel boundary re-aligns them for the next round
@@ -223,7 +220,7 @@ static void launch_csb(H *h, const SpmvArgs &a)
     static const int rounds = env_int("LSQRHIP_CSB_ROUNDS", 1);
     const int S = std::max(c.S, 1);
     const int step = rounds ? std::max(1, c.grid / S) : std::max(c.nrb, 1);   // row blocks per launch
-    CsbMat A{c.cval, c.cidx, c.ccb, c.cptr, c.crs, c.nrb, c.R, c.rows, c.cols, c.e1, c.e2, 0, 0, S, c.zsplit, c.cbad,
+    CsbMat A{c.cval, c.cidx, c.ccb, c.cptr, c.crs, c.nrb, c.R, c.rows, c.cols, c.e1, 0, 0, S, c.zsplit, c.cbad,
              h->d_scalar + 3};
     for (int b0 = 0; b0 < c.nrb || b0 == 0; b0 += step) {
         const int b1 = std::min(c.nrb, b0 + step);

@@ -88,6 +88,15 @@ module lsqr_module
          type(c_ptr), intent(out) :: h
          integer(c_int) :: rc
       end function
+      function lsqrhip_create_sharded_f32(m, n, nnz, irow, icol, a, ngpu, h) bind(C, name='lsqrhip_create_sharded_f32') result(rc)
+         import :: c_int, c_int64_t, c_float, c_ptr
+         integer(c_int), value :: m, n, ngpu
+         integer(c_int64_t), value :: nnz
+         integer(c_int), intent(in) :: irow(*), icol(*)
+         real(c_float), intent(in) :: a(*)
+         type(c_ptr), intent(out) :: h
+         integer(c_int) :: rc
+      end function
       function lsqrhip_destroy(h) bind(C, name='lsqrhip_destroy') result(rc)
          import :: c_int, c_ptr
          type(c_ptr), value :: h
@@ -262,17 +271,22 @@ contains
          deallocate (ir, ic)
          allocate (ir(1), ic(1))
       end if
-      if (wp == c_float .and. .not. present(ngpu)) then
-         ! the REAL32 build: real32 storage on the device too (binary64 in registers only)
+      if (wp == c_float) then
+         ! the REAL32 build: real32 storage on the device(s) too, and on the links of a sharded solve
+         ! (binary64 in registers only)
          allocate (af(max(size(a), 1)))
          af(1:size(a)) = real(a, c_float)
-         call check(lsqrhip_create_f32(int(m, c_int), int(n, c_int), nz, ir, ic, af, me%handle))
+         if (present(ngpu)) then
+            call check(lsqrhip_create_sharded_f32(int(m, c_int), int(n, c_int), nz, ir, ic, af, int(ngpu, c_int), me%handle))
+            me%sharded = .true.
+         else
+            call check(lsqrhip_create_f32(int(m, c_int), int(n, c_int), nz, ir, ic, af, me%handle))
+         end if
          me%io32 = .true.
       else
          allocate (av(max(size(a), 1)))
          av(1:size(a)) = real(a, c_double)
          if (present(ngpu)) then
-            ! (the row-sharded solve is binary64 on the devices in either build)
             call check(lsqrhip_create_sharded(int(m, c_int), int(n, c_int), nz, ir, ic, av, int(ngpu, c_int), me%handle))
             me%sharded = .true.
          else

@@ -11,13 +11,25 @@ program test_real32
    integer, allocatable :: irow(:), icol(:)
    real(wp), allocatable :: a(:), b(:), x(:), se(:)
    real(wp) :: anorm, acond, rnorm, arnorm, xnorm
-   integer :: i, j, k, nnz, istop, itn
+   integer :: i, j, k, nnz, istop, itn, ngpu
+   character(len=32) :: arg
    type(lsqr_solver_ez) :: s
 
    if (kind(one) /= kind(1.0)) error stop 'TEST FAILED: this program must be built with -DREAL32'
+   ! usage: test_real32 [ngpu]   -- with ngpu: the same systems with their rows sharded over ngpu devices
+   ngpu = 0
+   if (command_argument_count() >= 1) then
+      call get_command_argument(1, arg)
+      read (arg, *) ngpu
+   end if
    ! README system (README.md:33-38 of the reference) in real32
-   call s%initialize(3, 3, real([1, 4, 7, 2, 5, 88, 3, 66, 9], wp), [1, 2, 3, 1, 2, 3, 1, 2, 3], &
-                     [1, 1, 1, 2, 2, 2, 3, 3, 3])
+   if (ngpu > 0) then
+      call s%initialize(3, 3, real([1, 4, 7, 2, 5, 88, 3, 66, 9], wp), [1, 2, 3, 1, 2, 3, 1, 2, 3], &
+                        [1, 1, 1, 2, 2, 2, 3, 3, 3], ngpu=ngpu)
+   else
+      call s%initialize(3, 3, real([1, 4, 7, 2, 5, 88, 3, 66, 9], wp), [1, 2, 3, 1, 2, 3, 1, 2, 3], &
+                        [1, 1, 1, 2, 2, 2, 3, 3, 3])
+   end if
    allocate (x(3))
    call s%solve(real([1, 2, 3], wp), zero, x, istop)
    write (*, '(A,I2,1P,3E16.8)') 'README32 istop,x=', istop, x
@@ -49,7 +61,11 @@ program test_real32
          b(k) = real(mod(7*k, 13), wp)*0.25_wp - 1.5_wp
       end do
    end do
-   call s%initialize(n, n, a(1:nnz), irow(1:nnz), icol(1:nnz), atol=1.0e-7_wp, btol=1.0e-7_wp, itnlim=500)
+   if (ngpu > 0) then
+      call s%initialize(n, n, a(1:nnz), irow(1:nnz), icol(1:nnz), atol=1.0e-7_wp, btol=1.0e-7_wp, itnlim=500, ngpu=ngpu)
+   else
+      call s%initialize(n, n, a(1:nnz), irow(1:nnz), icol(1:nnz), atol=1.0e-7_wp, btol=1.0e-7_wp, itnlim=500)
+   end if
    call s%solve(b, 0.0625_wp, x, istop, se=se, itn=itn, anorm=anorm, acond=acond, rnorm=rnorm, arnorm=arnorm, &
                 xnorm=xnorm)
    write (*, '(A,I2,A,I4)') 'STENCIL32 istop=', istop, ' itn=', itn

@@ -19,10 +19,10 @@ LIB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 
 NUM = r"[-+]?\d\.\d+E[-+]\d+"
 
 
-def run(exe, check=True, env=None):
+def run(exe, check=True, env=None, args=()):
     path = os.path.join(LIB, exe)
     assert os.path.exists(path), f"{path} missing: run __graft_entry__.build()"
-    return subprocess.run([path], capture_output=True, text=True, timeout=300, check=check,
+    return subprocess.run([path, *[str(a) for a in args]], capture_output=True, text=True, timeout=300, check=check,
                           env=None if env is None else {**os.environ, **env})
 
 
@@ -212,7 +212,7 @@ def test_fortran_device_operator_and_user_subclass_on_gpu():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["real32", "mixed"])
+@pytest.mark.parametrize("mode", ["real32", "mixed", "real32 sharded over 3 ranks", "mixed sharded over 3 ranks"])
 def test_real32_build_on_gpu(mode):
     """-DREAL32 build of the host layer (wp = real32 like the reference's REAL32 macro).
     "real32" (the default): real32 arrays in, out AND on the device (values, u, v, w, x, se), binary64
@@ -222,7 +222,12 @@ def test_real32_build_on_gpu(mode):
     reference compiled with -DREAL32 (tests/golden/real32_ref.json): agreement to what an all-real32
     iteration can hold, and never further from the binary64 answer than that reference is."""
     import json
-    out = run("test_real32", env={"LSQRHIP_REAL32_MIXED": "1" if mode == "mixed" else "0"}).stdout
+    # "... sharded": initialize(..., ngpu=3) of the same build (lsqrhip_create_sharded_f32; three ranks on this GPU
+    # through the loopback exchanges): real32 storage in every row block and on the links
+    sharded = "sharded" in mode
+    mode = mode.split()[0]
+    out = run("test_real32", env={"LSQRHIP_REAL32_MIXED": "1" if mode == "mixed" else "0",
+                                  "LSQRHIP_SHARD_LOOPBACK": "1" if sharded else "0"}, args=(3,) if sharded else ()).stdout
     assert "REAL32 TESTS PASSED" in out
     line = {l.split("=")[0].strip(): l for l in out.splitlines() if "=" in l}
     ref32 = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "real32_ref.json")))

@@ -243,6 +243,14 @@ def test_bench_distributed_leg_at_world_one_and_its_fallback(fail):
     assert line["n_gpus"] == 1 and line["steps"] == 12 and line["result"]["itn"] == 12
     assert line["config"]["engine"] == ("c++" if fail == "0" else "python")
     assert (line["config"]["engine_note"] is None) == (fail == "0")
+    # the N > 1 line carries everything the N = 1 line does: roofline with live PMC traffic of rank
+    # 0's block, and the reference's CPU path on a scaled-down instance of the same generator
+    from lsqr_amd import dist_bench
+    assert set(dist_bench.LINE_KEYS) <= set(line)
+    assert set(dist_bench.ROOFLINE_KEYS) <= set(line["roofline"]) and line["roofline"]["traffic"] is not None
+    assert line["roofline"]["traffic"] >= 0.9 * line["roofline"]["bytes_per_launch"]
+    assert set(dist_bench.CPU_BASELINE_KEYS) <= set(line["cpu_baseline"]) and line["cpu_baseline"]["value"] > 0
+    assert line["cpu_baseline"]["cores"] == 1 and line["cpu_baseline"]["kind"] in ("reference", "port")
 
 
 @pytest.mark.parametrize("csb", ["0", "1"])

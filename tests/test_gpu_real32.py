@@ -199,3 +199,71 @@ def test_log_records_of_a_real32_solve(env):
     # (records follow the reference's selective-print rule: the first and the last ten iterations here)
     assert rec.shape[0] == 21 and rec[0, 0] == 1 and rec[-1, 0] == itn.value
     assert abs(rec[-1, 1] - float(x[0])) <= EPS32 * abs(float(x[0]))   # x(1): the float value the device holds
+
+
+@pytest.mark.parametrize("ngpu", [1, 3])
+@pytest.mark.parametrize("name", ["random_over_damped", "random_over_se", "poisson_20x20_it50", "shuffled_dups",
+                                  "empty_rows_cols", "b_zero", "one_by_one"])
+def test_sharded_real32_handle(env, name, ngpu):
+    """lsqrhip_create_sharded_f32 (what `initialize(..., ngpu=)` of the -DREAL32 host layer binds): real32 storage
+    in every row block and real32 slices in both exchanges, binary64 registers -- through lsqrhip_solve_f32 /
+    lsqrhip_aprod_f32 with float host vectors, several ranks on this GPU (loopback).  Same bounds as the one-GPU
+    REAL32 handle: a product is off by the real32 rounding of the result (of each rank's partial result in mode
+    2), a solve follows the binary64 oracle to what rounding every vector once per iteration costs."""
+    os.environ["LSQRHIP_SHARD_LOOPBACK"] = "1"
+    try:
+        p, o = CASES[name]
+        a32, b32 = as32(p)
+        L = capi.lib()
+        h = C.c_void_p()
+        irow = np.ascontiguousarray(p.irow, np.int32)
+        icol = np.ascontiguousarray(p.icol, np.int32)
+        capi.check(L.lsqrhip_create_sharded_f32(p.m, p.n, a32.size, irow.ctypes.data, icol.ctypes.data, a32.ctypes.data,
+                                                ngpu, C.byref(h)))
+        try:
+            itn_lim = min(o["itnlim"], 25)
+            x, se = np.zeros(max(p.n, 1), np.float32), np.zeros(max(p.n, 1), np.float32)
+            istop, itn = C.c_int(), C.c_int()
+            sc = [C.c_double() for _ in range(5)]
+
+            def solve():
+                capi.check(L.lsqrhip_solve_f32(h, b32.ctypes.data, o["damp"], o["atol"], o["btol"], o["conlim"], itn_lim,
+                                               int(o["wantse"]), 0, x.ctypes.data, se.ctypes.data if o["wantse"] else None,
+                                               C.addressof(istop), C.addressof(itn), *[C.addressof(v) for v in sc]))
+                return x[:p.n].copy(), istop.value, itn.value, [v.value for v in sc]
+            xs, is_, it_, scal = solve()
+            g = oracle.port().solve(p.m, p.n, p.irow, p.icol, a32.astype(np.float64), b32.astype(np.float64),
+                                    damp=o["damp"], wantse=o["wantse"], atol=o["atol"], btol=o["btol"],
+                                    conlim=o["conlim"], itnlim=itn_lim)
+            assert it_ <= g.itn + 2
+            if it_ == g.itn:
+                assert is_ == g.istop
+            nx = np.linalg.norm(g.x)
+            assert np.linalg.norm(xs - g.x) <= 2e-4 * nx + 1e-30
+            if it_ == g.itn and g.itn > 0:
+                assert abs(scal[0] - g.anorm) <= 2e-4 * g.anorm and abs(scal[2] - g.rnorm) <= 2e-4 * g.rnorm + 1e-30
+                if o["wantse"]:
+                    assert np.linalg.norm(se[:p.n] - g.se) <= 2e-3 * np.linalg.norm(g.se) + 1e-30
+            xs2, is2, it2, scal2 = solve()               # repeats itself exactly
+            assert np.array_equal(xs2, xs) and (is2, it2, scal2) == (is_, it_, scal)
+            if p.nnz:
+                xp, yp = vecs32(p)
+                a64 = a32.astype(np.float64)
+                po = oracle.port()
+                y1 = po.aprod(1, p.m, p.n, p.irow, p.icol, a64, xp.astype(np.float64), yp.astype(np.float64))[1]
+                x2 = po.aprod(2, p.m, p.n, p.irow, p.icol, a64, xp.astype(np.float64), yp.astype(np.float64))[0]
+                xx, yy = xp.copy(), yp.copy()
+                capi.check(L.lsqrhip_aprod_f32(h, 1, xx.ctypes.data, yy.ctypes.data))
+                assert np.all(np.abs(yy.astype(np.float64) - y1) <= 0.5 * EPS32 * np.abs(y1) + 1e-11 * (1 + np.abs(y1).max()))
+                xx, yy = xp.copy(), yp.copy()
+                capi.check(L.lsqrhip_aprod_f32(h, 2, xx.ctypes.data, yy.ctypes.data))
+                assert np.all(np.abs(xx.astype(np.float64) - x2) <= (ngpu + 1) * EPS32 * np.abs(x2).max() + 1e-11)
+            # the binary64 entry points refuse it
+            b64, x64 = np.zeros(max(p.m, 1)), np.zeros(max(p.n, 1))
+            rc = L.lsqrhip_solve(h, b64.ctypes.data, 0.0, 0.0, 0.0, 0.0, 5, 0, 0, x64.ctypes.data, None,
+                                 C.addressof(istop), C.addressof(itn), *[C.addressof(v) for v in sc])
+            assert rc == capi.ERR_ARG
+        finally:
+            capi.check(L.lsqrhip_destroy(h))
+    finally:
+        os.environ.pop("LSQRHIP_SHARD_LOOPBACK", None)
