@@ -49,7 +49,7 @@ INFINITY_CACHE = 256 << 20
 HEADLINE = "poisson2d:1000:1000"
 HBM_INSTANCES = [("poisson2d:4000:4000", {}, "value dictionary (1-byte codes), 16-bit columns"),
                  ("poisson2d:4000:4000", {"LSQRHIP_VAL8": "0"}, "8-byte values, 16-bit columns")]
-PRODUCT_KERNELS = ("k_spmv_", "k_panel_combine")
+PRODUCT_KERNELS = ("k_spmv_", "k_panel_combine", "k_csb_combine", "k_csb_xmax")
 
 
 def parse():
@@ -293,7 +293,7 @@ def pmc_child(counter: str):
         reps = 10 if facts["nnz"] < 200_000_000 else 4
         s.bench_kernel(1, reps)
         manifest.append({"spec": spec, "env": env, "rows": rows, "launches": 3 + reps,
-                         "kernels_per_product": s.get_option("launches_mode1")})
+                         "kernels_per_product": s.get_option("dispatches_mode1")})
         del s, d_b
     print("PMC_MANIFEST " + json.dumps(manifest), flush=True)
 

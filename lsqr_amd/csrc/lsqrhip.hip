@@ -914,7 +914,8 @@ static int build_csb(hipStream_t s, const int *rowk, const int *colk, const doub
     out.grid = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)nrb * S, CSB_GRID));  // workgroups per launch
     out.out_grid = nrb;
     out.nblk = nrb;
-    out.bytes = (int64_t)nchunks * CSB_CHUNK * 12 + (int64_t)nchunks * 4 + (int64_t)(nrb + 1) * 8;
+    // (+ 8 bytes per column: the k_csb_xmax pass reads the gathered vector once more than the sweeps' "x once")
+    out.bytes = (int64_t)nchunks * CSB_CHUNK * 12 + (int64_t)nchunks * 4 + (int64_t)(nrb + 1) * 8 + (int64_t)cols * 8;
     return LSQRHIP_OK;
 }
 
@@ -1711,12 +1712,15 @@ extern "C" int lsqrhip_get_option(lsqrhip_handle_t h, const char *name, int64_t 
     else if (k == "pipeline") *value = h->pipeline;
     else if (k == "norm_exp") *value = h->norm_exp;
     else if (k == "log_truncated") *value = log_owner(h)->h_state ? log_owner(h)->h_state->log_truncated : 0;  // of the last solve
-    else if (k == "launches_mode1" || k == "launches_mode2") {  // kernel launches one product takes (profiling)
-        const Csr &c = k == "launches_mode1" ? h->A : h->AT;
+    else if (k == "launches_mode1" || k == "launches_mode2" || k == "dispatches_mode1" || k == "dispatches_mode2") {
+        // launches_*: launches of the product's main kernel (+ its combine kernel) -- what rocprofv3's per-kernel
+        // average is divided over; dispatches_*: every kernel one product enqueues (the max|x| pass of csb.h too)
+        const Csr &c = (k == "launches_mode1" || k == "dispatches_mode1") ? h->A : h->AT;
+        const bool all = k[0] == 'd';
         static const int rounds = env_int("LSQRHIP_CSB_ROUNDS", 1);
         if (c.csb) {
             const int step = std::max(1, c.grid / std::max(c.S, 1));
-            *value = (rounds ? std::max(1, (c.nrb + step - 1) / step) : 1) + (c.S > 1 ? 1 : 0);
+            *value = (all ? 1 : 0) + (rounds ? std::max(1, (c.nrb + step - 1) / step) : 1) + (c.S > 1 ? 1 : 0);
         }
         else *value = c.P > 1 ? 2 : 1;
     } else if (k == "csb_blocks_mode1" || k == "csb_blocks_mode2") {  // row blocks of a column-swept layout (0: another layout)

@@ -211,7 +211,7 @@ static void launch_csb(H *h, const SpmvArgs &a)
     // the product gathers from -- the solver's own vectors too (a bound from |x|_2 = 1 alone does not survive
     // duplicate entries, and is the looser one besides)
     CsbX xb{h->xmax_part, vec_grid(2 * (int64_t)c.cols)};
-    hipLaunchKernelGGL(k_amax<VT>, dim3(xb.nxmax), dim3(VEC_BLOCK), 0, a.stream, x, (int64_t)c.cols, h->xmax_part);
+    hipLaunchKernelGGL(k_csb_xmax<VT>, dim3(xb.nxmax), dim3(VEC_BLOCK), 0, a.stream, x, (int64_t)c.cols, h->xmax_part);
     // One launch per ROUND of row blocks (256 at a time, one per CU).  Every workgroup sweeps x from its
     // first to its last column; workgroups that start a sweep together stay close enough for the part of x
     // they gather from to sit in their XCD's L2, and a kernel boundary re-aligns them for the next round

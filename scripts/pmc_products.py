@@ -8,7 +8,7 @@ spec = sys.argv[1]
 dp = devgen.generate(spec)
 s = dp.solver
 g = s.get_option
-print("LAYOUT", spec, "launches", g("launches_mode1"), g("launches_mode2"), "blocks", g("csb_blocks_mode1"),
+print("LAYOUT", spec, "launches", g("dispatches_mode1"), g("dispatches_mode2"), "blocks", g("csb_blocks_mode1"),
       g("csb_blocks_mode2"), "splits", g("csb_splits_mode1"), g("csb_splits_mode2"), "bytes", s.info()["csr_bytes"],
       s.info()["csrt_bytes"], flush=True)
 t1 = s.bench_kernel(1, 10)

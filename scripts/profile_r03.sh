@@ -54,7 +54,7 @@ roof() {   # tag, env assignment or "-", workload
     [ -n "$f" ] && python3 - "$f" <<'PY'
 import csv, sys
 for r in csv.DictReader(open(sys.argv[1])):
-    if "k_spmv_" in r.get("Name", "") or "k_panel_combine" in r.get("Name", "") or "k_csb_combine" in r.get("Name", ""):
+    if any(k in r.get("Name", "") for k in ("k_spmv_", "k_panel_combine", "k_csb_combine", "k_csb_xmax")):
         print("%-110s calls=%6s total_ns=%13s avg_ns=%12s" % (r["Name"][:110], r.get("Calls"), r.get("TotalDurationNs"), r.get("AverageNs")))
 PY
   } > "$OUT/${tag}_roofline.txt"
