@@ -832,7 +832,9 @@ static int build_csb(hipStream_t s, const int *rowk, const int *colk, const doub
     } else {
         for (;; --S) {       // column splits: 256 / S blocks, one unit per CU and no second pass
             if (S <= 1) break;
-            const int nb = std::max(1, CSB_GRID / S);
+            int nb = std::max(1, CSB_GRID / S);
+            if (s_forced)    // (test / experiment hook: as many rounds of 256 / S blocks as the rows need)
+                nb *= (int)std::max<int64_t>(1, ((int64_t)rows + (int64_t)nb * rfill - 1) / ((int64_t)nb * rfill));
             if ((int64_t)nb * rmax < rows) continue;
             rstart = cut(nb, rmax, false);
             if ((int)rstart.size() - 1 <= nb || s_forced) break;
