@@ -817,38 +817,38 @@ static int build_csb(hipStream_t s, const int *rowk, const int *colk, const doub
         return rs;
     };
     const int rfill = even_rows ? (int)(0.97 * rmax) : (int)(0.9 * rmax);
+    // rounds of 256 / S blocks: the fewest for which the cut by nonzeros stays within them
+    auto cut_rounds = [&](int S_, std::vector<int> &rs) {
+        const int per_round = std::max(1, CSB_GRID / S_);
+        const int kmin = (int)std::max<int64_t>(1, ((int64_t)rows + (int64_t)per_round * rmax - 1) / ((int64_t)per_round * rmax));
+        for (int k = kmin;; ++k) {
+            // (small systems: a few whole blocks of >= 512 rows rather than 256 slivers)
+            const int nb = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)per_round * k, ((int64_t)rows + 511) / 512));
+            rs = cut(nb, rmax, false);
+            if ((int)rs.size() - 1 <= per_round * k || k >= kmin + 4) return;
+        }
+    };
     int S = env_int("LSQRHIP_CSB_S", 0);
-    const bool s_forced = S > 0;
-    if (!s_forced) {
-        S = (int)std::min<int64_t>(8, std::max<int64_t>(1, (int64_t)rfill * CSB_GRID / std::max(rows, 1)));
-        if ((int64_t)rows * S < (int64_t)CSB_GRID * 512) S = 1;   // small systems: not worth a second launch
-    }
-    S = std::min(S, 8);
     std::vector<int> rstart;
     const int r_forced = env_int("LSQRHIP_CSB_R", 0);
+    if (S > 0) {
+        S = std::min(S, 8);
+    } else {
+        // few rows: as many splits as keep one round of blocks tall
+        S = (int)std::min<int64_t>(8, std::max<int64_t>(1, (int64_t)rfill * CSB_GRID / std::max(rows, 1)));
+        if ((int64_t)rows * S < (int64_t)CSB_GRID * 512) S = 1;   // small systems: not worth a second launch
+        // many rows (two rounds or more anyway) over an x far beyond L2: 4 splits -- every XCD then sweeps a quarter
+        // of x per launch (split = unit mod 4, XCD = unit mod 8), its workgroups drift a quarter as far apart and far
+        // fewer of their gathers miss L2.  Config 4 (profiles/r03/csb_column_splits.txt): 3.90 / 3.95 ms -> 3.53 / 3.53
+        // (S = 2: 3.44 / 3.46, S = 8: 3.79 / 3.73), PMC fetch 25 GB -> 16.4 GB for 12.3 GB of layout.  Not for
+        // one-round matrices (config 5: 0.39 -> 0.48 / 0.50 ms with 2 / 4 splits).
+        if (S == 1 && (int64_t)rows > (int64_t)CSB_GRID * rmax && (int64_t)cols * 8 > (32ll << 20)) S = 4;
+    }
     if (r_forced > 0 || nnz <= 0) {
         const int R = std::min(std::max(r_forced > 0 ? r_forced : rmax, 1), rmax);
         rstart = cut(0, R, true);
     } else {
-        for (;; --S) {       // column splits: 256 / S blocks, one unit per CU and no second pass
-            if (S <= 1) break;
-            int nb = std::max(1, CSB_GRID / S);
-            if (s_forced)    // (test / experiment hook: as many rounds of 256 / S blocks as the rows need)
-                nb *= (int)std::max<int64_t>(1, ((int64_t)rows + (int64_t)nb * rfill - 1) / ((int64_t)nb * rfill));
-            if ((int64_t)nb * rmax < rows) continue;
-            rstart = cut(nb, rmax, false);
-            if ((int)rstart.size() - 1 <= nb || s_forced) break;
-        }
-        if (S <= 1) {
-            S = 1;
-            const int kmin = (int)std::max<int64_t>(1, ((int64_t)rows + (int64_t)CSB_GRID * rmax - 1) / ((int64_t)CSB_GRID * rmax));
-            for (int k = kmin;; ++k) {
-                // (small systems: a few whole blocks of >= 512 rows rather than 256 slivers)
-                const int nb = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)CSB_GRID * k, ((int64_t)rows + 511) / 512));
-                rstart = cut(nb, rmax, false);
-                if ((int)rstart.size() - 1 <= CSB_GRID * k || k >= kmin + 4) break;
-            }
-        }
+        cut_rounds(S, rstart);
     }
     cnt.clear();
     cnt.shrink_to_fit();
