@@ -365,3 +365,52 @@ def test_captured_batches_and_eager_launches_agree_bitwise(loopback, ngpu):
             res[mode] = a
         assert np.array_equal(res["0"][0], res[None][0]) and res["0"][2:] == res[None][2:]
         assert res[None][3] == itnlim
+
+
+def test_entry_points_that_need_one_device_refuse_a_sharded_handle(loopback):
+    """The parent handle of a sharded system owns no work vectors of its own: the BLAS-1, acheck / xcheck, kernel
+    timing and stage entry points must say so (ERR_ARG) instead of launching kernels on null pointers; the
+    ordinary solve / aprod / info / log entry points work on it."""
+    p, o = CASES["random_over_damped"]
+    h = sharded_handle(p, 2)
+    try:
+        L = lib()
+        d = capi.DeviceBuffer(8 * 16)
+        res = C.c_double()
+        assert L.lsqrhip_dnrm2(h, 16, d.ptr, C.byref(res)) == capi.ERR_ARG
+        assert L.lsqrhip_ddot(h, 16, d.ptr, d.ptr, C.byref(res)) == capi.ERR_ARG
+        assert L.lsqrhip_dscal(h, 16, C.c_double(2.0), d.ptr) == capi.ERR_ARG
+        assert L.lsqrhip_dcopy(h, 16, d.ptr, d.ptr) == capi.ERR_ARG
+        inform = C.c_int()
+        assert L.lsqrhip_acheck(h, C.c_double(1e-16), C.byref(inform), C.byref(res)) == capi.ERR_ARG
+        ms = C.c_double()
+        assert L.lsqrhip_bench_kernel(h, 1, 1, C.byref(ms)) == capi.ERR_ARG
+        assert L.lsqrhip_shard_begin(h, d.ptr, p.m, 1, 0, C.c_double(0), C.c_double(0), C.c_double(0), C.c_double(0), 5, 0,
+                                     d.ptr, d.ptr, d.ptr, d.ptr) == capi.ERR_ARG
+        # ... and joining a world twice is refused too (the first group would leak)
+        x = solve_handle(h, p, o)[0]
+        assert np.all(np.isfinite(x))
+    finally:
+        check(lib().lsqrhip_destroy(h))
+    s = lsqr_solver_ez().initialize(p.m, p.n, p.a, p.irow, p.icol, itnlim=5)
+    check(lib().lsqrhip_shard_comm_init(s._h, 1, 0, 0, p.m, None))
+    assert lib().lsqrhip_shard_comm_init(s._h, 1, 0, 0, p.m, None) == capi.ERR_ARG
+
+
+def test_sharded_blocks_start_at_the_selected_device_and_must_fit_the_node():
+    """Row block k of a sharded handle goes to device (selected + k): asking for more blocks than there are
+    devices FROM the selected one on fails before any work is done (no loopback here: real devices)."""
+    import torch
+    have = torch.cuda.device_count()
+    p, o = CASES["random_over_damped"]
+    irow = np.ascontiguousarray(p.irow, np.int32)
+    icol = np.ascontiguousarray(p.icol, np.int32)
+    a = np.ascontiguousarray(p.a, np.float64)
+    h = C.c_void_p()
+    check(lib().lsqrhip_set_device(have - 1))
+    try:
+        rc = lib().lsqrhip_create_sharded(p.m, p.n, a.size, irow.ctypes.data, icol.ctypes.data, a.ctypes.data, 2, C.byref(h))
+        assert rc == capi.ERR_NO_DEVICE and not h.value
+        assert b"selected device" in lib().lsqrhip_last_error() or have < 2
+    finally:
+        check(lib().lsqrhip_set_device(0))
