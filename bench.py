@@ -403,7 +403,7 @@ def run_single(args):
         "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"{facts['name']} m={facts['m']} n={facts['n']} nnz={facts['nnz']} "
                                f"damp={facts['damp']}{cfgname}",
-                   "graph_iters": gi, "device_loop_ms": loop_ms, "restarts": restarts},
+                   "graph_iters": gi, "restarts": restarts},
         "result": {"istop": r.istop, "itn": r.itn, "anorm": r.anorm, "rnorm": r.rnorm},
     }
     if not args.no_roofline:

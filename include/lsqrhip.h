@@ -181,7 +181,8 @@ int lsqrhip_dcopy(lsqrhip_handle_t h, int64_t n, const double *d_x, double *d_y)
 /* ---------------------------------------------------------------------- */
 typedef struct {
     double solve_ms;      /* whole lsqrhip_solve* call, host clock                     */
-    double loop_ms;       /* device time of the iteration loop (HIP events)            */
+    double loop_ms;       /* device time of the iteration loop (HIP events): option
+                             "loop_events" or "time_kernels", 0 otherwise               */
     double spmv1_ms;      /* summed device time of the mode-1 SpMV kernel launches     */
     double spmv2_ms;      /* summed device time of the mode-2 SpMV kernel launches     */
     double update_ms;     /* summed device time of the x/w update kernel launches      */
@@ -235,7 +236,8 @@ int lsqrhip_lstp_vectors(lsqrhip_handle_t h, double *xtrue, double *b, double *d
  * "poll_ahead" (1 [default] = with graphs, the next batch is enqueued before the host waits
  * for the current one's stop flag, so the poll and the graph launch overlap device work; a
  * solve that stops inside batch k then runs batch k+1 as no-op launches; 0 = strict
- * launch-wait-check). */
+ * launch-wait-check), "loop_events" (1 = two HIP events around the iteration loop fill
+ * timing.loop_ms; default 0: the records cost a short solve 8-9 us). */
 int lsqrhip_set_option(lsqrhip_handle_t h, const char *name, int64_t value);
 /* Reads an option back.  Besides the above: "norm_exp" -- the fused in-loop norms (dnrm2,
  * src/lsqrblas.f90:123-159) are sqrt(sum (y 2^-e)^2) 2^e with e = norm_exp fixed per matrix

@@ -228,6 +228,8 @@ struct lsqrhip_handle_s {
     // options
     int use_graph = 1, graph_iters = 64, time_kernels = 0;
     int poll_ahead = 1;  // enqueue the next graph batch before waiting on the current one
+    bool loop_bracketed = false;  // the last solve recorded ev_loop0 / ev_loop1
+    int loop_events = 0;  // HIP events around the iteration loop: timing.loop_ms (0 without them)
     hipEvent_t ev_batch[2] = {nullptr, nullptr};
     hipGraphExec_t gexec = nullptr;
     hipGraphExec_t gexec_first = nullptr;  // the start of a solve (state upload, memsets, the five initial kernels) + the first batch
@@ -1172,6 +1174,7 @@ static int new_handle(int m, int n, int64_t nnz, H **out)
     if (nnz >= (1ll << 32)) return fail(LSQRHIP_ERR_TOO_LARGE, lsqrhip_error_string(LSQRHIP_ERR_TOO_LARGE));
     RET(use_device());
     H *h = new H();
+    h->loop_events = env_int("LSQRHIP_LOOP_EVENTS", h->loop_events);
     h->device = target_device();
     h->m = m;
     h->n = n;
@@ -1684,6 +1687,7 @@ extern "C" int lsqrhip_set_option(lsqrhip_handle_t h, const char *name, int64_t 
         h->graph_iters = (int)value;
     } else if (k == "time_kernels") h->time_kernels = value != 0;
     else if (k == "poll_ahead") h->poll_ahead = value != 0;
+    else if (k == "loop_events") h->loop_events = value != 0;
     else if (k == "op_batch") h->op_batch = value < 1 ? 1 : (int)value;
     else if (k == "pipeline") h->pipeline = value < 0 ? 0 : (value > 2 ? 2 : (int)value);
     else if (k == "shard_log") h->shard.want_log = value != 0;   // (rank 0 of a one-process-per-GPU world)
@@ -1710,6 +1714,7 @@ extern "C" int lsqrhip_get_option(lsqrhip_handle_t h, const char *name, int64_t 
     else if (k == "graph_iters") *value = h->graph_iters;
     else if (k == "time_kernels") *value = h->time_kernels;
     else if (k == "poll_ahead") *value = h->poll_ahead;
+    else if (k == "loop_events") *value = h->loop_events;
     else if (k == "op_batch") *value = h->op_batch;
     else if (k == "pipeline") *value = h->pipeline;
     else if (k == "norm_exp") *value = h->norm_exp;

@@ -118,6 +118,7 @@ static int solve_op(H *h, const double *b, bool b_on_device, double damp, double
     // Iterations enqueued ahead of each poll: the callbacks past the stopping iteration still
     // run (on zero vectors), so keep the batch short.
     const int G = std::max(1, h->op_batch);
+    h->loop_bracketed = true;
     HIPCHK(hipEventRecord(h->ev_loop0, s));
     const int64_t max_batches = (int64_t)std::max(itnlim, 0) / G + 2;
     for (int64_t batch = 0;; ++batch) {

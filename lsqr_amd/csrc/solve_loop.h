@@ -527,16 +527,19 @@ static int enqueue_solve_start(H *h, int wantse, bool lean)
     hipStream_t s = h->stream;
     const int m = h->m, n = h->n;
     LsqrState *st = h->d_state;
+    // (fewer, looping workgroups for k_start -- fewer reads of the slot across PCIe -- change nothing: 128 ... 1024
+    // workgroups against 1954 at config 2, profiles/r03/perf_misc.txt)
+    const int sg = h->vgrid_m;
     const int g = std::max(h->vgrid_m, h->vgrid_n);
     if (h->f32)
         hipLaunchKernelGGL(k_start<float>, dim3(g), dim3(VEC_BLOCK), 0, s, (const void *const *)h->h_bslot, (float *)h->U,
-                           (int64_t)m, h->vgrid_m, (float *)h->V, (float *)h->X, (float *)nullptr,
+                           (int64_t)m, sg, (float *)h->V, (float *)h->X, (float *)nullptr,
                            wantse ? (float *)h->SE : (float *)nullptr, (int64_t)n, h->partials);
     else
         hipLaunchKernelGGL(k_start<double>, dim3(g), dim3(VEC_BLOCK), 0, s, (const void *const *)h->h_bslot, h->U,
-                           (int64_t)m, h->vgrid_m, h->V, h->X, (double *)nullptr, wantse ? h->SE : (double *)nullptr,
+                           (int64_t)m, sg, h->V, h->X, (double *)nullptr, wantse ? h->SE : (double *)nullptr,
                            (int64_t)n, h->partials);
-    hipLaunchKernelGGL(k_s_init1<true>, dim3(1), dim3(SC_BLOCK), 0, s, (const double *)h->partials, h->vgrid_m,
+    hipLaunchKernelGGL(k_s_init1<true>, dim3(1), dim3(SC_BLOCK), 0, s, (const double *)h->partials, sg,
                        (const double *)nullptr, st, h->slots + 2, (const LsqrState *)h->h_state);
     {
         SpmvArgs a;
@@ -559,6 +562,8 @@ static int enqueue_solve_start(H *h, int wantse, bool lean)
 // Two graphs: a batch of G iterations, and the same batch preceded by the start of a solve -- a solve of
 // up to G iterations is then ONE graph launch (a dozen eager calls at ~3.5 us each with the GPU idle
 // behind them were 8 % of a 20-iteration solve at config 2).
+// (Launching the start kernels as plain launches ahead of the first graph, so that the GPU works while the host is
+// inside hipGraphLaunch, changes nothing: 565.6 against 565.9 us per 20-iteration solve, profiles/r03/perf_misc.txt.)
 static int capture_graph(H *h, int G, bool with_start, int wantse, hipGraphExec_t *out)
 {
     hipGraph_t g = nullptr;
@@ -696,8 +701,8 @@ static int finish_solve(H *h, int wantse, int want_log, double *x, double *se, b
         HIPCHK(hipMemcpyAsync(h->h_log.data(), h->d_log, sizeof(double) * h->h_log.size(), hipMemcpyDeviceToHost, s));
     }
     if (need_sync) HIPCHK(hipStreamSynchronize(s));
-    float loop_ms = 0;
-    (void)hipEventElapsedTime(&loop_ms, h->ev_loop0, h->ev_loop1);
+    float loop_ms = 0;   // (0 when the loop was not bracketed by events: option loop_events)
+    if (h->loop_bracketed) (void)hipEventElapsedTime(&loop_ms, h->ev_loop0, h->ev_loop1);
     tm.loop_ms = loop_ms;
     tm.itn = r.itn;
     if (!timed) tm.spmv1_launches = tm.spmv2_launches = tm.update_launches = r.itn;
@@ -779,7 +784,11 @@ static int solve_core(H *h, const double *b, bool b_on_device, double damp, doub
         h->ev.resize(6 * (size_t)G);
         for (size_t k = old; k < h->ev.size(); ++k) HIPCHK(hipEventCreate(&h->ev[k]));
     }
-    HIPCHK(hipEventRecord(h->ev_loop0, s));
+    // HIP events around the loop (timing.loop_ms) only on request: the two records cost a 20-iteration solve at
+    // config 2 8-9 us of its 566 (profiles/r03/perf_misc.txt)
+    const bool loop_events = h->loop_events != 0 || timed;
+    h->loop_bracketed = loop_events;
+    if (loop_events) HIPCHK(hipEventRecord(h->ev_loop0, s));
     // S3 raises `stop` at itn == itnlim at the latest; anything beyond this many batches
     // means the device loop is not advancing (never spin on a dead stream).
     const int64_t max_batches = (int64_t)std::max(itnlim, 0) / G + 2;
@@ -796,7 +805,7 @@ static int solve_core(H *h, const double *b, bool b_on_device, double damp, doub
             if (!h->pipeline)
                 HIPCHK(hipMemcpyAsync(h->h_state + 1 + (k & 1), st, sizeof(LsqrState), hipMemcpyDeviceToHost, s));
             if ((k + 1) * G >= (int64_t)itnlim) {   // no batch can follow this one
-                HIPCHK(hipEventRecord(h->ev_loop1, s));
+                if (loop_events) HIPCHK(hipEventRecord(h->ev_loop1, s));
                 loop1 = true;
                 if (!dev_out) {
                     RET(enqueue_outputs(h, wantse, x, se, out_on_device));
@@ -821,7 +830,7 @@ static int solve_core(H *h, const double *b, bool b_on_device, double damp, doub
         // the settled state: the snapshot taken behind the stopping batch (a batch enqueued past the stop
         // returns at its stop-flag tests and has not touched it)
         *h->h_state = h->h_state[1 + (stopped_in & 1)];
-        if (!loop1) HIPCHK(hipEventRecord(h->ev_loop1, s));
+        if (!loop1 && loop_events) HIPCHK(hipEventRecord(h->ev_loop1, s));
         if (dev_out)   // x was copied by the batch whose snapshot showed the stop, and that batch's event has been
                        // waited for; a batch enqueued behind it (look-ahead) repeats the copy: wait for that one too
             return finish_solve(h, wantse, want_log, x, se, out_on_device, istop, itn, anorm, acond, rnorm, arnorm,
@@ -863,7 +872,7 @@ static int solve_core(H *h, const double *b, bool b_on_device, double damp, doub
             if (h->h_state->stop != 0) break;
         }
     }
-    HIPCHK(hipEventRecord(h->ev_loop1, s));
+    if (loop_events) HIPCHK(hipEventRecord(h->ev_loop1, s));
 
     return finish_solve(h, wantse, want_log, x, se, out_on_device, istop, itn, anorm, acond, rnorm, arnorm, xnorm,
                         timed, t_host0);
