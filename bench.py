@@ -20,7 +20,7 @@ The ONE JSON line (rank 0) carries, for the dominant kernel (aprod mode 1):
                     WRITE_SIZE in passes of their own, FETCH_SIZE x2 on gfx950); `effective_gbps` = the
                     SURVEY 8d algorithmic bytes (12 B per nonzero ...) / the same time, labelled as such.
   roofline_hbm      the same kernel family on HBM-RESIDENT instances (configs[1] fits the 256 MB
-                    Infinity Cache): poisson2d:4000:4000 with the value dictionary and with 8-byte values.
+                    Infinity Cache): poisson2d:4000:4000 as row patterns, as packed records and with 8-byte values.
   strong_scaling_n1 configs[3] (10M x 10M, 1e9 nonzeros) whole on this GPU, with its own roofline:
                     N = 1 of the series the --gpus N lines continue.
   cpu_baseline      the reference's own CPU path (oracle/_ref), 1 core, bounded sample.
@@ -47,8 +47,10 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s measured float4 copy)
 INFINITY_CACHE = 256 << 20
 HEADLINE = "poisson2d:1000:1000"
-HBM_INSTANCES = [("poisson2d:4000:4000", {}, "value dictionary (1-byte codes), 16-bit columns"),
-                 ("poisson2d:4000:4000", {"LSQRHIP_VAL8": "0"}, "8-byte values, 16-bit columns")]
+HBM_INSTANCES = [("poisson2d:4000:4000", {}, "row patterns (what the build chooses for a constant-coefficient stencil)"),
+                 ("poisson2d:4000:4000", {"LSQRHIP_PAT": "0"}, "packed records: value dictionary (1-byte codes), 16-bit columns"),
+                 ("poisson2d:4000:4000", {"LSQRHIP_PAT": "0", "LSQRHIP_VAL8": "0"},
+                  "8-byte values, 16-bit columns (what a variable-coefficient stencil gets)")]
 PRODUCT_KERNELS = ("k_spmv_", "k_panel_combine", "k_csb_combine", "k_csb_xmax")
 
 
@@ -152,6 +154,8 @@ def build_workload(spec: str, env=None, itnlim=100, rows=None):
 
 
 def describe_layout(info):
+    if info["sell"] == 3:
+        return "row patterns (one byte per row, patterns in LDS)", "k_spmv_pat"
     if info["sell"] == 2:
         return "sliced ELL, packed 16-byte records", "k_spmv_sellp"
     if info["sell"]:

@@ -8,6 +8,23 @@ namespace lsqrhip {
 
 constexpr int WAVE = 64;
 
+// store_through: a store that goes on to memory (system scope: sc0 sc1) while the kernel runs instead of waiting in
+// L2 for the write-back at the kernel's end.  Used for y of the row-pattern product (pat.h): a launch of ~7 us that
+// leaves 8 MB dirty in the L2s otherwise spends ~0.7 us of its life on that write-back with nothing else to do --
+// 7.57 -> 6.88 us per product, 44.1k -> 46.8k iterations/s at configs[1]; no difference at HBM-resident sizes.
+// Measured and NOT used (profiles/r03/config2_patterns.txt): for x and w of the update (the update alone 5.3 -> 6.5 us,
+// the gain above gone), and for y of the packed-record product of sell.h (alone 7.7 -> 7.2 us, the solve 40.6k -> 39.1k).
+typedef double lsqrhip_d2 __attribute__((ext_vector_type(2)));
+typedef float lsqrhip_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void store_through(double *p, double v)
+{
+    asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void store_through(float *p, float v)
+{
+    asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+}
+
 // Fixed-shape reductions: the shuffle tree and the cross-wave order are the same
 // on every launch, so every norm is reproducible run to run (istop / itn depend
 // on them, reference src/lsqr.f90:635, 641, 691, 696, 798-810).

@@ -28,6 +28,7 @@
 #include "csr_build.h"
 #include "scalar.h"
 #include "sell.h"
+#include "pat.h"
 #include "spmv.h"
 #include "xl.h"
 #include "state.h"
@@ -136,7 +137,12 @@ struct Csr {
     unsigned char *val8 = nullptr;   // one-byte codes into dict (valdict.h) ...
     const double *dict = nullptr;    // ... the handle's dictionary (not owned)
     // sliced-ELL layout (sell.h), used instead of the arrays above when `sell` is set
-    int sell = 0;                    // 1 = column-major slices, 2 = packed 16-byte records (sell.h)
+    int sell = 0;                    // 1 = column-major slices, 2 = packed 16-byte records (sell.h), 3 = row patterns (pat.h)
+    unsigned char *pid = nullptr;    // sell = 3: [rows] pattern of each row ...
+    unsigned *pdesc = nullptr;       // ... [PAT_MAX] first entry | length << 16 of each pattern
+    int *pdelta = nullptr;           // ... [PAT_MAX_E] column - row of each entry
+    double *pval = nullptr;          // ... [PAT_MAX_E] value of each entry
+    int npat = 0, npat_e = 0;        // patterns, entries in use
     unsigned *soff = nullptr;        // [nslices+1] first element (sell = 2: first record) of each 64-row slice
     uint4 *srec = nullptr;           // sell = 2: records (5 columns, 5 value codes, row length)
     void *scol = nullptr;            // column-major columns (u16 relative to cbaseS, or i32)
@@ -323,6 +329,10 @@ static void free_csr(Csr &c)
     if (c.sval) (void)hipFree(c.sval);
     if (c.cbaseS) (void)hipFree(c.cbaseS);
     if (c.rlen) (void)hipFree(c.rlen);
+    if (c.pid) (void)hipFree(c.pid);
+    if (c.pdesc) (void)hipFree(c.pdesc);
+    if (c.pdelta) (void)hipFree(c.pdelta);
+    if (c.pval) (void)hipFree(c.pval);
     if (c.rb) (void)hipFree(c.rb);
     if (c.gpid) (void)hipFree(c.gpid);
     if (c.blk) (void)hipFree(c.blk);
@@ -414,6 +424,68 @@ static int bits_for(int limit)
 static void launch_scan_small(hipStream_t s, unsigned *a, int64_t L)
 {
     hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, s, a, L);
+}
+
+// Row patterns (pat.h): a matrix with <= 256 distinct rows keeps one byte per row.  On success out.sell = 3 and the
+// CSR arrays col / val are released; otherwise `out` is left as it was.
+static int try_pat(hipStream_t s, Csr &out, int64_t nnz)
+{
+    const int rows = out.rows;
+    const int mode = env_int("LSQRHIP_PAT", -1);
+    if (out.P > 1 || nnz <= 0 || rows <= 0 || mode == 0) return LSQRHIP_OK;
+    if (nnz > (int64_t)PAT_MAX_LEN * rows) return LSQRHIP_OK;
+    DevScratch s_keys, s_reps, s_slot, s_ctl, s_desc, s_delta, s_val, s_pid;
+    HIPCHK(s_keys.alloc(sizeof(unsigned long long) * PAT_TAB));
+    HIPCHK(s_reps.alloc(sizeof(int) * PAT_TAB));
+    HIPCHK(s_slot.alloc(sizeof(int) * PAT_TAB));
+    HIPCHK(s_ctl.alloc(sizeof(int) * 4));
+    HIPCHK(hipMemsetAsync(s_keys.p, 0, sizeof(unsigned long long) * PAT_TAB, s));
+    HIPCHK(hipMemsetAsync(s_reps.p, 0x7f, sizeof(int) * PAT_TAB, s));
+    HIPCHK(hipMemsetAsync(s_ctl.p, 0, sizeof(int) * 4, s));
+    const int g = (int)std::min<int64_t>(((int64_t)rows + 255) / 256, 2048);
+    int *ctl = s_ctl.as<int>();
+    hipLaunchKernelGGL(k_pat_discover, dim3(g), dim3(256), 0, s, (const int *)out.rowptr, (const int *)out.col,
+                       (const double *)out.val, rows, s_keys.as<unsigned long long>(), s_reps.as<int>(), ctl);
+    HIPCHK(hipGetLastError());
+    int got[4];
+    HIPCHK(hipMemcpyAsync(got, ctl, sizeof(got), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (got[1] != 0 || got[0] > PAT_MAX) return LSQRHIP_OK;
+    if (mode != 1 && (int64_t)got[0] * 16 > rows) return LSQRHIP_OK;  // too few rows per pattern to be a structure
+    HIPCHK(s_desc.alloc(sizeof(unsigned) * PAT_MAX));
+    HIPCHK(s_delta.alloc(sizeof(int) * PAT_MAX_E));
+    HIPCHK(s_val.alloc(sizeof(double) * PAT_MAX_E));
+    HIPCHK(s_pid.alloc((size_t)rows));
+    HIPCHK(hipMemsetAsync(s_delta.p, 0, sizeof(int) * PAT_MAX_E, s));
+    HIPCHK(hipMemsetAsync(s_val.p, 0, sizeof(double) * PAT_MAX_E, s));
+    hipLaunchKernelGGL(k_pat_table, dim3(1), dim3(PAT_TAB), 0, s, (const int *)out.rowptr, (const int *)out.col,
+                       (const double *)out.val, (const unsigned long long *)s_keys.p, (const int *)s_reps.p,
+                       s_slot.as<int>(), s_desc.as<unsigned>(), s_delta.as<int>(), s_val.as<double>(), ctl);
+    hipLaunchKernelGGL(k_pat_assign, dim3(g), dim3(256), 0, s, (const int *)out.rowptr, (const int *)out.col,
+                       (const double *)out.val, rows, (const unsigned long long *)s_keys.p, (const int *)s_slot.p,
+                       (const unsigned *)s_desc.p, (const int *)s_delta.p, (const double *)s_val.p,
+                       s_pid.as<unsigned char>(), ctl);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(got, ctl, sizeof(got), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (got[1] != 0) return LSQRHIP_OK;   // too many entries, or two different rows under one key
+    (void)hipFree(out.col);
+    (void)hipFree(out.val);
+    out.col = nullptr;
+    out.val = nullptr;
+    out.sell = 3;
+    out.pid = s_pid.release<unsigned char>();
+    out.pdesc = s_desc.release<unsigned>();
+    out.pdelta = s_delta.release<int>();
+    out.pval = s_val.release<double>();
+    out.npat = got[2];
+    out.npat_e = got[3];
+    out.nslices = (rows + 63) / 64;
+    out.nblk = (out.nslices + SELL_SLICES - 1) / SELL_SLICES;
+    out.nstored = 0;
+    // what one product reads of the matrix: a byte per row and the table
+    out.bytes = (int64_t)rows + (int64_t)sizeof(unsigned) * PAT_MAX + 12ll * got[3];
+    return LSQRHIP_OK;
 }
 
 static int try_sell(hipStream_t s, Csr &out, int64_t nnz, const double *dict, int ndict, unsigned long long *stats)
@@ -597,13 +669,17 @@ static int build_csr_T(hipStream_t s, const int *d_keys, const int *d_other, con
 
     // short, even rows: sliced-ELL layout instead of row windows (sell.h)
     if (std::is_same<OffT, int>::value) {
-        const int rcs = try_sell(s, out, nnz, dict, ndict, (unsigned long long *)hist);
+        int rcs = try_pat(s, out, nnz);   // rows that repeat: one byte per row (pat.h)
+        if (rcs == LSQRHIP_OK && !out.sell) rcs = try_sell(s, out, nnz, dict, ndict, (unsigned long long *)hist);
         if (rcs != LSQRHIP_OK) return rcs;
     }
     if (out.sell) {
         // 6 workgroups per CU: measured best at every size (config 2: 25.0 vs 26.1 us per iteration
         // with 8 per CU; fewer partial sums to re-read, still enough waves for the streams)
-        const int cap = std::min(std::max(env_int("LSQRHIP_SELL_GRID", SELL_MAX_GRID), 8), SPMV_MAX_GRID);
+        // row patterns (pat.h): 4 per CU, two slices per wave and trip -- config 2: 46.5k iterations/s, against 44.9k /
+        // 43.3k with 896 / 1152 workgroups and 45.4k with 1536 and one slice per trip (profiles/r03/config2_patterns.txt)
+        const int cap = out.sell == 3 ? std::min(std::max(env_int("LSQRHIP_PAT_GRID", PAT_MAX_GRID), 8), SPMV_MAX_GRID)
+                                      : std::min(std::max(env_int("LSQRHIP_SELL_GRID", SELL_MAX_GRID), 8), SPMV_MAX_GRID);
         int64_t grid = std::min<int64_t>(out.nblk, cap);
         if (grid >= 8) grid &= ~(int64_t)7;
         out.grid = (int)std::max<int64_t>(grid, 1);

@@ -1,0 +1,364 @@
+// pat.h -- row patterns: SpMV for matrices whose rows repeat (aprod mode 1 / mode 2).
+//
+// Same contract as sell.h / spmv.h (reference src/lsqr.f90:166-174 / :186-194 fused with the dscal before and
+// the dnrm2 after, :681-683 / :692-695):
+//
+//     y_i  <-  cy * (y_i * sy)  +  sum_j A_ij * (x_j * sx)        partial += y_i^2
+//
+// Why a third short-row layout.  A constant-coefficient stencil -- BASELINE.json configs[1], any finite-difference
+// operator on a structured grid -- has a handful of DISTINCT rows: row i is (column - i, value) for a few offsets,
+// the same list for every interior point, another few lists along the boundaries.  The packed records of sell.h
+// already store such a row in 16 bytes; here it is ONE byte, the number of its pattern, and the patterns
+// themselves (<= 256 lists, <= 1024 entries in all) sit in LDS.  A product then moves 1 + 8 + 16 = 25 bytes per
+// row instead of 40 -- on a bandwidth-bound kernel the only thing that still helps.
+//
+//   pid[r]     = pattern of row r                                              (u8, the only per-row data)
+//   desc[p]    = first entry of pattern p | its length << 16
+//   delta[e], val[e] = entry e: column - row, value; the entries of a pattern in the row's COO order
+//
+// Lane i of a wave owns row i of a 64-row slice as in sell.h; its sum is the plain left-to-right sum over the
+// pattern's entries starting from 0 -- bit-identical to the reference's and to the other short-row kernels.
+//
+// Build (k_pat_* below, from the CSR of csr_build.h, all on the device): every row is hashed over (length, column
+// offsets, value bits) into a 1024-slot table that gives up at the 257th distinct key; the keys are ranked (pattern
+// numbers do not depend on the order the rows arrived in), each pattern is copied from its first row, and every row is
+// then COMPARED with the pattern its hash names -- entry by entry, bit by bit; one mismatch (a hash collision) and the
+// matrix keeps the layout it would have had.  A matrix with unrelated rows leaves after a fraction of one pass.
+//
+// Chosen when the matrix has <= 256 distinct rows of <= 64 nonzeros, <= 1024 pattern entries, and at least 16 rows per
+// pattern.  LSQRHIP_PAT=0 never, =1 whenever the limits hold.
+#pragma once
+
+#include "common.h"
+#include "scalar.h"
+#include "sell.h"
+#include "state.h"
+#include "vec.h"
+
+namespace lsqrhip {
+
+constexpr int PAT_MAX = 256;       // patterns (one byte per row)
+constexpr int PAT_MAX_E = 1024;    // entries of all patterns together (12 KB of LDS)
+constexpr int PAT_MAX_LEN = 64;    // nonzeros of a row
+constexpr int PAT_TAB = 1024;      // slots of the discovery table
+constexpr int PAT_K = 5;           // entries in flight per lane and slice
+constexpr int PAT_U = 2;           // slices a wave takes through the chain together
+constexpr int PAT_MAX_GRID = 1024; // 4 workgroups per CU x 256 CUs (lsqrhip.hip)
+
+__device__ __forceinline__ unsigned long long pat_mix(unsigned long long h, unsigned long long v)
+{
+    h ^= v + 0x9e3779b97f4a7c15ull + (h << 6) + (h >> 2);
+    h *= 0xff51afd7ed558ccdull;
+    h ^= h >> 33;
+    return h;
+}
+// key of row r (never 0: 0 marks an empty slot)
+__device__ __forceinline__ unsigned long long pat_row_key(const int *__restrict__ col, const double *__restrict__ val,
+                                                          int q0, int len, int r)
+{
+    unsigned long long h = pat_mix(0x243f6a8885a308d3ull, (unsigned long long)len);
+    for (int k = 0; k < len; ++k) {
+        h = pat_mix(h, (unsigned long long)(unsigned)(col[q0 + k] - r));
+        h = pat_mix(h, (unsigned long long)__double_as_longlong(val[q0 + k]));
+    }
+    return h | 1ull;
+}
+
+// ctl[0] = distinct keys so far, ctl[1] = give up, ctl[2] = patterns, ctl[3] = entries (k_pat_table)
+__global__ __launch_bounds__(256) void k_pat_discover(const int *__restrict__ rowptr, const int *__restrict__ col,
+                                                      const double *__restrict__ val, int rows,
+                                                      unsigned long long *__restrict__ keys, int *__restrict__ reps,
+                                                      int *__restrict__ ctl)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += stride) {
+        if (*(volatile int *)&ctl[1] != 0) return;
+        const int q0 = rowptr[r], len = rowptr[r + 1] - q0;
+        if (len > PAT_MAX_LEN) {
+            ctl[1] = 1;
+            return;
+        }
+        const unsigned long long h = pat_row_key(col, val, q0, len, (int)r);
+        unsigned slot = (unsigned)(h >> 11) & (PAT_TAB - 1);
+        int tries = 0;
+        for (; tries < PAT_TAB; ++tries) {
+            // look before the exchange: a million interior rows of a stencil share ONE key, and a million compare-and-
+            // swaps on one word take 11 ms; a device-scope load (the L2 of another XCD may hold the word as it was) does not
+            unsigned long long old = __hip_atomic_load(&keys[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (old == 0ull) old = atomicCAS(&keys[slot], 0ull, h);
+            if (old == 0ull) {
+                if (atomicAdd(&ctl[0], 1) >= PAT_MAX) ctl[1] = 1;
+                atomicMin(&reps[slot], (int)r);
+                break;
+            }
+            if (old == h) {
+                if (__hip_atomic_load(&reps[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > (int)r)
+                    atomicMin(&reps[slot], (int)r);
+                break;
+            }
+            if (*(volatile int *)&ctl[1] != 0) return;
+            slot = (slot + 1) & (PAT_TAB - 1);
+        }
+        if (tries == PAT_TAB) {
+            ctl[1] = 1;
+            return;
+        }
+    }
+}
+
+// One workgroup of PAT_TAB threads: rank the keys (pattern p = p-th smallest key), lay the patterns out, copy each from
+// its first row.  slot_pat[slot] = pattern of the key in that slot.
+__global__ __launch_bounds__(PAT_TAB) void k_pat_table(const int *__restrict__ rowptr, const int *__restrict__ col,
+                                                       const double *__restrict__ val,
+                                                       const unsigned long long *__restrict__ keys,
+                                                       const int *__restrict__ reps, int *__restrict__ slot_pat,
+                                                       unsigned *__restrict__ desc, int *__restrict__ delta,
+                                                       double *__restrict__ pval, int *__restrict__ ctl)
+{
+    __shared__ unsigned long long skey[PAT_TAB];
+    __shared__ int slen[PAT_MAX], sstart[PAT_MAX + 1], srep[PAT_MAX];
+    const int t = threadIdx.x;
+    if (ctl[1] != 0) return;
+    const unsigned long long key = keys[t];
+    skey[t] = key;
+    if (t < PAT_MAX) slen[t] = 0;
+    __syncthreads();
+    int p = -1;
+    if (key != 0ull) {
+        p = 0;
+        for (int j = 0; j < PAT_TAB; ++j) p += (skey[j] != 0ull && skey[j] < key) ? 1 : 0;
+    }
+    slot_pat[t] = p;
+    if (p >= 0 && p < PAT_MAX) {
+        const int rep = reps[t];
+        srep[p] = rep;
+        slen[p] = rowptr[rep + 1] - rowptr[rep];
+    }
+    __syncthreads();
+    const int np = min(ctl[0], PAT_MAX);
+    if (t == 0) {
+        int e = 0;
+        for (int j = 0; j < np; ++j) {
+            sstart[j] = e;
+            e += slen[j];
+        }
+        sstart[np] = e;
+        ctl[2] = np;
+        ctl[3] = e;
+        if (e > PAT_MAX_E) ctl[1] = 1;
+    }
+    __syncthreads();
+    if (sstart[np] > PAT_MAX_E) return;
+    if (t < PAT_MAX) desc[t] = t < np ? ((unsigned)sstart[t] | ((unsigned)slen[t] << 16)) : 0u;
+    if (t < np) {
+        const int rep = srep[t], q0 = rowptr[rep], e0 = sstart[t];
+        for (int k = 0; k < slen[t]; ++k) {
+            delta[e0 + k] = col[q0 + k] - rep;
+            pval[e0 + k] = val[q0 + k];
+        }
+    }
+}
+
+// pid[r] = pattern of row r, after comparing the row with it entry by entry (ctl[1] = 1 on any difference)
+__global__ __launch_bounds__(256) void k_pat_assign(const int *__restrict__ rowptr, const int *__restrict__ col,
+                                                    const double *__restrict__ val, int rows,
+                                                    const unsigned long long *__restrict__ keys,
+                                                    const int *__restrict__ slot_pat, const unsigned *__restrict__ desc,
+                                                    const int *__restrict__ delta, const double *__restrict__ pval,
+                                                    unsigned char *__restrict__ pid, int *__restrict__ ctl)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += stride) {
+        const int q0 = rowptr[r], len = rowptr[r + 1] - q0;
+        const unsigned long long h = pat_row_key(col, val, q0, len, (int)r);
+        unsigned slot = (unsigned)(h >> 11) & (PAT_TAB - 1);
+        int p = -1;
+        for (int tries = 0; tries < PAT_TAB; ++tries) {
+            const unsigned long long k = keys[slot];
+            if (k == h) {
+                p = slot_pat[slot];
+                break;
+            }
+            if (k == 0ull) break;
+            slot = (slot + 1) & (PAT_TAB - 1);
+        }
+        bool same = p >= 0 && p < PAT_MAX;
+        if (same) {
+            const unsigned d = desc[p];
+            const int e0 = (int)(d & 0xffffu);
+            same = (int)(d >> 16) == len;
+            for (int k = 0; same && k < len; ++k)
+                same = delta[e0 + k] == col[q0 + k] - (int)r &&
+                       __double_as_longlong(pval[e0 + k]) == __double_as_longlong(val[q0 + k]);
+        }
+        if (!same) {
+            ctl[1] = 1;
+            return;
+        }
+        pid[r] = (unsigned char)p;
+    }
+}
+
+// The rows of PAT_U slices on their way through one trip: pattern -> entries (LDS) -> gathered x, y.
+struct PatTrip {
+    int r[PAT_U], e0[PAT_U], len[PAT_U];
+    bool active[PAT_U];
+    double y0[PAT_U];
+    double a[PAT_U][PAT_K], xv[PAT_U][PAT_K];
+};
+// request everything the first PAT_K entries of the rows need
+template <typename VT>
+__device__ __forceinline__ void pat_issue(PatTrip &t, int64_t b, const XcdRange &xr, int wave, int lane, int rows,
+                                          const int (&pidc)[PAT_U], const unsigned *sdesc, const int *sdelta,
+                                          const double *sval, const VT *__restrict__ x, const VT *__restrict__ y)
+{
+#pragma unroll
+    for (int u = 0; u < PAT_U; ++u) {
+        const int64_t bu = b + u * xr.stride;
+        t.r[u] = ((int)(bu * SELL_SLICES) + wave) * WAVE + lane;
+        t.active[u] = bu < xr.end && t.r[u] < rows;
+        t.y0[u] = (double)y[t.active[u] ? t.r[u] : 0];
+        const unsigned d = t.active[u] ? sdesc[pidc[u]] : 0u;
+        t.e0[u] = (int)(d & 0xffffu);
+        t.len[u] = (int)(d >> 16);
+    }
+#pragma unroll
+    for (int u = 0; u < PAT_U; ++u)
+#pragma unroll
+        for (int k = 0; k < PAT_K; ++k) {
+            const bool live = k < t.len[u];
+            const int e = live ? t.e0[u] + k : 0;
+            t.a[u][k] = sval[e];
+            t.xv[u][k] = (double)x[live ? t.r[u] + sdelta[e] : 0];   // (no entry: x[0], never added)
+        }
+}
+// the left-to-right sums, the rest of rows longer than PAT_K, y and its square
+template <typename VT>
+__device__ __forceinline__ void pat_finish(const PatTrip &t, double sx, double sy, double cy, const NScale nsc,
+                                           const int *sdelta, const double *sval, const VT *__restrict__ x,
+                                           VT *__restrict__ y, double &sq)
+{
+    double sum[PAT_U];
+#pragma unroll
+    for (int u = 0; u < PAT_U; ++u) {
+        sum[u] = 0.0;
+#pragma unroll
+        for (int k = 0; k < PAT_K; ++k) {
+            const double p = t.a[u][k] * (t.xv[u][k] * sx);
+            if (k < t.len[u]) sum[u] = sum[u] + p;
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < PAT_U; ++u) {
+        for (int k0 = PAT_K; __any(k0 < t.len[u]); k0 += PAT_K) {
+            double a[PAT_K], xv[PAT_K];
+#pragma unroll
+            for (int k = 0; k < PAT_K; ++k) {
+                const bool live = k0 + k < t.len[u];
+                const int e = live ? t.e0[u] + k0 + k : 0;
+                a[k] = sval[e];
+                xv[k] = (double)x[live ? t.r[u] + sdelta[e] : 0];
+            }
+#pragma unroll
+            for (int k = 0; k < PAT_K; ++k) {
+                const double p = a[k] * (xv[k] * sx);
+                if (k0 + k < t.len[u]) sum[u] = sum[u] + p;
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < PAT_U; ++u) {
+        if (t.active[u]) {
+            const VT yn = (VT)(cy * (t.y0[u] * sy) + sum[u]);
+            store_through(&y[t.r[u]], yn);
+            const double ys = (double)yn * nsc.s;
+            sq += ys * ys;
+        }
+    }
+}
+
+// UPD = true: the launch also carries the x/w update of the previous iteration (UpdArgs), as in sell.h.
+//
+// At configs[1] a wave has four slices and the launch lives ~7 us: the CHAIN of dependent round trips, not the bytes,
+// is what it waits for (stop flag, table -> the previous kernel's partial sums -> pattern number -> gathered x -> y).
+// So: the table, the stop flag and the pattern numbers of the first trip (a byte per lane) are requested at the top in
+// one go; PAT_U slices go through a trip together; the pattern numbers of the next trip are requested before the
+// gathers of this one.  NOT: the first trip's gathers ahead of the prologue, with this thread's share of the partial
+// sums requested before them -- the product alone takes the same 7.2 us, the solve drops from 46.7k to 45.5k
+// iterations/s (profiles/r03/config2_patterns.txt), as it did for the packed records of sell.h.
+template <bool UPD, typename VT = double>
+__global__ __launch_bounds__(SELL_BLOCK, 4) void k_spmv_pat(
+    const unsigned char *__restrict__ pid, const unsigned *__restrict__ desc, const int *__restrict__ delta,
+    const double *__restrict__ pval, int nent, int rows, int nslices, int64_t nblk, const VT *__restrict__ x,
+    VT *__restrict__ y, const SpmvCoef *__restrict__ coef, const int *__restrict__ stop,
+    double *__restrict__ partials, const double *__restrict__ pin, int npin, const NormSlot *__restrict__ slot_in,
+    NormSlot *__restrict__ slot_out, int skip_if_zero, Rider rider, UpdArgs upd, NScale nsc)
+{
+    __shared__ double red[SELL_BLOCK / WAVE + 1];
+    __shared__ unsigned sdesc[PAT_MAX];
+    __shared__ int sdelta[PAT_MAX_E];
+    __shared__ double sval[PAT_MAX_E];
+    const int shift = rider.kind != 0 ? 1 : 0;
+    const int nwg = (int)gridDim.x - shift;
+    const int wg = (int)blockIdx.x - shift;
+    if (wg < 0) {
+        run_rider(rider, red);
+        return;
+    }
+    const int tid = threadIdx.x;
+    const unsigned desc_mine = desc[tid];
+    int d_mine[PAT_MAX_E / SELL_BLOCK];
+    double v_mine[PAT_MAX_E / SELL_BLOCK];
+#pragma unroll
+    for (int j = 0; j < PAT_MAX_E / SELL_BLOCK; ++j) {
+        const int e = tid + j * SELL_BLOCK;
+        d_mine[j] = e < nent ? delta[e] : 0;
+        v_mine[j] = e < nent ? pval[e] : 0.0;
+    }
+    const int lane = tid & (WAVE - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const XcdRange xr = xcd_range(nblk, nwg, wg);
+    int64_t b = xr.first;
+    int pid_next[PAT_U];
+#pragma unroll
+    for (int u = 0; u < PAT_U; ++u) {
+        const int64_t bu = b + u * xr.stride;
+        const int r0 = ((int)(bu * SELL_SLICES) + wave) * WAVE + lane;
+        pid_next[u] = (bu < xr.end && r0 < rows) ? (int)pid[r0] : 0;
+    }
+
+    if (*stop != 0) return;
+    sdesc[tid] = desc_mine;
+#pragma unroll
+    for (int j = 0; j < PAT_MAX_E / SELL_BLOCK; ++j) {
+        const int e = tid + j * SELL_BLOCK;
+        if (e < nent) {
+            sdelta[e] = d_mine[j];
+            sval[e] = v_mine[j];
+        }
+    }
+    SellCoef kc;
+    if (!sell_prologue<UPD, VT>(coef, pin, npin, slot_in, slot_out, skip_if_zero, upd, nwg, wg, red, kc, nsc)) return;
+    const double sx = kc.sx, sy = kc.sy, cy = kc.cy;
+    __syncthreads();
+
+    double sq = 0.0;
+    for (; b < xr.end; b += PAT_U * xr.stride) {
+        int pidc[PAT_U];
+#pragma unroll
+        for (int u = 0; u < PAT_U; ++u) pidc[u] = pid_next[u];
+#pragma unroll
+        for (int u = 0; u < PAT_U; ++u) {
+            const int64_t bn = b + (PAT_U + u) * xr.stride;
+            const int rn = ((int)(bn * SELL_SLICES) + wave) * WAVE + lane;
+            pid_next[u] = (bn < xr.end && rn < rows) ? (int)pid[rn] : 0;
+        }
+        PatTrip trip;
+        pat_issue<VT>(trip, b, xr, wave, lane, rows, pidc, sdesc, sdelta, sval, x, y);
+        pat_finish<VT>(trip, sx, sy, cy, nsc, sdelta, sval, x, y, sq);
+    }
+    const double tot = block_sum<SELL_BLOCK>(sq, red);
+    if (tid == 0) partials[wg] = tot;
+}
+
+}  // namespace lsqrhip

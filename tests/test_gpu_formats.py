@@ -19,7 +19,8 @@ KNOBS = ("LSQRHIP_SELL", "LSQRHIP_SELLP", "LSQRHIP_VAL8", "LSQRHIP_COL16", "LSQR
 
 @pytest.fixture(autouse=True)
 def clean_env():
-    old = {k: os.environ.pop(k, None) for k in KNOBS}
+    old = {k: os.environ.pop(k, None) for k in KNOBS + ("LSQRHIP_PAT",)}
+    os.environ["LSQRHIP_PAT"] = "0"       # this file is about the layouts UNDER row patterns (tests/test_gpu_patterns.py)
     yield
     for k, v in old.items():
         os.environ.pop(k, None)

@@ -1,0 +1,190 @@
+"""Row patterns (csrc/pat.h): a matrix whose rows repeat -- a constant-coefficient stencil -- is stored as one byte per
+row plus the table of its distinct rows.  Like every other short-row layout it must give the reference's row sums bit
+for bit (src/lsqr.f90:166-174, 186-194: left to right in COO order) and the reference's solve; a matrix that does
+not qualify, or one whose rows collide under the hash, keeps the layout it would have had."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from cases import build_cases
+from lsqr_amd import problems as P
+from lsqr_amd.solver import lsqr_solver_ez
+
+pytestmark = pytest.mark.gpu
+CASES = build_cases()
+KNOBS = ("LSQRHIP_PAT", "LSQRHIP_SELL", "LSQRHIP_SELLP", "LSQRHIP_VAL8", "LSQRHIP_COL16", "LSQRHIP_CSB")
+
+
+@pytest.fixture(autouse=True)
+def clean_env():
+    old = {k: os.environ.pop(k, None) for k in KNOBS}
+    yield
+    for k, v in old.items():
+        os.environ.pop(k, None)
+        if v is not None:
+            os.environ[k] = v
+
+
+def _vec(stream, n):
+    return P.u64_to_unit(P.rng_u64(301, stream, np.arange(n, dtype=np.uint64)))
+
+
+def stencil(m, n, offsets, values, seed=1, shuffle=False, drop=None):
+    """Row r holds values[k] at column r + offsets[k] where that is inside [0, n), in the order given (duplicates and
+    unsorted offsets allowed: the order IS the summation order)."""
+    r = np.arange(m)
+    rows, cols, vals = [], [], []
+    for k, (off, v) in enumerate(zip(offsets, values)):
+        c = r + off
+        ok = (c >= 0) & (c < n)
+        if drop is not None:
+            ok &= ~drop(r, k)
+        rows.append(np.where(ok, r, -1)); cols.append(c); vals.append(np.full(m, v))
+    rows = np.stack(rows, axis=1).ravel(); cols = np.stack(cols, axis=1).ravel(); vals = np.stack(vals, axis=1).ravel()
+    keep = rows >= 0
+    irow, icol, a = rows[keep], cols[keep], vals[keep]
+    if shuffle:      # entry k of every row, then entry k - 1 of every row, ..., each time from the last row to the first:
+        # a stable sort by row leaves every row with its entries reversed
+        kk = np.stack([np.full(m, k) for k in range(len(offsets))], axis=1).ravel()[keep]
+        perm = np.lexsort((-irow, -kk))
+        irow, icol, a = irow[perm], icol[perm], a[perm]
+    b = _vec(7, m)
+    return m, n, (irow + 1).astype(np.int32), (icol + 1).astype(np.int32), a.astype(np.float64), b
+
+
+def check_against_oracle(m, n, irow, icol, a, b, damp=0.0, itnlim=25, want=3, want_t=3):
+    po = oracle.port()
+    xp, yp = _vec(9, n), _vec(10, m)
+    _, y_ref = po.aprod(1, m, n, irow, icol, a, xp, yp)
+    x_ref, _ = po.aprod(2, m, n, irow, icol, a, xp, yp)
+    o = po.solve(m, n, irow, icol, a, b, damp=damp, itnlim=itnlim)
+    s = lsqr_solver_ez().initialize(m, n, a, irow, icol, itnlim=itnlim)
+    info = s.info()
+    assert (info["sell"], info["sell_t"]) == (want, want_t), info
+    x, y = xp.copy(), yp.copy()
+    s.aprod(1, m, n, x, y)
+    assert np.array_equal(y, y_ref)               # the reference's row sums, bit for bit
+    x, y = xp.copy(), yp.copy()
+    s.aprod(2, m, n, x, y)
+    assert np.array_equal(x, x_ref)
+    outs = []
+    for pipeline in (0, 1, 2):
+        s.set_option("pipeline", pipeline)
+        r = s.solve(b, damp)
+        assert (r.istop, r.itn) == (o.istop, o.itn)
+        assert np.linalg.norm(r.x - o.x) <= 1e-10 * max(np.linalg.norm(o.x), 1e-300)
+        assert abs(r.anorm - o.anorm) <= 1e-10 * o.anorm and abs(r.rnorm - o.rnorm) <= 1e-10 * max(o.rnorm, 1e-300)
+        outs.append(r)
+    for r in outs[1:]:
+        assert np.array_equal(r.x, outs[0].x) and r.anorm == outs[0].anorm and r.rnorm == outs[0].rnorm
+    return s, outs[0]
+
+
+@pytest.mark.parametrize("shape", [(300, 200), (64, 3), (257, 131), (1000, 2)])
+def test_a_stencil_is_stored_as_row_patterns_and_gives_the_references_bits(shape):
+    p = P.poisson2d(*shape)
+    s, r = check_against_oracle(p.m, p.n, p.irow, p.icol, p.a, p.b)
+    info = s.info()
+    # a byte per row and the table: far below the 16 bytes per row of the packed records
+    assert info["csr_bytes"] <= p.m + 1024 + 12 * 1024
+    # ... and the same bits as the layouts underneath
+    os.environ["LSQRHIP_PAT"] = "0"
+    s0 = lsqr_solver_ez().initialize(p.m, p.n, p.a, p.irow, p.icol, itnlim=25)
+    assert s0.info()["sell"] in (1, 2)
+    r0 = s0.solve(p.b, 0.0)
+    assert np.array_equal(r0.x, r.x) and r0.anorm == r.anorm and r0.rnorm == r.rnorm and r0.itn == r.itn
+
+
+def test_unsymmetric_patterns_duplicates_and_the_order_inside_a_row():
+    """An upwind-like stencil whose transpose has other values, one offset twice (a duplicate (i, j) entry), offsets
+    out of order, rows delivered last-first: the stable sort by row keeps the order inside each row, and that order is
+    the summation order of the pattern."""
+    offs = (3, -2, 0, 3, 1, -40)
+    vals = (0.3, -1.7, 2.0 / 3.0, 1e-3, -0.0, 5.5)
+    m, n, irow, icol, a, b = stencil(5000, 5007, offs, vals, shuffle=True)
+    check_against_oracle(m, n, irow, icol, a, b, damp=1e-2)
+
+
+def test_rows_with_holes_make_more_patterns():
+    """Every 7th row lacks its second entry, every 11th its fourth: 4 interior patterns and the boundary ones."""
+    drop = lambda r, k: ((k == 1) & (r % 7 == 0)) | ((k == 3) & (r % 11 == 0))   # noqa: E731
+    m, n, irow, icol, a, b = stencil(9000, 9000, (-5, -1, 0, 1, 5), (-1.0, -1.0, 4.0, -1.0, -1.0), drop=drop)
+    check_against_oracle(m, n, irow, icol, a, b)
+
+
+def test_empty_rows_are_a_pattern_of_their_own():
+    drop = lambda r, k: r % 5 == 2          # noqa: E731
+    m, n, irow, icol, a, b = stencil(4000, 3990, (-1, 0, 2), (1.0, -2.0, 1.0), drop=drop)
+    check_against_oracle(m, n, irow, icol, a, b, damp=1e-3)
+
+
+def test_matrices_without_repeating_rows_keep_their_layout():
+    # arbitrary real values on a band: every row is its own pattern
+    m, n, irow, icol, a, b = stencil(70001, 70003, (-7, -1, 0, 1, 7), (1.0,) * 5)
+    a = _vec(3, a.size) + 0.5
+    info = lsqr_solver_ez().initialize(m, n, a, irow, icol).info()
+    assert info["sell"] == 1 and info["sell_t"] == 1
+    # random columns
+    p = P.random_rows(30000, 20000, 8, seed=4)
+    info = lsqr_solver_ez().initialize(p.m, p.n, p.a, p.irow, p.icol).info()
+    assert info["sell"] != 3 and info["sell_t"] != 3
+    # nd distinct diagonal values, each 100 times, over a constant superdiagonal that the last row lacks: nd + 1
+    # patterns -- 256 fit a byte, 257 do not
+    for nd, want in ((255, 3), (256, 1)):
+        m = n = 100 * nd
+        r = np.arange(m)
+        irow = np.concatenate([r, r[:-1]])
+        icol = np.concatenate([r, r[:-1] + 1])
+        a = np.concatenate([1.0 + (r % nd), np.full(m - 1, -1.0)])
+        order = np.argsort(irow, kind="stable")
+        irow, icol, a = (irow[order] + 1).astype(np.int32), (icol[order] + 1).astype(np.int32), a[order]
+        if want == 3:
+            check_against_oracle(m, n, irow, icol, a, _vec(7, m), itnlim=8)
+        else:
+            assert lsqr_solver_ez().initialize(m, n, a, irow, icol).info()["sell"] == want
+
+
+def test_limits_rows_per_pattern_entries_and_row_length():
+    # 3 x 3 dense (README example): three patterns for three rows -- only when forced
+    p, o = CASES["t1_readme_damped"]
+    assert lsqr_solver_ez().initialize(p.m, p.n, p.a, p.irow, p.icol).info()["sell"] != 3
+    os.environ["LSQRHIP_PAT"] = "1"
+    s = lsqr_solver_ez().initialize(p.m, p.n, p.a, p.irow, p.icol, itnlim=o["itnlim"])
+    assert s.info()["sell"] == 3 and s.info()["sell_t"] == 3
+    r = s.solve(p.b, o["damp"])
+    ref = oracle.port().solve(p.m, p.n, p.irow, p.icol, p.a, p.b, damp=o["damp"], itnlim=o["itnlim"])
+    assert r.istop == ref.istop and np.linalg.norm(r.x - ref.x) <= 1e-10 * np.linalg.norm(ref.x)
+    os.environ.pop("LSQRHIP_PAT")
+    # 60 entries per row, interior + 2 x 30 boundary patterns: more than 1024 entries in all
+    offs = tuple(range(-30, 30))
+    m, n, irow, icol, a, b = stencil(20000, 20000, offs, tuple(1.0 + 0.01 * k for k in range(60)))
+    assert lsqr_solver_ez().initialize(m, n, a, irow, icol).info()["sell"] != 3
+    # 12 entries per row: 1 + 2 x 6 patterns, ~130 entries
+    offs = tuple(range(-6, 6))
+    m, n, irow, icol, a, b = stencil(20000, 20000, offs, tuple(1.0 + 0.01 * k for k in range(12)))
+    check_against_oracle(m, n, irow, icol, a, b, itnlim=10)
+    # rows of 65 nonzeros: beyond the row length a pattern may have
+    offs = tuple(range(-32, 33))
+    m, n, irow, icol, a, b = stencil(5000, 5000, offs, (1.0,) * 65)
+    assert lsqr_solver_ez().initialize(m, n, a, irow, icol).info()["sell"] != 3
+
+
+def test_real32_patterns():
+    """REAL32 handle on the pattern layout: float vectors, binary64 registers, the table stays binary64 (of values that
+    are exactly float)."""
+    p = P.poisson2d(120, 90)
+    a32, b32 = p.a.astype(np.float32), p.b.astype(np.float32)
+    s = lsqr_solver_ez().initialize(p.m, p.n, a32, p.irow, p.icol, itnlim=30, real32=True)
+    assert s.info()["sell"] == 3
+    xp, yp = _vec(9, p.n).astype(np.float32), _vec(10, p.m).astype(np.float32)
+    po = oracle.port()
+    _, y_ref = po.aprod(1, p.m, p.n, p.irow, p.icol, a32.astype(np.float64), xp.astype(np.float64), yp.astype(np.float64))
+    x, y = xp.copy(), yp.copy()
+    s.aprod(1, p.m, p.n, x, y)
+    assert np.array_equal(y, y_ref.astype(np.float32))      # binary64 sums, rounded once
+    os.environ["LSQRHIP_PAT"] = "0"
+    s0 = lsqr_solver_ez().initialize(p.m, p.n, a32, p.irow, p.icol, itnlim=30, real32=True)
+    r, r0 = s.solve(b32, 0.0), s0.solve(b32, 0.0)
+    assert np.array_equal(r.x, r0.x) and r.itn == r0.itn and r.anorm == r0.anorm
