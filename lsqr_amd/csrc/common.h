@@ -100,6 +100,40 @@ __device__ __forceinline__ double block_sum_all(const double *__restrict__ p, in
     return out;
 }
 
+// block_sum_all for a caller that requested its share of the partials itself (strided_share_load): the loads were
+// issued early, among other requests, and are summed here in strided_sum's order -- the same bits.
+constexpr int SHARE_K = 4;
+template <int BLOCK>
+__device__ __forceinline__ void strided_share_load(const double *__restrict__ p, int np, double (&v)[SHARE_K])
+{
+    const int t = threadIdx.x;
+    const int last = np > 0 ? np - 1 : 0;
+#pragma unroll
+    for (int k = 0; k < SHARE_K; ++k) {
+        const int i = t + k * BLOCK;
+        v[k] = p[i < last ? i : last];
+    }
+}
+template <int BLOCK>
+__device__ __forceinline__ double strided_share_sum(const double (&v)[SHARE_K], int np)
+{
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < SHARE_K; ++k)
+        if ((int)threadIdx.x + k * BLOCK < np) s += v[k];
+    return s;
+}
+template <int BLOCK>
+__device__ __forceinline__ double block_sum_all_share(double s, double *lds)
+{
+    const double r = block_sum<BLOCK>(s, lds);
+    if (threadIdx.x == 0) lds[BLOCK / WAVE] = r;
+    __syncthreads();
+    const double out = lds[BLOCK / WAVE];
+    __syncthreads();
+    return out;
+}
+
 // Blue's range-safe sum of squares (constants of LAPACK 3.10's dnrm2); see scalar.h "range-safe norms".
 constexpr double BLUE_TSML = 0x1p-511, BLUE_TBIG = 0x1p486, BLUE_SSML = 0x1p537, BLUE_SBIG = 0x1p-538;
 

@@ -283,9 +283,11 @@ __device__ __forceinline__ void pat_finish(const PatTrip &t, double sx, double s
 // is what it waits for (stop flag, table -> the previous kernel's partial sums -> pattern number -> gathered x -> y).
 // So: the table, the stop flag and the pattern numbers of the first trip (a byte per lane) are requested at the top in
 // one go; PAT_U slices go through a trip together; the pattern numbers of the next trip are requested before the
-// gathers of this one.  NOT: the first trip's gathers ahead of the prologue, with this thread's share of the partial
-// sums requested before them -- the product alone takes the same 7.2 us, the solve drops from 46.7k to 45.5k
-// iterations/s (profiles/r03/config2_patterns.txt), as it did for the packed records of sell.h.
+// gathers of this one; this thread's share of the previous kernel's partial sums is requested at the top as well
+// (46.6k -> 47.6k iterations/s).  NOT: the first trip's gathers ahead of the prologue (the product alone takes the
+// same 7.2 us, the solve drops from 46.7k to 45.5k iterations/s, as it did for the packed records of sell.h), nor
+// between the prologue's norm and the update it carries (47.5k -> 44.3k): requests in flight while the update
+// streams delay it more than they save (profiles/r03/config2_patterns.txt).
 template <bool UPD, typename VT = double>
 __global__ __launch_bounds__(SELL_BLOCK, 4) void k_spmv_pat(
     const unsigned char *__restrict__ pid, const unsigned *__restrict__ desc, const int *__restrict__ delta,
@@ -315,6 +317,10 @@ __global__ __launch_bounds__(SELL_BLOCK, 4) void k_spmv_pat(
         d_mine[j] = e < nent ? delta[e] : 0;
         v_mine[j] = e < nent ? pval[e] : 0.0;
     }
+    // ... and this thread's share of the previous kernel's partial sums (the lazy norm of the prologue)
+    const bool pre = pin != nullptr && npin <= SHARE_K * SELL_BLOCK;   // (uniform)
+    double pshare[SHARE_K];
+    if (pre) strided_share_load<SELL_BLOCK>(pin, npin, pshare);
     const int lane = tid & (WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const XcdRange xr = xcd_range(nblk, nwg, wg);
@@ -338,7 +344,9 @@ __global__ __launch_bounds__(SELL_BLOCK, 4) void k_spmv_pat(
         }
     }
     SellCoef kc;
-    if (!sell_prologue<UPD, VT>(coef, pin, npin, slot_in, slot_out, skip_if_zero, upd, nwg, wg, red, kc, nsc)) return;
+    const double share = pre ? strided_share_sum<SELL_BLOCK>(pshare, npin) : 0.0;
+    if (!sell_prologue<UPD, VT>(coef, pin, npin, slot_in, slot_out, skip_if_zero, upd, nwg, wg, red, kc, nsc, pre, share))
+        return;
     const double sx = kc.sx, sy = kc.sy, cy = kc.cy;
     __syncthreads();
 

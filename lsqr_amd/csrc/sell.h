@@ -197,15 +197,17 @@ struct SellCoef {
 // What every workgroup of a sliced-ELL product does before its rows: the lazy coefficients from
 // the previous kernel's partial sums (spmv.h) and, with UPD, its share of the x/w update of the
 // previous iteration (vec.h UpdArgs).  false = this product is skipped.
-template <bool UPD, typename VT>
-__device__ __forceinline__ bool sell_prologue(const SpmvCoef *__restrict__ coef, const double *__restrict__ pin, int npin,
-                                              const NormSlot *__restrict__ slot_in, NormSlot *__restrict__ slot_out,
-                                              int skip_if_zero, const UpdArgs &upd, int nwg, int wg, double *red,
-                                              SellCoef &k, const NScale nsc)
+// In two halves: the coefficients ...
+__device__ __forceinline__ bool sell_coefs(const SpmvCoef *__restrict__ coef, const double *__restrict__ pin, int npin,
+                                           const NormSlot *__restrict__ slot_in, NormSlot *__restrict__ slot_out,
+                                           int skip_if_zero, int wg, double *red, SellCoef &k, double &nrm_out,
+                                           const NScale nsc, bool have_share = false, double share = 0.0)
 {
     const int tid = threadIdx.x;
-    if (pin != nullptr) {  // lazy coefficients (spmv.h)
-        const double nrm = sqrt(block_sum_all<SELL_BLOCK>(pin, npin, red)) * nsc.inv;
+    if (pin != nullptr) {  // lazy coefficients (spmv.h); `share`: this thread's part of the partials, already summed
+        const double nrm = sqrt(have_share ? block_sum_all_share<SELL_BLOCK>(share, red)
+                                           : block_sum_all<SELL_BLOCK>(pin, npin, red)) * nsc.inv;
+        nrm_out = nrm;
         if (skip_if_zero && !(nrm > 0.0)) {  // mode 2 is skipped when beta == 0 (:691)
             if (wg == 0 && tid == 0) {
                 slot_out->nrm = nrm;
@@ -220,35 +222,55 @@ __device__ __forceinline__ bool sell_prologue(const SpmvCoef *__restrict__ coef,
             slot_out->nrm = nrm;
             slot_out->scale = k.sx;
         }
-        if (UPD && upd.on == 2) {  // the first launch of a solve: w <- v / alpha  (src/lsqr.f90:641-644)
-            const XcdRange ur = xcd_range(upd.ugrid, nwg, wg);
-            for (int ub = (int)ur.first; ub < (int)ur.end; ub += (int)ur.stride)
-                winit_block<VT>((VT *)upd.w, (const VT *)upd.V, upd.n, k.sx, ub, upd.ugrid);
-        } else if (UPD && upd.on) {  // x/w update of the previous iteration (vec.h UpdArgs)
-            const double beta = slot_in->nrm;
-            double alpha = nrm, sv = k.sx;
-            if (!(beta > 0.0)) {  // mode 2 was skipped (src/lsqr.f90:691): alpha, v unchanged
-                alpha = upd.alpha_prev->nrm;
-                sv = upd.alpha_prev->scale;
-            }
-            const LsqrState *ust = upd.st;
-            const Rot rt = rot_step(ust->rhobar2[upd.par], ust->phibar2[upd.par], ust->damp, ust->damped, alpha, beta);
-            const bool wantse = ust->wantse != 0;
-            // XCD-contiguous blocks, like the rows below: the slice of V this XCD updates from is
-            // the slice its rows gather from (one trip from beyond L2 instead of two)
-            const XcdRange ur = xcd_range(upd.ugrid, nwg, wg);
-            for (int ub = (int)ur.first; ub < (int)ur.end; ub += (int)ur.stride) {
-                const double tot = update_block<VT>((VT *)upd.x, (VT *)upd.w, (const VT *)upd.V, (VT *)upd.se, upd.n, rt.t1,
-                                                    rt.t2, rt.t3, sv, wantse, ub, upd.ugrid, red);
-                if (tid == 0) upd.pout[ub] = tot;
-            }
-        }
         return true;
     }
+    nrm_out = 0.0;
     if (coef->skip != 0) return false;
     k.sx = coef->sx;
     k.sy = coef->sy;
     k.cy = coef->cy;
+    return true;
+}
+// ... and the update a lazy launch carries (nothing for an explicit-coefficient launch)
+template <bool UPD, typename VT>
+__device__ __forceinline__ void sell_update(bool lazy, const NormSlot *__restrict__ slot_in, const UpdArgs &upd, int nwg,
+                                            int wg, double *red, double nrm, double sx)
+{
+    if (!UPD || !lazy) return;
+    const int tid = threadIdx.x;
+    if (upd.on == 2) {  // the first launch of a solve: w <- v / alpha  (src/lsqr.f90:641-644)
+        const XcdRange ur = xcd_range(upd.ugrid, nwg, wg);
+        for (int ub = (int)ur.first; ub < (int)ur.end; ub += (int)ur.stride)
+            winit_block<VT>((VT *)upd.w, (const VT *)upd.V, upd.n, sx, ub, upd.ugrid);
+    } else if (upd.on) {  // x/w update of the previous iteration (vec.h UpdArgs)
+        const double beta = slot_in->nrm;
+        double alpha = nrm, sv = sx;
+        if (!(beta > 0.0)) {  // mode 2 was skipped (src/lsqr.f90:691): alpha, v unchanged
+            alpha = upd.alpha_prev->nrm;
+            sv = upd.alpha_prev->scale;
+        }
+        const LsqrState *ust = upd.st;
+        const Rot rt = rot_step(ust->rhobar2[upd.par], ust->phibar2[upd.par], ust->damp, ust->damped, alpha, beta);
+        const bool wantse = ust->wantse != 0;
+        // XCD-contiguous blocks, like the rows below: the slice of V this XCD updates from is
+        // the slice its rows gather from (one trip from beyond L2 instead of two)
+        const XcdRange ur = xcd_range(upd.ugrid, nwg, wg);
+        for (int ub = (int)ur.first; ub < (int)ur.end; ub += (int)ur.stride) {
+            const double tot = update_block<VT>((VT *)upd.x, (VT *)upd.w, (const VT *)upd.V, (VT *)upd.se, upd.n, rt.t1,
+                                                rt.t2, rt.t3, sv, wantse, ub, upd.ugrid, red);
+            if (tid == 0) upd.pout[ub] = tot;
+        }
+    }
+}
+template <bool UPD, typename VT>
+__device__ __forceinline__ bool sell_prologue(const SpmvCoef *__restrict__ coef, const double *__restrict__ pin, int npin,
+                                              const NormSlot *__restrict__ slot_in, NormSlot *__restrict__ slot_out,
+                                              int skip_if_zero, const UpdArgs &upd, int nwg, int wg, double *red,
+                                              SellCoef &k, const NScale nsc, bool have_share = false, double share = 0.0)
+{
+    double nrm;
+    if (!sell_coefs(coef, pin, npin, slot_in, slot_out, skip_if_zero, wg, red, k, nrm, nsc, have_share, share)) return false;
+    sell_update<UPD, VT>(pin != nullptr, slot_in, upd, nwg, wg, red, nrm, k.sx);
     return true;
 }
 
