@@ -464,6 +464,9 @@ __device__ __forceinline__ double sellp_add(double sum, const uint4 q, int k0, i
 //     system with 40 MB of product requests right behind a kernel boundary that is still writing the previous
 //     kernel's output back, and the prologue -- which the fused update and every row sum wait for -- ends
 //     later.  Not kept.
+//   * (after pat.h) the slice descriptors two trips ahead, the first record of a slice one trip ahead -- in front of
+//     or behind the current trip's gathers -- and this thread's share of the partial sums requested at the top: the
+//     product alone 7.7 -> 8.5 us, the solve 40.2k -> 37.1k iterations/s (profiles/r03/config2_patterns.txt).  Not kept.
 template <bool UPD, typename VT = double>
 __global__ __launch_bounds__(SELL_BLOCK, 6) void k_spmv_sellp(
     const unsigned *__restrict__ roff, const uint4 *__restrict__ rec, const int *__restrict__ cbaseS,
