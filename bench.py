@@ -195,8 +195,11 @@ def product_roofline(s, facts, reps, traffic=None):
             "effective_gbps": alg1 / (avg1 * 1e-3) / 1e9, "effective_bytes_per_launch": alg1,
             "effective_is": "SURVEY 8d algorithmic bytes (8-byte values, 4-byte columns, row pointers) / the same time; "
                             "exceeds the physical rate whenever the layout compresses -- not a roofline fraction",
-            "format": {"layout": layout, "value_bytes": info["value_bytes"], "col_bytes": info["col_bytes"],
-                       "dict_entries": info["dict_entries"]},
+            "format": ({"layout": layout, "row_bytes": 1, "value_bytes": 0, "col_bytes": 0,
+                        "note": "one pattern number per row; the distinct rows (<= 256, <= 1024 entries) live in LDS"}
+                       if info["sell"] == 3 else
+                       {"layout": layout, "value_bytes": info["value_bytes"], "col_bytes": info["col_bytes"],
+                        "dict_entries": info["dict_entries"]}),
             "resident": ("infinity cache (iteration working set %.0f MB < 256 MB: 'HBM' bytes are fabric requests "
                          "that may be served on-die)" % (wset / 1e6)) if wset < INFINITY_CACHE else
                         "hbm (iteration working set %.1f GB)" % (wset / 1e9)}

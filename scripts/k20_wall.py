@@ -14,6 +14,9 @@ s.atol = s.btol = s.conlim = 0.0
 s.set_option("graph_iters", min(K + (K & 1), 50))
 for _ in range(8):
     bench.timed_solve(s, d_b, d_x, facts["damp"], K)
-ts = sorted(bench.timed_solve(s, d_b, d_x, facts["damp"], K)[0] for _ in range(60))
+raw = [bench.timed_solve(s, d_b, d_x, facts["damp"], K)[0] for _ in range(60)]
+if os.environ.get("K20_RAW"):
+    print("in order, us:", " ".join(f"{1e6*t:.0f}" for t in raw), flush=True)
+ts = sorted(raw)
 env = " ".join(f"{k[8:]}={v}" for k, v in sorted(os.environ.items()) if k.startswith("LSQRHIP_"))
 print(f"K={K} [{env:24s}] median {1e6*ts[len(ts)//2]:7.1f} us  min {1e6*ts[0]:7.1f} us  -> {K/ts[len(ts)//2]:8.0f} it/s", flush=True)

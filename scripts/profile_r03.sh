@@ -7,13 +7,15 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/r03
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-run() {   # tag, env assignment or "-", bench args...
+setenvs() { if [ "$1" != "-" ]; then for e in ${1//,/ }; do export $e; done; fi; }     # "A=1,B=2" or "-"
+unsetenvs() { if [ "$1" != "-" ]; then for e in ${1//,/ }; do unset ${e%%=*}; done; fi; }
+run() {   # tag, env assignments ("A=1,B=2") or "-", bench args...
   local tag=$1 envs=$2; shift 2
   local d=$OUT/$tag
   rm -rf "$d"; mkdir -p "$d"
-  if [ "$envs" != "-" ]; then export $envs; fi
+  setenvs "$envs"
   timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$d/trace" -o t -- python3 "$R/bench.py" "$@" --traffic off --cpu-iters 0 > "$d/bench.json" 2> "$d/err.txt"
-  if [ "$envs" != "-" ]; then unset ${envs%%=*}; fi
+  unsetenvs "$envs"
   local f=$(find "$d/trace" -name "*kernel_stats.csv" | head -1)
   {
     echo "# $tag: rocprofv3 --kernel-trace --stats -- python3 bench.py $* --traffic off --cpu-iters 0   ${envs}"
@@ -42,9 +44,9 @@ roof() {   # tag, env assignment or "-", workload
   local tag=$1 envs=$2 spec=$3
   local d=$OUT/${tag}_roofline
   rm -rf "$d"; mkdir -p "$d"
-  if [ "$envs" != "-" ]; then export $envs; fi
+  setenvs "$envs"
   timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$d/trace" -o t -- python3 "$R/bench.py" --workload $spec --roofline-only > "$d/bench.json" 2> "$d/err.txt"
-  if [ "$envs" != "-" ]; then unset ${envs%%=*}; fi
+  unsetenvs "$envs"
   local f=$(find "$d/trace" -name "*kernel_stats.csv" | head -1)
   {
     echo "# ${tag}_roofline: rocprofv3 --kernel-trace --stats -- python3 bench.py --workload $spec --roofline-only   ${envs}"
@@ -60,15 +62,19 @@ PY
   } > "$OUT/${tag}_roofline.txt"
   cat "$OUT/${tag}_roofline.txt"
 }
-TAGS=${*:-"config2 poisson4000_dict poisson4000_val8 config4 shard8 config3_100 config5"}
+TAGS=${*:-"config2 config2_packed poisson4000_pat poisson4000_dict poisson4000_val8 config4 shard8 config3_100 config5"}
 for t in $TAGS; do
   case $t in
     config2)          run config2_poisson1000 - --workload poisson2d:1000:1000 --extras off --steps 2000 --warmup 200
                       roof config2_poisson1000 - poisson2d:1000:1000 ;;
-    poisson4000_dict) run poisson4000_dict - --workload poisson2d:4000:4000 --steps 200 --warmup 20
-                      roof poisson4000_dict - poisson2d:4000:4000 ;;
-    poisson4000_val8) run poisson4000_val8 LSQRHIP_VAL8=0 --workload poisson2d:4000:4000 --steps 200 --warmup 20
-                      roof poisson4000_val8 LSQRHIP_VAL8=0 poisson2d:4000:4000 ;;
+    config2_packed)   run config2_packed_records LSQRHIP_PAT=0 --workload poisson2d:1000:1000 --extras off --steps 2000 --warmup 200
+                      roof config2_packed_records LSQRHIP_PAT=0 poisson2d:1000:1000 ;;
+    poisson4000_pat)  run poisson4000_patterns - --workload poisson2d:4000:4000 --steps 200 --warmup 20
+                      roof poisson4000_patterns - poisson2d:4000:4000 ;;
+    poisson4000_dict) run poisson4000_dict LSQRHIP_PAT=0 --workload poisson2d:4000:4000 --steps 200 --warmup 20
+                      roof poisson4000_dict LSQRHIP_PAT=0 poisson2d:4000:4000 ;;
+    poisson4000_val8) run poisson4000_val8 LSQRHIP_PAT=0,LSQRHIP_VAL8=0 --workload poisson2d:4000:4000 --steps 200 --warmup 20
+                      roof poisson4000_val8 LSQRHIP_PAT=0,LSQRHIP_VAL8=0 poisson2d:4000:4000 ;;
     config4)          run config4_random_10Mx10Mx100 - --workload random:10000000:10000000:100 --steps 20 --warmup 2
                       roof config4_random_10Mx10Mx100 - random:10000000:10000000:100 ;;
     shard8)           run shard8_random_1250000x10Mx100 - --workload random:1250000:10000000:100 --steps 40 --warmup 4
