@@ -397,8 +397,12 @@ def run_single(args):
     # setup, untimed: the graphs of this batch size are captured and instantiated by the first solve, and the
     # interpreter and the device clocks settle over a few more (a 20-iteration solve is 0.6 ms of device work:
     # the first timed call after an idle start otherwise measures the ramp, +6 %)
-    for _ in range(3):
+    # ... a 20-iteration solve still speeds up by 4 % over its first ~30 repeats, profiles/r03/perf_misc.txt): at
+    # least 3 solves and at least 60 ms of them
+    t_warm, n_warm = time.perf_counter(), 0
+    while n_warm < 3 or (time.perf_counter() - t_warm < 0.06 and n_warm < 400):
         timed_solve(s, d_b, d_x, facts["damp"], min(K, 100))
+        n_warm += 1
     if W > 0:                                   # the W warm-up steps of the contract, through the timed path
         timed_solve(s, d_b, d_x, facts["damp"], W)
     dt, r, restarts, loop_ms = timed_solve(s, d_b, d_x, facts["damp"], K)
