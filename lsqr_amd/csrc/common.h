@@ -102,8 +102,7 @@ __device__ __forceinline__ double block_sum_all(const double *__restrict__ p, in
 
 // block_sum_all for a caller that requested its share of the partials itself (strided_share_load): the loads were
 // issued early, among other requests, and are summed here in strided_sum's order -- the same bits.
-constexpr int SHARE_K = 4;
-template <int BLOCK>
+template <int BLOCK, int SHARE_K>
 __device__ __forceinline__ void strided_share_load(const double *__restrict__ p, int np, double (&v)[SHARE_K])
 {
     const int t = threadIdx.x;
@@ -114,7 +113,7 @@ __device__ __forceinline__ void strided_share_load(const double *__restrict__ p,
         v[k] = p[i < last ? i : last];
     }
 }
-template <int BLOCK>
+template <int BLOCK, int SHARE_K>
 __device__ __forceinline__ double strided_share_sum(const double (&v)[SHARE_K], int np)
 {
     double s = 0.0;

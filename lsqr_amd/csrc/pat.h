@@ -43,6 +43,7 @@ constexpr int PAT_MAX_LEN = 64;    // nonzeros of a row
 constexpr int PAT_TAB = 1024;      // slots of the discovery table
 constexpr int PAT_K = 5;           // entries in flight per lane and slice
 constexpr int PAT_U = 2;           // slices a wave takes through the chain together
+constexpr int PAT_SHARE_K = 4;     // partial sums of the previous kernel per thread requested at the top (<= 1024 of them)
 constexpr int PAT_MAX_GRID = 1024; // 4 workgroups per CU x 256 CUs (lsqrhip.hip)
 
 __device__ __forceinline__ unsigned long long pat_mix(unsigned long long h, unsigned long long v)
@@ -318,9 +319,9 @@ __global__ __launch_bounds__(SELL_BLOCK, 4) void k_spmv_pat(
         v_mine[j] = e < nent ? pval[e] : 0.0;
     }
     // ... and this thread's share of the previous kernel's partial sums (the lazy norm of the prologue)
-    const bool pre = pin != nullptr && npin <= SHARE_K * SELL_BLOCK;   // (uniform)
-    double pshare[SHARE_K];
-    if (pre) strided_share_load<SELL_BLOCK>(pin, npin, pshare);
+    const bool pre = pin != nullptr && npin <= PAT_SHARE_K * SELL_BLOCK;   // (uniform)
+    double pshare[PAT_SHARE_K];
+    if (pre) strided_share_load<SELL_BLOCK, PAT_SHARE_K>(pin, npin, pshare);
     const int lane = tid & (WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const XcdRange xr = xcd_range(nblk, nwg, wg);
@@ -344,7 +345,7 @@ __global__ __launch_bounds__(SELL_BLOCK, 4) void k_spmv_pat(
         }
     }
     SellCoef kc;
-    const double share = pre ? strided_share_sum<SELL_BLOCK>(pshare, npin) : 0.0;
+    const double share = pre ? strided_share_sum<SELL_BLOCK, PAT_SHARE_K>(pshare, npin) : 0.0;
     if (!sell_prologue<UPD, VT>(coef, pin, npin, slot_in, slot_out, skip_if_zero, upd, nwg, wg, red, kc, nsc, pre, share))
         return;
     const double sx = kc.sx, sy = kc.sy, cy = kc.cy;

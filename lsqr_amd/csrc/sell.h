@@ -44,6 +44,7 @@ constexpr int SELL_BLOCK = 256;                 // 4 slices per workgroup trip
 constexpr int SELL_SLICES = SELL_BLOCK / WAVE;
 constexpr int SELL_MAX_W = 64;
 constexpr int SELL_MAX_GRID = 1536;             // 6 workgroups per CU x 256 CUs (lsqrhip.hip)
+constexpr int SELL_SHARE_K = 6;                 // partial sums per thread requested at the top (<= 1536 of them)
 constexpr int SELLP_K = 5;                      // nonzeros per 16-byte record of the packed layout
 
 // width64[s] = 64 * W_s (elements of slice s); stats[0] += 64 W_s, stats[1] = max W,
@@ -294,12 +295,19 @@ __global__ __launch_bounds__(SELL_BLOCK, 8) void k_spmv_sell(
         run_rider(rider, red);
         return;
     }
+    // this thread's share of the previous kernel's partial sums, requested with the stop flag (pat.h)
+    const bool pre = pin != nullptr && npin <= SELL_SHARE_K * SELL_BLOCK;   // (uniform)
+    double pshare[SELL_SHARE_K];
+    if (pre) strided_share_load<SELL_BLOCK, SELL_SHARE_K>(pin, npin, pshare);
+#endif
     if (*stop != 0) return;
     const int tid = threadIdx.x;
     if (V8) sdict[tid] = dict[tid];  // visible after the first barrier below
 
     SellCoef kc;
-    if (!sell_prologue<UPD, VT>(coef, pin, npin, slot_in, slot_out, skip_if_zero, upd, nwg, wg, red, kc, nsc)) return;
+    const double share = pre ? strided_share_sum<SELL_BLOCK, SELL_SHARE_K>(pshare, npin) : 0.0;
+    if (!sell_prologue<UPD, VT>(coef, pin, npin, slot_in, slot_out, skip_if_zero, upd, nwg, wg, red, kc, nsc, pre, share))
+        return;
     const double sx = kc.sx, sy = kc.sy, cy = kc.cy;
     if (V8) __syncthreads();
 
@@ -486,6 +494,9 @@ __global__ __launch_bounds__(SELL_BLOCK, 6) void k_spmv_sellp(
     }
     const int tid = threadIdx.x;
     const double dict_mine = dict[tid];  // (requested here, stored below: one round trip with the stop flag's)
+    const bool pre = pin != nullptr && npin <= SELL_SHARE_K * SELL_BLOCK;   // (uniform)
+    double pshare[SELL_SHARE_K];
+    if (pre) strided_share_load<SELL_BLOCK, SELL_SHARE_K>(pin, npin, pshare);
     const int lane = tid & (WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: the slice descriptors arrive in SGPRs
     const XcdRange xr = xcd_range(nblk, nwg, wg);
@@ -494,7 +505,10 @@ __global__ __launch_bounds__(SELL_BLOCK, 6) void k_spmv_sellp(
     sdict[tid] = dict_mine;   // visible after the barrier below
 
     SellCoef kc;
-    if (!sell_prologue<UPD, VT>(coef, pin, npin, slot_in, slot_out, skip_if_zero, upd, nwg, wg, red, kc, nsc)) return;
+#if SELL_SHARE
+    const double share = pre ? strided_share_sum<SELL_BLOCK, SELL_SHARE_K>(pshare, npin) : 0.0;
+    if (!sell_prologue<UPD, VT>(coef, pin, npin, slot_in, slot_out, skip_if_zero, upd, nwg, wg, red, kc, nsc, pre, share))
+        return;
     const double sx = kc.sx, sy = kc.sy, cy = kc.cy;
     __syncthreads();
 
