@@ -295,11 +295,11 @@ __global__ __launch_bounds__(SELL_BLOCK, 8) void k_spmv_sell(
         run_rider(rider, red);
         return;
     }
-    // this thread's share of the previous kernel's partial sums, requested with the stop flag (pat.h)
+    // this thread's share of the previous kernel's partial sums, requested with the stop flag (as in pat.h: packed
+    // records 40.3k -> 41.7k it/s at configs[1], 8-byte values 28.7k -> 29.2k; profiles/r03/config2_patterns.txt)
     const bool pre = pin != nullptr && npin <= SELL_SHARE_K * SELL_BLOCK;   // (uniform)
     double pshare[SELL_SHARE_K];
     if (pre) strided_share_load<SELL_BLOCK, SELL_SHARE_K>(pin, npin, pshare);
-#endif
     if (*stop != 0) return;
     const int tid = threadIdx.x;
     if (V8) sdict[tid] = dict[tid];  // visible after the first barrier below
@@ -494,8 +494,8 @@ __global__ __launch_bounds__(SELL_BLOCK, 6) void k_spmv_sellp(
     }
     const int tid = threadIdx.x;
     const double dict_mine = dict[tid];  // (requested here, stored below: one round trip with the stop flag's)
-    const bool pre = pin != nullptr && npin <= SELL_SHARE_K * SELL_BLOCK;   // (uniform)
-    double pshare[SELL_SHARE_K];
+    const bool pre = pin != nullptr && npin <= SELL_SHARE_K * SELL_BLOCK;   // (uniform) ... and so is this thread's
+    double pshare[SELL_SHARE_K];                                             // share of the partial sums
     if (pre) strided_share_load<SELL_BLOCK, SELL_SHARE_K>(pin, npin, pshare);
     const int lane = tid & (WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: the slice descriptors arrive in SGPRs
@@ -505,7 +505,6 @@ __global__ __launch_bounds__(SELL_BLOCK, 6) void k_spmv_sellp(
     sdict[tid] = dict_mine;   // visible after the barrier below
 
     SellCoef kc;
-#if SELL_SHARE
     const double share = pre ? strided_share_sum<SELL_BLOCK, SELL_SHARE_K>(pshare, npin) : 0.0;
     if (!sell_prologue<UPD, VT>(coef, pin, npin, slot_in, slot_out, skip_if_zero, upd, nwg, wg, red, kc, nsc, pre, share))
         return;
