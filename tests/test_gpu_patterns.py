@@ -146,6 +146,41 @@ def test_matrices_without_repeating_rows_keep_their_layout():
             assert lsqr_solver_ez().initialize(m, n, a, irow, icol).info()["sell"] == want
 
 
+def grid3d(nx, ny, nz, radius_taps):
+    """Row (i, j, k) of an nx x ny x nz grid: one entry per tap (di, dj, dk) that stays inside the grid, value a
+    function of the tap only (constant coefficients), taps in a fixed order."""
+    taps = [(di, dj, dk) for dk in (-1, 0, 1) for dj in (-1, 0, 1) for di in (-1, 0, 1)
+            if abs(di) + abs(dj) + abs(dk) <= radius_taps]
+    idx = np.arange(nx * ny * nz)
+    i, j, k = idx % nx, (idx // nx) % ny, idx // (nx * ny)
+    rows, cols, vals = [], [], []
+    for t, (di, dj, dk) in enumerate(taps):
+        ok = (i + di >= 0) & (i + di < nx) & (j + dj >= 0) & (j + dj < ny) & (k + dk >= 0) & (k + dk < nz)
+        rows.append(np.where(ok, idx, -1)); cols.append(idx + di + nx * dj + nx * ny * dk)
+        vals.append(np.full(idx.size, 26.0 if (di, dj, dk) == (0, 0, 0) else -1.0 / (1 + abs(di) + abs(dj) + abs(dk)) - 0.001 * t))
+    rows = np.stack(rows, axis=1).ravel(); cols = np.stack(cols, axis=1).ravel(); vals = np.stack(vals, axis=1).ravel()
+    keep = rows >= 0
+    m = idx.size
+    return m, m, (rows[keep] + 1).astype(np.int32), (cols[keep] + 1).astype(np.int32), vals[keep], _vec(7, m), len(taps)
+
+
+@pytest.mark.parametrize("taps", [1, 3])
+def test_three_dimensional_stencils(taps):
+    """7-point (radius 1 in the 1-norm) and 27-point operators on a 3-D grid: 27 boundary variants each, 343 pattern
+    entries for the 27-point one; unsymmetric values, so A' has patterns of its own."""
+    m, n, irow, icol, a, b, ntaps = grid3d(24, 19, 17, taps)
+    assert ntaps == (7 if taps == 1 else 27)
+    check_against_oracle(m, n, irow, icol, a, b, itnlim=12)
+
+
+def test_a_convolution_of_31_taps():
+    """Banded Toeplitz: y = k * x with a 31-tap kernel, zero boundary -- 31 patterns, ~730 entries."""
+    offs = tuple(range(-15, 16))
+    vals = tuple(np.exp(-0.02 * o * o) * (1.0 + 0.1 * np.sin(o)) for o in offs)
+    m, n, irow, icol, a, b = stencil(30000, 30000, offs, vals)
+    check_against_oracle(m, n, irow, icol, a, b, damp=1e-3, itnlim=10)
+
+
 def test_limits_rows_per_pattern_entries_and_row_length():
     # 3 x 3 dense (README example): three patterns for three rows -- only when forced
     p, o = CASES["t1_readme_damped"]
