@@ -223,3 +223,13 @@ def test_real32_patterns():
     s0 = lsqr_solver_ez().initialize(p.m, p.n, a32, p.irow, p.icol, itnlim=30, real32=True)
     r, r0 = s.solve(b32, 0.0), s0.solve(b32, 0.0)
     assert np.array_equal(r.x, r0.x) and r.itn == r0.itn and r.anorm == r0.anorm
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_the_golden_parity_cases_with_patterns_forced(name):
+    """Every case of tests/test_gpu_parity.py once more with LSQRHIP_PAT=1: whatever has <= 256 distinct rows of <= 64
+    nonzeros and <= 1024 entries -- most of the small systems: every row its own pattern -- goes through the pattern
+    kernel and must hold the same golden values; the others keep their layout."""
+    import test_gpu_parity as tp
+    os.environ["LSQRHIP_PAT"] = "1"
+    tp.test_solve_parity_vs_reference_golden(name)
