@@ -211,7 +211,7 @@ struct PatTrip {
 template <typename VT>
 __device__ __forceinline__ void pat_issue(PatTrip &t, int64_t b, const XcdRange &xr, int wave, int lane, int rows,
                                           const int (&pidc)[PAT_U], const unsigned *sdesc, const int *sdelta,
-                                          const double *sval, const VT *__restrict__ x, const VT *__restrict__ y)
+                                          const double *sval, const VT *__restrict__ x, const VT *y)
 {
 #pragma unroll
     for (int u = 0; u < PAT_U; ++u) {
