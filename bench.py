@@ -203,6 +203,11 @@ def product_roofline(s, facts, reps, traffic=None):
             "resident": ("infinity cache (iteration working set %.0f MB < 256 MB: 'HBM' bytes are fabric requests "
                          "that may be served on-die)" % (wset / 1e6)) if wset < INFINITY_CACHE else
                         "hbm (iteration working set %.1f GB)" % (wset / 1e9)}
+    if info["sell"] == 3 and avg1 * 1e3 < 20.0:
+        roof["frac_is"] = ("a launch-latency figure: this launch lives %.1f us and moves %.0f MB -- a chain of dependent round "
+                           "trips (DESIGN.md 3.4b), not a stream; the same kernel on an HBM-resident instance is "
+                           "roofline_hbm[0], the layout it replaced at this size read 0.64 and was 17 %% slower per "
+                           "iteration" % (avg1 * 1e3, lay1 / 1e6))
     if frac > 1.0:      # physical bytes faster than HBM can deliver them: the working set is served by a cache
         roof["bound"] = "cache"
         roof["frac_exceeds_hbm_peak"] = True
