@@ -49,8 +49,10 @@ INFINITY_CACHE = 256 << 20
 HEADLINE = "poisson2d:1000:1000"
 HBM_INSTANCES = [("poisson2d:4000:4000", {}, "row patterns (what the build chooses for a constant-coefficient stencil)"),
                  ("poisson2d:4000:4000", {"LSQRHIP_PAT": "0"}, "packed records: value dictionary (1-byte codes), 16-bit columns"),
+                 ("poisson2d:4000:4000", {"LSQRHIP_PAT": "0", "LSQRHIP_VAL8": "0", "LSQRHIP_SPAT": "0"},
+                  "sliced ELL: 8-byte values, 16-bit columns (matrices without a repeating structure)"),
                  ("poisson2d:4000:4000", {"LSQRHIP_PAT": "0", "LSQRHIP_VAL8": "0"},
-                  "8-byte values, 16-bit columns (what a variable-coefficient stencil gets)")]
+                  "structure patterns: 8-byte values, no column indices (what a variable-coefficient stencil gets)")]
 PRODUCT_KERNELS = ("k_spmv_", "k_panel_combine", "k_csb_combine", "k_csb_xmax")
 
 
@@ -154,6 +156,8 @@ def build_workload(spec: str, env=None, itnlim=100, rows=None):
 
 
 def describe_layout(info):
+    if info["sell"] == 4:
+        return "structure patterns (one byte per row + 8-byte values, column offsets in LDS)", "k_spmv_spat"
     if info["sell"] == 3:
         return "row patterns (one byte per row, patterns in LDS)", "k_spmv_pat"
     if info["sell"] == 2:

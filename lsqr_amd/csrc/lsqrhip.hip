@@ -137,7 +137,7 @@ struct Csr {
     unsigned char *val8 = nullptr;   // one-byte codes into dict (valdict.h) ...
     const double *dict = nullptr;    // ... the handle's dictionary (not owned)
     // sliced-ELL layout (sell.h), used instead of the arrays above when `sell` is set
-    int sell = 0;                    // 1 = column-major slices, 2 = packed 16-byte records (sell.h), 3 = row patterns (pat.h)
+    int sell = 0;                    // 1 = column-major slices, 2 = packed 16-byte records (sell.h), 3 = row patterns, 4 = structure patterns (pat.h)
     unsigned char *pid = nullptr;    // sell = 3: [rows] pattern of each row ...
     unsigned *pdesc = nullptr;       // ... [PAT_MAX] first entry | length << 16 of each pattern
     int *pdelta = nullptr;           // ... [PAT_MAX_E] column - row of each entry
@@ -428,10 +428,12 @@ static void launch_scan_small(hipStream_t s, unsigned *a, int64_t L)
 
 // Row patterns (pat.h): a matrix with <= 256 distinct rows keeps one byte per row.  On success out.sell = 3 and the
 // CSR arrays col / val are released; otherwise `out` is left as it was.
-static int try_pat(hipStream_t s, Csr &out, int64_t nnz)
+static int try_pat(hipStream_t s, Csr &out, int64_t nnz, bool vals, unsigned long long *stats)
 {
     const int rows = out.rows;
-    const int mode = env_int("LSQRHIP_PAT", -1);
+    // vals = false: structure patterns (pat.h "sell = 4") -- the column structure of the rows repeats, their values
+    // do not; LSQRHIP_SPAT=0 never, =1 whenever the limits hold
+    const int mode = vals ? env_int("LSQRHIP_PAT", -1) : env_int("LSQRHIP_SPAT", -1);
     if (out.P > 1 || nnz <= 0 || rows <= 0 || mode == 0) return LSQRHIP_OK;
     if (nnz > (int64_t)PAT_MAX_LEN * rows) return LSQRHIP_OK;
     DevScratch s_keys, s_reps, s_slot, s_ctl, s_desc, s_delta, s_val, s_pid;
@@ -445,7 +447,8 @@ static int try_pat(hipStream_t s, Csr &out, int64_t nnz)
     const int g = (int)std::min<int64_t>(((int64_t)rows + 255) / 256, 2048);
     int *ctl = s_ctl.as<int>();
     hipLaunchKernelGGL(k_pat_discover, dim3(g), dim3(256), 0, s, (const int *)out.rowptr, (const int *)out.col,
-                       (const double *)out.val, rows, s_keys.as<unsigned long long>(), s_reps.as<int>(), ctl);
+                       (const double *)out.val, rows, vals ? 1 : 0, s_keys.as<unsigned long long>(), s_reps.as<int>(),
+                       ctl);
     HIPCHK(hipGetLastError());
     int got[4];
     HIPCHK(hipMemcpyAsync(got, ctl, sizeof(got), hipMemcpyDeviceToHost, s));
@@ -459,16 +462,58 @@ static int try_pat(hipStream_t s, Csr &out, int64_t nnz)
     HIPCHK(hipMemsetAsync(s_delta.p, 0, sizeof(int) * PAT_MAX_E, s));
     HIPCHK(hipMemsetAsync(s_val.p, 0, sizeof(double) * PAT_MAX_E, s));
     hipLaunchKernelGGL(k_pat_table, dim3(1), dim3(PAT_TAB), 0, s, (const int *)out.rowptr, (const int *)out.col,
-                       (const double *)out.val, (const unsigned long long *)s_keys.p, (const int *)s_reps.p,
+                       (const double *)out.val, vals ? 1 : 0, (const unsigned long long *)s_keys.p, (const int *)s_reps.p,
                        s_slot.as<int>(), s_desc.as<unsigned>(), s_delta.as<int>(), s_val.as<double>(), ctl);
     hipLaunchKernelGGL(k_pat_assign, dim3(g), dim3(256), 0, s, (const int *)out.rowptr, (const int *)out.col,
-                       (const double *)out.val, rows, (const unsigned long long *)s_keys.p, (const int *)s_slot.p,
+                       (const double *)out.val, rows, vals ? 1 : 0, (const unsigned long long *)s_keys.p,
+                       (const int *)s_slot.p,
                        (const unsigned *)s_desc.p, (const int *)s_delta.p, (const double *)s_val.p,
                        s_pid.as<unsigned char>(), ctl);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(got, ctl, sizeof(got), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     if (got[1] != 0) return LSQRHIP_OK;   // too many entries, or two different rows under one key
+    if (!vals) {   // structure patterns: the values stay, column-major per 64-row slice (sell.h's slices)
+        const int nslices = (rows + 63) / 64;
+        const unsigned gr = (unsigned)(((int64_t)nslices * 64 + 255) / 256);
+        DevScratch s_off, s_sv;
+        HIPCHK(s_off.alloc(sizeof(unsigned) * ((size_t)nslices + 1)));
+        unsigned *soff = s_off.as<unsigned>();
+        HIPCHK(hipMemsetAsync(stats, 0, 4 * sizeof(unsigned long long), s));
+        HIPCHK(hipMemsetAsync(soff + nslices, 0, sizeof(unsigned), s));
+        hipLaunchKernelGGL(k_sell_width, dim3(gr), dim3(256), 0, s, (const int *)out.rowptr, rows, nslices, soff, stats);
+        HIPCHK(hipGetLastError());
+        unsigned long long st[4];
+        HIPCHK(hipMemcpyAsync(st, stats, sizeof(st), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        const unsigned long long padded = st[0];
+        if (padded > (unsigned long long)(nnz + nnz / 8 + 4096) || padded >= (1ull << 31)) return LSQRHIP_OK;
+        launch_scan_small(s, soff, (int64_t)nslices + 1);
+        const size_t np = (size_t)std::max<unsigned long long>(padded, 1);
+        HIPCHK(s_sv.alloc(np * sizeof(double)));
+        hipLaunchKernelGGL(k_spat_fill, dim3(gr), dim3(256), 0, s, (const int *)out.rowptr, (const double *)out.val,
+                           (const unsigned *)soff, rows, nslices, s_sv.as<double>());
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(s));
+        (void)hipFree(out.col);
+        (void)hipFree(out.val);
+        out.col = nullptr;
+        out.val = nullptr;
+        out.sell = 4;
+        out.pid = s_pid.release<unsigned char>();
+        out.pdesc = s_desc.release<unsigned>();
+        out.pdelta = s_delta.release<int>();
+        out.npat = got[2];
+        out.npat_e = got[3];
+        out.soff = s_off.release<unsigned>();
+        out.sval = s_sv.release<void>();
+        out.nslices = nslices;
+        out.nblk = (nslices + SELL_SLICES - 1) / SELL_SLICES;
+        out.nstored = (int64_t)np;
+        // what one product reads of the matrix: the values, a byte per row, the slice offsets and the table
+        out.bytes = (int64_t)padded * 8 + rows + (int64_t)nslices * 4 + 4 + (int64_t)sizeof(unsigned) * PAT_MAX + 4ll * got[3];
+        return LSQRHIP_OK;
+    }
     (void)hipFree(out.col);
     (void)hipFree(out.val);
     out.col = nullptr;
@@ -669,7 +714,9 @@ static int build_csr_T(hipStream_t s, const int *d_keys, const int *d_other, con
 
     // short, even rows: sliced-ELL layout instead of row windows (sell.h)
     if (std::is_same<OffT, int>::value) {
-        int rcs = try_pat(s, out, nnz);   // rows that repeat: one byte per row (pat.h)
+        int rcs = try_pat(s, out, nnz, true, (unsigned long long *)hist);   // rows that repeat: one byte per row (pat.h)
+        // ... rows whose column structure repeats, without a value dictionary: no column indices (pat.h)
+        if (rcs == LSQRHIP_OK && !out.sell && ndict == 0) rcs = try_pat(s, out, nnz, false, (unsigned long long *)hist);
         if (rcs == LSQRHIP_OK && !out.sell) rcs = try_sell(s, out, nnz, dict, ndict, (unsigned long long *)hist);
         if (rcs != LSQRHIP_OK) return rcs;
     }
@@ -1139,7 +1186,7 @@ static int build_dictionary(H *h, const double *d_a, unsigned long long *table, 
 // exactly converted inputs; dictionary codes stay codes, the 256-entry table stays binary64).
 static int values_to_f32(H *h, Csr &c)
 {
-    double **slot = c.csb ? &c.cval : (c.sell == 1 && !c.sell_v8 ? (double **)&c.sval : (!c.sell && c.val ? &c.val : nullptr));
+    double **slot = c.csb ? &c.cval : (((c.sell == 1 && !c.sell_v8) || c.sell == 4) ? (double **)&c.sval : (!c.sell && c.val ? &c.val : nullptr));
     if (!slot || !*slot || c.nstored <= 0) return LSQRHIP_OK;
     float *f = nullptr;
     HIPCHK(hipMalloc((void **)&f, sizeof(float) * (size_t)c.nstored));

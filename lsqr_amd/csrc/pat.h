@@ -54,20 +54,21 @@ __device__ __forceinline__ unsigned long long pat_mix(unsigned long long h, unsi
     return h;
 }
 // key of row r (never 0: 0 marks an empty slot)
+// (vals = 0: the key of the row's STRUCTURE alone -- length and column offsets -- for the structure patterns below)
 __device__ __forceinline__ unsigned long long pat_row_key(const int *__restrict__ col, const double *__restrict__ val,
-                                                          int q0, int len, int r)
+                                                          int q0, int len, int r, int vals)
 {
     unsigned long long h = pat_mix(0x243f6a8885a308d3ull, (unsigned long long)len);
     for (int k = 0; k < len; ++k) {
         h = pat_mix(h, (unsigned long long)(unsigned)(col[q0 + k] - r));
-        h = pat_mix(h, (unsigned long long)__double_as_longlong(val[q0 + k]));
+        if (vals) h = pat_mix(h, (unsigned long long)__double_as_longlong(val[q0 + k]));
     }
     return h | 1ull;
 }
 
 // ctl[0] = distinct keys so far, ctl[1] = give up, ctl[2] = patterns, ctl[3] = entries (k_pat_table)
 __global__ __launch_bounds__(256) void k_pat_discover(const int *__restrict__ rowptr, const int *__restrict__ col,
-                                                      const double *__restrict__ val, int rows,
+                                                      const double *__restrict__ val, int rows, int vals,
                                                       unsigned long long *__restrict__ keys, int *__restrict__ reps,
                                                       int *__restrict__ ctl)
 {
@@ -79,7 +80,7 @@ __global__ __launch_bounds__(256) void k_pat_discover(const int *__restrict__ ro
             ctl[1] = 1;
             return;
         }
-        const unsigned long long h = pat_row_key(col, val, q0, len, (int)r);
+        const unsigned long long h = pat_row_key(col, val, q0, len, (int)r, vals);
         unsigned slot = (unsigned)(h >> 11) & (PAT_TAB - 1);
         int tries = 0;
         for (; tries < PAT_TAB; ++tries) {
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(256) void k_pat_discover(const int *__restrict__ ro
 // One workgroup of PAT_TAB threads: rank the keys (pattern p = p-th smallest key), lay the patterns out, copy each from
 // its first row.  slot_pat[slot] = pattern of the key in that slot.
 __global__ __launch_bounds__(PAT_TAB) void k_pat_table(const int *__restrict__ rowptr, const int *__restrict__ col,
-                                                       const double *__restrict__ val,
+                                                       const double *__restrict__ val, int vals,
                                                        const unsigned long long *__restrict__ keys,
                                                        const int *__restrict__ reps, int *__restrict__ slot_pat,
                                                        unsigned *__restrict__ desc, int *__restrict__ delta,
@@ -155,14 +156,14 @@ __global__ __launch_bounds__(PAT_TAB) void k_pat_table(const int *__restrict__ r
         const int rep = srep[t], q0 = rowptr[rep], e0 = sstart[t];
         for (int k = 0; k < slen[t]; ++k) {
             delta[e0 + k] = col[q0 + k] - rep;
-            pval[e0 + k] = val[q0 + k];
+            if (vals) pval[e0 + k] = val[q0 + k];
         }
     }
 }
 
 // pid[r] = pattern of row r, after comparing the row with it entry by entry (ctl[1] = 1 on any difference)
 __global__ __launch_bounds__(256) void k_pat_assign(const int *__restrict__ rowptr, const int *__restrict__ col,
-                                                    const double *__restrict__ val, int rows,
+                                                    const double *__restrict__ val, int rows, int vals,
                                                     const unsigned long long *__restrict__ keys,
                                                     const int *__restrict__ slot_pat, const unsigned *__restrict__ desc,
                                                     const int *__restrict__ delta, const double *__restrict__ pval,
@@ -171,7 +172,7 @@ __global__ __launch_bounds__(256) void k_pat_assign(const int *__restrict__ rowp
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += stride) {
         const int q0 = rowptr[r], len = rowptr[r + 1] - q0;
-        const unsigned long long h = pat_row_key(col, val, q0, len, (int)r);
+        const unsigned long long h = pat_row_key(col, val, q0, len, (int)r, vals);
         unsigned slot = (unsigned)(h >> 11) & (PAT_TAB - 1);
         int p = -1;
         for (int tries = 0; tries < PAT_TAB; ++tries) {
@@ -190,7 +191,7 @@ __global__ __launch_bounds__(256) void k_pat_assign(const int *__restrict__ rowp
             same = (int)(d >> 16) == len;
             for (int k = 0; same && k < len; ++k)
                 same = delta[e0 + k] == col[q0 + k] - (int)r &&
-                       __double_as_longlong(pval[e0 + k]) == __double_as_longlong(val[q0 + k]);
+                       (!vals || __double_as_longlong(pval[e0 + k]) == __double_as_longlong(val[q0 + k]));
         }
         if (!same) {
             ctl[1] = 1;
@@ -365,6 +366,115 @@ __global__ __launch_bounds__(SELL_BLOCK, 4) void k_spmv_pat(
         PatTrip trip;
         pat_issue<VT>(trip, b, xr, wave, lane, rows, pidc, sdesc, sdelta, sval, x, y);
         pat_finish<VT>(trip, sx, sy, cy, nsc, sdelta, sval, x, y, sq);
+    }
+    const double tot = block_sum<SELL_BLOCK>(sq, red);
+    if (tid == 0) partials[wg] = tot;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Structure patterns (sell = 4): rows whose column STRUCTURE repeats while their values do not -- a stencil with
+// variable coefficients.  The pattern table holds (length, column offsets) only; the values stay 8 bytes each,
+// column-major per 64-row slice as in sell.h (element (row i of slice s, k) at soff[s] + 64 k + i, padding 0.0, never
+// added).  Against sliced ELL with 16-bit columns that is 2 bytes less per nonzero and a byte per row instead of the
+// row length + slice base: 65 instead of 75 bytes per row of a 5-point operator.  Same left-to-right row sums.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_spat_fill(const int *__restrict__ rowptr, const double *__restrict__ val,
+                                                   const unsigned *__restrict__ soff, int rows, int nslices,
+                                                   double *__restrict__ sval)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int s = (int)(r >> 6), lane = (int)(r & 63);
+    if (s >= nslices) return;
+    const unsigned o0 = soff[s];
+    const int W = (int)((soff[s + 1] - o0) >> 6);
+    int q0 = 0, len = 0;
+    if (r < rows) {
+        q0 = rowptr[r];
+        len = rowptr[r + 1] - q0;
+    }
+    for (int k = 0; k < W; ++k) sval[(size_t)o0 + (size_t)k * 64 + lane] = k < len ? val[q0 + k] : 0.0;
+}
+
+template <bool UPD, typename VT = double>
+__global__ __launch_bounds__(SELL_BLOCK, 6) void k_spmv_spat(
+    const unsigned char *__restrict__ pid, const unsigned *__restrict__ desc, const int *__restrict__ delta, int nent,
+    const unsigned *__restrict__ soff, const VT *__restrict__ sv, int rows, int nslices, int64_t nblk,
+    const VT *__restrict__ x, VT *__restrict__ y, const SpmvCoef *__restrict__ coef, const int *__restrict__ stop,
+    double *__restrict__ partials, const double *__restrict__ pin, int npin, const NormSlot *__restrict__ slot_in,
+    NormSlot *__restrict__ slot_out, int skip_if_zero, Rider rider, UpdArgs upd, NScale nsc)
+{
+    __shared__ double red[SELL_BLOCK / WAVE + 1];
+    __shared__ unsigned sdesc[PAT_MAX];
+    __shared__ int sdelta[PAT_MAX_E];
+    const int shift = rider.kind != 0 ? 1 : 0;
+    const int nwg = (int)gridDim.x - shift;
+    const int wg = (int)blockIdx.x - shift;
+    if (wg < 0) {
+        run_rider(rider, red);
+        return;
+    }
+    const int tid = threadIdx.x;
+    const unsigned desc_mine = desc[tid];
+    int d_mine[PAT_MAX_E / SELL_BLOCK];
+#pragma unroll
+    for (int j = 0; j < PAT_MAX_E / SELL_BLOCK; ++j) {
+        const int e = tid + j * SELL_BLOCK;
+        d_mine[j] = e < nent ? delta[e] : 0;
+    }
+    const bool pre = pin != nullptr && npin <= SELL_SHARE_K * SELL_BLOCK;   // (uniform)
+    double pshare[SELL_SHARE_K];
+    if (pre) strided_share_load<SELL_BLOCK, SELL_SHARE_K>(pin, npin, pshare);
+    const int lane = tid & (WAVE - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const XcdRange xr = xcd_range(nblk, nwg, wg);
+
+    if (*stop != 0) return;
+    sdesc[tid] = desc_mine;
+#pragma unroll
+    for (int j = 0; j < PAT_MAX_E / SELL_BLOCK; ++j) {
+        const int e = tid + j * SELL_BLOCK;
+        if (e < nent) sdelta[e] = d_mine[j];
+    }
+    SellCoef kc;
+    const double share = pre ? strided_share_sum<SELL_BLOCK, SELL_SHARE_K>(pshare, npin) : 0.0;
+    if (!sell_prologue<UPD, VT>(coef, pin, npin, slot_in, slot_out, skip_if_zero, upd, nwg, wg, red, kc, nsc, pre, share))
+        return;
+    const double sx = kc.sx, sy = kc.sy, cy = kc.cy;
+    __syncthreads();
+
+    double sq = 0.0;
+    for (int64_t b = xr.first; b < xr.end; b += xr.stride) {
+        const int s = (int)(b * SELL_SLICES) + wave;
+        if (s >= nslices) continue;
+        const unsigned o0 = soff[s];
+        const int W = (int)((soff[s + 1] - o0) >> 6);
+        const int r = s * WAVE + lane;
+        const bool active = r < rows;
+        const double y0 = (double)y[active ? r : 0];
+        const unsigned d = active ? sdesc[pid[r]] : 0u;
+        const int e0 = (int)(d & 0xffffu), len = (int)(d >> 16);
+        const VT *__restrict__ pv = sv + (size_t)o0 + lane;
+        double sum = 0.0;
+        for (int k0 = 0; k0 < W; k0 += PAT_K) {   // W is the slice's longest row (uniform)
+            double a[PAT_K], xv[PAT_K];
+#pragma unroll
+            for (int k = 0; k < PAT_K; ++k) {
+                const bool live = k0 + k < len;
+                a[k] = (double)pv[(size_t)min(k0 + k, W - 1) * 64];
+                xv[k] = (double)x[live ? r + sdelta[e0 + k0 + k] : 0];
+            }
+#pragma unroll
+            for (int k = 0; k < PAT_K; ++k) {
+                const double p = a[k] * (xv[k] * sx);
+                if (k0 + k < len) sum = sum + p;
+            }
+        }
+        if (active) {
+            const VT yn = (VT)(cy * (y0 * sy) + sum);
+            y[r] = yn;
+            const double ys = (double)yn * nsc.s;
+            sq += ys * ys;
+        }
     }
     const double tot = block_sum<SELL_BLOCK>(sq, red);
     if (tid == 0) partials[wg] = tot;

@@ -194,6 +194,26 @@ static void launch_pat(const SpmvArgs &a)
                               a.pout, a.pin, a.npin, a.slot_in, a.slot_out, a.skip_if_zero, a.rider, a.upd, a.nsc);
 }
 
+template <bool UPD, typename VT = double>
+static void launch_spat(const SpmvArgs &a)
+{
+    const Csr &c = *a.c;
+    const VT *x = reinterpret_cast<const VT *>(a.x);
+    VT *y = reinterpret_cast<VT *>(a.y);
+    const dim3 grid(c.grid + (a.rider.kind != 0 ? 1 : 0));
+    if (a.e0 == nullptr && a.e1 == nullptr)
+        hipLaunchKernelGGL((k_spmv_spat<UPD, VT>), grid, dim3(SELL_BLOCK), 0, a.stream, (const unsigned char *)c.pid,
+                           (const unsigned *)c.pdesc, (const int *)c.pdelta, c.npat_e, (const unsigned *)c.soff,
+                           (const VT *)c.sval, c.rows, c.nslices, c.nblk, x, y, a.coef, a.stop, a.pout, a.pin, a.npin,
+                           a.slot_in, a.slot_out, a.skip_if_zero, a.rider, a.upd, a.nsc);
+    else
+        hipExtLaunchKernelGGL((k_spmv_spat<UPD, VT>), grid, dim3(SELL_BLOCK), 0, a.stream, a.e0, a.e1, 0,
+                              (const unsigned char *)c.pid, (const unsigned *)c.pdesc, (const int *)c.pdelta, c.npat_e,
+                              (const unsigned *)c.soff, (const VT *)c.sval, c.rows, c.nslices, c.nblk, x, y, a.coef,
+                              a.stop, a.pout, a.pin, a.npin, a.slot_in, a.slot_out, a.skip_if_zero, a.rider, a.upd,
+                              a.nsc);
+}
+
 template <typename OffT, bool V8, bool C16>
 static void launch_xl_C(const SpmvArgs &a, double *z)
 {
@@ -281,7 +301,10 @@ static void launch_spmv_args(H *h, const SpmvArgs &a_in)
         return;
     }
     if (a.f32) {  // REAL32 handle: float vectors and values (sliced ELL, row windows; never panels)
-        if (c.sell == 3) {
+        if (c.sell == 4) {
+            if (a.upd.on) launch_spat<true, float>(a);
+            else launch_spat<false, float>(a);
+        } else if (c.sell == 3) {
             if (a.upd.on) launch_pat<true, float>(a);
             else launch_pat<false, float>(a);
         } else if (c.sell == 2) {
@@ -304,6 +327,11 @@ static void launch_spmv_args(H *h, const SpmvArgs &a_in)
         } else {
             launch_spmv_F<int>(a, a.y, a.e0, a.e1);
         }
+        return;
+    }
+    if (c.sell == 4) {  // structure patterns (pat.h)
+        if (a.upd.on) launch_spat<true>(a);
+        else launch_spat<false>(a);
         return;
     }
     if (c.sell == 3) {  // row patterns (pat.h)

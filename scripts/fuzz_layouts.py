@@ -9,17 +9,18 @@ import oracle
 from lsqr_amd.solver import lsqr_solver_ez
 
 KNOBS = ["LSQRHIP_SELL", "LSQRHIP_SELLP", "LSQRHIP_VAL8", "LSQRHIP_COL16", "LSQRHIP_PANELS", "LSQRHIP_PANEL_KB",
-         "LSQRHIP_XLDS", "LSQRHIP_XLDS_COLS", "LSQRHIP_OFF64", "LSQRHIP_SKEW", "LSQRHIP_TUNE", "LSQRHIP_CSB", "LSQRHIP_CSB_R", "LSQRHIP_CSB_S", "LSQRHIP_PAT"]
+         "LSQRHIP_XLDS", "LSQRHIP_XLDS_COLS", "LSQRHIP_OFF64", "LSQRHIP_SKEW", "LSQRHIP_TUNE", "LSQRHIP_CSB", "LSQRHIP_CSB_R", "LSQRHIP_CSB_S", "LSQRHIP_PAT", "LSQRHIP_SPAT"]
 LAYOUTS = [
     {},                                                                        # whatever the build chooses
     {"LSQRHIP_PAT": "1"},                                                      # row patterns whenever the limits hold (pat.h)
-    {"LSQRHIP_PAT": "0"},                                                      # ... and never
-    {"LSQRHIP_PAT": "0", "LSQRHIP_SELL": "0"},
-    {"LSQRHIP_PAT": "0", "LSQRHIP_PANELS": "1", "LSQRHIP_PANEL_KB": "64", "LSQRHIP_XLDS": "0"},    # L2 panels (8192 columns)
-    {"LSQRHIP_PAT": "0", "LSQRHIP_PANELS": "1", "LSQRHIP_PANEL_KB": "64", "LSQRHIP_XLDS": "0", "LSQRHIP_OFF64": "1", "LSQRHIP_SKEW": "0"},
-    {"LSQRHIP_PAT": "0", "LSQRHIP_XLDS": "1", "LSQRHIP_XLDS_COLS": "1024"},                        # LDS panels (1024 columns)
-    {"LSQRHIP_PAT": "0", "LSQRHIP_XLDS": "1", "LSQRHIP_XLDS_COLS": "1024", "LSQRHIP_COL16": "0", "LSQRHIP_OFF64": "1"},
-    {"LSQRHIP_PAT": "0", "LSQRHIP_SELL": "1", "LSQRHIP_SELLP": "0"},
+    {"LSQRHIP_PAT": "0", "LSQRHIP_SPAT": "1"},                                 # structure patterns whenever the limits hold
+    {"LSQRHIP_PAT": "0", "LSQRHIP_SPAT": "0"},                                 # ... and neither kind
+    {"LSQRHIP_PAT": "0", "LSQRHIP_SPAT": "0", "LSQRHIP_SELL": "0"},
+    {"LSQRHIP_PAT": "0", "LSQRHIP_SPAT": "0", "LSQRHIP_PANELS": "1", "LSQRHIP_PANEL_KB": "64", "LSQRHIP_XLDS": "0"},    # L2 panels (8192 columns)
+    {"LSQRHIP_PAT": "0", "LSQRHIP_SPAT": "0", "LSQRHIP_PANELS": "1", "LSQRHIP_PANEL_KB": "64", "LSQRHIP_XLDS": "0", "LSQRHIP_OFF64": "1", "LSQRHIP_SKEW": "0"},
+    {"LSQRHIP_PAT": "0", "LSQRHIP_SPAT": "0", "LSQRHIP_XLDS": "1", "LSQRHIP_XLDS_COLS": "1024"},                        # LDS panels (1024 columns)
+    {"LSQRHIP_PAT": "0", "LSQRHIP_SPAT": "0", "LSQRHIP_XLDS": "1", "LSQRHIP_XLDS_COLS": "1024", "LSQRHIP_COL16": "0", "LSQRHIP_OFF64": "1"},
+    {"LSQRHIP_PAT": "0", "LSQRHIP_SPAT": "0", "LSQRHIP_SELL": "1", "LSQRHIP_SELLP": "0"},
     {"LSQRHIP_CSB": "1"},                                                      # column-swept row blocks (csb.h)
     {"LSQRHIP_CSB": "1", "LSQRHIP_CSB_R": "37"},                               # ... in many small blocks, ragged last one
     {"LSQRHIP_CSB": "1", "LSQRHIP_CSB_R": "129", "LSQRHIP_CSB_S": "3"},        # ... three workgroups per block (column splits)

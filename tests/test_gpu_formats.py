@@ -19,8 +19,9 @@ KNOBS = ("LSQRHIP_SELL", "LSQRHIP_SELLP", "LSQRHIP_VAL8", "LSQRHIP_COL16", "LSQR
 
 @pytest.fixture(autouse=True)
 def clean_env():
-    old = {k: os.environ.pop(k, None) for k in KNOBS + ("LSQRHIP_PAT",)}
-    os.environ["LSQRHIP_PAT"] = "0"       # this file is about the layouts UNDER row patterns (tests/test_gpu_patterns.py)
+    old = {k: os.environ.pop(k, None) for k in KNOBS + ("LSQRHIP_PAT", "LSQRHIP_SPAT")}
+    os.environ["LSQRHIP_PAT"] = "0"       # this file is about the layouts UNDER the patterns (tests/test_gpu_patterns.py)
+    os.environ["LSQRHIP_SPAT"] = "0"
     yield
     for k, v in old.items():
         os.environ.pop(k, None)

@@ -14,7 +14,7 @@ from lsqr_amd.solver import lsqr_solver_ez
 
 pytestmark = pytest.mark.gpu
 CASES = build_cases()
-KNOBS = ("LSQRHIP_PAT", "LSQRHIP_SELL", "LSQRHIP_SELLP", "LSQRHIP_VAL8", "LSQRHIP_COL16", "LSQRHIP_CSB")
+KNOBS = ("LSQRHIP_PAT", "LSQRHIP_SPAT", "LSQRHIP_SELL", "LSQRHIP_SELLP", "LSQRHIP_VAL8", "LSQRHIP_COL16", "LSQRHIP_CSB")
 
 
 @pytest.fixture(autouse=True)
@@ -91,6 +91,7 @@ def test_a_stencil_is_stored_as_row_patterns_and_gives_the_references_bits(shape
     assert info["csr_bytes"] <= p.m + 1024 + 12 * 1024
     # ... and the same bits as the layouts underneath
     os.environ["LSQRHIP_PAT"] = "0"
+    os.environ["LSQRHIP_SPAT"] = "0"
     s0 = lsqr_solver_ez().initialize(p.m, p.n, p.a, p.irow, p.icol, itnlim=25)
     assert s0.info()["sell"] in (1, 2)
     r0 = s0.solve(p.b, 0.0)
@@ -121,11 +122,15 @@ def test_empty_rows_are_a_pattern_of_their_own():
 
 
 def test_matrices_without_repeating_rows_keep_their_layout():
-    # arbitrary real values on a band: every row is its own pattern
+    # arbitrary real values on a band: every row is its own pattern -- but the STRUCTURE repeats (sell = 4, below)
     m, n, irow, icol, a, b = stencil(70001, 70003, (-7, -1, 0, 1, 7), (1.0,) * 5)
     a = _vec(3, a.size) + 0.5
     info = lsqr_solver_ez().initialize(m, n, a, irow, icol).info()
+    assert info["sell"] == 4 and info["sell_t"] == 4
+    os.environ["LSQRHIP_SPAT"] = "0"
+    info = lsqr_solver_ez().initialize(m, n, a, irow, icol).info()
     assert info["sell"] == 1 and info["sell_t"] == 1
+    os.environ.pop("LSQRHIP_SPAT")
     # random columns
     p = P.random_rows(30000, 20000, 8, seed=4)
     info = lsqr_solver_ez().initialize(p.m, p.n, p.a, p.irow, p.icol).info()
@@ -142,8 +147,8 @@ def test_matrices_without_repeating_rows_keep_their_layout():
         irow, icol, a = (irow[order] + 1).astype(np.int32), (icol[order] + 1).astype(np.int32), a[order]
         if want == 3:
             check_against_oracle(m, n, irow, icol, a, _vec(7, m), itnlim=8)
-        else:
-            assert lsqr_solver_ez().initialize(m, n, a, irow, icol).info()["sell"] == want
+        else:     # (one value too many for a dictionary as well: the structure -- two patterns -- is what is left)
+            assert lsqr_solver_ez().initialize(m, n, a, irow, icol).info()["sell"] in (want, 4)
 
 
 def grid3d(nx, ny, nz, radius_taps):
@@ -233,3 +238,72 @@ def test_the_golden_parity_cases_with_patterns_forced(name):
     import test_gpu_parity as tp
     os.environ["LSQRHIP_PAT"] = "1"
     tp.test_solve_parity_vs_reference_golden(name)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# structure patterns (sell = 4): the column structure of the rows repeats, their values do not
+# ---------------------------------------------------------------------------------------------------------------------
+def variable(m, n, irow, icol, a, b, seed=5):
+    """the same structure with arbitrary values"""
+    return m, n, irow, icol, _vec(seed, a.size) * 2.0 - 1.0 + 0.25, b
+
+
+def test_a_variable_coefficient_stencil_keeps_no_column_indices():
+    p = P.poisson2d(300, 200)
+    m, n, irow, icol, a, b = variable(p.m, p.n, p.irow, p.icol, p.a, p.b)
+    s, r = check_against_oracle(m, n, irow, icol, a, b, want=4, want_t=4)
+    info = s.info()
+    nnzp = 5 * 64 * ((m + 63) // 64)
+    assert info["csr_bytes"] <= 8 * nnzp + m + 4 * ((m + 63) // 64) + 8192      # values + a byte per row: no columns
+    os.environ["LSQRHIP_SPAT"] = "0"
+    s0 = lsqr_solver_ez().initialize(m, n, a, irow, icol, itnlim=25)
+    assert s0.info()["sell"] == 1 and s0.info()["csr_bytes"] > info["csr_bytes"]
+    r0 = s0.solve(b, 0.0)
+    assert np.array_equal(r0.x, r.x) and r0.anorm == r.anorm and r0.rnorm == r.rnorm and r0.itn == r.itn
+
+
+@pytest.mark.parametrize("case", ["3d7", "3d27", "holes", "conv31", "empty_rows", "unsym_dups"])
+def test_structure_patterns_on_other_shapes(case):
+    if case == "3d7":
+        m, n, irow, icol, a, b, _ = grid3d(24, 19, 17, 1)
+    elif case == "3d27":
+        m, n, irow, icol, a, b, _ = grid3d(24, 19, 17, 3)
+    elif case == "holes":
+        drop = lambda r, k: ((k == 1) & (r % 7 == 0)) | ((k == 3) & (r % 11 == 0))   # noqa: E731
+        m, n, irow, icol, a, b = stencil(9000, 9000, (-5, -1, 0, 1, 5), (1.0,) * 5, drop=drop)
+    elif case == "conv31":
+        m, n, irow, icol, a, b = stencil(30000, 30000, tuple(range(-15, 16)), (1.0,) * 31)
+    elif case == "empty_rows":
+        drop = lambda r, k: r % 5 == 2          # noqa: E731
+        m, n, irow, icol, a, b = stencil(4000, 3990, (-1, 0, 2), (1.0,) * 3, drop=drop)
+    else:
+        m, n, irow, icol, a, b = stencil(5000, 5007, (3, -2, 0, 3, 1, -40), (1.0,) * 6, shuffle=True)
+    m, n, irow, icol, a, b = variable(m, n, irow, icol, a, b)
+    check_against_oracle(m, n, irow, icol, a, b, damp=1e-3, itnlim=10, want=4, want_t=4)
+
+
+def test_structure_patterns_limits_and_real32():
+    # random columns: no structure to speak of
+    p = P.random_rows(30000, 20000, 8, seed=4)
+    info = lsqr_solver_ez().initialize(p.m, p.n, p.a, p.irow, p.icol).info()
+    assert info["sell"] not in (3, 4) and info["sell_t"] not in (3, 4)
+    # a dictionary (three values) on 5 offsets: 3^5 = 243 interior rows and the boundary ones -- too many to number in a
+    # byte, so no row patterns; and with a dictionary the packed records (3 bytes per nonzero) beat 8-byte values
+    m, n, irow, icol, a, b = stencil(50000, 50000, (-3, -1, 0, 1, 3), (1.0,) * 5)
+    a = np.choose((_vec(11, a.size) * 3).astype(int).clip(0, 2), [2.0, -1.0, 0.5])
+    assert lsqr_solver_ez().initialize(m, n, a, irow, icol).info()["sell"] == 2
+    # REAL32: float values and vectors, binary64 sums
+    p = P.poisson2d(120, 90)
+    m, n, irow, icol, a, b = variable(p.m, p.n, p.irow, p.icol, p.a, p.b)
+    a32, b32 = a.astype(np.float32), b.astype(np.float32)
+    s = lsqr_solver_ez().initialize(m, n, a32, irow, icol, itnlim=30, real32=True)
+    assert s.info()["sell"] == 4
+    xp, yp = _vec(9, n).astype(np.float32), _vec(10, m).astype(np.float32)
+    _, y_ref = oracle.port().aprod(1, m, n, irow, icol, a32.astype(np.float64), xp.astype(np.float64), yp.astype(np.float64))
+    x, y = xp.copy(), yp.copy()
+    s.aprod(1, m, n, x, y)
+    assert np.array_equal(y, y_ref.astype(np.float32))
+    os.environ["LSQRHIP_SPAT"] = "0"
+    s0 = lsqr_solver_ez().initialize(m, n, a32, irow, icol, itnlim=30, real32=True)
+    r, r0 = s.solve(b32, 0.0), s0.solve(b32, 0.0)
+    assert np.array_equal(r.x, r0.x) and r.itn == r0.itn and r.anorm == r0.anorm

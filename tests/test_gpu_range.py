@@ -62,7 +62,8 @@ def test_scaled_random_system_all_schedules_and_layouts(label, sa, sb):
 def test_scaled_poisson_sliced_ell(label, sa, sb):
     p = P.poisson2d(40, 30)
     run_case(p, sa, sb, 0.0, dict(itnlim=40), [{}, {"LSQRHIP_PAT": "0"}, {"LSQRHIP_PAT": "0", "LSQRHIP_SELLP": "0"},
-                                                {"LSQRHIP_PAT": "0", "LSQRHIP_SELL": "0"}])
+                                                {"LSQRHIP_PAT": "0", "LSQRHIP_VAL8": "0", "LSQRHIP_SPAT": "1"},
+                                                {"LSQRHIP_PAT": "0", "LSQRHIP_SPAT": "0", "LSQRHIP_SELL": "0"}])
 
 
 def test_norm_of_b_with_elements_across_the_whole_range():

@@ -27,7 +27,7 @@ EPS32 = float(np.finfo(np.float32).eps)          # 1.19e-7
 
 @pytest.fixture
 def env():
-    keys = ("LSQRHIP_CSB", "LSQRHIP_REAL32_MIXED", "LSQRHIP_XLDS", "LSQRHIP_SELL", "LSQRHIP_PAT")
+    keys = ("LSQRHIP_CSB", "LSQRHIP_REAL32_MIXED", "LSQRHIP_XLDS", "LSQRHIP_SELL", "LSQRHIP_PAT", "LSQRHIP_SPAT")
     old = {k: os.environ.get(k) for k in keys}
 
     def put(**kw):
@@ -56,9 +56,11 @@ def layouts(put, which):
     if which == "csb":
         put(LSQRHIP_CSB=1)
     elif which == "windows":
-        put(LSQRHIP_CSB=0, LSQRHIP_SELL=0, LSQRHIP_PAT=0)
+        put(LSQRHIP_CSB=0, LSQRHIP_SELL=0, LSQRHIP_PAT=0, LSQRHIP_SPAT=0)
     elif which == "sell":
-        put(LSQRHIP_CSB=0, LSQRHIP_PAT=0)
+        put(LSQRHIP_CSB=0, LSQRHIP_PAT=0, LSQRHIP_SPAT=0)
+    elif which == "spat":
+        put(LSQRHIP_CSB=0, LSQRHIP_PAT=0, LSQRHIP_SPAT=1)
     else:
         put(LSQRHIP_CSB=0)
 
@@ -67,7 +69,7 @@ NAMES = ["random_over_damped", "random_under", "shuffled_dups", "powerlaw_small"
          "poisson_20x20_it50", "t1_readme_damped", "one_by_one", "zero_matrix", "b_zero"]
 
 
-@pytest.mark.parametrize("layout", ["default", "csb", "windows", "sell"])
+@pytest.mark.parametrize("layout", ["default", "csb", "windows", "sell", "spat"])
 @pytest.mark.parametrize("name", NAMES)
 def test_products_round_once(env, name, layout):
     """y + A x and x + A' y: binary64 sums of exact products of real32 numbers, rounded to real32 once."""
@@ -94,7 +96,7 @@ def test_products_round_once(env, name, layout):
     assert np.all(np.abs(x.astype(np.float64) - x2) <= 0.5 * EPS32 * np.abs(x2) + slack(x2))
 
 
-@pytest.mark.parametrize("layout", ["default", "csb", "windows", "sell"])
+@pytest.mark.parametrize("layout", ["default", "csb", "windows", "sell", "spat"])
 @pytest.mark.parametrize("name", NAMES + ["itnlim_1", "illcond_conlim_it10"])
 def test_solve_all_real32_follows_binary64_oracle(env, name, layout):
     layouts(env, layout)
