@@ -85,7 +85,8 @@ int lsqrhip_retain(lsqrhip_handle_t h);
  * value (8, or 1 with the dictionary), bytes per column index in CSR(A) and CSR(A')
  * (4, or 2 for block-relative indices), column panels of CSR(A) and CSR(A'),
  * the short-row layout in use for A and for A' (0 = none, 1 = sliced ELL, 2 = its packed 16-byte records,
- * 3 = row patterns: one byte per row, csrc/pat.h), whether the panels are LDS-resident
+ * 3 = row patterns: one byte per row, 4 = structure patterns: a byte per row + the values, csrc/pat.h),
+ * whether the panels are LDS-resident
  * for A and for A' (0/1/2; 3 = column-swept row blocks, csrc/csb.h). */
 int lsqrhip_info(lsqrhip_handle_t h, int64_t *dims);
 
@@ -121,7 +122,7 @@ int lsqrhip_solve_device(lsqrhip_handle_t h, const double *d_b, double damp, dou
  * returned scalars are doubles (exact conversions of the host's real32 values).
  * LSQRHIP_REAL32_MIXED=1 (environment, read at create): the mixed mode -- binary64 storage on the device,
  * real32 only at this boundary.
- * Layouts: row patterns, sliced ELL, row windows, column-swept row blocks (no panel kernels).  A REAL32 handle works
+ * Layouts: row and structure patterns, sliced ELL, row windows, column-swept row blocks (no panel kernels).  A REAL32 handle works
  * with lsqrhip_solve_f32, lsqrhip_aprod_f32, the log, timing, option and info entry points; the binary64
  * entry points refuse it. */
 int lsqrhip_create_f32(int m, int n, int64_t nnz, const int *irow, const int *icol, const float *a,
