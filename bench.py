@@ -20,7 +20,8 @@ The ONE JSON line (rank 0) carries, for the dominant kernel (aprod mode 1):
                     WRITE_SIZE in passes of their own, FETCH_SIZE x2 on gfx950); `effective_gbps` = the
                     SURVEY 8d algorithmic bytes (12 B per nonzero ...) / the same time, labelled as such.
   roofline_hbm      the same kernel family on HBM-RESIDENT instances (configs[1] fits the 256 MB
-                    Infinity Cache): poisson2d:4000:4000 as row patterns, as packed records and with 8-byte values.
+                    Infinity Cache): poisson2d:4000:4000 as row patterns, packed records, sliced ELL with 8-byte values
+                    and structure patterns.
   strong_scaling_n1 configs[3] (10M x 10M, 1e9 nonzeros) whole on this GPU, with its own roofline:
                     N = 1 of the series the --gpus N lines continue.
   cpu_baseline      the reference's own CPU path (oracle/_ref), 1 core, bounded sample.

@@ -27,6 +27,9 @@
 //
 // Chosen when the matrix has <= 256 distinct rows of <= 64 nonzeros, <= 1024 pattern entries, and at least 16 rows per
 // pattern.  LSQRHIP_PAT=0 never, =1 whenever the limits hold.
+//
+// Second half of the file: STRUCTURE patterns (sell = 4) -- the same table over (length, column offsets) alone, for rows
+// whose values do not repeat (variable coefficients): 8-byte values column-major per slice and no column indices.
 #pragma once
 
 #include "common.h"

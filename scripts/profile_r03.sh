@@ -62,7 +62,7 @@ PY
   } > "$OUT/${tag}_roofline.txt"
   cat "$OUT/${tag}_roofline.txt"
 }
-TAGS=${*:-"config2 config2_packed poisson4000_pat poisson4000_dict poisson4000_val8 config4 shard8 config3_100 config5"}
+TAGS=${*:-"config2 config2_packed poisson4000_pat poisson4000_dict poisson4000_val8 poisson4000_spat config4 shard8 config3_100 config5"}
 for t in $TAGS; do
   case $t in
     config2)          run config2_poisson1000 - --workload poisson2d:1000:1000 --extras off --steps 2000 --warmup 200
@@ -73,8 +73,10 @@ for t in $TAGS; do
                       roof poisson4000_patterns - poisson2d:4000:4000 ;;
     poisson4000_dict) run poisson4000_dict LSQRHIP_PAT=0 --workload poisson2d:4000:4000 --steps 200 --warmup 20
                       roof poisson4000_dict LSQRHIP_PAT=0 poisson2d:4000:4000 ;;
-    poisson4000_val8) run poisson4000_val8 LSQRHIP_PAT=0,LSQRHIP_VAL8=0 --workload poisson2d:4000:4000 --steps 200 --warmup 20
-                      roof poisson4000_val8 LSQRHIP_PAT=0,LSQRHIP_VAL8=0 poisson2d:4000:4000 ;;
+    poisson4000_val8) run poisson4000_val8 LSQRHIP_PAT=0,LSQRHIP_VAL8=0,LSQRHIP_SPAT=0 --workload poisson2d:4000:4000 --steps 200 --warmup 20
+                      roof poisson4000_val8 LSQRHIP_PAT=0,LSQRHIP_VAL8=0,LSQRHIP_SPAT=0 poisson2d:4000:4000 ;;
+    poisson4000_spat) run poisson4000_structure_patterns LSQRHIP_PAT=0,LSQRHIP_VAL8=0 --workload poisson2d:4000:4000 --steps 200 --warmup 20
+                      roof poisson4000_structure_patterns LSQRHIP_PAT=0,LSQRHIP_VAL8=0 poisson2d:4000:4000 ;;
     config4)          run config4_random_10Mx10Mx100 - --workload random:10000000:10000000:100 --steps 20 --warmup 2
                       roof config4_random_10Mx10Mx100 - random:10000000:10000000:100 ;;
     shard8)           run shard8_random_1250000x10Mx100 - --workload random:1250000:10000000:100 --steps 40 --warmup 4

@@ -9,7 +9,7 @@ python bench.py --steps 20 --warmup 5 > $OUT/bench_default_k20.json 2> $OUT/benc
 LSQR_BENCH_FORCE_DIST=1 LSQR_BENCH_STRONG_REF=0 python -m torch.distributed.run --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29561 bench.py --gpus 1 --workload random:1250000:10000000:100 --steps 100 --warmup 10 2> $OUT/engine_1rank_shard8.err | grep '^{' | tail -1 > $OUT/engine_1rank_shard8.json
 LSQR_DIST_ENGINE=python LSQR_BENCH_FORCE_DIST=1 LSQR_BENCH_STRONG_REF=0 python -m torch.distributed.run --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29562 bench.py --gpus 1 --workload random:1250000:10000000:100 --steps 100 --warmup 10 --traffic off --cpu-iters 0 2> $OUT/engine_py_1rank_shard8.err | grep '^{' | tail -1 > $OUT/engine_py_1rank_shard8.json
 LSQRHIP_SHARD_GRAPH=0 LSQR_BENCH_FORCE_DIST=1 LSQR_BENCH_STRONG_REF=0 python -m torch.distributed.run --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29563 bench.py --gpus 1 --workload random:1250000:10000000:100 --steps 100 --warmup 10 --traffic off --cpu-iters 0 2> $OUT/engine_eager_1rank_shard8.err | grep '^{' | tail -1 > $OUT/engine_eager_1rank_shard8.json
-bash scripts/profile_r03.sh config2 config2_packed poisson4000_pat poisson4000_dict poisson4000_val8 config4 shard8 config3_100 config3_literal config5 > $OUT/profile_log.txt 2>&1
+bash scripts/profile_r03.sh config2 config2_packed poisson4000_pat poisson4000_dict poisson4000_val8 poisson4000_spat config4 shard8 config3_100 config3_literal config5 > $OUT/profile_log.txt 2>&1
 { python scripts/sharded_init_time.py random:2000000:1000000:50 1 8; python scripts/sharded_init_time.py random:10000000:10000000:20 8; } > $OUT/sharded_init_time.txt 2>&1
 export PMC_SETS="TCC_HIT_sum,TCC_MISS_sum TCP_TCC_READ_REQ_sum,TCP_TOTAL_CACHE_ACCESSES_sum FETCH_SIZE WRITE_SIZE"
 bash scripts/pmc_csb.sh random:10000000:10000000:100 r03/pmc_c4 > $OUT/pmc_config4.txt 2>&1
