@@ -307,3 +307,12 @@ def test_structure_patterns_limits_and_real32():
     s0 = lsqr_solver_ez().initialize(m, n, a32, irow, icol, itnlim=30, real32=True)
     r, r0 = s.solve(b32, 0.0), s0.solve(b32, 0.0)
     assert np.array_equal(r.x, r0.x) and r.itn == r0.itn and r.anorm == r0.anorm
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_the_golden_parity_cases_with_structure_patterns_forced(name):
+    """... and once more with the value dictionary off and LSQRHIP_SPAT=1: whatever has <= 256 distinct column
+    structures goes through k_spmv_spat."""
+    import test_gpu_parity as tp
+    os.environ.update(LSQRHIP_PAT="0", LSQRHIP_SPAT="1", LSQRHIP_VAL8="0")
+    tp.test_solve_parity_vs_reference_golden(name)
