@@ -25,6 +25,26 @@ __device__ __forceinline__ void store_through(float *p, float v)
     asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
 }
 
+// ld_stream<NT>: a load of matrix data that is read once per product.  Non-temporal (NT) when an iteration's working
+// set does not fit the 256 MB Infinity Cache (Csr.nt, decided at create): the stream then does not displace what is
+// reused (x, y) from the caches -- 16M-row 5-point operator: packed records 124 -> 98 us per product, structure
+// patterns 214 -> 172 us.  Plain when it fits: there the matrix itself is what the caches hold from one product to the
+// next (1M rows, non-temporal: 31.2k -> 28.0k iterations/s).  A compile-time choice: as a run-time flag the two
+// forms of every load cost the 1M-row kernels 2 us per launch.  profiles/r03/config2_patterns.txt section 14.
+template <bool NT, typename T>
+__device__ __forceinline__ T ld_stream(const T *p)
+{
+    return NT ? __builtin_nontemporal_load(p) : *p;
+}
+typedef unsigned lsqrhip_u4 __attribute__((ext_vector_type(4)));
+template <bool NT>
+__device__ __forceinline__ uint4 ld_stream4(const uint4 *p)
+{
+    if (!NT) return *p;
+    const lsqrhip_u4 q = __builtin_nontemporal_load(reinterpret_cast<const lsqrhip_u4 *>(p));
+    return make_uint4(q.x, q.y, q.z, q.w);
+}
+
 // Fixed-shape reductions: the shuffle tree and the cross-wave order are the same
 // on every launch, so every norm is reproducible run to run (istop / itn depend
 // on them, reference src/lsqr.f90:635, 641, 691, 696, 798-810).

@@ -143,6 +143,7 @@ struct Csr {
     int *pdelta = nullptr;           // ... [PAT_MAX_E] column - row of each entry
     double *pval = nullptr;          // ... [PAT_MAX_E] value of each entry
     int npat = 0, npat_e = 0;        // patterns, entries in use
+    bool nt = false;                 // short-row layouts: the matrix stream is loaded non-temporally (common.h ld_stream)
     unsigned *soff = nullptr;        // [nslices+1] first element (sell = 2: first record) of each 64-row slice
     uint4 *srec = nullptr;           // sell = 2: records (5 columns, 5 value codes, row length)
     void *scol = nullptr;            // column-major columns (u16 relative to cbaseS, or i32)
@@ -305,6 +306,15 @@ static int env_int(const char *name, int dflt)
     return (v && *v) ? std::atoi(v) : dflt;
 }
 
+static void dbg_stage(hipStream_t s, const char *what)
+{
+    static const int on = env_int("LSQRHIP_TRACE", 0);
+    if (!on) return;
+    hipError_t e = hipStreamSynchronize(s);
+    std::fprintf(stderr, "[lsqrhip trace] %s: %s\n", what, hipGetErrorString(e));
+    std::fflush(stderr);
+}
+
 static int vec_grid(int64_t n)
 {
     int64_t g = (n / 2 + VEC_BLOCK - 1) / VEC_BLOCK;
@@ -430,6 +440,7 @@ static void launch_scan_small(hipStream_t s, unsigned *a, int64_t L)
 // CSR arrays col / val are released; otherwise `out` is left as it was.
 static int try_pat(hipStream_t s, Csr &out, int64_t nnz, bool vals, unsigned long long *stats)
 {
+    dbg_stage(s, vals ? "try_pat(vals) enter" : "try_pat(structure) enter");
     const int rows = out.rows;
     // vals = false: structure patterns (pat.h "sell = 4") -- the column structure of the rows repeats, their values
     // do not; LSQRHIP_SPAT=0 never, =1 whenever the limits hold
@@ -450,6 +461,7 @@ static int try_pat(hipStream_t s, Csr &out, int64_t nnz, bool vals, unsigned lon
                        (const double *)out.val, rows, vals ? 1 : 0, s_keys.as<unsigned long long>(), s_reps.as<int>(),
                        ctl);
     HIPCHK(hipGetLastError());
+    dbg_stage(s, "k_pat_discover");
     int got[4];
     HIPCHK(hipMemcpyAsync(got, ctl, sizeof(got), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
@@ -459,6 +471,8 @@ static int try_pat(hipStream_t s, Csr &out, int64_t nnz, bool vals, unsigned lon
     HIPCHK(s_delta.alloc(sizeof(int) * PAT_MAX_E));
     HIPCHK(s_val.alloc(sizeof(double) * PAT_MAX_E));
     HIPCHK(s_pid.alloc((size_t)rows));
+    HIPCHK(hipMemsetAsync(s_desc.p, 0, sizeof(unsigned) * PAT_MAX, s));
+    HIPCHK(hipMemsetAsync(s_slot.p, 0xff, sizeof(int) * PAT_TAB, s));
     HIPCHK(hipMemsetAsync(s_delta.p, 0, sizeof(int) * PAT_MAX_E, s));
     HIPCHK(hipMemsetAsync(s_val.p, 0, sizeof(double) * PAT_MAX_E, s));
     hipLaunchKernelGGL(k_pat_table, dim3(1), dim3(PAT_TAB), 0, s, (const int *)out.rowptr, (const int *)out.col,
@@ -535,6 +549,7 @@ static int try_pat(hipStream_t s, Csr &out, int64_t nnz, bool vals, unsigned lon
 
 static int try_sell(hipStream_t s, Csr &out, int64_t nnz, const double *dict, int ndict, unsigned long long *stats)
 {
+    dbg_stage(s, "try_sell enter");
     const int rows = out.rows;
     // LSQRHIP_SELL: 0 never | 1 whenever the row shape qualifies | unset: also require local
     // columns (every slice spans < 65536 columns) -- with scattered columns the layout buys
@@ -712,6 +727,7 @@ static int build_csr_T(hipStream_t s, const int *d_keys, const int *d_other, con
     hipLaunchKernelGGL(k_rowptr_from_sorted<OffT>, dim3(g), dim3(256), 0, s, sorted, nnz, rows_v, (OffT *)out.rowptr);
     HIPCHK(hipGetLastError());
 
+    dbg_stage(s, "csr built");
     // short, even rows: sliced-ELL layout instead of row windows (sell.h)
     if (std::is_same<OffT, int>::value) {
         int rcs = try_pat(s, out, nnz, true, (unsigned long long *)hist);   // rows that repeat: one byte per row (pat.h)
@@ -720,6 +736,7 @@ static int build_csr_T(hipStream_t s, const int *d_keys, const int *d_other, con
         if (rcs == LSQRHIP_OK && !out.sell) rcs = try_sell(s, out, nnz, dict, ndict, (unsigned long long *)hist);
         if (rcs != LSQRHIP_OK) return rcs;
     }
+    dbg_stage(s, "short-row layouts tried");
     if (out.sell) {
         // 6 workgroups per CU: measured best at every size (config 2: 25.0 vs 26.1 us per iteration
         // with 8 per CU; fewer partial sums to re-read, still enough waves for the streams)
@@ -1281,10 +1298,18 @@ static int finish_create(H *h, const int *d_irow, const int *d_icol, const doubl
         if (rc == LSQRHIP_OK && !h->AT.csb)
             rc = build_csr_T<int>(s, d_icol, d_irow, d_a, nnz, h->n, h->m, LSQRHIP_ERR_ICOL, LSQRHIP_ERR_IROW, pt, pwt, xt, bufA, bufB, hist, d_flags, h->dict, h->ndict, h->AT);
     }
+    dbg_stage(s, "both matrices built");
     RET(rc);
     if (h->f32) {
         RET(values_to_f32(h, h->A));
         RET(values_to_f32(h, h->AT));
+    }
+    {   // the matrix stream of the short-row layouts: non-temporal once an iteration's working set (both matrices and
+        // the five vectors) exceeds the 256 MB Infinity Cache (common.h ld_stream); LSQRHIP_STREAM_NT=0 / 1 never / always
+        const int64_t esz = h->f32 ? 4 : 8;
+        const int64_t wset = h->A.bytes + h->AT.bytes + esz * ((int64_t)h->m + 4 * (int64_t)h->n);
+        const int mode = env_int("LSQRHIP_STREAM_NT", -1);
+        h->A.nt = h->AT.nt = mode < 0 ? wset > (256ll << 20) : mode != 0;
     }
     return alloc_workspace(h);
 }

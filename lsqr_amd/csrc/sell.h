@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256) void k_sell_fill(const int *__restrict__ rowpt
 
 // U columns of one slice, starting at element `e` (= soff + 64 k0 + lane): all loads first,
 // then the predicated left-to-right adds.
-template <int U, bool C16, bool V8, typename VT>
+template <int U, bool C16, bool V8, typename VT, bool NT>
 __device__ __forceinline__ double sell_chunk(double sum, size_t e, int k0, int len, int cb,
                                              const int *__restrict__ sc32, const unsigned short *__restrict__ sc16,
                                              const VT *__restrict__ sv, const unsigned char *__restrict__ sv8,
@@ -174,9 +174,9 @@ __device__ __forceinline__ double sell_chunk(double sum, size_t e, int k0, int l
 #pragma unroll
     for (int j = 0; j < U; ++j) {
         const size_t idx = e + (size_t)j * 64;
-        c[j] = C16 ? cb + (int)sc16[idx] : sc32[idx];
-        if (V8) code[j] = (int)sv8[idx];
-        else a[j] = (double)sv[idx];
+        c[j] = C16 ? cb + (int)ld_stream<NT>(&sc16[idx]) : ld_stream<NT>(&sc32[idx]);
+        if (V8) code[j] = (int)ld_stream<NT>(&sv8[idx]);
+        else a[j] = (double)ld_stream<NT>(&sv[idx]);
     }
 #pragma unroll
     for (int j = 0; j < U; ++j) xv[j] = (double)x[c[j]];
@@ -276,7 +276,7 @@ __device__ __forceinline__ bool sell_prologue(const SpmvCoef *__restrict__ coef,
 }
 
 // UPD = true: the launch also carries the x/w update of the previous iteration (UpdArgs).
-template <bool C16, bool V8, bool UPD, typename VT = double>
+template <bool C16, bool V8, bool UPD, typename VT = double, bool NT = false>
 __global__ __launch_bounds__(SELL_BLOCK, 8) void k_spmv_sell(
     const unsigned *__restrict__ soff, const void *__restrict__ scolv, const int *__restrict__ cbaseS,
     const void *__restrict__ svalv, const double *__restrict__ dict, const unsigned char *__restrict__ rlen,
@@ -336,15 +336,15 @@ __global__ __launch_bounds__(SELL_BLOCK, 8) void k_spmv_sell(
         size_t e = (size_t)o0 + lane;
         int k0 = 0;
         for (; W - k0 >= 8; k0 += 8, e += 8 * 64)
-            sum = sell_chunk<8, C16, V8, VT>(sum, e, k0, len, cb, sc32, sc16, sv, sv8, sdict, x, sx);
+            sum = sell_chunk<8, C16, V8, VT, NT>(sum, e, k0, len, cb, sc32, sc16, sv, sv8, sdict, x, sx);
         switch (W - k0) {  // uniform
-        case 7: sum = sell_chunk<7, C16, V8, VT>(sum, e, k0, len, cb, sc32, sc16, sv, sv8, sdict, x, sx); break;
-        case 6: sum = sell_chunk<6, C16, V8, VT>(sum, e, k0, len, cb, sc32, sc16, sv, sv8, sdict, x, sx); break;
-        case 5: sum = sell_chunk<5, C16, V8, VT>(sum, e, k0, len, cb, sc32, sc16, sv, sv8, sdict, x, sx); break;
-        case 4: sum = sell_chunk<4, C16, V8, VT>(sum, e, k0, len, cb, sc32, sc16, sv, sv8, sdict, x, sx); break;
-        case 3: sum = sell_chunk<3, C16, V8, VT>(sum, e, k0, len, cb, sc32, sc16, sv, sv8, sdict, x, sx); break;
-        case 2: sum = sell_chunk<2, C16, V8, VT>(sum, e, k0, len, cb, sc32, sc16, sv, sv8, sdict, x, sx); break;
-        case 1: sum = sell_chunk<1, C16, V8, VT>(sum, e, k0, len, cb, sc32, sc16, sv, sv8, sdict, x, sx); break;
+        case 7: sum = sell_chunk<7, C16, V8, VT, NT>(sum, e, k0, len, cb, sc32, sc16, sv, sv8, sdict, x, sx); break;
+        case 6: sum = sell_chunk<6, C16, V8, VT, NT>(sum, e, k0, len, cb, sc32, sc16, sv, sv8, sdict, x, sx); break;
+        case 5: sum = sell_chunk<5, C16, V8, VT, NT>(sum, e, k0, len, cb, sc32, sc16, sv, sv8, sdict, x, sx); break;
+        case 4: sum = sell_chunk<4, C16, V8, VT, NT>(sum, e, k0, len, cb, sc32, sc16, sv, sv8, sdict, x, sx); break;
+        case 3: sum = sell_chunk<3, C16, V8, VT, NT>(sum, e, k0, len, cb, sc32, sc16, sv, sv8, sdict, x, sx); break;
+        case 2: sum = sell_chunk<2, C16, V8, VT, NT>(sum, e, k0, len, cb, sc32, sc16, sv, sv8, sdict, x, sx); break;
+        case 1: sum = sell_chunk<1, C16, V8, VT, NT>(sum, e, k0, len, cb, sc32, sc16, sv, sv8, sdict, x, sx); break;
         default: break;
         }
         if (active) {
@@ -475,7 +475,7 @@ __device__ __forceinline__ double sellp_add(double sum, const uint4 q, int k0, i
 //   * (after pat.h) the slice descriptors two trips ahead, the first record of a slice one trip ahead -- in front of
 //     or behind the current trip's gathers -- and this thread's share of the partial sums requested at the top: the
 //     product alone 7.7 -> 8.5 us, the solve 40.2k -> 37.1k iterations/s (profiles/r03/config2_patterns.txt).  Not kept.
-template <bool UPD, typename VT = double>
+template <bool UPD, typename VT = double, bool NT = false>
 __global__ __launch_bounds__(SELL_BLOCK, 6) void k_spmv_sellp(
     const unsigned *__restrict__ roff, const uint4 *__restrict__ rec, const int *__restrict__ cbaseS,
     const double *__restrict__ dict, int rows, int nslices, int64_t nblk, const VT *__restrict__ x,
@@ -524,11 +524,11 @@ __global__ __launch_bounds__(SELL_BLOCK, 6) void k_spmv_sellp(
         const uint4 *__restrict__ p = rec + (size_t)o0 + lane;
         double sum = 0.0;
         if (nch == 1) {
-            sum = sellp_add<VT>(sum, p[0], 0, cb, sdict, x, sx);
+            sum = sellp_add<VT>(sum, ld_stream4<NT>(&p[0]), 0, cb, sdict, x, sx);
         } else {
             for (int j = 0; j < nch; j += 2) {  // two records in flight; the second one clamped, not branched on
-                const uint4 qa = p[(size_t)j * 64];
-                const uint4 qb = p[(size_t)min(j + 1, nch - 1) * 64];
+                const uint4 qa = ld_stream4<NT>(&p[(size_t)j * 64]);
+                const uint4 qb = ld_stream4<NT>(&p[(size_t)min(j + 1, nch - 1) * 64]);
                 sum = sellp_add<VT>(sum, qa, SELLP_K * j, cb, sdict, x, sx);
                 if (j + 1 < nch) sum = sellp_add<VT>(sum, qb, SELLP_K * (j + 1), cb, sdict, x, sx);
             }

@@ -136,43 +136,58 @@ static void launch_spmv_T(const SpmvArgs &a, double *y, hipEvent_t e0, hipEvent_
     }
 }
 
-template <bool C16, bool V8, bool UPD, typename VT = double>
-static void launch_sell_C(const SpmvArgs &a)
+template <bool C16, bool V8, bool UPD, typename VT, bool NT>
+static void launch_sell_N(const SpmvArgs &a)
 {
     const Csr &c = *a.c;
     const VT *x = reinterpret_cast<const VT *>(a.x);
     VT *y = reinterpret_cast<VT *>(a.y);
     const dim3 grid(c.grid + (a.rider.kind != 0 ? 1 : 0));
     if (a.e0 == nullptr && a.e1 == nullptr)
-        hipLaunchKernelGGL((k_spmv_sell<C16, V8, UPD, VT>), grid, dim3(SELL_BLOCK), 0, a.stream, (const unsigned *)c.soff,
+        hipLaunchKernelGGL((k_spmv_sell<C16, V8, UPD, VT, NT>), grid, dim3(SELL_BLOCK), 0, a.stream, (const unsigned *)c.soff,
                            (const void *)c.scol, (const int *)c.cbaseS, (const void *)c.sval, (const double *)c.dict,
                            (const unsigned char *)c.rlen, c.rows, c.nslices, c.nblk, x, y, a.coef, a.stop, a.pout,
                            a.pin, a.npin, a.slot_in, a.slot_out, a.skip_if_zero, a.rider, a.upd, a.nsc);
     else
-        hipExtLaunchKernelGGL((k_spmv_sell<C16, V8, UPD, VT>), grid, dim3(SELL_BLOCK), 0, a.stream, a.e0, a.e1, 0,
+        hipExtLaunchKernelGGL((k_spmv_sell<C16, V8, UPD, VT, NT>), grid, dim3(SELL_BLOCK), 0, a.stream, a.e0, a.e1, 0,
                               (const unsigned *)c.soff, (const void *)c.scol, (const int *)c.cbaseS,
                               (const void *)c.sval, (const double *)c.dict, (const unsigned char *)c.rlen, c.rows,
                               c.nslices, c.nblk, x, y, a.coef, a.stop, a.pout, a.pin, a.npin, a.slot_in,
                               a.slot_out, a.skip_if_zero, a.rider, a.upd, a.nsc);
 }
 
-template <bool UPD, typename VT = double>
-static void launch_sellp(const SpmvArgs &a)
+// (the matrix stream non-temporal or not: Csr.nt, common.h ld_stream)
+template <bool C16, bool V8, bool UPD, typename VT = double>
+static void launch_sell_C(const SpmvArgs &a)
+{
+    if (a.c->nt) launch_sell_N<C16, V8, UPD, VT, true>(a);
+    else launch_sell_N<C16, V8, UPD, VT, false>(a);
+}
+
+template <bool UPD, typename VT, bool NT>
+static void launch_sellp_N(const SpmvArgs &a)
 {
     const Csr &c = *a.c;
     const VT *x = reinterpret_cast<const VT *>(a.x);
     VT *y = reinterpret_cast<VT *>(a.y);
     const dim3 grid(c.grid + (a.rider.kind != 0 ? 1 : 0));
     if (a.e0 == nullptr && a.e1 == nullptr)
-        hipLaunchKernelGGL((k_spmv_sellp<UPD, VT>), grid, dim3(SELL_BLOCK), 0, a.stream, (const unsigned *)c.soff,
+        hipLaunchKernelGGL((k_spmv_sellp<UPD, VT, NT>), grid, dim3(SELL_BLOCK), 0, a.stream, (const unsigned *)c.soff,
                            (const uint4 *)c.srec, (const int *)c.cbaseS, (const double *)c.dict, c.rows, c.nslices,
                            c.nblk, x, y, a.coef, a.stop, a.pout, a.pin, a.npin, a.slot_in, a.slot_out,
                            a.skip_if_zero, a.rider, a.upd, a.nsc);
     else
-        hipExtLaunchKernelGGL((k_spmv_sellp<UPD, VT>), grid, dim3(SELL_BLOCK), 0, a.stream, a.e0, a.e1, 0,
+        hipExtLaunchKernelGGL((k_spmv_sellp<UPD, VT, NT>), grid, dim3(SELL_BLOCK), 0, a.stream, a.e0, a.e1, 0,
                               (const unsigned *)c.soff, (const uint4 *)c.srec, (const int *)c.cbaseS,
                               (const double *)c.dict, c.rows, c.nslices, c.nblk, x, y, a.coef, a.stop, a.pout,
                               a.pin, a.npin, a.slot_in, a.slot_out, a.skip_if_zero, a.rider, a.upd, a.nsc);
+}
+
+template <bool UPD, typename VT = double>
+static void launch_sellp(const SpmvArgs &a)
+{
+    if (a.c->nt) launch_sellp_N<UPD, VT, true>(a);
+    else launch_sellp_N<UPD, VT, false>(a);
 }
 
 template <bool UPD, typename VT = double>
@@ -194,24 +209,31 @@ static void launch_pat(const SpmvArgs &a)
                               a.pout, a.pin, a.npin, a.slot_in, a.slot_out, a.skip_if_zero, a.rider, a.upd, a.nsc);
 }
 
-template <bool UPD, typename VT = double>
-static void launch_spat(const SpmvArgs &a)
+template <bool UPD, typename VT, bool NT>
+static void launch_spat_N(const SpmvArgs &a)
 {
     const Csr &c = *a.c;
     const VT *x = reinterpret_cast<const VT *>(a.x);
     VT *y = reinterpret_cast<VT *>(a.y);
     const dim3 grid(c.grid + (a.rider.kind != 0 ? 1 : 0));
     if (a.e0 == nullptr && a.e1 == nullptr)
-        hipLaunchKernelGGL((k_spmv_spat<UPD, VT>), grid, dim3(SELL_BLOCK), 0, a.stream, (const unsigned char *)c.pid,
+        hipLaunchKernelGGL((k_spmv_spat<UPD, VT, NT>), grid, dim3(SELL_BLOCK), 0, a.stream, (const unsigned char *)c.pid,
                            (const unsigned *)c.pdesc, (const int *)c.pdelta, c.npat_e, (const unsigned *)c.soff,
                            (const VT *)c.sval, c.rows, c.nslices, c.nblk, x, y, a.coef, a.stop, a.pout, a.pin, a.npin,
                            a.slot_in, a.slot_out, a.skip_if_zero, a.rider, a.upd, a.nsc);
     else
-        hipExtLaunchKernelGGL((k_spmv_spat<UPD, VT>), grid, dim3(SELL_BLOCK), 0, a.stream, a.e0, a.e1, 0,
+        hipExtLaunchKernelGGL((k_spmv_spat<UPD, VT, NT>), grid, dim3(SELL_BLOCK), 0, a.stream, a.e0, a.e1, 0,
                               (const unsigned char *)c.pid, (const unsigned *)c.pdesc, (const int *)c.pdelta, c.npat_e,
                               (const unsigned *)c.soff, (const VT *)c.sval, c.rows, c.nslices, c.nblk, x, y, a.coef,
                               a.stop, a.pout, a.pin, a.npin, a.slot_in, a.slot_out, a.skip_if_zero, a.rider, a.upd,
                               a.nsc);
+}
+
+template <bool UPD, typename VT = double>
+static void launch_spat(const SpmvArgs &a)
+{
+    if (a.c->nt) launch_spat_N<UPD, VT, true>(a);
+    else launch_spat_N<UPD, VT, false>(a);
 }
 
 template <typename OffT, bool V8, bool C16>
