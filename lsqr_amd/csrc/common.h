@@ -36,6 +36,22 @@ __device__ __forceinline__ T ld_stream(const T *p)
 {
     return NT ? __builtin_nontemporal_load(p) : *p;
 }
+typedef double lsqrhip_d2v __attribute__((ext_vector_type(2)));
+typedef float lsqrhip_f2v __attribute__((ext_vector_type(2)));
+template <bool NT>
+__device__ __forceinline__ double2 ld_stream2(const double2 *p)
+{
+    if (!NT) return *p;
+    const lsqrhip_d2v q = __builtin_nontemporal_load(reinterpret_cast<const lsqrhip_d2v *>(p));
+    return make_double2(q.x, q.y);
+}
+template <bool NT>
+__device__ __forceinline__ float2 ld_stream2(const float2 *p)
+{
+    if (!NT) return *p;
+    const lsqrhip_f2v q = __builtin_nontemporal_load(reinterpret_cast<const lsqrhip_f2v *>(p));
+    return make_float2(q.x, q.y);
+}
 typedef unsigned lsqrhip_u4 __attribute__((ext_vector_type(4)));
 template <bool NT>
 __device__ __forceinline__ uint4 ld_stream4(const uint4 *p)

@@ -214,7 +214,7 @@ struct PatTrip {
     double a[PAT_U][PAT_K], xv[PAT_U][PAT_K];
 };
 // request everything the first PAT_K entries of the rows need
-template <typename VT>
+template <typename VT, bool NT>
 __device__ __forceinline__ void pat_issue(PatTrip &t, int64_t b, const XcdRange &xr, int wave, int lane, int rows,
                                           const int (&pidc)[PAT_U], const unsigned *sdesc, const int *sdelta,
                                           const double *sval, const VT *__restrict__ x, const VT *y)
@@ -224,7 +224,7 @@ __device__ __forceinline__ void pat_issue(PatTrip &t, int64_t b, const XcdRange 
         const int64_t bu = b + u * xr.stride;
         t.r[u] = ((int)(bu * SELL_SLICES) + wave) * WAVE + lane;
         t.active[u] = bu < xr.end && t.r[u] < rows;
-        t.y0[u] = (double)y[t.active[u] ? t.r[u] : 0];
+        t.y0[u] = (double)ld_stream<NT>(&y[t.active[u] ? t.r[u] : 0]);
         const unsigned d = t.active[u] ? sdesc[pidc[u]] : 0u;
         t.e0[u] = (int)(d & 0xffffu);
         t.len[u] = (int)(d >> 16);
@@ -295,7 +295,7 @@ __device__ __forceinline__ void pat_finish(const PatTrip &t, double sx, double s
 // same 7.2 us, the solve drops from 46.7k to 45.5k iterations/s, as it did for the packed records of sell.h), nor
 // between the prologue's norm and the update it carries (47.5k -> 44.3k): requests in flight while the update
 // streams delay it more than they save (profiles/r03/config2_patterns.txt).
-template <bool UPD, typename VT = double>
+template <bool UPD, typename VT = double, bool NT = false>
 __global__ __launch_bounds__(SELL_BLOCK, 4) void k_spmv_pat(
     const unsigned char *__restrict__ pid, const unsigned *__restrict__ desc, const int *__restrict__ delta,
     const double *__restrict__ pval, int nent, int rows, int nslices, int64_t nblk, const VT *__restrict__ x,
@@ -337,7 +337,7 @@ __global__ __launch_bounds__(SELL_BLOCK, 4) void k_spmv_pat(
     for (int u = 0; u < PAT_U; ++u) {
         const int64_t bu = b + u * xr.stride;
         const int r0 = ((int)(bu * SELL_SLICES) + wave) * WAVE + lane;
-        pid_next[u] = (bu < xr.end && r0 < rows) ? (int)pid[r0] : 0;
+        pid_next[u] = (bu < xr.end && r0 < rows) ? (int)ld_stream<NT>(&pid[r0]) : 0;
     }
 
     if (*stop != 0) return;
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(SELL_BLOCK, 4) void k_spmv_pat(
     }
     SellCoef kc;
     const double share = pre ? strided_share_sum<SELL_BLOCK, PAT_SHARE_K>(pshare, npin) : 0.0;
-    if (!sell_prologue<UPD, VT>(coef, pin, npin, slot_in, slot_out, skip_if_zero, upd, nwg, wg, red, kc, nsc, pre, share))
+    if (!sell_prologue<UPD, VT, NT>(coef, pin, npin, slot_in, slot_out, skip_if_zero, upd, nwg, wg, red, kc, nsc, pre, share))
         return;
     const double sx = kc.sx, sy = kc.sy, cy = kc.cy;
     __syncthreads();
@@ -366,10 +366,10 @@ __global__ __launch_bounds__(SELL_BLOCK, 4) void k_spmv_pat(
         for (int u = 0; u < PAT_U; ++u) {
             const int64_t bn = b + (PAT_U + u) * xr.stride;
             const int rn = ((int)(bn * SELL_SLICES) + wave) * WAVE + lane;
-            pid_next[u] = (bn < xr.end && rn < rows) ? (int)pid[rn] : 0;
+            pid_next[u] = (bn < xr.end && rn < rows) ? (int)ld_stream<NT>(&pid[rn]) : 0;
         }
         PatTrip trip;
-        pat_issue<VT>(trip, b, xr, wave, lane, rows, pidc, sdesc, sdelta, sval, x, y);
+        pat_issue<VT, NT>(trip, b, xr, wave, lane, rows, pidc, sdesc, sdelta, sval, x, y);
         pat_finish<VT>(trip, sx, sy, cy, nsc, sdelta, sval, x, y, sq);
     }
     const double tot = block_sum<SELL_BLOCK>(sq, red);
@@ -442,7 +442,7 @@ __global__ __launch_bounds__(SELL_BLOCK, 6) void k_spmv_spat(
     }
     SellCoef kc;
     const double share = pre ? strided_share_sum<SELL_BLOCK, SELL_SHARE_K>(pshare, npin) : 0.0;
-    if (!sell_prologue<UPD, VT>(coef, pin, npin, slot_in, slot_out, skip_if_zero, upd, nwg, wg, red, kc, nsc, pre, share))
+    if (!sell_prologue<UPD, VT, NT>(coef, pin, npin, slot_in, slot_out, skip_if_zero, upd, nwg, wg, red, kc, nsc, pre, share))
         return;
     const double sx = kc.sx, sy = kc.sy, cy = kc.cy;
     __syncthreads();
@@ -455,7 +455,7 @@ __global__ __launch_bounds__(SELL_BLOCK, 6) void k_spmv_spat(
         const int W = (int)((soff[s + 1] - o0) >> 6);
         const int r = s * WAVE + lane;
         const bool active = r < rows;
-        const double y0 = (double)y[active ? r : 0];
+        const double y0 = (double)ld_stream<NT>(&y[active ? r : 0]);
         const unsigned d = active ? sdesc[ld_stream<NT>(&pid[r])] : 0u;
         const int e0 = (int)(d & 0xffffu), len = (int)(d >> 16);
         const VT *__restrict__ pv = sv + (size_t)o0 + lane;

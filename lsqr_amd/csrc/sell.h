@@ -233,7 +233,7 @@ __device__ __forceinline__ bool sell_coefs(const SpmvCoef *__restrict__ coef, co
     return true;
 }
 // ... and the update a lazy launch carries (nothing for an explicit-coefficient launch)
-template <bool UPD, typename VT>
+template <bool UPD, typename VT, bool NT = false>
 __device__ __forceinline__ void sell_update(bool lazy, const NormSlot *__restrict__ slot_in, const UpdArgs &upd, int nwg,
                                             int wg, double *red, double nrm, double sx)
 {
@@ -257,13 +257,13 @@ __device__ __forceinline__ void sell_update(bool lazy, const NormSlot *__restric
         // the slice its rows gather from (one trip from beyond L2 instead of two)
         const XcdRange ur = xcd_range(upd.ugrid, nwg, wg);
         for (int ub = (int)ur.first; ub < (int)ur.end; ub += (int)ur.stride) {
-            const double tot = update_block<VT>((VT *)upd.x, (VT *)upd.w, (const VT *)upd.V, (VT *)upd.se, upd.n, rt.t1,
+            const double tot = update_block<VT, NT>((VT *)upd.x, (VT *)upd.w, (const VT *)upd.V, (VT *)upd.se, upd.n, rt.t1,
                                                 rt.t2, rt.t3, sv, wantse, ub, upd.ugrid, red);
             if (tid == 0) upd.pout[ub] = tot;
         }
     }
 }
-template <bool UPD, typename VT>
+template <bool UPD, typename VT, bool NT = false>
 __device__ __forceinline__ bool sell_prologue(const SpmvCoef *__restrict__ coef, const double *__restrict__ pin, int npin,
                                               const NormSlot *__restrict__ slot_in, NormSlot *__restrict__ slot_out,
                                               int skip_if_zero, const UpdArgs &upd, int nwg, int wg, double *red,
@@ -271,7 +271,7 @@ __device__ __forceinline__ bool sell_prologue(const SpmvCoef *__restrict__ coef,
 {
     double nrm;
     if (!sell_coefs(coef, pin, npin, slot_in, slot_out, skip_if_zero, wg, red, k, nrm, nsc, have_share, share)) return false;
-    sell_update<UPD, VT>(pin != nullptr, slot_in, upd, nwg, wg, red, nrm, k.sx);
+    sell_update<UPD, VT, NT>(pin != nullptr, slot_in, upd, nwg, wg, red, nrm, k.sx);
     return true;
 }
 
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(SELL_BLOCK, 8) void k_spmv_sell(
 
     SellCoef kc;
     const double share = pre ? strided_share_sum<SELL_BLOCK, SELL_SHARE_K>(pshare, npin) : 0.0;
-    if (!sell_prologue<UPD, VT>(coef, pin, npin, slot_in, slot_out, skip_if_zero, upd, nwg, wg, red, kc, nsc, pre, share))
+    if (!sell_prologue<UPD, VT, NT>(coef, pin, npin, slot_in, slot_out, skip_if_zero, upd, nwg, wg, red, kc, nsc, pre, share))
         return;
     const double sx = kc.sx, sy = kc.sy, cy = kc.cy;
     if (V8) __syncthreads();
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(SELL_BLOCK, 8) void k_spmv_sell(
         const bool active = r < rows;
         const int rc = active ? r : rows - 1;
         const int len = active ? (int)rlen[rc] : 0;
-        const double y0 = (double)y[rc];
+        const double y0 = (double)ld_stream<NT>(&y[rc]);
         double sum = 0.0;
         size_t e = (size_t)o0 + lane;
         int k0 = 0;
@@ -506,7 +506,7 @@ __global__ __launch_bounds__(SELL_BLOCK, 6) void k_spmv_sellp(
 
     SellCoef kc;
     const double share = pre ? strided_share_sum<SELL_BLOCK, SELL_SHARE_K>(pshare, npin) : 0.0;
-    if (!sell_prologue<UPD, VT>(coef, pin, npin, slot_in, slot_out, skip_if_zero, upd, nwg, wg, red, kc, nsc, pre, share))
+    if (!sell_prologue<UPD, VT, NT>(coef, pin, npin, slot_in, slot_out, skip_if_zero, upd, nwg, wg, red, kc, nsc, pre, share))
         return;
     const double sx = kc.sx, sy = kc.sy, cy = kc.cy;
     __syncthreads();
@@ -520,7 +520,7 @@ __global__ __launch_bounds__(SELL_BLOCK, 6) void k_spmv_sellp(
         const int cb = cbaseS[s];
         const int r = s * WAVE + lane;
         const bool active = r < rows;
-        const double y0 = (double)y[active ? r : rows - 1];
+        const double y0 = (double)ld_stream<NT>(&y[active ? r : rows - 1]);
         const uint4 *__restrict__ p = rec + (size_t)o0 + lane;
         double sum = 0.0;
         if (nch == 1) {

@@ -190,23 +190,30 @@ static void launch_sellp(const SpmvArgs &a)
     else launch_sellp_N<UPD, VT, false>(a);
 }
 
-template <bool UPD, typename VT = double>
-static void launch_pat(const SpmvArgs &a)
+template <bool UPD, typename VT, bool NT>
+static void launch_pat_N(const SpmvArgs &a)
 {
     const Csr &c = *a.c;
     const VT *x = reinterpret_cast<const VT *>(a.x);
     VT *y = reinterpret_cast<VT *>(a.y);
     const dim3 grid(c.grid + (a.rider.kind != 0 ? 1 : 0));
     if (a.e0 == nullptr && a.e1 == nullptr)
-        hipLaunchKernelGGL((k_spmv_pat<UPD, VT>), grid, dim3(SELL_BLOCK), 0, a.stream, (const unsigned char *)c.pid,
+        hipLaunchKernelGGL((k_spmv_pat<UPD, VT, NT>), grid, dim3(SELL_BLOCK), 0, a.stream, (const unsigned char *)c.pid,
                            (const unsigned *)c.pdesc, (const int *)c.pdelta, (const double *)c.pval, c.npat_e, c.rows,
                            c.nslices, c.nblk, x, y, a.coef, a.stop, a.pout, a.pin, a.npin, a.slot_in, a.slot_out,
                            a.skip_if_zero, a.rider, a.upd, a.nsc);
     else
-        hipExtLaunchKernelGGL((k_spmv_pat<UPD, VT>), grid, dim3(SELL_BLOCK), 0, a.stream, a.e0, a.e1, 0,
+        hipExtLaunchKernelGGL((k_spmv_pat<UPD, VT, NT>), grid, dim3(SELL_BLOCK), 0, a.stream, a.e0, a.e1, 0,
                               (const unsigned char *)c.pid, (const unsigned *)c.pdesc, (const int *)c.pdelta,
                               (const double *)c.pval, c.npat_e, c.rows, c.nslices, c.nblk, x, y, a.coef, a.stop,
                               a.pout, a.pin, a.npin, a.slot_in, a.slot_out, a.skip_if_zero, a.rider, a.upd, a.nsc);
+}
+
+template <bool UPD, typename VT = double>
+static void launch_pat(const SpmvArgs &a)
+{
+    if (a.c->nt) launch_pat_N<UPD, VT, true>(a);
+    else launch_pat_N<UPD, VT, false>(a);
 }
 
 template <bool UPD, typename VT, bool NT>

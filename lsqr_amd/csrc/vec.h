@@ -39,7 +39,7 @@ template <> struct Vec2<float> { typedef float2 type; };
 // runs it as a kernel of its own; the fused mode-1 kernels (spmv.h / sell.h, UpdArgs) run the
 // same blocks from inside the SpMV launch -- same elements per thread, same order, same
 // reduction, hence the same partials bit for bit.
-template <typename VT>
+template <typename VT, bool NT = false>
 __device__ __forceinline__ double update_block(VT *__restrict__ x, VT *__restrict__ w,
                                                const VT *__restrict__ V, VT *__restrict__ se, int64_t n,
                                                double t1, double t2, double t3, double sv, bool wantse, int ub,
@@ -54,8 +54,8 @@ __device__ __forceinline__ double update_block(VT *__restrict__ x, VT *__restric
     const V2T *V2 = reinterpret_cast<const V2T *>(V);
     V2T *se2 = reinterpret_cast<V2T *>(se);
     for (int64_t i = (int64_t)ub * VEC_BLOCK + threadIdx.x; i < n2; i += stride) {
-        const V2T t = w2[i];
-        V2T xv = x2[i];
+        const V2T t = ld_stream2<NT>(&w2[i]);
+        V2T xv = ld_stream2<NT>(&x2[i]);
         const V2T vv = V2[i];
         const double tx = (double)t.x, ty = (double)t.y;
         xv.x = (VT)(t1 * tx + (double)xv.x);
