@@ -466,7 +466,7 @@ __global__ __launch_bounds__(CSB_BLOCK, 1) void k_spmv_csb(
         if (A.S > 1) {  // a split: the exact sums as they are
             long long *zs = A.z + (size_t)sp * A.rows + row0;
             for (int r = tid; r < nr; r += CSB_BLOCK) {
-                zs[r] = (long long)acc[r];
+                __builtin_nontemporal_store((long long)acc[r], &zs[r]);   // (written once, read once by k_csb_combine)
                 acc[r] = 0ull;
             }
             if (tid == 0) {
@@ -533,8 +533,8 @@ __global__ __launch_bounds__(CSB_BLOCK) void k_csb_combine(
         const int nr = A.rstart[b + 1] - row0;
         double sq = 0.0;
         for (int r = tid; r < nr; r += CSB_BLOCK) {
-            long long s = A.z[row0 + r];
-            for (int sp = 1; sp < A.S; ++sp) s += A.z[(size_t)sp * A.rows + row0 + r];
+            long long s = __builtin_nontemporal_load(&A.z[row0 + r]);
+            for (int sp = 1; sp < A.S; ++sp) s += __builtin_nontemporal_load(&A.z[(size_t)sp * A.rows + row0 + r]);
             const double sum = (double)s * g;
             const VT yn = (VT)(cy * ((double)y[row0 + r] * sy) + sum);
             y[row0 + r] = yn;
