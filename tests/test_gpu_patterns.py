@@ -14,7 +14,7 @@ from lsqr_amd.solver import lsqr_solver_ez
 
 pytestmark = pytest.mark.gpu
 CASES = build_cases()
-KNOBS = ("LSQRHIP_PAT", "LSQRHIP_SPAT", "LSQRHIP_SELL", "LSQRHIP_SELLP", "LSQRHIP_VAL8", "LSQRHIP_COL16", "LSQRHIP_CSB")
+KNOBS = ("LSQRHIP_STREAM_NT", "LSQRHIP_PAT", "LSQRHIP_SPAT", "LSQRHIP_SELL", "LSQRHIP_SELLP", "LSQRHIP_VAL8", "LSQRHIP_COL16", "LSQRHIP_CSB")
 
 
 @pytest.fixture(autouse=True)
@@ -316,3 +316,24 @@ def test_the_golden_parity_cases_with_structure_patterns_forced(name):
     import test_gpu_parity as tp
     os.environ.update(LSQRHIP_PAT="0", LSQRHIP_SPAT="1", LSQRHIP_VAL8="0")
     tp.test_solve_parity_vs_reference_golden(name)
+
+
+@pytest.mark.parametrize("layout", [{}, {"LSQRHIP_PAT": "0"}, {"LSQRHIP_PAT": "0", "LSQRHIP_SELLP": "0"},
+                                    {"LSQRHIP_PAT": "0", "LSQRHIP_VAL8": "0"},
+                                    {"LSQRHIP_PAT": "0", "LSQRHIP_VAL8": "0", "LSQRHIP_SPAT": "0"}])
+def test_non_temporal_streams_change_no_bit(layout):
+    """The stream policy (common.h ld_stream: plain loads while an iteration's working set fits the Infinity Cache,
+    non-temporal beyond) selects another instantiation of the same kernel: every short-row layout must give the same
+    bits either way."""
+    p = P.poisson2d(200, 150)
+    os.environ.update(layout)
+    outs = []
+    for nt in ("0", "1"):
+        os.environ["LSQRHIP_STREAM_NT"] = nt
+        s = lsqr_solver_ez().initialize(p.m, p.n, p.a, p.irow, p.icol, itnlim=30)
+        x, y = _vec(9, p.n), _vec(10, p.m)
+        s.aprod(1, p.m, p.n, x, y)
+        outs.append((s.info()["sell"], y, s.solve(p.b, 1e-3)))
+    (l0, y0, r0), (l1, y1, r1) = outs
+    assert l0 == l1 != 0
+    assert np.array_equal(y0, y1) and np.array_equal(r0.x, r1.x) and r0.anorm == r1.anorm and r0.itn == r1.itn
