@@ -26,7 +26,7 @@ __device__ __forceinline__ void store_through(float *p, float v)
 }
 
 // ld_stream<NT>: a load of matrix data that is read once per product.  Non-temporal (NT) when an iteration's working
-// set does not fit the 256 MB Infinity Cache (Csr.nt, decided at create): the stream then does not displace what is
+// set exceeds twice the 256 MB Infinity Cache (Csr.nt, decided at create): the stream then does not displace what is
 // reused (x, y) from the caches -- 16M-row 5-point operator: packed records 124 -> 98 us per product, structure
 // patterns 214 -> 172 us.  Plain when it fits: there the matrix itself is what the caches hold from one product to the
 // next (1M rows, non-temporal: 31.2k -> 28.0k iterations/s).  A compile-time choice: as a run-time flag the two

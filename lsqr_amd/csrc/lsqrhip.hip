@@ -1305,11 +1305,13 @@ static int finish_create(H *h, const int *d_irow, const int *d_icol, const doubl
         RET(values_to_f32(h, h->AT));
     }
     {   // the matrix stream of the short-row layouts: non-temporal once an iteration's working set (both matrices and
-        // the five vectors) exceeds the 256 MB Infinity Cache (common.h ld_stream); LSQRHIP_STREAM_NT=0 / 1 never / always
+        // the five vectors) exceeds TWICE the 256 MB Infinity Cache (common.h ld_stream); LSQRHIP_STREAM_NT=0 / 1 never /
+        // always.  Measured crossover (profiles/r03/config2_patterns.txt section 15): at 288 MB plain loads still win
+        // by 6 % (half the set survives an iteration), at 336 MB the two are equal, at 576 MB non-temporal wins by 11 %.
         const int64_t esz = h->f32 ? 4 : 8;
         const int64_t wset = h->A.bytes + h->AT.bytes + esz * ((int64_t)h->m + 4 * (int64_t)h->n);
         const int mode = env_int("LSQRHIP_STREAM_NT", -1);
-        h->A.nt = h->AT.nt = mode < 0 ? wset > (256ll << 20) : mode != 0;
+        h->A.nt = h->AT.nt = mode < 0 ? wset > (512ll << 20) : mode != 0;
     }
     return alloc_workspace(h);
 }
