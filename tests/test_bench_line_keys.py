@@ -1,0 +1,64 @@
+"""The shape of the ONE JSON line bench.py prints (CPU test, no GPU): the contract's keys, the `roofline` and
+`cpu_baseline` objects -- for both line shapes, the single-GPU one and the distributed one -- held on the lines
+committed under profiles/ (what the driver's BENCH / SCALE files are made of) and on the key tuples the
+distributed leg builds its line from (lsqr_amd/dist_bench.py)."""
+import glob
+import json
+import os
+
+from lsqr_amd import dist_bench
+
+ROOT = os.path.join(os.path.dirname(__file__), "..")
+CONTRACT = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "config")
+
+
+def last_round_dir():
+    return sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]")))[-1]
+
+
+def load(name):
+    with open(os.path.join(last_round_dir(), name)) as f:
+        return json.loads(f.read().strip().splitlines()[-1])
+
+
+def check_line(d, n_gpus_min=1):
+    for k in CONTRACT:
+        assert k in d, k
+    assert d["metric"] == "lsqr_iterations_per_sec" and d["unit"] == "it/s" and d["higher_is_better"] is True
+    assert d["vs_baseline"] is None and d["data"] == "synthetic" and d["dtype"] in ("f64", "f32")
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert d["value"] > 0 and abs(d["ms_per_step"] * d["value"] / 1e3 - 1.0) < 1e-6 * max(1, d["n_gpus"]) + 1e-3
+    for k in dist_bench.ROOFLINE_KEYS:
+        assert k in d["roofline"], k
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "cache") and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    for k in dist_bench.CPU_BASELINE_KEYS:
+        assert k in d["cpu_baseline"], k
+    assert d["cpu_baseline"]["kind"] in ("reference", "port") and d["cpu_baseline"]["cores"] >= 1
+
+
+def test_distributed_leg_names_the_contract_keys():
+    for k in CONTRACT:
+        assert k in dist_bench.LINE_KEYS, k
+    assert "roofline" in dist_bench.LINE_KEYS and "cpu_baseline" in dist_bench.LINE_KEYS
+    assert set(dist_bench.ROOFLINE_KEYS) == {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+    assert set(dist_bench.CPU_BASELINE_KEYS) == {"value", "unit", "cores", "kind", "sample"}
+
+
+def test_committed_single_gpu_lines():
+    for name in ("bench_default.json", "bench_default_k20.json"):
+        d = load(name)
+        check_line(d)
+        assert d["n_gpus"] == 1 and d["scaling"] == "weak"
+        assert d["roofline"]["traffic"] is not None          # live PMC passes of the same run
+        assert isinstance(d.get("roofline_hbm"), list) and d["roofline_hbm"]
+        assert "roofline" in d["strong_scaling_n1"]
+    assert load("bench_default_k20.json")["steps"] == 20 and load("bench_default_k20.json")["warmup"] == 5
+
+
+def test_committed_distributed_line():
+    d = load("engine_1rank_shard8.json")        # the N > 1 line shape, forced at world = 1
+    check_line(d)
+    assert d["scaling"] == "strong" and d["config"]["engine"] in ("c++", "python") and "engine_note" in d["config"]
