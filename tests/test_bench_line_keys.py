@@ -14,7 +14,12 @@ CONTRACT = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step
 
 
 def last_round_dir():
-    return sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]")))[-1]
+    """the latest profiles/rNN that holds the lines (a new round's directory starts empty)"""
+    dirs = [d for d in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]")))
+            if all(os.path.exists(os.path.join(d, n)) for n in ("bench_default.json", "bench_default_k20.json",
+                                                                "engine_1rank_shard8.json"))]
+    assert dirs, "no profiles/rNN with the committed bench lines"
+    return dirs[-1]
 
 
 def load(name):
