@@ -90,6 +90,13 @@ def run(ncases, seed, verbose=True):
                 o2 = po.solve(m, n, irow[perm], icol[perm], a[perm], b, damp=1e-2, itnlim=6)
                 drift = max(drift, float(np.linalg.norm(o2.x - o.x) / max(np.linalg.norm(o.x), 1e-300)))
             tol_long = max(1e-9, 200.0 * drift)
+            # ... and not at all when the bidiagonalisation has broken down inside these 6 iterations (arnorm, which
+            # decreases while LSQR converges, jumps up): every rounding anywhere -- the norms' too, which a permutation
+            # of the input does not touch -- then decides x
+            if o.itn > 1:
+                o_prev = po.solve(m, n, irow, icol, a, b, damp=1e-2, itnlim=o.itn - 1)
+                if o.arnorm > 1.5 * o_prev.arnorm:
+                    tol_long = float("inf")
         for lay in LAYOUTS:
             for k in KNOBS:
                 os.environ.pop(k, None)
