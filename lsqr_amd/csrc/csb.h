@@ -22,25 +22,30 @@
 //     R d / n, the nonzeros a block holds per column -- hence R as large as the LDS allows.
 //   * the block's row sums are accumulated IN LDS, one 64-bit INTEGER per row (ds_add_u64).  Floating-
 //     point adds in an order nobody controls would not be reproducible; integer adds are exact and
-//     order-free by nature.  Each product p is rounded once to the fixed binary grid
-//         g = 2^(eb - 61),      2^eb > B >= |sum_j A_ij (x_j sx)| for every row i,
-//     q = rint(p / g) is added, and y's new part is (double)(sum of the q) * g: ONE more rounding.
-//     The bound: B = max_i sum_j |a_ij| * max_j |x_j sx| -- the largest row 1-norm, taken at build time as an
-//     integer sum (deterministic), times the largest entry of the vector, taken by a k_amax pass over x before
-//     every product (0.4 % of a config-4 product).  It holds whatever the matrix looks like -- in particular with
-//     DUPLICATE (i, j) entries, which the reference sums like any others: the first form of this bound,
-//     |a_i|_2 |x|_2 for the solver's unit vectors, is wrong with duplicates (185 equal entries on one (i, j)
-//     weigh 185, not sqrt(185): the sums wrapped on such a system, tests/test_gpu_fuzz.py) -- and for vectors
-//     without outliers it is also the tighter one (config 4: 60 * 1.6e-3 against 6.5).  Only the FINAL sum has to
-//     fit -- two's-complement adds wrap, so partial sums in any order may overflow on the way -- and it does
-//     with two bits to spare whatever the row length.  So the result does not depend on the order of the adds,
-//     on R, on the launch shape, on which workgroup took which block or on column splits: bit-reproducible by
-//     construction.  Accuracy: each product is off by <= g/2 = 2^-62 B, i.e. a row of k nonzeros by <= k 2^-62 B
-//     (typically sqrt(k) 2^-63 B) where the reference's left-to-right sum is off by up to k 2^-53 |a_i|'|x|.
-//     (r02 kept two parts per row, 12-16 bytes: 9766-13021 rows per block at config 4; 8 bytes per
-//     row give 19532 -- 50 % more nonzeros per column of x in every sweep and 2 rounds instead of 3.)
-//   * a product beyond the bound or not finite (inf / NaN in x: never in a solve that has not
-//     already failed) cannot enter an integer sum: the sweep leaves it out and raises a flag, and
+//     order-free by nature.  Each product p is rounded once to a fixed binary grid, q = rint(p / g) is added,
+//     and y's new part is (double)(sum of the q) * g: ONE more rounding.
+//   * the grid is the ROW's own (round 4; r03 had one grid for the whole matrix, which left a row whose 1-norm
+//     lay 2^s below the largest only 61 - s bits -- weighted least squares, badly scaled columns in mode 2):
+//       - build: every row i gets e1_i with 2^e1_i > sum_j |a_ij| (an integer sum relative to the row's own
+//         largest exponent: deterministic), and the stored values are a'_ij = a_ij 2^-e1_i -- exact, a power of
+//         two; a matrix for which it is not (a value that is not finite, an exponent beyond +-900, an entry
+//         2^-126 below its row in a REAL32 handle) declines this layout.  So sum_j |a'_ij| < 1 for every row
+//         and the epilogue multiplies the row's sum by 2^e1_i (2 bytes per row, read once per product).
+//       - product: with tau = 2^ef >= |x_j sx| for the columns the LDS sums take, |sum_j a'_ij x_j sx| < tau:
+//         g = 2^(ef - 61), the sum fits with two bits to spare whatever the row length -- only the FINAL sum
+//         has to fit, two's-complement adds wrap.  A row is off by <= k 2^-62 2^e1_i tau where the reference's
+//         left-to-right sum is off by up to k 2^-53 |a_i|'|x|.
+//   * tau is NOT simply max|x sx|: ONE large entry in x (a spike in v or u: a column or row of A scaled far above
+//     the others) would push the grid of every row up, also of the rows that never touch it.  The k_csb_xmax pass
+//     in front of every product leaves the maximum of each of its <= 4096 strided pieces of x; tau = min(max,
+//     8..32 x the MEDIAN piece maximum).  Columns with |x_j sx| >= tau ("big": none at
+//     all for a vector without outliers, a handful otherwise) go to a SECOND set of integer sums on the grid of
+//     max|x sx| itself, kept in HBM (zc, 8 bytes per row, global atomics: integer adds again, exact and order-free)
+//     and added by the epilogue of the blocks that used them.  Both grids are functions of x and the row alone:
+//     the result does not depend on the order of the adds, on R, on the launch shape, on which workgroup took
+//     which block or on column splits -- bit-reproducible by construction.
+//   * a big column whose product is beyond even the coarse bound or not finite (inf / NaN in x: never in a solve
+//     that has not already failed) cannot enter an integer sum: the sweep leaves it out and raises a flag, and
 //     the block's epilogue then reads the stream a second time, adds ONLY those products as doubles
 //     and patches the rows concerned -- inf and NaN come out as IEEE addition gives them, like the
 //     reference's (tests/test_gpu_csb.py::test_non_finite_and_huge_x_as_the_reference).
@@ -58,6 +63,8 @@
 //   cbase[c] = column of the first nonzero of chunk c.  A chunk spans < 2^17 columns or the build
 //   gives up (an almost empty block: such a matrix keeps the panel layout).
 #pragma once
+
+#include <climits>
 
 #include "common.h"
 #include "csr_build.h"
@@ -77,7 +84,10 @@ constexpr int CSB_LCOL_BITS = 17;
 constexpr unsigned CSB_LCOL_MASK = (1u << CSB_LCOL_BITS) - 1u;
 static_assert(CSB_NACC <= (1 << (32 - CSB_LCOL_BITS)), "local rows fit the index word");
 constexpr int CSB_GRID = 256;                    // one workgroup per CU
-constexpr int CSB_NORM_FRAC = 32;                // build: row 1-norms as integer sums of ceil(|a| 2^(32 - ea))
+constexpr int CSB_NORM_FRAC = 32;                // build: row 1-norms as integer sums of ceil(|a| 2^(32 - emax_i))
+constexpr int CSB_NO_EXP = INT_MIN;              // build: "this row has no nonzero value yet" in the rows' largest exponents
+constexpr int CSB_E1_LIMIT = 900;                // build: rows whose 1-norm lies beyond 2^+-900 decline the layout
+constexpr int CSB_XHIST = 64;                    // product: piece maxima of x binned by their distance (in exponents) from the largest
 // The (value, index) stream is read once: loaded non-temporal so that it does not push the part of x the
 // XCD's workgroups are gathering from out of L2 (PMC before: 15 % of the gathers missed L2, 2.6x the
 // layout's bytes fetched; config 4 4.80 -> 4.20 ms, config 3 at 100 per row 956 -> 900 us).
@@ -86,18 +96,19 @@ constexpr int CSB_NORM_FRAC = 32;                // build: row 1-norms as intege
 #endif
 
 struct CsbMat {
-    const void *val;        // VT values (double; float for a REAL32 handle)
+    const void *val;        // VT values (double; float for a REAL32 handle), each row scaled by 2^-rexp[row]
     const unsigned *idx;
     const int *cbase;
     const long long *cptr;  // [nrb + 1], in chunks
     const int *rstart;      // [nrb + 1] first row of each block (blocks are cut by NONZEROS, at most R rows each)
     int nrb, R, rows, cols; // R = the dummy accumulator's index = rows per block at most
-    int e1;  // 2^e1 > max_i sum_j |a_ij|: with max|x sx| the bound on a row sum
+    const short *rexp;      // [rows] e1_i: 2^e1_i > sum_j |a_ij|; the stored values are a_ij 2^-e1_i
+    long long *zc;          // [rows] integer sums of the products with "big" columns on the coarse grid (header); all zero between products
     int b0, b1;  // the row blocks of THIS launch: [b0, b1)
     int S;       // column splits: S workgroups share a row block, each sweeping 1/S of its chunks (see below)
     long long *z;   // S > 1: the splits' exact integer sums, [S][rows]
-    int *bad;       // S > 1: [nrb] a split of the block left a product out (beyond the bound / not finite)
-    double *gout;   // S > 1: this product's grid step g for k_csb_combine
+    int *bad;       // S > 1: [nrb] bit 0: a split of the block left a product out (beyond the bound / not finite);
+                    //        bit 1: a split of the block added to zc
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -123,40 +134,65 @@ __global__ __launch_bounds__(256) void k_csb_pack_col(const int *__restrict__ ro
     if (uns) atomicOr(&flags[1], 1);
 }
 
+__global__ __launch_bounds__(256) void k_fill_int(int *__restrict__ a, int64_t n, int v)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) a[i] = v;
+}
+
+// emax[row] = the largest exponent among the row's nonzero values (2^e > |a|, frexp's); flags[0] |= 1 when a value
+// is not finite (such a matrix keeps another layout: its row sums are inf / NaN by floating-point addition there)
+__global__ __launch_bounds__(256) void k_csb_rowemax(const int *__restrict__ rowk, const double *__restrict__ a, int64_t nnz,
+                                                     int *__restrict__ emax, int *__restrict__ flags)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int nf = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nnz; i += stride) {
+        const double v = fabs(a[i]);
+        if (!(v < 1.0e308 * 10.0)) { nf = 1; continue; }   // inf, NaN
+        if (v == 0.0) continue;
+        int e = 0;
+        (void)frexp(v, &e);
+        atomicMax(&emax[rowk[i] - 1], e);
+    }
+    if (nf) atomicOr(&flags[0], 1);
+}
+
 // pos1[i] = original position of the i-th nonzero in column order; cnt[row] += 1; and the row 1-norms behind
-// the bound on a row sum (header): n1[row] += ceil(|a| 2^(32 - ea)) with 2^ea > max|a| -- an integer sum, so the
-// bound does not depend on the order of the atomics.  (A value that is not finite counts as 2^ea: its products
-// are left to the outlier pass anyway.)
+// the rows' grids (header): n1[row] += ceil(|a| 2^(32 - emax[row])) -- an integer sum of terms <= 2^32, so the
+// bound does not depend on the order of the atomics and is relative to the ROW's own largest value.
 __global__ __launch_bounds__(256) void k_csb_pos(const unsigned long long *__restrict__ sorted, int64_t nnz,
-                                                 const int *__restrict__ rowk, const double *__restrict__ a, double sc,
+                                                 const int *__restrict__ rowk, const double *__restrict__ a,
+                                                 const int *__restrict__ emax,
                                                  unsigned *__restrict__ pos1, int *__restrict__ cnt,
                                                  unsigned long long *__restrict__ n1)
 {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    const double one = (double)(1ull << CSB_NORM_FRAC);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nnz; i += stride) {
         const unsigned p = (unsigned)(sorted[i] & 0xffffffffull);
         pos1[i] = p;
         const int r = rowk[p] - 1;
         atomicAdd(&cnt[r], 1);
-        double t = fabs(a[p]) * sc;      // in [0, 1)
-        t = t < 1.0 ? t : 1.0;           // (inf, NaN -> 1)
-        atomicAdd(&n1[r], (unsigned long long)ceil(t * one));
+        const double v = fabs(a[p]);
+        if (v > 0.0 && v < 1.0e308 * 10.0)
+            atomicAdd(&n1[r], (unsigned long long)ceil(ldexp(v, CSB_NORM_FRAC - emax[r])));   // exact, in (0, 2^32]
     }
 }
 
-__global__ __launch_bounds__(256) void k_csb_maxu64(const unsigned long long *__restrict__ a, int64_t n,
-                                                    unsigned long long *__restrict__ out)
+// rexp[row] = e1 with 2^e1 > sum_j |a_ij| (0 for a row without nonzero values); flags[1] |= 1 when |e1| > CSB_E1_LIMIT
+__global__ __launch_bounds__(256) void k_csb_rexp(const unsigned long long *__restrict__ n1, const int *__restrict__ emax,
+                                                  int rows, short *__restrict__ rexp, int *__restrict__ flags)
 {
-    unsigned long long m = 0;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) m = a[i] > m ? a[i] : m;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const unsigned long long o = __shfl_xor(m, off, WAVE);
-        m = o > m ? o : m;
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    const unsigned long long v = n1[r];
+    int e1 = 0;
+    if (v != 0ull) e1 = emax[r] - CSB_NORM_FRAC + (64 - __clzll((long long)v));   // v < 2^(64 - clz)
+    if (e1 > CSB_E1_LIMIT || e1 < -CSB_E1_LIMIT) {
+        atomicOr(&flags[1], 1);
+        e1 = 0;
     }
-    if ((threadIdx.x & (WAVE - 1)) == 0 && m > 0) atomicMax(out, m);
+    rexp[r] = (short)e1;
 }
 
 __global__ __launch_bounds__(256) void k_csb_maxint(const int *__restrict__ a, int64_t n, int *__restrict__ out)
@@ -188,7 +224,9 @@ __global__ __launch_bounds__(256) void k_csb_pack_rb(const int *__restrict__ row
 }
 
 // One workgroup per chunk: element t of chunk c of block b is the (c - cptr[b]) * 256 + t -th nonzero
-// of the block in column order, or padding.  flags[3] |= 1 if a chunk spans 2^17 columns or more.
+// of the block in column order, or padding.  The value stored is a 2^-rexp[row] (header).
+// flags[3] |= 1 if a chunk spans 2^17 columns or more; flags[2] |= 1 if a scaled value is not exact (it left the
+// normal range -- of binary32 when `f32`: the values of a REAL32 handle are narrowed after the build).
 __global__ __launch_bounds__(CSB_CHUNK) void k_csb_fill(const unsigned long long *__restrict__ sorted2,
                                                         const unsigned *__restrict__ pos1,
                                                         const int *__restrict__ rowk, const int *__restrict__ colk,
@@ -196,6 +234,7 @@ __global__ __launch_bounds__(CSB_CHUNK) void k_csb_fill(const unsigned long long
                                                         const long long *__restrict__ rbstart,
                                                         const long long *__restrict__ cptr,
                                                         const int *__restrict__ rstart, int nrb, int R,
+                                                        const short *__restrict__ rexp, int f32,
                                                         double *__restrict__ val, unsigned *__restrict__ idx,
                                                         int *__restrict__ cbase, int *__restrict__ flags)
 {
@@ -221,8 +260,14 @@ __global__ __launch_bounds__(CSB_CHUNK) void k_csb_fill(const unsigned long long
         const unsigned i = (unsigned)(sorted2[j0 + e] & 0xffffffffull);
         const unsigned p = pos1[i];
         col = colk[p] - 1;
-        lrow = (rowk[p] - 1) - rstart[b];
-        v = a[p];
+        const int row = rowk[p] - 1;
+        lrow = row - rstart[b];
+        const double v0 = a[p];
+        const int ex = rexp[row];
+        v = ldexp(v0, -ex);
+        bool exact = ldexp(v, ex) == v0;
+        if (f32) exact = exact && (double)(float)v == v;
+        if (!exact) atomicOr(&flags[2], 1);
     }
     if (threadIdx.x == 0) s_cb = col;  // the first element of a chunk is never padding
     __syncthreads();
@@ -239,8 +284,9 @@ __global__ __launch_bounds__(CSB_CHUNK) void k_csb_fill(const unsigned long long
 // product
 // ---------------------------------------------------------------------------------------------
 struct CsbX {
-    const double *xmax;  // partials of max|x| (vec.h k_amax over the vector this product gathers from)
+    const double *xmax;  // piece maxima of |x| (vec.h k_csb_xmax over the vector this product gathers from)
     int nxmax;
+    int split;           // 0: tau = the bound on max|x sx| whatever x looks like (LSQRHIP_CSB_TAU=0, ablation)
 };
 
 // sx, sy, cy of this launch: explicit (coef) or lazy from the previous kernel's partials (pin) -- the
@@ -284,40 +330,88 @@ __device__ __forceinline__ CsbCoef csb_coef(const SpmvCoef *__restrict__ coef, c
     return c;
 }
 
-// 2^eb > the bound on |row sum| of this launch (header): the largest row 1-norm times max|x sx|, the latter from
-// the partials of the k_amax pass that precedes every product; every thread gets the same value.
-__device__ __forceinline__ int csb_bound_exp(const CsbMat &A, CsbX xb, double sx, double *red)
+// The two grids of this launch (header) from the piece maxima the k_csb_xmax pass left (<= 4096, one per wave of it):
+//   ec: 2^ec > max_j |x_j sx|                                      -- the coarse grid, and what "in range" means;
+//   ef: tau = 2^ef, min(2^ec, 8..32 x the MEDIAN piece maximum)     -- the fine grid: columns with |x_j sx| < tau.
+// The median piece: spikes in up to half the pieces leave it alone, and for a vector without outliers -- Gaussian
+// entries: the largest of 10^7 is 1.4 x the median maximum of pieces of 2441; power-law rows up to 10^4 long
+// (config 5's u): 1.2 x -- tau is simply the bound on max|x sx| and no column is big.
+// Every thread gets the same values, and every kernel of a product (sweeps, combine) derives them from the same
+// partials: bit for bit the same grids.  `red`: CSB_WAVES doubles, `hist`: CSB_XHIST ints.
+struct CsbGrid {
+    int ef, ec;
+};
+__device__ __forceinline__ CsbGrid csb_grids(CsbX xb, double sx, double *red, int *hist)
 {
     const int tid = threadIdx.x, lane = tid & (WAVE - 1);
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nthreads = blockDim.x;
     double m = 0.0;
-    for (int i = tid; i < xb.nxmax; i += CSB_BLOCK) m = fmax(m, xb.xmax[i]);
+    for (int i = tid; i < xb.nxmax; i += nthreads) m = fmax(m, xb.xmax[i]);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off, WAVE));
     if (lane == 0) red[w] = m;
+    if (tid < CSB_XHIST) hist[tid] = 0;
     __syncthreads();
     m = red[0];
-#pragma unroll
-    for (int i = 1; i < CSB_WAVES; ++i) m = fmax(m, red[i]);
+    for (int i = 1; i < (nthreads >> 6); ++i) m = fmax(m, red[i]);
+    int em = 0;
+    const bool mfin = m > 0.0 && m < 1.0e308;
+    if (mfin) (void)frexp(m, &em);
+    // piece maxima by their distance from the largest, in exponents (zero pieces: the last bin)
+    for (int i = tid; i < xb.nxmax; i += nthreads) {
+        const double v = xb.xmax[i];
+        int d = CSB_XHIST - 1;
+        if (!(v < 1.0e308)) d = 0;   // (inf, NaN: with the largest)
+        else if (v > 0.0 && mfin) {
+            int e = 0;
+            (void)frexp(v, &e);
+            d = em - e;
+            d = d < 0 ? 0 : (d > CSB_XHIST - 1 ? CSB_XHIST - 1 : d);
+        }
+        // one LDS add per distinct bin of the wave (nearly all pieces share two or three bins)
+        unsigned long long todo = __ballot(1);
+        while (todo != 0ull) {
+            const int first = __ffsll((long long)todo) - 1;
+            const int d0 = __shfl(d, first, WAVE);
+            const unsigned long long same = __ballot(d == d0);
+            if (lane == first) atomicAdd(&hist[d0], __popcll(same));
+            todo &= ~same;
+            if (d == d0) break;
+        }
+    }
     __syncthreads();
+    // the median piece maximum: the first bin at which the running count reaches K
+    const int K = 1 + xb.nxmax / 2;
+    int dk = 0;
+    if (xb.nxmax >= K) {
+        int c = 0;
+        for (int d = 0; d < CSB_XHIST; ++d) {
+            c += hist[d];
+            dk = d;
+            if (c >= K) break;
+        }
+    }
+    __syncthreads();   // (red, hist may be reused by the caller)
     const double bound = m * fabs(sx);
     int ex = 0;
     if (bound > 0.0 && bound < 1.0e308) (void)frexp(bound, &ex);  // bound < 2^ex
-    int eb = A.e1 + ex;
-    eb = eb > 1020 ? 1020 : eb;      // 2^eb and 2^(61 - eb) must stay finite and normal
-    eb = eb < -960 ? -960 : eb;
-    return eb;
+    CsbGrid g;
+    g.ec = ex > 1020 ? 1020 : (ex < -960 ? -960 : ex);      // 2^ec and 2^(61 - ec) must stay finite and normal
+    g.ef = xb.split ? g.ec - dk + 4 : g.ec;                   // > 8 x the median piece maximum, scaled
+    g.ef = g.ef > g.ec ? g.ec : (g.ef < -960 ? -960 : g.ef);
+    return g;
 }
 
-// Rows that were sent a product beyond the bound or not finite.  The sweep left those products out (an
-// integer sum cannot hold them); here the chunks [c0, c1) of the block are read once more, ONLY those
+// Rows that were sent a product of a big column beyond the coarse bound or not finite.  The sweep left those
+// products out (an integer sum cannot hold them); here the chunks [c0, c1) of the block are read once more, ONLY those
 // products are added -- as doubles, in LDS (`accd`: the block's accumulators, all zero on entry and on
 // exit) -- and the rows concerned are patched in y: inf and NaN come out as IEEE addition gives them,
-// which is what the reference's row sum does with them.  Reached when x (or A) holds inf / NaN or
+// which is what the reference's row sum does with them.  Reached when x holds inf / NaN or
 // |x| is not what the bound was taken from; never by a healthy solve.
 template <typename VT>
 __device__ void csb_add_outliers(const CsbMat &A, const VT *__restrict__ aval, long long c0, long long c1,
-                                 const VT *__restrict__ x, double sx, double pmax, double *accd,
+                                 const VT *__restrict__ x, double sx, double tau, double pmax, double *accd,
                                  VT *__restrict__ y, int row0, int nr)
 {
     const int tid = threadIdx.x, lane = tid & (WAVE - 1);
@@ -328,16 +422,17 @@ __device__ void csb_add_outliers(const CsbMat &A, const VT *__restrict__ aval, l
 #pragma unroll
         for (int j = 0; j < CSB_U; ++j) {
             const unsigned i = A.idx[k + j * WAVE];
-            const double p = (double)aval[k + j * WAVE] * ((double)x[base + (int)(i & CSB_LCOL_MASK)] * sx);
+            const double xs = (double)x[base + (int)(i & CSB_LCOL_MASK)] * sx;
+            const double p = (double)aval[k + j * WAVE] * xs;
             const int r = (int)(i >> CSB_LCOL_BITS);
-            if (!(fabs(p) < pmax) && r < nr) atomicAdd(&accd[r], p);
+            if (!(fabs(xs) < tau) && !(fabs(p) < pmax) && r < nr) atomicAdd(&accd[r], p);
         }
     }
     __syncthreads();
     for (int r = tid; r < nr; r += CSB_BLOCK) {
         const double v = accd[r];
         if (v != 0.0) {   // (true for NaN)
-            y[row0 + r] = (VT)((double)y[row0 + r] + v);
+            y[row0 + r] = (VT)((double)y[row0 + r] + ldexp(v, (int)A.rexp[row0 + r]));
             accd[r] = 0.0;
         }
     }
@@ -356,6 +451,25 @@ __device__ __forceinline__ double csb_sumsq_rows(const VT *__restrict__ y, int r
     return sq;
 }
 
+// A row's sum from its integer parts: the LDS sum on the fine grid, and -- `coarse`: the block used them -- the
+// HBM sum of its big columns on the coarse grid (taken and cleared with agent-scope atomics: the adds of other
+// workgroups' sweeps -- column splits -- were performed at memory, not in this XCD's L2).  One rounding per
+// part and one for their sum; the row's power of two is exact.
+__device__ __forceinline__ double csb_row_sum(const CsbMat &A, long long fine, int row, CsbGrid gr, bool coarse)
+{
+    const int e = (int)A.rexp[row];
+    double sum = ldexp((double)fine, gr.ef - 61 + e);
+    if (coarse) {
+        const long long c = (long long)__hip_atomic_load((unsigned long long *)&A.zc[row], __ATOMIC_RELAXED,
+                                                         __HIP_MEMORY_SCOPE_AGENT);
+        if (c != 0) {
+            sum = sum + ldexp((double)c, gr.ec - 61 + e);
+            __hip_atomic_store((unsigned long long *)&A.zc[row], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    return sum;
+}
+
 template <typename VT = double>
 __global__ __launch_bounds__(CSB_BLOCK, 1) void k_spmv_csb(
     CsbMat A, const VT *__restrict__ x, VT *__restrict__ y, const SpmvCoef *__restrict__ coef,
@@ -365,7 +479,7 @@ __global__ __launch_bounds__(CSB_BLOCK, 1) void k_spmv_csb(
 {
     __shared__ unsigned long long acc[CSB_NACC];
     __shared__ double red[CSB_WAVES + 2];
-    __shared__ int s_bad;
+    __shared__ int s_bad, s_big;
     const int tid = threadIdx.x;
     const int lane = tid & (WAVE - 1);
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -388,17 +502,20 @@ __global__ __launch_bounds__(CSB_BLOCK, 1) void k_spmv_csb(
     if (co.skip) return;
     const double sx = co.sx, sy = co.sy, cy = co.cy;
 
-    // the binary grid of this launch
-    const int eb = csb_bound_exp(A, xb, sx, red);
-    const double pmax = ldexp(1.0, eb);          // a product is in range below this
-    const double ginv = ldexp(1.0, 61 - eb);     // 1 / g
-    const double g = ldexp(1.0, eb - 61);
+    // the binary grids of this launch (the histogram of the piece maxima borrows the accumulators' space)
+    const CsbGrid gr = csb_grids(xb, sx, red, reinterpret_cast<int *>(acc));
+    const double tau = ldexp(1.0, gr.ef);          // columns with |x sx| below this: the LDS sums
+    const double ginv = ldexp(1.0, 61 - gr.ef);    // 1 / g of the fine grid
+    const double pmax2 = ldexp(1.0, gr.ec);        // a product of a big column is in range below this
+    const double ginv2 = ldexp(1.0, 61 - gr.ec);   // 1 / g of the coarse grid
 
     for (int i = tid; i < CSB_NACC; i += CSB_BLOCK) acc[i] = 0ull;
-    if (tid == 0) s_bad = 0;
+    if (tid == 0) {
+        s_bad = 0;
+        s_big = 0;
+    }
     __syncthreads();
 
-    if (A.S > 1 && wg == 0 && tid == 0) *A.gout = g;
     // Column splits (few rows: fewer row blocks than CUs).  S workgroups share a block, each sweeping a
     // contiguous S-th of its column-sorted chunks into accumulators of its own; their integer sums go to
     // z and k_csb_combine adds them -- exact, so the result is bit for bit what ONE workgroup would have
@@ -409,12 +526,14 @@ __global__ __launch_bounds__(CSB_BLOCK, 1) void k_spmv_csb(
         const int b = A.b0 + u / A.S, sp = u % A.S;
         const long long cb0 = A.cptr[b], cb1 = A.cptr[b + 1];
         const long long c0 = cb0 + ((cb1 - cb0) * sp) / A.S, c1 = cb0 + ((cb1 - cb0) * (sp + 1)) / A.S;
+        const int row0 = A.rstart[b];
+        const int nr = A.rstart[b + 1] - row0;
         // software pipeline: the (value, index) stream of the wave's NEXT chunk is in flight while the
         // gathers and the LDS adds of this one run (two register sets, loads unconditional: clamped)
         double av[CSB_U], bv[CSB_U];
         unsigned iv[CSB_U], jv[CSB_U];
         int cb = 0, cbn = 0;
-        bool outlier = false;
+        bool outlier = false, tookbig = false;
         const long long clast = c1 > c0 ? c1 - 1 : c0;
         auto issue = [&](long long c, double (&a)[CSB_U], unsigned (&i)[CSB_U], int &base) {
             const long long cc = c < clast ? c : clast;
@@ -434,15 +553,29 @@ __global__ __launch_bounds__(CSB_BLOCK, 1) void k_spmv_csb(
         auto work = [&](const double (&a)[CSB_U], const unsigned (&i)[CSB_U], int base) {
             double xv[CSB_U];
 #pragma unroll
-            for (int j = 0; j < CSB_U; ++j) xv[j] = (double)x[base + (int)(i[j] & CSB_LCOL_MASK)];
+            for (int j = 0; j < CSB_U; ++j) xv[j] = (double)x[base + (int)(i[j] & CSB_LCOL_MASK)] * sx;
+            bool anybig = false;
 #pragma unroll
             for (int j = 0; j < CSB_U; ++j) {
-                const double p = a[j] * (xv[j] * sx);
+                const double p = a[j] * xv[j];
                 const int r = (int)(i[j] >> CSB_LCOL_BITS);
-                const bool out = !(fabs(p) < pmax);   // beyond the bound (or not finite): left to the outlier pass
-                outlier |= out;
+                const bool big = !(fabs(xv[j]) < tau);   // a big column (or x not finite): not for the fine grid
+                anybig |= big;
                 const long long q = __double2ll_rn(p * ginv);
-                atomicAdd(&acc[r], out ? 0ull : (unsigned long long)q);
+                atomicAdd(&acc[r], big ? 0ull : (unsigned long long)q);
+            }
+            if (__any(anybig)) {   // (wave-uniform; never taken for a vector without outliers)
+#pragma unroll
+                for (int j = 0; j < CSB_U; ++j) {
+                    const int r = (int)(i[j] >> CSB_LCOL_BITS);
+                    if (!(fabs(xv[j]) < tau) && r < nr) {   // (padding aims at the dummy accumulator R >= nr)
+                        const double p = a[j] * xv[j];
+                        if (fabs(p) < pmax2)
+                            atomicAdd((unsigned long long *)&A.zc[row0 + r], (unsigned long long)__double2ll_rn(p * ginv2));
+                        else outlier = true;   // beyond the coarse bound, or not finite: left to the outlier pass
+                        tookbig = true;
+                    }
+                }
             }
         };
         if (c0 + w < c1) {
@@ -457,12 +590,14 @@ __global__ __launch_bounds__(CSB_BLOCK, 1) void k_spmv_csb(
             }
         }
         if (outlier) s_bad = 1;
+        if (tookbig) {
+            s_big = 1;
+            __threadfence();   // this wave's adds to zc are performed before anyone reads them back
+        }
         __syncthreads();
         // epilogue of the block: y, its partial of sum (y ns)^2, accumulators cleared
-        const int row0 = A.rstart[b];
-        const int nr = A.rstart[b + 1] - row0;
-        const bool bad = s_bad != 0;
-        __syncthreads();   // (everyone has read the flag: it may be lowered)
+        const bool bad = s_bad != 0, big = s_big != 0;
+        __syncthreads();   // (everyone has read the flags: they may be lowered)
         if (A.S > 1) {  // a split: the exact sums as they are
             long long *zs = A.z + (size_t)sp * A.rows + row0;
             for (int r = tid; r < nr; r += CSB_BLOCK) {
@@ -472,14 +607,15 @@ __global__ __launch_bounds__(CSB_BLOCK, 1) void k_spmv_csb(
             if (tid == 0) {
                 acc[A.R] = 0ull;
                 s_bad = 0;
-                if (bad) atomicOr(&A.bad[b], 1);
+                s_big = 0;
+                if (bad || big) atomicOr(&A.bad[b], (bad ? 1 : 0) | (big ? 2 : 0));
             }
             __syncthreads();
             continue;
         }
         double sq = 0.0;
         for (int r = tid; r < nr; r += CSB_BLOCK) {
-            const double sum = (double)(long long)acc[r] * g;
+            const double sum = csb_row_sum(A, (long long)acc[r], row0 + r, gr, big);
             acc[r] = 0ull;
             const VT yn = (VT)(cy * ((double)y[row0 + r] * sy) + sum);
             y[row0 + r] = yn;
@@ -489,10 +625,11 @@ __global__ __launch_bounds__(CSB_BLOCK, 1) void k_spmv_csb(
         if (tid == 0) {  // the padding's dummy accumulator
             acc[A.R] = 0ull;
             s_bad = 0;
+            s_big = 0;
         }
         if (bad) {  // uniform
             __syncthreads();
-            csb_add_outliers<VT>(A, aval, c0, c1, x, sx, pmax, reinterpret_cast<double *>(acc), y, row0, nr);
+            csb_add_outliers<VT>(A, aval, c0, c1, x, sx, tau, pmax2, reinterpret_cast<double *>(acc), y, row0, nr);
             sq = csb_sumsq_rows<VT>(y, row0, nr, nsc);
         }
         sq = wave_sum(sq);
@@ -515,42 +652,61 @@ template <typename VT = double>
 __global__ __launch_bounds__(CSB_BLOCK) void k_csb_combine(
     CsbMat A, const VT *__restrict__ x, VT *__restrict__ y, const SpmvCoef *__restrict__ coef,
     const int *__restrict__ stop, double *__restrict__ partials, const double *__restrict__ pin, int npin,
-    const NormSlot *__restrict__ slot_in, int skip_if_zero, NScale nsc)
+    const NormSlot *__restrict__ slot_in, int skip_if_zero, CsbX xb, NScale nsc)
 {
     __shared__ double accd[CSB_NACC];   // the outlier pass only (all zero otherwise)
     __shared__ double red[CSB_WAVES + 2];
+    __shared__ int hist[CSB_XHIST];
     const int tid = threadIdx.x, lane = tid & (WAVE - 1);
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    if (*stop != 0) return;
+    if (*stop != 0) {
+        // The solve stopped while this product was under way (the scalar rider travels with its first sweep): some
+        // sweeps may have run and added to zc, y is no longer wanted.  What they left behind must still go -- the
+        // next product of this matrix expects zc all zero and the flags down.
+        for (int b = blockIdx.x; b < A.nrb; b += gridDim.x) {
+            const int flags = A.bad[b];
+            __syncthreads();
+            if (flags & 2) {
+                const int row0 = A.rstart[b], nr = A.rstart[b + 1] - row0;
+                for (int r = tid; r < nr; r += CSB_BLOCK)
+                    __hip_atomic_store((unsigned long long *)&A.zc[row0 + r], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (flags != 0 && tid == 0) A.bad[b] = 0;
+        }
+        return;
+    }
     const CsbCoef co = csb_coef(coef, pin, npin, slot_in, skip_if_zero, nsc, red);
     if (co.skip) return;
     const double sx = co.sx, sy = co.sy, cy = co.cy;
-    const double g = *A.gout;
+    const CsbGrid gr = csb_grids(xb, sx, red, hist);   // the sweeps' grids: same partials, same function
     const VT *__restrict__ aval = static_cast<const VT *>(A.val);
     bool cleared = false;
     for (int b = blockIdx.x; b < A.nrb; b += gridDim.x) {
         const int row0 = A.rstart[b];
         const int nr = A.rstart[b + 1] - row0;
+        const int flags = A.bad[b];   // uniform: what the splits of this block ran into (k_spmv_csb)
+        __syncthreads();              // (everyone has read the word: thread 0 may clear it below)
         double sq = 0.0;
         for (int r = tid; r < nr; r += CSB_BLOCK) {
             long long s = __builtin_nontemporal_load(&A.z[row0 + r]);
             for (int sp = 1; sp < A.S; ++sp) s += __builtin_nontemporal_load(&A.z[(size_t)sp * A.rows + row0 + r]);
-            const double sum = (double)s * g;
+            const double sum = csb_row_sum(A, s, row0 + r, gr, (flags & 2) != 0);
             const VT yn = (VT)(cy * ((double)y[row0 + r] * sy) + sum);
             y[row0 + r] = yn;
             const double ys = (double)yn * nsc.s;
             sq += ys * ys;
         }
-        if (A.bad[b] != 0) {  // uniform: a split of this block left products out (k_spmv_csb "outlier")
+        if (flags & 1) {  // a split of this block left products out
             if (!cleared) {
                 for (int i = tid; i < CSB_NACC; i += CSB_BLOCK) accd[i] = 0.0;
                 cleared = true;
             }
             __syncthreads();   // (y of this block is written; accd is zero)
-            csb_add_outliers<VT>(A, aval, A.cptr[b], A.cptr[b + 1], x, sx, g * 0x1p61, accd, y, row0, nr);
+            csb_add_outliers<VT>(A, aval, A.cptr[b], A.cptr[b + 1], x, sx, ldexp(1.0, gr.ef), ldexp(1.0, gr.ec), accd, y,
+                                 row0, nr);
             sq = csb_sumsq_rows<VT>(y, row0, nr, nsc);
-            if (tid == 0) A.bad[b] = 0;
         }
+        if (flags != 0 && tid == 0) A.bad[b] = 0;
         sq = wave_sum(sq);
         if (lane == 0) red[w] = sq;
         __syncthreads();

@@ -177,7 +177,8 @@ struct Csr {
     int *crs = nullptr;           // [nrb + 1] first row of each row block
     int64_t nchunks = 0;
     int nrb = 0, R = 0;
-    int e1 = 0;                   // 2^e1 > the largest row 1-norm: csb.h's bound on a row sum, with max|x|
+    short *rexp = nullptr;        // [rows] e1_i, 2^e1_i > the row's 1-norm: the stored values are a_ij 2^-e1_i (csb.h)
+    long long *zcoarse = nullptr; // [rows] integer sums of the products with big columns (csb.h); zero between products
     int S = 1;                    // column splits per row block (csb.h): S workgroups share a block
     long long *zsplit = nullptr;  // S > 1: [S][rows] exact integer sums of the splits
     int *cbad = nullptr;          // S > 1: [nrb] "a split left a product out" flags (csb.h outlier pass)
@@ -352,6 +353,8 @@ static void free_csr(Csr &c)
     if (c.cptr) (void)hipFree(c.cptr);
     if (c.crs) (void)hipFree(c.crs);
     if (c.zsplit) (void)hipFree(c.zsplit);
+    if (c.rexp) (void)hipFree(c.rexp);
+    if (c.zcoarse) (void)hipFree(c.zcoarse);
     if (c.cbad) (void)hipFree(c.cbad);
     c = Csr();
 }
@@ -879,23 +882,26 @@ static unsigned long long *radix_sort_words(hipStream_t s, unsigned long long *i
 //   LSQRHIP_CSB_R  rows per block (test hook; default: as many as the LDS holds, cut so that the
 //                  blocks divide evenly among the 256 workgroups)
 static int build_csb(hipStream_t s, const int *rowk, const int *colk, const double *d_a, int64_t nnz, int rows,
-                     int cols, int ea, int bad_code, int bad_code_other, unsigned long long *bufA,
+                     int cols, bool f32, int bad_code, int bad_code_other, unsigned long long *bufA,
                      unsigned long long *bufB, unsigned *hist, int *d_flags, Csr &out)
 {
     if (rows <= 0 || cols <= 0) return LSQRHIP_OK;
     const int g = (int)std::min<int64_t>(std::max<int64_t>((nnz + 255) / 256, 1), 4096);
     HIPCHK(hipMemsetAsync(d_flags, 0, 4 * sizeof(int), s));
     int got[4] = {0, 0, 0, 0};
-    DevScratch s_pos, s_cnt, s_rbs, s_nrm;
+    DevScratch s_pos, s_cnt, s_rbs, s_nrm, s_emax, s_rexp;
     HIPCHK(s_pos.alloc(sizeof(unsigned) * (size_t)std::max<int64_t>(nnz, 1)));
     HIPCHK(s_cnt.alloc(sizeof(int) * ((size_t)rows + 1)));
     HIPCHK(hipMemsetAsync(s_cnt.p, 0, sizeof(int) * ((size_t)rows + 1), s));
-    // row 1-norms as integer sums (csb.h k_csb_pos), then one word for their maximum
-    HIPCHK(s_nrm.alloc(sizeof(unsigned long long) * ((size_t)rows + 2)));
-    HIPCHK(hipMemsetAsync(s_nrm.p, 0, sizeof(unsigned long long) * ((size_t)rows + 2), s));
+    // per row: its largest exponent, its 1-norm as an integer sum relative to that (csb.h k_csb_pos), and from the
+    // two e1_i with 2^e1_i > sum_j |a_ij| -- the power of two the row's stored values are divided by
+    HIPCHK(s_nrm.alloc(sizeof(unsigned long long) * (size_t)rows));
+    HIPCHK(hipMemsetAsync(s_nrm.p, 0, sizeof(unsigned long long) * (size_t)rows, s));
+    HIPCHK(s_emax.alloc(sizeof(int) * (size_t)rows));
+    HIPCHK(s_rexp.alloc(sizeof(short) * (size_t)rows));
     unsigned long long *sorted1 = bufA;
     int maxrow = 0;
-    unsigned long long nmax[2] = {0, 0};
+    const dim3 gr((unsigned)std::min<int64_t>(((int64_t)rows + 255) / 256, 2048));
     if (nnz > 0) {
         hipLaunchKernelGGL(k_csb_pack_col, dim3(g), dim3(256), 0, s, rowk, colk, nnz, rows, cols, bufA, d_flags);
         HIPCHK(hipGetLastError());
@@ -904,25 +910,31 @@ static int build_csb(hipStream_t s, const int *rowk, const int *colk, const doub
         if (got[0]) return fail(bad_code, lsqrhip_error_string(bad_code));
         if (got[2]) return fail(bad_code_other, lsqrhip_error_string(bad_code_other));
         if (got[1]) sorted1 = radix_sort_words(s, bufA, bufB, nnz, bits_for(cols), hist);
-        unsigned long long *n1 = s_nrm.as<unsigned long long>(), *nm = n1 + rows;
-        hipLaunchKernelGGL(k_csb_pos, dim3(g), dim3(256), 0, s, (const unsigned long long *)sorted1, nnz, rowk, d_a,
-                           std::ldexp(1.0, -ea), s_pos.as<unsigned>(), s_cnt.as<int>(), n1);
-        // the longest row (how even the rows are), the largest row 1-norm (the bound on a row sum)
+        hipLaunchKernelGGL(k_fill_int, gr, dim3(256), 0, s, s_emax.as<int>(), (int64_t)rows, CSB_NO_EXP);
         HIPCHK(hipMemsetAsync(d_flags, 0, 4 * sizeof(int), s));
-        const dim3 gr((unsigned)std::min<int64_t>(((int64_t)rows + 255) / 256, 2048));
-        hipLaunchKernelGGL(k_csb_maxint, gr, dim3(256), 0, s, (const int *)s_cnt.as<int>(), (int64_t)rows, d_flags);
-        hipLaunchKernelGGL(k_csb_maxu64, gr, dim3(256), 0, s, (const unsigned long long *)n1, (int64_t)rows, nm);
+        hipLaunchKernelGGL(k_csb_rowemax, dim3(g), dim3(256), 0, s, rowk, d_a, nnz, s_emax.as<int>(), d_flags);
+        unsigned long long *n1 = s_nrm.as<unsigned long long>();
+        hipLaunchKernelGGL(k_csb_pos, dim3(g), dim3(256), 0, s, (const unsigned long long *)sorted1, nnz, rowk, d_a,
+                           (const int *)s_emax.as<int>(), s_pos.as<unsigned>(), s_cnt.as<int>(), n1);
+        hipLaunchKernelGGL(k_csb_rexp, dim3((unsigned)(((int64_t)rows + 255) / 256)), dim3(256), 0, s,
+                           (const unsigned long long *)n1, (const int *)s_emax.as<int>(), rows, s_rexp.as<short>(), d_flags);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(got, d_flags, sizeof(got), hipMemcpyDeviceToHost, s));
-        HIPCHK(hipMemcpyAsync(nmax, nm, sizeof(nmax), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        // a value that is not finite, or a row norm beyond 2^+-900: not this layout (csb.h)
+        if (got[0] || got[1]) return LSQRHIP_OK;
+        // the longest row (how even the rows are)
+        HIPCHK(hipMemsetAsync(d_flags, 0, 4 * sizeof(int), s));
+        hipLaunchKernelGGL(k_csb_maxint, gr, dim3(256), 0, s, (const int *)s_cnt.as<int>(), (int64_t)rows, d_flags);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(got, d_flags, sizeof(got), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
         maxrow = got[0];
+    } else {
+        HIPCHK(hipMemsetAsync(s_rexp.p, 0, sizeof(short) * (size_t)rows, s));
     }
+    s_emax.free_now();
     s_nrm.free_now();
-    // max_i sum_j |a_ij| < 2^e1 from the integer maximum (integer arithmetic: the same exponent on every build
-    // of the same matrix)
-    auto bits_u64 = [](unsigned long long v) { int b = 0; while (v) { ++b; v >>= 1; } return b; };   // v < 2^b
-    const int e1 = ea - CSB_NORM_FRAC + bits_u64(nmax[0]);
     // near-uniform rows (the longest <= 512): blocks cut by nonzeros stay close to the mean row count
     const bool even_rows = maxrow <= 512;
     const int rmax = CSB_RMAX;
@@ -1029,11 +1041,13 @@ static int build_csb(hipStream_t s, const int *rowk, const int *colk, const doub
         hipLaunchKernelGGL(k_csb_fill, dim3((unsigned)nchunks), dim3(CSB_CHUNK), 0, s, (const unsigned long long *)sorted2,
                            (const unsigned *)s_pos.as<unsigned>(), rowk, colk, d_a, (const long long *)s_rbs.as<long long>(),
                            (const long long *)s_cptr.as<long long>(), (const int *)s_rst.as<int>(), nrb, rmax,
-                           s_val.as<double>(), s_idx.as<unsigned>(), s_cb.as<int>(), d_flags);
+                           (const short *)s_rexp.as<short>(), f32 ? 1 : 0, s_val.as<double>(), s_idx.as<unsigned>(),
+                           s_cb.as<int>(), d_flags);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(got, d_flags, sizeof(got), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     if (got[3]) return LSQRHIP_OK;  // a chunk too wide for 18-bit local columns: not this layout
+    if (got[2]) return LSQRHIP_OK;  // a value that does not survive its row's power of two exactly: not this layout
     out = Csr();
     out.rows = rows;
     out.cols = cols;
@@ -1048,7 +1062,9 @@ static int build_csb(hipStream_t s, const int *rowk, const int *colk, const doub
     out.nstored = (int64_t)nchunks * CSB_CHUNK;
     out.nrb = nrb;
     out.R = rmax;   // the dummy accumulator's index (blocks hold at most this many rows)
-    out.e1 = e1;
+    out.rexp = s_rexp.release<short>();
+    HIPCHK(hipMalloc((void **)&out.zcoarse, sizeof(long long) * (size_t)rows));
+    HIPCHK(hipMemsetAsync(out.zcoarse, 0, sizeof(long long) * (size_t)rows, s));
     out.S = S;
     if (S > 1) {
         HIPCHK(hipMalloc((void **)&out.zsplit, sizeof(long long) * (size_t)S * (size_t)rows));
@@ -1058,8 +1074,10 @@ static int build_csb(hipStream_t s, const int *rowk, const int *colk, const doub
     out.grid = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)nrb * S, CSB_GRID));  // workgroups per launch
     out.out_grid = nrb;
     out.nblk = nrb;
-    // (+ 8 bytes per column: the k_csb_xmax pass reads the gathered vector once more than the sweeps' "x once")
-    out.bytes = (int64_t)nchunks * CSB_CHUNK * 12 + (int64_t)nchunks * 4 + (int64_t)(nrb + 1) * 8 + (int64_t)cols * 8;
+    // (+ 8 bytes per column: the k_csb_xmax pass reads the gathered vector once more than the sweeps' "x once";
+    //  + 2 bytes per row: the rows' powers of two)
+    out.bytes = (int64_t)nchunks * CSB_CHUNK * 12 + (int64_t)nchunks * 4 + (int64_t)(nrb + 1) * 8 + (int64_t)cols * 8 +
+                (int64_t)rows * 2;
     return LSQRHIP_OK;
 }
 
@@ -1133,7 +1151,7 @@ static int alloc_workspace(H *h)
     HIPCHK(hipMalloc((void **)&h->X, esz * n1));
     HIPCHK(hipMalloc((void **)&h->SE, esz * n1));
     HIPCHK(hipMalloc((void **)&h->partials, sizeof(double) * 3 * SPMV_MAX_GRID));
-    HIPCHK(hipMalloc((void **)&h->xmax_part, sizeof(double) * VEC_MAX_GRID));
+    HIPCHK(hipMalloc((void **)&h->xmax_part, sizeof(double) * CSB_XMAX_GRID * (VEC_BLOCK / WAVE)));
     {
         const int64_t zn = std::max<int64_t>(h->A.P > 1 ? h->A.rows_v : 0, h->AT.P > 1 ? h->AT.rows_v : 0);
         if (zn > 0) HIPCHK(hipMalloc((void **)&h->Z, sizeof(double) * (size_t)zn));
@@ -1280,8 +1298,8 @@ static int finish_create(H *h, const int *d_irow, const int *d_icol, const doubl
                        (h->f32 && pa > 1);
     const bool csb_t = cmode == 1 || (cmode == 2 && pt > 1 && xt == 0) || (cmode < 0 && csb_rule(h->m, nnz, dev_t)) ||
                        (h->f32 && pt > 1);
-    if (csb_a) RET(build_csb(s, d_irow, d_icol, d_a, nnz, h->m, h->n, h->amax_exp, LSQRHIP_ERR_IROW, LSQRHIP_ERR_ICOL, bufA, bufB, hist, d_flags, h->A));
-    if (csb_t) RET(build_csb(s, d_icol, d_irow, d_a, nnz, h->n, h->m, h->amax_exp, LSQRHIP_ERR_ICOL, LSQRHIP_ERR_IROW, bufA, bufB, hist, d_flags, h->AT));
+    if (csb_a) RET(build_csb(s, d_irow, d_icol, d_a, nnz, h->m, h->n, h->f32, LSQRHIP_ERR_IROW, LSQRHIP_ERR_ICOL, bufA, bufB, hist, d_flags, h->A));
+    if (csb_t) RET(build_csb(s, d_icol, d_irow, d_a, nnz, h->n, h->m, h->f32, LSQRHIP_ERR_ICOL, LSQRHIP_ERR_IROW, bufA, bufB, hist, d_flags, h->AT));
     if (h->f32) {  // ... and row windows over the whole x where a block was too empty for them
         if (!h->A.csb) { pa = 1; pwa = h->n; xa = 0; }
         if (!h->AT.csb) { pt = 1; pwt = h->m; xt = 0; }

@@ -275,11 +275,13 @@ static void launch_csb(H *h, const SpmvArgs &a)
     const Csr &c = *a.c;
     const VT *x = reinterpret_cast<const VT *>(a.x);
     VT *y = reinterpret_cast<VT *>(a.y);
-    // max|x| first (the bound on a row sum that fixes the grid of the exact sums, csb.h): one pass over the vector
+    // max|x| first, piece by piece (what fixes the grids of the exact sums, csb.h): one pass over the vector
     // the product gathers from -- the solver's own vectors too (a bound from |x|_2 = 1 alone does not survive
     // duplicate entries, and is the looser one besides)
-    CsbX xb{h->xmax_part, vec_grid(2 * (int64_t)c.cols)};
-    hipLaunchKernelGGL(k_csb_xmax<VT>, dim3(xb.nxmax), dim3(VEC_BLOCK), 0, a.stream, x, (int64_t)c.cols, h->xmax_part);
+    const int xg = (int)std::min<int64_t>(CSB_XMAX_GRID, std::max<int64_t>(1, ((int64_t)c.cols + VEC_BLOCK - 1) / VEC_BLOCK));
+    static const int tau_split = env_int("LSQRHIP_CSB_TAU", 1);
+    CsbX xb{h->xmax_part, xg * (VEC_BLOCK / WAVE), tau_split};
+    hipLaunchKernelGGL(k_csb_xmax<VT>, dim3(xg), dim3(VEC_BLOCK), 0, a.stream, x, (int64_t)c.cols, h->xmax_part);
     // One launch per ROUND of row blocks (256 at a time, one per CU).  Every workgroup sweeps x from its
     // first to its last column; workgroups that start a sweep together stay close enough for the part of x
     // they gather from to sit in their XCD's L2, and a kernel boundary re-aligns them for the next round
@@ -288,8 +290,8 @@ static void launch_csb(H *h, const SpmvArgs &a)
     static const int rounds = env_int("LSQRHIP_CSB_ROUNDS", 1);
     const int S = std::max(c.S, 1);
     const int step = rounds ? std::max(1, c.grid / S) : std::max(c.nrb, 1);   // row blocks per launch
-    CsbMat A{c.cval, c.cidx, c.ccb, c.cptr, c.crs, c.nrb, c.R, c.rows, c.cols, c.e1, 0, 0, S, c.zsplit, c.cbad,
-             h->d_scalar + 3};
+    CsbMat A{c.cval, c.cidx, c.ccb, c.cptr, c.crs, c.nrb, c.R, c.rows, c.cols, c.rexp, c.zcoarse, 0, 0, S, c.zsplit,
+             c.cbad};
     for (int b0 = 0; b0 < c.nrb || b0 == 0; b0 += step) {
         const int b1 = std::min(c.nrb, b0 + step);
         const bool first = b0 == 0, last = b1 >= c.nrb;
@@ -311,10 +313,10 @@ static void launch_csb(H *h, const SpmvArgs &a)
         const dim3 grid(std::max(1, std::min(c.nrb, 2 * CSB_GRID)));
         if (a.e1 == nullptr)
             hipLaunchKernelGGL(k_csb_combine<VT>, grid, dim3(CSB_BLOCK), 0, a.stream, A, x, y, a.coef, a.stop, a.pout,
-                               a.pin, a.npin, a.slot_in, a.skip_if_zero, a.nsc);
+                               a.pin, a.npin, a.slot_in, a.skip_if_zero, xb, a.nsc);
         else
             hipExtLaunchKernelGGL(k_csb_combine<VT>, grid, dim3(CSB_BLOCK), 0, a.stream, nullptr, a.e1, 0, A, x, y,
-                                  a.coef, a.stop, a.pout, a.pin, a.npin, a.slot_in, a.skip_if_zero, a.nsc);
+                                  a.coef, a.stop, a.pout, a.pin, a.npin, a.slot_in, a.skip_if_zero, xb, a.nsc);
     }
 }
 

@@ -400,23 +400,21 @@ __global__ __launch_bounds__(VEC_BLOCK) void k_amax(const VT *__restrict__ x, in
     if (threadIdx.x == 0) partials[blockIdx.x] = red[0];
 }
 
-// The same pass under a name of its own: the max|x| in front of every column-swept product (csb.h) -- so that
-// profiles and PMC passes can tell it from the build's k_amax over the matrix values.
+// The max|x| pass in front of every column-swept product (csb.h), under a name of its own so that profiles and PMC
+// passes can tell it from the build's k_amax over the matrix values.  It leaves one maximum per WAVE: the maxima
+// of 4 * gridDim.x strided pieces of x, from which csb.h takes max|x| and -- the median piece -- what the bulk of x
+// looks like (its "tau").  Grid: csb_xmax_grid(n) workgroups.
+constexpr int CSB_XMAX_GRID = 1024;
 template <typename VT>
 __global__ __launch_bounds__(VEC_BLOCK) void k_csb_xmax(const VT *__restrict__ x, int64_t n,
                                                         double *__restrict__ partials)
 {
-    __shared__ double red[VEC_BLOCK];
     double m = 0.0;
     const int64_t stride = (int64_t)gridDim.x * VEC_BLOCK;
     for (int64_t i = (int64_t)blockIdx.x * VEC_BLOCK + threadIdx.x; i < n; i += stride) m = fmax(m, fabs((double)x[i]));
-    red[threadIdx.x] = m;
-    __syncthreads();
-    for (int off = VEC_BLOCK / 2; off > 0; off >>= 1) {
-        if ((int)threadIdx.x < off) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + off]);
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) partials[blockIdx.x] = red[0];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off, WAVE));
+    if ((threadIdx.x & (WAVE - 1)) == 0) partials[blockIdx.x * (VEC_BLOCK / WAVE) + (threadIdx.x >> 6)] = m;
 }
 
 // partials[b] = sum over this workgroup's share of (x[i] * sc)^2   (sc a power of two: exact)

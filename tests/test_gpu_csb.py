@@ -184,3 +184,173 @@ def test_default_choice_at_moderate_scale(shape):
     assert (r.istop, r.itn) == (o.istop, o.itn)
     assert np.linalg.norm(r.x - o.x) <= 1e-10 * np.linalg.norm(o.x)
     assert abs(r.anorm - o.anorm) <= 1e-10 * o.anorm and abs(r.rnorm - o.rnorm) <= 1e-10 * o.rnorm
+
+
+# ---------------------------------------------------------------------------------------------
+# badly scaled systems: the grid of the exact sums is each ROW's own (csb.h, round 4)
+# ---------------------------------------------------------------------------------------------
+def _decades(seed, count, lo=-8.0, hi=8.0):
+    """10 ** U(lo, hi), from the library's own hash (the same numbers on every box)."""
+    u = 0.5 * (P.u64_to_unit(P.rng_u64(seed, 11, np.arange(count, dtype=np.uint64))) + 1.0)
+    return 10.0 ** (lo + (hi - lo) * u)
+
+
+def _scaled(p, what, seed=3):
+    a = p.a.copy()
+    if what in ("rows", "both"):
+        a *= _decades(seed, p.m)[p.irow - 1]
+    if what in ("columns", "both"):
+        a *= _decades(seed + 1, p.n)[p.icol - 1]
+    return P.Problem(p.name + "_scaled_" + what, p.m, p.n, p.irow, p.icol, a, p.b.copy(), p.damp)
+
+
+def _per_row_error(mode, p, got, ref, xv):
+    """max_i |got_i - ref_i| / sum_j |a_ij x_j| over the rows of the product (mode 2: of A')."""
+    rows = (p.irow if mode == 1 else p.icol) - 1
+    cols = (p.icol if mode == 1 else p.irow) - 1
+    scale = np.zeros(p.m if mode == 1 else p.n)
+    np.add.at(scale, rows, np.abs(p.a * xv[cols]))
+    nz = scale > 0
+    assert np.all(got[~nz] == ref[~nz])
+    return float(np.max(np.abs(got[nz] - ref[nz]) / scale[nz]))
+
+
+@pytest.mark.parametrize("what", ["rows", "columns", "both"])
+@pytest.mark.parametrize("R,S", [(None, None), (333, None), (1000, 3)])
+def test_badly_scaled_rows_and_columns_keep_every_row_accurate(csb_env, what, R, S):
+    """Rows and / or columns scaled by 10^U(-8, 8) -- weighted least squares, columns in different units.  r03's
+    single grid for the whole matrix left a row 2^s below the largest row 1-norm only 61 - s bits; now every
+    row is held to 1e-12 of ITS OWN sum_j |a_ij x_j| against the oracle, in both modes."""
+    csb_env(R)
+    os.environ.pop("LSQRHIP_CSB_S", None)
+    if S:
+        os.environ["LSQRHIP_CSB_S"] = str(S)
+    p = _scaled(P.random_rows(6000, 2500, 12, seed=17), what)
+    s = lsqr_solver_ez().initialize(p.m, p.n, p.a, p.irow, p.icol)
+    info = s.info()
+    assert info["xlds"] == 3 and info["xlds_t"] == 3
+    po = oracle.port()
+    xp, yp = vecs(p)
+    x, y = xp.copy(), np.zeros(p.m)
+    s.aprod(1, p.m, p.n, x, y)
+    _, y_ref = po.aprod(1, p.m, p.n, p.irow, p.icol, p.a, xp, np.zeros(p.m))
+    assert _per_row_error(1, p, y, y_ref, xp) <= 1e-12
+    x, y = np.zeros(p.n), yp.copy()
+    s.aprod(2, p.m, p.n, x, y)
+    x_ref, _ = po.aprod(2, p.m, p.n, p.irow, p.icol, p.a, np.zeros(p.n), yp)
+    assert _per_row_error(2, p, x, x_ref, yp) <= 1e-12
+
+
+@pytest.mark.parametrize("spikes", [1, 3, 40])
+@pytest.mark.parametrize("R,S", [(None, None), (500, 2)])
+def test_a_spike_in_x_does_not_cost_the_other_rows_their_bits(csb_env, spikes, R, S):
+    """x with a few entries 1e12 above the rest (v or u of a system with one badly scaled column / row): the rows that
+    never touch a spike keep a grid of their own magnitude -- the big columns are summed apart, on a coarse grid,
+    as integers again (csb.h "tau") -- and the rows that do touch one come out right as well."""
+    csb_env(R)
+    os.environ.pop("LSQRHIP_CSB_S", None)
+    if S:
+        os.environ["LSQRHIP_CSB_S"] = str(S)
+    p = P.random_rows(20000, 9000, 10, seed=23)
+    s = lsqr_solver_ez().initialize(p.m, p.n, p.a, p.irow, p.icol)
+    assert s.info()["xlds"] == 3 and s.info()["xlds_t"] == 3
+    po = oracle.port()
+    xp, yp = vecs(p)
+    at = P.u64_to_index(P.rng_u64(5, 12, np.arange(spikes, dtype=np.uint64)), p.n).astype(np.int64)
+    xq = xp.copy()
+    xq[at] *= 1.0e12
+    ys = []
+    for _ in range(2):
+        x, y = xq.copy(), np.zeros(p.m)
+        s.aprod(1, p.m, p.n, x, y)
+        ys.append(y)
+    assert np.array_equal(ys[0], ys[1])            # the coarse sums are integer sums: repeatable, and cleared
+    _, y_ref = po.aprod(1, p.m, p.n, p.irow, p.icol, p.a, xq, np.zeros(p.m))
+    assert _per_row_error(1, p, ys[0], y_ref, xq) <= 1e-12
+    at = P.u64_to_index(P.rng_u64(6, 12, np.arange(spikes, dtype=np.uint64)), p.m).astype(np.int64)
+    yq = yp.copy()
+    yq[at] *= 1.0e12
+    x, y = np.zeros(p.n), yq.copy()
+    s.aprod(2, p.m, p.n, x, y)
+    x_ref, _ = po.aprod(2, p.m, p.n, p.irow, p.icol, p.a, np.zeros(p.n), yq)
+    assert _per_row_error(2, p, x, x_ref, yq) <= 1e-12
+    # ... and the same matrix without spikes right after: nothing is left behind in the coarse sums
+    x, y = xp.copy(), np.zeros(p.m)
+    s.aprod(1, p.m, p.n, x, y)
+    _, y_ref = po.aprod(1, p.m, p.n, p.irow, p.icol, p.a, xp, np.zeros(p.m))
+    assert _per_row_error(1, p, y, y_ref, xp) <= 1e-12
+
+
+@pytest.mark.parametrize("what", ["rows", "columns", "both"])
+def test_short_solve_of_a_badly_scaled_system(csb_env, what):
+    """10 iterations on the scaled systems against the oracle: 1e-10, or ten times what the REFERENCE's own x moves by
+    when its COO input is permuted (the only freedom a row sum has: its order)."""
+    csb_env(None)
+    p = _scaled(P.random_rows(6000, 2500, 12, seed=17, damp=0.0), what, seed=9)
+    po = oracle.port()
+    kw = dict(itnlim=10)
+    g = po.solve(p.m, p.n, p.irow, p.icol, p.a, p.b, **kw)
+    q = P.shuffled(p)
+    g2 = po.solve(q.m, q.n, q.irow, q.icol, q.a, q.b, **kw)
+    nx = np.linalg.norm(g.x)
+    band = np.linalg.norm(g2.x - g.x) / nx
+    s = lsqr_solver_ez().initialize(p.m, p.n, p.a, p.irow, p.icol, **kw)
+    assert s.info()["xlds"] == 3 and s.info()["xlds_t"] == 3
+    r = s.solve(p.b, 0.0)
+    err = np.linalg.norm(r.x - g.x) / nx
+    print(f"scaled {what}: gpu {err:.2e}, reference under permutation {band:.2e}")
+    assert (r.istop, r.itn) == (g.istop, g.itn)
+    assert err <= max(1e-10, 10.0 * band)
+    assert abs(r.anorm - g.anorm) <= max(1e-10, 10.0 * abs(g2.anorm - g.anorm) / g.anorm) * g.anorm
+
+
+def test_values_that_do_not_survive_the_row_scaling_decline_the_layout(csb_env):
+    """A value that is not finite, or one 2^-1000 below its row's largest: the stored a_ij 2^-e1_i would not be
+    exact -- such a matrix keeps another layout (and the reference's floating-point row sums)."""
+    csb_env(None)
+    p = P.random_rows(3000, 1200, 8, seed=31)
+    po = oracle.port()
+    xp, yp = vecs(p)
+    for bad in (np.inf, np.nan, 1e-320):
+        a = p.a.copy()
+        a[17] = bad
+        if bad == 1e-320:
+            a[p.irow == p.irow[17]] *= 1e300      # the row's other entries: 2^2000 above it
+            a[17] = bad
+        s = lsqr_solver_ez().initialize(p.m, p.n, a, p.irow, p.icol)
+        assert s.info()["xlds"] != 3
+        x, y = xp.copy(), yp.copy()
+        s.aprod(1, p.m, p.n, x, y)
+        with np.errstate(all="ignore"):
+            _, y_ref = po.aprod(1, p.m, p.n, p.irow, p.icol, a, xp, yp)
+        fin = np.isfinite(y_ref)
+        assert np.array_equal(np.isnan(y), np.isnan(y_ref))
+        assert np.max(np.abs(y[fin] - y_ref[fin]) / np.maximum(np.abs(y_ref[fin]), 1.0)) <= 1e-13
+
+
+@pytest.mark.parametrize("S", [None, 2, 3])
+def test_solves_with_spiky_vectors_repeat_exactly(csb_env, S):
+    """A few rows and columns 1e6 above the rest: u and v carry spikes in every iteration, so every product uses the
+    coarse sums in HBM.  They are integer sums and must be back at zero after every product -- also after the
+    products a stopped solve leaves half done (speculative launches behind the stop flag): solves repeat bit for
+    bit, across the launch schedules too."""
+    csb_env(700)
+    os.environ.pop("LSQRHIP_CSB_S", None)
+    if S:
+        os.environ["LSQRHIP_CSB_S"] = str(S)
+    p = P.random_rows(9000, 4000, 9, seed=41, damp=1e-3)
+    a = p.a.copy()
+    a[np.isin(p.irow, [5, 1234, 8000])] *= 1.0e6
+    a[np.isin(p.icol, [77, 3000])] *= 1.0e6
+    s = lsqr_solver_ez().initialize(p.m, p.n, a, p.irow, p.icol, itnlim=7)
+    assert s.info()["xlds"] == 3 and s.info()["xlds_t"] == 3
+    g = oracle.port().solve(p.m, p.n, p.irow, p.icol, a, p.b, damp=1e-3, itnlim=7)
+    runs = []
+    for pipeline in (2, 2, 1, 0, 2):
+        s.set_option("pipeline", pipeline)
+        r = s.solve(p.b, 1e-3)
+        runs.append((r.istop, r.itn, r.anorm, r.rnorm, r.xnorm, r.x.copy()))
+    for o in runs[1:]:
+        assert o[:5] == runs[0][:5] and np.array_equal(o[5], runs[0][5])
+    assert (runs[0][0], runs[0][1]) == (g.istop, g.itn)
+    assert np.linalg.norm(runs[0][5] - g.x) <= 1e-10 * np.linalg.norm(g.x)
