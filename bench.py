@@ -233,14 +233,13 @@ def timed_solve(s, d_b, d_x, damp, K):
     the limit; a well-conditioned --workload can reach machine precision first: the solve is then
     started again on the same b until K iterations have run (`restarts`)."""
     import torch
-    done, restarts, loop_ms = 0, 0, 0.0
+    done, restarts = 0, 0
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     while done < K:
         s.itnlim = K - done
         r = s.solve_device(d_b.ptr.value, d_x.ptr.value, damp)
         done += r.itn
-        loop_ms += s.last_timing().loop_ms
         if done < K:
             restarts += 1
             if r.itn == 0:
@@ -248,7 +247,7 @@ def timed_solve(s, d_b, d_x, damp, K):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     assert done == K and (restarts > 0 or r.istop == 5), (done, r.itn, r.istop)
-    return dt, r, restarts, loop_ms
+    return dt, r, restarts
 
 
 def roofline_only(args):
@@ -415,7 +414,7 @@ def run_single(args):
         n_warm += 1
     if W > 0:                                   # the W warm-up steps of the contract, through the timed path
         timed_solve(s, d_b, d_x, facts["damp"], W)
-    dt, r, restarts, loop_ms = timed_solve(s, d_b, d_x, facts["damp"], K)
+    dt, r, restarts = timed_solve(s, d_b, d_x, facts["damp"], K)
 
     cfgname = " (BASELINE.json configs[1])" if spec == HEADLINE else ""
     out = {

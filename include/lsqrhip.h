@@ -184,7 +184,7 @@ int lsqrhip_dcopy(lsqrhip_handle_t h, int64_t n, const double *d_x, double *d_y)
 typedef struct {
     double solve_ms;      /* whole lsqrhip_solve* call, host clock                     */
     double loop_ms;       /* device time of the iteration loop (HIP events): option
-                             "loop_events" or "time_kernels", 0 otherwise               */
+                             "loop_events" or "time_kernels", -1 otherwise              */
     double spmv1_ms;      /* summed device time of the mode-1 SpMV kernel launches     */
     double spmv2_ms;      /* summed device time of the mode-2 SpMV kernel launches     */
     double update_ms;     /* summed device time of the x/w update kernel launches      */

@@ -1418,7 +1418,7 @@ extern "C" int lsqrhip_info(lsqrhip_handle_t h, int64_t *dims)
     dims[4] = h->AT.bytes;
     dims[5] = h->off64 ? 8 : 4;
     dims[6] = h->ndict;                          // value dictionary entries (0 = 8-byte values)
-    dims[7] = (h->A.val8 || h->A.sell_v8) ? 1 : 8;                 // bytes per stored value
+    dims[7] = h->A.sell == 3 ? 0 : ((h->A.val8 || h->A.sell_v8) ? 1 : 8);   // bytes per stored value (row patterns: none)
     dims[8] = (h->A.col16 || h->A.sell_c16) ? 2 : 4;                // bytes per column index, CSR(A)
     dims[9] = (h->AT.col16 || h->AT.sell_c16) ? 2 : 4;               //                        CSR(A')
     dims[10] = h->A.P;                           // column panels of CSR(A)

@@ -42,6 +42,10 @@ namespace lsqrhip {
 
 constexpr int PAT_MAX = 256;       // patterns (one byte per row)
 constexpr int PAT_MAX_E = 1024;    // entries of all patterns together (12 KB of LDS)
+// k_spmv_pat / k_spmv_spat stage the table with one descriptor per THREAD (desc[tid]) and PAT_MAX_E / SELL_BLOCK entries
+// per thread: the constants are tied to the workgroup size of sell.h
+static_assert(SELL_BLOCK == PAT_MAX, "one pattern descriptor per thread of a SELL_BLOCK workgroup");
+static_assert(PAT_MAX_E % SELL_BLOCK == 0, "the pattern entries divide evenly among the threads");
 constexpr int PAT_MAX_LEN = 64;    // nonzeros of a row
 constexpr int PAT_TAB = 1024;      // slots of the discovery table
 constexpr int PAT_K = 5;           // entries in flight per lane and slice
@@ -222,8 +226,9 @@ __device__ __forceinline__ void pat_issue(PatTrip &t, int64_t b, const XcdRange 
 #pragma unroll
     for (int u = 0; u < PAT_U; ++u) {
         const int64_t bu = b + u * xr.stride;
-        t.r[u] = ((int)(bu * SELL_SLICES) + wave) * WAVE + lane;
-        t.active[u] = bu < xr.end && t.r[u] < rows;
+        const int64_t r64 = (bu * SELL_SLICES + wave) * WAVE + lane;   // (64-bit: bu beyond xr.end may pass 2^31 rows)
+        t.active[u] = bu < xr.end && r64 < rows;
+        t.r[u] = t.active[u] ? (int)r64 : 0;
         t.y0[u] = (double)ld_stream<NT>(&y[t.active[u] ? t.r[u] : 0]);
         const unsigned d = t.active[u] ? sdesc[pidc[u]] : 0u;
         t.e0[u] = (int)(d & 0xffffu);
@@ -336,7 +341,7 @@ __global__ __launch_bounds__(SELL_BLOCK, 4) void k_spmv_pat(
 #pragma unroll
     for (int u = 0; u < PAT_U; ++u) {
         const int64_t bu = b + u * xr.stride;
-        const int r0 = ((int)(bu * SELL_SLICES) + wave) * WAVE + lane;
+        const int64_t r0 = (bu * SELL_SLICES + wave) * WAVE + lane;
         pid_next[u] = (bu < xr.end && r0 < rows) ? (int)ld_stream<NT>(&pid[r0]) : 0;
     }
 

@@ -508,11 +508,11 @@ static int create_sharded_T(int m, int n, int64_t nnz, const int *irow, const in
     if (have < ngpu && !loopback)
         return fail(LSQRHIP_ERR_NO_DEVICE, "ngpu = " + std::to_string(ngpu) + " but this node shows " + std::to_string(have) +
                                                " usable gfx950 device(s)");
+    ngpu = std::min(ngpu_asked, std::max(m, 1));  // never more row blocks than rows
     if (!loopback && g_device.load() + ngpu > have)   // blocks go to devices [selected, selected + ngpu)
         return fail(LSQRHIP_ERR_NO_DEVICE, "ngpu = " + std::to_string(ngpu) + " starting at the selected device " +
                                                std::to_string(g_device.load()) + " exceeds the " + std::to_string(have) +
                                                " device(s) of this node (lsqrhip_set_device)");
-    ngpu = std::min(ngpu_asked, std::max(m, 1));  // never more row blocks than rows
     if (ngpu > 1 && !loopback && !rccl()) return fail(LSQRHIP_ERR_HIP, "librccl.so.1 could not be loaded");
     // One pass over the triplets: the reference's checks (src/lsqr.f90:110-111) on the whole system, and the row
     // counts.  Then contiguous row blocks balanced by nonzeros (+1 per row: a row costs work even when empty).
@@ -548,13 +548,34 @@ static int create_sharded_T(int m, int n, int64_t nnz, const int *irow, const in
             if (ngpu <= 255) owner8[(size_t)r] = (unsigned char)p;
             else owner[(size_t)r] = p;
         }
-    // ... and ONE pass that files every triplet under its block, COO order kept inside each (the reference's
+    // Triplets that already come block by block (row-sorted input, what every generator and most callers hand over):
+    // block p is the range [first[p], first[p + 1]) of the caller's arrays as it stands -- only its row indices need a
+    // copy (rebased to the block), one block at a time: 4 bytes per nonzero of the LARGEST block instead of 16 bytes
+    // per nonzero of the whole system held through every block's create (16 GB at configs[3]).
+    bool blockwise = true;
+    {
+        int last = 0;
+        for (int64_t k = 0; k < nnz && blockwise; ++k) {
+            const int r = irow[k] - 1;
+            const int p = ngpu <= 255 ? (int)owner8[(size_t)r] : owner[(size_t)r];
+            blockwise = p >= last;
+            last = p;
+        }
+    }
+    // ... otherwise ONE pass that files every triplet under its block, COO order kept inside each (the reference's
     // row sums are formed in that order, src/lsqr.f90:168-172): O(nnz) host work whatever ngpu is
     // (uninitialised storage: value-initialising 16 bytes per nonzero first would cost as much as the pass itself)
-    const size_t cap = (size_t)std::max<int64_t>(nnz, 1);
-    std::unique_ptr<int[]> lr(new int[cap]), lc(new int[cap]);
-    std::unique_ptr<AT[]> la(new AT[cap]);
-    {
+    std::unique_ptr<int[]> lr, lc;
+    std::unique_ptr<AT[]> la;
+    if (blockwise) {
+        int64_t big = 1;
+        for (int p = 0; p < ngpu; ++p) big = std::max(big, first[(size_t)p + 1] - first[(size_t)p]);
+        lr.reset(new int[(size_t)big]);
+    } else {
+        const size_t cap = (size_t)std::max<int64_t>(nnz, 1);
+        lr.reset(new int[cap]);
+        lc.reset(new int[cap]);
+        la.reset(new AT[cap]);
         std::vector<int64_t> pos(first.begin(), first.end() - 1);
         for (int64_t k = 0; k < nnz; ++k) {
             const int r = irow[k] - 1;
@@ -589,7 +610,12 @@ static int create_sharded_T(int m, int n, int64_t nnz, const int *irow, const in
         q.row0 = cut[(size_t)p];
         // the block's device, for this thread's create only (never through the process-wide selection)
         t_device_override = loopback ? dev0 + p % have : dev0 + p;
-        rc = create_block(cut[(size_t)p + 1] - cut[(size_t)p], n, np, lr.get() + f, lc.get() + f, la.get() + f, &q.h);
+        if (blockwise) {
+            for (int64_t k = 0; k < np; ++k) lr[(size_t)k] = irow[f + k] - cut[(size_t)p];
+            rc = create_block(cut[(size_t)p + 1] - cut[(size_t)p], n, np, lr.get(), icol + f, a + f, &q.h);
+        } else {
+            rc = create_block(cut[(size_t)p + 1] - cut[(size_t)p], n, np, lr.get() + f, lc.get() + f, la.get() + f, &q.h);
+        }
         t_device_override = -1;
     }
     lr.reset();

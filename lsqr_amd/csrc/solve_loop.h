@@ -787,7 +787,8 @@ static int finish_solve(H *h, int wantse, int want_log, double *x, double *se, b
         HIPCHK(hipMemcpyAsync(h->h_log.data(), h->d_log, sizeof(double) * h->h_log.size(), hipMemcpyDeviceToHost, s));
     }
     if (need_sync) HIPCHK(hipStreamSynchronize(s));
-    float loop_ms = 0;   // (0 when the loop was not bracketed by events: option loop_events)
+    float loop_ms = -1.f;   // (-1 when the loop was not bracketed by events, option loop_events: a consumer that forgot to
+                            // ask for them reads a time that cannot be one instead of a plausible 0)
     if (h->loop_bracketed) (void)hipEventElapsedTime(&loop_ms, h->ev_loop0, h->ev_loop1);
     tm.loop_ms = loop_ms;
     tm.itn = r.itn;

@@ -66,7 +66,8 @@ def rank0_block_traffic(spec: str, row0: int, nrows: int):
     rendezvous meanwhile).  (traffic dict or None, note)"""
     import bench
     plan = [[spec, {}, int(row0), int(nrows)]]
-    traffic, note = bench.live_traffic(plan)
+    # (120 s per pass: the other ranks wait under the 600 s default of init_process_group)
+    traffic, note = bench.live_traffic(plan, timeout=120)
     return traffic.get((spec, "{}", (int(row0), int(nrows)))), note
 
 

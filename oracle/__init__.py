@@ -143,6 +143,14 @@ class _Port:
     def d2norm(self, a, b):
         return float(self.L.oracle_d2norm(float(a), float(b)))
 
+    # test hook ----------------------------------------------------------
+    def set_norm_ulp(self, itn: int, which: int, ulps: int) -> None:
+        """Move beta (which=1) or alpha (which=2) of iteration `itn` (0 = the start) of every following solve by
+        `ulps` units in the last place; which=0 switches it off (lsqr_oracle.c oracle_set_norm_ulp)."""
+        self.L.oracle_set_norm_ulp.restype = None
+        self.L.oracle_set_norm_ulp.argtypes = [C.c_int, C.c_int, C.c_int]
+        self.L.oracle_set_norm_ulp(int(itn), int(which), int(ulps))
+
     # operator -----------------------------------------------------------
     def validate(self, m, n, irow, icol):
         irow = np.ascontiguousarray(irow, dtype=np.int32)

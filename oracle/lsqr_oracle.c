@@ -79,6 +79,26 @@ double oracle_ddot(int n, const double *dx, int incx, const double *dy, int incy
 static int g_norm_order = 0;
 void oracle_set_norm_order(int order) { g_norm_order = order; }
 
+/* Test hook (never set by the parity tests themselves): move ONE norm of the bidiagonalisation -- beta (which = 1)
+ * or alpha (which = 2) of iteration `itn` (0: the start, src/lsqr.f90:632-641) -- by `ulps` units in the last place.
+ * tests/fuzz_layouts.py measures with it how far x of the reference itself moves under the smallest possible change
+ * of a norm -- the one rounding a permutation of the COO input does not touch -- and holds the GPU to a multiple of
+ * that.  which = 0 switches the hook off. */
+static int g_ulp_itn = 0, g_ulp_which = 0, g_ulp_count = 0;
+void oracle_set_norm_ulp(int itn, int which, int ulps)
+{
+    g_ulp_itn = itn;
+    g_ulp_which = which;
+    g_ulp_count = ulps;
+}
+static double nudge(double v, int itn, int which)
+{
+    if (g_ulp_which != which || g_ulp_itn != itn || v == 0.0) return v;
+    for (int k = 0; k < (g_ulp_count < 0 ? -g_ulp_count : g_ulp_count); ++k)
+        v = nextafter(v, g_ulp_count > 0 ? INFINITY : -INFINITY);
+    return v;
+}
+
 static double pairwise_sumsq(const double *x, int n)
 {
     if (n <= 8) {
@@ -229,11 +249,11 @@ int oracle_lsqr_op(int m, int n, oracle_aprod_fn aprod, void *ctx,
 
     /* :632-644 */
     double alpha = 0.0;
-    double beta = oracle_dnrm2(m, u, 1);
+    double beta = nudge(oracle_dnrm2(m, u, 1), 0, 1);
     if (beta > 0.0) {
         oracle_dscal(m, 1.0 / beta, u, 1);
         aprod(ctx, 2, m, n, v, u);
-        alpha = oracle_dnrm2(n, v, 1);
+        alpha = nudge(oracle_dnrm2(n, v, 1), 0, 2);
     }
     if (alpha > 0.0) {
         oracle_dscal(n, 1.0 / alpha, v, 1);
@@ -256,7 +276,7 @@ int oracle_lsqr_op(int m, int n, oracle_aprod_fn aprod, void *ctx,
             /* :681-683 */
             oracle_dscal(m, -alpha, u, 1);
             aprod(ctx, 1, m, n, v, u);
-            beta = oracle_dnrm2(m, u, 1);
+            beta = nudge(oracle_dnrm2(m, u, 1), itn, 1);
 
             /* :687-689 */
             double temp = oracle_d2norm(alpha, beta);
@@ -268,7 +288,7 @@ int oracle_lsqr_op(int m, int n, oracle_aprod_fn aprod, void *ctx,
                 oracle_dscal(m, 1.0 / beta, u, 1);
                 oracle_dscal(n, -beta, v, 1);
                 aprod(ctx, 2, m, n, v, u);
-                alpha = oracle_dnrm2(n, v, 1);
+                alpha = nudge(oracle_dnrm2(n, v, 1), itn, 2);
                 if (alpha > 0.0) oracle_dscal(n, 1.0 / alpha, v, 1);
             }
 

@@ -6,6 +6,7 @@ from lsqr_amd import devgen, capi
 K = 800
 dp = devgen.generate(sys.argv[1] if len(sys.argv) > 1 else "poisson2d:1000:1000", itnlim=K)
 s = dp.solver
+s.set_option("loop_events", 1)   # timing.loop_ms is -1 without it
 d_x = capi.DeviceBuffer(8 * dp.n)
 s.set_option("graph_iters", 100)
 for pipe in (2, 1, 0, 2, 1):

@@ -8,6 +8,7 @@ spec = sys.argv[1] if len(sys.argv) > 1 else "random:22000000:1000000:100"
 t0 = time.perf_counter()
 dp = devgen.generate(spec, itnlim=6)
 s = dp.solver
+s.set_option("loop_events", 1)   # timing.loop_ms is -1 without it
 info = s.info()
 print(f"{spec}: nnz {dp.nnz} ({dp.nnz / 2**31:.2f} x 2^31)  rowptr bytes {info['rowptr_bytes']}  panels {info['panels']}/{info['panels_t']}"
       f"  build {s.build_seconds:.2f} s  total {time.perf_counter() - t0:.1f} s", flush=True)

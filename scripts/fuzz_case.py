@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
-"""One case of scripts/fuzz_layouts.py in detail.  usage: fuzz_case.py SEED CASE"""
+"""One case of tests/fuzz_layouts.py in detail.  usage: fuzz_case.py SEED CASE"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import oracle
 import importlib.util
-spec = importlib.util.spec_from_file_location("fuzz_layouts", os.path.join(os.path.dirname(os.path.abspath(__file__)), "fuzz_layouts.py"))
+spec = importlib.util.spec_from_file_location("fuzz_layouts", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "fuzz_layouts.py"))
 fz = importlib.util.module_from_spec(spec); spec.loader.exec_module(fz)
 from lsqr_amd.solver import lsqr_solver_ez
 seed, want = int(sys.argv[1]), int(sys.argv[2])

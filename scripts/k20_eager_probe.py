@@ -13,7 +13,7 @@ def run(label):
         bench.timed_solve(s, d_b, d_x, facts["damp"], 20)
     ts = []
     for _ in range(30):
-        dt, r, restarts, loop_ms = bench.timed_solve(s, d_b, d_x, facts["damp"], 20)
+        dt, r, restarts = bench.timed_solve(s, d_b, d_x, facts["damp"], 20)
         ts.append(dt)
     ts.sort()
     print(f"{label:28s} median {1e6*ts[len(ts)//2]:7.1f} us  min {1e6*ts[0]:7.1f} us  -> {20/ts[len(ts)//2]:8.0f} it/s", flush=True)

@@ -7,6 +7,7 @@ K = 800
 pipe = int(sys.argv[1])
 dp = devgen.generate(sys.argv[2] if len(sys.argv) > 2 else "poisson2d:1000:1000", itnlim=K)
 s = dp.solver
+s.set_option("loop_events", 1)   # timing.loop_ms is -1 without it
 d_x = capi.DeviceBuffer(8 * dp.n)
 s.set_option("graph_iters", 100)
 s.set_option("pipeline", pipe)

@@ -6,6 +6,7 @@ from lsqr_amd import devgen, capi
 spec, K, pipe = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 dp = devgen.generate(spec, itnlim=K)
 s = dp.solver
+s.set_option("loop_events", 1)   # timing.loop_ms is -1 without it
 s.set_option("pipeline", pipe); s.set_option("graph_iters", 20)
 d_x = capi.DeviceBuffer(8 * dp.n)
 for _ in range(2):

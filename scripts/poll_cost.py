@@ -6,6 +6,7 @@ from lsqr_amd import devgen, capi
 K = 800
 dp = devgen.generate("poisson2d:1000:1000", itnlim=K)
 s = dp.solver
+s.set_option("loop_events", 1)   # timing.loop_ms is -1 without it
 d_x = capi.DeviceBuffer(8 * dp.n)
 for gi in (20, 50, 100, 200, 400, 800, 50, 800):
     s.set_option("graph_iters", gi)

@@ -8,6 +8,7 @@ from lsqr_amd import capi, problems as P
 from lsqr_amd.solver import lsqr_solver_ez
 p = P.poisson2d(1000, 1000)
 s = lsqr_solver_ez().initialize(p.m, p.n, p.a, p.irow, p.icol)
+s.set_option("loop_events", 1)   # timing.loop_ms is -1 without it
 d_b = capi.DeviceBuffer.from_array(p.b)
 d_x = capi.DeviceBuffer(8 * p.n)
 for K in (20, 20, 40, 200):

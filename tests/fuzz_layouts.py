@@ -1,12 +1,27 @@
 #!/usr/bin/env python3
 """Random small systems through every layout (forced by the knobs) against the oracle's aprod and a
 short solve.  Edge cases on purpose: empty rows / columns, one very long row, m < n, m > n, nnz = 0,
-duplicates, dictionary and non-dictionary values.  usage: fuzz_layouts.py [ncases] [seed]"""
+duplicates, dictionary and non-dictionary values.  The generator and the acceptance rule of
+tests/test_gpu_fuzz.py; `python tests/fuzz_layouts.py [ncases] [seed] [--bands]` runs more cases
+(--bands prints every case's measured bands: profiles/r04/fuzz_bands.txt)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import oracle
 from lsqr_amd.solver import lsqr_solver_ez
+
+# How far a short solve may lie from the oracle's where a row (or a column, mode 2) is longer than 16 -- summed by
+# several lanes, a tree instead of the reference's left-to-right sum -- and the norms are tree sums too:
+#   the REFERENCE's own movement, measured per case, (a) under six permutations of its COO input (the order of a
+#   row sum is the only freedom the reference leaves there) and (b) under ONE norm of its bidiagonalisation moved
+#   by ONE unit in the last place (oracle_set_norm_ulp: every beta and alpha of the run in turn, both directions)
+#   -- the rounding a permutation does not touch.  The GPU differs from the reference in every row sum and in
+#   every norm by a few ulps at once, so it is held to BAND_FACTOR times the larger of the two, and to 1e-9 where
+#   that is smaller.  No case is exempt; the share of results that needed more than 1e-9 is counted and bounded.
+BAND_FACTOR = 200.0
+N_PERMUTATIONS = 6
+TIGHT = 1e-9
+MAX_WIDENED_SHARE = 0.05
 
 KNOBS = ["LSQRHIP_SELL", "LSQRHIP_SELLP", "LSQRHIP_VAL8", "LSQRHIP_COL16", "LSQRHIP_PANELS", "LSQRHIP_PANEL_KB",
          "LSQRHIP_XLDS", "LSQRHIP_XLDS_COLS", "LSQRHIP_OFF64", "LSQRHIP_SKEW", "LSQRHIP_TUNE", "LSQRHIP_CSB", "LSQRHIP_CSB_R", "LSQRHIP_CSB_S", "LSQRHIP_PAT", "LSQRHIP_SPAT"]
@@ -66,37 +81,41 @@ def make_case(rs):
     return m, n, (irow + 1).astype(np.int32), (icol + 1).astype(np.int32), a.astype(np.float64), b
 
 
-def run(ncases, seed, verbose=True):
+def run(ncases, seed, verbose=True, bands=False, only=None):
+    """Returns (failures, results that needed a tolerance above TIGHT, results in all)."""
     rs = np.random.RandomState(seed)
     po = oracle.port()
-    bad = 0
+    bad = widened = total = 0
     for case in range(ncases):
         m, n, irow, icol, a, b = make_case(rs)
         xp, yp = rs.uniform(-1, 1, size=n), rs.uniform(-1, 1, size=m)
         _, y_ref = po.aprod(1, m, n, irow, icol, a, xp, yp)
         x_ref, _ = po.aprod(2, m, n, irow, icol, a, xp, yp)
+        if only is not None and case not in only:
+            continue
         o = po.solve(m, n, irow, icol, a, b, damp=1e-2, itnlim=6)
-        # rows (or columns, for mode 2) longer than 16 are summed by several lanes -- a tree, not the reference's
-        # left-to-right sum -- and LSQR amplifies that rounding difference: on a 64 x 30000 system with one 6000-entry
-        # row the reference itself moves x by 1e-3 .. 5e-2 in 6 iterations when its COO input is permuted (DESIGN.md
-        # 3.3).  The products are the layout check; the solve is held to 1e-9 where every sum is the reference's
-        # own, and to 200 x the reference's own drift under two permutations of its input (at least 1e-9) elsewhere.
         longest = max(int(np.bincount(irow - 1, minlength=m).max()), int(np.bincount(icol - 1, minlength=n).max())) if irow.size else 0
-        tol_long = 1e-9
+        tol_long, band_perm, band_ulp = TIGHT, 0.0, 0.0
         if longest > 16 and o.itn > 0:
-            drift = 0.0
-            for k in (1, 2):
+            nx = max(np.linalg.norm(o.x), 1e-300)
+            for k in range(1, 1 + N_PERMUTATIONS):
                 perm = np.random.RandomState(1000 + k).permutation(irow.size)
                 o2 = po.solve(m, n, irow[perm], icol[perm], a[perm], b, damp=1e-2, itnlim=6)
-                drift = max(drift, float(np.linalg.norm(o2.x - o.x) / max(np.linalg.norm(o.x), 1e-300)))
-            tol_long = max(1e-9, 200.0 * drift)
-            # ... and not at all when the bidiagonalisation has broken down inside these 6 iterations (arnorm, which
-            # decreases while LSQR converges, jumps up): every rounding anywhere -- the norms' too, which a permutation
-            # of the input does not touch -- then decides x
-            if o.itn > 1:
-                o_prev = po.solve(m, n, irow, icol, a, b, damp=1e-2, itnlim=o.itn - 1)
-                if o.arnorm > 1.5 * o_prev.arnorm:
-                    tol_long = float("inf")
+                band_perm = max(band_perm, float(np.linalg.norm(o2.x - o.x) / nx))
+            try:
+                for it in range(0, o.itn + 1):
+                    for which in (1, 2):
+                        for ulps in (1, -1):
+                            po.set_norm_ulp(it, which, ulps)
+                            o2 = po.solve(m, n, irow, icol, a, b, damp=1e-2, itnlim=6)
+                            band_ulp = max(band_ulp, float(np.linalg.norm(o2.x - o.x) / nx))
+            finally:
+                po.set_norm_ulp(0, 0, 0)
+            tol_long = max(TIGHT, BAND_FACTOR * max(band_perm, band_ulp))
+        if bands:
+            print(f"case {case} m={m} n={n} nnz={irow.size} longest={longest} itn={o.itn} reference x under permutation "
+                  f"{band_perm:.2e}, under one ulp of one norm {band_ulp:.2e} -> tolerance {tol_long:.2e}", flush=True)
+        worst = 0.0
         for lay in LAYOUTS:
             for k in KNOBS:
                 os.environ.pop(k, None)
@@ -120,18 +139,32 @@ def run(ncases, seed, verbose=True):
                 ok = e1 < 1e-12 and e2 < 1e-12 and (e3 < 1e-12 or (e3 < tol3 and abs(r.itn - o.itn) <= 1 and
                                                                     (r.istop == o.istop or r.itn != o.itn)))
                 info = s.info()
+                total += 1
+                if ok and not e3 < TIGHT:
+                    widened += 1
+                worst = max(worst, e3)
             except Exception as ex:        # noqa: BLE001
                 ok, e1, e2, e3, info = False, -1, -1, -1, repr(ex)
             if not ok:
                 bad += 1
                 ri, rn = (r.istop, r.itn) if e1 >= 0 else (None, None)
                 print(f"FAIL case {case} m={m} n={n} nnz={irow.size} layout={lay} e1={e1:.2e} e2={e2:.2e} e3={e3:.2e} istop {ri}/{o.istop} itn {rn}/{o.itn} {info}", flush=True)
+        if bands:
+            print(f"case {case}: worst GPU layout {worst:.2e}", flush=True)
     for k in KNOBS:
         os.environ.pop(k, None)
     if verbose:
-        print(f"{ncases} cases x {len(LAYOUTS)} layouts: {bad} failures")
-    return bad
+        print(f"{ncases} cases x {len(LAYOUTS)} layouts: {bad} failures; {widened} of {total} results needed more than "
+              f"{TIGHT:g} (at most {MAX_WIDENED_SHARE:.0%} may)")
+    return bad, widened, total
 
 
 if __name__ == "__main__":
-    sys.exit(1 if run(int(sys.argv[1]) if len(sys.argv) > 1 else 60, int(sys.argv[2]) if len(sys.argv) > 2 else 1) else 0)
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    only = None
+    for a in sys.argv[1:]:
+        if a.startswith("--only="):
+            only = {int(t) for t in a[7:].split(",")}
+    bad, widened, total = run(int(args[0]) if args else 60, int(args[1]) if len(args) > 1 else 1,
+                              bands="--bands" in sys.argv, only=only)
+    sys.exit(1 if bad or widened > MAX_WIDENED_SHARE * max(total, 1) else 0)

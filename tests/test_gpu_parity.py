@@ -73,6 +73,11 @@ def test_solve_parity_vs_reference_golden(name):
         twins = [t for t in TRUNCATED_TWINS if t.startswith(name + "_it")]
         assert twins, f"{name}: a case this sensitive needs a truncated twin that carries the strict tolerance"
         assert np.all(np.isfinite(r.x)) and 0.1 * nx <= np.linalg.norm(r.x) <= 10 * nx
+        # ... and wherever ten times the reference's own drift still says something about the direction of x
+        # (below 1e-2: powerlaw_small 4e-6, ...), that bound is held as before; only the truly chaotic runs
+        # (illcond_conlim: 7e-2) are left to the magnitude check and their twins.
+        if tx <= 1e-2:
+            assert np.linalg.norm(r.x - gx) / nx <= tx
     # itn is pinned only where the reference's own iteration count AND its own stopping
     # quantities do not move when its COO input is permuted (12 permutations, gen_golden.py):
     # anorm enters every stopping test (src/lsqr.f90:759-790), so a run whose anorm drifts by
