@@ -55,6 +55,9 @@ HBM_INSTANCES = [("poisson2d:4000:4000", {}, "row patterns (what the build choos
                  ("poisson2d:4000:4000", {"LSQRHIP_PAT": "0", "LSQRHIP_VAL8": "0"},
                   "structure patterns: 8-byte values, no column indices (what a variable-coefficient stencil gets)")]
 PRODUCT_KERNELS = ("k_spmv_", "k_panel_combine", "k_csb_combine", "k_csb_xmax")
+# the N = 1 line measures configs[1]; the series the --gpus N lines continue is strong_scaling_n1 (configs[3])
+SCALING_N1 = "n/a (configs[1]; the strong-scaling series is strong_scaling_n1)"
+GENERAL_INSTANCE = 2      # HBM_INSTANCES[2]: sliced ELL with 8-byte values -- the best HBM-resident GENERAL short-row kernel
 
 
 def parse():
@@ -216,6 +219,10 @@ def product_roofline(s, facts, reps, traffic=None):
     if frac > 1.0:      # physical bytes faster than HBM can deliver them: the working set is served by a cache
         roof["bound"] = "cache"
         roof["frac_exceeds_hbm_peak"] = True
+    # SURVEY 8d's own figure: ALGORITHMIC bytes (12 B per nonzero, row pointers, x once, y twice) / the same time /
+    # peak.  Above 1 the layout moves fewer bytes than that count and the product is not an HBM stream of it.
+    roof["frac_survey8d"] = alg1 / (avg1 * 1e-3) / 1e9 / HBM_PEAK_GBS
+    roof["bound_survey8d"] = "cache" if roof["frac_survey8d"] > 1.0 else "hbm"
     if traffic:
         roof["traffic"] = traffic.get("bytes_per_launch")
         roof["traffic_detail"] = traffic
@@ -280,7 +287,7 @@ def side_workload(spec, env, note, K, traffic):
         s.set_option("graph_iters", min(K + (K & 1), 50))
         s.itnlim = min(4, K)
         s.solve_device(d_b.ptr.value, d_x.ptr.value, facts["damp"])
-        dt, r, restarts, _ = timed_solve(s, d_b, d_x, facts["damp"], K)
+        dt, r, restarts = timed_solve(s, d_b, d_x, facts["damp"], K)
         reps = 100 if facts["nnz"] < 200_000_000 else 10
         roof, kernels, (alg1, alg2, lay1, lay2) = product_roofline(s, facts, reps, traffic)
         out = {"workload": f"{spec} m={facts['m']} n={facts['n']} nnz={facts['nnz']} damp={facts['damp']}",
@@ -420,7 +427,8 @@ def run_single(args):
     out = {
         "metric": "lsqr_iterations_per_sec", "value": K / dt, "unit": "it/s", "n_gpus": 1,
         "steps": K, "warmup": W, "ms_per_step": 1e3 * dt / K, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "scaling": SCALING_N1 if spec == HEADLINE else "n/a (one GPU, one workload)",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"{facts['name']} m={facts['m']} n={facts['n']} nnz={facts['nnz']} "
                                f"damp={facts['damp']}{cfgname}",
                    "graph_iters": gi, "restarts": restarts},
@@ -441,6 +449,16 @@ def run_single(args):
     del s, d_x
     if extras and not args.no_roofline:
         out["roofline_hbm"] = [side_workload(sp, env, note, 50, tr(sp, env)) for sp, env, note in HBM_INSTANCES]
+        # the general short-row kernel (no value dictionary, no repeating rows needed) on an HBM-resident instance,
+        # at top level: what a matrix without config 2's special structure gets from this library
+        g_inst = out["roofline_hbm"][GENERAL_INSTANCE]
+        if "roofline" in g_inst:
+            gen = dict(g_inst["roofline"])
+            gen["workload"] = g_inst["workload"]
+            gen["rocprof_summary"] = "profiles/r04/poisson4000_val8_roofline.txt"
+            out["roofline_general"] = gen
+        else:
+            out["roofline_general"] = g_inst
     if want_n1:
         n1 = side_workload(DEFAULT_SPEC, {}, "BASELINE.json configs[3], whole on one GPU", 40, tr(DEFAULT_SPEC, {}))
         n1["note"] = "the --gpus N > 1 lines shard this matrix by row blocks: compare their value with this one"

@@ -62,6 +62,13 @@
 //   cptr[b] = first chunk of block b; val[k], idx[k] = lrow << 17 | (col - cbase[k / 256]);
 //   cbase[c] = column of the first nonzero of chunk c.  A chunk spans < 2^17 columns or the build
 //   gives up (an almost empty block: such a matrix keeps the panel layout).
+//   NARROW form (round 4: 11 bytes per nonzero instead of 12; chosen whenever no two column-neighbours of a
+//   segment lie more than 255 columns apart -- every configuration of BASELINE.json: ~5 columns apart): the 64
+//   lanes of a wave take elements j * 64 + lane of a chunk (j = 0..3, "segments"); instead of idx the chunk holds,
+//   per LANE, its four local rows as u16 (8 bytes: one load) and its four column DELTAS as u8 (4 bytes: one load)
+//   -- delta of element e = col(e) - col(e - 1) inside its segment, 0 for the segment's first -- and cbase holds
+//   the first column of each segment (4 per chunk, wave-uniform).  A lane's columns are the inclusive scan of the
+//   deltas over the lanes before it: two DPP scans of two 16-bit fields each (a segment's deltas sum to < 2^16).
 #pragma once
 
 #include <climits>
@@ -87,6 +94,7 @@ constexpr int CSB_GRID = 256;                    // one workgroup per CU
 constexpr int CSB_NORM_FRAC = 32;                // build: row 1-norms as integer sums of ceil(|a| 2^(32 - emax_i))
 constexpr int CSB_NO_EXP = INT_MIN;              // build: "this row has no nonzero value yet" in the rows' largest exponents
 constexpr int CSB_E1_LIMIT = 900;                // build: rows whose 1-norm lies beyond 2^+-900 decline the layout
+constexpr int CSB_QMAX = 4;                      // product: at most this many workgroups of k_csb_combine share a row block
 constexpr int CSB_XHIST = 64;                    // product: piece maxima of x binned by their distance (in exponents) from the largest
 // The (value, index) stream is read once: loaded non-temporal so that it does not push the part of x the
 // XCD's workgroups are gathering from out of L2 (PMC before: 15 % of the gathers missed L2, 2.6x the
@@ -97,8 +105,9 @@ constexpr int CSB_XHIST = 64;                    // product: piece maxima of x b
 
 struct CsbMat {
     const void *val;        // VT values (double; float for a REAL32 handle), each row scaled by 2^-rexp[row]
-    const unsigned *idx;
-    const int *cbase;
+    const unsigned *idx;    // wide: [nchunks * 256] lrow << 17 | lcol; narrow: [nchunks * 64] pairs of words = a lane's 4 u16 rows
+    const unsigned *dcol;   // narrow: [nchunks * 64] a lane's 4 u8 column deltas
+    const int *cbase;       // wide: [nchunks] first column of each chunk; narrow: [nchunks * 4] of each segment
     const long long *cptr;  // [nrb + 1], in chunks
     const int *rstart;      // [nrb + 1] first row of each block (blocks are cut by NONZEROS, at most R rows each)
     int nrb, R, rows, cols; // R = the dummy accumulator's index = rows per block at most
@@ -107,8 +116,9 @@ struct CsbMat {
     int b0, b1;  // the row blocks of THIS launch: [b0, b1)
     int S;       // column splits: S workgroups share a row block, each sweeping 1/S of its chunks (see below)
     long long *z;   // S > 1: the splits' exact integer sums, [S][rows]
-    int *bad;       // S > 1: [nrb] bit 0: a split of the block left a product out (beyond the bound / not finite);
-                    //        bit 1: a split of the block added to zc
+    int *bad;       // S > 1: [nrb][CSB_QMAX] bit 0: a split of the block left a product out (beyond the bound / not
+                    //        finite); bit 1: a split of the block added to zc -- one copy per workgroup of k_csb_combine
+    int Q;          // S > 1: workgroups of k_csb_combine per row block (each takes a Q-th of its rows)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -280,6 +290,42 @@ __global__ __launch_bounds__(CSB_CHUNK) void k_csb_fill(const unsigned long long
     if (threadIdx.x == 0) cbase[c] = cb;
 }
 
+// The NARROW form of a chunk from its wide one (header): one workgroup of 256 threads per chunk, thread = element.
+// flags[1] |= 1 when two column-neighbours of a segment are more than 255 columns apart (the matrix keeps the wide form).
+__global__ __launch_bounds__(CSB_CHUNK) void k_csb_narrow(const unsigned *__restrict__ idx, const int *__restrict__ cbase,
+                                                          unsigned short *__restrict__ row16,
+                                                          unsigned char *__restrict__ dcol8, int *__restrict__ cbase4,
+                                                          int *__restrict__ flags)
+{
+    __shared__ int s_col[CSB_CHUNK];
+    const long long c = blockIdx.x;
+    const int e = threadIdx.x, j = e >> 6, l = e & (WAVE - 1);
+    const unsigned w = idx[c * CSB_CHUNK + e];
+    const int col = cbase[c] + (int)(w & CSB_LCOL_MASK);   // (padding: local column 0 -- below the columns before it)
+    s_col[e] = col;
+    __syncthreads();
+    // padding sits at the tail of a block's last chunk, aimed at the dummy accumulator: it takes the column of
+    // the element before it (delta 0) -- any column of x will do, its value is 0
+    int mycol = col, prev = l > 0 ? s_col[e - 1] : col;
+    const bool pad = (int)(w >> CSB_LCOL_BITS) >= CSB_RMAX;
+    if (pad) {
+        int k = e;
+        while (k > 0 && (int)(idx[c * CSB_CHUNK + k] >> CSB_LCOL_BITS) >= CSB_RMAX) --k;   // (the last real element)
+        mycol = s_col[k];
+        if (l > 0) {
+            int kp = e - 1;
+            while (kp > 0 && (int)(idx[c * CSB_CHUNK + kp] >> CSB_LCOL_BITS) >= CSB_RMAX) --kp;
+            prev = s_col[kp];
+        } else prev = mycol;
+    }
+    const int d = mycol - prev;
+    if (d < 0 || d > 255) atomicOr(&flags[1], 1);
+    const long long o = c * CSB_CHUNK + (long long)l * CSB_U + j;   // a lane's four elements side by side
+    row16[o] = (unsigned short)(w >> CSB_LCOL_BITS);
+    dcol8[o] = (unsigned char)(d & 255);
+    if (l == 0) cbase4[c * CSB_U + j] = mycol;
+}
+
 // ---------------------------------------------------------------------------------------------
 // product
 // ---------------------------------------------------------------------------------------------
@@ -403,33 +449,103 @@ __device__ __forceinline__ CsbGrid csb_grids(CsbX xb, double sx, double *red, in
     return g;
 }
 
+// Inclusive scan over the 64 lanes of a wave of two 16-bit fields packed in a word (neither overflows: callers
+// guarantee field sums < 2^16) -- row_shr 1, 2, 4, 8 inside the rows of 16 lanes, then the rows' totals handed on
+// (row_bcast 15 to rows 1 and 3, row_bcast 31 to rows 2 and 3): 6 DPP adds, no LDS.
+__device__ __forceinline__ unsigned wave_scan_u16x2(unsigned v)
+{
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);   // row_shr:1
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);   // row_shr:2
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);   // row_shr:4
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);   // row_shr:8
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, true);   // row_bcast:15 -> rows 1, 3
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, true);   // row_bcast:31 -> rows 2, 3
+    return v;
+}
+
+// What a lane holds of a chunk's index stream, raw (loaded ahead of use), and its decoding into local rows and
+// columns of x for the lane's four elements j * 64 + lane.
+template <bool NARROW>
+struct CsbRaw {
+    unsigned w[NARROW ? 3 : CSB_U];   // wide: the four index words; narrow: two words of rows, one of deltas
+    int base[NARROW ? CSB_U : 1];     // first column of the chunk (wide) / of each segment (narrow); wave-uniform
+};
+template <bool NARROW, bool NT>
+__device__ __forceinline__ void csb_load_raw(const CsbMat &A, long long cc, int lane, CsbRaw<NARROW> &q)
+{
+    if (NARROW) {
+        const long long k = cc * WAVE + lane;
+        const unsigned *pr = A.idx + 2 * k;
+        if (NT) {
+            q.w[0] = __builtin_nontemporal_load(pr);
+            q.w[1] = __builtin_nontemporal_load(pr + 1);
+            q.w[2] = __builtin_nontemporal_load(&A.dcol[k]);
+        } else {
+            q.w[0] = pr[0];
+            q.w[1] = pr[1];
+            q.w[2] = A.dcol[k];
+        }
+#pragma unroll
+        for (int j = 0; j < CSB_U; ++j) q.base[j] = A.cbase[cc * CSB_U + j];
+    } else {
+        const long long k = cc * CSB_CHUNK + lane;
+#pragma unroll
+        for (int j = 0; j < CSB_U; ++j) q.w[j] = NT ? __builtin_nontemporal_load(&A.idx[k + j * WAVE]) : A.idx[k + j * WAVE];
+        q.base[0] = A.cbase[cc];
+    }
+}
+template <bool NARROW>
+__device__ __forceinline__ void csb_decode(const CsbRaw<NARROW> &q, int (&r)[CSB_U], int (&col)[CSB_U])
+{
+    if (NARROW) {
+        const unsigned d = q.w[2];
+        const unsigned s01 = wave_scan_u16x2((d & 0xffu) | ((d & 0xff00u) << 8));
+        const unsigned s23 = wave_scan_u16x2(((d >> 16) & 0xffu) | ((d >> 8) & 0xff0000u));
+        col[0] = q.base[0] + (int)(s01 & 0xffffu);
+        col[1] = q.base[1] + (int)(s01 >> 16);
+        col[2] = q.base[2] + (int)(s23 & 0xffffu);
+        col[3] = q.base[3] + (int)(s23 >> 16);
+        r[0] = (int)(q.w[0] & 0xffffu);
+        r[1] = (int)(q.w[0] >> 16);
+        r[2] = (int)(q.w[1] & 0xffffu);
+        r[3] = (int)(q.w[1] >> 16);
+    } else {
+#pragma unroll
+        for (int j = 0; j < CSB_U; ++j) {
+            r[j] = (int)(q.w[j] >> CSB_LCOL_BITS);
+            col[j] = q.base[0] + (int)(q.w[j] & CSB_LCOL_MASK);
+        }
+    }
+}
+
 // Rows that were sent a product of a big column beyond the coarse bound or not finite.  The sweep left those
 // products out (an integer sum cannot hold them); here the chunks [c0, c1) of the block are read once more, ONLY those
 // products are added -- as doubles, in LDS (`accd`: the block's accumulators, all zero on entry and on
 // exit) -- and the rows concerned are patched in y: inf and NaN come out as IEEE addition gives them,
 // which is what the reference's row sum does with them.  Reached when x holds inf / NaN or
 // |x| is not what the bound was taken from; never by a healthy solve.
-template <typename VT>
+template <typename VT, bool NARROW>
 __device__ void csb_add_outliers(const CsbMat &A, const VT *__restrict__ aval, long long c0, long long c1,
                                  const VT *__restrict__ x, double sx, double tau, double pmax, double *accd,
-                                 VT *__restrict__ y, int row0, int nr)
-{
+                                 VT *__restrict__ y, int row0, int nr, int rlo = 0)
+{   // (rows [rlo, nr) of the block: a workgroup of k_csb_combine patches its own share only)
     const int tid = threadIdx.x, lane = tid & (WAVE - 1);
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     for (long long c = c0 + w; c < c1; c += CSB_WAVES) {
-        const int base = A.cbase[c];
+        CsbRaw<NARROW> q;
+        csb_load_raw<NARROW, false>(A, c, lane, q);
+        int r[CSB_U], col[CSB_U];
+        csb_decode<NARROW>(q, r, col);
         const long long k = c * CSB_CHUNK + lane;
 #pragma unroll
         for (int j = 0; j < CSB_U; ++j) {
-            const unsigned i = A.idx[k + j * WAVE];
-            const double xs = (double)x[base + (int)(i & CSB_LCOL_MASK)] * sx;
+            const double xs = (double)x[col[j]] * sx;
             const double p = (double)aval[k + j * WAVE] * xs;
-            const int r = (int)(i >> CSB_LCOL_BITS);
-            if (!(fabs(xs) < tau) && !(fabs(p) < pmax) && r < nr) atomicAdd(&accd[r], p);
+            if (!(fabs(xs) < tau) && !(fabs(p) < pmax) && r[j] < nr && r[j] >= rlo) atomicAdd(&accd[r[j]], p);
         }
     }
     __syncthreads();
-    for (int r = tid; r < nr; r += CSB_BLOCK) {
+    for (int r = rlo + tid; r < nr; r += CSB_BLOCK) {
         const double v = accd[r];
         if (v != 0.0) {   // (true for NaN)
             y[row0 + r] = (VT)((double)y[row0 + r] + ldexp(v, (int)A.rexp[row0 + r]));
@@ -441,10 +557,10 @@ __device__ void csb_add_outliers(const CsbMat &A, const VT *__restrict__ aval, l
 
 // the block's partial of sum (y ns)^2 from y as stored, with the epilogue's thread -> row mapping and reduction
 template <typename VT>
-__device__ __forceinline__ double csb_sumsq_rows(const VT *__restrict__ y, int row0, int nr, NScale nsc)
+__device__ __forceinline__ double csb_sumsq_rows(const VT *__restrict__ y, int row0, int nr, NScale nsc, int rlo = 0)
 {
     double sq = 0.0;
-    for (int r = threadIdx.x; r < nr; r += CSB_BLOCK) {
+    for (int r = rlo + threadIdx.x; r < nr; r += CSB_BLOCK) {
         const double ys = (double)y[row0 + r] * nsc.s;
         sq += ys * ys;
     }
@@ -470,7 +586,7 @@ __device__ __forceinline__ double csb_row_sum(const CsbMat &A, long long fine, i
     return sum;
 }
 
-template <typename VT = double>
+template <typename VT = double, bool NARROW = false>
 __global__ __launch_bounds__(CSB_BLOCK, 1) void k_spmv_csb(
     CsbMat A, const VT *__restrict__ x, VT *__restrict__ y, const SpmvCoef *__restrict__ coef,
     const int *__restrict__ stop, double *__restrict__ partials, const double *__restrict__ pin, int npin,
@@ -531,47 +647,51 @@ __global__ __launch_bounds__(CSB_BLOCK, 1) void k_spmv_csb(
         // software pipeline: the (value, index) stream of the wave's NEXT chunk is in flight while the
         // gathers and the LDS adds of this one run (two register sets, loads unconditional: clamped)
         double av[CSB_U], bv[CSB_U];
-        unsigned iv[CSB_U], jv[CSB_U];
-        int cb = 0, cbn = 0;
+        CsbRaw<NARROW> iv, jv;
         bool outlier = false, tookbig = false;
         const long long clast = c1 > c0 ? c1 - 1 : c0;
-        auto issue = [&](long long c, double (&a)[CSB_U], unsigned (&i)[CSB_U], int &base) {
+        auto issue = [&](long long c, double (&a)[CSB_U], CsbRaw<NARROW> &q) {
             const long long cc = c < clast ? c : clast;
-            base = A.cbase[cc];
-            const long long k = cc * CSB_CHUNK + lane;
+            csb_load_raw<NARROW, CSB_NT_STREAM != 0>(A, cc, lane, q);   // read-once stream: non-temporal, so that it does
+            const long long k = cc * CSB_CHUNK + lane;                  // not push x out of L2
 #pragma unroll
-            for (int j = 0; j < CSB_U; ++j) {
-                if (CSB_NT_STREAM) {   // read-once stream: non-temporal, so that it does not push x out of L2
-                    a[j] = (double)__builtin_nontemporal_load(&aval[k + j * WAVE]);
-                    i[j] = __builtin_nontemporal_load(&A.idx[k + j * WAVE]);
-                } else {
-                    a[j] = (double)aval[k + j * WAVE];
-                    i[j] = A.idx[k + j * WAVE];
-                }
-            }
+            for (int j = 0; j < CSB_U; ++j)
+                a[j] = CSB_NT_STREAM ? (double)__builtin_nontemporal_load(&aval[k + j * WAVE]) : (double)aval[k + j * WAVE];
         };
-        auto work = [&](const double (&a)[CSB_U], const unsigned (&i)[CSB_U], int base) {
-            double xv[CSB_U];
+        // One step of a wave, in the order the memory system wants it: (1) this chunk's columns decoded and its four
+        // gathers of x issued; (2) the NEXT chunk's stream requested; (3) the products and the LDS adds.  Loads return
+        // in order, so waiting for the gathers at (3) never waits for the stream requested at (2) -- the order is
+        // pinned with scheduling barriers (the compiler found it by itself for the wide form, not for the narrow
+        // one: its gathers were issued and waited for one by one, the prefetched stream with them).
+        int r[CSB_U];
+        double xv[CSB_U];
+        auto gather = [&](const CsbRaw<NARROW> &q) {
+            int col[CSB_U];
+            csb_decode<NARROW>(q, r, col);
 #pragma unroll
-            for (int j = 0; j < CSB_U; ++j) xv[j] = (double)x[base + (int)(i[j] & CSB_LCOL_MASK)] * sx;
+            for (int j = 0; j < CSB_U; ++j) xv[j] = (double)x[col[j]];
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto accumulate = [&](const double (&a)[CSB_U]) {
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < CSB_U; ++j) xv[j] = xv[j] * sx;
             bool anybig = false;
 #pragma unroll
             for (int j = 0; j < CSB_U; ++j) {
                 const double p = a[j] * xv[j];
-                const int r = (int)(i[j] >> CSB_LCOL_BITS);
                 const bool big = !(fabs(xv[j]) < tau);   // a big column (or x not finite): not for the fine grid
                 anybig |= big;
-                const long long q = __double2ll_rn(p * ginv);
-                atomicAdd(&acc[r], big ? 0ull : (unsigned long long)q);
+                const long long q1 = __double2ll_rn(p * ginv);
+                atomicAdd(&acc[r[j]], big ? 0ull : (unsigned long long)q1);
             }
             if (__any(anybig)) {   // (wave-uniform; never taken for a vector without outliers)
 #pragma unroll
                 for (int j = 0; j < CSB_U; ++j) {
-                    const int r = (int)(i[j] >> CSB_LCOL_BITS);
-                    if (!(fabs(xv[j]) < tau) && r < nr) {   // (padding aims at the dummy accumulator R >= nr)
+                    if (!(fabs(xv[j]) < tau) && r[j] < nr) {   // (padding aims at the dummy accumulator R >= nr)
                         const double p = a[j] * xv[j];
                         if (fabs(p) < pmax2)
-                            atomicAdd((unsigned long long *)&A.zc[row0 + r], (unsigned long long)__double2ll_rn(p * ginv2));
+                            atomicAdd((unsigned long long *)&A.zc[row0 + r[j]], (unsigned long long)__double2ll_rn(p * ginv2));
                         else outlier = true;   // beyond the coarse bound, or not finite: left to the outlier pass
                         tookbig = true;
                     }
@@ -579,13 +699,15 @@ __global__ __launch_bounds__(CSB_BLOCK, 1) void k_spmv_csb(
             }
         };
         if (c0 + w < c1) {
-            issue(c0 + w, av, iv, cb);
+            issue(c0 + w, av, iv);
             for (long long c = c0 + w; c < c1; c += 2 * CSB_WAVES) {
-                issue(c + CSB_WAVES, bv, jv, cbn);
-                work(av, iv, cb);
+                gather(iv);
+                issue(c + CSB_WAVES, bv, jv);
+                accumulate(av);
                 if (c + CSB_WAVES < c1) {  // uniform
-                    issue(c + 2 * CSB_WAVES, av, iv, cb);
-                    work(bv, jv, cbn);
+                    gather(jv);
+                    issue(c + 2 * CSB_WAVES, av, iv);
+                    accumulate(bv);
                 }
             }
         }
@@ -608,7 +730,8 @@ __global__ __launch_bounds__(CSB_BLOCK, 1) void k_spmv_csb(
                 acc[A.R] = 0ull;
                 s_bad = 0;
                 s_big = 0;
-                if (bad || big) atomicOr(&A.bad[b], (bad ? 1 : 0) | (big ? 2 : 0));
+                if (bad || big)
+                    for (int qi = 0; qi < A.Q; ++qi) atomicOr(&A.bad[b * CSB_QMAX + qi], (bad ? 1 : 0) | (big ? 2 : 0));
             }
             __syncthreads();
             continue;
@@ -629,7 +752,7 @@ __global__ __launch_bounds__(CSB_BLOCK, 1) void k_spmv_csb(
         }
         if (bad) {  // uniform
             __syncthreads();
-            csb_add_outliers<VT>(A, aval, c0, c1, x, sx, tau, pmax2, reinterpret_cast<double *>(acc), y, row0, nr);
+            csb_add_outliers<VT, NARROW>(A, aval, c0, c1, x, sx, tau, pmax2, reinterpret_cast<double *>(acc), y, row0, nr);
             sq = csb_sumsq_rows<VT>(y, row0, nr, nsc);
         }
         sq = wave_sum(sq);
@@ -645,10 +768,11 @@ __global__ __launch_bounds__(CSB_BLOCK, 1) void k_spmv_csb(
     }
 }
 
-// The second launch of a column-split product: y and the blocks' partials of sum (y ns)^2 from the
-// splits' exact sums.  One workgroup per row block with the thread -> row mapping and the reduction of
-// k_spmv_csb's own epilogue, so y AND the partials are bit for bit those of the unsplit kernel.
-template <typename VT = double>
+// The second launch of a column-split product: y and the partials of sum (y ns)^2 from the splits' exact sums.
+// Q workgroups per row block, each with a Q-th of the block's rows and a partial of its own (partials[b * Q + qi]):
+// one rank's block of config 4 at N = 8 has 64 row blocks -- with one workgroup each the launch kept a quarter of
+// the chip busy and took 43 us for 100 MB.  y is what the unsplit kernel would have produced, bit for bit.
+template <typename VT = double, bool NARROW = false>
 __global__ __launch_bounds__(CSB_BLOCK) void k_csb_combine(
     CsbMat A, const VT *__restrict__ x, VT *__restrict__ y, const SpmvCoef *__restrict__ coef,
     const int *__restrict__ stop, double *__restrict__ partials, const double *__restrict__ pin, int npin,
@@ -659,19 +783,22 @@ __global__ __launch_bounds__(CSB_BLOCK) void k_csb_combine(
     __shared__ int hist[CSB_XHIST];
     const int tid = threadIdx.x, lane = tid & (WAVE - 1);
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int Q = A.Q;
     if (*stop != 0) {
         // The solve stopped while this product was under way (the scalar rider travels with its first sweep): some
         // sweeps may have run and added to zc, y is no longer wanted.  What they left behind must still go -- the
         // next product of this matrix expects zc all zero and the flags down.
-        for (int b = blockIdx.x; b < A.nrb; b += gridDim.x) {
-            const int flags = A.bad[b];
+        for (int u = blockIdx.x; u < A.nrb * Q; u += gridDim.x) {
+            const int b = u / Q, qi = u % Q;
+            const int flags = A.bad[b * CSB_QMAX + qi];
             __syncthreads();
             if (flags & 2) {
                 const int row0 = A.rstart[b], nr = A.rstart[b + 1] - row0;
-                for (int r = tid; r < nr; r += CSB_BLOCK)
+                const int rlo = (int)((long long)nr * qi / Q), rhi = (int)((long long)nr * (qi + 1) / Q);
+                for (int r = rlo + tid; r < rhi; r += CSB_BLOCK)
                     __hip_atomic_store((unsigned long long *)&A.zc[row0 + r], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            if (flags != 0 && tid == 0) A.bad[b] = 0;
+            if (flags != 0 && tid == 0) A.bad[b * CSB_QMAX + qi] = 0;
         }
         return;
     }
@@ -681,13 +808,15 @@ __global__ __launch_bounds__(CSB_BLOCK) void k_csb_combine(
     const CsbGrid gr = csb_grids(xb, sx, red, hist);   // the sweeps' grids: same partials, same function
     const VT *__restrict__ aval = static_cast<const VT *>(A.val);
     bool cleared = false;
-    for (int b = blockIdx.x; b < A.nrb; b += gridDim.x) {
+    for (int u = blockIdx.x; u < A.nrb * Q; u += gridDim.x) {
+        const int b = u / Q, qi = u % Q;
         const int row0 = A.rstart[b];
         const int nr = A.rstart[b + 1] - row0;
-        const int flags = A.bad[b];   // uniform: what the splits of this block ran into (k_spmv_csb)
+        const int rlo = (int)((long long)nr * qi / Q), rhi = (int)((long long)nr * (qi + 1) / Q);
+        const int flags = A.bad[b * CSB_QMAX + qi];   // uniform: what the splits of this block ran into (k_spmv_csb)
         __syncthreads();              // (everyone has read the word: thread 0 may clear it below)
         double sq = 0.0;
-        for (int r = tid; r < nr; r += CSB_BLOCK) {
+        for (int r = rlo + tid; r < rhi; r += CSB_BLOCK) {
             long long s = __builtin_nontemporal_load(&A.z[row0 + r]);
             for (int sp = 1; sp < A.S; ++sp) s += __builtin_nontemporal_load(&A.z[(size_t)sp * A.rows + row0 + r]);
             const double sum = csb_row_sum(A, s, row0 + r, gr, (flags & 2) != 0);
@@ -701,12 +830,12 @@ __global__ __launch_bounds__(CSB_BLOCK) void k_csb_combine(
                 for (int i = tid; i < CSB_NACC; i += CSB_BLOCK) accd[i] = 0.0;
                 cleared = true;
             }
-            __syncthreads();   // (y of this block is written; accd is zero)
-            csb_add_outliers<VT>(A, aval, A.cptr[b], A.cptr[b + 1], x, sx, ldexp(1.0, gr.ef), ldexp(1.0, gr.ec), accd, y,
-                                 row0, nr);
-            sq = csb_sumsq_rows<VT>(y, row0, nr, nsc);
+            __syncthreads();   // (y of this share is written; accd is zero)
+            csb_add_outliers<VT, NARROW>(A, aval, A.cptr[b], A.cptr[b + 1], x, sx, ldexp(1.0, gr.ef), ldexp(1.0, gr.ec), accd, y,
+                                         row0, rhi, rlo);
+            sq = csb_sumsq_rows<VT>(y, row0, rhi, nsc, rlo);
         }
-        if (flags != 0 && tid == 0) A.bad[b] = 0;
+        if (flags != 0 && tid == 0) A.bad[b * CSB_QMAX + qi] = 0;
         sq = wave_sum(sq);
         if (lane == 0) red[w] = sq;
         __syncthreads();
@@ -714,7 +843,7 @@ __global__ __launch_bounds__(CSB_BLOCK) void k_csb_combine(
             double t = 0.0;
 #pragma unroll
             for (int i = 0; i < CSB_WAVES; ++i) t += red[i];
-            partials[b] = t;
+            partials[u] = t;
         }
         __syncthreads();
     }

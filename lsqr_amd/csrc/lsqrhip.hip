@@ -171,8 +171,10 @@ struct Csr {
     // column-swept row blocks (csb.h), used instead of everything above when `csb` is set
     int csb = 0;
     double *cval = nullptr;       // [nchunks * 256] values, each block sorted by column, padded to whole chunks
-    unsigned *cidx = nullptr;     // [nchunks * 256] local row << 17 | column - cbase[chunk]
-    int *ccb = nullptr;           // [nchunks] first column of each chunk
+    unsigned *cidx = nullptr;     // [nchunks * 256] local row << 17 | column - cbase[chunk]; narrow form (csb.h): the u16 rows
+    unsigned *cdel = nullptr;     // narrow form: [nchunks * 64] four u8 column deltas per lane
+    int *ccb = nullptr;           // [nchunks] first column of each chunk; narrow form: [nchunks * 4] of each segment
+    bool cnarrow = false;         // 11 bytes per nonzero (csb.h "NARROW form")
     long long *cptr = nullptr;    // [nrb + 1] first chunk of each row block
     int *crs = nullptr;           // [nrb + 1] first row of each row block
     int64_t nchunks = 0;
@@ -181,7 +183,8 @@ struct Csr {
     long long *zcoarse = nullptr; // [rows] integer sums of the products with big columns (csb.h); zero between products
     int S = 1;                    // column splits per row block (csb.h): S workgroups share a block
     long long *zsplit = nullptr;  // S > 1: [S][rows] exact integer sums of the splits
-    int *cbad = nullptr;          // S > 1: [nrb] "a split left a product out" flags (csb.h outlier pass)
+    int *cbad = nullptr;          // S > 1: [nrb][CSB_QMAX] "a split left a product out / used the coarse sums" flags (csb.h)
+    int Q = 1;                    // S > 1: workgroups of k_csb_combine per row block
 };
 
 // One rank's view of a row-sharded solve (shard_api.h): its place in the world, the caller-owned
@@ -349,6 +352,7 @@ static void free_csr(Csr &c)
     if (c.blk) (void)hipFree(c.blk);
     if (c.cval) (void)hipFree(c.cval);
     if (c.cidx) (void)hipFree(c.cidx);
+    if (c.cdel) (void)hipFree(c.cdel);
     if (c.ccb) (void)hipFree(c.ccb);
     if (c.cptr) (void)hipFree(c.cptr);
     if (c.crs) (void)hipFree(c.crs);
@@ -1048,14 +1052,51 @@ static int build_csb(hipStream_t s, const int *rowk, const int *colk, const doub
     HIPCHK(hipStreamSynchronize(s));
     if (got[3]) return LSQRHIP_OK;  // a chunk too wide for 18-bit local columns: not this layout
     if (got[2]) return LSQRHIP_OK;  // a value that does not survive its row's power of two exactly: not this layout
+    // The narrow form of the index stream (csb.h: u16 rows + u8 column deltas, 11 bytes per nonzero), where every
+    // delta fits a byte: LSQRHIP_CSB_NARROW=1.  Built and measured in round 4 (profiles/r04/csb_narrow_index.txt):
+    // 8 % less memory, the SAME time per product on every BASELINE configuration (alternating runs in one process:
+    // 3492 / 3499 against 3617 / 3475 us at config 4, 494 / 457 against 502 / 457 on one rank's block, 379 / 395
+    // against 385 / 401 at config 5, 931 / 961 against 941 / 943 at config 3) -- what bounds the sweep is not the
+    // bytes of its stream (scripts/csb_ceiling.hip).  So the 12-byte form stays the default: one code path fewer in
+    // every product; the narrow one is for matrices that would not fit otherwise.
+    bool narrow = false;
+    DevScratch s_row16, s_del, s_cb4;
+    if (nchunks > 0 && env_int("LSQRHIP_CSB_NARROW", 0) != 0) {
+        HIPCHK(s_row16.alloc(sizeof(unsigned short) * ne));
+        HIPCHK(s_del.alloc(ne));
+        HIPCHK(s_cb4.alloc(sizeof(int) * (size_t)nchunks * CSB_U));
+        HIPCHK(hipMemsetAsync(d_flags, 0, 4 * sizeof(int), s));
+        hipLaunchKernelGGL(k_csb_narrow, dim3((unsigned)nchunks), dim3(CSB_CHUNK), 0, s, (const unsigned *)s_idx.as<unsigned>(),
+                           (const int *)s_cb.as<int>(), s_row16.as<unsigned short>(), s_del.as<unsigned char>(),
+                           s_cb4.as<int>(), d_flags);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(got, d_flags, sizeof(got), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        narrow = got[1] == 0;
+        if (narrow) {
+            s_idx.free_now();
+            s_cb.free_now();
+        } else {
+            s_row16.free_now();
+            s_del.free_now();
+            s_cb4.free_now();
+        }
+    }
     out = Csr();
     out.rows = rows;
     out.cols = cols;
     out.rows_v = rows;
     out.csb = 1;
     out.cval = s_val.release<double>();
-    out.cidx = s_idx.release<unsigned>();
-    out.ccb = s_cb.release<int>();
+    out.cnarrow = narrow;
+    if (narrow) {
+        out.cidx = reinterpret_cast<unsigned *>(s_row16.release<unsigned short>());
+        out.cdel = reinterpret_cast<unsigned *>(s_del.release<unsigned char>());
+        out.ccb = s_cb4.release<int>();
+    } else {
+        out.cidx = s_idx.release<unsigned>();
+        out.ccb = s_cb.release<int>();
+    }
     out.cptr = s_cptr.release<long long>();
     out.crs = s_rst.release<int>();
     out.nchunks = nchunks;
@@ -1068,16 +1109,19 @@ static int build_csb(hipStream_t s, const int *rowk, const int *colk, const doub
     out.S = S;
     if (S > 1) {
         HIPCHK(hipMalloc((void **)&out.zsplit, sizeof(long long) * (size_t)S * (size_t)rows));
-        HIPCHK(hipMalloc((void **)&out.cbad, sizeof(int) * (size_t)nrb));
-        HIPCHK(hipMemsetAsync(out.cbad, 0, sizeof(int) * (size_t)nrb, s));
+        HIPCHK(hipMalloc((void **)&out.cbad, sizeof(int) * (size_t)nrb * CSB_QMAX));
+        HIPCHK(hipMemsetAsync(out.cbad, 0, sizeof(int) * (size_t)nrb * CSB_QMAX, s));
+        // the combine launch: enough workgroups for the whole chip (csb.h k_csb_combine)
+        out.Q = (int)std::min<int64_t>(CSB_QMAX, std::max<int64_t>(1, (2 * CSB_GRID + nrb - 1) / nrb));
+        while (out.Q > 1 && (int64_t)nrb * out.Q > SPMV_MAX_GRID) --out.Q;
     }
     out.grid = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)nrb * S, CSB_GRID));  // workgroups per launch
-    out.out_grid = nrb;
+    out.out_grid = nrb * out.Q;   // partials of sum(y^2) one product leaves behind
     out.nblk = nrb;
     // (+ 8 bytes per column: the k_csb_xmax pass reads the gathered vector once more than the sweeps' "x once";
     //  + 2 bytes per row: the rows' powers of two)
-    out.bytes = (int64_t)nchunks * CSB_CHUNK * 12 + (int64_t)nchunks * 4 + (int64_t)(nrb + 1) * 8 + (int64_t)cols * 8 +
-                (int64_t)rows * 2;
+    out.bytes = (int64_t)nchunks * CSB_CHUNK * (narrow ? 11 : 12) + (int64_t)nchunks * (narrow ? 16 : 4) +
+                (int64_t)(nrb + 1) * 8 + (int64_t)cols * 8 + (int64_t)rows * 2;
     return LSQRHIP_OK;
 }
 
@@ -1419,8 +1463,8 @@ extern "C" int lsqrhip_info(lsqrhip_handle_t h, int64_t *dims)
     dims[5] = h->off64 ? 8 : 4;
     dims[6] = h->ndict;                          // value dictionary entries (0 = 8-byte values)
     dims[7] = h->A.sell == 3 ? 0 : ((h->A.val8 || h->A.sell_v8) ? 1 : 8);   // bytes per stored value (row patterns: none)
-    dims[8] = (h->A.col16 || h->A.sell_c16) ? 2 : 4;                // bytes per column index, CSR(A)
-    dims[9] = (h->AT.col16 || h->AT.sell_c16) ? 2 : 4;               //                        CSR(A')
+    dims[8] = (h->A.csb && h->A.cnarrow) ? 3 : ((h->A.col16 || h->A.sell_c16) ? 2 : 4);   // bytes per column index, CSR(A) (3: csb.h narrow form, u16 row + u8 column delta)
+    dims[9] = (h->AT.csb && h->AT.cnarrow) ? 3 : ((h->AT.col16 || h->AT.sell_c16) ? 2 : 4);   //                        CSR(A')
     dims[10] = h->A.P;                           // column panels of CSR(A)
     dims[11] = h->AT.P;                          //                  CSR(A')
     dims[12] = h->A.sell;                        // sliced-ELL layout in use for A

@@ -269,8 +269,8 @@ static void launch_xl(const SpmvArgs &a, double *z)
 }
 
 // column-swept row blocks (csb.h)
-template <typename VT>
-static void launch_csb(H *h, const SpmvArgs &a)
+template <typename VT, bool NARROW>
+static void launch_csb_N(H *h, const SpmvArgs &a)
 {
     const Csr &c = *a.c;
     const VT *x = reinterpret_cast<const VT *>(a.x);
@@ -290,8 +290,8 @@ static void launch_csb(H *h, const SpmvArgs &a)
     static const int rounds = env_int("LSQRHIP_CSB_ROUNDS", 1);
     const int S = std::max(c.S, 1);
     const int step = rounds ? std::max(1, c.grid / S) : std::max(c.nrb, 1);   // row blocks per launch
-    CsbMat A{c.cval, c.cidx, c.ccb, c.cptr, c.crs, c.nrb, c.R, c.rows, c.cols, c.rexp, c.zcoarse, 0, 0, S, c.zsplit,
-             c.cbad};
+    CsbMat A{c.cval, c.cidx, c.cdel, c.ccb, c.cptr, c.crs, c.nrb, c.R, c.rows, c.cols, c.rexp, c.zcoarse, 0, 0, S, c.zsplit,
+             c.cbad, std::max(c.Q, 1)};
     for (int b0 = 0; b0 < c.nrb || b0 == 0; b0 += step) {
         const int b1 = std::min(c.nrb, b0 + step);
         const bool first = b0 == 0, last = b1 >= c.nrb;
@@ -301,23 +301,30 @@ static void launch_csb(H *h, const SpmvArgs &a)
         const dim3 grid(std::max(1, std::min(c.grid, (b1 - b0) * S)) + (rider.kind != 0 ? 1 : 0));
         hipEvent_t e0 = first ? a.e0 : nullptr, e1 = (last && S == 1) ? a.e1 : nullptr;
         if (e0 == nullptr && e1 == nullptr)
-            hipLaunchKernelGGL(k_spmv_csb<VT>, grid, dim3(CSB_BLOCK), 0, a.stream, A, x, y, a.coef, a.stop, a.pout,
+            hipLaunchKernelGGL((k_spmv_csb<VT, NARROW>), grid, dim3(CSB_BLOCK), 0, a.stream, A, x, y, a.coef, a.stop, a.pout,
                                a.pin, a.npin, a.slot_in, a.slot_out, a.skip_if_zero, rider, xb, a.nsc);
         else
-            hipExtLaunchKernelGGL(k_spmv_csb<VT>, grid, dim3(CSB_BLOCK), 0, a.stream, e0, e1, 0, A, x, y, a.coef,
+            hipExtLaunchKernelGGL((k_spmv_csb<VT, NARROW>), grid, dim3(CSB_BLOCK), 0, a.stream, e0, e1, 0, A, x, y, a.coef,
                                   a.stop, a.pout, a.pin, a.npin, a.slot_in, a.slot_out, a.skip_if_zero, rider, xb,
                                   a.nsc);
         if (last) break;
     }
     if (S > 1) {  // the splits' sums -> y and the blocks' partials (csb.h k_csb_combine)
-        const dim3 grid(std::max(1, std::min(c.nrb, 2 * CSB_GRID)));
+        const dim3 grid(std::max(1, std::min(c.nrb * std::max(c.Q, 1), 2 * CSB_GRID)));
         if (a.e1 == nullptr)
-            hipLaunchKernelGGL(k_csb_combine<VT>, grid, dim3(CSB_BLOCK), 0, a.stream, A, x, y, a.coef, a.stop, a.pout,
+            hipLaunchKernelGGL((k_csb_combine<VT, NARROW>), grid, dim3(CSB_BLOCK), 0, a.stream, A, x, y, a.coef, a.stop, a.pout,
                                a.pin, a.npin, a.slot_in, a.skip_if_zero, xb, a.nsc);
         else
-            hipExtLaunchKernelGGL(k_csb_combine<VT>, grid, dim3(CSB_BLOCK), 0, a.stream, nullptr, a.e1, 0, A, x, y,
+            hipExtLaunchKernelGGL((k_csb_combine<VT, NARROW>), grid, dim3(CSB_BLOCK), 0, a.stream, nullptr, a.e1, 0, A, x, y,
                                   a.coef, a.stop, a.pout, a.pin, a.npin, a.slot_in, a.skip_if_zero, xb, a.nsc);
     }
+}
+
+template <typename VT>
+static void launch_csb(H *h, const SpmvArgs &a)
+{
+    if (a.c->cnarrow) launch_csb_N<VT, true>(h, a);
+    else launch_csb_N<VT, false>(h, a);
 }
 
 static void launch_spmv_args(H *h, const SpmvArgs &a_in)

@@ -265,13 +265,18 @@ def run_distributed(args):
                          "traffic_detail": traffic, "traffic_note": traffic_note,
                          "bytes_per_launch": lay1, "avg_launch_us": avg1 * 1e3, "launches": reps,
                          "bytes_are": "the layout in use: matrix as stored + x once + y read and written (physical)",
-                         "effective_gbps": b1 / (avg1 * 1e-3) / 1e9, "effective_bytes_per_launch": b1},
+                         "effective_gbps": b1 / (avg1 * 1e-3) / 1e9, "effective_bytes_per_launch": b1,
+                         "frac_survey8d": b1 / (avg1 * 1e-3) / 1e9 / 8000.0,
+                         "bound_survey8d": "cache" if b1 / (avg1 * 1e-3) / 1e9 > 8000.0 else "hbm"},
         }
+        # next to `value`: the same matrix whole on ONE GPU, measured by this run, and the ratio -- the strong-scaling
+        # number of this line.  (bench.py's own N = 1 line measures configs[1], another workload: never divide by it.)
+        out["value_1gpu_same_workload"] = ref["value"] if ref and "value" in ref else None
+        out["speedup_vs_1gpu_same_workload"] = (K / dt) / ref["value"] if ref and "value" in ref else None
+        out["overlap"] = int(os.environ.get("LSQRHIP_SHARD_OVERLAP", "0") or 0)
         out["cpu_baseline"] = cpu
         if ref is not None:
             out["strong_scaling_ref"] = ref
-            if "value" in ref:
-                out["speedup_vs_1gpu_same_workload"] = (K / dt) / ref["value"]
         print(json.dumps(out), flush=True)
     dist.barrier()
     dist.destroy_process_group()

@@ -151,6 +151,16 @@ class _Port:
         self.L.oracle_set_norm_ulp.argtypes = [C.c_int, C.c_int, C.c_int]
         self.L.oracle_set_norm_ulp(int(itn), int(which), int(ulps))
 
+    def set_accurate_sums(self, on: bool) -> None:
+        """Compensated row sums in aprod and pairwise sums of squares in dnrm2 for every following call (test hooks
+        oracle_set_accurate_rowsums / oracle_set_norm_order): the same recurrences with correctly rounded sums."""
+        self.L.oracle_set_accurate_rowsums.restype = None
+        self.L.oracle_set_accurate_rowsums.argtypes = [C.c_int]
+        self.L.oracle_set_norm_order.restype = None
+        self.L.oracle_set_norm_order.argtypes = [C.c_int]
+        self.L.oracle_set_accurate_rowsums(1 if on else 0)
+        self.L.oracle_set_norm_order(1 if on else 0)
+
     # operator -----------------------------------------------------------
     def validate(self, m, n, irow, icol):
         irow = np.ascontiguousarray(irow, dtype=np.int32)

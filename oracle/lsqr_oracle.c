@@ -161,9 +161,41 @@ double oracle_d2norm(double a, double b)
 /* mode 1: y += A x  (row sums formed from zero in COO order, then added, :166-174)
  * mode 2: x += A' y (:186-194).  irow/icol are 1-based like the reference.
  * scratch must hold max(m,n) doubles.  Returns 0, or 5 for a bad mode (:197). */
+/* Test hook: 1 = every row sum of aprod as a COMPENSATED sum (Neumaier: the error of each add is carried along, so the
+ * result is the correctly rounded sum for all practical purposes) instead of the reference's left-to-right one.
+ * Never set by a parity test: tests/fuzz_layouts.py measures with it (and oracle_set_norm_order(1)) how far the
+ * reference's x lies from an evaluation of the same recurrences with accurate sums -- its own rounding error,
+ * including the part no permutation of the input reveals (thousands of EQUAL addends in a row drift one way in
+ * every order: 64 x 5000 with one 6000-entry row of dictionary values, 2.8e-14 of the row sum in all of them). */
+static int g_accurate_rowsums = 0;
+void oracle_set_accurate_rowsums(int on) { g_accurate_rowsums = on; }
+
+static void comp_add(double *s, double *c, double t)
+{
+    const double sum = *s + t;
+    if (fabs(*s) >= fabs(t)) *c += (*s - sum) + t;
+    else *c += (t - sum) + *s;
+    *s = sum;
+}
+
 int oracle_aprod(int mode, int m, int n, long long nnz, const int *irow, const int *icol,
                  const double *a, double *x, double *y, double *scratch)
 {
+    if (g_accurate_rowsums && (mode == 1 || mode == 2)) {
+        const int len = mode == 1 ? m : n;
+        double *comp = (double *)calloc((size_t)(len > 0 ? len : 1), sizeof(double));
+        if (!comp) return 5;
+        for (int i = 0; i < len; ++i) scratch[i] = 0.0;
+        for (long long k = 0; k < nnz; ++k) {
+            const int r = irow[k] - 1, c = icol[k] - 1;
+            if (mode == 1) comp_add(&scratch[r], &comp[r], a[k] * x[c]);
+            else comp_add(&scratch[c], &comp[c], a[k] * y[r]);
+        }
+        if (mode == 1) for (int i = 0; i < m; ++i) y[i] = y[i] + (scratch[i] + comp[i]);
+        else for (int j = 0; j < n; ++j) x[j] = x[j] + (scratch[j] + comp[j]);
+        free(comp);
+        return 0;
+    }
     if (mode == 1) {
         for (int i = 0; i < m; ++i) scratch[i] = 0.0;
         for (long long k = 0; k < nnz; ++k) {

@@ -52,6 +52,7 @@ typedef struct {
 void oracle_lstp_set_sum_order(int order);
 void oracle_set_norm_order(int order);
 void oracle_set_norm_ulp(int itn, int which, int ulps);   /* test hook: see lsqr_oracle.c */
+void oracle_set_accurate_rowsums(int on);                  /* test hook: see lsqr_oracle.c */
 void oracle_hprod(int n, const double *hz, const double *x, double *y);
 void oracle_lstp_aprod(void *ctx, int mode, int m, int n, double *x, double *y);
 int oracle_lstp_alloc(oracle_lstp_t *c, int m, int n);

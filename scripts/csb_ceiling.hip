@@ -1,0 +1,246 @@
+// csb_ceiling.hip -- what the memory system of one MI355X delivers for the ACCESS PATTERN of a product over
+// column-swept row blocks (lsqr_amd/csrc/csb.h), with the arithmetic and the LDS sums taken away.
+//
+// Round 3's review: k_spmv_csb reads 0.43-0.48 of the HBM roofline on the scattered configurations and the
+// explanation -- a CU keeps ~64 cache lines in flight and the 12-byte stream from HBM shares them with 0.3 gathered
+// lines of x per nonzero -- was an argument, not a measurement.  This program measures it.  It builds the REAL
+// layout (chunks of 256 column-sorted nonzeros: f64 value, u32 local row << 17 | column - chunk base, one base per
+// chunk; blocks of R rows x d nonzeros per row over n columns, columns uniform) and runs the real sweep -- one
+// 1024-thread workgroup per CU, wave w takes chunks w, w + 16, ..., the next chunk's stream in flight while this
+// one's gathers run, non-temporal stream loads, one launch per round of 256 units, S column splits -- in four forms:
+//
+//   stream      the (value, index, base) stream alone                      -> what HBM gives this read pattern
+//   gather      the gathers of x alone (indices recomputed, no stream)      -> what L2 / Infinity Cache give
+//   both        stream + gathers, products summed in registers              -> THE CEILING of the pattern
+//   both+lds    ... and one ds_add_u64 per nonzero on a rounded product     -> the product without its epilogue
+//
+// "GB/s" counts 12 bytes per stored nonzero + 4 per chunk + x once per round (8 n per launch set) -- the layout
+// bytes bench.py's roofline.achieved uses, without y (no epilogue here).
+//
+//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off scripts/csb_ceiling.hip -o scripts/_bin/csb_ceiling
+//   scripts/_bin/csb_ceiling            (table: profiles/r04/csb_ceiling.txt)
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CK(e)                                                                              \
+    do {                                                                                   \
+        hipError_t _e = (e);                                                               \
+        if (_e != hipSuccess) {                                                            \
+            std::fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(_e)); \
+            std::exit(1);                                                                  \
+        }                                                                                  \
+    } while (0)
+
+constexpr int WAVE = 64, BLOCK = 1024, WAVES = BLOCK / WAVE, U = 4, CHUNK = U * WAVE;
+constexpr int RMAX = 20352, NACC = RMAX + 64, LBITS = 17;
+constexpr unsigned LMASK = (1u << LBITS) - 1u;
+
+__device__ __forceinline__ uint64_t mix(uint64_t z)
+{
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0xBF58476D1CE4E5B9ull;
+    return z ^ (z >> 31);
+}
+
+// chunk c of block b: 256 nonzeros whose columns ascend uniformly over [0, n) along the block
+// (element j of the block: column ~ (j + u) * n / per), local rows uniform in [0, R)
+__global__ __launch_bounds__(CHUNK) void k_fill(double *val, unsigned *idx, int *cbase, int64_t cpb, int64_t per, int n,
+                                                int R)
+{
+    const int64_t c = blockIdx.x;          // global chunk
+    const int64_t j0 = (c % cpb) * CHUNK;  // first element of the chunk inside its block
+    const double gap = (double)n / (double)per;
+    const int64_t j = j0 + threadIdx.x;
+    const uint64_t h = mix((uint64_t)c * CHUNK + threadIdx.x);
+    const double u = (double)(h >> 11) * (1.0 / 9007199254740992.0);
+    int col = (int)(((double)(j < per ? j : per - 1) + u) * gap);
+    col = col >= n ? n - 1 : col;
+    int base = (int)((double)(j0 < per ? j0 : per - 1) * gap);
+    base = base > col ? col : base;
+    __shared__ int s_base;
+    if (threadIdx.x == 0) s_base = base;
+    __syncthreads();
+    const int lc = col - s_base;
+    const unsigned lrow = j < per ? (unsigned)((h >> 40) % (uint64_t)R) : (unsigned)RMAX;
+    val[c * CHUNK + threadIdx.x] = j < per ? 0.25 + (double)(h & 1023) * (1.0 / 1024.0) : 0.0;
+    idx[c * CHUNK + threadIdx.x] = (lrow << LBITS) | ((unsigned)(lc < 0 ? 0 : lc) & LMASK);
+    if (threadIdx.x == 0) cbase[c] = s_base;
+}
+
+// MODE 0 stream | 1 gather | 2 both | 3 both + LDS integer adds
+template <int MODE>
+__global__ __launch_bounds__(BLOCK, 1) void k_sweep(const double *__restrict__ val, const unsigned *__restrict__ idx,
+                                                    const int *__restrict__ cbase, const double *__restrict__ x,
+                                                    int64_t cpb, int b0, int nunits, int S, double ginv, int gapi,
+                                                    double *__restrict__ out)
+{
+    __shared__ unsigned long long acc[MODE == 3 ? NACC : 1];
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1);
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (MODE == 3) {
+        for (int i = tid; i < NACC; i += BLOCK) acc[i] = 0ull;
+        __syncthreads();
+    }
+    double keep = 0.0;
+    unsigned keepi = 0;
+    for (int u = blockIdx.x; u < nunits; u += gridDim.x) {
+        const int b = b0 + u / S, sp = u % S;
+        const int64_t cb0 = (int64_t)b * cpb;
+        const int64_t c0 = cb0 + (cpb * sp) / S, c1 = cb0 + (cpb * (sp + 1)) / S;
+        double av[U], bv[U];
+        unsigned iv[U], jv[U];
+        int cb = 0, cbn = 0;
+        const int64_t clast = c1 > c0 ? c1 - 1 : c0;
+        auto issue = [&](int64_t c, double (&a)[U], unsigned (&i)[U], int &base) {
+            const int64_t cc = c < clast ? c : clast;
+            if (MODE == 1) {   // no stream: the indices a chunk of this density would hold, from arithmetic
+                base = (int)((cc - cb0) * (int64_t)gapi);
+#pragma unroll
+                for (int j = 0; j < U; ++j) {
+                    a[j] = 1.0;
+                    i[j] = (unsigned)(((j * WAVE + lane) * gapi) >> 8);
+                }
+                return;
+            }
+            base = cbase[cc];
+            const int64_t k = cc * CHUNK + lane;
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                a[j] = __builtin_nontemporal_load(&val[k + j * WAVE]);
+                i[j] = __builtin_nontemporal_load(&idx[k + j * WAVE]);
+            }
+        };
+        auto work = [&](const double (&a)[U], const unsigned (&i)[U], int base) {
+            if (MODE == 0) {
+#pragma unroll
+                for (int j = 0; j < U; ++j) {
+                    keep += a[j];
+                    keepi ^= i[j] + (unsigned)base;
+                }
+                return;
+            }
+            double xv[U];
+#pragma unroll
+            for (int j = 0; j < U; ++j) xv[j] = x[base + (int)(i[j] & LMASK)];
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                const double p = a[j] * xv[j];
+                if (MODE == 3) {
+                    const int r = (int)(i[j] >> LBITS);
+                    atomicAdd(&acc[r], (unsigned long long)__double2ll_rn(p * ginv));
+                } else {
+                    keep += p;
+                }
+            }
+        };
+        if (c0 + w < c1) {
+            issue(c0 + w, av, iv, cb);
+            for (int64_t c = c0 + w; c < c1; c += 2 * WAVES) {
+                issue(c + WAVES, bv, jv, cbn);
+                work(av, iv, cb);
+                if (c + WAVES < c1) {
+                    issue(c + 2 * WAVES, av, iv, cb);
+                    work(bv, jv, cbn);
+                }
+            }
+        }
+    }
+    if (MODE == 3) {
+        __syncthreads();
+        unsigned long long t = 0;
+        for (int i = tid; i < NACC; i += BLOCK) t += acc[i];
+        if (t == 0x123456789ull) out[1] = 1.0;
+    }
+    if (keep == 123.456 || keepi == 0x87654321u) out[0] = keep;
+}
+
+struct Cfg {
+    const char *name;
+    int n;          // columns of x
+    int R;          // rows per block
+    double d;       // nonzeros per row
+    int nblocks;    // row blocks of the matrix
+    int S;          // column splits
+    double measured_ms;   // the product of the library on this configuration (mode 1, profiles/r03, r04), for the table
+};
+
+template <int MODE>
+static double run(const Cfg &c, const double *val, const unsigned *idx, const int *cbase, const double *x, int64_t cpb,
+                  double *out, int reps)
+{
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    const int per_launch = std::max(1, 256 / c.S);   // row blocks per launch: one unit per CU
+    const int gapi = (int)(256.0 * (double)c.n / (c.R * c.d));   // columns per nonzero, 8.8 fixed point (gather-only form)
+    auto product = [&]() {
+        for (int b0 = 0; b0 < c.nblocks; b0 += per_launch) {
+            const int nb = std::min(per_launch, c.nblocks - b0);
+            hipLaunchKernelGGL(k_sweep<MODE>, dim3(std::min(256, nb * c.S)), dim3(BLOCK), 0, 0, val, idx, cbase, x, cpb, b0,
+                               nb * c.S, c.S, 0x1p40, gapi, out);
+        }
+    };
+    product();
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0, 0));
+    for (int r = 0; r < reps; ++r) product();
+    CK(hipEventRecord(e1, 0));
+    CK(hipEventSynchronize(e1));
+    CK(hipGetLastError());
+    float ms = 0;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    CK(hipEventDestroy(e0));
+    CK(hipEventDestroy(e1));
+    return ms / reps;
+}
+
+int main(int argc, char **argv)
+{
+    const int reps = argc > 1 ? std::atoi(argv[1]) : 5;
+    const Cfg cfgs[] = {
+        {"config 4: 10M x 10M x 100, 512 blocks, S = 4 (8 launches)", 10000000, 19532, 100.0, 512, 4, 3.45},
+        {"config 4, S = 1 (2 launches)", 10000000, 19532, 100.0, 512, 1, 3.7},
+        {"one rank's block of config 4 at N = 8: 1.25M x 10M x 100, 64 blocks, S = 4", 10000000, 19532, 100.0, 64, 4, 0.46},
+        {"config 5: 5M x 2M power law (mean 21.3 per row), 256 blocks, S = 1", 2000000, 19532, 21.29, 256, 1, 0.37},
+        {"config 3 at 100 per row: 4M x 1M, 256 blocks of 15625 rows, S = 1", 1000000, 15625, 100.0, 256, 1, 0.91},
+    };
+    double *x, *out;
+    CK(hipMalloc(&x, sizeof(double) * 11000000));   // (+ slack: the last chunk of the gather-only form may overshoot n)
+    CK(hipMemset(x, 0, sizeof(double) * 11000000));
+    CK(hipMalloc(&out, 64));
+    std::printf("%-78s %9s %9s %9s %9s | %9s %9s\n", "configuration", "stream", "gather", "both", "both+lds", "library",
+                "lib/both");
+    for (const Cfg &c : cfgs) {
+        const int64_t per = (int64_t)(c.R * c.d);
+        const int64_t cpb = (per + CHUNK - 1) / CHUNK;
+        const int64_t nchunks = cpb * c.nblocks;
+        double *val;
+        unsigned *idx;
+        int *cbase;
+        CK(hipMalloc(&val, sizeof(double) * nchunks * CHUNK));
+        CK(hipMalloc(&idx, sizeof(unsigned) * nchunks * CHUNK));
+        CK(hipMalloc(&cbase, sizeof(int) * nchunks));
+        hipLaunchKernelGGL(k_fill, dim3((unsigned)nchunks), dim3(CHUNK), 0, 0, val, idx, cbase, cpb, per, c.n, c.R);
+        CK(hipDeviceSynchronize());
+        const double t0 = run<0>(c, val, idx, cbase, x, cpb, out, reps);
+        const double t1 = run<1>(c, val, idx, cbase, x, cpb, out, reps);
+        const double t2 = run<2>(c, val, idx, cbase, x, cpb, out, reps);
+        const double t3 = run<3>(c, val, idx, cbase, x, cpb, out, reps);
+        const double bytes = (double)nchunks * CHUNK * 12.0 + (double)nchunks * 4.0 + 8.0 * c.n;
+        std::printf("%-78s %9.3f %9.3f %9.3f %9.3f | %9.3f %9.2f   ms\n", c.name, t0, t1, t2, t3, c.measured_ms,
+                    c.measured_ms / t2);
+        std::printf("%-78s %9.0f %9s %9.0f %9.0f | %9.0f %9s   GB/s of layout bytes (%.2f GB)\n", "", bytes / t0 / 1e6, "-",
+                    bytes / t2 / 1e6, bytes / t3 / 1e6, bytes / c.measured_ms / 1e6, "", bytes / 1e9);
+        std::fflush(stdout);
+        CK(hipFree(val));
+        CK(hipFree(idx));
+        CK(hipFree(cbase));
+    }
+    return 0;
+}

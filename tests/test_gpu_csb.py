@@ -20,7 +20,7 @@ CASES = build_cases()
 
 @pytest.fixture
 def csb_env():
-    keys = ("LSQRHIP_CSB", "LSQRHIP_CSB_R", "LSQRHIP_CSB_S")
+    keys = ("LSQRHIP_CSB", "LSQRHIP_CSB_R", "LSQRHIP_CSB_S", "LSQRHIP_CSB_NARROW")
     old = {k: os.environ.get(k) for k in keys}
     os.environ["LSQRHIP_CSB"] = "1"
 
@@ -96,13 +96,17 @@ def test_results_do_not_depend_on_the_blocking_bit_for_bit(csb_env, kind):
         p = P.random_rows(6000, 2500, 9, seed=7, damp=1e-3)      # A: 9 per row; A': ~22 per row
     xp, yp = vecs(p)
     ys, xs = [], []
-    for R, S in ((None, None), (64, None), (1000, None), (4097, None), (1000, 2), (700, 3), (None, 5)):
+    for R, S, narrow in ((None, None, 0), (64, None, 0), (1000, None, 0), (4097, None, 0), (1000, 2, 0), (700, 3, 0),
+                         (None, 5, 0), (None, None, 1), (900, 4, 1)):
         csb_env(R)
         # column splits: S workgroups share a row block and their exact sums are added by a second kernel
         os.environ.pop("LSQRHIP_CSB_S", None)
         if S:
             os.environ["LSQRHIP_CSB_S"] = str(S)
+        # the 11-byte form of the index stream (u16 rows, u8 column deltas decoded by wave scans): the same bits
+        os.environ["LSQRHIP_CSB_NARROW"] = str(narrow)
         s = lsqr_solver_ez().initialize(p.m, p.n, p.a, p.irow, p.icol, itnlim=15)
+        assert s.info()["col_bytes"] == (3 if narrow else 4) and s.info()["colt_bytes"] == (3 if narrow else 4)
         x, y = xp.copy(), yp.copy()
         s.aprod(1, p.m, p.n, x, y)
         ys.append(y)
