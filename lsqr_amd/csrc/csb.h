@@ -233,12 +233,22 @@ __global__ __launch_bounds__(256) void k_csb_pack_rb(const int *__restrict__ row
     }
 }
 
+// perm[j] = COO position of the j-th nonzero in (block, column) order: the block-order words point into the
+// column order, whose positions point into the triplets
+__global__ __launch_bounds__(256) void k_csb_compose(const unsigned long long *__restrict__ sorted2,
+                                                     const unsigned *__restrict__ pos1, int64_t nnz,
+                                                     unsigned *__restrict__ perm)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < nnz; j += stride)
+        perm[j] = pos1[(unsigned)(sorted2[j] & 0xffffffffull)];
+}
+
 // One workgroup per chunk: element t of chunk c of block b is the (c - cptr[b]) * 256 + t -th nonzero
 // of the block in column order, or padding.  The value stored is a 2^-rexp[row] (header).
 // flags[3] |= 1 if a chunk spans 2^17 columns or more; flags[2] |= 1 if a scaled value is not exact (it left the
 // normal range -- of binary32 when `f32`: the values of a REAL32 handle are narrowed after the build).
-__global__ __launch_bounds__(CSB_CHUNK) void k_csb_fill(const unsigned long long *__restrict__ sorted2,
-                                                        const unsigned *__restrict__ pos1,
+__global__ __launch_bounds__(CSB_CHUNK) void k_csb_fill(const unsigned *__restrict__ perm,
                                                         const int *__restrict__ rowk, const int *__restrict__ colk,
                                                         const double *__restrict__ a,
                                                         const long long *__restrict__ rbstart,
@@ -267,8 +277,7 @@ __global__ __launch_bounds__(CSB_CHUNK) void k_csb_fill(const unsigned long long
     int col = 0, lrow = R;  // padding: the dummy accumulator
     double v = 0.0;
     if (real) {
-        const unsigned i = (unsigned)(sorted2[j0 + e] & 0xffffffffull);
-        const unsigned p = pos1[i];
+        const unsigned p = perm[j0 + e];
         col = colk[p] - 1;
         const int row = rowk[p] - 1;
         lrow = row - rstart[b];

@@ -210,6 +210,8 @@ struct lsqrhip_handle_s {
     int m = 0, n = 0;
     int64_t nnz = 0;
     bool off64 = false;
+    int64_t build_peak = 0;      // peak device bytes of the create beyond the caller's triplets; kept: bytes it holds now
+    int64_t build_kept = 0;
     bool f32_device_ok = false;  // (internal: lsqrhip_aprod_f32 calls lsqrhip_aprod_device on float vectors)
     bool io32 = false;  // created by lsqrhip_create_f32 (whether stored as float or, mixed mode, as double)
     bool f32 = false;   // REAL32 handle: values and the vectors U, V, W, X, SE are float arrays (the pointers below are
@@ -303,6 +305,15 @@ struct DevScratch {
         return q;
     }
 };
+
+// Peak device memory of a create beyond what the caller holds (the COO triplets): free memory is sampled where the
+// build's footprint peaks (after its scratch and the layout arrays are allocated) -- get_option "build_peak_bytes".
+static thread_local size_t t_min_free = ~(size_t)0;
+static void probe_mem()
+{
+    size_t fr = 0, tot = 0;
+    if (hipMemGetInfo(&fr, &tot) == hipSuccess && fr < t_min_free) t_min_free = fr;
+}
 
 static int env_int(const char *name, int dflt)
 {
@@ -696,6 +707,7 @@ static int build_csr_T(hipStream_t s, const int *d_keys, const int *d_other, con
     HIPCHK(hipMalloc((void **)&out.val, sizeof(double) * (size_t)std::max<int64_t>(nnz, 1)));
     out.bytes = (int64_t)sizeof(OffT) * (rows_v + 1) + 12 * nnz;
     out.nstored = nnz;
+    probe_mem();
 
     HIPCHK(hipMemsetAsync(d_flags, 0, 4 * sizeof(int), s));
     const int g = (int)std::min<int64_t>(std::max<int64_t>((nnz + 255) / 256, 1), 4096);
@@ -886,10 +898,22 @@ static unsigned long long *radix_sort_words(hipStream_t s, unsigned long long *i
 //   LSQRHIP_CSB_R  rows per block (test hook; default: as many as the LDS holds, cut so that the
 //                  blocks divide evenly among the 256 workgroups)
 static int build_csb(hipStream_t s, const int *rowk, const int *colk, const double *d_a, int64_t nnz, int rows,
-                     int cols, bool f32, int bad_code, int bad_code_other, unsigned long long *bufA,
-                     unsigned long long *bufB, unsigned *hist, int *d_flags, Csr &out)
+                     int cols, bool f32, int bad_code, int bad_code_other, DevScratch &sbufA, DevScratch &sbufB,
+                     unsigned *hist, int *d_flags, Csr &out)
 {
     if (rows <= 0 || cols <= 0) return LSQRHIP_OK;
+    unsigned long long *bufA = sbufA.as<unsigned long long>(), *bufB = sbufB.as<unsigned long long>();
+    // (the two sort buffers are the caller's, 8 bytes per nonzero each, and are handed back allocated; while the
+    //  layout's own arrays are filled they are released -- see below)
+    struct Restore {
+        DevScratch &a, &b;
+        size_t bytes;
+        ~Restore()
+        {
+            if (!a.p) (void)a.alloc(bytes);
+            if (!b.p) (void)b.alloc(bytes);
+        }
+    } restore{sbufA, sbufB, sizeof(unsigned long long) * (size_t)std::max<int64_t>(nnz, 1)};
     const int g = (int)std::min<int64_t>(std::max<int64_t>((nnz + 255) / 256, 1), 4096);
     HIPCHK(hipMemsetAsync(d_flags, 0, 4 * sizeof(int), s));
     int got[4] = {0, 0, 0, 0};
@@ -1033,17 +1057,35 @@ static int build_csb(hipStream_t s, const int *rowk, const int *colk, const doub
     for (int b = 0; b < nrb; ++b) cptr[b + 1] = cptr[b] + (rbs[b + 1] - rbs[b] + CSB_CHUNK - 1) / CSB_CHUNK;
     const long long nchunks = cptr[nrb];
     if (nchunks >= (1ll << 31)) return LSQRHIP_OK;
+    // The sorts are done: what the fill needs of them is, per element of the layout, the COO position it comes from --
+    // 4 bytes, composed here from the block-order words (8) and the column-order positions (4).  The sort buffers and
+    // the positions are released before the layout's 12 bytes per nonzero are allocated: the build peaks at the
+    // triplets + 8 + 8 + 4 + 4 bytes per nonzero while it sorts and at the triplets + 4 + 12 while it fills, not at
+    // their sum (the literal config 3, 4e9 nonzeros: ~210 GB -> ~165 GB at the peak for a 96 GB result).
+    DevScratch s_perm;
+    HIPCHK(s_perm.alloc(sizeof(unsigned) * (size_t)std::max<int64_t>(nnz, 1)));
+    probe_mem();
+    if (nnz > 0)
+        hipLaunchKernelGGL(k_csb_compose, dim3(g), dim3(256), 0, s, (const unsigned long long *)sorted2,
+                           (const unsigned *)s_pos.as<unsigned>(), nnz, s_perm.as<unsigned>());
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(s));
+    s_pos.free_now();
+    sbufA.free_now();
+    sbufB.free_now();
+    bufA = bufB = sorted2 = nullptr;
     DevScratch s_val, s_idx, s_cb, s_cptr;
     const size_t ne = (size_t)std::max<long long>(nchunks, 1) * CSB_CHUNK;
     HIPCHK(s_val.alloc(sizeof(double) * ne));
     HIPCHK(s_idx.alloc(sizeof(unsigned) * ne));
     HIPCHK(s_cb.alloc(sizeof(int) * (size_t)std::max<long long>(nchunks, 1)));
     HIPCHK(s_cptr.alloc(sizeof(long long) * cptr.size()));
+    probe_mem();
     HIPCHK(hipMemcpyAsync(s_cptr.p, cptr.data(), sizeof(long long) * cptr.size(), hipMemcpyHostToDevice, s));
     HIPCHK(hipMemsetAsync(d_flags, 0, 4 * sizeof(int), s));
     if (nchunks > 0)
-        hipLaunchKernelGGL(k_csb_fill, dim3((unsigned)nchunks), dim3(CSB_CHUNK), 0, s, (const unsigned long long *)sorted2,
-                           (const unsigned *)s_pos.as<unsigned>(), rowk, colk, d_a, (const long long *)s_rbs.as<long long>(),
+        hipLaunchKernelGGL(k_csb_fill, dim3((unsigned)nchunks), dim3(CSB_CHUNK), 0, s,
+                           (const unsigned *)s_perm.as<unsigned>(), rowk, colk, d_a, (const long long *)s_rbs.as<long long>(),
                            (const long long *)s_cptr.as<long long>(), (const int *)s_rst.as<int>(), nrb, rmax,
                            (const short *)s_rexp.as<short>(), f32 ? 1 : 0, s_val.as<double>(), s_idx.as<unsigned>(),
                            s_cb.as<int>(), d_flags);
@@ -1284,6 +1326,9 @@ static int finish_create(H *h, const int *d_irow, const int *d_icol, const doubl
 {
     hipStream_t s = h->stream;
     const int64_t nnz = h->nnz;
+    size_t free0 = 0, tot0 = 0;
+    (void)hipMemGetInfo(&free0, &tot0);
+    t_min_free = free0;
     DevScratch sA, sB, sH, sF;  // sort buffers, histogram (+ scan block sums), flags
     const int64_t nb = std::max<int64_t>((nnz + RS_TILE - 1) / RS_TILE, 1);
     HIPCHK(sA.alloc(sizeof(unsigned long long) * (size_t)std::max<int64_t>(nnz, 1)));
@@ -1342,8 +1387,11 @@ static int finish_create(H *h, const int *d_irow, const int *d_icol, const doubl
                        (h->f32 && pa > 1);
     const bool csb_t = cmode == 1 || (cmode == 2 && pt > 1 && xt == 0) || (cmode < 0 && csb_rule(h->m, nnz, dev_t)) ||
                        (h->f32 && pt > 1);
-    if (csb_a) RET(build_csb(s, d_irow, d_icol, d_a, nnz, h->m, h->n, h->f32, LSQRHIP_ERR_IROW, LSQRHIP_ERR_ICOL, bufA, bufB, hist, d_flags, h->A));
-    if (csb_t) RET(build_csb(s, d_icol, d_irow, d_a, nnz, h->n, h->m, h->f32, LSQRHIP_ERR_ICOL, LSQRHIP_ERR_IROW, bufA, bufB, hist, d_flags, h->AT));
+    if (csb_a) RET(build_csb(s, d_irow, d_icol, d_a, nnz, h->m, h->n, h->f32, LSQRHIP_ERR_IROW, LSQRHIP_ERR_ICOL, sA, sB, hist, d_flags, h->A));
+    if (csb_t) RET(build_csb(s, d_icol, d_irow, d_a, nnz, h->n, h->m, h->f32, LSQRHIP_ERR_ICOL, LSQRHIP_ERR_IROW, sA, sB, hist, d_flags, h->AT));
+    if (!sA.p || !sB.p) return fail(LSQRHIP_ERR_ALLOC, lsqrhip_error_string(LSQRHIP_ERR_ALLOC));
+    bufA = sA.as<unsigned long long>();   // (build_csb releases the sort buffers while it fills and hands them back)
+    bufB = sB.as<unsigned long long>();
     if (h->f32) {  // ... and row windows over the whole x where a block was too empty for them
         if (!h->A.csb) { pa = 1; pwa = h->n; xa = 0; }
         if (!h->AT.csb) { pt = 1; pwt = h->m; xt = 0; }
@@ -1361,6 +1409,7 @@ static int finish_create(H *h, const int *d_irow, const int *d_icol, const doubl
             rc = build_csr_T<int>(s, d_icol, d_irow, d_a, nnz, h->n, h->m, LSQRHIP_ERR_ICOL, LSQRHIP_ERR_IROW, pt, pwt, xt, bufA, bufB, hist, d_flags, h->dict, h->ndict, h->AT);
     }
     dbg_stage(s, "both matrices built");
+    probe_mem();
     RET(rc);
     if (h->f32) {
         RET(values_to_f32(h, h->A));
@@ -1375,7 +1424,16 @@ static int finish_create(H *h, const int *d_irow, const int *d_icol, const doubl
         const int mode = env_int("LSQRHIP_STREAM_NT", -1);
         h->A.nt = h->AT.nt = mode < 0 ? wset > (512ll << 20) : mode != 0;
     }
-    return alloc_workspace(h);
+    sA.free_now();
+    sB.free_now();
+    sH.free_now();
+    RET(alloc_workspace(h));
+    probe_mem();
+    size_t free1 = 0;
+    (void)hipMemGetInfo(&free1, &tot0);
+    h->build_peak = (int64_t)free0 - (int64_t)t_min_free;
+    h->build_kept = (int64_t)free0 - (int64_t)free1;
+    return LSQRHIP_OK;
 }
 
 static int new_handle(int m, int n, int64_t nnz, H **out)
@@ -1930,6 +1988,8 @@ extern "C" int lsqrhip_get_option(lsqrhip_handle_t h, const char *name, int64_t 
     else if (k == "op_batch") *value = h->op_batch;
     else if (k == "pipeline") *value = h->pipeline;
     else if (k == "norm_exp") *value = h->norm_exp;
+    else if (k == "build_peak_bytes") *value = h->build_peak;   // peak device memory of the create beyond the caller's triplets
+    else if (k == "build_kept_bytes") *value = h->build_kept;   // ... and what the handle holds now (layouts + work vectors)
     else if (k == "log_truncated") *value = log_owner(h)->h_state ? log_owner(h)->h_state->log_truncated : 0;  // of the last solve
     else if (k == "launches_mode1" || k == "launches_mode2" || k == "dispatches_mode1" || k == "dispatches_mode2") {
         // launches_*: launches of the product's main kernel (+ its combine kernel) -- what rocprofv3's per-kernel

@@ -194,3 +194,54 @@ def test_scale_properties_of_the_panelled_baseline_configurations(spec, expect):
     assert out[0][:2] == (5, 12)
     for o in out[1:]:
         assert o[:5] == out[0][:5] and np.array_equal(o[5], out[0][5])
+
+
+def test_scale_properties_of_one_rank_of_config4_at_1000_per_row():
+    """SURVEY 8d asks config 4 at r = 100 AND r = 1000 nonzeros per row.  At 1000 the whole matrix (1e10 nonzeros)
+    only exists sharded: this is ONE rank's block of it at N = 8 -- rows [0, 1.25M) of the 10M x 10M system,
+    1.25e9 nonzeros, 15 GB each for A_p and A_p' -- the largest matrix a rank of the scaling run can meet and the
+    closest a real run comes to the 2^32 nonzeros a handle can index.  Generated in HBM; size-independent checks as
+    for the other full-size shapes: acheck's adjoint identity, linearity, bit-level determinism of both products, a
+    short solve that repeats itself exactly across the launch schedules and passes the reference's xcheck."""
+    import torch
+    from lsqr_amd.capi import DeviceBuffer
+    free, _ = torch.cuda.mem_get_info()
+    if free < 120e9:
+        pytest.skip("needs ~90 GB of free HBM while it builds")
+    dp = devgen.generate("random:10000000:10000000:1000", 0, 1250000, itnlim=8)
+    s = dp.solver
+    info = s.info()
+    assert dp.nnz == 1_250_000_000 and dp.nrows == 1_250_000 and dp.n == 10_000_000
+    assert info["xlds"] == 3 and info["xlds_t"] == 3
+    peak, kept = s.get_option("build_peak_bytes"), s.get_option("build_kept_bytes")
+    print(f"build peak {peak / 1e9:.1f} GB beyond the 20 GB of triplets, kept {kept / 1e9:.1f} GB")
+    assert kept < 33e9 and peak < 80e9
+    inform, err = s.acheck()
+    assert inform == 0 and err < 1e-12
+    xa = P.u64_to_unit(P.rng_u64(1, 9, np.arange(dp.n, dtype=np.uint64)))
+    yb = P.u64_to_unit(P.rng_u64(2, 9, np.arange(dp.nrows, dtype=np.uint64)))
+    y1, y2, y3 = np.zeros(dp.nrows), np.zeros(dp.nrows), np.zeros(dp.nrows)
+    s.aprod(1, dp.nrows, dp.n, xa, y1)
+    s.aprod(1, dp.nrows, dp.n, xa, y2)
+    s.aprod(1, dp.nrows, dp.n, 3.0 * xa, y3)
+    assert np.array_equal(y1, y2)
+    assert np.max(np.abs(y3 - 3.0 * y1)) <= 1e-13 * np.max(np.abs(y3))
+    x1, x2 = np.zeros(dp.n), np.zeros(dp.n)
+    s.aprod(2, dp.nrows, dp.n, x1, yb)
+    s.aprod(2, dp.nrows, dp.n, x2, yb)
+    assert np.array_equal(x1, x2)
+    d_x = DeviceBuffer(8 * dp.n)
+    out = []
+    for pipeline in (2, 1, 0):
+        s.set_option("pipeline", pipeline)
+        r = s.solve_device(dp.d_b.ptr.value, d_x.ptr.value, 1e-3)
+        out.append((r.istop, r.itn, r.anorm, r.rnorm, r.xnorm, d_x.to_array(np.float64, dp.n)))
+    assert out[0][:2] == (5, 8)
+    for o in out[1:]:
+        assert o[:5] == out[0][:5] and np.array_equal(o[5], out[0][5])
+    # 8 iterations do not converge; the reference's xcheck recomputes the residual u = b - A x from scratch (one more
+    # mode-1 product of the 1.25e9 nonzeros): it must agree with the rnorm the recurrences carried along
+    b = dp.d_b.to_array(np.float64, dp.nrows)
+    inform, tests, u, v, w = s.xcheck(out[0][2], 1e-3, b, out[0][5])
+    rn = np.sqrt(np.linalg.norm(u) ** 2 + (1e-3 * np.linalg.norm(out[0][5])) ** 2)
+    assert np.isfinite(tests).all() and abs(rn - out[0][3]) <= 1e-8 * out[0][3]
