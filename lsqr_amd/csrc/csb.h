@@ -119,6 +119,11 @@ struct CsbMat {
     int *bad;       // S > 1: [nrb][CSB_QMAX] bit 0: a split of the block left a product out (beyond the bound / not
                     //        finite); bit 1: a split of the block added to zc -- one copy per workgroup of k_csb_combine
     int Q;          // S > 1: workgroups of k_csb_combine per row block (each takes a Q-th of its rows)
+    // Column stripes / phases (shard_engine.h "overlap"; all off: NS = 1, border = null, sp0 = 0, sp1 = S):
+    const long long *gptr;  // NS > 1: [nrb * NS + 1] first chunk of every (block, stripe) group -- chunks never straddle a stripe
+    int NS, G, J, Pst;      // stripes = Pst slices x G parts; split sp = k * J + j sweeps the stripes q * G + k, q = j, j + J, ...
+    const int *border;      // the launch order of the row blocks (position -> block), or null: natural order
+    int sp0, sp1;           // the column splits of THIS launch: [sp0, sp1)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -215,21 +220,36 @@ __global__ __launch_bounds__(256) void k_csb_maxint(const int *__restrict__ a, i
     if ((threadIdx.x & (WAVE - 1)) == 0 && m > 0) atomicMax(out, m);
 }
 
-// packed[i] = block(row of the i-th nonzero in column order) << 32 | i;  block b = rows [rstart[b], rstart[b+1])
-__global__ __launch_bounds__(256) void k_csb_pack_rb(const int *__restrict__ rowk, const unsigned *__restrict__ pos1,
+// packed[i] = group(i-th nonzero in column order) << 32 | i;  group = block * NS + stripe: block b = rows
+// [rstart[b], rstart[b+1]), stripe s = columns [scut[s], scut[s+1]) (NS = 1: no stripes, the group is the block)
+__global__ __launch_bounds__(256) void k_csb_pack_rb(const int *__restrict__ rowk, const int *__restrict__ colk,
+                                                     const unsigned *__restrict__ pos1,
                                                      int64_t nnz, const int *__restrict__ rstart, int nrb,
+                                                     const int *__restrict__ scut, int NS,
                                                      unsigned long long *__restrict__ packed)
 {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nnz; i += stride) {
-        const int r = rowk[pos1[i]] - 1;
+        const unsigned p = pos1[i];
+        const int r = rowk[p] - 1;
         int lo = 0, hi = nrb - 1;  // last b with rstart[b] <= r
         while (lo < hi) {
             const int mid = (lo + hi + 1) >> 1;
             if (rstart[mid] <= r) lo = mid;
             else hi = mid - 1;
         }
-        packed[i] = ((unsigned long long)(unsigned)lo << 32) | (unsigned long long)(unsigned)i;
+        unsigned g = (unsigned)lo;
+        if (NS > 1) {
+            const int c = colk[p] - 1;
+            int sl = 0, sh = NS - 1;  // last s with scut[s] <= c
+            while (sl < sh) {
+                const int mid = (sl + sh + 1) >> 1;
+                if (scut[mid] <= c) sl = mid;
+                else sh = mid - 1;
+            }
+            g = (unsigned)lo * (unsigned)NS + (unsigned)sl;
+        }
+        packed[i] = ((unsigned long long)g << 32) | (unsigned long long)(unsigned)i;
     }
 }
 
@@ -253,15 +273,15 @@ __global__ __launch_bounds__(CSB_CHUNK) void k_csb_fill(const unsigned *__restri
                                                         const double *__restrict__ a,
                                                         const long long *__restrict__ rbstart,
                                                         const long long *__restrict__ cptr,
-                                                        const int *__restrict__ rstart, int nrb, int R,
+                                                        const int *__restrict__ rstart, int nrb, int NS, int R,
                                                         const short *__restrict__ rexp, int f32,
                                                         double *__restrict__ val, unsigned *__restrict__ idx,
                                                         int *__restrict__ cbase, int *__restrict__ flags)
 {
     __shared__ int s_b, s_cb;
     const long long c = blockIdx.x;
-    if (threadIdx.x == 0) {
-        int lo = 0, hi = nrb - 1;  // last b with cptr[b] <= c
+    if (threadIdx.x == 0) {   // (cptr, rbstart: per GROUP = block * NS + stripe; an empty group has no chunk)
+        int lo = 0, hi = nrb * NS - 1;  // last g with cptr[g] <= c
         while (lo < hi) {
             const int mid = (lo + hi + 1) >> 1;
             if (cptr[mid] <= c) lo = mid;
@@ -270,9 +290,9 @@ __global__ __launch_bounds__(CSB_CHUNK) void k_csb_fill(const unsigned *__restri
         s_b = lo;
     }
     __syncthreads();
-    const int b = s_b;
-    const long long e = (c - cptr[b]) * CSB_CHUNK + threadIdx.x;  // rank inside the block
-    const long long j0 = rbstart[b], j1 = rbstart[b + 1];
+    const int gidx = s_b, b = gidx / NS;
+    const long long e = (c - cptr[gidx]) * CSB_CHUNK + threadIdx.x;  // rank inside the group
+    const long long j0 = rbstart[gidx], j1 = rbstart[gidx + 1];
     const bool real = j0 + e < j1;
     int col = 0, lrow = R;  // padding: the dummy accumulator
     double v = 0.0;
@@ -646,18 +666,37 @@ __global__ __launch_bounds__(CSB_BLOCK, 1) void k_spmv_csb(
     // z and k_csb_combine adds them -- exact, so the result is bit for bit what ONE workgroup would have
     // produced.  A block of R rows then still holds R d / n nonzeros per column although 256 / S blocks
     // cover the matrix: R can stay large (one rank's block of config 4 at N = 8).
-    const int nunits = (A.b1 - A.b0) * A.S;
+    // the units of this launch: row blocks at positions [b0, b1) of the launch order x column splits [sp0, sp1)
+    const int nsp = A.sp1 - A.sp0;
+    const int nunits = (A.b1 - A.b0) * nsp;
     for (int u = wg; u < nunits; u += nwg) {
-        const int b = A.b0 + u / A.S, sp = u % A.S;
-        const long long cb0 = A.cptr[b], cb1 = A.cptr[b + 1];
-        const long long c0 = cb0 + ((cb1 - cb0) * sp) / A.S, c1 = cb0 + ((cb1 - cb0) * (sp + 1)) / A.S;
+        const int pos = A.b0 + u / nsp, sp = A.sp0 + u % nsp;
+        const int b = A.border != nullptr ? A.border[pos] : pos;
         const int row0 = A.rstart[b];
         const int nr = A.rstart[b + 1] - row0;
+        // the chunk ranges of the unit: one -- an S-th of the block's chunks -- or, with column stripes, those of
+        // the stripes q * G + k for q = j, j + J, ... (split sp = k * J + j: part k of the slices j, j + J, ...)
+        const int kpart = A.NS > 1 ? sp / A.J : 0, jsub = A.NS > 1 ? sp % A.J : 0;
+        const int nranges = A.NS > 1 ? (A.Pst - jsub + A.J - 1) / A.J : 1;
+        auto range = [&](int i, long long &c0, long long &c1) {
+            if (A.NS > 1) {
+                const long long gi = (long long)b * A.NS + (long long)(jsub + i * A.J) * A.G + kpart;
+                c0 = A.gptr[gi];
+                c1 = A.gptr[gi + 1];
+            } else {
+                const long long cb0 = A.cptr[b], cb1 = A.cptr[b + 1];
+                c0 = cb0 + ((cb1 - cb0) * sp) / A.S;
+                c1 = cb0 + ((cb1 - cb0) * (sp + 1)) / A.S;
+            }
+        };
+        bool outlier = false, tookbig = false;
+      for (int ri = 0; ri < nranges; ++ri) {
+        long long c0, c1;
+        range(ri, c0, c1);
         // software pipeline: the (value, index) stream of the wave's NEXT chunk is in flight while the
         // gathers and the LDS adds of this one run (two register sets, loads unconditional: clamped)
         double av[CSB_U], bv[CSB_U];
         CsbRaw<NARROW> iv, jv;
-        bool outlier = false, tookbig = false;
         const long long clast = c1 > c0 ? c1 - 1 : c0;
         auto issue = [&](long long c, double (&a)[CSB_U], CsbRaw<NARROW> &q) {
             const long long cc = c < clast ? c : clast;
@@ -720,6 +759,7 @@ __global__ __launch_bounds__(CSB_BLOCK, 1) void k_spmv_csb(
                 }
             }
         }
+      }   // (ranges of the unit)
         if (outlier) s_bad = 1;
         if (tookbig) {
             s_big = 1;
@@ -761,7 +801,11 @@ __global__ __launch_bounds__(CSB_BLOCK, 1) void k_spmv_csb(
         }
         if (bad) {  // uniform
             __syncthreads();
-            csb_add_outliers<VT, NARROW>(A, aval, c0, c1, x, sx, tau, pmax2, reinterpret_cast<double *>(acc), y, row0, nr);
+            for (int ri = 0; ri < nranges; ++ri) {
+                long long c0, c1;
+                range(ri, c0, c1);
+                csb_add_outliers<VT, NARROW>(A, aval, c0, c1, x, sx, tau, pmax2, reinterpret_cast<double *>(acc), y, row0, nr);
+            }
             sq = csb_sumsq_rows<VT>(y, row0, nr, nsc);
         }
         sq = wave_sum(sq);

@@ -106,6 +106,7 @@ extern "C" int lsqrhip_set_device(int device)
 
 // The device of the handles THIS thread creates next, when >= 0 (lsqrhip_create_sharded places its row blocks
 // with it); otherwise the process-wide selection of lsqrhip_set_device.
+static thread_local int t_shard_world = 0;   // lsqrhip_create_sharded: the world its row blocks are being created for
 static thread_local int t_device_override = -1;
 static int target_device() { return t_device_override >= 0 ? t_device_override : g_device.load(); }
 
@@ -175,6 +176,12 @@ struct Csr {
     unsigned *cdel = nullptr;     // narrow form: [nchunks * 64] four u8 column deltas per lane
     int *ccb = nullptr;           // [nchunks] first column of each chunk; narrow form: [nchunks * 4] of each segment
     bool cnarrow = false;         // 11 bytes per nonzero (csb.h "NARROW form")
+    // overlap plan of the sharded engine (csb.h "Column stripes / phases"); all off: NS = 1, border = null
+    long long *gptr = nullptr;    // [nrb * NS + 1] first chunk of every (block, stripe) group
+    int *border = nullptr;        // [nrb] launch order of the row blocks (phase-major), or null
+    int NS = 1, G = 1, J = 1, Pst = 1;
+    int phases = 1;               // launches of a product fall into this many phases (shard_engine.h waits between them)
+    std::vector<int> phase_pos;   // border form: [phases + 1] positions of the launch order where the phases begin
     long long *cptr = nullptr;    // [nrb + 1] first chunk of each row block
     int *crs = nullptr;           // [nrb + 1] first row of each row block
     int64_t nchunks = 0;
@@ -197,6 +204,9 @@ struct ShardCtx {
     double *wsq = nullptr;        // [1] this rank's sum of w_q^2 (owned)
     int *live = nullptr;          // [1] "this iteration runs" (owned)
     int wantse = 0;
+    bool own_in_T = false;        // the rank's own slice of T is read in place by k_rs_combine (never copied to R)
+    bool vmax_msg = false;        // the caller's `sums` is a SHARD_MSG-double message that carries this rank's piece maxima of |v_q|
+                                  // (shard_engine.h, which hands the gathered maxima to mode 1 in xmax_part)
     int want_log = 0;             // option "shard_log": this rank keeps the iteration log of the next sharded solves
                                   // (rank 0's business: the scalars are replicated and x(1) lies on its slice)
     bool active = false;
@@ -364,6 +374,8 @@ static void free_csr(Csr &c)
     if (c.cval) (void)hipFree(c.cval);
     if (c.cidx) (void)hipFree(c.cidx);
     if (c.cdel) (void)hipFree(c.cdel);
+    if (c.gptr) (void)hipFree(c.gptr);
+    if (c.border) (void)hipFree(c.border);
     if (c.ccb) (void)hipFree(c.ccb);
     if (c.cptr) (void)hipFree(c.cptr);
     if (c.crs) (void)hipFree(c.crs);
@@ -892,6 +904,22 @@ static unsigned long long *radix_sort_words(hipStream_t s, unsigned long long *i
     return in;
 }
 
+// The parts an n-vector is exchanged in by the sharded engine with LSQRHIP_SHARD_OVERLAP=1: slice q of P (columns
+// [q c, (q + 1) c), c = ceil(n / P)) in G parts of cg = ceil(c / G) columns.  Part (q, k) = [lo, hi), clipped to n.
+static void shard_part(int64_t n, int P, int G, int q, int k, int64_t *lo, int64_t *hi)
+{
+    const int64_t c = (n + P - 1) / P, cg = (c + G - 1) / G;
+    *lo = std::min<int64_t>(n, (int64_t)q * c + std::min<int64_t>((int64_t)k * cg, c));
+    *hi = std::min<int64_t>(n, (int64_t)q * c + std::min<int64_t>((int64_t)(k + 1) * cg, c));
+}
+// What the overlap asks of a layout: `stripes` -- the chunks of every row block are formed per part of the gathered
+// vector (mode 1: v arrives part by part) --, `segments` -- the row blocks are cut per part of the OUTPUT vector and
+// launched part-major (mode 2: T leaves part by part).  P = 0: neither.
+struct CsbPlan {
+    int P = 0, G = 2;
+    bool stripes = false, segments = false;
+};
+
 // Column-swept row blocks (csb.h) of the product whose rows are `rowk` and whose gathered vector is
 // indexed by `colk`.  On success out.csb = 1; when a chunk would span 2^18 columns or more (an almost
 // empty row block) `out` is left untouched and the caller builds the panel layout instead.
@@ -899,7 +927,7 @@ static unsigned long long *radix_sort_words(hipStream_t s, unsigned long long *i
 //                  blocks divide evenly among the 256 workgroups)
 static int build_csb(hipStream_t s, const int *rowk, const int *colk, const double *d_a, int64_t nnz, int rows,
                      int cols, bool f32, int bad_code, int bad_code_other, DevScratch &sbufA, DevScratch &sbufB,
-                     unsigned *hist, int *d_flags, Csr &out)
+                     unsigned *hist, int *d_flags, Csr &out, const CsbPlan &plan = CsbPlan())
 {
     if (rows <= 0 || cols <= 0) return LSQRHIP_OK;
     unsigned long long *bufA = sbufA.as<unsigned long long>(), *bufB = sbufB.as<unsigned long long>();
@@ -1026,7 +1054,51 @@ static int build_csb(hipStream_t s, const int *rowk, const int *colk, const doub
         // one-round matrices (config 5: 0.39 -> 0.48 / 0.50 ms with 2 / 4 splits).
         if (S == 1 && (int64_t)rows > (int64_t)CSB_GRID * rmax && (int64_t)cols * 8 > (32ll << 20)) S = 4;
     }
-    if (r_forced > 0 || nnz <= 0) {
+    std::vector<int> border, phase_pos;   // segments: launch order of the blocks, where its phases begin
+    const bool segments = plan.segments && plan.P > 1 && plan.G > 1 && nnz > 0 && r_forced <= 0 && S == 1;
+    if (segments) {
+        // Row blocks cut per part (q, k) of the rows, by nonzeros inside each part, and launched part-major: all
+        // parts k = 0 first -- one round (or a few) of 256 blocks after which T's first parts are complete -- then
+        // k = 1, ...  Blocks per part: an equal share of the rounds a phase gets.
+        const int P = plan.P, G = plan.G;
+        const int kmin = (int)std::max<int64_t>(1, ((int64_t)rows + (int64_t)CSB_GRID * rmax - 1) / ((int64_t)CSB_GRID * rmax));
+        const int rpp = std::max(1, (kmin + G - 1) / G);                   // rounds per phase
+        const int nbs = std::max(1, CSB_GRID * rpp / P);                   // blocks per part
+        std::vector<std::vector<int>> first((size_t)P * G);                // first rows of the blocks of every part
+        rstart.clear();
+        std::vector<int> part_first_block((size_t)P * G + 1, 0);
+        for (int q = 0; q < P; ++q)
+            for (int k = 0; k < G; ++k) {
+                int64_t lo, hi;
+                shard_part(rows, P, G, q, k, &lo, &hi);
+                part_first_block[(size_t)q * G + k] = (int)rstart.size();
+                if (hi <= lo) continue;
+                double tot = 0.0;
+                for (int64_t r = lo; r < hi; ++r) tot += cnt[(size_t)r];
+                const int nb = (int)std::max<int64_t>(1, std::min<int64_t>(nbs, (hi - lo + 511) / 512));
+                const double target = tot / nb;
+                double acc = 0.0;
+                int inblk = 0, made = 1;
+                rstart.push_back((int)lo);
+                for (int64_t r = lo; r < hi; ++r) {
+                    acc += cnt[(size_t)r];
+                    ++inblk;
+                    if ((inblk >= rmax || acc >= target * made) && r + 1 < hi) {
+                        rstart.push_back((int)(r + 1));
+                        inblk = 0;
+                        ++made;
+                    }
+                }
+            }
+        part_first_block[(size_t)P * G] = (int)rstart.size();
+        rstart.push_back(rows);
+        for (int k = 0; k < G; ++k) {
+            phase_pos.push_back((int)border.size());
+            for (int q = 0; q < P; ++q)
+                for (int b = part_first_block[(size_t)q * G + k]; b < part_first_block[(size_t)q * G + k + 1]; ++b) border.push_back(b);
+        }
+        phase_pos.push_back((int)border.size());
+    } else if (r_forced > 0 || nnz <= 0) {
         const int R = std::min(std::max(r_forced > 0 ? r_forced : rmax, 1), rmax);
         rstart = cut(0, R, true);
     } else {
@@ -1035,26 +1107,53 @@ static int build_csb(hipStream_t s, const int *rowk, const int *colk, const doub
     cnt.clear();
     cnt.shrink_to_fit();
     const int nrb = (int)rstart.size() - 1;
+    // Column stripes (mode 1 of a rank of the overlapping engine): the chunks of a block are formed per part (q, k) of
+    // the gathered vector; split sp = k * J + j of a block sweeps part k of the slices j, j + J, ...  J sub-splits so
+    // that one phase (all blocks x J splits) fills the chip.
+    int NS = 1, G = 1, J = 1;
+    std::vector<int> scut;
+    if (plan.stripes && plan.P > 1 && plan.G > 1 && nnz > 0 && env_int("LSQRHIP_CSB_S", 0) <= 0) {
+        G = plan.G;
+        J = std::max(1, std::min(S, 8 / G));   // (S so far: the splits that keep one round of blocks tall)
+        while (J > 1 && plan.P % J != 0) --J;  // every sub-split the same number of slices
+        S = G * J;
+        NS = plan.P * G;
+        for (int q = 0; q < plan.P; ++q)
+            for (int k = 0; k < G; ++k) {
+                int64_t lo, hi;
+                shard_part(cols, plan.P, G, q, k, &lo, &hi);
+                scut.push_back((int)lo);
+            }
+        scut.push_back(cols);
+    }
     if (nrb > SPMV_MAX_GRID) return LSQRHIP_OK;  // one partial of sum(y^2) per block
     DevScratch s_rst;
     HIPCHK(s_rst.alloc(sizeof(int) * rstart.size()));
     HIPCHK(hipMemcpyAsync(s_rst.p, rstart.data(), sizeof(int) * rstart.size(), hipMemcpyHostToDevice, s));
-    HIPCHK(s_rbs.alloc(sizeof(long long) * ((size_t)nrb + 1)));
+    if ((int64_t)nrb * NS >= (1ll << 30)) return LSQRHIP_OK;
+    const int ngrp = nrb * NS;   // groups = (block, stripe): the units chunks are formed in
+    HIPCHK(s_rbs.alloc(sizeof(long long) * ((size_t)ngrp + 1)));
+    DevScratch s_scut;
+    if (NS > 1) {
+        HIPCHK(s_scut.alloc(sizeof(int) * scut.size()));
+        HIPCHK(hipMemcpyAsync(s_scut.p, scut.data(), sizeof(int) * scut.size(), hipMemcpyHostToDevice, s));
+    }
     unsigned long long *sorted2 = bufA;
     if (nnz > 0) {
-        hipLaunchKernelGGL(k_csb_pack_rb, dim3(g), dim3(256), 0, s, rowk, (const unsigned *)s_pos.as<unsigned>(), nnz,
-                           (const int *)s_rst.as<int>(), nrb, bufA);
+        hipLaunchKernelGGL(k_csb_pack_rb, dim3(g), dim3(256), 0, s, rowk, colk, (const unsigned *)s_pos.as<unsigned>(), nnz,
+                           (const int *)s_rst.as<int>(), nrb, (const int *)s_scut.as<int>(), NS, bufA);
         HIPCHK(hipGetLastError());
-        sorted2 = nrb > 1 ? radix_sort_words(s, bufA, bufB, nnz, bits_for(nrb), hist) : bufA;
+        sorted2 = ngrp > 1 ? radix_sort_words(s, bufA, bufB, nnz, bits_for(ngrp), hist) : bufA;
     }
     hipLaunchKernelGGL(k_rowptr_from_sorted<long long>, dim3(g), dim3(256), 0, s, (const unsigned long long *)sorted2, nnz,
-                       nrb, s_rbs.as<long long>());
+                       ngrp, s_rbs.as<long long>());
     HIPCHK(hipGetLastError());
-    std::vector<long long> rbs((size_t)nrb + 1), cptr((size_t)nrb + 1);
+    std::vector<long long> rbs((size_t)ngrp + 1), gptr((size_t)ngrp + 1), cptr((size_t)nrb + 1);
     HIPCHK(hipMemcpyAsync(rbs.data(), s_rbs.p, sizeof(long long) * rbs.size(), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
-    cptr[0] = 0;
-    for (int b = 0; b < nrb; ++b) cptr[b + 1] = cptr[b] + (rbs[b + 1] - rbs[b] + CSB_CHUNK - 1) / CSB_CHUNK;
+    gptr[0] = 0;
+    for (int gi = 0; gi < ngrp; ++gi) gptr[gi + 1] = gptr[gi] + (rbs[gi + 1] - rbs[gi] + CSB_CHUNK - 1) / CSB_CHUNK;
+    for (int b = 0; b <= nrb; ++b) cptr[b] = gptr[(size_t)b * NS];
     const long long nchunks = cptr[nrb];
     if (nchunks >= (1ll << 31)) return LSQRHIP_OK;
     // The sorts are done: what the fill needs of them is, per element of the layout, the COO position it comes from --
@@ -1079,14 +1178,17 @@ static int build_csb(hipStream_t s, const int *rowk, const int *colk, const doub
     HIPCHK(s_val.alloc(sizeof(double) * ne));
     HIPCHK(s_idx.alloc(sizeof(unsigned) * ne));
     HIPCHK(s_cb.alloc(sizeof(int) * (size_t)std::max<long long>(nchunks, 1)));
+    DevScratch s_gptr;
     HIPCHK(s_cptr.alloc(sizeof(long long) * cptr.size()));
+    HIPCHK(s_gptr.alloc(sizeof(long long) * gptr.size()));
     probe_mem();
     HIPCHK(hipMemcpyAsync(s_cptr.p, cptr.data(), sizeof(long long) * cptr.size(), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(s_gptr.p, gptr.data(), sizeof(long long) * gptr.size(), hipMemcpyHostToDevice, s));
     HIPCHK(hipMemsetAsync(d_flags, 0, 4 * sizeof(int), s));
     if (nchunks > 0)
         hipLaunchKernelGGL(k_csb_fill, dim3((unsigned)nchunks), dim3(CSB_CHUNK), 0, s,
                            (const unsigned *)s_perm.as<unsigned>(), rowk, colk, d_a, (const long long *)s_rbs.as<long long>(),
-                           (const long long *)s_cptr.as<long long>(), (const int *)s_rst.as<int>(), nrb, rmax,
+                           (const long long *)s_gptr.as<long long>(), (const int *)s_rst.as<int>(), nrb, NS, rmax,
                            (const short *)s_rexp.as<short>(), f32 ? 1 : 0, s_val.as<double>(), s_idx.as<unsigned>(),
                            s_cb.as<int>(), d_flags);
     HIPCHK(hipGetLastError());
@@ -1145,6 +1247,20 @@ static int build_csb(hipStream_t s, const int *rowk, const int *colk, const doub
     out.nstored = (int64_t)nchunks * CSB_CHUNK;
     out.nrb = nrb;
     out.R = rmax;   // the dummy accumulator's index (blocks hold at most this many rows)
+    out.NS = NS;
+    out.G = G;
+    out.J = J;
+    out.Pst = NS > 1 ? plan.P : 1;
+    if (NS > 1) {
+        out.gptr = s_gptr.release<long long>();
+        out.phases = G;
+    }
+    if (!border.empty()) {
+        HIPCHK(hipMalloc((void **)&out.border, sizeof(int) * border.size()));
+        HIPCHK(hipMemcpy(out.border, border.data(), sizeof(int) * border.size(), hipMemcpyHostToDevice));
+        out.phase_pos = phase_pos;
+        out.phases = (int)phase_pos.size() - 1;
+    }
     out.rexp = s_rexp.release<short>();
     HIPCHK(hipMalloc((void **)&out.zcoarse, sizeof(long long) * (size_t)rows));
     HIPCHK(hipMemsetAsync(out.zcoarse, 0, sizeof(long long) * (size_t)rows, s));
@@ -1165,6 +1281,24 @@ static int build_csb(hipStream_t s, const int *rowk, const int *colk, const doub
     out.bytes = (int64_t)nchunks * CSB_CHUNK * (narrow ? 11 : 12) + (int64_t)nchunks * (narrow ? 16 : 4) +
                 (int64_t)(nrb + 1) * 8 + (int64_t)cols * 8 + (int64_t)rows * 2;
     return LSQRHIP_OK;
+}
+
+// sweep launches of one column-swept product (solve_loop.h launch_csb)
+static int csb_sweep_launches(const Csr &c, bool rounds)
+{
+    const int S = std::max(c.S, 1);
+    if (c.NS > 1) {   // stripes: every phase launches all blocks x its J splits
+        const int step = std::max(1, c.grid / std::max(c.J, 1));
+        return c.phases * std::max(1, (c.nrb + step - 1) / step);
+    }
+    const int step = rounds ? std::max(1, c.grid / S) : std::max(c.nrb, 1);
+    if (c.border != nullptr) {   // segments: the rounds of every phase
+        int nl = 0;
+        for (int ph = 0; ph < c.phases; ++ph)
+            nl += std::max(1, (c.phase_pos[(size_t)ph + 1] - c.phase_pos[(size_t)ph] + step - 1) / step);
+        return nl;
+    }
+    return std::max(1, (c.nrb + step - 1) / step);
 }
 
 // Column panels for a product whose x vector has `cols` entries?  (spmv.h "Column panels")
@@ -1387,8 +1521,22 @@ static int finish_create(H *h, const int *d_irow, const int *d_icol, const doubl
                        (h->f32 && pa > 1);
     const bool csb_t = cmode == 1 || (cmode == 2 && pt > 1 && xt == 0) || (cmode < 0 && csb_rule(h->m, nnz, dev_t)) ||
                        (h->f32 && pt > 1);
-    if (csb_a) RET(build_csb(s, d_irow, d_icol, d_a, nnz, h->m, h->n, h->f32, LSQRHIP_ERR_IROW, LSQRHIP_ERR_ICOL, sA, sB, hist, d_flags, h->A));
-    if (csb_t) RET(build_csb(s, d_icol, d_irow, d_a, nnz, h->n, h->m, h->f32, LSQRHIP_ERR_ICOL, LSQRHIP_ERR_IROW, sA, sB, hist, d_flags, h->AT));
+    // The overlap plan of the sharded engine (LSQRHIP_SHARD_OVERLAP=1; shard_engine.h): this matrix is one rank's row
+    // block of a world of P -- the world lsqrhip_create_sharded is building, or LSQRHIP_SHARD_WORLD for a rank that
+    // creates its own handle (bench.py --gpus N) -- whose n-vectors travel in G parts per slice (LSQRHIP_SHARD_PARTS).
+    CsbPlan plan_a, plan_t;
+    if (env_int("LSQRHIP_SHARD_OVERLAP", 0) != 0) {
+        const int P = t_shard_world > 0 ? t_shard_world : env_int("LSQRHIP_SHARD_WORLD", 0);
+        const int G = std::min(std::max(env_int("LSQRHIP_SHARD_PARTS", 2), 2), 4);
+        if (P > 1 && (int64_t)P * G <= 256) {
+            plan_a.P = plan_t.P = P;
+            plan_a.G = plan_t.G = G;
+            plan_a.stripes = true;    // mode 1 gathers v, which arrives part by part
+            plan_t.segments = true;   // mode 2 produces T, which leaves part by part
+        }
+    }
+    if (csb_a) RET(build_csb(s, d_irow, d_icol, d_a, nnz, h->m, h->n, h->f32, LSQRHIP_ERR_IROW, LSQRHIP_ERR_ICOL, sA, sB, hist, d_flags, h->A, plan_a));
+    if (csb_t) RET(build_csb(s, d_icol, d_irow, d_a, nnz, h->n, h->m, h->f32, LSQRHIP_ERR_ICOL, LSQRHIP_ERR_IROW, sA, sB, hist, d_flags, h->AT, plan_t));
     if (!sA.p || !sB.p) return fail(LSQRHIP_ERR_ALLOC, lsqrhip_error_string(LSQRHIP_ERR_ALLOC));
     bufA = sA.as<unsigned long long>();   // (build_csb releases the sort buffers while it fills and hands them back)
     bufB = sB.as<unsigned long long>();
@@ -1997,14 +2145,14 @@ extern "C" int lsqrhip_get_option(lsqrhip_handle_t h, const char *name, int64_t 
         const Csr &c = (k == "launches_mode1" || k == "dispatches_mode1") ? h->A : h->AT;
         const bool all = k[0] == 'd';
         static const int rounds = env_int("LSQRHIP_CSB_ROUNDS", 1);
-        if (c.csb) {
-            const int step = std::max(1, c.grid / std::max(c.S, 1));
-            *value = (all ? 1 : 0) + (rounds ? std::max(1, (c.nrb + step - 1) / step) : 1) + (c.S > 1 ? 1 : 0);
-        }
+        if (c.csb) *value = (all ? 1 : 0) + csb_sweep_launches(c, rounds != 0) + (c.S > 1 ? 1 : 0);
         else *value = c.P > 1 ? 2 : 1;
     } else if (k == "csb_blocks_mode1" || k == "csb_blocks_mode2") {  // row blocks of a column-swept layout (0: another layout)
         const Csr &c = k == "csb_blocks_mode1" ? h->A : h->AT;
         *value = c.csb ? c.nrb : 0;
+    } else if (k == "csb_phases_mode1" || k == "csb_phases_mode2") {   // launch phases of the overlap plan (1: none)
+        const Csr &c = k == "csb_phases_mode1" ? h->A : h->AT;
+        *value = c.csb ? std::max(c.phases, 1) : 0;
     } else if (k == "csb_splits_mode1" || k == "csb_splits_mode2") {
         const Csr &c = k == "csb_splits_mode1" ? h->A : h->AT;
         *value = c.csb ? c.S : 0;

@@ -28,28 +28,46 @@ namespace lsqrhip {
 
 // Vq_i <- cy (Vq_i sy) + (R[0][i] + R[1][i] + ... + R[P-1][i])   (rank order); partials of sum (Vq ns)^2.
 // R[r] = slice q of rank r's T (what the all-to-all delivered), each `chunk` long; i < len <= chunk.
+// `own` (or null: all P slices lie in R): this rank's own slice, read where mode 2 left it in T -- it never travels.
 template <typename VT>
 __global__ __launch_bounds__(VEC_BLOCK) void k_rs_combine(VT *__restrict__ Vq, const VT *__restrict__ R,
+                                                          const VT *__restrict__ own, int rank,
                                                           int P, int64_t chunk, int64_t len,
                                                           const SpmvCoef *__restrict__ coef,
                                                           const int *__restrict__ stop,
-                                                          double *__restrict__ partials, NScale nsc)
-{
+                                                          double *__restrict__ partials, NScale nsc,
+                                                          double *__restrict__ maxpart)
+{   // maxpart (or null): [gridDim.x] max |Vq_i| of this workgroup's strided share -- the piece maxima csb.h wants of
+    // the vector the next mode-1 product gathers from, taken where the slice is written instead of in a pass of its own
     if (*stop != 0 || coef->skip != 0) return;
     const double sy = coef->sy, cy = coef->cy;
     __shared__ double red[VEC_BLOCK / WAVE];
-    double s = 0.0;
+    double s = 0.0, mx = 0.0;
     const int64_t stride = (int64_t)gridDim.x * VEC_BLOCK;
     for (int64_t i = (int64_t)blockIdx.x * VEC_BLOCK + threadIdx.x; i < len; i += stride) {
-        double t = (double)R[i];
-        for (int r = 1; r < P; ++r) t = t + (double)R[(int64_t)r * chunk + i];
+        double t = (own != nullptr && rank == 0) ? (double)own[i] : (double)R[i];
+        for (int r = 1; r < P; ++r)
+            t = t + ((own != nullptr && r == rank) ? (double)own[i] : (double)R[(int64_t)r * chunk + i]);
         const VT v = (VT)(cy * ((double)Vq[i] * sy) + t);
         Vq[i] = v;
         const double vs = (double)v * nsc.s;
         s += vs * vs;
+        mx = fmax(mx, fabs((double)v));
     }
     const double tot = block_sum<VEC_BLOCK>(s, red);
     if (threadIdx.x == 0) partials[blockIdx.x] = tot;
+    if (maxpart != nullptr) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off, WAVE));
+        __syncthreads();
+        if ((threadIdx.x & (WAVE - 1)) == 0) red[threadIdx.x >> 6] = mx;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double m = red[0];
+            for (int i = 1; i < VEC_BLOCK / WAVE; ++i) m = fmax(m, red[i]);
+            maxpart[blockIdx.x] = m;
+        }
+    }
 }
 
 // out[i] = in[0*chunk + i] + in[1*chunk + i] + ... in rank order (for callers that reduce a whole
@@ -117,9 +135,15 @@ __global__ __launch_bounds__(VEC_BLOCK) void k_init_w_slice(VT *__restrict__ w, 
 }
 
 // sums[0] <- the np partials of sum (V_q ns)^2 in fixed order, sums[1] <- *wsq (this rank's sum of w_q^2)
+// ... and, `maxpart` given (the C++ engine: its message is SHARD_MSG doubles), sums[4 + i] <- the largest of the
+// workgroup maxima i, i + SHARD_NMAX, ... : this rank's SHARD_NMAX piece maxima of |V_q| (k_rs_combine).  A skipped
+// product left V_q as it was: its maxima of the last product stand.
+constexpr int SHARD_MSG = 64;                 // doubles a rank contributes to the exchange of the norms
+constexpr int SHARD_NMAX = SHARD_MSG - 4;     // ... of which piece maxima of its slice of v
 __global__ __launch_bounds__(VEC_BLOCK) void k_shard_sums(const double *__restrict__ partials, int np,
                                                           const double *__restrict__ wsq, double *__restrict__ sums,
-                                                          const SpmvCoef *__restrict__ coef)
+                                                          const SpmvCoef *__restrict__ coef,
+                                                          const double *__restrict__ maxpart)
 {
     __shared__ double red[VEC_BLOCK / WAVE];
     const double s = np > 0 ? strided_sum<VEC_BLOCK>(partials, np) : 0.0;
@@ -127,6 +151,11 @@ __global__ __launch_bounds__(VEC_BLOCK) void k_shard_sums(const double *__restri
     if (threadIdx.x == 0) {
         sums[0] = coef->skip != 0 ? 0.0 : tot;  // a skipped product left no partials (beta == 0, :691)
         sums[1] = *wsq;
+    }
+    if (maxpart != nullptr && coef->skip == 0 && (int)threadIdx.x < SHARD_NMAX) {
+        double m = 0.0;
+        for (int i = threadIdx.x; i < np; i += SHARD_NMAX) m = fmax(m, maxpart[i]);
+        sums[4 + threadIdx.x] = m;
     }
 }
 
@@ -220,7 +249,7 @@ extern "C" int lsqrhip_shard_begin(lsqrhip_handle_t h, const double *d_b_local, 
         HIPCHK(hipMemsetAsync(h->W, 0, esz * sl, s));
         if (wantse) HIPCHK(hipMemsetAsync(h->SE, 0, esz * sl, s));
     }
-    HIPCHK(hipMemsetAsync(d_sums, 0, 4 * sizeof(double), s));
+    HIPCHK(hipMemsetAsync(d_sums, 0, (c.vmax_msg ? SHARD_MSG : 4) * sizeof(double), s));
     HIPCHK(hipMemsetAsync(c.wsq, 0, sizeof(double), s));
     HIPCHK(hipMemsetAsync(c.live, 0, sizeof(int), s));
     c.active = true;
@@ -236,6 +265,8 @@ static void shard_stage_vec(H *h, int stage)
     ShardCtx &c = h->shard;
     VT *Vq = reinterpret_cast<VT *>(c.V) + c.my0;
     const VT *R = reinterpret_cast<const VT *>(c.R);
+    // (the C++ engine leaves the rank's own slice of T where it is: shard_engine.h ex_scatter)
+    const VT *own = c.own_in_T ? reinterpret_cast<const VT *>(c.T) + c.my0 : nullptr;
     VT *X = reinterpret_cast<VT *>(h->X), *W = reinterpret_cast<VT *>(h->W), *SE = reinterpret_cast<VT *>(h->SE);
     const int gq = vec_grid(2 * std::max<int64_t>(c.mylen, 1));
     switch (stage) {
@@ -244,16 +275,18 @@ static void shard_stage_vec(H *h, int stage)
                            (int64_t)h->m, h->partials);
         break;
     case ST_INIT_V:
-        hipLaunchKernelGGL(k_rs_combine<VT>, dim3(gq), dim3(VEC_BLOCK), 0, s, Vq, R, c.P, c.chunk, c.mylen,
-                           (const SpmvCoef *)&st->c2, (const int *)h->d_zero, h->partials, h->nsc);
+        hipLaunchKernelGGL(k_rs_combine<VT>, dim3(gq), dim3(VEC_BLOCK), 0, s, Vq, R, own, c.rank, c.P, c.chunk, c.mylen,
+                           (const SpmvCoef *)&st->c2, (const int *)h->d_zero, h->partials, h->nsc,
+                           c.vmax_msg ? h->partials + SPMV_MAX_GRID : (double *)nullptr);
         break;
     case ST_INIT_W:
         hipLaunchKernelGGL(k_init_w_slice<VT>, dim3(gq), dim3(VEC_BLOCK), 0, s, W, (const VT *)Vq, c.mylen,
                            (const LsqrState *)st, h->partials);
         break;
     case ST_VCOMBINE:
-        hipLaunchKernelGGL(k_rs_combine<VT>, dim3(gq), dim3(VEC_BLOCK), 0, s, Vq, R, c.P, c.chunk, c.mylen,
-                           (const SpmvCoef *)&st->c2, (const int *)&st->stop, h->partials, h->nsc);
+        hipLaunchKernelGGL(k_rs_combine<VT>, dim3(gq), dim3(VEC_BLOCK), 0, s, Vq, R, own, c.rank, c.P, c.chunk, c.mylen,
+                           (const SpmvCoef *)&st->c2, (const int *)&st->stop, h->partials, h->nsc,
+                           c.vmax_msg ? h->partials + SPMV_MAX_GRID : (double *)nullptr);
         break;
     case ST_UPDATE:
         hipLaunchKernelGGL(k_update_slice<VT>, dim3(gq), dim3(VEC_BLOCK), 0, s, X, W, (const VT *)Vq, SE, c.mylen,
@@ -292,7 +325,8 @@ extern "C" int lsqrhip_shard_stage(lsqrhip_handle_t h, int stage)
     case ST_INIT_V:
         vec(stage);
         hipLaunchKernelGGL(k_shard_sums, dim3(1), dim3(VEC_BLOCK), 0, s, (const double *)h->partials, gq,
-                           (const double *)c.wsq, sums, (const SpmvCoef *)&st->c2);
+                           (const double *)c.wsq, sums, (const SpmvCoef *)&st->c2,
+                           c.vmax_msg ? (const double *)(h->partials + SPMV_MAX_GRID) : (const double *)nullptr);
         break;
     case ST_INIT_W:
         hipLaunchKernelGGL((k_s_init2<false>), dim3(1), dim3(SC_BLOCK), 0, s, (const double *)h->partials, 0,
@@ -300,8 +334,17 @@ extern "C" int lsqrhip_shard_stage(lsqrhip_handle_t h, int stage)
         vec(stage);
         hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(VEC_BLOCK), 0, s, (const double *)h->partials, gq, c.wsq);
         break;
-    case ST_MODE1:
-        launch_spmv(h, h->A, c.V, h->U, &st->c1, &st->stop, nullptr, nullptr, true);
+    case ST_MODE1: {
+        // (the C++ engine: the piece maxima of v came with the norms, P * SHARD_NMAX of them in xmax_part)
+        SpmvArgs a;
+        a.c = &h->A; a.x = c.V; a.y = h->U; a.coef = &st->c1; a.stop = &st->stop; a.pout = h->partials; a.stream = s;
+        a.unit_x = true;
+        if (c.vmax_msg) {
+            a.xmax_in = h->xmax_part;
+            a.nxmax_in = c.P * SHARD_NMAX;
+        }
+        launch_spmv_args(h, a);
+    }
         hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(VEC_BLOCK), 0, s, (const double *)h->partials,
                            h->A.out_grid, sums);
         break;
@@ -313,7 +356,8 @@ extern "C" int lsqrhip_shard_stage(lsqrhip_handle_t h, int stage)
     case ST_VCOMBINE:
         vec(stage);
         hipLaunchKernelGGL(k_shard_sums, dim3(1), dim3(VEC_BLOCK), 0, s, (const double *)h->partials, gq,
-                           (const double *)c.wsq, sums, (const SpmvCoef *)&st->c2);
+                           (const double *)c.wsq, sums, (const SpmvCoef *)&st->c2,
+                           c.vmax_msg ? (const double *)(h->partials + SPMV_MAX_GRID) : (const double *)nullptr);
         break;
     case ST_UPDATE:
         hipLaunchKernelGGL(k_shard_s2, dim3(1), dim3(1), 0, s, (const double *)sums, st, c.live);
@@ -399,5 +443,7 @@ extern "C" int lsqrhip_shard_end(lsqrhip_handle_t h, double *d_x, double *d_se, 
     if (arnorm) *arnorm = r.arnorm;
     if (xnorm) *xnorm = r.xnorm;
     c.active = false;
+    c.own_in_T = false;
+    c.vmax_msg = false;   // (the next caller of lsqrhip_shard_begin may bring a 4-double `sums`: lsqr_amd/dist.py)
     return LSQRHIP_OK;
 }

@@ -27,14 +27,20 @@
 
 namespace lsqrhip {
 
-// sums[j] <- gath[0*4 + j] + gath[1*4 + j] + ... (rank order), j < k
-__global__ void k_sum_ranks(const double *__restrict__ gath, int P, int k, double *__restrict__ sums)
+// sums[j] <- gath[0*msg + j] + gath[1*msg + j] + ... (rank order), j < k; and, msg = SHARD_MSG: the ranks' piece
+// maxima of |v| side by side in vmax[P * SHARD_NMAX] (what csb.h's mode-1 product reads instead of a pass over v)
+__global__ void k_sum_ranks(const double *__restrict__ gath, int P, int k, int msg, double *__restrict__ sums,
+                            double *__restrict__ vmax)
 {
     const int j = threadIdx.x;
-    if (j >= k) return;
-    double s = gath[j];
-    for (int r = 1; r < P; ++r) s = s + gath[4 * r + j];
-    sums[j] = s;
+    if (j < k) {
+        double s = gath[j];
+        for (int r = 1; r < P; ++r) s = s + gath[msg * r + j];
+        sums[j] = s;
+    }
+    if (vmax != nullptr && msg == SHARD_MSG)
+        for (int i = threadIdx.x; i < P * SHARD_NMAX; i += blockDim.x)
+            vmax[i] = gath[(i / SHARD_NMAX) * SHARD_MSG + 4 + i % SHARD_NMAX];
 }
 
 __global__ void k_max_int(const int *__restrict__ a, int n, int *__restrict__ out)
@@ -130,6 +136,8 @@ struct ShardGroup {
     bool loopback = false;         // exchanges by device copies inside this process instead of RCCL (all ranks are local)
     std::vector<hipEvent_t> ev;    // loopback: one event per rank
     int poll_every = 16;
+    int msg = 4;                   // doubles a rank contributes to the exchange of the norms: 4, or SHARD_MSG when its piece
+                                   // maxima of |v_q| ride along (every matrix in column-swept row blocks: csb.h)
     // one captured batch of `poll_every` iterations -- stages AND exchanges of every local rank (capture_group_batch)
     hipGraphExec_t gexec = nullptr;
     std::vector<int> gexec_epoch;  // the ranks' graph_epoch at capture
@@ -179,8 +187,8 @@ static int alloc_rank_buffers(ShardGroup &g, ShardRank &k)
     g.esz = k.h->f32 ? sizeof(float) : sizeof(double);
     const size_t full = (size_t)std::max<int64_t>(g.chunk * g.P, 1);
     for (double **pp : {&k.T, &k.R, &k.V, &k.xfull, &k.sefull}) HIPCHK(hipMalloc((void **)pp, g.esz * full));
-    HIPCHK(hipMalloc((void **)&k.sums, sizeof(double) * 4));
-    HIPCHK(hipMalloc((void **)&k.gath, sizeof(double) * 4 * (size_t)g.P));
+    HIPCHK(hipMalloc((void **)&k.sums, sizeof(double) * SHARD_MSG));
+    HIPCHK(hipMalloc((void **)&k.gath, sizeof(double) * SHARD_MSG * (size_t)g.P));
     HIPCHK(hipMalloc((void **)&k.bloc, g.esz * (size_t)std::max(k.h->m, 1)));
     return LSQRHIP_OK;
 }
@@ -228,35 +236,40 @@ static int ex_scalars(ShardGroup &g, int k, bool with_v = false)
 {
     Rccl *rc = rccl();
     const size_t c = (size_t)g.chunk;
+    const size_t msg = (size_t)g.msg;
     const ncclDataType_t vtype = g.esz == sizeof(float) ? ncclFloat : ncclDouble;
+    auto sum_ranks = [&](ShardRank &q, const double *gath) -> int {
+        HIPCHK(hipSetDevice(q.h->device));
+        hipLaunchKernelGGL(k_sum_ranks, dim3(1), dim3(64), 0, q.h->stream, gath, g.P, k, g.msg, q.sums,
+                           g.msg == SHARD_MSG ? q.h->xmax_part : (double *)nullptr);
+        return LSQRHIP_OK;
+    };
     if (g.P > 1 && g.loopback) {
         RET(fence_ranks(g));
         for (ShardRank &q : g.r)
             for (ShardRank &p : g.r) {
-                RET(loop_copy(q, q.gath + 4 * (size_t)p.grank, p.sums, 4 * sizeof(double)));
+                RET(loop_copy(q, q.gath + msg * (size_t)p.grank, p.sums, msg * sizeof(double)));
                 if (with_v && &p != &q)
                     RET(loop_copy(q, at(q.V, (size_t)p.grank * c, g.esz), at(p.V, (size_t)p.grank * c, g.esz), c * g.esz));
             }
         RET(fence_ranks(g));
-        for (ShardRank &q : g.r) {
-            HIPCHK(hipSetDevice(q.h->device));
-            hipLaunchKernelGGL(k_sum_ranks, dim3(1), dim3(4), 0, q.h->stream, (const double *)q.gath, g.P, k, q.sums);
-        }
+        for (ShardRank &q : g.r) RET(sum_ranks(q, q.gath));
         return LSQRHIP_OK;
     }
     if (g.P > 1) {
         NCCLCHK(rc->GroupStart());
         for (ShardRank &q : g.r) {
-            NCCLCHK(rc->AllGather(q.sums, q.gath, 4, ncclDouble, q.comm, q.h->stream));
+            NCCLCHK(rc->AllGather(q.sums, q.gath, msg, ncclDouble, q.comm, q.h->stream));
             if (with_v && c > 0)
                 NCCLCHK(rc->AllGather(at(q.V, (size_t)q.grank * c, g.esz), q.V, c, vtype, q.comm, q.h->stream));
         }
         NCCLCHK(rc->GroupEnd());
-        for (ShardRank &q : g.r) {
-            HIPCHK(hipSetDevice(q.h->device));
-            hipLaunchKernelGGL(k_sum_ranks, dim3(1), dim3(4), 0, q.h->stream, (const double *)q.gath, g.P, k, q.sums);
-        }
+        for (ShardRank &q : g.r) RET(sum_ranks(q, q.gath));
+        return LSQRHIP_OK;
     }
+    // a world of one: nothing to exchange, but the piece maxima still go where mode 1 looks for them
+    if (g.msg == SHARD_MSG && k == 2)
+        for (ShardRank &q : g.r) RET(sum_ranks(q, q.sums));
     return LSQRHIP_OK;
 }
 
@@ -265,23 +278,16 @@ static int ex_scatter(ShardGroup &g)  // slice q of every rank's T -> rank q's R
     Rccl *rc = rccl();
     const size_t c = (size_t)g.chunk, e = g.esz;
     const ncclDataType_t vtype = e == sizeof(float) ? ncclFloat : ncclDouble;
-    if (g.P == 1 || c == 0) {
-        for (ShardRank &q : g.r)
-            if (c) HIPCHK(hipMemcpyAsync(q.R, q.T, e * c, hipMemcpyDeviceToDevice, q.h->stream));
-        return LSQRHIP_OK;
-    }
+    if (g.P == 1 || c == 0) return LSQRHIP_OK;   // (the rank's own slice is read in T where it lies: shard_api.h own_in_T)
     if (g.loopback) {
         RET(fence_ranks(g));
         for (ShardRank &q : g.r)
-            for (ShardRank &p : g.r) RET(loop_copy(q, at(q.R, (size_t)p.grank * c, e), at(p.T, (size_t)q.grank * c, e), c * e));
+            for (ShardRank &p : g.r)
+                if (&p != &q) RET(loop_copy(q, at(q.R, (size_t)p.grank * c, e), at(p.T, (size_t)q.grank * c, e), c * e));
         return fence_ranks(g);
     }
-    // the rank's own slice never leaves the device; the others go to their owners over all links at once
-    for (ShardRank &q : g.r) {
-        HIPCHK(hipSetDevice(q.h->device));
-        HIPCHK(hipMemcpyAsync(at(q.R, (size_t)q.grank * c, e), at(q.T, (size_t)q.grank * c, e), e * c,
-                              hipMemcpyDeviceToDevice, q.h->stream));
-    }
+    // the rank's own slice never leaves the device (nor T: k_rs_combine reads it there); the others go to their
+    // owners over all links at once
     NCCLCHK(rc->GroupStart());
     for (ShardRank &q : g.r)
         for (int peer = 0; peer < g.P; ++peer) {
@@ -395,6 +401,19 @@ static int run_group(ShardGroup &g, double damp, double atol, double btol, doubl
                      int *istop, int *itn, double *anorm, double *acond, double *rnorm, double *arnorm, double *xnorm)
 {
     if (g.P > 1 && !g.loopback && !rccl()) return fail(LSQRHIP_ERR_HIP, "librccl.so.1 could not be loaded");
+    // v's piece maxima ride with the norms when mode 1 of this rank's block wants them (column-swept row blocks) --
+    // a property of the local matrix only, but the message length must be the world's: every rank of a sharded
+    // system built by one rule from one matrix takes the same layout family; LSQRHIP_SHARD_VMAX=0 / 1 forces it
+    {
+        const int force = env_int("LSQRHIP_SHARD_VMAX", -1);
+        bool want = force < 0 ? (int64_t)g.P * SHARD_NMAX <= (int64_t)CSB_XMAX_GRID * (VEC_BLOCK / WAVE) : force != 0;
+        if ((int64_t)g.P * SHARD_NMAX > (int64_t)CSB_XMAX_GRID * (VEC_BLOCK / WAVE)) want = false;
+        g.msg = want ? SHARD_MSG : 4;
+        for (ShardRank &q : g.r) {
+            q.h->shard.vmax_msg = want;
+            q.h->shard.own_in_T = true;
+        }
+    }
     for (ShardRank &q : g.r)
         RET(lsqrhip_shard_begin(q.h, q.bloc, g.m, g.P, q.grank, damp, atol, btol, conlim, itnlim, wantse, q.T, q.R, q.V,
                                 q.sums));
@@ -610,6 +629,7 @@ static int create_sharded_T(int m, int n, int64_t nnz, const int *irow, const in
         q.row0 = cut[(size_t)p];
         // the block's device, for this thread's create only (never through the process-wide selection)
         t_device_override = loopback ? dev0 + p % have : dev0 + p;
+        t_shard_world = ngpu;   // (the overlap plan of the block's layouts, if asked for: lsqrhip.hip finish_create)
         if (blockwise) {
             for (int64_t k = 0; k < np; ++k) lr[(size_t)k] = irow[f + k] - cut[(size_t)p];
             rc = create_block(cut[(size_t)p + 1] - cut[(size_t)p], n, np, lr.get(), icol + f, a + f, &q.h);
@@ -617,6 +637,7 @@ static int create_sharded_T(int m, int n, int64_t nnz, const int *irow, const in
             rc = create_block(cut[(size_t)p + 1] - cut[(size_t)p], n, np, lr.get() + f, lc.get() + f, la.get() + f, &q.h);
         }
         t_device_override = -1;
+        t_shard_world = 0;
     }
     lr.reset();
     lc.reset();

@@ -65,7 +65,10 @@ struct SpmvArgs {
     hipEvent_t e0 = nullptr, e1 = nullptr;  // kernel begin/end timestamps (hipExtLaunchKernelGGL)
     NScale nsc{1.0, 1.0};            // power-of-two scale inside the sums of squares (filled in by launch_spmv_args)
     bool f32 = false;                // x, y, the values and the update's vectors are float arrays (REAL32 handle)
-    bool unit_x = false;             // |x * sx| <= 1 is known (solver-internal vectors): csb.h needs no max|x| pass
+    bool unit_x = false;             // |x * sx| <= 1 is known (solver-internal vectors)
+    const double *xmax_in = nullptr; // csb.h: piece maxima of |x| the caller already holds (the sharded engine: each rank's
+    int nxmax_in = 0;                // share travels with the norms) -- the k_csb_xmax pass over x is then left out
+    int phase = -1, nphases = 1;     // csb.h with column stripes: launch only the sweeps of this phase (-1: the whole product)
 };
 
 template <typename OffT, bool PANEL, bool C16, bool V8, bool UPD, bool XL = false, typename VT = double>
@@ -275,41 +278,65 @@ static void launch_csb_N(H *h, const SpmvArgs &a)
     const Csr &c = *a.c;
     const VT *x = reinterpret_cast<const VT *>(a.x);
     VT *y = reinterpret_cast<VT *>(a.y);
+    const int nph = std::max(c.phases, 1);
+    const int ph0 = a.phase < 0 ? 0 : std::min(a.phase, nph - 1), ph1 = a.phase < 0 ? nph : ph0 + 1;
+    const bool head = ph0 == 0, tail = ph1 == nph;   // this call opens / closes the product
     // max|x| first, piece by piece (what fixes the grids of the exact sums, csb.h): one pass over the vector
     // the product gathers from -- the solver's own vectors too (a bound from |x|_2 = 1 alone does not survive
     // duplicate entries, and is the looser one besides)
     const int xg = (int)std::min<int64_t>(CSB_XMAX_GRID, std::max<int64_t>(1, ((int64_t)c.cols + VEC_BLOCK - 1) / VEC_BLOCK));
     static const int tau_split = env_int("LSQRHIP_CSB_TAU", 1);
     CsbX xb{h->xmax_part, xg * (VEC_BLOCK / WAVE), tau_split};
-    hipLaunchKernelGGL(k_csb_xmax<VT>, dim3(xg), dim3(VEC_BLOCK), 0, a.stream, x, (int64_t)c.cols, h->xmax_part);
+    if (a.xmax_in != nullptr) {   // the caller holds the piece maxima (shard_engine.h): no pass over x
+        xb.xmax = a.xmax_in;
+        xb.nxmax = a.nxmax_in;
+    } else if (head) {
+        hipLaunchKernelGGL(k_csb_xmax<VT>, dim3(xg), dim3(VEC_BLOCK), 0, a.stream, x, (int64_t)c.cols, h->xmax_part);
+    }
     // One launch per ROUND of row blocks (256 at a time, one per CU).  Every workgroup sweeps x from its
     // first to its last column; workgroups that start a sweep together stay close enough for the part of x
     // they gather from to sit in their XCD's L2, and a kernel boundary re-aligns them for the next round
     // (one launch over all blocks lets them drift apart: config 4 7.3 instead of 5.x ms).  The scalar rider
     // goes with the first launch.  LSQRHIP_CSB_ROUNDS=0: one launch.
+    // With the overlap plan of the sharded engine (csb.h "Column stripes / phases") the launches fall into phases:
+    // stripes -- phase k = all blocks x the J splits of part k of the gathered vector; segments -- phase k = the blocks
+    // of part k of the output vector; `a.phase` picks one (the engine waits for an exchange between them).
     static const int rounds = env_int("LSQRHIP_CSB_ROUNDS", 1);
     const int S = std::max(c.S, 1);
-    const int step = rounds ? std::max(1, c.grid / S) : std::max(c.nrb, 1);   // row blocks per launch
     CsbMat A{c.cval, c.cidx, c.cdel, c.ccb, c.cptr, c.crs, c.nrb, c.R, c.rows, c.cols, c.rexp, c.zcoarse, 0, 0, S, c.zsplit,
-             c.cbad, std::max(c.Q, 1)};
-    for (int b0 = 0; b0 < c.nrb || b0 == 0; b0 += step) {
-        const int b1 = std::min(c.nrb, b0 + step);
-        const bool first = b0 == 0, last = b1 >= c.nrb;
-        A.b0 = b0;
-        A.b1 = b1;
-        Rider rider = first ? a.rider : Rider{};
-        const dim3 grid(std::max(1, std::min(c.grid, (b1 - b0) * S)) + (rider.kind != 0 ? 1 : 0));
-        hipEvent_t e0 = first ? a.e0 : nullptr, e1 = (last && S == 1) ? a.e1 : nullptr;
-        if (e0 == nullptr && e1 == nullptr)
-            hipLaunchKernelGGL((k_spmv_csb<VT, NARROW>), grid, dim3(CSB_BLOCK), 0, a.stream, A, x, y, a.coef, a.stop, a.pout,
-                               a.pin, a.npin, a.slot_in, a.slot_out, a.skip_if_zero, rider, xb, a.nsc);
-        else
-            hipExtLaunchKernelGGL((k_spmv_csb<VT, NARROW>), grid, dim3(CSB_BLOCK), 0, a.stream, e0, e1, 0, A, x, y, a.coef,
-                                  a.stop, a.pout, a.pin, a.npin, a.slot_in, a.slot_out, a.skip_if_zero, rider, xb,
-                                  a.nsc);
-        if (last) break;
+             c.cbad, std::max(c.Q, 1), c.gptr, c.NS, c.G, c.J, c.Pst, c.border, 0, S};
+    bool first = head;
+    for (int ph = ph0; ph < ph1; ++ph) {
+        int p0 = 0, p1 = c.nrb, nsp = S;   // positions of the launch order, splits per unit row
+        if (c.NS > 1) {
+            A.sp0 = ph * c.J;
+            A.sp1 = A.sp0 + c.J;
+            nsp = c.J;
+        } else if (c.border != nullptr) {
+            p0 = c.phase_pos[(size_t)ph];
+            p1 = c.phase_pos[(size_t)ph + 1];
+        }
+        const int step = (rounds || nph > 1) ? std::max(1, c.grid / nsp) : std::max(c.nrb, 1);   // row blocks per launch
+        for (int b0 = p0; b0 < p1 || (b0 == p0 && p0 == 0 && c.nrb == 0); b0 += step) {
+            const int b1 = std::min(p1, b0 + step);
+            const bool last = tail && ph == ph1 - 1 && b1 >= p1;
+            A.b0 = b0;
+            A.b1 = b1;
+            Rider rider = first ? a.rider : Rider{};
+            const dim3 grid(std::max(1, std::min(c.grid, (b1 - b0) * nsp)) + (rider.kind != 0 ? 1 : 0));
+            hipEvent_t e0 = first ? a.e0 : nullptr, e1 = (last && S == 1) ? a.e1 : nullptr;
+            if (e0 == nullptr && e1 == nullptr)
+                hipLaunchKernelGGL((k_spmv_csb<VT, NARROW>), grid, dim3(CSB_BLOCK), 0, a.stream, A, x, y, a.coef, a.stop, a.pout,
+                                   a.pin, a.npin, a.slot_in, a.slot_out, a.skip_if_zero, rider, xb, a.nsc);
+            else
+                hipExtLaunchKernelGGL((k_spmv_csb<VT, NARROW>), grid, dim3(CSB_BLOCK), 0, a.stream, e0, e1, 0, A, x, y, a.coef,
+                                      a.stop, a.pout, a.pin, a.npin, a.slot_in, a.slot_out, a.skip_if_zero, rider, xb,
+                                      a.nsc);
+            first = false;
+            if (b1 >= p1) break;
+        }
     }
-    if (S > 1) {  // the splits' sums -> y and the blocks' partials (csb.h k_csb_combine)
+    if (S > 1 && tail) {  // the splits' sums -> y and the blocks' partials (csb.h k_csb_combine)
         const dim3 grid(std::max(1, std::min(c.nrb * std::max(c.Q, 1), 2 * CSB_GRID)));
         if (a.e1 == nullptr)
             hipLaunchKernelGGL((k_csb_combine<VT, NARROW>), grid, dim3(CSB_BLOCK), 0, a.stream, A, x, y, a.coef, a.stop, a.pout,

@@ -358,3 +358,45 @@ def test_solves_with_spiky_vectors_repeat_exactly(csb_env, S):
         assert o[:5] == runs[0][:5] and np.array_equal(o[5], runs[0][5])
     assert (runs[0][0], runs[0][1]) == (g.istop, g.itn)
     assert np.linalg.norm(runs[0][5] - g.x) <= 1e-10 * np.linalg.norm(g.x)
+
+
+@pytest.mark.parametrize("world,parts", [(2, 2), (3, 2), (8, 2), (8, 4), (5, 3)])
+def test_overlap_plan_of_the_sharded_engine_changes_no_bit_of_a_product(world, parts):
+    """LSQRHIP_SHARD_OVERLAP=1 builds a rank's layouts for exchanges in parts (csb.h "Column stripes / phases"): the
+    chunks of A's row blocks are formed per part of the gathered vector and swept part by part, the row blocks of A'
+    are cut per part of the output vector and launched part-major.  Row sums are exact integer sums: neither may
+    change a bit of y -- launched whole (here) or phase by phase (the engine, tests/test_gpu_engine.py)."""
+    keys = ("LSQRHIP_CSB", "LSQRHIP_SHARD_OVERLAP", "LSQRHIP_SHARD_WORLD", "LSQRHIP_SHARD_PARTS")
+    old = {k: os.environ.get(k) for k in keys}
+    # (12000 columns: A' has few enough rows for whole blocks without column splits, which the part-major launch
+    # order needs -- as the 10M-row A' of a rank of config 4 has for the opposite reason)
+    p = P.random_rows(60000, 12000, 10, seed=29, damp=1e-3)
+    xp, yp = vecs(p)
+    try:
+        os.environ["LSQRHIP_CSB"] = "1"
+        res = []
+        for overlap in (0, 1):
+            os.environ["LSQRHIP_SHARD_OVERLAP"] = str(overlap)
+            os.environ["LSQRHIP_SHARD_WORLD"] = str(world)
+            os.environ["LSQRHIP_SHARD_PARTS"] = str(parts)
+            s = lsqr_solver_ez().initialize(p.m, p.n, p.a, p.irow, p.icol, itnlim=12)
+            assert s.info()["xlds"] == 3 and s.info()["xlds_t"] == 3
+            ph = (s.get_option("csb_phases_mode1"), s.get_option("csb_phases_mode2"))
+            assert ph == ((min(parts, 4), min(parts, 4)) if overlap else (1, 1))
+            x, y = xp.copy(), yp.copy()
+            s.aprod(1, p.m, p.n, x, y)
+            x2, y2 = xp.copy(), yp.copy()
+            s.aprod(2, p.m, p.n, x2, y2)
+            r = s.solve(p.b, 1e-3)
+            res.append((y, x2, r))
+    finally:
+        for k, v in old.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+    # (a solve: the partial sums of |A'u|^2 are per row block, and the blocks of A' are cut differently -- rounding)
+    assert (res[0][2].istop, res[0][2].itn) == (res[1][2].istop, res[1][2].itn)
+    assert np.linalg.norm(res[0][2].x - res[1][2].x) <= 1e-12 * np.linalg.norm(res[0][2].x)
+    _, y_ref = oracle.port().aprod(1, p.m, p.n, p.irow, p.icol, p.a, xp, yp)
+    assert np.max(np.abs(res[1][0] - y_ref)) <= 1e-13 * np.max(np.abs(y_ref))
