@@ -1111,6 +1111,7 @@ static int build_csb(hipStream_t s, const int *rowk, const int *colk, const doub
     // the gathered vector; split sp = k * J + j of a block sweeps part k of the slices j, j + J, ...  J sub-splits so
     // that one phase (all blocks x J splits) fills the chip.
     int NS = 1, G = 1, J = 1;
+    const int S_plain = S;   // the splits this matrix has without the plan
     std::vector<int> scut;
     if (plan.stripes && plan.P > 1 && plan.G > 1 && nnz > 0 && env_int("LSQRHIP_CSB_S", 0) <= 0) {
         G = plan.G;
@@ -1272,6 +1273,9 @@ static int build_csb(hipStream_t s, const int *rowk, const int *colk, const doub
         // the combine launch: enough workgroups for the whole chip (csb.h k_csb_combine)
         out.Q = (int)std::min<int64_t>(CSB_QMAX, std::max<int64_t>(1, (2 * CSB_GRID + nrb - 1) / nrb));
         while (out.Q > 1 && (int64_t)nrb * out.Q > SPMV_MAX_GRID) --out.Q;
+        // (splits that exist only for the overlap plan: one workgroup per block, whose partial of sum y^2 is bit for
+        // bit the unsplit kernel's -- a solve with the plan repeats the solve without it)
+        if (S_plain == 1) out.Q = 1;
     }
     out.grid = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)nrb * S, CSB_GRID));  // workgroups per launch
     out.out_grid = nrb * out.Q;   // partials of sum(y^2) one product leaves behind

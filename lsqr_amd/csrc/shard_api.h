@@ -297,8 +297,14 @@ static void shard_stage_vec(H *h, int stage)
     }
 }
 
-// Enqueue one stage on the handle's stream (asynchronous).
-extern "C" int lsqrhip_shard_stage(lsqrhip_handle_t h, int stage)
+// Enqueue one stage on the handle's stream (asynchronous).  `phase` (shard_engine.h with LSQRHIP_SHARD_OVERLAP=1): the
+// products of ST_MODE1 / ST_S1_ATU are launched one phase of their layout's plan at a time (csb.h "Column stripes /
+// phases") -- the stage's scalar kernel goes with its first phase, the reduction of the partials with its last;
+// -1: the whole stage.
+static int shard_stage_phase(lsqrhip_handle_t h, int stage, int phase);
+extern "C" int lsqrhip_shard_stage(lsqrhip_handle_t h, int stage) { return shard_stage_phase(h, stage, -1); }
+
+static int shard_stage_phase(lsqrhip_handle_t h, int stage, int phase)
 {
     if (!h || !h->shard.active) return fail(LSQRHIP_ERR_NOT_INIT, "lsqrhip_shard_begin was not called");
     HIPCHK(hipSetDevice(h->device));
@@ -339,20 +345,28 @@ extern "C" int lsqrhip_shard_stage(lsqrhip_handle_t h, int stage)
         SpmvArgs a;
         a.c = &h->A; a.x = c.V; a.y = h->U; a.coef = &st->c1; a.stop = &st->stop; a.pout = h->partials; a.stream = s;
         a.unit_x = true;
+        a.phase = phase;
         if (c.vmax_msg) {
             a.xmax_in = h->xmax_part;
             a.nxmax_in = c.P * SHARD_NMAX;
         }
         launch_spmv_args(h, a);
+        if (phase < 0 || phase >= std::max(h->A.csb ? h->A.phases : 1, 1) - 1)
+            hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(VEC_BLOCK), 0, s, (const double *)h->partials,
+                               h->A.out_grid, sums);
+        break;
     }
-        hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(VEC_BLOCK), 0, s, (const double *)h->partials,
-                           h->A.out_grid, sums);
+    case ST_S1_ATU: {
+        if (phase <= 0)
+            hipLaunchKernelGGL((k_s1<false>), dim3(1), dim3(SC_BLOCK), 0, s, (const double *)h->partials, 0,
+                               (const double *)sums, st);
+        SpmvArgs a;
+        a.c = &h->AT; a.x = h->U; a.y = T; a.coef = &st->c2p; a.stop = &st->stop; a.pout = h->partials; a.stream = s;
+        a.unit_x = true;
+        a.phase = phase;
+        launch_spmv_args(h, a);
         break;
-    case ST_S1_ATU:
-        hipLaunchKernelGGL((k_s1<false>), dim3(1), dim3(SC_BLOCK), 0, s, (const double *)h->partials, 0,
-                           (const double *)sums, st);
-        launch_spmv(h, h->AT, h->U, T, &st->c2p, &st->stop, nullptr, nullptr, true);
-        break;
+    }
     case ST_VCOMBINE:
         vec(stage);
         hipLaunchKernelGGL(k_shard_sums, dim3(1), dim3(VEC_BLOCK), 0, s, (const double *)h->partials, gq,

@@ -58,6 +58,7 @@ struct Rccl {
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommSplit)(ncclComm_t, int, int, ncclComm_t *, void *) = nullptr;   // (optional: the overlap's second communicator)
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -93,6 +94,7 @@ static Rccl *rccl()
     r.GroupStart = (decltype(r.GroupStart))sym("ncclGroupStart");
     r.GroupEnd = (decltype(r.GroupEnd))sym("ncclGroupEnd");
     r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
+    r.CommSplit = (decltype(r.CommSplit))dlsym(r.lib, "ncclCommSplit");
     if (!ok) {
         r.lib = nullptr;
         return nullptr;
@@ -122,6 +124,12 @@ struct ShardRank {
     int grank = 0;           // rank in the world
     int64_t row0 = 0;        // first global row of the block
     ncclComm_t comm = nullptr;
+    // LSQRHIP_SHARD_OVERLAP=1: the exchanges of the n-vectors run on a stream of their own, part by part, beside the
+    // products (a second communicator: one communicator must not be used from two streams at once)
+    ncclComm_t comm2 = nullptr;
+    hipStream_t cstream = nullptr;
+    hipEvent_t evV = nullptr, evRS = nullptr;          // v_q final (compute stream) / all parts of R received (comm stream)
+    std::vector<hipEvent_t> evAG, evT;                 // part k of v gathered (comm stream) / part k of T complete (compute stream)
     double *T = nullptr, *R = nullptr, *V = nullptr, *sums = nullptr, *gath = nullptr;  // exchange buffers (owned)
     double *xfull = nullptr, *sefull = nullptr, *bloc = nullptr;                         // P*chunk, P*chunk, m_p
 };
@@ -136,6 +144,8 @@ struct ShardGroup {
     bool loopback = false;         // exchanges by device copies inside this process instead of RCCL (all ranks are local)
     std::vector<hipEvent_t> ev;    // loopback: one event per rank
     int poll_every = 16;
+    int overlap = 0;               // LSQRHIP_SHARD_OVERLAP at creation: exchanges in `parts` parts beside the products
+    int parts = 1;
     int msg = 4;                   // doubles a rank contributes to the exchange of the norms: 4, or SHARD_MSG when its piece
                                    // maxima of |v_q| ride along (every matrix in column-swept row blocks: csb.h)
     // one captured batch of `poll_every` iterations -- stages AND exchanges of every local rank (capture_group_batch)
@@ -159,7 +169,13 @@ static void free_group(ShardGroup *g)
     for (ShardRank &k : g->r) {
         if (k.h) (void)hipSetDevice(k.h->device);
         else if (k.dev >= 0) (void)hipSetDevice(k.dev);
+        if (k.comm2 && rccl()) (void)rccl()->CommDestroy(k.comm2);
         if (k.comm && rccl()) (void)rccl()->CommDestroy(k.comm);
+        for (hipEvent_t e : k.evAG) if (e) (void)hipEventDestroy(e);
+        for (hipEvent_t e : k.evT) if (e) (void)hipEventDestroy(e);
+        if (k.evV) (void)hipEventDestroy(k.evV);
+        if (k.evRS) (void)hipEventDestroy(k.evRS);
+        if (k.cstream) (void)hipStreamDestroy(k.cstream);
         for (double *p : {k.T, k.R, k.V, k.sums, k.gath, k.xfull, k.sefull, k.bloc})
             if (p) (void)hipFree(p);
         if (g->owned && k.h) lsqrhip_destroy(k.h);
@@ -328,9 +344,186 @@ static int ex_gather(ShardGroup &g, bool x_too, bool se_too)  // in-place all-ga
     return LSQRHIP_OK;
 }
 
-static int stage_all(ShardGroup &g, int st)
+static int stage_all(ShardGroup &g, int st, int phase = -1)
 {
-    for (ShardRank &q : g.r) RET(lsqrhip_shard_stage(q.h, st));
+    for (ShardRank &q : g.r) RET(shard_stage_phase(q.h, st, phase));
+    return LSQRHIP_OK;
+}
+
+// ---- LSQRHIP_SHARD_OVERLAP=1: the two n-vector exchanges of an iteration in parts, beside the products -------------
+// Every slice travels in G parts (lsqrhip.hip shard_part).  The layouts of a rank's blocks were built for it
+// (finish_create): mode 1 sweeps part k of all slices in its phase k, so it only needs part k of the all-gather of v
+// -- part k + 1 arrives while it runs; mode 2 completes part k of all slices of T in its phase k, which is sent
+// while phase k + 1 runs.  Compute stream S = the handle's; exchange stream C = cstream.  Per iteration:
+//     S: wait evAG[k]; mode 1 phase k          (k = 0 .. G-1)        C: (still gathering parts k+1 .. of the last v)
+//     S: beta (all-gather of the norms, on S, first communicator)
+//     S: mode 2 phase k; record evT[k]         (k = 0 .. G-1)        C: wait evT[k]; part k of T -> the owners' R
+//     S: wait evRS; v_q <- combine(R); record evV                    C: record evRS;  wait evV; gather part k of v,
+//     S: alpha (norms + piece maxima); x_q, w_q update                  record evAG[k]   (k = 0 .. G-1)
+// Nothing of the arithmetic changes: the same kernels on the same data in the same order of sums -- a solve with the
+// switch on is bit for bit the solve with it off on the same layouts (tests/test_gpu_engine.py).
+static int overlap_setup(ShardGroup &g)
+{
+    for (ShardRank &q : g.r) {
+        if (q.cstream) continue;
+        HIPCHK(hipSetDevice(q.h->device));
+        HIPCHK(hipStreamCreateWithFlags(&q.cstream, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&q.evV, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&q.evRS, hipEventDisableTiming));
+        q.evAG.assign((size_t)g.parts, nullptr);
+        q.evT.assign((size_t)g.parts, nullptr);
+        for (int k = 0; k < g.parts; ++k) {
+            HIPCHK(hipEventCreateWithFlags(&q.evAG[(size_t)k], hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&q.evT[(size_t)k], hipEventDisableTiming));
+        }
+    }
+    return LSQRHIP_OK;
+}
+
+// part k of slice `sl`: offset from the slice's start and length, in elements
+static void part_of(const ShardGroup &g, int sl, int k, size_t *off, size_t *len)
+{
+    int64_t lo, hi;
+    shard_part(g.n, g.P, g.parts, sl, k, &lo, &hi);
+    *off = (size_t)(lo - std::min<int64_t>((int64_t)sl * g.chunk, g.n));
+    *len = (size_t)(hi - lo);
+}
+
+// part k of T to the owners, on the exchange streams; waits for evT[k]
+static int ov_scatter_part(ShardGroup &g, int k)
+{
+    Rccl *rc = rccl();
+    const size_t c = (size_t)g.chunk, e = g.esz;
+    const ncclDataType_t vtype = e == sizeof(float) ? ncclFloat : ncclDouble;
+    if (g.loopback) {
+        for (ShardRank &q : g.r) {
+            HIPCHK(hipSetDevice(q.h->device));
+            size_t off, len;
+            part_of(g, q.grank, k, &off, &len);
+            for (ShardRank &p : g.r) {
+                if (&p == &q || len == 0) continue;
+                HIPCHK(hipStreamWaitEvent(q.cstream, p.evT[(size_t)k], 0));
+                HIPCHK(hipMemcpyAsync(at(q.R, (size_t)p.grank * c + off, e), at(p.T, (size_t)q.grank * c + off, e), len * e,
+                                      hipMemcpyDeviceToDevice, q.cstream));
+            }
+        }
+        return LSQRHIP_OK;
+    }
+    for (ShardRank &q : g.r) {
+        HIPCHK(hipSetDevice(q.h->device));
+        HIPCHK(hipStreamWaitEvent(q.cstream, q.evT[(size_t)k], 0));
+    }
+    NCCLCHK(rc->GroupStart());
+    for (ShardRank &q : g.r) {
+        size_t offq, lenq;
+        part_of(g, q.grank, k, &offq, &lenq);
+        for (int peer = 0; peer < g.P; ++peer) {
+            if (peer == q.grank) continue;
+            size_t offp, lenp;
+            part_of(g, peer, k, &offp, &lenp);
+            if (lenp) NCCLCHK(rc->Send(at(q.T, (size_t)peer * c + offp, e), lenp, vtype, peer, q.comm2, q.cstream));
+            if (lenq) NCCLCHK(rc->Recv(at(q.R, (size_t)peer * c + offq, e), lenq, vtype, peer, q.comm2, q.cstream));
+        }
+    }
+    NCCLCHK(rc->GroupEnd());
+    return LSQRHIP_OK;
+}
+
+// part k of every slice of v to everybody, on the exchange streams (after evV); records evAG[k]
+static int ov_gather_part(ShardGroup &g, int k)
+{
+    Rccl *rc = rccl();
+    const size_t c = (size_t)g.chunk, e = g.esz;
+    const ncclDataType_t vtype = e == sizeof(float) ? ncclFloat : ncclDouble;
+    if (g.loopback) {
+        for (ShardRank &q : g.r) {
+            HIPCHK(hipSetDevice(q.h->device));
+            for (ShardRank &p : g.r) {
+                if (&p == &q) continue;
+                size_t off, len;
+                part_of(g, p.grank, k, &off, &len);
+                if (len == 0) continue;
+                HIPCHK(hipMemcpyAsync(at(q.V, (size_t)p.grank * c + off, e), at(p.V, (size_t)p.grank * c + off, e), len * e,
+                                      hipMemcpyDeviceToDevice, q.cstream));
+            }
+            HIPCHK(hipEventRecord(q.evAG[(size_t)k], q.cstream));
+        }
+        return LSQRHIP_OK;
+    }
+    NCCLCHK(rc->GroupStart());
+    for (ShardRank &q : g.r) {
+        size_t offq, lenq;
+        part_of(g, q.grank, k, &offq, &lenq);
+        for (int peer = 0; peer < g.P; ++peer) {
+            if (peer == q.grank) continue;
+            size_t offp, lenp;
+            part_of(g, peer, k, &offp, &lenp);
+            if (lenq) NCCLCHK(rc->Send(at(q.V, (size_t)q.grank * c + offq, e), lenq, vtype, peer, q.comm2, q.cstream));
+            if (lenp) NCCLCHK(rc->Recv(at(q.V, (size_t)peer * c + offp, e), lenp, vtype, peer, q.comm2, q.cstream));
+        }
+    }
+    NCCLCHK(rc->GroupEnd());
+    for (ShardRank &q : g.r) {
+        HIPCHK(hipSetDevice(q.h->device));
+        HIPCHK(hipEventRecord(q.evAG[(size_t)k], q.cstream));
+    }
+    return LSQRHIP_OK;
+}
+
+static int enqueue_iteration_overlap(ShardGroup &g)
+{
+    const int G = g.parts;
+    // which products have a plan of G phases (column-swept layouts built under the switch): the others run whole
+    bool phA = true, phT = true;
+    for (ShardRank &q : g.r) {
+        phA = phA && q.h->A.csb && q.h->A.phases == G;
+        phT = phT && q.h->AT.csb && q.h->AT.phases == G;
+    }
+    auto wait_all = [&](ShardRank &q, auto getev) -> int {   // q's compute stream waits for an exchange-stream event
+        HIPCHK(hipSetDevice(q.h->device));
+        for (ShardRank &p : g.r)
+            if (&p == &q || g.loopback) HIPCHK(hipStreamWaitEvent(q.h->stream, getev(p), 0));
+        return LSQRHIP_OK;
+    };
+    // mode 1, phase by phase behind the parts of v
+    for (int k = 0; k < G; ++k) {
+        for (ShardRank &q : g.r) RET(wait_all(q, [&](ShardRank &p) { return p.evAG[(size_t)k]; }));
+        if (phA) RET(stage_all(g, ST_MODE1, k));
+    }
+    if (!phA) RET(stage_all(g, ST_MODE1));
+    RET(ex_scalars(g, 1));
+    // mode 2, its parts leaving as they complete
+    for (int k = 0; k < G; ++k) {
+        if (phT) RET(stage_all(g, ST_S1_ATU, k));
+        else if (k == G - 1) RET(stage_all(g, ST_S1_ATU));
+        if (phT || k == G - 1)
+            for (int kk = phT ? k : 0; kk <= k; ++kk) {
+                for (ShardRank &q : g.r) {
+                    HIPCHK(hipSetDevice(q.h->device));
+                    HIPCHK(hipEventRecord(q.evT[(size_t)kk], q.h->stream));
+                }
+                RET(ov_scatter_part(g, kk));
+            }
+    }
+    for (ShardRank &q : g.r) {
+        HIPCHK(hipSetDevice(q.h->device));
+        HIPCHK(hipEventRecord(q.evRS, q.cstream));
+    }
+    for (ShardRank &q : g.r) RET(wait_all(q, [&](ShardRank &p) { return p.evRS; }));
+    RET(stage_all(g, ST_VCOMBINE));
+    for (ShardRank &q : g.r) {
+        HIPCHK(hipSetDevice(q.h->device));
+        HIPCHK(hipEventRecord(q.evV, q.h->stream));
+    }
+    // the gather of v, part by part on the exchange streams, while the compute streams finish the iteration
+    for (ShardRank &q : g.r) {
+        HIPCHK(hipSetDevice(q.h->device));
+        for (ShardRank &p : g.r)
+            if (&p == &q || g.loopback) HIPCHK(hipStreamWaitEvent(q.cstream, p.evV, 0));
+    }
+    for (int k = 0; k < G; ++k) RET(ov_gather_part(g, k));
+    RET(ex_scalars(g, 2, false));
+    RET(stage_all(g, ST_UPDATE));
     return LSQRHIP_OK;
 }
 
@@ -338,6 +531,10 @@ static int stage_all(ShardGroup &g, int st)
 static int enqueue_iterations(ShardGroup &g, int count)
 {
     for (int k = 0; k < count; ++k) {
+        if (g.overlap) {
+            RET(enqueue_iteration_overlap(g));
+            continue;
+        }
         RET(stage_all(g, ST_MODE1));
         RET(ex_scalars(g, 1));
         RET(stage_all(g, ST_S1_ATU));
@@ -361,7 +558,7 @@ static int enqueue_iterations(ShardGroup &g, int count)
 static bool group_graph_wanted(const ShardGroup &g)
 {
     const int mode = env_int("LSQRHIP_SHARD_GRAPH", -1);   // (read at every solve: the tests switch it)
-    if (mode == 0 || g.graph_state < 0 || g.r.size() != 1) return false;
+    if (mode == 0 || g.graph_state < 0 || g.r.size() != 1 || g.overlap) return false;
     return g.P == 1 || mode == 1;
 }
 
@@ -401,6 +598,13 @@ static int run_group(ShardGroup &g, double damp, double atol, double btol, doubl
                      int *istop, int *itn, double *anorm, double *acond, double *rnorm, double *arnorm, double *xnorm)
 {
     if (g.P > 1 && !g.loopback && !rccl()) return fail(LSQRHIP_ERR_HIP, "librccl.so.1 could not be loaded");
+    if (g.overlap) {
+        RET(overlap_setup(g));
+        for (ShardRank &q : g.r) {   // (what a previous solve left running on the exchange streams reads V, T: let it finish)
+            HIPCHK(hipSetDevice(q.h->device));
+            HIPCHK(hipStreamSynchronize(q.cstream));
+        }
+    }
     // v's piece maxima ride with the norms when mode 1 of this rank's block wants them (column-swept row blocks) --
     // a property of the local matrix only, but the message length must be the world's: every rank of a sharded
     // system built by one rule from one matrix takes the same layout family; LSQRHIP_SHARD_VMAX=0 / 1 forces it
@@ -425,6 +629,12 @@ static int run_group(ShardGroup &g, double damp, double atol, double btol, doubl
     RET(ex_scalars(g, 2));
     RET(stage_all(g, ST_INIT_W));
     RET(ex_gather(g, false, false));
+    if (g.overlap) {   // the first iteration's mode 1 waits for "its" parts of v: they are all there
+        for (ShardRank &q : g.r) {
+            HIPCHK(hipSetDevice(q.h->device));
+            for (int k = 0; k < g.parts; ++k) HIPCHK(hipEventRecord(q.evAG[(size_t)k], q.h->stream));
+        }
+    }
     int st3[3] = {0, 0, 0};
     auto poll = [&]() -> int {   // the scalar recurrences are replicated bit for bit: every rank sees the same flag
         for (ShardRank &q : g.r) RET(lsqrhip_shard_poll(q.h, st3));
@@ -458,6 +668,11 @@ static int run_group(ShardGroup &g, double damp, double atol, double btol, doubl
         }
         RET(poll());
     }
+    if (g.overlap)   // (iterations enqueued past the stop still exchanged: drain them before x is assembled)
+        for (ShardRank &q : g.r) {
+            HIPCHK(hipSetDevice(q.h->device));
+            HIPCHK(hipStreamSynchronize(q.cstream));
+        }
     for (ShardRank &q : g.r) {
         int is = 0, it = 0;
         double sc[5];
@@ -654,6 +869,21 @@ static int create_sharded_T(int m, int n, int64_t nnz, const int *irow, const in
         else
             for (int p = 0; p < ngpu; ++p) g->r[(size_t)p].comm = comms[(size_t)p];
     }
+    // LSQRHIP_SHARD_OVERLAP=1: the n-vector exchanges in parts beside the products (enqueue_iteration_overlap); the
+    // blocks' layouts were built for it above (t_shard_world).  Over RCCL it needs a second communicator.
+    if (rc == LSQRHIP_OK && ngpu > 1 && env_int("LSQRHIP_SHARD_OVERLAP", 0) != 0) {
+        g->overlap = 1;
+        g->parts = std::min(std::max(env_int("LSQRHIP_SHARD_PARTS", 2), 2), 4);
+        if (!loopback) {
+            std::vector<int> devs;
+            std::vector<ncclComm_t> comms((size_t)ngpu);
+            for (ShardRank &q : g->r) devs.push_back(q.h->device);
+            ncclResult_t nr = rccl()->CommInitAll(comms.data(), ngpu, devs.data());
+            if (nr != ncclSuccess) g->overlap = 0;   // (never fatal: the plain schedule is always there)
+            else
+                for (int p = 0; p < ngpu; ++p) g->r[(size_t)p].comm2 = comms[(size_t)p];
+        }
+    }
     if (rc == LSQRHIP_OK) rc = agree_norm_exp(*g);
     if (rc != LSQRHIP_OK) {
         std::string keep = g_last_error;
@@ -771,6 +1001,18 @@ extern "C" int lsqrhip_shard_comm_init(lsqrhip_handle_t h, int world, int rank, 
         std::memcpy(id.internal, id128, NCCL_UNIQUE_ID_BYTES);
         ncclResult_t nr = rccl()->CommInitRank(&q.comm, world, id, rank);
         if (nr != ncclSuccess) rc = fail(LSQRHIP_ERR_HIP, std::string("ncclCommInitRank: ") + rccl()->GetErrorString(nr));
+    }
+    // LSQRHIP_SHARD_OVERLAP=1 (set on EVERY rank, before the handle was created: its layouts are built for it with
+    // LSQRHIP_SHARD_WORLD = world): a second communicator for the exchange stream, split off the first
+    if (rc == LSQRHIP_OK && world > 1 && env_int("LSQRHIP_SHARD_OVERLAP", 0) != 0) {
+        if (rccl()->CommSplit == nullptr) {
+            rc = fail(LSQRHIP_ERR_HIP, "LSQRHIP_SHARD_OVERLAP=1 needs ncclCommSplit, which this librccl does not export");
+        } else {
+            ncclResult_t nr = rccl()->CommSplit(q.comm, 0, rank, &q.comm2, nullptr);
+            if (nr != ncclSuccess) rc = fail(LSQRHIP_ERR_HIP, std::string("ncclCommSplit: ") + rccl()->GetErrorString(nr));
+            g->overlap = 1;
+            g->parts = std::min(std::max(env_int("LSQRHIP_SHARD_PARTS", 2), 2), 4);
+        }
     }
     if (rc == LSQRHIP_OK) rc = agree_norm_exp(*g);
     if (rc != LSQRHIP_OK) {

@@ -102,6 +102,10 @@ def run_distributed(args):
 
     K, W = args.steps, args.warmup
     row0, nrows = blocks[rank]
+    # LSQRHIP_SHARD_OVERLAP=1 (on every rank): the rank's layouts are built for exchanges in parts -- the build must
+    # know the world it is a block of (csrc/lsqrhip.hip finish_create)
+    if os.environ.get("LSQRHIP_SHARD_OVERLAP", "0") not in ("", "0"):
+        os.environ["LSQRHIP_SHARD_WORLD"] = str(world)
     prob = devgen.generate(spec, row0, nrows)
     # the loop itself -- kernels and RCCL calls -- runs in C++ (csrc/shard_engine.h); LSQR_DIST_ENGINE=python
     # selects the stage-by-stage driver over torch.distributed instead (same stages, same arithmetic).

@@ -188,10 +188,13 @@ def _two_gpus():
     return torch.cuda.device_count() >= 2
 
 
+@pytest.mark.parametrize("overlap", ["0", "1"])
 @pytest.mark.parametrize("name", ["random_over_se", "poisson_20x20_it50", "empty_rows_cols_it20"])
-def test_rccl_two_gpus_single_process(name):
+def test_rccl_two_gpus_single_process(name, overlap, monkeypatch):
+    """(overlap = 1: the exchanges in parts on a second communicator beside the products, shard_engine.h)"""
     if not _two_gpus():
         pytest.skip("needs two GPUs (RCCL refuses ranks that share a device)")
+    monkeypatch.setenv("LSQRHIP_SHARD_OVERLAP", overlap)
     p, o = CASES[name]
     h = sharded_handle(p, 2)
     try:
@@ -205,8 +208,10 @@ def test_rccl_two_gpus_single_process(name):
         check(lib().lsqrhip_destroy(h))
 
 
-def test_rccl_two_ranks_through_bench_launcher():
-    """`bench.py --gpus 2` starts its own two ranks (one process per GPU, RCCL), the C++ engine drives them."""
+@pytest.mark.parametrize("overlap", ["0", "1"])
+def test_rccl_two_ranks_through_bench_launcher(overlap):
+    """`bench.py --gpus 2` starts its own two ranks (one process per GPU, RCCL), the C++ engine drives them --
+    with the exchanges overlapped (LSQRHIP_SHARD_OVERLAP=1: a second communicator split off the first) as well."""
     if not _two_gpus():
         pytest.skip("needs two GPUs")
     import json
@@ -214,13 +219,13 @@ def test_rccl_two_ranks_through_bench_launcher():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = {**os.environ, "LSQR_BENCH_STRONG_REF": "0"}
+    env = {**os.environ, "LSQR_BENCH_STRONG_REF": "0", "LSQRHIP_SHARD_OVERLAP": overlap}
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "2",
                         "--workload", "random:200000:100000:20"], capture_output=True, text=True, timeout=900, env=env)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["config"]["world_size"] == 2 and line["steps"] == 20
-    assert line["result"]["itn"] == 20 and line["value"] > 0
+    assert line["result"]["itn"] == 20 and line["value"] > 0 and line["overlap"] == int(overlap)
 
 
 @pytest.mark.parametrize("fail", ["0", "1"])
@@ -414,3 +419,61 @@ def test_sharded_blocks_start_at_the_selected_device_and_must_fit_the_node():
         assert b"selected device" in lib().lsqrhip_last_error() or have < 2
     finally:
         check(lib().lsqrhip_set_device(0))
+
+
+def _solve_with_log(h, p, o):
+    x, se = np.zeros(max(p.n, 1)), np.zeros(max(p.n, 1))
+    istop, itn = C.c_int(), C.c_int()
+    sc = [C.c_double() for _ in range(5)]
+    b = np.ascontiguousarray(p.b, np.float64)
+    check(lib().lsqrhip_solve(h, b.ctypes.data, o["damp"], o["atol"], o["btol"], o["conlim"], o["itnlim"],
+                              int(o["wantse"]), 1, x.ctypes.data, se.ctypes.data if o["wantse"] else None,
+                              C.addressof(istop), C.addressof(itn), *[C.addressof(s) for s in sc]))
+    k = lib().lsqrhip_log_count(h)
+    rec = np.zeros((k, capi.LOG_STRIDE))
+    check(lib().lsqrhip_log_fetch(h, 0, k, rec.ctypes.data))
+    return x[:p.n].copy(), se[:p.n].copy(), istop.value, itn.value, [s.value for s in sc], rec
+
+
+@pytest.mark.parametrize("ngpu", [2, 3, 8])
+@pytest.mark.parametrize("csb,parts", [(None, 2), ("1", 2), ("1", 3)])
+def test_overlapped_exchanges_change_no_bit(loopback, ngpu, csb, parts):
+    """LSQRHIP_SHARD_OVERLAP=1: the reduce-scatter of T leaves in parts behind the phases of mode 2 and the all-gather
+    of v arrives in parts ahead of the phases of mode 1, on an exchange stream of its own (shard_engine.h
+    enqueue_iteration_overlap; here in the loopback harness -- the exchanges are device copies, the streams, events
+    and parts are the production schedule).  The kernels, their data and the order of every sum are those of the plain
+    schedule: x, se, every scalar and every line of the iteration log must be identical to the last bit -- with the
+    ranks' blocks in column-swept row blocks built for the parts (stripes, part-major row blocks: the products run
+    phase by phase) and in whatever the build chooses at this size (the products run whole, the exchanges in parts)."""
+    import os
+    keys = ("LSQRHIP_CSB", "LSQRHIP_SHARD_OVERLAP", "LSQRHIP_SHARD_PARTS")
+    old = {k: os.environ.get(k) for k in keys}
+    p = P.random_rows(60000, 12011, 10, seed=31, damp=1e-3)      # (12011: ragged slices and parts)
+    o = dict(damp=p.damp, atol=1e-10, btol=1e-10, conlim=0.0, itnlim=25, wantse=True)
+    out = []
+    try:
+        if csb:
+            os.environ["LSQRHIP_CSB"] = csb
+        os.environ["LSQRHIP_SHARD_PARTS"] = str(parts)
+        for overlap in ("0", "1"):
+            os.environ["LSQRHIP_SHARD_OVERLAP"] = overlap
+            h = sharded_handle(p, ngpu)
+            try:
+                first = _solve_with_log(h, p, o)
+                again = _solve_with_log(h, p, o)          # ... and repeats itself (nothing left on the exchange streams)
+                assert np.array_equal(first[0], again[0]) and first[2:5] == again[2:5]
+                out.append(first)
+            finally:
+                check(lib().lsqrhip_destroy(h))
+    finally:
+        for k, v in old.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v
+    off, on = out
+    assert (off[2], off[3]) == (on[2], on[3]) and off[3] > 5
+    assert np.array_equal(off[0], on[0]) and np.array_equal(off[1], on[1])
+    assert off[4] == on[4]
+    assert off[5].shape == on[5].shape and np.array_equal(off[5], on[5])
+    g = oracle.port().solve(p.m, p.n, p.irow, p.icol, p.a, p.b, damp=p.damp, atol=1e-10, btol=1e-10, itnlim=25)
+    assert (on[2], on[3]) == (g.istop, g.itn) and np.linalg.norm(on[0] - g.x) <= 1e-10 * np.linalg.norm(g.x)
