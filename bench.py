@@ -57,6 +57,11 @@ HBM_INSTANCES = [("poisson2d:4000:4000", {}, "row patterns (what the build choos
 PRODUCT_KERNELS = ("k_spmv_", "k_panel_combine", "k_csb_combine", "k_csb_xmax")
 # the N = 1 line measures configs[1]; the series the --gpus N lines continue is strong_scaling_n1 (configs[3])
 SCALING_N1 = "n/a (configs[1]; the strong-scaling series is strong_scaling_n1)"
+# What the memory system delivers for the ACCESS PATTERN of the column-swept product -- the real layout and sweep without
+# arithmetic, LDS sums and epilogue (scripts/csb_ceiling.hip "both"; profiles/r04/csb_ceiling.txt), GB/s of layout bytes.
+# Keyed by (columns of x, nonzeros per column and row block rounded to 0.01): the two things the pattern depends on.
+CSB_CEILING_GBS = {"random:10000000:10000000:100": 3945.0, "random:1250000:10000000:100": 3828.0,
+                   "powerlaw:5000000:2000000:10000": 3772.0, "random:4000000:1000000:100": 5751.0}
 GENERAL_INSTANCE = 2      # HBM_INSTANCES[2]: sliced ELL with 8-byte values -- the best HBM-resident GENERAL short-row kernel
 
 
@@ -146,16 +151,16 @@ def build_workload(spec: str, env=None, itnlim=100, rows=None):
         if rows is not None:
             dp = devgen.generate(spec, int(rows[0]), int(rows[1]), itnlim=itnlim)
             s, d_b = dp.solver, dp.d_b
-            facts = dict(name=f"{spec} rows {rows[0]}..{rows[0] + rows[1]}", m=dp.nrows, n=dp.n, nnz=dp.nnz, damp=dp.damp)
+            facts = dict(name=f"{spec} rows {rows[0]}..{rows[0] + rows[1]}", m=dp.nrows, n=dp.n, nnz=dp.nnz, damp=dp.damp, spec="")
         elif nnz_est <= 60_000_000 and not env:     # the host copy only exists for the CPU baseline
             host = make_problem(spec)
             s = lsqr_solver_ez().initialize(host.m, host.n, host.a, host.irow, host.icol, itnlim=itnlim)
             d_b = capi.DeviceBuffer.from_array(host.b)
-            facts = dict(name=host.name, m=host.m, n=host.n, nnz=host.nnz, damp=host.damp)
+            facts = dict(name=host.name, m=host.m, n=host.n, nnz=host.nnz, damp=host.damp, spec=spec)
         else:                                        # generated in HBM (bit-identical generator, csrc/gen_api.h)
             dp = devgen.generate(spec, itnlim=itnlim)
             s, d_b = dp.solver, dp.d_b
-            facts = dict(name=spec, m=dp.m, n=dp.n, nnz=dp.nnz, damp=dp.damp)
+            facts = dict(name=spec, m=dp.m, n=dp.n, nnz=dp.nnz, damp=dp.damp, spec=spec)
     return s, d_b, facts, host
 
 
@@ -223,6 +228,14 @@ def product_roofline(s, facts, reps, traffic=None):
     # peak.  Above 1 the layout moves fewer bytes than that count and the product is not an HBM stream of it.
     roof["frac_survey8d"] = alg1 / (avg1 * 1e-3) / 1e9 / HBM_PEAK_GBS
     roof["bound_survey8d"] = "cache" if roof["frac_survey8d"] > 1.0 else "hbm"
+    ceil_gbs = CSB_CEILING_GBS.get(facts.get("spec", ""))
+    if info["xlds"] == 3 and ceil_gbs:
+        roof["ceiling_gbps"] = ceil_gbs
+        roof["ceiling_frac"] = ceil_gbs / HBM_PEAK_GBS
+        roof["of_ceiling"] = ach / ceil_gbs
+        roof["ceiling_is"] = ("what the memory system delivers for this product's access pattern -- the real chunk layout and "
+                              "sweep (12-byte stream from HBM + sorted gathers of x through L2) with the arithmetic, the LDS "
+                              "sums and the epilogue taken away: scripts/csb_ceiling.hip, profiles/r04/csb_ceiling.txt")
     if traffic:
         roof["traffic"] = traffic.get("bytes_per_launch")
         roof["traffic_detail"] = traffic

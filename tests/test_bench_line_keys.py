@@ -52,14 +52,41 @@ def test_distributed_leg_names_the_contract_keys():
     assert set(dist_bench.CPU_BASELINE_KEYS) == {"value", "unit", "cores", "kind", "sample"}
 
 
+def round_of_lines():
+    return int(os.path.basename(last_round_dir())[1:])
+
+
+def check_survey8d(r):
+    """round 4 on: SURVEY 8d's own fraction (algorithmic bytes / time / peak) beside the physical one"""
+    assert abs(r["frac_survey8d"] - r["effective_gbps"] / r["peak"]) < 1e-9
+    assert r["bound_survey8d"] == ("cache" if r["frac_survey8d"] > 1.0 else "hbm")
+
+
 def test_committed_single_gpu_lines():
     for name in ("bench_default.json", "bench_default_k20.json"):
         d = load(name)
         check_line(d)
-        assert d["n_gpus"] == 1 and d["scaling"] == "weak"
+        assert d["n_gpus"] == 1
         assert d["roofline"]["traffic"] is not None          # live PMC passes of the same run
         assert isinstance(d.get("roofline_hbm"), list) and d["roofline_hbm"]
         assert "roofline" in d["strong_scaling_n1"]
+        if round_of_lines() >= 4:
+            # the N = 1 line measures configs[1]: it says so instead of claiming a scaling mode, and points at the
+            # series the --gpus N lines continue
+            assert d["scaling"].startswith("n/a") and "strong_scaling_n1" in d["scaling"]
+            check_survey8d(d["roofline"])
+            for e in d["roofline_hbm"]:
+                check_survey8d(e["roofline"])
+            n1 = d["strong_scaling_n1"]["roofline"]
+            check_survey8d(n1)
+            # the column-swept product against the measured ceiling of its access pattern (scripts/csb_ceiling.hip)
+            assert n1["ceiling_gbps"] > 0 and abs(n1["of_ceiling"] - n1["achieved"] / n1["ceiling_gbps"]) < 1e-9
+            # the best HBM-resident GENERAL short-row kernel at top level, with the rocprofv3 summary that backs it
+            g = d["roofline_general"]
+            assert g["bound"] == "hbm" and 0 < g["frac"] <= 1 and "poisson2d:4000:4000" in g["workload"]
+            assert os.path.exists(os.path.join(ROOT, g["rocprof_summary"]))
+        else:
+            assert d["scaling"] == "weak"
     assert load("bench_default_k20.json")["steps"] == 20 and load("bench_default_k20.json")["warmup"] == 5
 
 
@@ -67,3 +94,10 @@ def test_committed_distributed_line():
     d = load("engine_1rank_shard8.json")        # the N > 1 line shape, forced at world = 1
     check_line(d)
     assert d["scaling"] == "strong" and d["config"]["engine"] in ("c++", "python") and "engine_note" in d["config"]
+    if round_of_lines() >= 4:
+        check_survey8d(d["roofline"])
+        # next to `value`: the same workload on one GPU and the ratio (None at world = 1: nothing to compare), and
+        # whether the exchanges ran overlapped
+        for k in ("value_1gpu_same_workload", "speedup_vs_1gpu_same_workload", "overlap"):
+            assert k in d, k
+        assert d["overlap"] in (0, 1)
