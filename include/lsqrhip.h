@@ -217,6 +217,12 @@ int lsqrhip_bench_kernel(lsqrhip_handle_t h, int which, int reps, double *avg_ms
  * entry points; option "op_batch" = iterations queued ahead of each stop poll (default 8). */
 typedef int (*lsqrhip_aprod_fn)(void *user, int mode, int m, int n, double *d_x, double *d_y, void *hip_stream);
 int lsqrhip_create_operator(int m, int n, lsqrhip_aprod_fn aprod, void *user, lsqrhip_handle_t *h);
+/* The same in the reference's REAL32 build (src/lsqr_kinds.F90:16-17 makes wp = real32 for the abstract class too,
+ * src/lsqr.f90:16-30): x, y and every work vector of the iteration are real32 arrays on the device; arithmetic in
+ * registers stays binary64.  Solve with lsqrhip_solve_f32 / lsqrhip_solve_device_f32, apply with lsqrhip_aprod_f32 /
+ * lsqrhip_aprod_device_f32.  (acheck / xcheck on the device exist in binary64 only.) */
+typedef int (*lsqrhip_aprod_f32_fn)(void *user, int mode, int m, int n, float *d_x, float *d_y, void *hip_stream);
+int lsqrhip_create_operator_f32(int m, int n, lsqrhip_aprod_f32_fn aprod, void *user, lsqrhip_handle_t *h);
 
 /* The reference's own test operator A = HY * D * HZ as a device operator, with the problem
  * generator `lstp` (test/lsqrtest_module.f90: hprod :385-403, aprod1 :319-343, aprod2 :353-377,
@@ -228,6 +234,11 @@ int lsqrhip_lstp_create(int m, int n, int nduplc, int npower, double damp, lsqrh
                         double *rnorm);
 int lsqrhip_lstp_vectors(lsqrhip_handle_t h, double *xtrue, double *b, double *d, double *hy, double *hz,
                          const double **d_b);
+/* ... generated in binary32 arithmetic, as the reference's test module is under -DREAL32, and held in real32 arrays on
+ * the device (an operator handle of the REAL32 kind; lsqrhip_lstp_vectors returns its vectors widened to double, d_b
+ * points at a float array). */
+int lsqrhip_lstp_create_f32(int m, int n, int nduplc, int npower, double damp, lsqrhip_handle_t *h, double *acond,
+                            double *rnorm);
 
 /* Options: "graph" (1 = hipGraph-captured iteration batches [default], 0 = eager
  * launches), "graph_iters" (iterations per captured batch, default 64), "time_kernels"

@@ -36,7 +36,8 @@ EXPORTS = [
     "lsqrhip_aprod_device_f32",
     "lsqrhip_create_sharded", "lsqrhip_create_sharded_f32", "lsqrhip_rccl_unique_id", "lsqrhip_shard_comm_init", "lsqrhip_shard_solve",
     "lsqrhip_gen_count", "lsqrhip_gen_coo",
-    "lsqrhip_create_operator", "lsqrhip_lstp_create", "lsqrhip_lstp_vectors",
+    "lsqrhip_create_operator", "lsqrhip_create_operator_f32", "lsqrhip_lstp_create", "lsqrhip_lstp_create_f32",
+    "lsqrhip_lstp_vectors",
 ]
 
 
@@ -127,6 +128,8 @@ def lib() -> C.CDLL:
     L.lsqrhip_create_operator.argtypes = [i32, i32, APROD_FN, vp, C.POINTER(vp)]
     L.lsqrhip_lstp_create.argtypes = [i32, i32, i32, i32, f64, C.POINTER(vp), C.POINTER(f64), C.POINTER(f64)]
     L.lsqrhip_lstp_vectors.argtypes = [vp, vp, vp, vp, vp, vp, C.POINTER(vp)]
+    L.lsqrhip_create_operator_f32.argtypes = [i32, i32, APROD_FN, vp, C.POINTER(vp)]
+    L.lsqrhip_lstp_create_f32.argtypes = [i32, i32, i32, i32, f64, C.POINTER(vp), C.POINTER(f64), C.POINTER(f64)]
     for name in EXPORTS:
         getattr(L, name)  # every declared symbol must be exported
     _lib = L

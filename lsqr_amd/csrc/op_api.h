@@ -23,8 +23,10 @@
 namespace lsqrhip {
 
 // target <- cy (target sy)   and   scaled <- src sx      (or: target untouched, scaled <- 0)
-__global__ __launch_bounds__(VEC_BLOCK) void k_op_prep(double *__restrict__ target, int64_t nt,
-                                                       double *__restrict__ scaled, const double *__restrict__ src,
+// (VT = float: the vectors of a REAL32 operator handle -- lsqrhip_create_operator_f32; the arithmetic stays binary64)
+template <typename VT>
+__global__ __launch_bounds__(VEC_BLOCK) void k_op_prep(VT *__restrict__ target, int64_t nt,
+                                                       VT *__restrict__ scaled, const VT *__restrict__ src,
                                                        int64_t ns, const SpmvCoef *__restrict__ coef,
                                                        const int *__restrict__ stop)
 {
@@ -33,11 +35,11 @@ __global__ __launch_bounds__(VEC_BLOCK) void k_op_prep(double *__restrict__ targ
     const int64_t stride = (int64_t)gridDim.x * VEC_BLOCK;
     const int64_t i0 = (int64_t)blockIdx.x * VEC_BLOCK + threadIdx.x;
     if (idle) {
-        for (int64_t i = i0; i < ns; i += stride) scaled[i] = 0.0;
+        for (int64_t i = i0; i < ns; i += stride) scaled[i] = (VT)0;
         return;
     }
-    for (int64_t i = i0; i < nt; i += stride) target[i] = cy * (target[i] * sy);
-    for (int64_t i = i0; i < ns; i += stride) scaled[i] = src[i] * sx;
+    for (int64_t i = i0; i < nt; i += stride) target[i] = (VT)(cy * ((double)target[i] * sy));
+    for (int64_t i = i0; i < ns; i += stride) scaled[i] = (VT)((double)src[i] * sx);
 }
 
 }  // namespace lsqrhip
@@ -50,27 +52,55 @@ static int op_call(H *h, int mode, double *d_x, double *d_y)
 }
 
 // One LSQR iteration on the operator, sequential schedule (src/lsqr.f90:673-852).
-static int op_iteration(H *h)
+template <typename VT>
+static int op_iteration_T(H *h)
 {
     LsqrState *st = h->d_state;
     hipStream_t s = h->stream;
     const int64_t m = h->m, n = h->n;
     const int gmn = vec_grid(std::max(m, n));
-    hipLaunchKernelGGL(k_op_prep, dim3(gmn), dim3(VEC_BLOCK), 0, s, h->U, m, h->opX, (const double *)h->V, n,
+    VT *U = reinterpret_cast<VT *>(h->U), *V = reinterpret_cast<VT *>(h->V);
+    VT *opX = reinterpret_cast<VT *>(h->opX), *opY = reinterpret_cast<VT *>(h->opY);
+    hipLaunchKernelGGL(k_op_prep<VT>, dim3(gmn), dim3(VEC_BLOCK), 0, s, U, m, opX, (const VT *)V, n,
                        (const SpmvCoef *)&st->c1, (const int *)&st->stop);
     RET(op_call(h, 1, h->opX, h->U));
-    hipLaunchKernelGGL(k_sumsq3, dim3(h->vgrid_m), dim3(VEC_BLOCK), 0, s, (const double *)h->U, m, h->partials);
+    hipLaunchKernelGGL(k_sumsq3<VT>, dim3(h->vgrid_m), dim3(VEC_BLOCK), 0, s, (const VT *)U, m, h->partials);
     hipLaunchKernelGGL((k_s1<true, true>), dim3(1), dim3(SC_BLOCK), 0, s, (const double *)h->partials, h->vgrid_m,
                        (const double *)nullptr, st);
-    hipLaunchKernelGGL(k_op_prep, dim3(gmn), dim3(VEC_BLOCK), 0, s, h->V, n, h->opY, (const double *)h->U, m,
+    hipLaunchKernelGGL(k_op_prep<VT>, dim3(gmn), dim3(VEC_BLOCK), 0, s, V, n, opY, (const VT *)U, m,
                        (const SpmvCoef *)&st->c2, (const int *)&st->stop);
     RET(op_call(h, 2, h->V, h->opY));
-    hipLaunchKernelGGL(k_sumsq3, dim3(h->vgrid_n), dim3(VEC_BLOCK), 0, s, (const double *)h->V, n, h->partials);
+    hipLaunchKernelGGL(k_sumsq3<VT>, dim3(h->vgrid_n), dim3(VEC_BLOCK), 0, s, (const VT *)V, n, h->partials);
     hipLaunchKernelGGL((k_s2<true, true>), dim3(1), dim3(SC_BLOCK), 0, s, (const double *)h->partials, h->vgrid_n,
                        (const double *)nullptr, st);
     launch_update(h, h->partials, nullptr, nullptr);
     hipLaunchKernelGGL(k_s3<true>, dim3(1), dim3(SC_BLOCK), 0, s, (const double *)h->partials, h->vgrid_n,
-                       (const double *)nullptr, st, (const void *)h->X, 0, h->d_log);
+                       (const double *)nullptr, st, (const void *)h->X, h->f32 ? 1 : 0, h->d_log);
+    HIPCHK(hipGetLastError());
+    return LSQRHIP_OK;
+}
+static int op_iteration(H *h) { return h->f32 ? op_iteration_T<float>(h) : op_iteration_T<double>(h); }
+
+// the start of a solve on the operator: beta = norm(u); u /= beta; v = A'u; alpha = norm(v); v /= alpha; w = v (:632-644)
+template <typename VT>
+static int op_start_T(H *h)
+{
+    hipStream_t s = h->stream;
+    const int m = h->m, n = h->n;
+    LsqrState *st = h->d_state;
+    VT *U = reinterpret_cast<VT *>(h->U), *V = reinterpret_cast<VT *>(h->V), *W = reinterpret_cast<VT *>(h->W);
+    hipLaunchKernelGGL(k_sumsq3<VT>, dim3(h->vgrid_m), dim3(VEC_BLOCK), 0, s, (const VT *)U, (int64_t)m, h->partials);
+    hipLaunchKernelGGL(k_s_init1<true>, dim3(1), dim3(SC_BLOCK), 0, s, (const double *)h->partials, h->vgrid_m,
+                       (const double *)nullptr, st, (NormSlot *)nullptr);
+    hipLaunchKernelGGL(k_op_prep<VT>, dim3(vec_grid(std::max(m, n))), dim3(VEC_BLOCK), 0, s, V, (int64_t)n,
+                       reinterpret_cast<VT *>(h->opY), (const VT *)U, (int64_t)m, (const SpmvCoef *)&st->c2,
+                       (const int *)h->d_zero);
+    RET(op_call(h, 2, h->V, h->opY));
+    hipLaunchKernelGGL(k_sumsq3<VT>, dim3(h->vgrid_n), dim3(VEC_BLOCK), 0, s, (const VT *)V, (int64_t)n, h->partials);
+    hipLaunchKernelGGL((k_s_init2<true, true>), dim3(1), dim3(SC_BLOCK), 0, s, (const double *)h->partials, h->vgrid_n,
+                       (const double *)nullptr, st);
+    hipLaunchKernelGGL(k_copy_scale<VT>, dim3(h->vgrid_n), dim3(VEC_BLOCK), 0, s, W, (const VT *)V, (int64_t)n,
+                       (const LsqrState *)st);
     HIPCHK(hipGetLastError());
     return LSQRHIP_OK;
 }
@@ -87,30 +117,17 @@ static int solve_op(H *h, const double *b, bool b_on_device, double damp, double
     RET(prepare_log(h, itnlim, want_log));
     RET(upload_initial_state(h, damp, atol, btol, conlim, itnlim, wantse, want_log));
     HIPCHK(hipMemcpyAsync(h->d_state, h->h_state, sizeof(LsqrState), hipMemcpyHostToDevice, s));
+    const size_t esz = h->f32 ? sizeof(float) : sizeof(double);   // (b, x, se: float arrays for a REAL32 operator handle)
     if (m > 0)
-        HIPCHK(hipMemcpyAsync(h->U, b, sizeof(double) * (size_t)m,
+        HIPCHK(hipMemcpyAsync(h->U, b, esz * (size_t)m,
                               b_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
     if (n > 0) {
-        HIPCHK(hipMemsetAsync(h->V, 0, sizeof(double) * (size_t)n, s));
-        HIPCHK(hipMemsetAsync(h->X, 0, sizeof(double) * (size_t)n, s));
-        HIPCHK(hipMemsetAsync(h->W, 0, sizeof(double) * (size_t)n, s));
-        if (wantse) HIPCHK(hipMemsetAsync(h->SE, 0, sizeof(double) * (size_t)n, s));
+        HIPCHK(hipMemsetAsync(h->V, 0, esz * (size_t)n, s));
+        HIPCHK(hipMemsetAsync(h->X, 0, esz * (size_t)n, s));
+        HIPCHK(hipMemsetAsync(h->W, 0, esz * (size_t)n, s));
+        if (wantse) HIPCHK(hipMemsetAsync(h->SE, 0, esz * (size_t)n, s));
     }
-    // beta = norm(u); u /= beta; v = A'u; alpha = norm(v); v /= alpha; w = v      (:632-644)
-    hipLaunchKernelGGL(k_sumsq3, dim3(h->vgrid_m), dim3(VEC_BLOCK), 0, s, (const double *)h->U, (int64_t)m,
-                       h->partials);
-    hipLaunchKernelGGL(k_s_init1<true>, dim3(1), dim3(SC_BLOCK), 0, s, (const double *)h->partials, h->vgrid_m,
-                       (const double *)nullptr, st, (NormSlot *)nullptr);
-    hipLaunchKernelGGL(k_op_prep, dim3(vec_grid(std::max(m, n))), dim3(VEC_BLOCK), 0, s, h->V, (int64_t)n, h->opY,
-                       (const double *)h->U, (int64_t)m, (const SpmvCoef *)&st->c2, (const int *)h->d_zero);
-    RET(op_call(h, 2, h->V, h->opY));
-    hipLaunchKernelGGL(k_sumsq3, dim3(h->vgrid_n), dim3(VEC_BLOCK), 0, s, (const double *)h->V, (int64_t)n,
-                       h->partials);
-    hipLaunchKernelGGL((k_s_init2<true, true>), dim3(1), dim3(SC_BLOCK), 0, s, (const double *)h->partials, h->vgrid_n,
-                       (const double *)nullptr, st);
-    hipLaunchKernelGGL(k_copy_scale, dim3(h->vgrid_n), dim3(VEC_BLOCK), 0, s, h->W, (const double *)h->V, (int64_t)n,
-                       (const LsqrState *)st);
-    HIPCHK(hipGetLastError());
+    RET(h->f32 ? op_start_T<float>(h) : op_start_T<double>(h));
 
     lsqrhip_timing_t &tm = h->timing;
     tm = lsqrhip_timing_t{};
@@ -134,17 +151,19 @@ static int solve_op(H *h, const double *b, bool b_on_device, double damp, double
                         false, t_host0);
 }
 
-extern "C" int lsqrhip_create_operator(int m, int n, lsqrhip_aprod_fn aprod, void *user, lsqrhip_handle_t *out)
+static int create_operator_any(int m, int n, lsqrhip_aprod_fn aprod, void *user, bool f32, lsqrhip_handle_t *out)
 {
     if (!aprod) return fail(LSQRHIP_ERR_ARG, "null aprod callback");
     H *h = nullptr;
     RET(new_handle(m, n, 0, &h));
     h->op = aprod;
     h->op_user = user;
+    h->f32 = h->io32 = f32;
+    const size_t esz = f32 ? sizeof(float) : sizeof(double);
     int rc = alloc_workspace(h);
     if (rc == LSQRHIP_OK) {
-        hipError_t e1 = hipMalloc((void **)&h->opX, sizeof(double) * (size_t)std::max(n, 1));
-        hipError_t e2 = hipMalloc((void **)&h->opY, sizeof(double) * (size_t)std::max(m, 1));
+        hipError_t e1 = hipMalloc((void **)&h->opX, esz * (size_t)std::max(n, 1));
+        hipError_t e2 = hipMalloc((void **)&h->opY, esz * (size_t)std::max(m, 1));
         if (e1 != hipSuccess || e2 != hipSuccess) rc = fail(LSQRHIP_ERR_ALLOC, "operator scratch vectors");
     }
     if (rc != LSQRHIP_OK) {
@@ -157,17 +176,44 @@ extern "C" int lsqrhip_create_operator(int m, int n, lsqrhip_aprod_fn aprod, voi
     return LSQRHIP_OK;
 }
 
+extern "C" int lsqrhip_create_operator(int m, int n, lsqrhip_aprod_fn aprod, void *user, lsqrhip_handle_t *out)
+{
+    return create_operator_any(m, n, aprod, user, false, out);
+}
+
+// The REAL32 build of the abstract class (src/lsqr_kinds.F90:16-17 applies to lsqr_solver too, src/lsqr.f90:16-30):
+// the operator's vectors -- and every work vector of the iteration -- are real32 arrays on the device; the callback
+// receives float pointers (in the same argument slots); solve with lsqrhip_solve_f32 / lsqrhip_solve_device_f32.
+extern "C" int lsqrhip_create_operator_f32(int m, int n, lsqrhip_aprod_f32_fn aprod, void *user, lsqrhip_handle_t *out)
+{
+    return create_operator_any(m, n, reinterpret_cast<lsqrhip_aprod_fn>(aprod), user, true, out);
+}
+
 // ---------------------------------------------------------------------------
 // The reference's test operator  A = HY * D * HZ  on the device
 // (test/lsqrtest_module.f90: hprod :385-403, aprod1 :319-343, aprod2 :353-377, lstp :422-505)
 // ---------------------------------------------------------------------------
 namespace lsqrhip {
 
+// partials[b] = sum over this workgroup's share of x[i] * y[i] (vec.h k_dot for either storage type)
+template <typename VT>
+__global__ __launch_bounds__(VEC_BLOCK) void k_dot_T(const VT *__restrict__ x, const VT *__restrict__ y, int64_t n,
+                                                     double *__restrict__ partials)
+{
+    __shared__ double red[VEC_BLOCK / WAVE];
+    double s = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * VEC_BLOCK;
+    for (int64_t i = (int64_t)blockIdx.x * VEC_BLOCK + threadIdx.x; i < n; i += stride) s += (double)x[i] * (double)y[i];
+    const double tot = block_sum<VEC_BLOCK>(s, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = tot;
+}
+
 // out_i = (x_i - (2 s) h_i) [* d_i for i < nd],  s = sum of `partials` (hprod, then the diagonal);
 // i in [nx, nout) is set to zero (the `w(i) = zero` loops of aprod1 / aprod2).
-__global__ __launch_bounds__(VEC_BLOCK) void k_hprod_scale(double *__restrict__ out, int64_t nout,
-                                                           const double *__restrict__ x, const double *__restrict__ hv,
-                                                           int64_t nx, const double *__restrict__ d, int64_t nd,
+template <typename VT>
+__global__ __launch_bounds__(VEC_BLOCK) void k_hprod_scale(VT *__restrict__ out, int64_t nout,
+                                                           const VT *__restrict__ x, const VT *__restrict__ hv,
+                                                           int64_t nx, const VT *__restrict__ d, int64_t nd,
                                                            const double *__restrict__ partials, int np)
 {
     __shared__ double red[VEC_BLOCK / WAVE + 1];
@@ -177,16 +223,17 @@ __global__ __launch_bounds__(VEC_BLOCK) void k_hprod_scale(double *__restrict__ 
     for (int64_t i = (int64_t)blockIdx.x * VEC_BLOCK + threadIdx.x; i < nout; i += stride) {
         double v = 0.0;
         if (i < nx) {
-            v = x[i] - s * hv[i];
-            if (i < nd) v = d[i] * v;
+            v = (double)x[i] - s * (double)hv[i];
+            if (i < nd) v = (double)d[i] * v;
         }
-        out[i] = v;
+        out[i] = (VT)v;
     }
 }
 
 // y_i <- y_i + (w_i - (2 s) h_i)        (second hprod of aprod1 / aprod2, then the add)
-__global__ __launch_bounds__(VEC_BLOCK) void k_hprod_add(double *__restrict__ y, const double *__restrict__ w,
-                                                         const double *__restrict__ hv, int64_t n,
+template <typename VT>
+__global__ __launch_bounds__(VEC_BLOCK) void k_hprod_add(VT *__restrict__ y, const VT *__restrict__ w,
+                                                         const VT *__restrict__ hv, int64_t n,
                                                          const double *__restrict__ partials, int np)
 {
     __shared__ double red[VEC_BLOCK / WAVE + 1];
@@ -194,57 +241,72 @@ __global__ __launch_bounds__(VEC_BLOCK) void k_hprod_add(double *__restrict__ y,
     s = s + s;
     const int64_t stride = (int64_t)gridDim.x * VEC_BLOCK;
     for (int64_t i = (int64_t)blockIdx.x * VEC_BLOCK + threadIdx.x; i < n; i += stride)
-        y[i] = y[i] + (w[i] - s * hv[i]);
+        y[i] = (VT)((double)y[i] + ((double)w[i] - s * (double)hv[i]));
 }
 
 }  // namespace lsqrhip
 
+// (device arrays of T = double or, for the REAL32 build, float; the host copies keep the generated values as doubles)
 struct LstpOp {
     int m = 0, n = 0, minmn = 0;
-    double *d = nullptr, *hy = nullptr, *hz = nullptr, *w = nullptr, *part = nullptr;
-    double *b = nullptr, *xtrue = nullptr;  // device copies of the generated right-hand side / true solution
+    bool f32 = false;
+    void *d = nullptr, *hy = nullptr, *hz = nullptr, *w = nullptr, *b = nullptr, *xtrue = nullptr;
+    double *part = nullptr;
     std::vector<double> h_d, h_hy, h_hz, h_b, h_xtrue;
 };
+
+template <typename VT>
+static int lstp_aprod_T(LstpOp *o, int mode, int m, int n, VT *x, VT *y, hipStream_t s)
+{
+    // mode 1: w = D HZ x (n -> m entries), y += HY w.   mode 2: w = D' HY y (m -> n), x += HZ w.
+    const int64_t nin = mode == 1 ? n : m, nout = mode == 1 ? m : n;
+    const VT *hin = (const VT *)(mode == 1 ? o->hz : o->hy), *hout = (const VT *)(mode == 1 ? o->hy : o->hz);
+    const VT *vin = mode == 1 ? x : y;
+    VT *vout = mode == 1 ? y : x;
+    VT *w = (VT *)o->w;
+    const int gin = vec_grid(nin), gout = vec_grid(nout);
+    if (std::is_same<VT, double>::value)   // (binary64: vec.h's k_dot, whose partial sums the goldens of round 2 hold)
+        hipLaunchKernelGGL(k_dot, dim3(gin), dim3(VEC_BLOCK), 0, s, (const double *)hin, (const double *)vin, nin, o->part);
+    else
+        hipLaunchKernelGGL(k_dot_T<VT>, dim3(gin), dim3(VEC_BLOCK), 0, s, hin, vin, nin, o->part);
+    hipLaunchKernelGGL(k_hprod_scale<VT>, dim3(gout), dim3(VEC_BLOCK), 0, s, w, nout, vin, hin, nin, (const VT *)o->d,
+                       (int64_t)o->minmn, (const double *)o->part, gin);
+    if (std::is_same<VT, double>::value)
+        hipLaunchKernelGGL(k_dot, dim3(gout), dim3(VEC_BLOCK), 0, s, (const double *)hout, (const double *)w, nout, o->part);
+    else
+        hipLaunchKernelGGL(k_dot_T<VT>, dim3(gout), dim3(VEC_BLOCK), 0, s, hout, (const VT *)w, nout, o->part);
+    hipLaunchKernelGGL(k_hprod_add<VT>, dim3(gout), dim3(VEC_BLOCK), 0, s, vout, (const VT *)w, hout, nout,
+                       (const double *)o->part, gout);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
 
 static int lstp_aprod(void *user, int mode, int m, int n, double *x, double *y, void *stream)
 {
     LstpOp *o = (LstpOp *)user;
-    hipStream_t s = (hipStream_t)stream;
-    // mode 1: w = D HZ x (n -> m entries), y += HY w.   mode 2: w = D' HY y (m -> n), x += HZ w.
-    const int64_t nin = mode == 1 ? n : m, nout = mode == 1 ? m : n;
-    const double *hin = mode == 1 ? o->hz : o->hy, *hout = mode == 1 ? o->hy : o->hz;
-    const double *vin = mode == 1 ? x : y;
-    double *vout = mode == 1 ? y : x;
-    const int gin = vec_grid(nin), gout = vec_grid(nout);
-    hipLaunchKernelGGL(k_dot, dim3(gin), dim3(VEC_BLOCK), 0, s, hin, vin, nin, o->part);
-    hipLaunchKernelGGL(k_hprod_scale, dim3(gout), dim3(VEC_BLOCK), 0, s, o->w, nout, vin, hin, nin, (const double *)o->d,
-                       (int64_t)o->minmn, (const double *)o->part, gin);
-    hipLaunchKernelGGL(k_dot, dim3(gout), dim3(VEC_BLOCK), 0, s, hout, (const double *)o->w, nout, o->part);
-    hipLaunchKernelGGL(k_hprod_add, dim3(gout), dim3(VEC_BLOCK), 0, s, vout, (const double *)o->w, hout, nout,
-                       (const double *)o->part, gout);
-    return hipGetLastError() == hipSuccess ? 0 : 1;
+    if (o->f32) return lstp_aprod_T<float>(o, mode, m, n, reinterpret_cast<float *>(x), reinterpret_cast<float *>(y), (hipStream_t)stream);
+    return lstp_aprod_T<double>(o, mode, m, n, x, y, (hipStream_t)stream);
 }
 
 static void lstp_free(void *user)
 {
     LstpOp *o = (LstpOp *)user;
-    for (double *p : {o->d, o->hy, o->hz, o->w, o->part, o->b, o->xtrue})
+    for (void *p : {o->d, o->hy, o->hz, o->w, (void *)o->part, o->b, o->xtrue})
         if (p) (void)hipFree(p);
     delete o;
 }
 
-// dnrm2 as the reference computes it (src/lsqrblas.f90:123-159: scaled sum of squares)
-static double host_dnrm2(const std::vector<double> &x)
+// dnrm2 as the reference computes it (src/lsqrblas.f90:123-159: scaled sum of squares), in the working precision T
+template <typename T>
+static T host_dnrm2(const std::vector<T> &x, size_t n)
 {
-    const size_t n = x.size();
-    if (n < 1) return 0.0;
+    if (n < 1) return (T)0;
     if (n == 1) return std::fabs(x[0]);
-    double scale = 0.0, ssq = 1.0;
+    T scale = 0, ssq = 1;
     for (size_t i = 0; i < n; ++i) {
-        if (x[i] != 0.0) {
-            const double absxi = std::fabs(x[i]);
+        if (x[i] != (T)0) {
+            const T absxi = std::fabs(x[i]);
             if (scale < absxi) {
-                ssq = 1.0 + ssq * (scale / absxi) * (scale / absxi);
+                ssq = (T)1 + ssq * (scale / absxi) * (scale / absxi);
                 scale = absxi;
             } else {
                 ssq = ssq + (absxi / scale) * (absxi / scale);
@@ -254,87 +316,96 @@ static double host_dnrm2(const std::vector<double> &x)
     return scale * std::sqrt(ssq);
 }
 
-static void host_hprod(const std::vector<double> &hz, size_t n, const double *x, double *y)
+template <typename T>
+static void host_hprod(const std::vector<T> &hz, size_t n, const T *x, T *y)
 {
-    double s = 0.0;
+    T s = 0;
     for (size_t i = 0; i < n; ++i) s = hz[i] * x[i] + s;
     s = s + s;
     for (size_t i = 0; i < n; ++i) y[i] = x[i] - s * hz[i];
 }
 
-// lstp (test/lsqrtest_module.f90:422-505), generated on the host in the reference's own
-// operation order (O(m + n) work, once), then uploaded.
-extern "C" int lsqrhip_lstp_create(int m, int n, int nduplc, int npower, double damp, lsqrhip_handle_t *out,
-                                   double *acond_out, double *rnorm_out)
+// lstp (test/lsqrtest_module.f90:422-505), generated on the host in the reference's own operation order AND working
+// precision T (O(m + n) work, once), then uploaded as T.
+template <typename T>
+static int lstp_create_T(int m, int n, int nduplc, int npower, double damp_, lsqrhip_handle_t *out, double *acond_out,
+                         double *rnorm_out)
 {
     if (m < 1 || n < 1 || nduplc < 1) return fail(LSQRHIP_ERR_ARG, "lstp needs m, n, nduplc >= 1");
     LstpOp *o = new LstpOp();
     o->m = m;
     o->n = n;
+    o->f32 = std::is_same<T, float>::value;
     const int minmn = std::min(m, n), maxmn = std::max(m, n);
     o->minmn = minmn;
-    std::vector<double> &d = o->h_d, &hy = o->h_hy, &hz = o->h_hz, &b = o->h_b, &x = o->h_xtrue;
-    d.resize(minmn); hy.resize(m); hz.resize(n); b.resize(m); x.resize(n);
-    std::vector<double> w(maxmn);
-    for (int j = 1; j <= n; ++j) x[j - 1] = j * 0.1;                            // test :151-154
-    const double fourpi = 4.0 * std::acos(-1.0);                                // :436
-    const double dampsq = damp * damp;
-    double alfa = fourpi / m, beta = fourpi / n;
-    for (int i = 1; i <= m; ++i) hy[i - 1] = std::sin(i * alfa);
-    for (int i = 1; i <= n; ++i) hz[i - 1] = std::cos(i * beta);
-    alfa = host_dnrm2(hy);
-    beta = host_dnrm2(hz);
-    for (double &v : hy) v = (-1.0 / alfa) * v;
-    for (double &v : hz) v = (-1.0 / beta) * v;
+    const T damp = (T)damp_;
+    std::vector<T> d(minmn), hy(m), hz(n), b(m), x(n), w(maxmn);
+    for (int j = 1; j <= n; ++j) x[j - 1] = (T)j * (T)0.1;                      // test :151-154
+    const T fourpi = (T)4 * std::acos((T)-1);                                   // :436
+    const T dampsq = damp * damp;
+    T alfa = fourpi / (T)m, beta = fourpi / (T)n;
+    for (int i = 1; i <= m; ++i) hy[i - 1] = std::sin((T)i * alfa);
+    for (int i = 1; i <= n; ++i) hz[i - 1] = std::cos((T)i * beta);
+    alfa = host_dnrm2(hy, (size_t)m);
+    beta = host_dnrm2(hz, (size_t)n);
+    for (T &v : hy) v = ((T)-1 / alfa) * v;
+    for (T &v : hz) v = ((T)-1 / beta) * v;
     for (int i = 1; i <= minmn; ++i) {                                          // :463-468
         const int j = (i - 1 + nduplc) / nduplc;
-        double t = (double)(j * nduplc);
-        t = t / minmn;
-        d[i - 1] = __builtin_powi(t, npower);
+        T t = (T)(j * nduplc);
+        t = t / (T)minmn;
+        T pw = 1;
+        for (int k = 0; k < npower; ++k) pw = pw * t;
+        d[i - 1] = std::is_same<T, double>::value ? (T)__builtin_powi((double)t, npower) : pw;
     }
-    const double acond = std::sqrt((d[minmn - 1] * d[minmn - 1] + dampsq) / (d[0] * d[0] + dampsq));
-    host_hprod(hz, n, x.data(), w.data());                                      // :478-484
-    for (int i = m; i < n; ++i) w[i] = 0.0;
+    const T acond = std::sqrt((d[minmn - 1] * d[minmn - 1] + dampsq) / (d[0] * d[0] + dampsq));
+    host_hprod(hz, (size_t)n, x.data(), w.data());                              // :478-484
+    for (int i = m; i < n; ++i) w[i] = 0;
     {
-        std::vector<double> t(w.begin(), w.begin() + n);
-        host_hprod(hz, n, t.data(), x.data());
+        std::vector<T> t(w.begin(), w.begin() + n);
+        host_hprod(hz, (size_t)n, t.data(), x.data());
     }
     for (int i = 0; i < minmn; ++i) w[i] = dampsq * w[i] / d[i];                // :489-491
-    for (int i = minmn; i < m; ++i) w[i] = 1.0;                                 // :496-498
+    for (int i = minmn; i < m; ++i) w[i] = 1;                                   // :496-498
     {
-        std::vector<double> t(w.begin(), w.begin() + m);
-        host_hprod(hy, m, t.data(), w.data());                                  // :500
+        std::vector<T> t(w.begin(), w.begin() + m);
+        host_hprod(hy, (size_t)m, t.data(), w.data());                          // :500
     }
-    const double rnorm = host_dnrm2(std::vector<double>(w.begin(), w.begin() + m));
+    const T rnorm = host_dnrm2(w, (size_t)m);
     for (int i = 0; i < m; ++i) b[i] = w[i];
     {   // b = r + A x   (aprod1, :319-343)
-        std::vector<double> t(maxmn), t2(maxmn);
-        host_hprod(hz, n, x.data(), t.data());
+        std::vector<T> t(maxmn), t2(maxmn);
+        host_hprod(hz, (size_t)n, x.data(), t.data());
         for (int i = 0; i < minmn; ++i) t[i] = d[i] * t[i];
-        for (int i = n; i < m; ++i) t[i] = 0.0;
-        host_hprod(hy, m, t.data(), t2.data());
+        for (int i = n; i < m; ++i) t[i] = 0;
+        host_hprod(hy, (size_t)m, t.data(), t2.data());
         for (int i = 0; i < m; ++i) b[i] = b[i] + t2[i];
     }
-    if (acond_out) *acond_out = acond;
-    if (rnorm_out) *rnorm_out = rnorm;
+    if (acond_out) *acond_out = (double)acond;
+    if (rnorm_out) *rnorm_out = (double)rnorm;
+    o->h_d.assign(d.begin(), d.end());
+    o->h_hy.assign(hy.begin(), hy.end());
+    o->h_hz.assign(hz.begin(), hz.end());
+    o->h_b.assign(b.begin(), b.end());
+    o->h_xtrue.assign(x.begin(), x.end());
 
     int rc = use_device();
     if (rc != LSQRHIP_OK) {
         delete o;
         return rc;
     }
-    auto up = [&](double **p, const std::vector<double> &v, size_t cap) -> bool {
-        if (hipMalloc((void **)p, sizeof(double) * std::max<size_t>(cap, 1)) != hipSuccess) return false;
-        return v.empty() || hipMemcpy(*p, v.data(), sizeof(double) * v.size(), hipMemcpyHostToDevice) == hipSuccess;
+    auto up = [&](void **p, const std::vector<T> &v, size_t cap) -> bool {
+        if (hipMalloc(p, sizeof(T) * std::max<size_t>(cap, 1)) != hipSuccess) return false;
+        return v.empty() || hipMemcpy(*p, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice) == hipSuccess;
     };
     const bool ok = up(&o->d, d, d.size()) && up(&o->hy, hy, hy.size()) && up(&o->hz, hz, hz.size()) &&
                     up(&o->b, b, b.size()) && up(&o->xtrue, x, x.size()) && up(&o->w, {}, (size_t)maxmn) &&
-                    up(&o->part, {}, (size_t)VEC_MAX_GRID);
+                    hipMalloc((void **)&o->part, sizeof(double) * VEC_MAX_GRID) == hipSuccess;
     if (!ok) {
         lstp_free(o);
         return fail(LSQRHIP_ERR_ALLOC, "lstp device vectors");
     }
-    rc = lsqrhip_create_operator(m, n, lstp_aprod, o, out);
+    rc = create_operator_any(m, n, lstp_aprod, o, o->f32, out);
     if (rc != LSQRHIP_OK) {
         lstp_free(o);
         return rc;
@@ -342,6 +413,20 @@ extern "C" int lsqrhip_lstp_create(int m, int n, int nduplc, int npower, double 
     (*out)->op_free = lstp_free;
     (*out)->op_is_lstp = true;
     return LSQRHIP_OK;
+}
+
+extern "C" int lsqrhip_lstp_create(int m, int n, int nduplc, int npower, double damp, lsqrhip_handle_t *out,
+                                   double *acond_out, double *rnorm_out)
+{
+    return lstp_create_T<double>(m, n, nduplc, npower, damp, out, acond_out, rnorm_out);
+}
+
+// ... in the reference's REAL32 build (src/lsqr_kinds.F90:16-17: wp = real32 in the test module too): the problem is
+// generated in binary32 arithmetic and lives in real32 arrays on the device (a handle of lsqrhip_create_operator_f32)
+extern "C" int lsqrhip_lstp_create_f32(int m, int n, int nduplc, int npower, double damp, lsqrhip_handle_t *out,
+                                       double *acond_out, double *rnorm_out)
+{
+    return lstp_create_T<float>(m, n, nduplc, npower, damp, out, acond_out, rnorm_out);
 }
 
 extern "C" int lsqrhip_lstp_vectors(lsqrhip_handle_t h, double *xtrue, double *b, double *d, double *hy, double *hz,
@@ -354,6 +439,6 @@ extern "C" int lsqrhip_lstp_vectors(lsqrhip_handle_t h, double *xtrue, double *b
     if (d) std::memcpy(d, o->h_d.data(), sizeof(double) * o->h_d.size());
     if (hy) std::memcpy(hy, o->h_hy.data(), sizeof(double) * o->h_hy.size());
     if (hz) std::memcpy(hz, o->h_hz.data(), sizeof(double) * o->h_hz.size());
-    if (d_b) *d_b = o->b;
+    if (d_b) *d_b = (const double *)o->b;   // (a float array for a handle of lsqrhip_lstp_create_f32)
     return LSQRHIP_OK;
 }

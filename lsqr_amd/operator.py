@@ -32,7 +32,9 @@ class lsqr_solver_device(lsqr_solver_ez):  # noqa: N801  (named after the refere
     the same signature.  `solve`, `aprod`, `acheck`, `xcheck`, `nout` logging work as on
     `lsqr_solver_ez`; `lsqr(...)` takes the reference's argument list (src/lsqr.f90:432-435)."""
 
-    def initialize(self, m, n, aprod=None, atol=None, btol=None, conlim=None, itnlim=None, nout=None):
+    def initialize(self, m, n, aprod=None, atol=None, btol=None, conlim=None, itnlim=None, nout=None, real32=False):
+        """real32=True: the reference's REAL32 build of the abstract class (src/lsqr_kinds.F90:16-17): the operator's
+        x and y -- and b, x, se of `solve` -- are float32 arrays (on the device: d_x, d_y point at floats)."""
         self._free()
         self._reset()
         self._user_aprod = aprod
@@ -49,8 +51,10 @@ class lsqr_solver_device(lsqr_solver_ez):  # noqa: N801  (named after the refere
         self._callback_error = None
         self._cb = capi.APROD_FN(trampoline)      # keep alive as long as the handle
         h = C.c_void_p()
-        check(lib().lsqrhip_create_operator(int(m), int(n), self._cb, None, C.byref(h)))
+        create = lib().lsqrhip_create_operator_f32 if real32 else lib().lsqrhip_create_operator
+        check(create(int(m), int(n), self._cb, None, C.byref(h)))
         self._h = h
+        self.real32 = bool(real32)
         self.m, self.n = int(m), int(n)
         for k, v in (("atol", atol), ("btol", btol), ("conlim", conlim)):
             if v is not None:
@@ -78,13 +82,16 @@ class lsqr_solver_device(lsqr_solver_ez):  # noqa: N801  (named after the refere
 class saunders_problem(lsqr_solver_ez):  # noqa: N801
     """P(m, n, nduplc, npower, damp) of the reference's test class as a device operator."""
 
-    def __init__(self, m, n, nduplc, npower, damp):
+    def __init__(self, m, n, nduplc, npower, damp, real32=False):
+        """real32=True: the problem generated in binary32 arithmetic and held in real32 arrays on the device, as the
+        reference's test module is under -DREAL32 (lsqrhip_lstp_create_f32)."""
         super().__init__()
         h = C.c_void_p()
         acond, rnorm = C.c_double(), C.c_double()
-        check(lib().lsqrhip_lstp_create(int(m), int(n), int(nduplc), int(npower), float(damp), C.byref(h),
-                                        C.byref(acond), C.byref(rnorm)))
+        create = lib().lsqrhip_lstp_create_f32 if real32 else lib().lsqrhip_lstp_create
+        check(create(int(m), int(n), int(nduplc), int(npower), float(damp), C.byref(h), C.byref(acond), C.byref(rnorm)))
         self._h = h
+        self.real32 = bool(real32)
         self.m, self.n = int(m), int(n)
         self.nduplc, self.npower, self.damp = int(nduplc), int(npower), float(damp)
         self.acond_lstp, self.rnorm_lstp = acond.value, rnorm.value
@@ -95,8 +102,27 @@ class saunders_problem(lsqr_solver_ez):  # noqa: N801
                                          self.hy.ctypes.data, self.hz.ctypes.data, C.byref(d_b)))
         self.d_b = d_b.value
 
+    def test32(self) -> dict:
+        """One problem of the suite under REAL32 (test/lsqrtest_module.f90:119-272 with wp = real32): LSQR with the
+        tolerances the test derives from the working precision, the error against xtrue.  (acheck / xcheck on the
+        device exist in binary64 only.)"""
+        m, n, damp = self.m, self.n, self.damp
+        eps32 = float(np.finfo(np.float32).eps)
+        self.atol = self.btol = float(np.float32(eps32) ** np.float32(0.99))          # :199-202
+        self.conlim = float(np.float32(1000.0) * np.float32(self.acond_lstp))
+        self.itnlim = 4 * (m + n + 50)
+        self.nout = 0
+        r = self.solve(self.b.astype(np.float32), damp, wantse=False)
+        x = r.x.astype(np.float64)
+        enorm = float(np.linalg.norm(x - self.xtrue) / (1.0 + np.linalg.norm(self.xtrue)))
+        return dict(m=m, n=n, nduplc=self.nduplc, npower=self.npower, damp=damp, istop=r.istop, itn=r.itn,
+                    anorm=r.anorm, acond=r.acond, rnorm=r.rnorm, arnorm=r.arnorm, xnorm=r.xnorm, x=r.x, enorm=enorm,
+                    success=enorm <= 0.001)
+
     def test(self, nout=None) -> dict:
         """One problem of the suite: test/lsqrtest_module.f90:119-272."""
+        if self.real32:
+            return self.test32()
         m, n, damp = self.m, self.n, self.damp
         w = nout.write if nout is not None else (lambda s: None)
         line = "-" * 34
@@ -145,10 +171,10 @@ SUITE = [(m, n, 40, p, 10.0 ** (-p - 6)) for (m, n) in ((2000, 1000), (1000, 100
 """lsqr_test (test/lsqrtest_module.f90:55-94): nbar = 1000, nduplc = 40, npower = ndamp = 2..7."""
 
 
-def run_suite(nout=None, problems=None) -> list[dict]:
+def run_suite(nout=None, problems=None, real32=False) -> list[dict]:
     """The reference's 18-problem suite on the device operator; `nout` (a text stream) receives
-    a log in the layout of the reference's LSQR.LIS."""
-    return [saunders_problem(*p).test(nout) for p in (problems or SUITE)]
+    a log in the layout of the reference's LSQR.LIS.  real32=True: the suite of the reference's REAL32 build."""
+    return [saunders_problem(*p, real32=real32).test(nout) for p in (problems or SUITE)]
 
 
 if __name__ == "__main__":      # python -m lsqr_amd.operator > LSQR.LIS
