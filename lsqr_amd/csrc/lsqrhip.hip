@@ -930,18 +930,13 @@ static int build_csb(hipStream_t s, const int *rowk, const int *colk, const doub
                      unsigned *hist, int *d_flags, Csr &out, const CsbPlan &plan = CsbPlan())
 {
     if (rows <= 0 || cols <= 0) return LSQRHIP_OK;
+    // (the two sort buffers are the caller's, 8 bytes per nonzero each: allocated here when a previous build released
+    //  them, released again while the layout's own arrays are filled -- see below -- and NOT handed back: the caller
+    //  allocates them again only if something still needs them, so that they never sit beside two finished layouts)
+    const size_t sort_bytes = sizeof(unsigned long long) * (size_t)std::max<int64_t>(nnz, 1);
+    if (!sbufA.p) HIPCHK(sbufA.alloc(sort_bytes));
+    if (!sbufB.p) HIPCHK(sbufB.alloc(sort_bytes));
     unsigned long long *bufA = sbufA.as<unsigned long long>(), *bufB = sbufB.as<unsigned long long>();
-    // (the two sort buffers are the caller's, 8 bytes per nonzero each, and are handed back allocated; while the
-    //  layout's own arrays are filled they are released -- see below)
-    struct Restore {
-        DevScratch &a, &b;
-        size_t bytes;
-        ~Restore()
-        {
-            if (!a.p) (void)a.alloc(bytes);
-            if (!b.p) (void)b.alloc(bytes);
-        }
-    } restore{sbufA, sbufB, sizeof(unsigned long long) * (size_t)std::max<int64_t>(nnz, 1)};
     const int g = (int)std::min<int64_t>(std::max<int64_t>((nnz + 255) / 256, 1), 4096);
     HIPCHK(hipMemsetAsync(d_flags, 0, 4 * sizeof(int), s));
     int got[4] = {0, 0, 0, 0};
@@ -1161,7 +1156,11 @@ static int build_csb(hipStream_t s, const int *rowk, const int *colk, const doub
     // 4 bytes, composed here from the block-order words (8) and the column-order positions (4).  The sort buffers and
     // the positions are released before the layout's 12 bytes per nonzero are allocated: the build peaks at the
     // triplets + 8 + 8 + 4 + 4 bytes per nonzero while it sorts and at the triplets + 4 + 12 while it fills, not at
-    // their sum (the literal config 3, 4e9 nonzeros: ~210 GB -> ~165 GB at the peak for a 96 GB result).
+    // their sum, and the sort buffers never sit beside two finished layouts (the literal config 3, 4e9 nonzeros: the
+    // peak beyond the 64 GB of triplets is A + 8 + 8 + 4 bytes per nonzero of the second build = 128 GB for a 96 GB result).
+    HIPCHK(hipStreamSynchronize(s));
+    if (sorted2 == bufA) sbufB.free_now();   // (the sort's other buffer is done with)
+    else sbufA.free_now();
     DevScratch s_perm;
     HIPCHK(s_perm.alloc(sizeof(unsigned) * (size_t)std::max<int64_t>(nnz, 1)));
     probe_mem();
@@ -1541,8 +1540,12 @@ static int finish_create(H *h, const int *d_irow, const int *d_icol, const doubl
     }
     if (csb_a) RET(build_csb(s, d_irow, d_icol, d_a, nnz, h->m, h->n, h->f32, LSQRHIP_ERR_IROW, LSQRHIP_ERR_ICOL, sA, sB, hist, d_flags, h->A, plan_a));
     if (csb_t) RET(build_csb(s, d_icol, d_irow, d_a, nnz, h->n, h->m, h->f32, LSQRHIP_ERR_ICOL, LSQRHIP_ERR_IROW, sA, sB, hist, d_flags, h->AT, plan_t));
-    if (!sA.p || !sB.p) return fail(LSQRHIP_ERR_ALLOC, lsqrhip_error_string(LSQRHIP_ERR_ALLOC));
-    bufA = sA.as<unsigned long long>();   // (build_csb releases the sort buffers while it fills and hands them back)
+    if (!(h->A.csb && h->AT.csb)) {   // (build_csb releases the sort buffers while it fills: a row-window / panel build needs them again)
+        const size_t sort_bytes = sizeof(unsigned long long) * (size_t)std::max<int64_t>(nnz, 1);
+        if (!sA.p) HIPCHK(sA.alloc(sort_bytes));
+        if (!sB.p) HIPCHK(sB.alloc(sort_bytes));
+    }
+    bufA = sA.as<unsigned long long>();
     bufB = sB.as<unsigned long long>();
     if (h->f32) {  // ... and row windows over the whole x where a block was too empty for them
         if (!h->A.csb) { pa = 1; pwa = h->n; xa = 0; }

@@ -367,7 +367,12 @@ static int overlap_setup(ShardGroup &g)
     for (ShardRank &q : g.r) {
         if (q.cstream) continue;
         HIPCHK(hipSetDevice(q.h->device));
-        HIPCHK(hipStreamCreateWithFlags(&q.cstream, hipStreamNonBlocking));
+        {   // (highest priority: the sweeps hold every CU with one LDS-filling workgroup each, so a send / receive
+            // kernel only finds room where a sweep's workgroup has just finished -- it should be first in line there)
+            int lo = 0, hi = 0;
+            (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+            HIPCHK(hipStreamCreateWithPriority(&q.cstream, hipStreamNonBlocking, hi));
+        }
         HIPCHK(hipEventCreateWithFlags(&q.evV, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&q.evRS, hipEventDisableTiming));
         q.evAG.assign((size_t)g.parts, nullptr);

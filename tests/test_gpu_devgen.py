@@ -126,6 +126,12 @@ def test_scale_properties_of_baseline_config3_at_its_literal_size():
     if free < 230e9:
         pytest.skip("needs ~210 GB of free HBM")
     dp = devgen.generate("random:4000000:1000000:1000", atol=1e-8, btol=1e-8, itnlim=40)
+    # (round 4: the build composes the fill's 4-byte permutation and releases its sort buffers before the layout is
+    # allocated, and never keeps them beside two finished layouts -- the peak beyond the 64 GB of triplets: 113 GB for
+    # a 96 GB result, 177 GB in all; round 3: ~210 GB)
+    peak, kept = dp.solver.get_option("build_peak_bytes"), dp.solver.get_option("build_kept_bytes")
+    print(f"build peak {peak / 1e9:.1f} GB beyond the 64 GB of triplets, kept {kept / 1e9:.1f} GB")
+    assert kept < 100e9 and peak < 125e9
     s = dp.solver
     info = s.info()
     assert dp.nnz == 4_000_000_000
@@ -215,7 +221,7 @@ def test_scale_properties_of_one_rank_of_config4_at_1000_per_row():
     assert info["xlds"] == 3 and info["xlds_t"] == 3
     peak, kept = s.get_option("build_peak_bytes"), s.get_option("build_kept_bytes")
     print(f"build peak {peak / 1e9:.1f} GB beyond the 20 GB of triplets, kept {kept / 1e9:.1f} GB")
-    assert kept < 33e9 and peak < 80e9
+    assert kept < 33e9 and peak < 45e9
     inform, err = s.acheck()
     assert inform == 0 and err < 1e-12
     xa = P.u64_to_unit(P.rng_u64(1, 9, np.arange(dp.n, dtype=np.uint64)))
