@@ -153,6 +153,12 @@ int lsqrhip_acheck(lsqrhip_handle_t h, double eps, int *inform, double *relerr);
 /* u[m], v[n], w[n] receive r = b - Ax, A'r, A'r - damp^2 x (may be NULL). tests[3]. */
 int lsqrhip_xcheck(lsqrhip_handle_t h, double anorm, double damp, double eps, const double *b,
                    const double *x, double *u, double *v, double *w, int *inform, double *tests);
+/* ... for REAL32 handles (matrix handles of lsqrhip_create_f32, operator handles of lsqrhip_create_operator_f32):
+ * real32 vectors on the device and at the boundary, binary64 arithmetic between them (src/lsqr.f90:908-994,
+ * 1015-1154 under src/lsqr_kinds.F90:16-17). */
+int lsqrhip_acheck_f32(lsqrhip_handle_t h, double eps, int *inform, double *relerr);
+int lsqrhip_xcheck_f32(lsqrhip_handle_t h, double anorm, double damp, double eps, const float *b, const float *x,
+                       float *u, float *v, float *w, int *inform, double *tests);
 
 /* ---------------------------------------------------------------------- */
 /* iteration log (nout /= 0)         replaces src/lsqr.f90:813-837          */
@@ -220,7 +226,7 @@ int lsqrhip_create_operator(int m, int n, lsqrhip_aprod_fn aprod, void *user, ls
 /* The same in the reference's REAL32 build (src/lsqr_kinds.F90:16-17 makes wp = real32 for the abstract class too,
  * src/lsqr.f90:16-30): x, y and every work vector of the iteration are real32 arrays on the device; arithmetic in
  * registers stays binary64.  Solve with lsqrhip_solve_f32 / lsqrhip_solve_device_f32, apply with lsqrhip_aprod_f32 /
- * lsqrhip_aprod_device_f32.  (acheck / xcheck on the device exist in binary64 only.) */
+ * lsqrhip_aprod_device_f32, check with lsqrhip_acheck_f32 / lsqrhip_xcheck_f32. */
 typedef int (*lsqrhip_aprod_f32_fn)(void *user, int mode, int m, int n, float *d_x, float *d_y, void *hip_stream);
 int lsqrhip_create_operator_f32(int m, int n, lsqrhip_aprod_f32_fn aprod, void *user, lsqrhip_handle_t *h);
 

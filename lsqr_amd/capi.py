@@ -37,7 +37,7 @@ EXPORTS = [
     "lsqrhip_create_sharded", "lsqrhip_create_sharded_f32", "lsqrhip_rccl_unique_id", "lsqrhip_shard_comm_init", "lsqrhip_shard_solve",
     "lsqrhip_gen_count", "lsqrhip_gen_coo",
     "lsqrhip_create_operator", "lsqrhip_create_operator_f32", "lsqrhip_lstp_create", "lsqrhip_lstp_create_f32",
-    "lsqrhip_lstp_vectors",
+    "lsqrhip_lstp_vectors", "lsqrhip_acheck_f32", "lsqrhip_xcheck_f32",
 ]
 
 
@@ -128,6 +128,8 @@ def lib() -> C.CDLL:
     L.lsqrhip_create_operator.argtypes = [i32, i32, APROD_FN, vp, C.POINTER(vp)]
     L.lsqrhip_lstp_create.argtypes = [i32, i32, i32, i32, f64, C.POINTER(vp), C.POINTER(f64), C.POINTER(f64)]
     L.lsqrhip_lstp_vectors.argtypes = [vp, vp, vp, vp, vp, vp, C.POINTER(vp)]
+    L.lsqrhip_acheck_f32.argtypes = [vp, f64, vp, vp]
+    L.lsqrhip_xcheck_f32.argtypes = [vp, f64, f64, f64, vp, vp, vp, vp, vp, vp, vp]
     L.lsqrhip_create_operator_f32.argtypes = [i32, i32, APROD_FN, vp, C.POINTER(vp)]
     L.lsqrhip_lstp_create_f32.argtypes = [i32, i32, i32, i32, f64, C.POINTER(vp), C.POINTER(f64), C.POINTER(f64)]
     for name in EXPORTS:

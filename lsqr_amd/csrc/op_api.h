@@ -442,3 +442,166 @@ extern "C" int lsqrhip_lstp_vectors(lsqrhip_handle_t h, double *xtrue, double *b
     if (d_b) *d_b = (const double *)o->b;   // (a float array for a handle of lsqrhip_lstp_create_f32)
     return LSQRHIP_OK;
 }
+
+// ---------------------------------------------------------------------------
+// acheck / xcheck for REAL32 handles -- matrix handles of lsqrhip_create_f32 and operator handles of
+// lsqrhip_create_operator_f32 alike (src/lsqr.f90:908-994, 1015-1154 with wp = real32: real32 vectors, here
+// with binary64 arithmetic between them, like everything else of the REAL32 build)
+// ---------------------------------------------------------------------------
+namespace lsqrhip {
+
+__global__ __launch_bounds__(VEC_BLOCK) void k_f32_acheck_fill(float *__restrict__ x, int64_t n, int inverse)
+{
+    const int64_t stride = (int64_t)gridDim.x * VEC_BLOCK;
+    for (int64_t i = (int64_t)blockIdx.x * VEC_BLOCK + threadIdx.x; i < n; i += stride) {
+        const double s = sqrt((double)(i + 2));
+        x[i] = (float)(inverse ? 1.0 / s : s);
+    }
+}
+__global__ __launch_bounds__(VEC_BLOCK) void k_f32_scale(float *__restrict__ x, int64_t n, double a)
+{
+    const int64_t stride = (int64_t)gridDim.x * VEC_BLOCK;
+    for (int64_t i = (int64_t)blockIdx.x * VEC_BLOCK + threadIdx.x; i < n; i += stride) x[i] = (float)(a * (double)x[i]);
+}
+__global__ __launch_bounds__(VEC_BLOCK) void k_f32_axpy(float *__restrict__ y, const float *__restrict__ x, int64_t n, double a)
+{
+    const int64_t stride = (int64_t)gridDim.x * VEC_BLOCK;
+    for (int64_t i = (int64_t)blockIdx.x * VEC_BLOCK + threadIdx.x; i < n; i += stride)
+        y[i] = (float)((double)y[i] + a * (double)x[i]);
+}
+
+}  // namespace lsqrhip
+
+struct DevVecF {
+    float *p = nullptr;
+    ~DevVecF()
+    {
+        if (p) (void)hipFree(p);
+    }
+    int alloc(int64_t n)
+    {
+        hipError_t e = hipMalloc((void **)&p, sizeof(float) * (size_t)std::max<int64_t>(n, 1));
+        return e == hipSuccess ? LSQRHIP_OK : fail(LSQRHIP_ERR_ALLOC, hipGetErrorString(e));
+    }
+};
+
+// sum_i x_i y_i of two real32 device vectors, accumulated in binary64 in a fixed tree (x == y: the square of the
+// norm -- real32 entries cannot overflow a binary64 square, so no scaling pass is needed)
+static int f32_dot(H *h, int64_t n, const float *d_x, const float *d_y, double *result)
+{
+    *result = 0.0;
+    if (n <= 0) return LSQRHIP_OK;
+    const int g = vec_grid(n);
+    hipLaunchKernelGGL(k_dot_T<float>, dim3(g), dim3(VEC_BLOCK), 0, h->stream, d_x, d_y, n, h->partials);
+    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(VEC_BLOCK), 0, h->stream, (const double *)h->partials, g, h->d_scalar);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(result, h->d_scalar, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return LSQRHIP_OK;
+}
+static int f32_nrm2(H *h, int64_t n, const float *d_x, double *result)
+{
+    RET(f32_dot(h, n, d_x, d_x, result));
+    *result = std::sqrt(*result);
+    return LSQRHIP_OK;
+}
+static int f32_scale(H *h, int64_t n, double a, float *d_x)
+{
+    if (n > 0) hipLaunchKernelGGL(k_f32_scale, dim3(vec_grid(n)), dim3(VEC_BLOCK), 0, h->stream, d_x, n, a);
+    HIPCHK(hipGetLastError());
+    return LSQRHIP_OK;
+}
+
+extern "C" int lsqrhip_acheck_f32(lsqrhip_handle_t h, double eps, int *inform, double *relerr)
+{
+    if (h && h->group) return fail(LSQRHIP_ERR_ARG, "not available on a handle sharded over several GPUs (lsqrhip_create_sharded)");
+    if (!h || !inform) return fail(LSQRHIP_ERR_NOT_INIT, lsqrhip_error_string(LSQRHIP_ERR_NOT_INIT));
+    if (!h->f32) return fail(LSQRHIP_ERR_ARG, "not a REAL32 handle (binary64 vectors on the device: lsqrhip_acheck)");
+    HIPCHK(hipSetDevice(h->device));
+    const int64_t m = h->m, n = h->n;
+    hipStream_t s = h->stream;
+    DevVecF v, w, x, y;
+    RET(v.alloc(n)); RET(w.alloc(m)); RET(x.alloc(n)); RET(y.alloc(m));
+    const double tol = std::pow(eps, 0.5);                                      // src/lsqr.f90:939
+    hipLaunchKernelGGL(k_f32_acheck_fill, dim3(vec_grid(n)), dim3(VEC_BLOCK), 0, s, x.p, n, 0);   // :946-950
+    hipLaunchKernelGGL(k_f32_acheck_fill, dim3(vec_grid(m)), dim3(VEC_BLOCK), 0, s, y.p, m, 1);   // :952-956
+    double alfa = 0, beta = 0;
+    RET(f32_nrm2(h, n, x.p, &alfa));                                            // :958-961
+    RET(f32_nrm2(h, m, y.p, &beta));
+    RET(f32_scale(h, n, 1.0 / alfa, x.p));
+    RET(f32_scale(h, m, 1.0 / beta, y.p));
+    if (m > 0) HIPCHK(hipMemcpyAsync(w.p, y.p, sizeof(float) * (size_t)m, hipMemcpyDeviceToDevice, s));   // :969-972
+    if (n > 0) HIPCHK(hipMemcpyAsync(v.p, x.p, sizeof(float) * (size_t)n, hipMemcpyDeviceToDevice, s));
+    RET(lsqrhip_aprod_device_f32(h, 1, x.p, w.p));
+    RET(lsqrhip_aprod_device_f32(h, 2, v.p, y.p));
+    RET(f32_dot(h, m, y.p, w.p, &alfa));                                        // :976-980
+    RET(f32_dot(h, n, x.p, v.p, &beta));
+    const double test1 = std::fabs(alfa - beta);
+    const double test2 = 1.0 + std::fabs(alfa) + std::fabs(beta);
+    const double test3 = test1 / test2;
+    if (relerr) *relerr = test3;
+    *inform = test3 <= tol ? 0 : 1;                                             // :984-992
+    return LSQRHIP_OK;
+}
+
+extern "C" int lsqrhip_xcheck_f32(lsqrhip_handle_t h, double anorm, double damp, double eps, const float *b,
+                                  const float *x, float *u, float *v, float *w, int *inform, double *tests)
+{
+    if (h && h->group) return fail(LSQRHIP_ERR_ARG, "not available on a handle sharded over several GPUs (lsqrhip_create_sharded)");
+    if (!h || !inform || !tests) return fail(LSQRHIP_ERR_NOT_INIT, lsqrhip_error_string(LSQRHIP_ERR_NOT_INIT));
+    if (!h->f32) return fail(LSQRHIP_ERR_ARG, "not a REAL32 handle (binary64 vectors on the device: lsqrhip_xcheck)");
+    HIPCHK(hipSetDevice(h->device));
+    const int64_t m = h->m, n = h->n;
+    hipStream_t s = h->stream;
+    DevVecF db, dx, du, dv, dw;
+    RET(db.alloc(m)); RET(dx.alloc(n)); RET(du.alloc(m)); RET(dv.alloc(n)); RET(dw.alloc(n));
+    if (m > 0) HIPCHK(hipMemcpyAsync(db.p, b, sizeof(float) * (size_t)m, hipMemcpyHostToDevice, s));
+    if (n > 0) HIPCHK(hipMemcpyAsync(dx.p, x, sizeof(float) * (size_t)n, hipMemcpyHostToDevice, s));
+    const double dampsq = damp * damp, tol = std::pow(eps, 0.5);
+    if (m > 0) HIPCHK(hipMemcpyAsync(du.p, db.p, sizeof(float) * (size_t)m, hipMemcpyDeviceToDevice, s));   // :1073-1076
+    RET(f32_scale(h, m, -1.0, du.p));
+    RET(lsqrhip_aprod_device_f32(h, 1, dx.p, du.p));
+    RET(f32_scale(h, m, -1.0, du.p));
+    if (n > 0) HIPCHK(hipMemsetAsync(dv.p, 0, sizeof(float) * (size_t)n, s));  // :1080-1083
+    RET(lsqrhip_aprod_device_f32(h, 2, dv.p, du.p));
+    if (n > 0) HIPCHK(hipMemcpyAsync(dw.p, dv.p, sizeof(float) * (size_t)n, hipMemcpyDeviceToDevice, s));   // :1089-1094
+    if (damp != 0.0 && n > 0) {
+        hipLaunchKernelGGL(k_f32_axpy, dim3(vec_grid(n)), dim3(VEC_BLOCK), 0, s, dw.p, (const float *)dx.p, n, -dampsq);
+        HIPCHK(hipGetLastError());
+    }
+    double bnorm, xnorm, rho1, sigma1, rho2, sigma2;
+    RET(f32_nrm2(h, m, db.p, &bnorm));                                          // :1098-1101
+    RET(f32_nrm2(h, n, dx.p, &xnorm));
+    RET(f32_nrm2(h, m, du.p, &rho1));
+    RET(f32_nrm2(h, n, dv.p, &sigma1));
+    if (damp == 0.0) {                                                          // :1110-1124
+        rho2 = rho1;
+        sigma2 = sigma1;
+    } else {
+        rho2 = std::sqrt(rho1 * rho1 + dampsq * (xnorm * xnorm));
+        RET(f32_nrm2(h, n, dw.p, &sigma2));
+    }
+    double test1, test2, test3;
+    if (bnorm == 0.0 && xnorm == 0.0) {                                         // :1129-1144
+        *inform = 0;
+        test1 = test2 = test3 = 0.0;
+    } else {
+        *inform = 4;
+        test1 = rho1 / (bnorm + anorm * xnorm);
+        test2 = 0.0;
+        if (rho1 > 0.0) test2 = sigma1 / (anorm * rho1);
+        test3 = test2;
+        if (rho2 > 0.0) test3 = sigma2 / (anorm * rho2);
+        if (test3 <= tol) *inform = 3;
+        if (test2 <= tol) *inform = 2;
+        if (test1 <= tol) *inform = 1;
+    }
+    tests[0] = test1;
+    tests[1] = test2;
+    tests[2] = test3;
+    if (u && m > 0) HIPCHK(hipMemcpyAsync(u, du.p, sizeof(float) * (size_t)m, hipMemcpyDeviceToHost, s));
+    if (v && n > 0) HIPCHK(hipMemcpyAsync(v, dv.p, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, s));
+    if (w && n > 0) HIPCHK(hipMemcpyAsync(w, dw.p, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return LSQRHIP_OK;
+}

@@ -16,6 +16,29 @@
 !!
 !! An object that has been initialised must stay where it is (declare it `target`; do not copy
 !! it): the library calls back into that very object.
+!!
+!! Precision (src/lsqr_kinds.F90:16-24 applies to the abstract class too): this file is preprocessed.  Under
+!! -DREAL32 (wp = real32) it binds the library's REAL32 operator entry points -- lsqrhip_create_operator_f32,
+!! lsqrhip_lstp_create_f32, lsqrhip_solve_f32, lsqrhip_acheck_f32, lsqrhip_xcheck_f32 -- so that x, y of
+!! `aprod_device` and every work vector of the iteration are real32 arrays ON THE DEVICE (binary64 registers), as
+!! `lsqr_module` does for the EZ class; otherwise the binary64 ones.
+#ifdef REAL32
+#define CWP c_float
+#define NAME_CREATE_OPERATOR 'lsqrhip_create_operator_f32'
+#define NAME_LSTP_CREATE 'lsqrhip_lstp_create_f32'
+#define NAME_SOLVE 'lsqrhip_solve_f32'
+#define NAME_ACHECK 'lsqrhip_acheck_f32'
+#define NAME_XCHECK 'lsqrhip_xcheck_f32'
+#define NAME_APROD_DEVICE 'lsqrhip_aprod_device_f32'
+#else
+#define CWP c_double
+#define NAME_CREATE_OPERATOR 'lsqrhip_create_operator'
+#define NAME_LSTP_CREATE 'lsqrhip_lstp_create'
+#define NAME_SOLVE 'lsqrhip_solve'
+#define NAME_ACHECK 'lsqrhip_acheck'
+#define NAME_XCHECK 'lsqrhip_xcheck'
+#define NAME_APROD_DEVICE 'lsqrhip_aprod_device'
+#endif
 module lsqr_device_module
    use, intrinsic :: iso_c_binding
    use lsqr_kinds
@@ -67,7 +90,7 @@ module lsqr_device_module
    end interface
 
    interface
-      function lsqrhip_create_operator(m, n, aprod, user, h) bind(C, name='lsqrhip_create_operator') result(rc)
+      function lsqrhip_create_operator(m, n, aprod, user, h) bind(C, name=NAME_CREATE_OPERATOR) result(rc)
          import :: c_int, c_ptr, c_funptr
          integer(c_int), value :: m, n
          type(c_funptr), value :: aprod
@@ -76,7 +99,7 @@ module lsqr_device_module
          integer(c_int) :: rc
       end function
       function lsqrhip_lstp_create(m, n, nduplc, npower, damp, h, acond, rnorm) &
-         bind(C, name='lsqrhip_lstp_create') result(rc)
+         bind(C, name=NAME_LSTP_CREATE) result(rc)
          import :: c_int, c_double, c_ptr
          integer(c_int), value :: m, n, nduplc, npower
          real(c_double), value :: damp
@@ -97,19 +120,19 @@ module lsqr_device_module
          integer(c_int) :: rc
       end function
       function lsqrhip_solve(h, b, damp, atol, btol, conlim, itnlim, wantse, want_log, x, se, istop, itn, &
-                             anorm, acond, rnorm, arnorm, xnorm) bind(C, name='lsqrhip_solve') result(rc)
-         import :: c_int, c_double, c_ptr
+                             anorm, acond, rnorm, arnorm, xnorm) bind(C, name=NAME_SOLVE) result(rc)
+         import :: c_int, c_double, c_float, c_ptr
          type(c_ptr), value :: h
-         real(c_double), intent(in) :: b(*)
+         real(CWP), intent(in) :: b(*)
          real(c_double), value :: damp, atol, btol, conlim
          integer(c_int), value :: itnlim, wantse, want_log
-         real(c_double), intent(out) :: x(*)
-         real(c_double), intent(inout) :: se(*)
+         real(CWP), intent(out) :: x(*)
+         real(CWP), intent(inout) :: se(*)
          integer(c_int), intent(out) :: istop, itn
          real(c_double), intent(out) :: anorm, acond, rnorm, arnorm, xnorm
          integer(c_int) :: rc
       end function
-      function lsqrhip_acheck(h, eps, inform, relerr) bind(C, name='lsqrhip_acheck') result(rc)
+      function lsqrhip_acheck(h, eps, inform, relerr) bind(C, name=NAME_ACHECK) result(rc)
          import :: c_int, c_double, c_ptr
          type(c_ptr), value :: h
          real(c_double), value :: eps
@@ -118,12 +141,12 @@ module lsqr_device_module
          integer(c_int) :: rc
       end function
       function lsqrhip_xcheck(h, anorm, damp, eps, b, x, u, v, w, inform, tests) &
-         bind(C, name='lsqrhip_xcheck') result(rc)
-         import :: c_int, c_double, c_ptr
+         bind(C, name=NAME_XCHECK) result(rc)
+         import :: c_int, c_double, c_float, c_ptr
          type(c_ptr), value :: h
          real(c_double), value :: anorm, damp, eps
-         real(c_double), intent(in) :: b(*), x(*)
-         real(c_double), intent(out) :: u(*), v(*), w(*)
+         real(CWP), intent(in) :: b(*), x(*)
+         real(CWP), intent(out) :: u(*), v(*), w(*)
          integer(c_int), intent(out) :: inform
          real(c_double), intent(out) :: tests(3)
          integer(c_int) :: rc
@@ -133,7 +156,7 @@ module lsqr_device_module
    !> Library calls a Fortran user may want inside `aprod_device` (e.g. to apply another handle's
    !! product on the same stream).
    interface
-      function lsqrhip_aprod_device(h, mode, d_x, d_y) bind(C, name='lsqrhip_aprod_device') result(rc)
+      function lsqrhip_aprod_device(h, mode, d_x, d_y) bind(C, name=NAME_APROD_DEVICE) result(rc)
          import :: c_int, c_ptr
          type(c_ptr), value :: h, d_x, d_y
          integer(c_int), value :: mode
@@ -222,7 +245,7 @@ contains
       real(wp), intent(out) :: anorm, acond, rnorm, arnorm, xnorm
       integer(c_int) :: istop_, itn_
       real(c_double) :: sc(5)
-      real(c_double), allocatable :: bl(:), xl(:), sel(:)
+      real(CWP), allocatable :: bl(:), xl(:), sel(:)
       if (.not. c_associated(me%handle) .or. m /= me%m .or. n /= me%n) call lsqr_check_status(4_c_int)
       allocate (bl(max(m, 1)), xl(max(n, 1)), sel(max(n, 1)))
       bl(1:m) = u(1:m)
@@ -278,7 +301,7 @@ contains
       real(wp), intent(out) :: test1, test2, test3
       integer(c_int) :: inf
       real(c_double) :: tests(3)
-      real(c_double), allocatable :: bl(:), xl(:), ul(:), vl(:), wl(:)
+      real(CWP), allocatable :: bl(:), xl(:), ul(:), vl(:), wl(:)
       if (.not. c_associated(me%handle) .or. m /= me%m .or. n /= me%n) call lsqr_check_status(4_c_int)
       allocate (bl(max(m, 1)), xl(max(n, 1)), ul(max(m, 1)), vl(max(n, 1)), wl(max(n, 1)))
       bl(1:m) = b

@@ -36,8 +36,12 @@ program test_device_operator
    use lsqr_device_module
    use wrapped_operator
    implicit none
-   integer, parameter :: m = 2000, n = 1000, nduplc = 40, npower = 3
-   real(wp), parameter :: damp = 1.0e-9_wp
+   ! (the same source serves the REAL32 build -- lib/test_device_operator32, -DREAL32 modules: the operator's vectors
+   !  are real32 arrays on the device there --, with the suite's first problem, the one real32 can still solve to the
+   !  test's 1e-3: P(2000, 1000, 40, 2, 1e-8); binary64: P(2000, 1000, 40, 3, 1e-9))
+   logical, parameter :: single = epsilon(one) > 1.0e-10_wp
+   integer, parameter :: m = 2000, n = 1000, nduplc = 40, npower = merge(2, 3, single)
+   real(wp), parameter :: damp = merge(1.0e-8_wp, 1.0e-9_wp, single)
    type(lsqr_test_problem_device), target :: p
    type(wrapped_solver), target :: ws
    real(wp) :: u(m), v(n), w(n), x(n), x2(n), se(1), y(m), wm(m), vv(n), xx(n)
@@ -74,6 +78,6 @@ program test_device_operator
    if (ws%calls < 2*itn + 1) error stop 'TEST FAILED: callback not used'
    call ws%destroy()
    call p%destroy()
-   if (istop /= 3 .or. enorm > 1.0e-6_wp) error stop 'TEST FAILED'
+   if (istop /= 3 .or. enorm > merge(1.0e-3_wp, 1.0e-6_wp, single)) error stop 'TEST FAILED'
    write (*, '(A)') 'DEVICE OPERATOR TESTS PASSED'
 end program test_device_operator

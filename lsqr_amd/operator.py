@@ -103,21 +103,23 @@ class saunders_problem(lsqr_solver_ez):  # noqa: N801
         self.d_b = d_b.value
 
     def test32(self) -> dict:
-        """One problem of the suite under REAL32 (test/lsqrtest_module.f90:119-272 with wp = real32): LSQR with the
-        tolerances the test derives from the working precision, the error against xtrue.  (acheck / xcheck on the
-        device exist in binary64 only.)"""
+        """One problem of the suite under REAL32 (test/lsqrtest_module.f90:119-272 with wp = real32): acheck, LSQR with
+        the tolerances the test derives from the working precision, xcheck, the error against xtrue."""
         m, n, damp = self.m, self.n, self.damp
         eps32 = float(np.finfo(np.float32).eps)
+        ainform, aerr = self.acheck(eps32)                                             # :184
         self.atol = self.btol = float(np.float32(eps32) ** np.float32(0.99))          # :199-202
         self.conlim = float(np.float32(1000.0) * np.float32(self.acond_lstp))
         self.itnlim = 4 * (m + n + 50)
         self.nout = 0
         r = self.solve(self.b.astype(np.float32), damp, wantse=False)
+        xinform, tests, *_ = self.xcheck(r.anorm, damp, self.b.astype(np.float32), r.x, eps32)   # :218-220
         x = r.x.astype(np.float64)
         enorm = float(np.linalg.norm(x - self.xtrue) / (1.0 + np.linalg.norm(self.xtrue)))
-        return dict(m=m, n=n, nduplc=self.nduplc, npower=self.npower, damp=damp, istop=r.istop, itn=r.itn,
-                    anorm=r.anorm, acond=r.acond, rnorm=r.rnorm, arnorm=r.arnorm, xnorm=r.xnorm, x=r.x, enorm=enorm,
-                    success=enorm <= 0.001)
+        return dict(m=m, n=n, nduplc=self.nduplc, npower=self.npower, damp=damp, acheck_inform=ainform, acheck_err=aerr,
+                    istop=r.istop, itn=r.itn, anorm=r.anorm, acond=r.acond, rnorm=r.rnorm, arnorm=r.arnorm,
+                    xnorm=r.xnorm, xcheck_inform=xinform, test1=tests[0], test2=tests[1], test3=tests[2], x=r.x,
+                    enorm=enorm, success=enorm <= 0.001)
 
     def test(self, nout=None) -> dict:
         """One problem of the suite: test/lsqrtest_module.f90:119-272."""

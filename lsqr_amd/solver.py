@@ -173,19 +173,29 @@ class lsqr_solver_ez:  # noqa: N801  (name kept from the reference)
         check(aprod(self._h, int(mode), x.ctypes.data, y.ctypes.data))  # :197 -> ERR_MODE
 
     # -- acheck / xcheck, src/lsqr.f90:908-994, 1015-1154 ------------------------
-    def acheck(self, eps=_EPS):
+    def acheck(self, eps=None):
+        """eps defaults to the machine precision of the build's working precision, as the callers of the reference
+        pass it (test/lsqrtest_module.f90:184)."""
         self._need()
+        if eps is None:
+            eps = float(np.finfo(np.float32).eps) if self.real32 else _EPS
         inform, err = C.c_int(), C.c_double()
-        check(lib().lsqrhip_acheck(self._h, float(eps), C.addressof(inform), C.addressof(err)))
+        fn = lib().lsqrhip_acheck_f32 if self.real32 else lib().lsqrhip_acheck
+        check(fn(self._h, float(eps), C.addressof(inform), C.addressof(err)))
         return inform.value, err.value
 
-    def xcheck(self, anorm, damp, b, x, eps=_EPS):
+    def xcheck(self, anorm, damp, b, x, eps=None):
         self._need()
-        b = np.ascontiguousarray(b, dtype=np.float64)
-        x = np.ascontiguousarray(x, dtype=np.float64)
-        u, v, w, tests = np.zeros(max(self.m, 1)), np.zeros(max(self.n, 1)), np.zeros(max(self.n, 1)), np.zeros(3)
+        wp = np.float32 if self.real32 else np.float64
+        if eps is None:
+            eps = float(np.finfo(wp).eps)
+        b = np.ascontiguousarray(b, dtype=wp)
+        x = np.ascontiguousarray(x, dtype=wp)
+        u, v, w = np.zeros(max(self.m, 1), wp), np.zeros(max(self.n, 1), wp), np.zeros(max(self.n, 1), wp)
+        tests = np.zeros(3)
         inform = C.c_int()
-        check(lib().lsqrhip_xcheck(self._h, float(anorm), float(damp), float(eps), b.ctypes.data, x.ctypes.data,
+        fn = lib().lsqrhip_xcheck_f32 if self.real32 else lib().lsqrhip_xcheck
+        check(fn(self._h, float(anorm), float(damp), float(eps), b.ctypes.data, x.ctypes.data,
                                    u.ctypes.data, v.ctypes.data, w.ctypes.data, C.addressof(inform),
                                    tests.ctypes.data))
         return inform.value, tests, u[:self.m], v[:self.n], w[:self.n]

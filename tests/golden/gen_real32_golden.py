@@ -31,10 +31,13 @@ for blk in lis.split("Least-Squares Test Problem")[1:]:
     ex = re.search(r"istop\s*=\s*(\d+)\s+itn\s*=\s*(\d+)", blk)
     er = re.search(r"appears to (be successful|have failed)\.\s+Relative error in  x  =\s*([-+0-9.E]+)", blk)
     cn = re.search(r"Condition no\. =\s*([-+0-9.E]+)\s+Residual function =\s*([-+0-9.E]+)", blk)
+    ac = re.search(r"aprod seems (OK|incorrect)", blk)
+    xi = re.search(r"inform\s*=\s*(\d+)", blk)
     probs.append(dict(m=int(head.group(1)), n=int(head.group(2)), nduplc=int(head.group(3)), npower=int(head.group(4)),
                       damp=float(head.group(5)), istop=int(ex.group(1)), itn=int(ex.group(2)),
                       success=er.group(1) == "be successful", enorm=float(er.group(2)),
-                      acond=float(cn.group(1)), rnorm=float(cn.group(2))))
+                      acond=float(cn.group(1)), rnorm=float(cn.group(2)),
+                      acheck_ok=ac.group(1) == "OK", xcheck_inform=int(xi.group(1))))
 assert len(probs) == 18
 json.dump(probs, open(os.path.join(HERE, "real32_lstp_ref.json"), "w"), indent=0)
 print("REAL32 suite:", [(p["istop"], p["itn"], p["enorm"]) for p in probs])

@@ -212,6 +212,28 @@ def test_fortran_device_operator_and_user_subclass_on_gpu():
 
 
 @pytest.mark.gpu
+def test_fortran_device_operator_in_the_real32_build_on_gpu():
+    """lsqr_device_module compiled -DREAL32 binds the REAL32 operator entry points (lsqrhip_create_operator_f32,
+    lsqrhip_lstp_create_f32, lsqrhip_solve_f32, lsqrhip_acheck_f32, lsqrhip_xcheck_f32): real32 vectors on the device.
+    The suite's first problem, acheck -> lsqr -> xcheck -> error, and the user subclass, against what the UNMODIFIED
+    reference compiled -DREAL32 reports for it (tests/golden/real32_lstp_ref.json)."""
+    import json
+    out = run("test_device_operator32").stdout
+    assert "DEVICE OPERATOR TESTS PASSED" in out
+    line = {k: l for l in out.splitlines() for k in ("ACHECK", "LSQR istop", "XCHECK", "ENORM", "USER istop",
+                                                      "USER maxdiff") if l.startswith(k)}
+    ref = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "real32_lstp_ref.json")))
+    g = next(p for p in ref if (p["m"], p["n"], p["npower"]) == (2000, 1000, 2))
+    assert "inform= 0" in line["ACHECK"] and g["acheck_ok"]
+    istop, itn = (int(t) for t in re.findall(r"=\s*(\d+)", line["LSQR istop"]))
+    assert istop == g["istop"] and 0.5 * g["itn"] <= itn <= 1.05 * g["itn"]
+    assert int(re.search(r"inform,tests=\s*(\d+)", line["XCHECK"]).group(1)) == g["xcheck_inform"]
+    assert numbers(line["ENORM"])[0] <= 1e-3 and g["success"]
+    uistop, uitn, calls = (int(t) for t in re.findall(r"=\s*(\d+)", line["USER istop"]))
+    assert (uistop, uitn) == (istop, itn) and calls >= 2 * itn + 1 and numbers(line["USER maxdiff"])[0] == 0.0
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("mode", ["real32", "mixed", "real32 sharded over 3 ranks", "mixed sharded over 3 ranks"])
 def test_real32_build_on_gpu(mode):
     """-DREAL32 build of the host layer (wp = real32 like the reference's REAL32 macro).

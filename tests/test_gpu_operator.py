@@ -191,6 +191,9 @@ def test_real32_suite_on_the_device_operator_follows_the_references_real32_build
         assert r["x"].dtype == np.float32
         assert r["istop"] == g["istop"], (r["npower"], r["istop"], g["istop"])
         assert r["success"] == g["success"]
+        # acheck and xcheck in real32 on the device (lsqrhip_acheck_f32 / _xcheck_f32): the reference's verdicts
+        assert (r["acheck_inform"] == 0) == g["acheck_ok"] and r["acheck_err"] < 1e-5
+        assert r["xcheck_inform"] == g["xcheck_inform"], (r["xcheck_inform"], g["xcheck_inform"])
         if g["success"]:
             assert r["enorm"] <= 1e-3
         else:
@@ -225,6 +228,11 @@ def test_real32_user_operator_hook_reproduces_the_real32_matrix_path():
     assert r.istop == r_ez.istop and abs(r.itn - r_ez.itn) <= 1
     assert np.linalg.norm(r.x.astype(np.float64) - r_ez.x) <= 2e-5 * np.linalg.norm(r_ez.x)
     assert r.anorm == pytest.approx(r_ez.anorm, rel=1e-5) and r.rnorm == pytest.approx(r_ez.rnorm, rel=1e-5)
+    assert op.acheck()[0] == 0 and ez.acheck()[0] == 0               # (real32: lsqrhip_acheck_f32, matrix and operator handles)
+    inform, tests, u, v, w = op.xcheck(r.anorm, 1e-2, b32, r.x)
+    inform_ez, tests_ez, *_ = ez.xcheck(r_ez.anorm, 1e-2, b32, r_ez.x)
+    assert inform in (1, 2, 3) and inform == inform_ez and u.dtype == np.float32
+    assert tests[2] == pytest.approx(tests_ez[2], rel=1e-2, abs=1e-7)
     # the binary64 entry points refuse the handle instead of reading floats as doubles
     with pytest.raises(capi.LsqrHipError):
         lsqr_solver_ez.solve(_as64(op), p.b, 1e-2)

@@ -185,8 +185,10 @@ def test_device_pointer_forms_and_refusals(env):
     s64 = lsqr_solver_ez().initialize(p.m, p.n, p.a, p.irow, p.icol)
     assert L.lsqrhip_aprod_f32(s64._h, 1, xp.ctypes.data, yp.ctypes.data) == capi.ERR_ARG
     assert L.lsqrhip_aprod_device_f32(s64._h, 1, dx.ptr.value, dy.ptr.value) == capi.ERR_ARG
-    with pytest.raises(LsqrHipError):
-        s.acheck()
+    assert L.lsqrhip_acheck_f32(s64._h, 1e-7, C.addressof(inform), C.addressof(err)) == capi.ERR_ARG
+    # acheck on the REAL32 handle itself (round 4: lsqrhip_acheck_f32 -- real32 vectors, the adjoint identity to real32)
+    ainf, aerr = s.acheck()
+    assert ainf == 0 and aerr < 1e-6
 
 
 def test_log_records_of_a_real32_solve(env):
