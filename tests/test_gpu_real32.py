@@ -273,3 +273,44 @@ def test_sharded_real32_handle(env, name, ngpu):
             capi.check(L.lsqrhip_destroy(h))
     finally:
         os.environ.pop("LSQRHIP_SHARD_LOOPBACK", None)
+
+
+@pytest.mark.parametrize("ngpu,csb,parts", [(3, None, 2), (8, "1", 2), (4, "1", 4)])
+def test_sharded_real32_with_overlapped_exchanges_changes_no_bit(env, ngpu, csb, parts):
+    """LSQRHIP_SHARD_OVERLAP=1 on REAL32 row blocks (real32 slices in parts on the exchange stream; column-swept
+    float layouts built for the parts): the solve of the plain schedule, bit for bit (loopback harness)."""
+    keys = ("LSQRHIP_SHARD_LOOPBACK", "LSQRHIP_CSB", "LSQRHIP_SHARD_OVERLAP", "LSQRHIP_SHARD_PARTS")
+    old = {k: os.environ.get(k) for k in keys}
+    p = P.random_rows(40000, 9001, 10, seed=37, damp=1e-2)
+    a32, b32 = p.a.astype(np.float32), p.b.astype(np.float32)
+    L = capi.lib()
+    irow, icol = np.ascontiguousarray(p.irow, np.int32), np.ascontiguousarray(p.icol, np.int32)
+    out = []
+    try:
+        os.environ["LSQRHIP_SHARD_LOOPBACK"] = "1"
+        os.environ["LSQRHIP_SHARD_PARTS"] = str(parts)
+        if csb:
+            os.environ["LSQRHIP_CSB"] = csb
+        for overlap in ("0", "1"):
+            os.environ["LSQRHIP_SHARD_OVERLAP"] = overlap
+            h = C.c_void_p()
+            capi.check(L.lsqrhip_create_sharded_f32(p.m, p.n, a32.size, irow.ctypes.data, icol.ctypes.data,
+                                                    a32.ctypes.data, ngpu, C.byref(h)))
+            try:
+                x, se = np.zeros(p.n, np.float32), np.zeros(p.n, np.float32)
+                istop, itn = C.c_int(), C.c_int()
+                sc = [C.c_double() for _ in range(5)]
+                capi.check(L.lsqrhip_solve_f32(h, b32.ctypes.data, 1e-2, 1e-6, 1e-6, 0.0, 30, 1, 0, x.ctypes.data,
+                                               se.ctypes.data, C.addressof(istop), C.addressof(itn),
+                                               *[C.addressof(v) for v in sc]))
+                out.append((x.copy(), se.copy(), istop.value, itn.value, [v.value for v in sc]))
+            finally:
+                capi.check(L.lsqrhip_destroy(h))
+    finally:
+        for k, v in old.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v
+    off, on = out
+    assert off[2:] == on[2:] and off[3] > 3
+    assert np.array_equal(off[0], on[0]) and np.array_equal(off[1], on[1])
