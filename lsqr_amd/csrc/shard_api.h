@@ -140,6 +140,7 @@ __global__ __launch_bounds__(VEC_BLOCK) void k_init_w_slice(VT *__restrict__ w, 
 // product left V_q as it was: its maxima of the last product stand.
 constexpr int SHARD_MSG = 64;                 // doubles a rank contributes to the exchange of the norms
 constexpr int SHARD_NMAX = SHARD_MSG - 4;     // ... of which piece maxima of its slice of v
+static_assert(VEC_BLOCK == 256 && SHARD_NMAX <= 64, "k_shard_sums: four 64-thread parts, one piece per lane");
 __global__ __launch_bounds__(VEC_BLOCK) void k_shard_sums(const double *__restrict__ partials, int np,
                                                           const double *__restrict__ wsq, double *__restrict__ sums,
                                                           const SpmvCoef *__restrict__ coef,
@@ -152,10 +153,17 @@ __global__ __launch_bounds__(VEC_BLOCK) void k_shard_sums(const double *__restri
         sums[0] = coef->skip != 0 ? 0.0 : tot;  // a skipped product left no partials (beta == 0, :691)
         sums[1] = *wsq;
     }
-    if (maxpart != nullptr && coef->skip == 0 && (int)threadIdx.x < SHARD_NMAX) {
+    if (maxpart != nullptr && coef->skip == 0) {   // piece i: workgroups i, i + NMAX, ... -- four threads share one piece
+        __shared__ double mx[4][SHARD_NMAX];
+        const int piece = threadIdx.x % 64, part = threadIdx.x / 64;   // (VEC_BLOCK = 256: parts 0..3)
         double m = 0.0;
-        for (int i = threadIdx.x; i < np; i += SHARD_NMAX) m = fmax(m, maxpart[i]);
-        sums[4 + threadIdx.x] = m;
+        if (piece < SHARD_NMAX)
+            for (int i = piece + part * SHARD_NMAX; i < np; i += 4 * SHARD_NMAX) m = fmax(m, maxpart[i]);
+        __syncthreads();
+        if (piece < SHARD_NMAX) mx[part][piece] = m;
+        __syncthreads();
+        if ((int)threadIdx.x < SHARD_NMAX)
+            sums[4 + threadIdx.x] = fmax(fmax(mx[0][threadIdx.x], mx[1][threadIdx.x]), fmax(mx[2][threadIdx.x], mx[3][threadIdx.x]));
     }
 }
 
