@@ -204,6 +204,8 @@ struct ShardCtx {
     double *wsq = nullptr;        // [1] this rank's sum of w_q^2 (owned)
     int *live = nullptr;          // [1] "this iteration runs" (owned)
     int wantse = 0;
+    const double *gath = nullptr; // the C++ engine: where the all-gather of the norms lands (P messages of `msg` doubles) -- the
+    int msg = 4;                  // scalar steps then sum the ranks themselves (shard_api.h k_shard_s1g / s2g / s3w)
     bool own_in_T = false;        // the rank's own slice of T is read in place by k_rs_combine (never copied to R)
     bool vmax_msg = false;        // the caller's `sums` is a SHARD_MSG-double message that carries this rank's piece maxima of |v_q|
                                   // (shard_engine.h, which hands the gathered maxima to mode 1 in xmax_part)

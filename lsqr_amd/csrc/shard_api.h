@@ -187,6 +187,56 @@ __global__ void k_shard_s3(const double *__restrict__ sums, LsqrState *st, const
     s3_step(st, (st->t3 * st->t3) * sums[1], x1, log);
 }
 
+// ---- the C++ engine's forms of the three scalar steps (shard_engine.h): each takes over the small kernel that used
+// to run in front of it -- the rank-ordered sum of the gathered norms (k_sum_ranks) or the reduction of this rank's
+// partials of sum w^2 -- so that an iteration has three launches fewer.  `src`: the P messages of `msg` doubles the
+// all-gather delivered (a world of one: the rank's own message).  Same sums in the same order: the same bits.
+__global__ void k_shard_s1g(const double *__restrict__ src, int P, int msg, LsqrState *st)
+{
+    if (st->stop != 0 || threadIdx.x != 0) return;
+    double s = src[0];
+    for (int r = 1; r < P; ++r) s = s + src[msg * r];
+    s1_step(st, sqrt(s) * st->ns_inv);
+}
+
+__global__ __launch_bounds__(64) void k_shard_s2g(const double *__restrict__ src, int P, int msg,
+                                                  double *__restrict__ sums, LsqrState *st, int *__restrict__ live,
+                                                  double *__restrict__ vmax)
+{
+    if (vmax != nullptr && msg == SHARD_MSG)   // the ranks' piece maxima of |v| side by side (k_sum_ranks)
+        for (int i = threadIdx.x; i < P * SHARD_NMAX; i += blockDim.x)
+            vmax[i] = src[(i / SHARD_NMAX) * SHARD_MSG + 4 + i % SHARD_NMAX];
+    if (threadIdx.x != 0) return;
+    double s0 = src[0], s1 = src[1];
+    for (int r = 1; r < P; ++r) {
+        s0 = s0 + src[msg * r];
+        s1 = s1 + src[msg * r + 1];
+    }
+    sums[0] = s0;
+    sums[1] = s1;   // (step 3 reads it after the update)
+    if (st->stop != 0) {
+        *live = 0;
+        return;
+    }
+    *live = 1;
+    s2_step(st, sqrt(s0) * st->ns_inv, st->c2.skip != 0);
+}
+
+__global__ __launch_bounds__(VEC_BLOCK) void k_shard_s3w(const double *__restrict__ partials, int np,
+                                                         double *__restrict__ wsq, const double *__restrict__ sums,
+                                                         LsqrState *st, const int *__restrict__ live,
+                                                         const void *__restrict__ x, int f32, double *__restrict__ log)
+{
+    __shared__ double red[VEC_BLOCK / WAVE];
+    const double s = np > 0 ? strided_sum<VEC_BLOCK>(partials, np) : 0.0;
+    const double tot = block_sum<VEC_BLOCK>(s, red);   // (k_reduce_partials' reduction, bit for bit)
+    if (threadIdx.x != 0) return;
+    wsq[0] = tot;
+    if (*live == 0) return;
+    const double x1 = x == nullptr ? 0.0 : (f32 ? (double)static_cast<const float *>(x)[0] : static_cast<const double *>(x)[0]);
+    s3_step(st, (st->t3 * st->t3) * sums[1], x1, log);
+}
+
 }  // namespace lsqrhip
 
 // stage ids (keep in sync with lsqr_amd/dist.py)
@@ -365,9 +415,14 @@ static int shard_stage_phase(lsqrhip_handle_t h, int stage, int phase)
         break;
     }
     case ST_S1_ATU: {
-        if (phase <= 0)
-            hipLaunchKernelGGL((k_s1<false>), dim3(1), dim3(SC_BLOCK), 0, s, (const double *)h->partials, 0,
-                               (const double *)sums, st);
+        if (phase <= 0) {
+            if (c.gath != nullptr)   // (the C++ engine: the rank-ordered sum of the gathered norms rides along)
+                hipLaunchKernelGGL(k_shard_s1g, dim3(1), dim3(64), 0, s, (const double *)(c.P > 1 ? c.gath : sums), c.P,
+                                   c.msg, st);
+            else
+                hipLaunchKernelGGL((k_s1<false>), dim3(1), dim3(SC_BLOCK), 0, s, (const double *)h->partials, 0,
+                                   (const double *)sums, st);
+        }
         SpmvArgs a;
         a.c = &h->AT; a.x = h->U; a.y = T; a.coef = &st->c2p; a.stop = &st->stop; a.pout = h->partials; a.stream = s;
         a.unit_x = true;
@@ -382,13 +437,22 @@ static int shard_stage_phase(lsqrhip_handle_t h, int stage, int phase)
                            c.vmax_msg ? (const double *)(h->partials + SPMV_MAX_GRID) : (const double *)nullptr);
         break;
     case ST_UPDATE:
-        hipLaunchKernelGGL(k_shard_s2, dim3(1), dim3(1), 0, s, (const double *)sums, st, c.live);
+        if (c.gath != nullptr)
+            hipLaunchKernelGGL(k_shard_s2g, dim3(1), dim3(64), 0, s, (const double *)(c.P > 1 ? c.gath : sums), c.P, c.msg,
+                               sums, st, c.live, c.vmax_msg ? h->xmax_part : (double *)nullptr);
+        else
+            hipLaunchKernelGGL(k_shard_s2, dim3(1), dim3(1), 0, s, (const double *)sums, st, c.live);
         vec(stage);
-        hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(VEC_BLOCK), 0, s, (const double *)h->partials, gq, c.wsq);
         // step 3 AFTER the update, as in the reference (src/lsqr.f90:729-745, then :751-837): the x(1) of the
         // iteration log is the updated one; both are gated by `live`, which step 2 set for this iteration
-        hipLaunchKernelGGL(k_shard_s3, dim3(1), dim3(1), 0, s, (const double *)sums, st, (const int *)c.live,
-                           (const void *)h->X, h->f32 ? 1 : 0, h->d_log);
+        if (c.gath != nullptr) {
+            hipLaunchKernelGGL(k_shard_s3w, dim3(1), dim3(VEC_BLOCK), 0, s, (const double *)h->partials, gq, c.wsq,
+                               (const double *)sums, st, (const int *)c.live, (const void *)h->X, h->f32 ? 1 : 0, h->d_log);
+        } else {
+            hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(VEC_BLOCK), 0, s, (const double *)h->partials, gq, c.wsq);
+            hipLaunchKernelGGL(k_shard_s3, dim3(1), dim3(1), 0, s, (const double *)sums, st, (const int *)c.live,
+                               (const void *)h->X, h->f32 ? 1 : 0, h->d_log);
+        }
         break;
     default:
         return fail(LSQRHIP_ERR_ARG, "unknown shard stage");
@@ -466,6 +530,7 @@ extern "C" int lsqrhip_shard_end(lsqrhip_handle_t h, double *d_x, double *d_se, 
     if (xnorm) *xnorm = r.xnorm;
     c.active = false;
     c.own_in_T = false;
+    c.gath = nullptr;
     c.vmax_msg = false;   // (the next caller of lsqrhip_shard_begin may bring a 4-double `sums`: lsqr_amd/dist.py)
     return LSQRHIP_OK;
 }

@@ -248,7 +248,8 @@ static inline char *at(double *base, size_t i, size_t esz) { return reinterpret_
 // sums[0..k) <- sum over ranks, in rank order, same bits everywhere.  `with_v`: the in-place all-gather of the v
 // slices rides in the same RCCL group (one collective latency instead of two: after ST_VCOMBINE the slices are
 // final -- the update that follows only reads them).
-static int ex_scalars(ShardGroup &g, int k, bool with_v = false)
+// `fused`: the scalar step that follows sums the ranks itself (shard_api.h k_shard_s1g / k_shard_s2g): no k_sum_ranks
+static int ex_scalars(ShardGroup &g, int k, bool with_v = false, bool fused = false)
 {
     Rccl *rc = rccl();
     const size_t c = (size_t)g.chunk;
@@ -269,7 +270,8 @@ static int ex_scalars(ShardGroup &g, int k, bool with_v = false)
                     RET(loop_copy(q, at(q.V, (size_t)p.grank * c, g.esz), at(p.V, (size_t)p.grank * c, g.esz), c * g.esz));
             }
         RET(fence_ranks(g));
-        for (ShardRank &q : g.r) RET(sum_ranks(q, q.gath));
+        if (!fused)
+            for (ShardRank &q : g.r) RET(sum_ranks(q, q.gath));
         return LSQRHIP_OK;
     }
     if (g.P > 1) {
@@ -280,11 +282,12 @@ static int ex_scalars(ShardGroup &g, int k, bool with_v = false)
                 NCCLCHK(rc->AllGather(at(q.V, (size_t)q.grank * c, g.esz), q.V, c, vtype, q.comm, q.h->stream));
         }
         NCCLCHK(rc->GroupEnd());
-        for (ShardRank &q : g.r) RET(sum_ranks(q, q.gath));
+        if (!fused)
+            for (ShardRank &q : g.r) RET(sum_ranks(q, q.gath));
         return LSQRHIP_OK;
     }
     // a world of one: nothing to exchange, but the piece maxima still go where mode 1 looks for them
-    if (g.msg == SHARD_MSG && k == 2)
+    if (g.msg == SHARD_MSG && k == 2 && !fused)
         for (ShardRank &q : g.r) RET(sum_ranks(q, q.sums));
     return LSQRHIP_OK;
 }
@@ -496,7 +499,7 @@ static int enqueue_iteration_overlap(ShardGroup &g)
         if (phA) RET(stage_all(g, ST_MODE1, k));
     }
     if (!phA) RET(stage_all(g, ST_MODE1));
-    RET(ex_scalars(g, 1));
+    RET(ex_scalars(g, 1, false, true));
     // mode 2, its parts leaving as they complete
     for (int k = 0; k < G; ++k) {
         if (phT) RET(stage_all(g, ST_S1_ATU, k));
@@ -527,7 +530,7 @@ static int enqueue_iteration_overlap(ShardGroup &g)
             if (&p == &q || g.loopback) HIPCHK(hipStreamWaitEvent(q.cstream, p.evV, 0));
     }
     for (int k = 0; k < G; ++k) RET(ov_gather_part(g, k));
-    RET(ex_scalars(g, 2, false));
+    RET(ex_scalars(g, 2, false, true));
     RET(stage_all(g, ST_UPDATE));
     return LSQRHIP_OK;
 }
@@ -541,11 +544,11 @@ static int enqueue_iterations(ShardGroup &g, int count)
             continue;
         }
         RET(stage_all(g, ST_MODE1));
-        RET(ex_scalars(g, 1));
+        RET(ex_scalars(g, 1, false, true));
         RET(stage_all(g, ST_S1_ATU));
         RET(ex_scatter(g));
         RET(stage_all(g, ST_VCOMBINE));
-        RET(ex_scalars(g, 2, true));    // alpha^2, dknorm^2 and the v slices in one group
+        RET(ex_scalars(g, 2, true, true));    // alpha^2, dknorm^2 and the v slices in one group
         RET(stage_all(g, ST_UPDATE));
     }
     return LSQRHIP_OK;
@@ -621,6 +624,8 @@ static int run_group(ShardGroup &g, double damp, double atol, double btol, doubl
         for (ShardRank &q : g.r) {
             q.h->shard.vmax_msg = want;
             q.h->shard.own_in_T = true;
+            q.h->shard.gath = q.gath;
+            q.h->shard.msg = g.msg;
         }
     }
     for (ShardRank &q : g.r)
