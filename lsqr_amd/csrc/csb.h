@@ -36,9 +36,11 @@
 //         has to fit, two's-complement adds wrap.  A row is off by <= k 2^-62 2^e1_i tau where the reference's
 //         left-to-right sum is off by up to k 2^-53 |a_i|'|x|.
 //   * tau is NOT simply max|x sx|: ONE large entry in x (a spike in v or u: a column or row of A scaled far above
-//     the others) would push the grid of every row up, also of the rows that never touch it.  The k_csb_xmax pass
-//     in front of every product leaves the maximum of each of its <= 4096 strided pieces of x; tau = min(max,
-//     8..32 x the MEDIAN piece maximum).  Columns with |x_j sx| >= tau ("big": none at
+//     the others) would push the grid of every row up, also of the rows that never touch it.  x is cut into <= 4096
+//     PIECES (csb_pieces: aligned groups of 64..1024 elements dealt round-robin -- a function of its length alone) and
+//     the product is handed each piece's maximum: by the k_csb_xmax pass over x, or -- inside the solver's loop -- by
+//     the epilogue of the product that WROTE x (csb_group_max: the same words, no pass).  tau = min(max, 8..32 x the
+//     MEDIAN piece maximum).  Columns with |x_j sx| >= tau ("big": none at
 //     all for a vector without outliers, a handful otherwise) go to a SECOND set of integer sums on the grid of
 //     max|x sx| itself, kept in HBM (zc, 8 bytes per row, global atomics: integer adds again, exact and order-free)
 //     and added by the epilogue of the blocks that used them.  Both grids are functions of x and the row alone:
@@ -124,6 +126,9 @@ struct CsbMat {
     int NS, G, J, Pst;      // stripes = Pst slices x G parts; split sp = k * J + j sweeps the stripes q * G + k, q = j, j + J, ...
     const int *border;      // the launch order of the row blocks (position -> block), or null: natural order
     int sp0, sp1;           // the column splits of THIS launch: [sp0, sp1)
+    unsigned long long *ymax;  // or null: the piece maxima of |y| (csb_pieces(rows): the words the k_csb_xmax pass over y would
+                               // leave), raised by the epilogue with atomic max -- all zero on entry.  The NEXT product (the
+                               // one that gathers from this y) takes its grids from them: no pass.
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -362,6 +367,8 @@ struct CsbX {
     const double *xmax;  // piece maxima of |x| (vec.h k_csb_xmax over the vector this product gathers from)
     int nxmax;
     int split;           // 0: tau = the bound on max|x sx| whatever x looks like (LSQRHIP_CSB_TAU=0, ablation)
+    unsigned long long *clr;  // or null: nxmax words the sweeps of this product zero on their way -- the piece maxima (CsbMat.ymax)
+                              // the NEXT product that writes x will raise (two sets by iteration parity, solve_loop.h)
 };
 
 // sx, sy, cy of this launch: explicit (coef) or lazy from the previous kernel's partials (pin) -- the
@@ -596,6 +603,97 @@ __device__ __forceinline__ double csb_sumsq_rows(const VT *__restrict__ y, int r
     return sq;
 }
 
+// v = |x| -> the high word of a binary64 >= v (0: v == 0 or NaN -- a NaN is not a magnitude, the products find it
+// themselves; 0x7ff00000: inf, also for the top 2^-20 of the finite range)
+__device__ __forceinline__ unsigned csb_hi_up(double v)
+{
+    if (!(v > 0.0)) return 0u;
+    const unsigned hi = (unsigned)((unsigned long long)__double_as_longlong(v) >> 32);
+    return hi >= 0x7fefffffu ? 0x7ff00000u : hi + 1u;
+}
+// The largest of an unsigned word over the 64 lanes, valid in lane 63: row_shr 1, 2, 4, 8 inside the rows of 16 lanes, then
+// the rows' maxima handed on (row_bcast 15 / 31) -- 6 DPP operations, no LDS.
+__device__ __forceinline__ unsigned wave_max_u32_l63(unsigned v)
+{
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true));
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true));
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true));
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true));
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, true));
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, true));
+    return v;
+}
+// The pieces of a vector of n elements whose maxima fix a product's grids (csb_grids): element i belongs to piece
+// (i >> L) % NP -- aligned groups of 2^L elements dealt round-robin to NP <= 4096 pieces; L and NP depend on n alone
+// (so the grids, and with them every bit of a product, do not depend on how the matrix was blocked):
+//   L = 6 up to 2^18 elements, one more per doubling, 10 from 2^22 on.
+// Whoever WRITES the vector leaves the maxima -- the k_csb_xmax pass over x, or the epilogue of the column-swept product
+// that wrote it (csb_group_max: no pass) -- as the same words.
+struct CsbPieces {
+    int L, NP;
+};
+__host__ __device__ inline CsbPieces csb_pieces(long long n)
+{
+    int L = 6;
+    while (L < 10 && (n >> (L + 12)) > 0) ++L;
+    const long long groups = (n + (1ll << L) - 1) >> L;
+    return CsbPieces{L, (int)(groups < 1 ? 1 : (groups > 4096 ? 4096 : groups))};
+}
+constexpr int CSB_XMAX_PIECES = 4096;
+constexpr int CSB_GMX = 24;   // epilogue: a row block's (share's) groups kept in LDS while they fit, else straight to HBM
+
+// The epilogue's share of that.  A wave's 64 consecutive rows, the first at global row `grow0`: `hv` = csb_hi_up(|y|) of
+// the lane's row (0: no row).  The rows lie in at most two groups; a group's maximum goes to gmx[group - g_first] in LDS
+// (`inlds`: the block's groups fit; csb_group_flush hands them on, one atomic per group and block) or straight to the
+// piece in HBM (one per wave and step: at 10^7 rows 84 us per product -- same-line atomics at the memory side).
+// All 64 lanes call.
+__device__ __forceinline__ void csb_group_max(unsigned long long *__restrict__ ymax, CsbPieces pc, unsigned *gmx, bool inlds,
+                                              long long g_first, long long grow0, unsigned hv)
+{
+    const int lane = threadIdx.x & (WAVE - 1);
+    const long long ga = grow0 >> pc.L, gb = (grow0 + WAVE - 1) >> pc.L;
+    auto put = [&](long long g, unsigned v) {
+        if (v == 0u) return;
+        if (inlds) atomicMax(&gmx[g - g_first], v);
+        else atomicMax(&ymax[g % pc.NP], (unsigned long long)v << 32);
+    };
+    if (ga == gb) {   // (uniform)
+        const unsigned m = wave_max_u32_l63(hv);
+        if (lane == WAVE - 1) put(ga, m);
+        return;
+    }
+    const int cut = (int)((gb << pc.L) - grow0);   // lanes [0, cut): group ga
+    const unsigned lo = wave_max_u32_l63(lane < cut ? hv : 0u);
+    const unsigned hi = wave_max_u32_l63(lane >= cut ? hv : 0u);
+    if (lane == WAVE - 1) {
+        put(ga, lo);
+        put(gb, hi);
+    }
+}
+// after a barrier behind the last csb_group_max: the groups' maxima -> the pieces, gmx zero again (a barrier before its next use)
+__device__ __forceinline__ void csb_group_flush(unsigned long long *__restrict__ ymax, CsbPieces pc, unsigned *gmx, bool inlds,
+                                                long long g_first, int ng)
+{
+    const int tid = threadIdx.x;
+    if (inlds && tid < ng) {
+        const unsigned v = gmx[tid];
+        gmx[tid] = 0u;
+        if (v != 0u) atomicMax(&ymax[(g_first + tid) % pc.NP], (unsigned long long)v << 32);
+    }
+}
+// ... the maxima from y as stored (the outlier path: y was patched after the epilogue computed it), rows [rlo, nr)
+template <typename VT>
+__device__ __forceinline__ void csb_group_max_rows(unsigned long long *__restrict__ ymax, CsbPieces pc, unsigned *gmx, bool inlds,
+                                                   long long g_first, const VT *__restrict__ y, int row0, int nr, int rlo = 0)
+{
+    const int tid = threadIdx.x;
+    for (int rb = rlo; rb < nr; rb += CSB_BLOCK) {
+        const int r = rb + tid;
+        const unsigned hv = r < nr ? csb_hi_up(fabs((double)y[row0 + r])) : 0u;
+        csb_group_max(ymax, pc, gmx, inlds, g_first, (long long)row0 + rb + (tid & ~(WAVE - 1)), hv);
+    }
+}
+
 // A row's sum from its integer parts: the LDS sum on the fine grid, and -- `coarse`: the block used them -- the
 // HBM sum of its big columns on the coarse grid (taken and cleared with agent-scope atomics: the adds of other
 // workgroups' sweeps -- column splits -- were performed at memory, not in this XCD's L2).  One rounding per
@@ -625,6 +723,7 @@ __global__ __launch_bounds__(CSB_BLOCK, 1) void k_spmv_csb(
     __shared__ unsigned long long acc[CSB_NACC];
     __shared__ double red[CSB_WAVES + 2];
     __shared__ int s_bad, s_big;
+    __shared__ unsigned gmx[CSB_GMX];
     const int tid = threadIdx.x;
     const int lane = tid & (WAVE - 1);
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -638,6 +737,8 @@ __global__ __launch_bounds__(CSB_BLOCK, 1) void k_spmv_csb(
     }
     if (*stop != 0) return;
     const VT *__restrict__ aval = static_cast<const VT *>(A.val);
+    if (xb.clr != nullptr)
+        for (int i = wg * CSB_BLOCK + tid; i < xb.nxmax; i += nwg * CSB_BLOCK) xb.clr[i] = 0ull;
 
     const CsbCoef co = csb_coef(coef, pin, npin, slot_in, skip_if_zero, nsc, red);
     if (pin != nullptr && wg == 0 && tid == 0) {
@@ -659,6 +760,8 @@ __global__ __launch_bounds__(CSB_BLOCK, 1) void k_spmv_csb(
         s_bad = 0;
         s_big = 0;
     }
+    if (tid < CSB_GMX) gmx[tid] = 0u;
+    const CsbPieces pc = csb_pieces(A.rows);
     __syncthreads();
 
     // Column splits (few rows: fewer row blocks than CUs).  S workgroups share a block, each sweeping a
@@ -786,13 +889,23 @@ __global__ __launch_bounds__(CSB_BLOCK, 1) void k_spmv_csb(
             continue;
         }
         double sq = 0.0;
-        for (int r = tid; r < nr; r += CSB_BLOCK) {
-            const double sum = csb_row_sum(A, (long long)acc[r], row0 + r, gr, big);
-            acc[r] = 0ull;
-            const VT yn = (VT)(cy * ((double)y[row0 + r] * sy) + sum);
-            y[row0 + r] = yn;
-            const double ys = (double)yn * nsc.s;
-            sq += ys * ys;
+        const bool pieces = A.ymax != nullptr && !bad;   // (uniform; with outliers: from y as patched, below)
+        const long long g_first = (long long)row0 >> pc.L;
+        const int ng = nr > 0 ? (int)((((long long)row0 + nr - 1) >> pc.L) - g_first) + 1 : 0;
+        const bool inlds = ng <= CSB_GMX;
+        for (int rb = 0; rb < nr; rb += CSB_BLOCK) {     // (every wave runs every step: csb_group_max is a wave operation)
+            const int r = rb + tid;
+            unsigned hv = 0u;
+            if (r < nr) {
+                const double sum = csb_row_sum(A, (long long)acc[r], row0 + r, gr, big);
+                acc[r] = 0ull;
+                const VT yn = (VT)(cy * ((double)y[row0 + r] * sy) + sum);
+                y[row0 + r] = yn;
+                const double ys = (double)yn * nsc.s;
+                sq += ys * ys;
+                hv = csb_hi_up(fabs((double)yn));
+            }
+            if (pieces) csb_group_max(A.ymax, pc, gmx, inlds, g_first, (long long)row0 + rb + (tid & ~(WAVE - 1)), hv);
         }
         if (tid == 0) {  // the padding's dummy accumulator
             acc[A.R] = 0ull;
@@ -807,6 +920,7 @@ __global__ __launch_bounds__(CSB_BLOCK, 1) void k_spmv_csb(
                 csb_add_outliers<VT, NARROW>(A, aval, c0, c1, x, sx, tau, pmax2, reinterpret_cast<double *>(acc), y, row0, nr);
             }
             sq = csb_sumsq_rows<VT>(y, row0, nr, nsc);
+            if (A.ymax != nullptr) csb_group_max_rows<VT>(A.ymax, pc, gmx, inlds, g_first, y, row0, nr);
         }
         sq = wave_sum(sq);
         if (lane == 0) red[w] = sq;
@@ -817,6 +931,7 @@ __global__ __launch_bounds__(CSB_BLOCK, 1) void k_spmv_csb(
             for (int i = 0; i < CSB_WAVES; ++i) t += red[i];
             partials[b] = t;
         }
+        if (A.ymax != nullptr) csb_group_flush(A.ymax, pc, gmx, inlds, g_first, ng);
         __syncthreads();
     }
 }
@@ -834,9 +949,12 @@ __global__ __launch_bounds__(CSB_BLOCK) void k_csb_combine(
     __shared__ double accd[CSB_NACC];   // the outlier pass only (all zero otherwise)
     __shared__ double red[CSB_WAVES + 2];
     __shared__ int hist[CSB_XHIST];
+    __shared__ unsigned gmx[CSB_GMX];
     const int tid = threadIdx.x, lane = tid & (WAVE - 1);
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int Q = A.Q;
+    const CsbPieces pc = csb_pieces(A.rows);
+    if (tid < CSB_GMX) gmx[tid] = 0u;   // (the barriers of csb_coef / csb_grids come before its first use)
     if (*stop != 0) {
         // The solve stopped while this product was under way (the scalar rider travels with its first sweep): some
         // sweeps may have run and added to zc, y is no longer wanted.  What they left behind must still go -- the
@@ -869,14 +987,24 @@ __global__ __launch_bounds__(CSB_BLOCK) void k_csb_combine(
         const int flags = A.bad[b * CSB_QMAX + qi];   // uniform: what the splits of this block ran into (k_spmv_csb)
         __syncthreads();              // (everyone has read the word: thread 0 may clear it below)
         double sq = 0.0;
-        for (int r = rlo + tid; r < rhi; r += CSB_BLOCK) {
-            long long s = __builtin_nontemporal_load(&A.z[row0 + r]);
-            for (int sp = 1; sp < A.S; ++sp) s += __builtin_nontemporal_load(&A.z[(size_t)sp * A.rows + row0 + r]);
-            const double sum = csb_row_sum(A, s, row0 + r, gr, (flags & 2) != 0);
-            const VT yn = (VT)(cy * ((double)y[row0 + r] * sy) + sum);
-            y[row0 + r] = yn;
-            const double ys = (double)yn * nsc.s;
-            sq += ys * ys;
+        const bool pieces = A.ymax != nullptr && !(flags & 1);
+        const long long g_first = ((long long)row0 + rlo) >> pc.L;
+        const int ng = rhi > rlo ? (int)((((long long)row0 + rhi - 1) >> pc.L) - g_first) + 1 : 0;
+        const bool inlds = ng <= CSB_GMX;
+        for (int rb = rlo; rb < rhi; rb += CSB_BLOCK) {
+            const int r = rb + tid;
+            unsigned hv = 0u;
+            if (r < rhi) {
+                long long s = __builtin_nontemporal_load(&A.z[row0 + r]);
+                for (int sp = 1; sp < A.S; ++sp) s += __builtin_nontemporal_load(&A.z[(size_t)sp * A.rows + row0 + r]);
+                const double sum = csb_row_sum(A, s, row0 + r, gr, (flags & 2) != 0);
+                const VT yn = (VT)(cy * ((double)y[row0 + r] * sy) + sum);
+                y[row0 + r] = yn;
+                const double ys = (double)yn * nsc.s;
+                sq += ys * ys;
+                hv = csb_hi_up(fabs((double)yn));
+            }
+            if (pieces) csb_group_max(A.ymax, pc, gmx, inlds, g_first, (long long)row0 + rb + (tid & ~(WAVE - 1)), hv);
         }
         if (flags & 1) {  // a split of this block left products out
             if (!cleared) {
@@ -887,6 +1015,7 @@ __global__ __launch_bounds__(CSB_BLOCK) void k_csb_combine(
             csb_add_outliers<VT, NARROW>(A, aval, A.cptr[b], A.cptr[b + 1], x, sx, ldexp(1.0, gr.ef), ldexp(1.0, gr.ec), accd, y,
                                          row0, rhi, rlo);
             sq = csb_sumsq_rows<VT>(y, row0, rhi, nsc, rlo);
+            if (A.ymax != nullptr) csb_group_max_rows<VT>(A.ymax, pc, gmx, inlds, g_first, y, row0, rhi, rlo);
         }
         if (flags != 0 && tid == 0) A.bad[b * CSB_QMAX + qi] = 0;
         sq = wave_sum(sq);
@@ -898,6 +1027,7 @@ __global__ __launch_bounds__(CSB_BLOCK) void k_csb_combine(
             for (int i = 0; i < CSB_WAVES; ++i) t += red[i];
             partials[u] = t;
         }
+        if (A.ymax != nullptr) csb_group_flush(A.ymax, pc, gmx, inlds, g_first, ng);
         __syncthreads();
     }
 }

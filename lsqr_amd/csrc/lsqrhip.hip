@@ -207,6 +207,7 @@ struct ShardCtx {
     const double *gath = nullptr; // the C++ engine: where the all-gather of the norms lands (P messages of `msg` doubles) -- the
     int msg = 4;                  // scalar steps then sum the ranks themselves (shard_api.h k_shard_s1g / s2g / s3w)
     bool own_in_T = false;        // the rank's own slice of T is read in place by k_rs_combine (never copied to R)
+    int upar = 0;                 // the C++ engine: which set of u's piece maxima (H::MXU) the last mode 1 raised
     bool vmax_msg = false;        // the caller's `sums` is a SHARD_MSG-double message that carries this rank's piece maxima of |v_q|
                                   // (shard_engine.h, which hands the gathered maxima to mode 1 in xmax_part)
     int want_log = 0;             // option "shard_log": this rank keeps the iteration log of the next sharded solves
@@ -234,7 +235,8 @@ struct lsqrhip_handle_s {
     double *U = nullptr, *V = nullptr, *W = nullptr, *X = nullptr, *SE = nullptr;
     double *Z = nullptr;         // per-panel row sums of a panelled product (max over A, A')
     double *partials = nullptr;  // 3 * SPMV_MAX_GRID (three planes for Blue's norm of b, vec.h k_sumsq3)
-    double *xmax_part = nullptr; // VEC_MAX_GRID partials of max|x| for csb.h products on caller vectors
+    double *xmax_part = nullptr; // piece maxima of |x| for csb.h products (k_csb_xmax; the sharded engine's gathered maxima of v)
+    double *MXU = nullptr, *MXV = nullptr;  // piece maxima of U / V left by the column-swept product that wrote them (csb.h ymax)
     NScale nsc{1.0, 1.0};        // fused norms: sum of (y * nsc.s)^2, sqrt(sum) * nsc.inv (scalar.h "range-safe norms")
     int norm_exp = 0;            // nsc.s = 2^-norm_exp (option "norm_exp": ranks of a sharded solve agree on one)
     int amax_exp = 0;            // 2^amax_exp > max|a_ij| of THIS matrix (csb.h's bound on the products)
@@ -427,8 +429,8 @@ extern "C" int lsqrhip_destroy(lsqrhip_handle_t h)
     destroy_graph(h);
     free_csr(h->A);
     free_csr(h->AT);
-    for (double *p : {h->U, h->V, h->W, h->X, h->SE, h->Z, h->partials, h->xmax_part, h->d_scalar, h->d_log, h->dict, h->opX,
-                      h->opY})
+    for (double *p : {h->U, h->V, h->W, h->X, h->SE, h->Z, h->partials, h->xmax_part, h->MXU, h->MXV, h->d_scalar, h->d_log,
+                      h->dict, h->opX, h->opY})
         if (p) (void)hipFree(p);
     if (h->op_free) h->op_free(h->op_user);
     if (h->shard.wsq) (void)hipFree(h->shard.wsq);
@@ -1377,6 +1379,13 @@ static int alloc_workspace(H *h)
     HIPCHK(hipMalloc((void **)&h->SE, esz * n1));
     HIPCHK(hipMalloc((void **)&h->partials, sizeof(double) * 3 * SPMV_MAX_GRID));
     HIPCHK(hipMalloc((void **)&h->xmax_part, sizeof(double) * CSB_XMAX_GRID * (VEC_BLOCK / WAVE)));
+    if (h->A.csb && h->AT.csb && env_int("LSQRHIP_CSB_XFOLD", 1) != 0) {   // solve_loop.h xmax_folded: two sets each
+        const size_t bytes = sizeof(double) * 2 * CSB_XMAX_GRID * (VEC_BLOCK / WAVE);
+        HIPCHK(hipMalloc((void **)&h->MXU, bytes));
+        HIPCHK(hipMalloc((void **)&h->MXV, bytes));
+        HIPCHK(hipMemsetAsync(h->MXU, 0, bytes, s));
+        HIPCHK(hipMemsetAsync(h->MXV, 0, bytes, s));
+    }
     {
         const int64_t zn = std::max<int64_t>(h->A.P > 1 ? h->A.rows_v : 0, h->AT.P > 1 ? h->AT.rows_v : 0);
         if (zn > 0) HIPCHK(hipMalloc((void **)&h->Z, sizeof(double) * (size_t)zn));

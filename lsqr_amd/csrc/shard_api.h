@@ -269,6 +269,8 @@ extern "C" int lsqrhip_shard_begin(lsqrhip_handle_t h, const double *d_b_local, 
     c.mylen = std::min<int64_t>(c.chunk, (int64_t)h->n - c.my0);
     c.T = d_T; c.R = d_R; c.V = d_V; c.sums = d_sums;
     c.wantse = wantse;
+    c.upar = 0;
+    if (h->MXU != nullptr) HIPCHK(hipMemsetAsync(h->MXU, 0, sizeof(double) * 2 * MX_SET, s));   // (xmax_folded: both sets zero)
     if (!c.wsq) HIPCHK(hipMalloc((void **)&c.wsq, sizeof(double)));
     if (!c.live) HIPCHK(hipMalloc((void **)&c.live, sizeof(int)));
     RET(prepare_log(h, itnlim, c.want_log));
@@ -408,6 +410,10 @@ static int shard_stage_phase(lsqrhip_handle_t h, int stage, int phase)
             a.xmax_in = h->xmax_part;
             a.nxmax_in = c.P * SHARD_NMAX;
         }
+        if (c.gath != nullptr && xmax_folded(h)) {   // (the engine: u's piece maxima for mode 2, solve_loop.h xmax_folded)
+            if (phase <= 0) c.upar ^= 1;
+            a.ymax_out = h->MXU + c.upar * MX_SET;
+        }
         launch_spmv_args(h, a);
         if (phase < 0 || phase >= std::max(h->A.csb ? h->A.phases : 1, 1) - 1)
             hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(VEC_BLOCK), 0, s, (const double *)h->partials,
@@ -427,6 +433,11 @@ static int shard_stage_phase(lsqrhip_handle_t h, int stage, int phase)
         a.c = &h->AT; a.x = h->U; a.y = T; a.coef = &st->c2p; a.stop = &st->stop; a.pout = h->partials; a.stream = s;
         a.unit_x = true;
         a.phase = phase;
+        if (c.gath != nullptr && xmax_folded(h)) {
+            a.xmax_in = h->MXU + c.upar * MX_SET;
+            a.nxmax_in = csb_npieces(h->m);
+            a.xmax_clr = h->MXU + (c.upar ^ 1) * MX_SET;   // (what the next mode 1 raises)
+        }
         launch_spmv_args(h, a);
         break;
     }

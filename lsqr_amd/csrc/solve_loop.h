@@ -68,6 +68,9 @@ struct SpmvArgs {
     bool unit_x = false;             // |x * sx| <= 1 is known (solver-internal vectors)
     const double *xmax_in = nullptr; // csb.h: piece maxima of |x| the caller already holds (the sharded engine: each rank's
     int nxmax_in = 0;                // share travels with the norms) -- the k_csb_xmax pass over x is then left out
+    double *ymax_out = nullptr;      // csb.h: where this product raises the piece maxima of the y it writes (csb_npieces(rows)
+                                     // words, zero on entry), for the product that gathers from it next -- or null
+    double *xmax_clr = nullptr;      // csb.h: with xmax_in, the other set of x's piece maxima: zeroed on the way (CsbX.clr)
     int phase = -1, nphases = 1;     // csb.h with column stripes: launch only the sweeps of this phase (-1: the whole product)
 };
 
@@ -284,14 +287,15 @@ static void launch_csb_N(H *h, const SpmvArgs &a)
     // max|x| first, piece by piece (what fixes the grids of the exact sums, csb.h): one pass over the vector
     // the product gathers from -- the solver's own vectors too (a bound from |x|_2 = 1 alone does not survive
     // duplicate entries, and is the looser one besides)
-    const int xg = (int)std::min<int64_t>(CSB_XMAX_GRID, std::max<int64_t>(1, ((int64_t)c.cols + VEC_BLOCK - 1) / VEC_BLOCK));
+    const CsbPieces xpc = csb_pieces(c.cols);
     static const int tau_split = env_int("LSQRHIP_CSB_TAU", 1);
-    CsbX xb{h->xmax_part, xg * (VEC_BLOCK / WAVE), tau_split};
-    if (a.xmax_in != nullptr) {   // the caller holds the piece maxima (shard_engine.h): no pass over x
+    CsbX xb{h->xmax_part, xpc.NP, tau_split, nullptr};
+    if (a.xmax_in != nullptr) {   // the caller holds the piece maxima (the product that wrote x; shard_engine.h): no pass over x
         xb.xmax = a.xmax_in;
         xb.nxmax = a.nxmax_in;
+        if (a.xmax_clr != nullptr && a.nxmax_in == csb_npieces(c.cols)) xb.clr = reinterpret_cast<unsigned long long *>(a.xmax_clr);
     } else if (head) {
-        hipLaunchKernelGGL(k_csb_xmax<VT>, dim3(xg), dim3(VEC_BLOCK), 0, a.stream, x, (int64_t)c.cols, h->xmax_part);
+        hipLaunchKernelGGL(k_csb_xmax<VT>, dim3(xpc.NP), dim3(VEC_BLOCK), 0, a.stream, x, (int64_t)c.cols, xpc, h->xmax_part);
     }
     // One launch per ROUND of row blocks (256 at a time, one per CU).  Every workgroup sweeps x from its
     // first to its last column; workgroups that start a sweep together stay close enough for the part of x
@@ -304,7 +308,8 @@ static void launch_csb_N(H *h, const SpmvArgs &a)
     static const int rounds = env_int("LSQRHIP_CSB_ROUNDS", 1);
     const int S = std::max(c.S, 1);
     CsbMat A{c.cval, c.cidx, c.cdel, c.ccb, c.cptr, c.crs, c.nrb, c.R, c.rows, c.cols, c.rexp, c.zcoarse, 0, 0, S, c.zsplit,
-             c.cbad, std::max(c.Q, 1), c.gptr, c.NS, c.G, c.J, c.Pst, c.border, 0, S};
+             c.cbad, std::max(c.Q, 1), c.gptr, c.NS, c.G, c.J, c.Pst, c.border, 0, S,
+             reinterpret_cast<unsigned long long *>(a.ymax_out)};
     bool first = head;
     for (int ph = ph0; ph < ph1; ++ph) {
         int p0 = 0, p1 = c.nrb, nsp = S;   // positions of the launch order, splits per unit row
@@ -525,6 +530,16 @@ static Rider rider_init2(H *h)  // k_s_init2 of the start of a solve (alpha, arn
     r.st = h->d_state;
     return r;
 }
+// Both matrices in column-swept row blocks: each product's epilogue raises the piece maxima of the vector it writes
+// (csb.h CsbMat.ymax -- the words the k_csb_xmax pass would leave) and the other product takes its grids from them: no
+// pass inside the loop, same results bit for bit (LSQRHIP_CSB_XFOLD=0 at create: the passes).  Two sets per vector, by
+// the parity of the iteration: the atomic maxima need zeros to start from, and the product that READS set p of a vector
+// zeroes set 1 - p on its way -- between the last reader of that set and its next writer.
+constexpr int MX_SET = CSB_XMAX_GRID * (VEC_BLOCK / WAVE);
+static bool xmax_folded(const H *h)
+{
+    return h->A.csb && h->AT.csb && h->MXU != nullptr && h->MXV != nullptr;
+}
 // The fused schedule (pipeline 2) is used when A is neither panelled nor in column-swept row blocks.
 static bool fused_schedule(const H *h) { return h->pipeline >= 2 && h->A.P <= 1 && !h->A.csb; }
 
@@ -540,6 +555,11 @@ static void launch_k1(H *h, int i, const Rider &rider, hipEvent_t e0, hipEvent_t
     a.slot_in = &slotB[prev]; a.slot_out = &slotA[par]; a.skip_if_zero = 0; a.stop = &h->d_state->stop;
     a.pout = h->P1[par]; a.rider = rider; a.stream = h->stream; a.e0 = e0; a.e1 = e1;
     a.unit_x = true;
+    if (xmax_folded(h)) {   // v's piece maxima came out of the mode-2 product that wrote it; u's go to the next one
+        a.xmax_in = h->MXV + par * MX_SET; a.nxmax_in = csb_npieces(h->n);
+        a.xmax_clr = h->MXV + prev * MX_SET;   // (what K2(i) will raise: its last reader, K1(i-1), is done)
+        a.ymax_out = h->MXU + par * MX_SET;
+    }
     if (fuse) {
         UpdArgs &u = a.upd;
         u.on = fuse;
@@ -562,6 +582,11 @@ static void launch_k2(H *h, int i, const Rider &rider, hipEvent_t e0, hipEvent_t
     a.slot_in = &slotA[par]; a.slot_out = &slotB[par]; a.skip_if_zero = 1; a.stop = &h->d_state->stop;
     a.pout = h->P2[par]; a.rider = rider; a.stream = h->stream; a.e0 = e0; a.e1 = e1;
     a.unit_x = true;
+    if (xmax_folded(h)) {
+        a.xmax_in = h->MXU + par * MX_SET; a.nxmax_in = csb_npieces(h->m);
+        a.xmax_clr = h->MXU + (par ^ 1) * MX_SET;   // (what K1(i+1) will raise)
+        a.ymax_out = h->MXV + (par ^ 1) * MX_SET;   // K1(i+1) reads the set of ITS parity
+    }
     launch_spmv_args(h, a);
 }
 
@@ -665,6 +690,11 @@ static int enqueue_solve_start(H *h, int wantse, bool lean)
         SpmvArgs a;
         a.c = &h->AT; a.x = h->U; a.y = h->V; a.coef = &st->c2; a.stop = h->d_zero; a.pout = h->P2[0]; a.stream = s;
         a.unit_x = true;
+        if (xmax_folded(h)) {   // (u = b / beta: its maxima by the pass; v's for the first mode 1, iteration 1; all sets zero)
+            HIPCHK(hipMemsetAsync(h->MXU, 0, sizeof(double) * 2 * MX_SET, s));
+            HIPCHK(hipMemsetAsync(h->MXV, 0, sizeof(double) * 2 * MX_SET, s));
+            a.ymax_out = h->MXV + 1 * MX_SET;
+        }
         launch_spmv_args(h, a);
     }
     if (lean) return LSQRHIP_OK;

@@ -20,6 +20,7 @@
 #pragma once
 
 #include "common.h"
+#include "csb.h"   // csb_hi_up
 #include "state.h"
 
 namespace lsqrhip {
@@ -400,21 +401,36 @@ __global__ __launch_bounds__(VEC_BLOCK) void k_amax(const VT *__restrict__ x, in
     if (threadIdx.x == 0) partials[blockIdx.x] = red[0];
 }
 
-// The max|x| pass in front of every column-swept product (csb.h), under a name of its own so that profiles and PMC
-// passes can tell it from the build's k_amax over the matrix values.  It leaves one maximum per WAVE: the maxima
-// of 4 * gridDim.x strided pieces of x, from which csb.h takes max|x| and -- the median piece -- what the bulk of x
-// looks like (its "tau").  Grid: csb_xmax_grid(n) workgroups.
-constexpr int CSB_XMAX_GRID = 1024;
+// The max|x| pass in front of a column-swept product (csb.h), under a name of its own so that profiles and PMC
+// passes can tell it from the build's k_amax over the matrix values.  One workgroup per PIECE of x (csb.h csb_pieces:
+// aligned groups of 2^L elements dealt round-robin to NP pieces), one maximum each: from them csb.h takes max|x| and --
+// the median piece -- what the bulk of x looks like (its "tau").
+// A piece's maximum is kept to the high word of the binary64, rounded UP (csb_hi_up): a bound within 2^-19 of the
+// maximum, which a product that WRITES the vector can also keep with a 32-bit wave reduction per 64 rows and one atomic
+// max per group (csb.h csb_group_max) -- inside the solver's loop the pass is left out and both ways give the same words.
+constexpr int CSB_XMAX_GRID = 1024;   // (x 4: the most pieces, csb.h CSB_XMAX_PIECES)
+static_assert(CSB_XMAX_GRID * (VEC_BLOCK / WAVE) == CSB_XMAX_PIECES, "xmax_part holds one word per piece");
+static inline int csb_npieces(int64_t n) { return csb_pieces(n).NP; }
 template <typename VT>
-__global__ __launch_bounds__(VEC_BLOCK) void k_csb_xmax(const VT *__restrict__ x, int64_t n,
+__global__ __launch_bounds__(VEC_BLOCK) void k_csb_xmax(const VT *__restrict__ x, int64_t n, CsbPieces pc,
                                                         double *__restrict__ partials)
 {
+    __shared__ double red[VEC_BLOCK / WAVE];
     double m = 0.0;
-    const int64_t stride = (int64_t)gridDim.x * VEC_BLOCK;
-    for (int64_t i = (int64_t)blockIdx.x * VEC_BLOCK + threadIdx.x; i < n; i += stride) m = fmax(m, fabs((double)x[i]));
+    const int64_t groups = (n + ((int64_t)1 << pc.L) - 1) >> pc.L;
+    for (int64_t g = blockIdx.x; g < groups; g += pc.NP) {
+        const int64_t i0 = g << pc.L, i1 = std::min<int64_t>(i0 + ((int64_t)1 << pc.L), n);
+        for (int64_t i = i0 + threadIdx.x; i < i1; i += VEC_BLOCK) m = fmax(m, fabs((double)x[i]));
+    }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off, WAVE));
-    if ((threadIdx.x & (WAVE - 1)) == 0) partials[blockIdx.x * (VEC_BLOCK / WAVE) + (threadIdx.x >> 6)] = m;
+    if ((threadIdx.x & (WAVE - 1)) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 1; i < VEC_BLOCK / WAVE; ++i) m = fmax(m, red[i]);
+        partials[blockIdx.x] = __longlong_as_double((long long)((unsigned long long)csb_hi_up(m) << 32));
+    }
 }
 
 // partials[b] = sum over this workgroup's share of (x[i] * sc)^2   (sc a power of two: exact)

@@ -20,7 +20,7 @@ CASES = build_cases()
 
 @pytest.fixture
 def csb_env():
-    keys = ("LSQRHIP_CSB", "LSQRHIP_CSB_R", "LSQRHIP_CSB_S", "LSQRHIP_CSB_NARROW")
+    keys = ("LSQRHIP_CSB", "LSQRHIP_CSB_R", "LSQRHIP_CSB_S", "LSQRHIP_CSB_NARROW", "LSQRHIP_CSB_XFOLD")
     old = {k: os.environ.get(k) for k in keys}
     os.environ["LSQRHIP_CSB"] = "1"
 
@@ -123,6 +123,8 @@ def test_results_do_not_depend_on_the_blocking_bit_for_bit(csb_env, kind):
         assert np.array_equal(y, ys[0])
     for x in xs[1:]:
         assert np.array_equal(x, xs[0])
+    # (pipeline 0 runs the k_csb_xmax pass in front of every product, pipeline 1 takes the piece maxima from the product
+    #  that wrote the vector: the same words -- test_piece_maxima_of_the_writing_product_are_those_of_the_pass)
     # ... and scaling x by a power of two scales y exactly (the grids move with max|x|)
     os.environ.pop("LSQRHIP_CSB_S", None)
     csb_env(None)
@@ -400,3 +402,28 @@ def test_overlap_plan_of_the_sharded_engine_changes_no_bit_of_a_product(world, p
     assert np.linalg.norm(res[0][2].x - res[1][2].x) <= 1e-12 * np.linalg.norm(res[0][2].x)
     _, y_ref = oracle.port().aprod(1, p.m, p.n, p.irow, p.icol, p.a, xp, yp)
     assert np.max(np.abs(res[1][0] - y_ref)) <= 1e-13 * np.max(np.abs(y_ref))
+
+
+@pytest.mark.parametrize("real32", [False, True])
+def test_piece_maxima_of_the_writing_product_are_those_of_the_pass(csb_env, real32):
+    """Inside the loop no k_csb_xmax pass runs: the epilogue of the product that WRITES u (v) raises the piece maxima the
+    pass would have left -- same pieces, same words (csb.h csb_piece_max) -- and the other product takes its grids from
+    them.  LSQRHIP_CSB_XFOLD=0 brings the passes back; on vectors whose grids depend on the pieces (power-law rows: spikes
+    in u) a solve must not move by a bit, whatever the blocking (row blocks that start anywhere inside a group of 64
+    rows, column splits whose second kernel writes y)."""
+    p = P.powerlaw_rows(5000, 3000, seed=11, dmin=3, dmax=2500, damp=1e-3)
+    for R, S in ((None, None), (777, None), (1000, 3), (64, None)):
+        csb_env(R)
+        os.environ.pop("LSQRHIP_CSB_S", None)
+        if S:
+            os.environ["LSQRHIP_CSB_S"] = str(S)
+        out = []
+        for fold in (1, 0):
+            os.environ["LSQRHIP_CSB_XFOLD"] = str(fold)
+            s = lsqr_solver_ez().initialize(p.m, p.n, p.a, p.irow, p.icol, itnlim=40, real32=real32)
+            assert s.info()["xlds"] == 3 and s.info()["xlds_t"] == 3
+            r = s.solve(p.b, 1e-3)
+            out.append((r.x.copy(), r.anorm, r.rnorm, r.arnorm, r.itn))
+            r = s.solve(p.b, 1e-3)    # (the second solve of a handle starts from sets the first one left)
+            assert np.array_equal(r.x, out[-1][0]) and r.anorm == out[-1][1]
+        assert np.array_equal(out[0][0], out[1][0]) and out[0][1:] == out[1][1:]
