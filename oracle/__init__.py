@@ -344,7 +344,10 @@ def port() -> _Port:
     if _port is None:
         path = os.path.join(_HERE, "liblsqr_oracle.so")
         src = os.path.join(_HERE, "lsqr_oracle.c")
-        if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
+        san = os.environ.get("LSQR_ORACLE_LIB")    # tests/test_oracle_sanitized.py: the ASan / UBSan build of the same sources
+        if san:
+            path = san
+        elif not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
             build()
         _port = _Port(path)
     return _port

@@ -84,3 +84,29 @@ def test_lsqrtest_ez_compiles_unchanged_and_links(tmp_path):
     else:
         assert p.returncode != 0
         assert "no usable MI355X" in out
+
+
+def test_host_layer_under_address_sanitizer(tmp_path):
+    """The Fortran host layer (lsqr_kinds, lsqpblas_module, lsqr_module with its host `lsqr` / `acheck` / `xcheck`, and
+    lsqr_device_module) compiled with -fsanitize=address and driven by the reference's 18-problem program on the host
+    path: no read or write outside an array, no use after free, nothing leaked (sanitizers exist for CPU code only on
+    this pool; the HIP side is held by the bitwise-repeatability tests)."""
+    tmp = str(tmp_path)
+    src = os.path.join(ROOT, "lsqr_amd", "fortran")
+    san = ["-O1", "-g", "-fsanitize=address", "-ffp-contract=off"]
+    for f, cpp in (("lsqr_kinds.F90", True), ("lsqrblas.f90", False), ("lsqr_module.f90", False),
+                   ("lsqr_device_module.F90", True)):
+        p = subprocess.run([FC] + san + (["-cpp"] if cpp else []) + ["-c", os.path.join(src, f)], cwd=tmp,
+                           capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-3000:]
+    objs = ["lsqr_kinds.o", "lsqrblas.o", "lsqr_module.o", "lsqr_device_module.o"]
+    exe = os.path.join(tmp, "lsqrtest_san")
+    p = subprocess.run([FC] + san + [os.path.join(REF, "test", "lsqrtest_module.f90"), os.path.join(REF, "test", "lsqrtest.f90")]
+                       + objs + ["-L" + LIB, "-llsqrhip", "-Wl,-rpath," + LIB, "-o", exe], cwd=tmp, capture_output=True,
+                       text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=1")
+    p = subprocess.run([exe], cwd=tmp, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "AddressSanitizer" not in p.stderr and "LeakSanitizer" not in p.stderr, p.stderr[-3000:]
+    lis = open(os.path.join(tmp, "LSQR.LIS")).read()
+    assert len(re.findall(r"LSQR\s+appears to be successful", lis)) == 16
