@@ -488,7 +488,7 @@ def spawn_ranks(args):
     exec), BEFORE this process touches the GPU, and pass the child's JSON line through."""
     import torch
     have = torch.cuda.device_count()          # does not initialise a context
-    if have < args.gpus:
+    if have < args.gpus and os.environ.get("LSQR_RANKS_SHARE_GPU", "0") in ("", "0"):   # (the test switch: dist_bench.share_one_gpu)
         raise SystemExit(f"bench.py: --gpus {args.gpus} needs {args.gpus} GPUs, this node shows {have}")
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))

@@ -71,6 +71,20 @@ def rank0_block_traffic(spec: str, row0: int, nrows: int):
     return traffic.get((spec, "{}", (int(row0), int(nrows)))), note
 
 
+def share_one_gpu(rank: int) -> bool:
+    """LSQR_RANKS_SHARE_GPU=1 (a TEST switch, never a measurement): every rank of the job uses device 0.  RCCL refuses
+    ranks that share a device of one HOST, so each rank claims a host of its own (NCCL_HOSTID) and the ranks talk over the
+    loopback interface: the socket transport instead of xGMI, but the same communicator set-up, the same grouped
+    send / receive and all-gather calls, the same stream ordering -- what a one-GPU box can execute of the N > 1 path.
+    Must run before anything initialises RCCL (torch's or the library's)."""
+    if os.environ.get("LSQR_RANKS_SHARE_GPU", "0") in ("", "0"):
+        return False
+    os.environ["NCCL_HOSTID"] = f"lsqr-shared-gpu-rank{rank}"
+    os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+    os.environ.setdefault("NCCL_IB_DISABLE", "1")
+    return True
+
+
 def run_distributed(args):
     import numpy as np
     import torch
@@ -82,6 +96,9 @@ def run_distributed(args):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    shared = share_one_gpu(rank)
+    if shared:
+        local = 0
     if not torch.cuda.is_available():
         raise SystemExit("bench.py: no MI355X visible; the HIP path has no CPU fallback")
     spec = DEFAULT_SPEC if args.workload == "auto" else args.workload
@@ -225,7 +242,12 @@ def run_distributed(args):
             torch.cuda.synchronize()
             dt1 = time.perf_counter() - t1
             ref = {"n_gpus": 1, "steps": kr, "value": rr.itn / dt1, "unit": "it/s", "ms_per_step": 1e3 * dt1 / rr.itn,
-                   "note": "same matrix, whole on rank 0's GPU, measured after the timed sharded solve"}
+                   "note": "same matrix, whole on rank 0's GPU, measured after the timed sharded solve",
+                   "result": {"istop": rr.istop, "itn": rr.itn, "anorm": rr.anorm, "rnorm": rr.rnorm}}
+            if kr == K and restarts == 0 and rr.itn == r.itn:
+                # the same K iterations on one handle and on `world` ranks: how far the run's norms lie apart
+                ref["sharded_vs_1gpu"] = {"rnorm_rel": abs(r.rnorm - rr.rnorm) / abs(rr.rnorm) if rr.rnorm else 0.0,
+                                          "anorm_rel": abs(r.anorm - rr.anorm) / abs(rr.anorm) if rr.anorm else 0.0}
             del full, d_x
         except Exception as e:  # e.g. not enough HBM for the whole matrix: report, do not fail the run
             ref = {"error": repr(e)}
@@ -260,7 +282,8 @@ def run_distributed(args):
                            {"allreduce_scalars": "1 + 2 doubles (all-gather + rank-ordered sum)",
                             "reduce_scatter_bytes_out_per_gpu": 8 * cfg["n"] * (world - 1) // world,
                             "allgather_bytes_in_per_gpu": 8 * cfg["n"] * (world - 1) // world},
-                       "backend": "nccl (RCCL over xGMI)", "engine": engine, "engine_note": engine_note, "world_size": dist.get_world_size(),
+                       "backend": ("nccl (RCCL; TEST: all ranks on ONE GPU, socket transport over lo -- not a measurement)" if shared
+                                   else "nccl (RCCL over xGMI)"), "ranks_share_one_gpu": shared, "engine": engine, "engine_note": engine_note, "world_size": dist.get_world_size(),
                        "restarts": restarts},
             "result": {"istop": r.istop, "itn": r.itn, "anorm": r.anorm, "rnorm": r.rnorm},
             "roofline": {"bound": "hbm", "kernel": f"{kname} (aprod mode 1, local row block, rank 0)",

@@ -182,7 +182,8 @@ def test_one_rank_world_through_comm_init_and_shard_solve(name):
     assert r3.istop == g.istop
 
 
-# ---- real RCCL, two ranks: only on a node with at least two GPUs (skipped on the one-GPU test boxes) ----
+# ---- real RCCL, two ranks on two GPUs (skipped on the one-GPU test boxes; the same calls run there with ranks that
+#      SHARE the GPU: test_rccl_ranks_sharing_one_gpu_through_bench_launcher below) ----
 def _two_gpus():
     import torch
     return torch.cuda.device_count() >= 2
@@ -226,6 +227,47 @@ def test_rccl_two_ranks_through_bench_launcher(overlap):
     line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["config"]["world_size"] == 2 and line["steps"] == 20
     assert line["result"]["itn"] == 20 and line["value"] > 0 and line["overlap"] == int(overlap)
+
+
+@pytest.mark.parametrize("world,overlap", [(2, "0"), (2, "1"), (3, "0"), (4, "1"), (8, "0"), (8, "1")])
+def test_rccl_ranks_sharing_one_gpu_through_bench_launcher(world, overlap):
+    """The RCCL branch at world > 1 on a ONE-GPU box: `bench.py --gpus N` with LSQR_RANKS_SHARE_GPU=1 starts N processes
+    that all use device 0; each claims a host of its own (NCCL_HOSTID) so that RCCL takes them, over its socket
+    transport on `lo`.  What runs is the real thing above the transport: ncclCommInitRank from an id handed round by
+    torch.distributed, the second communicator split off it (overlap = 1), the grouped ncclSend / ncclRecv reduce-scatter,
+    both all-gathers, the exchange stream and its events -- driven by the C++ engine, which dist_bench first holds
+    against the stage-by-stage Python driver (torch.distributed collectives) on four iterations: `engine` = "c++" with
+    no `engine_note` says they agreed on every rank.  The result is then held against ONE handle solving the whole
+    matrix."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec, K = "random:200000:100000:20", 20
+    env = {**os.environ, "LSQR_BENCH_STRONG_REF": "0", "LSQRHIP_SHARD_OVERLAP": overlap, "LSQR_RANKS_SHARE_GPU": "1",
+           "LSQR_DIST_PROBE_TIMEOUT": "300"}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", str(K), "--warmup", "2",
+           "--workload", spec, "--traffic", "off", "--cpu-iters", "0"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == world and line["config"]["world_size"] == world and line["steps"] == K
+    assert line["config"]["ranks_share_one_gpu"] is True and "TEST" in line["config"]["backend"]
+    assert line["config"]["engine"] == "c++" and line["config"]["engine_note"] is None, line["config"]
+    assert line["result"]["itn"] == K and line["value"] > 0 and line["overlap"] == int(overlap)
+    # the same 20 iterations on one handle that holds the whole matrix (same generator)
+    from lsqr_amd import devgen
+    from lsqr_amd.capi import DeviceBuffer
+    dp = devgen.generate(spec)
+    s = dp.solver
+    s.atol = s.btol = s.conlim = 0.0
+    s.itnlim = K
+    d_x = DeviceBuffer(8 * dp.n)
+    r = s.solve_device(dp.d_b.ptr.value, d_x.ptr.value, dp.damp)
+    tol = 1e-10
+    assert r.itn == K
+    assert abs(line["result"]["rnorm"] - r.rnorm) <= tol * r.rnorm and abs(line["result"]["anorm"] - r.anorm) <= tol * r.anorm
 
 
 @pytest.mark.parametrize("fail", ["0", "1"])
@@ -477,3 +519,30 @@ def test_overlapped_exchanges_change_no_bit(loopback, ngpu, csb, parts):
     assert off[5].shape == on[5].shape and np.array_equal(off[5], on[5])
     g = oracle.port().solve(p.m, p.n, p.irow, p.icol, p.a, p.b, damp=p.damp, atol=1e-10, btol=1e-10, itnlim=25)
     assert (on[2], on[3]) == (g.istop, g.itn) and np.linalg.norm(on[0] - g.x) <= 1e-10 * np.linalg.norm(g.x)
+
+
+@pytest.mark.parametrize("overlap", ["0", "1"])
+def test_configs3_as_stated_eight_rccl_ranks_sharing_one_gpu(overlap):
+    """BASELINE configs[3] AS STATED -- 10M x 10M at 100 per row (1e9 nonzeros), row blocks on EIGHT ranks, RCCL -- on a
+    one-GPU box: the eight processes share device 0 (LSQR_RANKS_SHARE_GPU=1, see the test above).  The C++ engine's
+    20 iterations must match the stage-by-stage Python driver's (dist_bench's cross-check: engine "c++", no note) and
+    ONE handle that holds the whole matrix, run by the same job on rank 0: anorm and rnorm to 1e-10 (measured:
+    2e-16 / 2e-15, profiles/r04/rccl_shared_gpu_configs3_*.json).  Needs ~60 GB of HBM and about a minute."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {**os.environ, "LSQR_BENCH_STRONG_REF": "1", "LSQRHIP_SHARD_OVERLAP": overlap, "LSQR_RANKS_SHARE_GPU": "1",
+           "LSQR_DIST_PROBE_TIMEOUT": "600"}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "20", "--warmup", "2",
+                        "--workload", "random:10000000:10000000:100", "--traffic", "off", "--cpu-iters", "0"],
+                       capture_output=True, text=True, timeout=1500, env=env)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 8 and line["config"]["ranks_share_one_gpu"] is True and line["overlap"] == int(overlap)
+    assert line["config"]["engine"] == "c++" and line["config"]["engine_note"] is None, line["config"]
+    assert line["config"]["rows_per_rank"] == [1250000] * 8 and line["result"]["itn"] == 20
+    ref = line["strong_scaling_ref"]
+    assert ref["result"]["itn"] == 20 and ref["result"]["istop"] == line["result"]["istop"]
+    assert ref["sharded_vs_1gpu"]["rnorm_rel"] <= 1e-10 and ref["sharded_vs_1gpu"]["anorm_rel"] <= 1e-10
