@@ -2,7 +2,9 @@
 
     python tests/dist_worker.py RANK WORLD PORT CASE BACKEND OUT.npz
 
-BACKEND = numpy (CPU, gloo, oracle-backed stage stand-in) | hip (C-ABI stages on cuda:0, gloo)."""
+BACKEND = numpy (CPU, gloo, oracle-backed stage stand-in) | hip (C-ABI stages on cuda:0, gloo)
+        | engine / engine32 / engine_ov / engine32_ov (the C++ engine over RCCL, binary64 / REAL32, exchanges plain /
+          overlapped: the ranks SHARE cuda:0, each with a NCCL_HOSTID of its own -- lsqr_amd.dist_bench.share_one_gpu)."""
 import os
 import sys
 
@@ -22,6 +24,8 @@ def main():
     from cases import build_cases
     from lsqr_amd.dist import ShardedLSQR, TorchComm, local_block, partition_rows
 
+    if backend.startswith("engine"):
+        return engine_rank(rank, world, port, case, backend, out)
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     p, o = build_cases()[case]
     w = np.bincount(p.irow - 1, minlength=p.m).astype(np.float64)
@@ -47,6 +51,45 @@ def main():
     se = None if r.se is None else (r.se.cpu().numpy() if hasattr(r.se, "cpu") else np.asarray(r.se))
     np.savez(out, x=x, se=se if se is not None else np.zeros(0), istop=r.istop, itn=r.itn, anorm=r.anorm,
              acond=r.acond, rnorm=r.rnorm, arnorm=r.arnorm, xnorm=r.xnorm, row0=row0, nrows=nrows)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def engine_rank(rank, world, port, case, backend, out):
+    """The C++ engine (csrc/shard_engine.h) on this rank's row block, RCCL between the ranks."""
+    os.environ["LSQR_RANKS_SHARE_GPU"] = "1"
+    real32 = "32" in backend
+    if backend.endswith("_ov"):
+        os.environ["LSQRHIP_SHARD_OVERLAP"] = "1"
+        os.environ["LSQRHIP_SHARD_WORLD"] = str(world)
+    from lsqr_amd.dist_bench import share_one_gpu
+    assert share_one_gpu(rank)
+    import torch
+    import torch.distributed as dist
+    from cases import build_cases
+    from lsqr_amd import capi
+    from lsqr_amd.dist import EngineSolver, local_block, partition_rows
+    from lsqr_amd.solver import lsqr_solver_ez
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world,
+                            device_id=torch.device("cuda:0"))
+    p, o = build_cases()[case]
+    w = np.bincount(p.irow - 1, minlength=p.m).astype(np.float64)
+    row0, nrows = partition_rows(p.m, world, w)[rank]
+    irow, icol, a, b = local_block(p.irow, p.icol, p.a, p.b, row0, nrows)
+    s = lsqr_solver_ez().initialize(nrows, p.n, a, irow, icol, real32=real32)
+    wp = np.float32 if real32 else np.float64
+    d_b = capi.DeviceBuffer.from_array((b if nrows else np.zeros(1)).astype(wp))
+    eng = EngineSolver(s, row0, p.m, world, rank)
+    r = eng.solve(d_b.ptr.value, damp=o["damp"], atol=o["atol"], btol=o["btol"], conlim=o["conlim"], itnlim=o["itnlim"],
+                  wantse=o["wantse"])
+    r2 = eng.solve(d_b.ptr.value, damp=o["damp"], atol=o["atol"], btol=o["btol"], conlim=o["conlim"], itnlim=o["itnlim"],
+                   wantse=o["wantse"])       # the communicators, streams and buffers serve a second solve: same bits
+    x = r.x.to_array(wp, p.n).astype(np.float64)
+    se = r.se.to_array(wp, p.n).astype(np.float64) if r.se is not None else np.zeros(0)
+    np.savez(out, x=x, se=se, istop=r.istop, itn=r.itn, anorm=r.anorm, acond=r.acond, rnorm=r.rnorm, arnorm=r.arnorm,
+             xnorm=r.xnorm, row0=row0, nrows=nrows, again_same=int((r2.istop, r2.itn, r2.anorm, r2.rnorm) ==
+                                                                     (r.istop, r.itn, r.anorm, r.rnorm)))
     dist.barrier()
     dist.destroy_process_group()
 

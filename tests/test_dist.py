@@ -111,3 +111,46 @@ def test_sharded_driver_gloo_cpu(case, world, tmp_path):
 @pytest.mark.parametrize("case", ["random_over_damped", "poisson_20x20_it50", "random_over_se"])
 def test_sharded_hip_stages_two_ranks_one_gpu(case, tmp_path):
     check_against_oracle(case, run_world(case, 2, "hip", tmp_path))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case,world,backend", [
+    ("random_over_se", 2, "engine"),             # wantse: the standard errors' slices gathered over RCCL
+    ("random_over_damped", 3, "engine"),         # n = 500 over 3 ranks: ragged last column slice
+    ("poisson_20x20_it50", 5, "engine_ov"),      # 400 columns over 5 ranks, exchanges in parts on the second communicator
+    ("empty_rows_cols_it20", 2, "engine_ov"),
+    ("shuffled_dups", 4, "engine"),              # n = 60, unsorted COO with duplicates
+    ("one_by_one", 2, "engine"),                 # one row on two ranks: rank 1 holds an EMPTY row block
+    ("zero_matrix", 3, "engine"),
+    ("b_zero", 2, "engine"),                     # stops before the first exchange
+])
+def test_cpp_engine_over_rccl_ranks_sharing_one_gpu(case, world, backend, tmp_path):
+    """The C++ engine's RCCL branch between real processes (one per rank, all on cuda:0: each rank claims a host of its
+    own, lsqr_amd.dist_bench.share_one_gpu): against the oracle's solve of the whole system -- istop, itn, x, se, the
+    norms -- replicated bit for bit on every rank, and repeatable on the same communicators."""
+    res = run_world(case, world, backend, tmp_path)
+    assert all(int(r["again_same"]) == 1 for r in res)
+    if case == "b_zero":
+        assert all(int(r["istop"]) == 0 and int(r["itn"]) == 0 and not r["x"].any() for r in res)
+    else:
+        check_against_oracle(case, res)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case,world,backend", [("random_over_se", 2, "engine32"), ("poisson_20x20_it50", 3, "engine32_ov")])
+def test_cpp_engine_real32_over_rccl_ranks_sharing_one_gpu(case, world, backend, tmp_path):
+    """REAL32 handles (src/lsqr_kinds.F90:16-17): float blocks, float exchange buffers -- half the bytes through
+    ncclSend / ncclRecv / all-gather (ncclFloat) -- held to ONE REAL32 handle solving the whole system."""
+    from lsqr_amd.solver import lsqr_solver_ez
+    res = run_world(case, world, backend, tmp_path)
+    p, o = CASES[case]
+    s = lsqr_solver_ez().initialize(p.m, p.n, p.a, p.irow, p.icol, atol=o["atol"], btol=o["btol"], conlim=o["conlim"],
+                                    itnlim=o["itnlim"], real32=True)
+    ref = s.solve(p.b, o["damp"], wantse=o["wantse"])
+    for r in res:
+        assert int(r["again_same"]) == 1
+        assert int(r["istop"]) == ref.istop and abs(int(r["itn"]) - ref.itn) <= max(2, ref.itn // 10)
+        assert np.linalg.norm(r["x"] - ref.x) <= 2e-3 * np.linalg.norm(ref.x)
+        assert abs(float(r["rnorm"]) - ref.rnorm) <= 2e-3 * ref.rnorm
+    for r in res[1:]:
+        assert np.array_equal(r["x"], res[0]["x"])
