@@ -126,8 +126,8 @@ def run_distributed(args):
     prob = devgen.generate(spec, row0, nrows)
     # the loop itself -- kernels and RCCL calls -- runs in C++ (csrc/shard_engine.h); LSQR_DIST_ENGINE=python
     # selects the stage-by-stage driver over torch.distributed instead (same stages, same arithmetic).
-    # The C++ engine's RCCL calls could only be exercised at world = 1 and through the in-process loopback
-    # while this was written (one-GPU boxes), so at world > 1 it is first checked against the Python driver
+    # The C++ engine's RCCL calls have run at world > 1 only between processes that share one GPU (share_one_gpu: socket
+    # transport) and through the in-process loopback -- never over xGMI -- so at world > 1 it is first checked against the Python driver
     # on a 4-iteration solve -- the two must agree to rounding -- and any failure or disagreement, on any
     # rank, falls back to the Python driver for the timed run (reported in config.engine).
     engine = os.environ.get("LSQR_DIST_ENGINE", "c++")

@@ -229,8 +229,9 @@ def test_rccl_two_ranks_through_bench_launcher(overlap):
     assert line["result"]["itn"] == 20 and line["value"] > 0 and line["overlap"] == int(overlap)
 
 
-@pytest.mark.parametrize("world,overlap", [(2, "0"), (2, "1"), (3, "0"), (4, "1"), (8, "0"), (8, "1")])
-def test_rccl_ranks_sharing_one_gpu_through_bench_launcher(world, overlap):
+@pytest.mark.parametrize("world,overlap,graph", [(2, "0", ""), (2, "1", ""), (3, "0", ""), (4, "1", ""), (8, "0", ""),
+                                                 (8, "1", ""), (2, "0", "1"), (3, "0", "1")])
+def test_rccl_ranks_sharing_one_gpu_through_bench_launcher(world, overlap, graph):
     """The RCCL branch at world > 1 on a ONE-GPU box: `bench.py --gpus N` with LSQR_RANKS_SHARE_GPU=1 starts N processes
     that all use device 0; each claims a host of its own (NCCL_HOSTID) so that RCCL takes them, over its socket
     transport on `lo`.  What runs is the real thing above the transport: ncclCommInitRank from an id handed round by
@@ -238,15 +239,18 @@ def test_rccl_ranks_sharing_one_gpu_through_bench_launcher(world, overlap):
     both all-gathers, the exchange stream and its events -- driven by the C++ engine, which dist_bench first holds
     against the stage-by-stage Python driver (torch.distributed collectives) on four iterations: `engine` = "c++" with
     no `engine_note` says they agreed on every rank.  The result is then held against ONE handle solving the whole
-    matrix."""
+    matrix.  graph = "1": LSQRHIP_SHARD_GRAPH=1, the batches of 16 iterations captured WITH their RCCL calls and replayed
+    (40 iterations: two replays and an eager tail)."""
     import json
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    spec, K = "random:200000:100000:20", 20
+    spec, K = "random:200000:100000:20", 40 if graph else 20
     env = {**os.environ, "LSQR_BENCH_STRONG_REF": "0", "LSQRHIP_SHARD_OVERLAP": overlap, "LSQR_RANKS_SHARE_GPU": "1",
            "LSQR_DIST_PROBE_TIMEOUT": "300"}
+    if graph:
+        env["LSQRHIP_SHARD_GRAPH"] = graph
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", str(K), "--warmup", "2",
            "--workload", spec, "--traffic", "off", "--cpu-iters", "0"]
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
