@@ -550,3 +550,25 @@ def test_configs3_as_stated_eight_rccl_ranks_sharing_one_gpu(overlap):
     ref = line["strong_scaling_ref"]
     assert ref["result"]["itn"] == 20 and ref["result"]["istop"] == line["result"]["istop"]
     assert ref["sharded_vs_1gpu"]["rnorm_rel"] <= 1e-10 and ref["sharded_vs_1gpu"]["anorm_rel"] <= 1e-10
+
+
+def test_python_stage_driver_over_nccl_ranks_sharing_one_gpu():
+    """The fall-back of bench.py's distributed leg at world > 1: the C++ engine "fails" on every rank (simulated), the
+    ranks agree on it and the stage-by-stage Python driver runs the timed solve -- lsqr_amd.dist.ShardedLSQR with its
+    scalar all-reduce, slice scatter and gather as torch.distributed collectives on the nccl backend (three ranks that
+    share device 0).  Same 20 iterations as one handle on the whole matrix."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {**os.environ, "LSQR_BENCH_STRONG_REF": "1", "LSQR_RANKS_SHARE_GPU": "1", "LSQR_DIST_TEST_ENGINE_FAILURE": "1"}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--steps", "20", "--warmup", "2",
+                        "--workload", "random:200000:100000:20", "--traffic", "off", "--cpu-iters", "0"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 3 and line["config"]["engine"] == "python" and "LSQR_DIST_TEST_ENGINE_FAILURE" in line["config"]["engine_note"]
+    assert line["result"]["itn"] == 20
+    d = line["strong_scaling_ref"]["sharded_vs_1gpu"]
+    assert d["rnorm_rel"] <= 1e-10 and d["anorm_rel"] <= 1e-10
