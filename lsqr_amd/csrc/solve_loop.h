@@ -639,10 +639,10 @@ static int launch_batch(H *h, int i0, int G, hipEvent_t *ev, bool solve_start = 
         if (E(G - 1, 4))
             hipExtLaunchKernelGGL(kern, grid, dim3(VEC_BLOCK), 0, s, E(G - 1, 4), E(G - 1, 5), 0,
                                   (const double *)h->P2[prev], h->AT.out_grid, (const NormSlot *)&slotB[prev], u, r12,
-                                  h->nsc, (const int *)&st->stop);
+                                  h->nsc, (const int *)&st->stop, snap ? 1 : 0);
         else
             hipLaunchKernelGGL(kern, grid, dim3(VEC_BLOCK), 0, s, (const double *)h->P2[prev], h->AT.out_grid,
-                               (const NormSlot *)&slotB[prev], u, r12, h->nsc, (const int *)&st->stop);
+                               (const NormSlot *)&slotB[prev], u, r12, h->nsc, (const int *)&st->stop, snap ? 1 : 0);
     } else {
         hipLaunchKernelGGL(k_s12, dim3(1), dim3(SC_BLOCK), 0, s, (const double *)h->P1[il & 1], h->A.out_grid,
                            (const double *)h->P2[il & 1], h->AT.out_grid, st);
@@ -651,9 +651,11 @@ static int launch_batch(H *h, int i0, int G, hipEvent_t *ev, bool solve_start = 
     if (snap) {
         hipLaunchKernelGGL(k_s3_snap<true>, dim3(1), dim3(SC_BLOCK), 0, s, (const double *)h->P3, h->vgrid_n,
                            (const double *)nullptr, st, (const void *)h->X, h->f32 ? 1 : 0, h->d_log, h->h_state + 1);
-        const int64_t bytes = (int64_t)(h->f32 ? sizeof(float) : sizeof(double)) * h->n;
-        hipLaunchKernelGGL(k_out_copy, dim3(vec_grid(bytes / 8)), dim3(VEC_BLOCK), 0, s, (const LsqrState *)st,
-                           (const void *)h->X, bytes);
+        if (!fuse) {   // (the fused tail has left x at xout itself: spmv.h k_update_lazy copy_out)
+            const int64_t bytes = (int64_t)(h->f32 ? sizeof(float) : sizeof(double)) * h->n;
+            hipLaunchKernelGGL(k_out_copy, dim3(vec_grid(bytes / 8)), dim3(VEC_BLOCK), 0, s, (const LsqrState *)st,
+                               (const void *)h->X, bytes);
+        }
     } else
         hipLaunchKernelGGL(k_s3<true>, dim3(1), dim3(SC_BLOCK), 0, s, (const double *)h->P3, h->vgrid_n,
                            (const double *)nullptr, st, (const void *)h->X, h->f32 ? 1 : 0, h->d_log);

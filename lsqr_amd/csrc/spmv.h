@@ -601,10 +601,15 @@ __global__ __launch_bounds__(SPMV_BLOCK) void k_panel_combine(
 // mode-2 partials, beta from the slot the mode-2 launch published, rhobar / phibar by parity), and steps 1+2 of
 // that iteration as the rider (block 0) -- one launch where k_s12 and then k_update ran.  Same functions on the
 // same inputs: the same bits.
+// `copy_out`: the batch ends with the snapshot the host polls, and x may be wanted at an address of the caller's
+// (LsqrState.xout, device-resident solves).  The new x is then stored there as well as in X; and if the stop flag is
+// already up -- the solve ended earlier in this batch, or in the batch before this look-ahead one -- X is final and is
+// copied there.  Either way x is at xout when the batch ends, whether or not step 3 of this iteration then stops the
+// solve: vec.h k_out_copy (a launch of its own, 4.8 us of a 20-iteration solve at config 2) is not needed behind it.
 template <typename VT>
 __global__ __launch_bounds__(VEC_BLOCK) void k_update_lazy(const double *__restrict__ pin, int npin,
                                                            const NormSlot *__restrict__ slot_in, UpdArgs upd, Rider rider,
-                                                           NScale nsc, const int *__restrict__ stop)
+                                                           NScale nsc, const int *__restrict__ stop, int copy_out)
 {
     __shared__ double red[VEC_BLOCK / WAVE + 1];
     const int wg = (int)blockIdx.x - 1;
@@ -612,7 +617,15 @@ __global__ __launch_bounds__(VEC_BLOCK) void k_update_lazy(const double *__restr
         run_rider(rider, red);
         return;
     }
-    if (*stop != 0) return;
+    VT *xout = copy_out ? static_cast<VT *>(upd.st->xout) : nullptr;
+    if (*stop != 0) {
+        if (xout != nullptr) {
+            const VT *X = static_cast<const VT *>(upd.x);
+            const int64_t stride = (int64_t)upd.ugrid * VEC_BLOCK;
+            for (int64_t i = (int64_t)wg * VEC_BLOCK + threadIdx.x; i < upd.n; i += stride) xout[i] = X[i];
+        }
+        return;
+    }
     const double nrm = sqrt(block_sum_all<VEC_BLOCK>(pin, npin, red)) * nsc.inv;
     const double beta = slot_in->nrm;
     double alpha = nrm, sv = nrm > 0.0 ? 1.0 / nrm : 1.0;
@@ -623,7 +636,7 @@ __global__ __launch_bounds__(VEC_BLOCK) void k_update_lazy(const double *__restr
     const LsqrState *ust = upd.st;
     const Rot rt = rot_step(ust->rhobar2[upd.par], ust->phibar2[upd.par], ust->damp, ust->damped, alpha, beta);
     const double tot = update_block<VT>((VT *)upd.x, (VT *)upd.w, (const VT *)upd.V, (VT *)upd.se, upd.n, rt.t1, rt.t2,
-                                        rt.t3, sv, ust->wantse != 0, wg, upd.ugrid, red);
+                                        rt.t3, sv, ust->wantse != 0, wg, upd.ugrid, red, xout);
     if (threadIdx.x == 0) upd.pout[wg] = tot;
 }
 

@@ -44,7 +44,7 @@ template <typename VT, bool NT = false>
 __device__ __forceinline__ double update_block(VT *__restrict__ x, VT *__restrict__ w,
                                                const VT *__restrict__ V, VT *__restrict__ se, int64_t n,
                                                double t1, double t2, double t3, double sv, bool wantse, int ub,
-                                               int ugrid, double *red)
+                                               int ugrid, double *red, VT *__restrict__ xc = nullptr)
 {
     typedef typename Vec2<VT>::type V2T;
     double dk = 0.0;
@@ -67,6 +67,10 @@ __device__ __forceinline__ double update_block(VT *__restrict__ x, VT *__restric
         const double d0 = (t3 * tx) * (t3 * tx), d1 = (t3 * ty) * (t3 * ty);
         x2[i] = xv;
         w2[i] = wn;
+        if (xc != nullptr) {   // (the tail of a batch: x also to where the solve was told to leave it -- element stores,
+            xc[2 * i] = xv.x;  //  the caller's array need not be aligned for pairs)
+            xc[2 * i + 1] = xv.y;
+        }
         if (wantse) {
             V2T s = se2[i];
             s.x = (VT)(d0 + (double)s.x);
@@ -80,6 +84,7 @@ __device__ __forceinline__ double update_block(VT *__restrict__ x, VT *__restric
         const int64_t i = n - 1;
         const double t = (double)w[i];
         x[i] = (VT)(t1 * t + (double)x[i]);
+        if (xc != nullptr) xc[i] = x[i];
         w[i] = (VT)(t2 * t + (double)V[i] * sv);
         const double d = (t3 * t) * (t3 * t);
         if (wantse) se[i] = (VT)(d + (double)se[i]);
