@@ -2053,9 +2053,38 @@ extern "C" int lsqrhip_bench_kernel(lsqrhip_handle_t h, int which, int reps, dou
     HIPCHK(s_tmp.alloc(sizeof(LsqrState)));
     LsqrState *d_tmp = s_tmp.as<LsqrState>();
     HIPCHK(hipMemcpyAsync(d_tmp, &tmp, sizeof(tmp), hipMemcpyHostToDevice, s));
+    // A column-swept product inside the solver's loop runs no max|x| pass: the product that wrote x left the piece
+    // maxima, and this one leaves those of y (solve_loop.h xmax_folded).  Timed here in that form: the operand is a
+    // constant vector, its piece maxima are written down directly (the word csb_hi_up would keep), the epilogue's
+    // share stays in.
+    const bool loop_form = which != 3 && xmax_folded(h);
+    if (loop_form) {
+        double bound = 0.0;
+        if (!h->f32) {
+            const double v = 1.0e-3;
+            unsigned long long bits;
+            std::memcpy(&bits, &v, sizeof bits);
+            bits = ((bits >> 32) + 1ull) << 32;
+            std::memcpy(&bound, &bits, sizeof bound);
+        }
+        hipLaunchKernelGGL(k_fill, dim3(vec_grid(CSB_XMAX_PIECES)), dim3(VEC_BLOCK), 0, s, h->xmax_part,
+                           (int64_t)CSB_XMAX_PIECES, bound);
+    }
     auto one = [&]() {
-        if (which == 1) launch_spmv(h, h->A, h->V, h->U, &d_tmp->c1, &d_tmp->stop, nullptr, nullptr, true);
-        else if (which == 2) launch_spmv(h, h->AT, h->U, h->V, &d_tmp->c2, &d_tmp->stop, nullptr, nullptr, true);
+        if (which == 1 || which == 2) {
+            SpmvArgs a;
+            a.c = which == 1 ? &h->A : &h->AT;
+            a.x = which == 1 ? h->V : h->U;
+            a.y = which == 1 ? h->U : h->V;
+            a.coef = which == 1 ? &d_tmp->c1 : &d_tmp->c2;
+            a.stop = &d_tmp->stop; a.pout = h->partials; a.stream = s; a.unit_x = true;
+            if (loop_form) {
+                a.xmax_in = h->xmax_part;
+                a.nxmax_in = csb_npieces(a.c->cols);
+                a.ymax_out = which == 1 ? h->MXU : h->MXV;   // (never cleared here: a solve zeroes the sets when it starts)
+            }
+            launch_spmv_args(h, a);
+        }
         else if (h->f32)
             hipLaunchKernelGGL(k_update<float>, dim3(h->vgrid_n), dim3(VEC_BLOCK), 0, s, (float *)h->X, (float *)h->W,
                                (const float *)h->V, (float *)h->SE, (int64_t)h->n, (const LsqrState *)d_tmp, h->partials);
@@ -2163,7 +2192,9 @@ extern "C" int lsqrhip_get_option(lsqrhip_handle_t h, const char *name, int64_t 
         const Csr &c = (k == "launches_mode1" || k == "dispatches_mode1") ? h->A : h->AT;
         const bool all = k[0] == 'd';
         static const int rounds = env_int("LSQRHIP_CSB_ROUNDS", 1);
-        if (c.csb) *value = (all ? 1 : 0) + csb_sweep_launches(c, rounds != 0) + (c.S > 1 ? 1 : 0);
+        // (the pass is not part of a product inside the loop when both matrices are column-swept: xmax_folded, and
+        //  lsqrhip_bench_kernel times that form)
+        if (c.csb) *value = (all && !xmax_folded(h) ? 1 : 0) + csb_sweep_launches(c, rounds != 0) + (c.S > 1 ? 1 : 0);
         else *value = c.P > 1 ? 2 : 1;
     } else if (k == "csb_blocks_mode1" || k == "csb_blocks_mode2") {  // row blocks of a column-swept layout (0: another layout)
         const Csr &c = k == "csb_blocks_mode1" ? h->A : h->AT;
