@@ -182,10 +182,13 @@ class HipShardBackend:
         self.stream = torch.cuda.Stream()
         capi.check(capi.lib().lsqrhip_set_stream(self.h, C.c_void_p(self.stream.cuda_stream)))
         full = max(self.chunk * self.world, 1)
+        # a REAL32 handle (src/lsqr_kinds.F90:16-17): b, the exchange buffers, x and se are float arrays -- half the
+        # bytes in every collective; the scalars stay binary64
+        wp = torch.float32 if getattr(solver, "real32", False) else torch.float64
         with torch.cuda.stream(self.stream):
-            z = lambda k: torch.zeros(k, dtype=torch.float64, device="cuda")     # noqa: E731
+            z = lambda k: torch.zeros(k, dtype=wp, device="cuda")     # noqa: E731
             self.T, self.R, self.V, self.x, self.se = z(full), z(full), z(full), z(full), z(full)
-            self.sums = z(4)
+            self.sums = torch.zeros(4, dtype=torch.float64, device="cuda")
         self.wantse = False
 
     def run(self, fn):

@@ -2,7 +2,7 @@
 
     python tests/dist_worker.py RANK WORLD PORT CASE BACKEND OUT.npz
 
-BACKEND = numpy (CPU, gloo, oracle-backed stage stand-in) | hip (C-ABI stages on cuda:0, gloo)
+BACKEND = numpy (CPU, gloo, oracle-backed stage stand-in) | hip / hip32 (C-ABI stages on cuda:0, gloo; binary64 / REAL32)
         | engine / engine32 / engine_ov / engine32_ov (the C++ engine over RCCL, binary64 / REAL32, exchanges plain /
           overlapped: the ranks SHARE cuda:0, each with a NCCL_HOSTID of its own -- lsqr_amd.dist_bench.share_one_gpu)."""
 import os
@@ -41,14 +41,15 @@ def main():
         from lsqr_amd import capi
         from lsqr_amd.dist import HipShardBackend
         from lsqr_amd.solver import lsqr_solver_ez
-        s = lsqr_solver_ez().initialize(nrows, p.n, a, irow, icol)
+        real32 = backend == "hip32"      # REAL32 handle: float blocks, float exchange buffers (half the bytes over gloo too)
+        s = lsqr_solver_ez().initialize(nrows, p.n, a, irow, icol, real32=real32)
         be = HipShardBackend(s, p.m, world, rank)
-        d_b = capi.DeviceBuffer.from_array(b if nrows else np.zeros(1))
+        d_b = capi.DeviceBuffer.from_array((b if nrows else np.zeros(1)).astype(np.float32 if real32 else np.float64))
         b_arg = d_b.ptr.value
     r = ShardedLSQR(be, comm, poll_every=3).solve(b_arg, damp=o["damp"], atol=o["atol"], btol=o["btol"],
                                                  conlim=o["conlim"], itnlim=o["itnlim"], wantse=o["wantse"])
-    x = r.x.cpu().numpy() if hasattr(r.x, "cpu") else np.asarray(r.x)
-    se = None if r.se is None else (r.se.cpu().numpy() if hasattr(r.se, "cpu") else np.asarray(r.se))
+    x = (r.x.cpu().numpy() if hasattr(r.x, "cpu") else np.asarray(r.x)).astype(np.float64)
+    se = None if r.se is None else (r.se.cpu().numpy() if hasattr(r.se, "cpu") else np.asarray(r.se)).astype(np.float64)
     np.savez(out, x=x, se=se if se is not None else np.zeros(0), istop=r.istop, itn=r.itn, anorm=r.anorm,
              acond=r.acond, rnorm=r.rnorm, arnorm=r.arnorm, xnorm=r.xnorm, row0=row0, nrows=nrows)
     dist.barrier()

@@ -137,7 +137,8 @@ def test_cpp_engine_over_rccl_ranks_sharing_one_gpu(case, world, backend, tmp_pa
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case,world,backend", [("random_over_se", 2, "engine32"), ("poisson_20x20_it50", 3, "engine32_ov")])
+@pytest.mark.parametrize("case,world,backend", [("random_over_se", 2, "engine32"), ("poisson_20x20_it50", 3, "engine32_ov"),
+                                                ("random_over_se", 3, "hip32")])   # hip32: the Python stage driver, gloo
 def test_cpp_engine_real32_over_rccl_ranks_sharing_one_gpu(case, world, backend, tmp_path):
     """REAL32 handles (src/lsqr_kinds.F90:16-17): float blocks, float exchange buffers -- half the bytes through
     ncclSend / ncclRecv / all-gather (ncclFloat) -- held to ONE REAL32 handle solving the whole system."""
@@ -148,7 +149,7 @@ def test_cpp_engine_real32_over_rccl_ranks_sharing_one_gpu(case, world, backend,
                                     itnlim=o["itnlim"], real32=True)
     ref = s.solve(p.b, o["damp"], wantse=o["wantse"])
     for r in res:
-        assert int(r["again_same"]) == 1
+        assert backend == "hip32" or int(r["again_same"]) == 1
         assert int(r["istop"]) == ref.istop and abs(int(r["itn"]) - ref.itn) <= max(2, ref.itn // 10)
         assert np.linalg.norm(r["x"] - ref.x) <= 2e-3 * np.linalg.norm(ref.x)
         assert abs(float(r["rnorm"]) - ref.rnorm) <= 2e-3 * ref.rnorm
