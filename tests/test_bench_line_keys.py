@@ -27,7 +27,7 @@ def load(name):
         return json.loads(f.read().strip().splitlines()[-1])
 
 
-def check_line(d, n_gpus_min=1):
+def check_line(d, n_gpus_min=1, cpu=True):
     for k in CONTRACT:
         assert k in d, k
     assert d["metric"] == "lsqr_iterations_per_sec" and d["unit"] == "it/s" and d["higher_is_better"] is True
@@ -39,6 +39,9 @@ def check_line(d, n_gpus_min=1):
     r = d["roofline"]
     assert r["bound"] in ("hbm", "cache") and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    if not cpu:      # (a run made with --cpu-iters 0: the key is there, the leg was not run)
+        assert "cpu_baseline" in d
+        return
     for k in dist_bench.CPU_BASELINE_KEYS:
         assert k in d["cpu_baseline"], k
     assert d["cpu_baseline"]["kind"] in ("reference", "port") and d["cpu_baseline"]["cores"] >= 1
@@ -101,3 +104,23 @@ def test_committed_distributed_line():
         for k in ("value_1gpu_same_workload", "speedup_vs_1gpu_same_workload", "overlap"):
             assert k in d, k
         assert d["overlap"] in (0, 1)
+
+
+def test_committed_line_of_configs3_on_eight_rccl_ranks():
+    """BASELINE configs[3] as stated (8 ranks, RCCL), run with the ranks sharing one GPU (round 4 on): the N > 1 line in
+    full, produced by the C++ engine without a fall-back, carrying the one-handle result of the same iterations and the
+    distance to it."""
+    if round_of_lines() < 4:
+        return
+    for ov in (0, 1):
+        path = os.path.join(last_round_dir(), f"rccl_shared_gpu_configs3_w8_overlap{ov}.json")
+        with open(path) as f:
+            d = json.loads(f.read().strip().splitlines()[-1])
+        check_line(d, cpu=False)
+        assert d["n_gpus"] == 8 and d["scaling"] == "strong" and d["overlap"] == ov
+        c = d["config"]
+        assert c["world_size"] == 8 and c["rows_per_rank"] == [1250000] * 8 and "random:10000000:10000000:100" in c["workload"]
+        assert c["engine"] == "c++" and c["engine_note"] is None and c["ranks_share_one_gpu"] is True
+        ref = d["strong_scaling_ref"]
+        assert ref["result"]["itn"] == d["result"]["itn"] == d["steps"]
+        assert ref["sharded_vs_1gpu"]["rnorm_rel"] <= 1e-10 and ref["sharded_vs_1gpu"]["anorm_rel"] <= 1e-10
