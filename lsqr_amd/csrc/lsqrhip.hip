@@ -1046,15 +1046,18 @@ static int build_csb(hipStream_t s, const int *rowk, const int *colk, const doub
         // few rows: as many splits as keep one round of blocks tall
         S = (int)std::min<int64_t>(8, std::max<int64_t>(1, (int64_t)rfill * CSB_GRID / std::max(rows, 1)));
         if ((int64_t)rows * S < (int64_t)CSB_GRID * 512) S = 1;   // small systems: not worth a second launch
-        // many rows (more than half a round of full blocks) over an x far beyond L2: 2 splits -- every XCD then sweeps
-        // half of x per launch (split = unit mod 2), its workgroups drift half as far apart and far fewer of their
-        // gathers miss L2.  Config 4 (profiles/r03/csb_column_splits.txt): 3.90 / 3.95 ms without -> 3.44 / 3.46 with 2,
+        // many rows (more than half a round of full blocks) over an x far beyond L2: 2 or 4 splits -- every XCD then
+        // sweeps a half / a quarter of x per launch (split = unit mod S), its workgroups drift that much less far apart
+        // and far fewer of their gathers miss L2.  Config 4 (profiles/r03/csb_column_splits.txt): 3.90 / 3.95 ms without -> 3.44 / 3.46 with 2,
         // 3.53 / 3.53 with 4, 3.79 / 3.73 with 8; PMC fetch 25 GB -> 16.4 GB for 12.3 GB of layout.  Round 4
         // (profiles/r04/csb_splits_by_shape.txt, one process per shape): config 4 3.32 / 3.30 ms with 2 and 3.33 / 3.33
         // with 4; the row block of one rank of TWO (5M x 10M, just under a full round: no splits until then) 1.87 /
         // 1.86 -> 1.69 / 1.73 ms with 2 where its transpose had 4.  Not for matrices whose x fits L2 (config 5: 0.39 ->
         // 0.48 / 0.50 ms with 2 / 4 splits; the transposed blocks of 4 and 8 ranks).
-        if (S == 1 && 2 * (int64_t)rows > (int64_t)CSB_GRID * rmax && (int64_t)cols * 8 > (32ll << 20)) S = 2;
+        // Two and four are equal in TIME on config 4, but four move less: PMC fetch 17.6 GB per product against 19.7 GB
+        // with two (12.36 GB of layout) -- so four where the matrix needs two rounds or more anyway and x is twice L2.
+        if (S == 1 && 2 * (int64_t)rows > (int64_t)CSB_GRID * rmax && (int64_t)cols * 8 > (32ll << 20))
+            S = ((int64_t)rows > (int64_t)CSB_GRID * rmax && (int64_t)cols * 8 >= (64ll << 20)) ? 4 : 2;
     }
     std::vector<int> border, phase_pos;   // segments: launch order of the blocks, where its phases begin
     const bool segments = plan.segments && plan.P > 1 && plan.G > 1 && nnz > 0 && r_forced <= 0 && S == 1;
