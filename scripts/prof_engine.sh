@@ -7,7 +7,7 @@ OUT=$R/gpurun_out/$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 export LSQR_BENCH_FORCE_DIST=1 LSQR_BENCH_STRONG_REF=0 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 MASTER_ADDR=127.0.0.1 MASTER_PORT=29577
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o t -- python3 "$R/bench.py" --gpus 1 --workload random:1250000:10000000:100 --steps 100 --warmup 10 --traffic off --cpu-iters 0 > "$OUT/bench.json" 2> "$OUT/err.txt"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o t -- python3 "$R/bench.py" --gpus 1 --workload ${SPEC:-random:1250000:10000000:100} --steps 100 --warmup 10 --traffic off --cpu-iters 0 --no-roofline > "$OUT/bench.json" 2> "$OUT/err.txt"
 F=$(find "$OUT/trace" -name "*kernel_stats.csv" | head -1)
 tail -1 "$OUT/bench.json" | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('# value %.1f it/s ms_per_step %.4f engine %s' % (d['value'], d['ms_per_step'], d['config']['engine']))"
 python3 - "$F" <<'PY'

@@ -407,7 +407,7 @@ def test_overlap_plan_of_the_sharded_engine_changes_no_bit_of_a_product(world, p
 @pytest.mark.parametrize("real32", [False, True])
 def test_piece_maxima_of_the_writing_product_are_those_of_the_pass(csb_env, real32):
     """Inside the loop no k_csb_xmax pass runs: the epilogue of the product that WRITES u (v) raises the piece maxima the
-    pass would have left -- same pieces, same words (csb.h csb_piece_max) -- and the other product takes its grids from
+    pass would have left -- same pieces, same words (csb.h csb_group_max) -- and the other product takes its grids from
     them.  LSQRHIP_CSB_XFOLD=0 brings the passes back; on vectors whose grids depend on the pieces (power-law rows: spikes
     in u) a solve must not move by a bit, whatever the blocking (row blocks that start anywhere inside a group of 64
     rows, column splits whose second kernel writes y)."""
