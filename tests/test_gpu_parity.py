@@ -492,4 +492,14 @@ def test_device_resident_solve_copies_x_out_in_graph(name):
                     r = s.solve_device(d_b.ptr.value, d_x.ptr.value, o["damp"], d_se.ptr.value)
                     assert np.array_equal(d_x.to_array(np.float64, p.n), ref.x)
                     assert np.array_equal(d_se.to_array(np.float64, p.n), ref.se)
+    # an output address that is aligned for a double but not for a pair of them (the fused batch tail stores x there
+    # itself, element by element: spmv.h k_update_lazy copy_out)
+    d_x2 = capi.DeviceBuffer(8 * (p.n + 1))
+    d_x2.copy_from(np.full(p.n + 1, np.nan))
+    s.set_option("graph", 1)
+    s.set_option("graph_iters", 6)
+    s.set_option("poll_ahead", 1)
+    r = s.solve_device(d_b.ptr.value, d_x2.ptr.value + 8, o["damp"])
+    got = d_x2.to_array(np.float64, p.n + 1)
+    assert (r.istop, r.itn) == (ref.istop, ref.itn) and np.isnan(got[0]) and np.array_equal(got[1:], ref.x)
     assert np.array_equal(d_b.to_array(np.float64, p.m), p.b)
