@@ -2,7 +2,8 @@
 """Random small systems through every layout (forced by the knobs) against the oracle's aprod and a
 short solve.  Edge cases on purpose: empty rows / columns, one very long row, m < n, m > n, nnz = 0,
 duplicates, dictionary and non-dictionary values.  The generator and the acceptance rule of
-tests/test_gpu_fuzz.py; `python tests/fuzz_layouts.py [ncases] [seed] [--bands]` runs more cases
+tests/test_gpu_fuzz.py; `python tests/fuzz_layouts.py [ncases] [seed] [--bands] [--engine]` runs more cases (--engine: the
+same cases through the sharded engine, several ranks on the one device)
 (--bands prints every case's measured bands: profiles/r04/fuzz_bands.txt)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -51,6 +52,45 @@ LAYOUTS = [
 ]
 
 
+# ... and the same cases through the sharded C++ engine (csrc/shard_engine.h), several ranks on the one device
+# (LSQRHIP_SHARD_LOOPBACK=1: the exchanges as device copies), row blocks cut wherever the nonzeros put them: more ranks
+# than rows, empty blocks, ragged column slices, the overlapped schedule.  (world, environment)
+ENGINE_KNOBS = ["LSQRHIP_SHARD_LOOPBACK", "LSQRHIP_SHARD_OVERLAP", "LSQRHIP_SHARD_PARTS"]
+ENGINES = [
+    (2, {}),
+    (3, {"LSQRHIP_CSB": "1", "LSQRHIP_CSB_R": "129"}),
+    (5, {"LSQRHIP_SHARD_OVERLAP": "1", "LSQRHIP_CSB": "1"}),
+    (8, {"LSQRHIP_SHARD_OVERLAP": "1", "LSQRHIP_SHARD_PARTS": "3"}),
+]
+
+
+class _ShardedHandle:
+    """lsqrhip_create_sharded + the ordinary entry points on it, with the solver's call shapes"""
+
+    def __init__(self, m, n, a, irow, icol, world):
+        import ctypes as C
+        from lsqr_amd.capi import check, lib
+        self.C, self.check, self.lib, self.m, self.n = C, check, lib, m, n
+        self.h = C.c_void_p()
+        check(lib().lsqrhip_create_sharded(m, n, a.size, irow.ctypes.data, icol.ctypes.data, a.ctypes.data, world,
+                                           C.byref(self.h)))
+
+    def aprod(self, mode, x, y):
+        self.check(self.lib().lsqrhip_aprod(self.h, mode, x.ctypes.data, y.ctypes.data))
+
+    def solve(self, b, damp, itnlim):
+        C = self.C
+        x = np.zeros(max(self.n, 1))
+        istop, itn = C.c_int(), C.c_int()
+        sc = [C.c_double() for _ in range(5)]
+        self.check(self.lib().lsqrhip_solve(self.h, b.ctypes.data, damp, 0.0, 0.0, 0.0, itnlim, 0, 0, x.ctypes.data,
+                                            None, C.addressof(istop), C.addressof(itn), *[C.addressof(s) for s in sc]))
+        return x[:self.n], istop.value, itn.value
+
+    def close(self):
+        self.check(self.lib().lsqrhip_destroy(self.h))
+
+
 def make_case(rs):
     kind = rs.randint(0, 6)
     m = int(rs.choice([1, 2, 63, 64, 65, 300, 1000, 5000, 20000]))
@@ -90,8 +130,9 @@ def make_case(rs):
     return m, n, (irow + 1).astype(np.int32), (icol + 1).astype(np.int32), a.astype(np.float64), b
 
 
-def run(ncases, seed, verbose=True, bands=False, only=None):
-    """Returns (failures, results that needed a tolerance above TIGHT, results in all)."""
+def run(ncases, seed, verbose=True, bands=False, only=None, engine=False):
+    """Returns (failures, results that needed a tolerance above TIGHT, results in all).  engine: the sharded engine's
+    variants (ENGINES) in place of the layouts."""
     rs = np.random.RandomState(seed)
     po = oracle.port()
     bad = widened = total = 0
@@ -132,19 +173,36 @@ def run(ncases, seed, verbose=True, bands=False, only=None):
                   f"{band_perm:.2e}, under one ulp of one norm {band_ulp:.2e}, with accurate sums {band_acc:.2e} "
                   f"-> tolerance {tol_long:.2e}", flush=True)
         worst = worst_ref = 0.0
-        for lay in LAYOUTS:
-            for k in KNOBS:
+        for lay in (ENGINES if engine else LAYOUTS):
+            for k in KNOBS + ENGINE_KNOBS:
                 os.environ.pop(k, None)
-            os.environ.update(lay)
+            sh = None
             try:
-                s = lsqr_solver_ez().initialize(m, n, a, irow, icol, itnlim=6)
-                x, y = xp.copy(), yp.copy()
-                s.aprod(1, m, n, x, y)
-                e1 = np.max(np.abs(y - y_ref)) / max(np.max(np.abs(y_ref)), 1.0)
-                x, y = xp.copy(), yp.copy()
-                s.aprod(2, m, n, x, y)
-                e2 = np.max(np.abs(x - x_ref)) / max(np.max(np.abs(x_ref)), 1.0)
-                r = s.solve(b, 1e-2)
+                if engine:
+                    world, env = lay
+                    os.environ.update(env)
+                    os.environ["LSQRHIP_SHARD_LOOPBACK"] = "1"
+                    sh = _ShardedHandle(m, n, a, irow, icol, world)
+                    x, y = xp.copy(), yp.copy()
+                    sh.aprod(1, x, y)
+                    e1 = np.max(np.abs(y - y_ref)) / max(np.max(np.abs(y_ref)), 1.0)
+                    x, y = xp.copy(), yp.copy()
+                    sh.aprod(2, x, y)
+                    e2 = np.max(np.abs(x - x_ref)) / max(np.max(np.abs(x_ref)), 1.0)
+                    from types import SimpleNamespace
+                    xs, istop_s, itn_s = sh.solve(b, 1e-2, 6)
+                    r = SimpleNamespace(x=xs, istop=istop_s, itn=itn_s)
+                    s = SimpleNamespace(info=lambda: {"world": world, **env})
+                else:
+                    os.environ.update(lay)
+                    s = lsqr_solver_ez().initialize(m, n, a, irow, icol, itnlim=6)
+                    x, y = xp.copy(), yp.copy()
+                    s.aprod(1, m, n, x, y)
+                    e1 = np.max(np.abs(y - y_ref)) / max(np.max(np.abs(y_ref)), 1.0)
+                    x, y = xp.copy(), yp.copy()
+                    s.aprod(2, m, n, x, y)
+                    e2 = np.max(np.abs(x - x_ref)) / max(np.max(np.abs(x_ref)), 1.0)
+                    r = s.solve(b, 1e-2)
                 e3 = np.linalg.norm(r.x - o.x) / max(np.linalg.norm(o.x), 1e-300) if o.itn > 0 else float(np.max(np.abs(r.x)))
                 e3_ref = e3
                 if o_acc is not None:   # ... or the reference with accurate sums, whichever is nearer (header (c))
@@ -165,6 +223,9 @@ def run(ncases, seed, verbose=True, bands=False, only=None):
                 worst_ref = max(worst_ref, e3_ref)
             except Exception as ex:        # noqa: BLE001
                 ok, e1, e2, e3, info = False, -1, -1, -1, repr(ex)
+            finally:
+                if sh is not None:
+                    sh.close()
             if not ok:
                 bad += 1
                 ri, rn = (r.istop, r.itn) if e1 >= 0 else (None, None)
@@ -172,10 +233,10 @@ def run(ncases, seed, verbose=True, bands=False, only=None):
         if bands:
             print(f"case {case}: worst GPU layout {worst_ref:.2e} from the reference's x, {worst:.2e} from the nearer of the "
                   f"reference's and the accurately summed one's", flush=True)
-    for k in KNOBS:
+    for k in KNOBS + ENGINE_KNOBS:
         os.environ.pop(k, None)
     if verbose:
-        print(f"{ncases} cases x {len(LAYOUTS)} layouts: {bad} failures; {widened} of {total} results needed more than "
+        print(f"{ncases} cases x {len(ENGINES if engine else LAYOUTS)} {'engine variants' if engine else 'layouts'}: {bad} failures; {widened} of {total} results needed more than "
               f"{TIGHT:g} (at most {MAX_WIDENED_SHARE:.0%} may)")
     return bad, widened, total
 
@@ -187,5 +248,5 @@ if __name__ == "__main__":
         if a.startswith("--only="):
             only = {int(t) for t in a[7:].split(",")}
     bad, widened, total = run(int(args[0]) if args else 60, int(args[1]) if len(args) > 1 else 1,
-                              bands="--bands" in sys.argv, only=only)
+                              bands="--bands" in sys.argv, only=only, engine="--engine" in sys.argv)
     sys.exit(1 if bad or widened > MAX_WIDENED_SHARE * max(total, 1) else 0)

@@ -30,3 +30,23 @@ def test_random_systems_through_every_layout(seed):
     assert bad == 0
     assert total >= 40 * len(fuzz_layouts.LAYOUTS) - 5
     assert widened <= fuzz_layouts.MAX_WIDENED_SHARE * total
+
+
+@pytest.mark.parametrize("seed", [4, 5])
+def test_random_systems_through_the_sharded_engine(seed):
+    """The same generator through the C++ engine with 2, 3, 5 and 8 ranks on the one device (loopback exchanges; the
+    overlapped schedule for two of them; column-swept blocks forced for two): both aprod modes of the sharded handle
+    and the short solve, against the oracle, same acceptance rule."""
+    keys = fuzz_layouts.KNOBS + fuzz_layouts.ENGINE_KNOBS
+    old = {k: os.environ.get(k) for k in keys}
+    try:
+        bad, widened, total = fuzz_layouts.run(30, seed, verbose=False, engine=True)
+    finally:
+        for k, v in old.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v
+    print(f"seed {seed}: {widened} of {total} engine results needed more than {fuzz_layouts.TIGHT:g}")
+    assert bad == 0
+    assert total >= 30 * len(fuzz_layouts.ENGINES) - 5
+    assert widened <= fuzz_layouts.MAX_WIDENED_SHARE * total
