@@ -412,11 +412,12 @@ __device__ __forceinline__ CsbCoef csb_coef(const SpmvCoef *__restrict__ coef, c
     return c;
 }
 
-// The two grids of this launch (header) from the piece maxima the k_csb_xmax pass left (<= 4096, one per wave of it):
+// The two grids of this launch (header) from the piece maxima of x (<= 4096: csb_pieces; left by the k_csb_xmax pass, by
+// the epilogue of the product that wrote x, or -- the sharded engine's v -- gathered with the norms):
 //   ec: 2^ec > max_j |x_j sx|                                      -- the coarse grid, and what "in range" means;
 //   ef: tau = 2^ef, min(2^ec, 8..32 x the MEDIAN piece maximum)     -- the fine grid: columns with |x_j sx| < tau.
 // The median piece: spikes in up to half the pieces leave it alone, and for a vector without outliers -- Gaussian
-// entries: the largest of 10^7 is 1.4 x the median maximum of pieces of 2441; power-law rows up to 10^4 long
+// entries: the largest of 10^7 is 1.4 x the median maximum of pieces of ~2400; power-law rows up to 10^4 long
 // (config 5's u): 1.2 x -- tau is simply the bound on max|x sx| and no column is big.
 // Every thread gets the same values, and every kernel of a product (sweeps, combine) derives them from the same
 // partials: bit for bit the same grids.  `red`: CSB_WAVES doubles, `hist`: CSB_XHIST ints.
