@@ -2,8 +2,8 @@
 """Random small systems through every layout (forced by the knobs) against the oracle's aprod and a
 short solve.  Edge cases on purpose: empty rows / columns, one very long row, m < n, m > n, nnz = 0,
 duplicates, dictionary and non-dictionary values.  The generator and the acceptance rule of
-tests/test_gpu_fuzz.py; `python tests/fuzz_layouts.py [ncases] [seed] [--bands] [--engine]` runs more cases (--engine: the
-same cases through the sharded engine, several ranks on the one device)
+tests/test_gpu_fuzz.py; `python tests/fuzz_layouts.py [ncases] [seed] [--bands] [--engine | --real32]` runs more cases (--engine: the
+same cases through the sharded engine, several ranks on the one device; --real32: every layout as a REAL32 handle)
 (--bands prints every case's measured bands: profiles/r04/fuzz_bands.txt)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -130,9 +130,12 @@ def make_case(rs):
     return m, n, (irow + 1).astype(np.int32), (icol + 1).astype(np.int32), a.astype(np.float64), b
 
 
-def run(ncases, seed, verbose=True, bands=False, only=None, engine=False):
+def run(ncases, seed, verbose=True, bands=False, only=None, engine=False, real32=False):
     """Returns (failures, results that needed a tolerance above TIGHT, results in all).  engine: the sharded engine's
-    variants (ENGINES) in place of the layouts."""
+    variants (ENGINES) in place of the layouts.  real32: every layout as a REAL32 handle (src/lsqr_kinds.F90:16-17) --
+    see run_real32."""
+    if real32:
+        return run_real32(ncases, seed, verbose)
     rs = np.random.RandomState(seed)
     po = oracle.port()
     bad = widened = total = 0
@@ -241,6 +244,64 @@ def run(ncases, seed, verbose=True, bands=False, only=None, engine=False):
     return bad, widened, total
 
 
+EPS32 = float(np.finfo(np.float32).eps)
+
+
+def run_real32(ncases, seed, verbose=True):
+    """The same cases with real32 storage (values, vectors) in every layout.  A REAL32 product is the binary64 sum of exact
+    products of real32 numbers, rounded to real32 ONCE (tests/test_gpu_real32.py): held element by element to one real32
+    rounding of the oracle's binary64 product of the same real32-valued inputs.  The short solve rounds every vector to
+    real32 once per iteration: where the binary64 reference itself is insensitive (tolerance TIGHT, see the header) and
+    both run the same number of iterations, x must lie within 2e-3 of the binary64 oracle's."""
+    rs = np.random.RandomState(seed)
+    po = oracle.port()
+    bad = total = compared = 0
+    for case in range(ncases):
+        m, n, irow, icol, a, b = make_case(rs)
+        xp, yp = rs.uniform(-1, 1, size=n), rs.uniform(-1, 1, size=m)
+        a32, b32, xp32, yp32 = (v.astype(np.float32) for v in (a, b, xp, yp))
+        a64, b64, xp64, yp64 = (v.astype(np.float64) for v in (a32, b32, xp32, yp32))
+        _, y_ref = po.aprod(1, m, n, irow, icol, a64, xp64, yp64)
+        x_ref, _ = po.aprod(2, m, n, irow, icol, a64, xp64, yp64)
+        o = po.solve(m, n, irow, icol, a64, b64, damp=1e-2, itnlim=6)
+        longest = max(int(np.bincount(irow - 1, minlength=m).max()), int(np.bincount(icol - 1, minlength=n).max())) if irow.size else 0
+        for lay in LAYOUTS:
+            for k in KNOBS:
+                os.environ.pop(k, None)
+            os.environ.update(lay)
+            try:
+                s = lsqr_solver_ez().initialize(m, n, a32, irow, icol, itnlim=6, real32=True)
+                x, y = xp32.copy(), yp32.copy()
+                s.aprod(1, m, n, x, y)
+                f1 = EPS32 * np.abs(y_ref) + 1e-12 * max(float(np.max(np.abs(y_ref))), 1.0)
+                e1 = float(np.max(np.abs(y.astype(np.float64) - y_ref) / f1)) if m else 0.0
+                x, y = xp32.copy(), yp32.copy()
+                s.aprod(2, m, n, x, y)
+                f2 = EPS32 * np.abs(x_ref) + 1e-12 * max(float(np.max(np.abs(x_ref))), 1.0)
+                e2 = float(np.max(np.abs(x.astype(np.float64) - x_ref) / f2)) if n else 0.0
+                r = s.solve(b32, 1e-2)
+                ok = e1 <= 1.0 and e2 <= 1.0 and np.all(np.isfinite(r.x))
+                e3 = -1.0
+                if longest <= 16 and o.itn > 0 and r.itn == o.itn:
+                    e3 = float(np.linalg.norm(r.x.astype(np.float64) - o.x) / max(np.linalg.norm(o.x), 1e-300))
+                    ok = ok and e3 <= 2e-3
+                    compared += 1
+                total += 1
+                info = s.info()
+            except Exception as ex:        # noqa: BLE001
+                ok, e1, e2, e3, info = False, -1, -1, -1, repr(ex)
+            if not ok:
+                bad += 1
+                print(f"FAIL (REAL32) case {case} m={m} n={n} nnz={irow.size} layout={lay} e1={e1:.2e} e2={e2:.2e} "
+                      f"e3={e3:.2e} (in real32 roundings / relative) {info}", flush=True)
+    for k in KNOBS:
+        os.environ.pop(k, None)
+    if verbose:
+        print(f"{ncases} cases x {len(LAYOUTS)} layouts in REAL32: {bad} failures; {compared} of {total} solves compared "
+              f"with the binary64 oracle's")
+    return bad, 0, total
+
+
 if __name__ == "__main__":
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     only = None
@@ -248,5 +309,6 @@ if __name__ == "__main__":
         if a.startswith("--only="):
             only = {int(t) for t in a[7:].split(",")}
     bad, widened, total = run(int(args[0]) if args else 60, int(args[1]) if len(args) > 1 else 1,
-                              bands="--bands" in sys.argv, only=only, engine="--engine" in sys.argv)
+                              bands="--bands" in sys.argv, only=only, engine="--engine" in sys.argv,
+                              real32="--real32" in sys.argv)
     sys.exit(1 if bad or widened > MAX_WIDENED_SHARE * max(total, 1) else 0)

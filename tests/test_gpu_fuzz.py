@@ -50,3 +50,20 @@ def test_random_systems_through_the_sharded_engine(seed):
     assert bad == 0
     assert total >= 30 * len(fuzz_layouts.ENGINES) - 5
     assert widened <= fuzz_layouts.MAX_WIDENED_SHARE * total
+
+
+@pytest.mark.parametrize("seed", [6, 7])
+def test_random_systems_through_every_layout_in_real32(seed):
+    """The same generator with REAL32 handles (src/lsqr_kinds.F90:16-17) in every layout: both products element by
+    element within ONE real32 rounding of the binary64 oracle's product of the same real32-valued inputs, and the short
+    solve within 2e-3 of the binary64 oracle's where that one is insensitive (fuzz_layouts.run_real32)."""
+    old = {k: os.environ.get(k) for k in fuzz_layouts.KNOBS}
+    try:
+        bad, _, total = fuzz_layouts.run(30, seed, verbose=False, real32=True)
+    finally:
+        for k, v in old.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v
+    assert bad == 0
+    assert total >= 30 * len(fuzz_layouts.LAYOUTS) - 5
