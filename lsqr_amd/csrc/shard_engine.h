@@ -130,6 +130,11 @@ struct ShardRank {
     hipStream_t cstream = nullptr;
     hipEvent_t evV = nullptr, evRS = nullptr;          // v_q final (compute stream) / all parts of R received (comm stream)
     std::vector<hipEvent_t> evAG, evT;                 // part k of v gathered (comm stream) / part k of T complete (compute stream)
+    // exchanges as copies (ShardGroup::loopback): one copy stream per peer (COPY_STREAMS of them, peer mod that), so that
+    // the pulls from different peers run on different SDMA engines / links at once; pe[i] = the last copy on ps[i]
+    std::vector<hipStream_t> ps;
+    std::vector<hipEvent_t> pe;
+    hipEvent_t eb = nullptr;                           // "the base stream up to here" for the copy streams to wait on
     double *T = nullptr, *R = nullptr, *V = nullptr, *sums = nullptr, *gath = nullptr;  // exchange buffers (owned)
     double *xfull = nullptr, *sefull = nullptr, *bloc = nullptr;                         // P*chunk, P*chunk, m_p
 };
@@ -141,8 +146,12 @@ struct ShardGroup {
     size_t esz = sizeof(double);   // bytes per vector element: 4 for REAL32 handles (T, R, V, x, se, b are float arrays then)
     std::vector<ShardRank> r;      // the ranks driven by this process
     bool owned = false;            // sub-handles belong to the group (single-process form)
-    bool loopback = false;         // exchanges by device copies inside this process instead of RCCL (all ranks are local)
+    bool loopback = false;         // exchanges by device copies inside this process instead of RCCL (all ranks are local):
+                                   // LSQRHIP_SHARD_COPY=1 (peer copies between the devices of a one-process group: no CU
+                                   // set aside for an exchange) or the one-device test harness LSQRHIP_SHARD_LOOPBACK=1
     std::vector<hipEvent_t> ev;    // loopback: one event per rank
+    bool copy_streams = true;      // ... and one copy stream per peer (LSQRHIP_SHARD_COPY_STREAMS=0 at creation: the pulls on
+                                   // the rank's own stream, one after the other)
     int poll_every = 16;
     int overlap = 0;               // LSQRHIP_SHARD_OVERLAP at creation: exchanges in `parts` parts beside the products
     int parts = 1;
@@ -176,6 +185,9 @@ static void free_group(ShardGroup *g)
         if (k.evV) (void)hipEventDestroy(k.evV);
         if (k.evRS) (void)hipEventDestroy(k.evRS);
         if (k.cstream) (void)hipStreamDestroy(k.cstream);
+        for (hipEvent_t e : k.pe) if (e) (void)hipEventDestroy(e);
+        for (hipStream_t st : k.ps) if (st) (void)hipStreamDestroy(st);
+        if (k.eb) (void)hipEventDestroy(k.eb);
         for (double *p : {k.T, k.R, k.V, k.sums, k.gath, k.xfull, k.sefull, k.bloc})
             if (p) (void)hipFree(p);
         if (g->owned && k.h) lsqrhip_destroy(k.h);
@@ -235,11 +247,66 @@ static int fence_ranks(ShardGroup &g)  // every rank's stream waits for all that
     return LSQRHIP_OK;
 }
 
-static int loop_copy(ShardRank &dst, void *d, const void *s, size_t bytes)
+// Exchanges as copies: rank `dst` PULLS from its peers.  A batch of pulls hangs off a base stream of dst (its compute
+// stream, or the exchange stream of the overlapped schedule): the copy streams wait for the base as it stands at
+// pull_begin (whatever the base had waited for -- the sources' data -- they inherit) and, per pull, for an event of the
+// source if given; pull_end makes the base wait for every copy.  One copy stream per peer (mod COPY_STREAMS): pulls from
+// different peers are independent commands -- on a node they go over different links at once, which one stream (one
+// copy at a time: one link at a time) would not allow.  LSQRHIP_SHARD_COPY_STREAMS=0: all pulls on the base itself.
+constexpr int COPY_STREAMS = 8;
+struct PullBatch {
+    ShardRank *q = nullptr;
+    hipStream_t base = nullptr;
+    bool streams = false;
+    unsigned used = 0;   // copy streams this batch touched
+};
+static int pull_begin(PullBatch &b, const ShardGroup &g, ShardRank &dst, hipStream_t base)
+{
+    b.q = &dst;
+    b.base = base;
+    b.streams = g.copy_streams;
+    b.used = 0;
+    HIPCHK(hipSetDevice(dst.h->device));
+    if (!b.streams) return LSQRHIP_OK;
+    if (dst.ps.empty()) {
+        dst.ps.assign(COPY_STREAMS, nullptr);
+        dst.pe.assign(COPY_STREAMS, nullptr);
+        for (int i = 0; i < COPY_STREAMS; ++i) {
+            HIPCHK(hipStreamCreateWithFlags(&dst.ps[(size_t)i], hipStreamNonBlocking));
+            HIPCHK(hipEventCreateWithFlags(&dst.pe[(size_t)i], hipEventDisableTiming));
+        }
+        HIPCHK(hipEventCreateWithFlags(&dst.eb, hipEventDisableTiming));
+    }
+    HIPCHK(hipEventRecord(dst.eb, base));
+    return LSQRHIP_OK;
+}
+static int pull(PullBatch &b, const ShardRank &src, void *d, const void *s, size_t bytes, hipEvent_t src_ready = nullptr)
 {
     if (!bytes) return LSQRHIP_OK;
-    HIPCHK(hipSetDevice(dst.h->device));
-    HIPCHK(hipMemcpyAsync(d, s, bytes, hipMemcpyDeviceToDevice, dst.h->stream));
+    ShardRank &q = *b.q;
+    hipStream_t st = b.base;
+    if (b.streams) {
+        const int i = src.grank % COPY_STREAMS;
+        st = q.ps[(size_t)i];
+        if (!(b.used & (1u << i))) HIPCHK(hipStreamWaitEvent(st, q.eb, 0));
+        b.used |= 1u << i;
+    }
+    if (src_ready) HIPCHK(hipStreamWaitEvent(st, src_ready, 0));
+    if (src.h->device != q.h->device)
+        HIPCHK(hipMemcpyPeerAsync(d, q.h->device, s, src.h->device, bytes, st));
+    else
+        HIPCHK(hipMemcpyAsync(d, s, bytes, hipMemcpyDeviceToDevice, st));
+    return LSQRHIP_OK;
+}
+static int pull_end(PullBatch &b)
+{
+    if (!b.streams) return LSQRHIP_OK;
+    ShardRank &q = *b.q;
+    for (int i = 0; i < COPY_STREAMS; ++i)
+        if (b.used & (1u << i)) {
+            HIPCHK(hipEventRecord(q.pe[(size_t)i], q.ps[(size_t)i]));
+            HIPCHK(hipStreamWaitEvent(b.base, q.pe[(size_t)i], 0));
+        }
     return LSQRHIP_OK;
 }
 // element i of a vector buffer (binary64 or REAL32 elements)
@@ -263,12 +330,16 @@ static int ex_scalars(ShardGroup &g, int k, bool with_v = false, bool fused = fa
     };
     if (g.P > 1 && g.loopback) {
         RET(fence_ranks(g));
-        for (ShardRank &q : g.r)
+        for (ShardRank &q : g.r) {
+            PullBatch pb;
+            RET(pull_begin(pb, g, q, q.h->stream));
             for (ShardRank &p : g.r) {
-                RET(loop_copy(q, q.gath + msg * (size_t)p.grank, p.sums, msg * sizeof(double)));
+                RET(pull(pb, p, q.gath + msg * (size_t)p.grank, p.sums, msg * sizeof(double)));
                 if (with_v && &p != &q)
-                    RET(loop_copy(q, at(q.V, (size_t)p.grank * c, g.esz), at(p.V, (size_t)p.grank * c, g.esz), c * g.esz));
+                    RET(pull(pb, p, at(q.V, (size_t)p.grank * c, g.esz), at(p.V, (size_t)p.grank * c, g.esz), c * g.esz));
             }
+            RET(pull_end(pb));
+        }
         RET(fence_ranks(g));
         if (!fused)
             for (ShardRank &q : g.r) RET(sum_ranks(q, q.gath));
@@ -300,9 +371,13 @@ static int ex_scatter(ShardGroup &g)  // slice q of every rank's T -> rank q's R
     if (g.P == 1 || c == 0) return LSQRHIP_OK;   // (the rank's own slice is read in T where it lies: shard_api.h own_in_T)
     if (g.loopback) {
         RET(fence_ranks(g));
-        for (ShardRank &q : g.r)
+        for (ShardRank &q : g.r) {
+            PullBatch pb;
+            RET(pull_begin(pb, g, q, q.h->stream));
             for (ShardRank &p : g.r)
-                if (&p != &q) RET(loop_copy(q, at(q.R, (size_t)p.grank * c, e), at(p.T, (size_t)q.grank * c, e), c * e));
+                if (&p != &q) RET(pull(pb, p, at(q.R, (size_t)p.grank * c, e), at(p.T, (size_t)q.grank * c, e), c * e));
+            RET(pull_end(pb));
+        }
         return fence_ranks(g);
     }
     // the rank's own slice never leaves the device (nor T: k_rs_combine reads it there); the others go to their
@@ -326,14 +401,18 @@ static int ex_gather(ShardGroup &g, bool x_too, bool se_too)  // in-place all-ga
     if (g.P == 1 || c == 0) return LSQRHIP_OK;
     if (g.loopback) {
         RET(fence_ranks(g));
-        for (ShardRank &q : g.r)
+        for (ShardRank &q : g.r) {
+            PullBatch pb;
+            RET(pull_begin(pb, g, q, q.h->stream));
             for (ShardRank &p : g.r) {
                 if (&p == &q) continue;
                 const size_t o = (size_t)p.grank * c;
-                if (!x_too) RET(loop_copy(q, at(q.V, o, e), at(p.V, o, e), c * e));
-                if (x_too) RET(loop_copy(q, at(q.xfull, o, e), at(p.xfull, o, e), c * e));
-                if (se_too) RET(loop_copy(q, at(q.sefull, o, e), at(p.sefull, o, e), c * e));
+                if (!x_too) RET(pull(pb, p, at(q.V, o, e), at(p.V, o, e), c * e));
+                if (x_too) RET(pull(pb, p, at(q.xfull, o, e), at(p.xfull, o, e), c * e));
+                if (se_too) RET(pull(pb, p, at(q.sefull, o, e), at(p.sefull, o, e), c * e));
             }
+            RET(pull_end(pb));
+        }
         return fence_ranks(g);
     }
     NCCLCHK(rc->GroupStart());
@@ -405,15 +484,16 @@ static int ov_scatter_part(ShardGroup &g, int k)
     const ncclDataType_t vtype = e == sizeof(float) ? ncclFloat : ncclDouble;
     if (g.loopback) {
         for (ShardRank &q : g.r) {
-            HIPCHK(hipSetDevice(q.h->device));
             size_t off, len;
             part_of(g, q.grank, k, &off, &len);
+            PullBatch pb;
+            RET(pull_begin(pb, g, q, q.cstream));
             for (ShardRank &p : g.r) {
                 if (&p == &q || len == 0) continue;
-                HIPCHK(hipStreamWaitEvent(q.cstream, p.evT[(size_t)k], 0));
-                HIPCHK(hipMemcpyAsync(at(q.R, (size_t)p.grank * c + off, e), at(p.T, (size_t)q.grank * c + off, e), len * e,
-                                      hipMemcpyDeviceToDevice, q.cstream));
+                RET(pull(pb, p, at(q.R, (size_t)p.grank * c + off, e), at(p.T, (size_t)q.grank * c + off, e), len * e,
+                         p.evT[(size_t)k]));
             }
+            RET(pull_end(pb));
         }
         return LSQRHIP_OK;
     }
@@ -445,15 +525,16 @@ static int ov_gather_part(ShardGroup &g, int k)
     const ncclDataType_t vtype = e == sizeof(float) ? ncclFloat : ncclDouble;
     if (g.loopback) {
         for (ShardRank &q : g.r) {
-            HIPCHK(hipSetDevice(q.h->device));
+            PullBatch pb;
+            RET(pull_begin(pb, g, q, q.cstream));
             for (ShardRank &p : g.r) {
                 if (&p == &q) continue;
                 size_t off, len;
                 part_of(g, p.grank, k, &off, &len);
                 if (len == 0) continue;
-                HIPCHK(hipMemcpyAsync(at(q.V, (size_t)p.grank * c + off, e), at(p.V, (size_t)p.grank * c + off, e), len * e,
-                                      hipMemcpyDeviceToDevice, q.cstream));
+                RET(pull(pb, p, at(q.V, (size_t)p.grank * c + off, e), at(p.V, (size_t)p.grank * c + off, e), len * e));
             }
+            RET(pull_end(pb));
             HIPCHK(hipEventRecord(q.evAG[(size_t)k], q.cstream));
         }
         return LSQRHIP_OK;
@@ -748,12 +829,16 @@ static int create_sharded_T(int m, int n, int64_t nnz, const int *irow, const in
     if (nnz > 0 && (!irow || !icol || !a)) return fail(LSQRHIP_ERR_SIZES, lsqrhip_error_string(LSQRHIP_ERR_SIZES));
     const int have = lsqrhip_device_count();
     // test harness: more ranks than devices, exchanges as device copies inside the process (see fence_ranks)
-    const bool loopback = env_int("LSQRHIP_SHARD_LOOPBACK", 0) != 0 && have >= 1;
+    // LSQRHIP_SHARD_COPY=1: the same copies between the DEVICES of the node (one rank per device, peer copies -- the
+    // SDMA engines -- instead of RCCL's send / receive kernels: no CU set aside for an exchange; opt-in, not timed yet)
+    const bool copy_mode = env_int("LSQRHIP_SHARD_COPY", 0) != 0 && have >= std::min(ngpu, std::max(m, 1));
+    const bool harness = env_int("LSQRHIP_SHARD_LOOPBACK", 0) != 0 && have >= 1;
+    const bool loopback = harness || copy_mode;
     if (have < ngpu && !loopback)
         return fail(LSQRHIP_ERR_NO_DEVICE, "ngpu = " + std::to_string(ngpu) + " but this node shows " + std::to_string(have) +
                                                " usable gfx950 device(s)");
     ngpu = std::min(ngpu_asked, std::max(m, 1));  // never more row blocks than rows
-    if (!loopback && g_device.load() + ngpu > have)   // blocks go to devices [selected, selected + ngpu)
+    if (!harness && g_device.load() + ngpu > have)   // blocks go to devices [selected, selected + ngpu)
         return fail(LSQRHIP_ERR_NO_DEVICE, "ngpu = " + std::to_string(ngpu) + " starting at the selected device " +
                                                std::to_string(g_device.load()) + " exceeds the " + std::to_string(have) +
                                                " device(s) of this node (lsqrhip_set_device)");
@@ -845,6 +930,7 @@ static int create_sharded_T(int m, int n, int64_t nnz, const int *irow, const in
     g->chunk = ((int64_t)n + ngpu - 1) / ngpu;
     g->owned = true;
     g->loopback = loopback;
+    g->copy_streams = env_int("LSQRHIP_SHARD_COPY_STREAMS", 1) != 0;
     g->r.resize((size_t)ngpu);
     int rc = LSQRHIP_OK;
     for (int p = 0; p < ngpu && rc == LSQRHIP_OK; ++p) {
@@ -853,7 +939,7 @@ static int create_sharded_T(int m, int n, int64_t nnz, const int *irow, const in
         q.grank = p;
         q.row0 = cut[(size_t)p];
         // the block's device, for this thread's create only (never through the process-wide selection)
-        t_device_override = loopback ? dev0 + p % have : dev0 + p;
+        t_device_override = harness ? dev0 + p % have : dev0 + p;
         t_shard_world = ngpu;   // (the overlap plan of the block's layouts, if asked for: lsqrhip.hip finish_create)
         if (blockwise) {
             for (int64_t k = 0; k < np; ++k) lr[(size_t)k] = irow[f + k] - cut[(size_t)p];

@@ -572,3 +572,62 @@ def test_python_stage_driver_over_nccl_ranks_sharing_one_gpu():
     assert line["result"]["itn"] == 20
     d = line["strong_scaling_ref"]["sharded_vs_1gpu"]
     assert d["rnorm_rel"] <= 1e-10 and d["anorm_rel"] <= 1e-10
+
+
+@pytest.mark.parametrize("ngpu,overlap", [(3, "0"), (8, "0"), (5, "1")])
+def test_exchanges_as_copies_on_a_stream_per_peer_change_no_bit(ngpu, overlap):
+    """The copy form of the exchanges (what LSQRHIP_SHARD_COPY=1 offers a one-process group on a node -- peer copies,
+    no CU set aside -- and what the loopback harness runs on one device): every rank pulls from each peer on a copy
+    stream of that peer's, tied to the rank's stream by events (shard_engine.h PullBatch), so that pulls from different
+    peers are independent commands.  With LSQRHIP_SHARD_COPY_STREAMS=0 the pulls queue on the rank's own stream, one
+    after the other: x, se, the scalars and the log must not differ by a bit.  (LSQRHIP_SHARD_COPY=1 itself needs one
+    device per rank; together with the harness switch it takes the harness's device mapping.)"""
+    import os
+    keys = ("LSQRHIP_SHARD_LOOPBACK", "LSQRHIP_SHARD_COPY", "LSQRHIP_SHARD_COPY_STREAMS", "LSQRHIP_SHARD_OVERLAP")
+    old = {k: os.environ.get(k) for k in keys}
+    p = P.random_rows(30000, 7001, 9, seed=37, damp=1e-3)
+    o = dict(damp=p.damp, atol=1e-10, btol=1e-10, conlim=0.0, itnlim=20, wantse=True)
+    out = []
+    try:
+        os.environ["LSQRHIP_SHARD_LOOPBACK"] = "1"
+        os.environ["LSQRHIP_SHARD_COPY"] = "1"
+        os.environ["LSQRHIP_SHARD_OVERLAP"] = overlap
+        for streams in ("1", "0"):
+            os.environ["LSQRHIP_SHARD_COPY_STREAMS"] = streams
+            h = sharded_handle(p, ngpu)
+            try:
+                out.append(_solve_with_log(h, p, o))
+            finally:
+                check(lib().lsqrhip_destroy(h))
+    finally:
+        for k, v in old.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v
+    a, b = out
+    assert (a[2], a[3]) == (b[2], b[3]) and a[3] > 5 and a[4] == b[4]
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[5], b[5])
+    g = oracle.port().solve(p.m, p.n, p.irow, p.icol, p.a, p.b, damp=p.damp, atol=1e-10, btol=1e-10, itnlim=20)
+    assert (a[2], a[3]) == (g.istop, g.itn) and np.linalg.norm(a[0] - g.x) <= 1e-10 * np.linalg.norm(g.x)
+
+
+def test_copy_mode_without_a_device_per_rank_fails_loudly():
+    """LSQRHIP_SHARD_COPY=1 is for ranks on devices of their own: three ranks on a one-GPU box (and no harness switch)
+    is the no-device error, as without it."""
+    import os
+    import torch
+    if torch.cuda.device_count() >= 3:
+        pytest.skip("this node has a device per rank")
+    old = {k: os.environ.get(k) for k in ("LSQRHIP_SHARD_COPY", "LSQRHIP_SHARD_LOOPBACK")}
+    os.environ["LSQRHIP_SHARD_COPY"] = "1"
+    os.environ.pop("LSQRHIP_SHARD_LOOPBACK", None)
+    try:
+        p, _ = CASES["random_over_damped"]
+        with pytest.raises(capi.LsqrHipError) as ei:
+            sharded_handle(p, 3)
+        assert ei.value.code == capi.ERR_NO_DEVICE
+    finally:
+        for k, v in old.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v
