@@ -47,12 +47,17 @@ contains
    end function ddot
 
    !> ||x||_2 without overflow / underflow     (replaces src/lsqrblas.f90:123-159)
-   !! Two passes: the largest magnitude, then the sum of squares of x/max.
+   !! One pass, LAPACK's dlassq recurrence: the running pair (big, acc) holds sum x_k^2 = big^2 * acc with big the
+   !! largest magnitude met so far; a new largest rescales acc, anything else adds (|x|/big)^2.  The reference does
+   !! exactly this (src/lsqrblas.f90:143-154), and the host lsqr / acheck / xcheck of a user type that supplies its own
+   !! aprod take every beta and alpha from here: the SAME recurrence, operation for operation, is what makes that path
+   !! bit-identical to the reference's (tests/test_reference_programs_unchanged.py compares the 18-problem log).
+   !! (Round 4 took two passes -- max, then sum (x/max)^2 -- which is as accurate and differs in the last bits.)
    real(wp) function dnrm2(n, x, incx)
       integer :: n, incx
       real(wp) :: x(*)
       integer :: k, ix
-      real(wp) :: big, acc, t
+      real(wp) :: big, acc, mag
       dnrm2 = zero
       if (n < 1 .or. incx < 1) return
       if (n == 1) then
@@ -60,18 +65,18 @@ contains
          return
       end if
       big = zero
+      acc = one
       ix = 1
       do k = 1, n
-         big = max(big, abs(x(ix)))
+         mag = abs(x(ix))
          ix = ix + incx
-      end do
-      if (big == zero) return
-      acc = zero
-      ix = 1
-      do k = 1, n
-         t = x(ix)/big
-         acc = acc + t*t
-         ix = ix + incx
+         if (mag == zero) cycle
+         if (mag > big) then
+            acc = one + acc*(big/mag)**2
+            big = mag
+         else
+            acc = acc + (mag/big)**2
+         end if
       end do
       dnrm2 = big*sqrt(acc)
    end function dnrm2

@@ -1,0 +1,582 @@
+// csb_break.hip -- round 5: three attempts to get the column sweep of csb.h past the ceiling csb_ceiling.hip measured
+// (stream and gathers share a CU's ~64 cache lines in flight: together they take the SUM of their times).
+//
+// Same layout and sweep as csb_ceiling.hip "both + lds" (chunks of 256 column-sorted nonzeros: f64 value, u32 local
+// row << 17 | column - chunk base; one 1024-thread workgroup per CU; wave w takes chunks w, w + 16, ...; next chunk's
+// stream in flight behind this chunk's gathers; non-temporal stream loads; one ds_add_u64 per nonzero), every variant
+// built into ONE process and timed alternately (boxes differ by more than most variants do):
+//
+//   base        csb_ceiling's "both + lds"
+//   (a) spf     + the stream of the chunk a wave will load DS steps from now touched through the SCALAR cache
+//               (s_load_dword on NV of its 16 value lines and NI of its 8 index lines): the scalar cache misses to L2
+//               by a path of its own, so the later vector loads should find their lines in L2 (~220 cycles instead of
+//               ~750) and give their TCP slots back three times sooner
+//   (b) ring    P of the 16 waves only MOVE the stream: global_load_lds_dwordx4 into a ring of SL chunk slots in LDS
+//               (full / free counters in LDS), the other 16 - P waves take chunks from the ring, gather and add.  The ring
+//               costs accumulators: R falls by SL * 3 KB / 8 rows
+//   (c) xwin    rows dense enough that a chunk spans few columns (config 3 literal, 1000 per row): each wave copies
+//               the span of x its chunk touches into an LDS window of its own with coalesced loads and gathers from LDS
+//
+//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off scripts/csb_break.hip -o scripts/_bin/csb_break
+//   scripts/_bin/csb_break [reps] [which: a b c]      (table: profiles/r05/csb_break.txt)
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#define CK(e)                                                                              \
+    do {                                                                                   \
+        hipError_t _e = (e);                                                               \
+        if (_e != hipSuccess) {                                                            \
+            std::fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(_e)); \
+            std::exit(1);                                                                  \
+        }                                                                                  \
+    } while (0)
+
+constexpr int WAVE = 64, BLOCK = 1024, WAVES = BLOCK / WAVE, U = 4, CHUNK = U * WAVE;
+constexpr int RMAX = 20352, NACC = RMAX + 64, LBITS = 17;
+constexpr unsigned LMASK = (1u << LBITS) - 1u;
+
+__device__ __forceinline__ uint64_t mix(uint64_t z)
+{
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0xBF58476D1CE4E5B9ull;
+    return z ^ (z >> 31);
+}
+
+// chunk c of block b: 256 nonzeros whose columns ascend uniformly over [0, n) along the block, local rows uniform in [0, R)
+__global__ __launch_bounds__(CHUNK) void k_fill(double *val, unsigned *idx, int *cbase, int64_t cpb, int64_t per, int n,
+                                                int R)
+{
+    const int64_t c = blockIdx.x;
+    const int64_t j0 = (c % cpb) * CHUNK;
+    const double gap = (double)n / (double)per;
+    const int64_t j = j0 + threadIdx.x;
+    const uint64_t h = mix((uint64_t)c * CHUNK + threadIdx.x);
+    const double u = (double)(h >> 11) * (1.0 / 9007199254740992.0);
+    int col = (int)(((double)(j < per ? j : per - 1) + u) * gap);
+    col = col >= n ? n - 1 : col;
+    int base = (int)((double)(j0 < per ? j0 : per - 1) * gap);
+    base = base > col ? col : base;
+    __shared__ int s_base;
+    if (threadIdx.x == 0) s_base = base;
+    __syncthreads();
+    const int lc = col - s_base;
+    const unsigned lrow = j < per ? (unsigned)((h >> 40) % (uint64_t)R) : (unsigned)R;   // padding: the dummy accumulator
+    val[c * CHUNK + threadIdx.x] = j < per ? 0.25 + (double)(h & 1023) * (1.0 / 1024.0) : 0.0;
+    idx[c * CHUNK + threadIdx.x] = (lrow << LBITS) | ((unsigned)(lc < 0 ? 0 : lc) & LMASK);
+    if (threadIdx.x == 0) cbase[c] = s_base;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// base and (a): NV + NI scalar prefetches per step, DS steps ahead of the vector loads (NV = NI = 0: base)
+// ---------------------------------------------------------------------------------------------------------------
+template <int NV, int NI, int DS>
+__global__ __launch_bounds__(BLOCK, 1) void k_sweep_spf(const double *__restrict__ val, const unsigned *__restrict__ idx,
+                                                        const int *__restrict__ cbase, const double *__restrict__ x,
+                                                        int64_t cpb, int b0, int nunits, int S, double ginv,
+                                                        double *__restrict__ out)
+{
+    __shared__ unsigned long long acc[NACC];
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1);
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int i = tid; i < NACC; i += BLOCK) acc[i] = 0ull;
+    __syncthreads();
+    constexpr int PF = NV + NI;
+    unsigned d[PF > 0 ? PF : 1];
+#pragma unroll
+    for (int k = 0; k < (PF > 0 ? PF : 1); ++k) d[k] = 0;
+    unsigned sink = 0;
+    for (int u = blockIdx.x; u < nunits; u += gridDim.x) {
+        const int b = b0 + u / S, sp = u % S;
+        const int64_t cb0 = (int64_t)b * cpb;
+        const int64_t c0 = cb0 + (cpb * sp) / S, c1 = cb0 + (cpb * (sp + 1)) / S;
+        double av[U], bv[U];
+        unsigned iv[U], jv[U];
+        int cb = 0, cbn = 0;
+        const int64_t clast = c1 > c0 ? c1 - 1 : c0;
+        auto issue = [&](int64_t c, double (&a)[U], unsigned (&i)[U], int &base) {
+            const int64_t cc = c < clast ? c : clast;
+            if (PF > 0) {   // by hand: the compiler would sink the load to its use and wait there -- for the touches too
+                const unsigned long long ba = (unsigned long long)(cbase + cc);
+                const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)ba), bhi = __builtin_amdgcn_readfirstlane((unsigned)(ba >> 32));
+                const unsigned long long bs = ((unsigned long long)bhi << 32) | blo;
+                asm volatile("s_load_dword %0, %1, 0x0" : "=s"(base) : "s"(bs) : "memory");
+            } else {
+                base = cbase[cc];
+            }
+            const int64_t k = cc * CHUNK + lane;
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                a[j] = __builtin_nontemporal_load(&val[k + j * WAVE]);
+                i[j] = __builtin_nontemporal_load(&idx[k + j * WAVE]);
+            }
+        };
+        auto prefetch = [&](int64_t c) {
+            if (PF == 0) return;
+            const int64_t cc = c < clast ? c : clast;
+            const unsigned long long va = (unsigned long long)(val + cc * CHUNK), ia = (unsigned long long)(idx + cc * CHUNK);
+            const unsigned vlo = __builtin_amdgcn_readfirstlane((unsigned)va), vhi = __builtin_amdgcn_readfirstlane((unsigned)(va >> 32));
+            const unsigned ilo = __builtin_amdgcn_readfirstlane((unsigned)ia), ihi = __builtin_amdgcn_readfirstlane((unsigned)(ia >> 32));
+            const unsigned long long vs = ((unsigned long long)vhi << 32) | vlo, is = ((unsigned long long)ihi << 32) | ilo;
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {   // NV of the chunk's 16 value lines
+                const unsigned long long a = vs + (unsigned long long)(k * (16 / NV)) * 128ull;
+                asm volatile("s_load_dword %0, %1, 0x0" : "=s"(d[k]) : "s"(a) : "memory");
+            }
+#pragma unroll
+            for (int k = 0; k < NI; ++k) {   // NI of its 8 index lines
+                const unsigned long long a = is + (unsigned long long)(k * (8 / (NI > 0 ? NI : 1))) * 128ull;
+                asm volatile("s_load_dword %0, %1, 0x0" : "=s"(d[NV + k]) : "s"(a) : "memory");
+            }
+        };
+        // a step, in the library's order: (1) this chunk's gathers, (2) the next chunk's stream, (2') the scalar touches of
+        // the chunk after it, (3) products and LDS adds.  The chunk's base (a scalar load of the step before) is consumed at
+        // (1), right behind the wait that retires the previous step's scalar touches: the compiler's own lgkmcnt(0) for it
+        // then costs nothing, and nothing waits on the touches issued at (2') until the next step.
+        double xv[U];
+        auto gather = [&](const unsigned (&i)[U], int base) {
+            if (PF > 0) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int k = 0; k < PF; ++k) asm volatile("" : "+s"(d[k]));
+#pragma unroll
+                for (int k = 0; k < PF; ++k) sink += d[k] & 1u;
+                asm volatile("" : "+s"(base));
+            }
+#pragma unroll
+            for (int j = 0; j < U; ++j) xv[j] = x[base + (int)(i[j] & LMASK)];
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto accumulate = [&](const double (&a)[U], const unsigned (&i)[U]) {
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                const double p = a[j] * xv[j];
+                const int r = (int)(i[j] >> LBITS);
+                atomicAdd(&acc[r], (unsigned long long)__double2ll_rn(p * ginv));
+            }
+        };
+        if (c0 + w < c1) {
+            issue(c0 + w, av, iv, cb);
+            for (int64_t c = c0 + w; c < c1; c += 2 * WAVES) {
+                gather(iv, cb);
+                issue(c + WAVES, bv, jv, cbn);
+                prefetch(c + (1 + DS) * WAVES);
+                accumulate(av, iv);
+                if (c + WAVES < c1) {
+                    gather(jv, cbn);
+                    issue(c + 2 * WAVES, av, iv, cb);
+                    prefetch(c + (2 + DS) * WAVES);
+                    accumulate(bv, jv);
+                }
+            }
+        }
+    }
+    if (PF > 0) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int k = 0; k < PF; ++k) asm volatile("" : "+s"(d[k]));
+#pragma unroll
+        for (int k = 0; k < PF; ++k) sink += d[k] & 1u;
+    }
+    __syncthreads();
+    unsigned long long t = 0;
+    for (int i = tid; i < NACC; i += BLOCK) t += acc[i];
+    if (t == 0x123456789ull || sink == 0x7fffffffu) out[1] = 1.0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// (b): P producer waves move the stream into a ring of SL chunk slots by LDS-DMA, 16 - P consumer waves gather and add
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int SLOT_BYTES = CHUNK * 12;   // 2 KiB of values + 1 KiB of index words
+__device__ __forceinline__ void glds16(const void *g, void *lds)
+{
+    __builtin_amdgcn_global_load_lds(g, (__attribute__((address_space(3))) void *)lds, 16, 0, 2 /* nt */);
+}
+template <int P, int SL, int D>   // D chunks in flight per producer wave
+__global__ __launch_bounds__(BLOCK, 1) void k_sweep_ring(const double *__restrict__ val, const unsigned *__restrict__ idx,
+                                                         const int *__restrict__ cbase, const double *__restrict__ x,
+                                                         int64_t cpb, int b0, int nunits, int S, double ginv, int nacc,
+                                                         double *__restrict__ out)
+{
+    extern __shared__ unsigned long long dyn[];
+    unsigned long long *acc = dyn;                                        // [nacc]
+    char *ring = reinterpret_cast<char *>(dyn + nacc);                     // [SL][SLOT_BYTES]
+    __shared__ unsigned flg[2 * SL];   // [0, SL): chunks published into each slot; [SL, 2 SL): chunks taken out of it
+    // (LDS words read and written with ds_ instructions by hand: a volatile access would drain vmcnt -- the DMAs in flight)
+    auto lds_addr = [&](int i) { return (unsigned)(size_t)(__attribute__((address_space(3))) unsigned *)&flg[i]; };
+    auto put = [&](int i, unsigned v) { asm volatile("ds_write_b32 %0, %1" ::"v"(lds_addr(i)), "v"(v) : "memory"); };
+    auto get = [&](int i) {
+        unsigned v;
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(lds_addr(i)) : "memory");
+        return v;
+    };
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1);
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int C = WAVES - P;
+    for (int i = tid; i < nacc; i += BLOCK) acc[i] = 0ull;
+    for (int u = blockIdx.x; u < nunits; u += gridDim.x) {
+        const int b = b0 + u / S, sp = u % S;
+        const int64_t cb0 = (int64_t)b * cpb;
+        const int64_t c0 = cb0 + (cpb * sp) / S, c1 = cb0 + (cpb * (sp + 1)) / S;
+        const int nc = (int)(c1 - c0);
+        __syncthreads();
+        if (tid < 2 * SL) flg[tid] = 0u;
+        __syncthreads();
+        if (w < P) {
+            // producer: chunk k -> slot k % SL once the slot's previous chunk (k - SL) was taken; published D chunks later
+            int kpub = w;   // the next chunk of this wave to publish
+            for (int k = w; k < nc; k += P) {
+                const int slot = k % SL;
+                const unsigned need = (unsigned)(k / SL);
+                while (get(SL + slot) != need) __builtin_amdgcn_s_sleep(1);
+                const int64_t c = c0 + k;
+                char *dst = ring + slot * SLOT_BYTES;
+                const char *vsrc = reinterpret_cast<const char *>(val + c * CHUNK);
+                const char *isrc = reinterpret_cast<const char *>(idx + c * CHUNK);
+                glds16(vsrc + lane * 16, dst);
+                glds16(vsrc + 1024 + lane * 16, dst + 1024);
+                glds16(isrc + lane * 16, dst + 2048);
+                if ((k - w) / P >= D - 1) {
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * (D - 1)) : "memory");
+                    const int sl = kpub % SL;
+                    if (lane == 0) put(sl, (unsigned)(kpub / SL) + 1u);
+                    kpub += P;
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            for (; kpub < nc; kpub += P)
+                if (lane == 0) put(kpub % SL, (unsigned)(kpub / SL) + 1u);
+        } else {
+            const int cw = w - P;
+            for (int k = cw; k < nc; k += C) {
+                const int slot = k % SL;
+                const unsigned gen = (unsigned)(k / SL) + 1u;
+                const int base = cbase[c0 + k];
+                while (get(slot) != gen) __builtin_amdgcn_s_sleep(1);
+                const double *sv = reinterpret_cast<const double *>(ring + slot * SLOT_BYTES);
+                const unsigned *si = reinterpret_cast<const unsigned *>(ring + slot * SLOT_BYTES + 2048);
+                double a[U];
+                unsigned i[U];
+#pragma unroll
+                for (int j = 0; j < U; ++j) {
+                    a[j] = sv[j * WAVE + lane];
+                    i[j] = si[j * WAVE + lane];
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane == 0) put(SL + slot, gen);
+                double xv[U];
+#pragma unroll
+                for (int j = 0; j < U; ++j) xv[j] = x[base + (int)(i[j] & LMASK)];
+#pragma unroll
+                for (int j = 0; j < U; ++j) {
+                    const double p = a[j] * xv[j];
+                    const int r = (int)(i[j] >> LBITS);
+                    atomicAdd(&acc[r], (unsigned long long)__double2ll_rn(p * ginv));
+                }
+            }
+        }
+    }
+    __syncthreads();
+    unsigned long long t = 0;
+    for (int i = tid; i < nacc; i += BLOCK) t += acc[i];
+    if (t == 0x123456789ull) out[1] = 1.0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// (c): dense rows -- a wave copies the span of x its next chunk touches into a window of its own in LDS (LDS-DMA, WCOLS
+// columns from the chunk's base on) beside the next chunk's stream, and gathers from LDS.  WCOLS = 0: the base form with
+// `nacc` accumulators (what the smaller R alone costs).
+// ---------------------------------------------------------------------------------------------------------------
+template <int WCOLS>
+__global__ __launch_bounds__(BLOCK, 1) void k_sweep_xwin(const double *__restrict__ val, const unsigned *__restrict__ idx,
+                                                         const int *__restrict__ cbase, const double *__restrict__ x,
+                                                         int64_t cpb, int b0, int nunits, int S, double ginv, int nacc,
+                                                         double *__restrict__ out)
+{
+    extern __shared__ unsigned long long dyn[];
+    unsigned long long *acc = dyn;
+    double *xw = reinterpret_cast<double *>(dyn + nacc) + (size_t)(threadIdx.x >> 6) * (WCOLS > 0 ? WCOLS : 1);   // this wave's window
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1);
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int i = tid; i < nacc; i += BLOCK) acc[i] = 0ull;
+    __syncthreads();
+    for (int u = blockIdx.x; u < nunits; u += gridDim.x) {
+        const int b = b0 + u / S, sp = u % S;
+        const int64_t cb0 = (int64_t)b * cpb;
+        const int64_t c0 = cb0 + (cpb * sp) / S, c1 = cb0 + (cpb * (sp + 1)) / S;
+        const int64_t clast = c1 > c0 ? c1 - 1 : c0;
+        double av[U], bv[U];
+        unsigned iv[U], jv[U];
+        int cb = 0, cbn = 0;
+        auto issue = [&](int64_t c, double (&a)[U], unsigned (&i)[U], int &base) {
+            const int64_t cc = c < clast ? c : clast;
+            base = cbase[cc];
+            const int64_t k = cc * CHUNK + lane;
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                a[j] = __builtin_nontemporal_load(&val[k + j * WAVE]);
+                i[j] = __builtin_nontemporal_load(&idx[k + j * WAVE]);
+            }
+            if (WCOLS > 0) {   // the window of that chunk: WCOLS columns from base & ~1 on (16-byte pieces)
+                const double *src = x + (base & ~1);
+#pragma unroll
+                for (int q = 0; q < WCOLS / 128; ++q) glds16(src + q * 128 + lane * 2, xw + q * 128);
+            }
+        };
+        double xv[U];
+        auto gather = [&](const unsigned (&i)[U], int base) {
+            if (WCOLS > 0) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this chunk's stream and window have landed
+#pragma unroll
+                for (int j = 0; j < U; ++j) xv[j] = xw[(base & 1) + (int)(i[j] & LMASK)];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // ... and are read: the window may be refilled
+            } else {
+#pragma unroll
+                for (int j = 0; j < U; ++j) xv[j] = x[base + (int)(i[j] & LMASK)];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto accumulate = [&](const double (&a)[U], const unsigned (&i)[U]) {
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                const double p = a[j] * xv[j];
+                const int r = (int)(i[j] >> LBITS);
+                atomicAdd(&acc[r], (unsigned long long)__double2ll_rn(p * ginv));
+            }
+        };
+        if (c0 + w < c1) {
+            issue(c0 + w, av, iv, cb);
+            for (int64_t c = c0 + w; c < c1; c += 2 * WAVES) {
+                gather(iv, cb);
+                issue(c + WAVES, bv, jv, cbn);
+                accumulate(av, iv);
+                if (c + WAVES < c1) {
+                    gather(jv, cbn);
+                    issue(c + 2 * WAVES, av, iv, cb);
+                    accumulate(bv, jv);
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    unsigned long long t = 0;
+    for (int i = tid; i < nacc; i += BLOCK) t += acc[i];
+    if (t == 0x123456789ull) out[1] = 1.0;
+}
+
+struct Cfg {
+    const char *name;
+    int n;          // columns of x
+    int R;          // rows per block
+    double d;       // nonzeros per row
+    int nblocks;    // row blocks of the matrix
+    int S;          // column splits
+};
+
+struct Mat {
+    double *val;
+    unsigned *idx;
+    int *cbase;
+    int64_t cpb, nchunks;
+    double bytes;
+};
+static Mat build(const Cfg &c)
+{
+    Mat m;
+    const int64_t per = (int64_t)(c.R * c.d);
+    m.cpb = (per + CHUNK - 1) / CHUNK;
+    m.nchunks = m.cpb * c.nblocks;
+    CK(hipMalloc(&m.val, sizeof(double) * m.nchunks * CHUNK));
+    CK(hipMalloc(&m.idx, sizeof(unsigned) * m.nchunks * CHUNK));
+    CK(hipMalloc(&m.cbase, sizeof(int) * m.nchunks));
+    hipLaunchKernelGGL(k_fill, dim3((unsigned)m.nchunks), dim3(CHUNK), 0, 0, m.val, m.idx, m.cbase, m.cpb, per, c.n, c.R);
+    CK(hipDeviceSynchronize());
+    m.bytes = (double)m.nchunks * CHUNK * 12.0 + (double)m.nchunks * 4.0 + 8.0 * c.n;
+    return m;
+}
+static void release(Mat &m)
+{
+    CK(hipFree(m.val));
+    CK(hipFree(m.idx));
+    CK(hipFree(m.cbase));
+}
+
+template <typename L>
+static double time_product(const Cfg &c, L launch, int reps)
+{
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    const int per_launch = std::max(1, 256 / c.S);
+    auto product = [&]() {
+        for (int b0 = 0; b0 < c.nblocks; b0 += per_launch) {
+            const int nb = std::min(per_launch, c.nblocks - b0);
+            launch(b0, nb * c.S, std::min(256, nb * c.S));
+        }
+    };
+    product();
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0, 0));
+    for (int r = 0; r < reps; ++r) product();
+    CK(hipEventRecord(e1, 0));
+    CK(hipEventSynchronize(e1));
+    CK(hipGetLastError());
+    float ms = 0;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    CK(hipEventDestroy(e0));
+    CK(hipEventDestroy(e1));
+    return ms / reps;
+}
+
+template <int NV, int NI, int DS>
+static double run_spf(const Cfg &c, const Mat &m, const double *x, double *out, int reps)
+{
+    return time_product(c, [&](int b0, int nunits, int grid) {
+        hipLaunchKernelGGL((k_sweep_spf<NV, NI, DS>), dim3(grid), dim3(BLOCK), 0, 0, m.val, m.idx, m.cbase, x, m.cpb, b0, nunits,
+                           c.S, 0x1p40, out);
+    }, reps);
+}
+
+// the blocking the library would choose for `rows` rows of at most Rcap each: whole rounds of 256 blocks without splits
+// (S = 1), whole sets of 256 / S blocks with S splits (many rows), or -- fewer rows than 256 full blocks -- the fewest
+// splits S for which 256 / S blocks of <= Rcap rows cover the matrix
+static Cfg blocking(const char *name, int n, double d, int64_t rows, int S, int Rcap)
+{
+    int nb = (int)((rows + Rcap - 1) / Rcap);
+    if (S == 1) nb = ((nb + 255) / 256) * 256;
+    else if (nb >= 256) nb = ((nb + 256 / S - 1) / (256 / S)) * (256 / S);
+    else {
+        for (S = 1; S <= 8; ++S) {
+            nb = 256 / S;
+            if ((rows + nb - 1) / nb <= Rcap) break;
+        }
+    }
+    return Cfg{name, n, (int)((rows + nb - 1) / nb), d, nb, S};
+}
+
+template <int P, int SL, int D>
+static double run_ring(const Cfg &c, const Mat &m, const double *x, double *out, int reps)
+{
+    const int nacc = c.R + 64;
+    const size_t lds = (size_t)nacc * 8 + (size_t)SL * SLOT_BYTES;
+    if (lds + 2 * SL * 4 > 160 * 1024) return -1.0;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sweep_ring<P, SL, D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    return time_product(c, [&](int b0, int nunits, int grid) {
+        hipLaunchKernelGGL((k_sweep_ring<P, SL, D>), dim3(grid), dim3(BLOCK), lds, 0, m.val, m.idx, m.cbase, x, m.cpb, b0, nunits,
+                           c.S, 0x1p40, nacc, out);
+    }, reps);
+}
+template <int WCOLS>
+static double run_xwin(const Cfg &c, const Mat &m, const double *x, double *out, int reps)
+{
+    const int nacc = c.R + 64;
+    const size_t lds = (size_t)nacc * 8 + (size_t)WAVES * WCOLS * 8;
+    if (lds > 160 * 1024) return -1.0;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sweep_xwin<WCOLS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    return time_product(c, [&](int b0, int nunits, int grid) {
+        hipLaunchKernelGGL((k_sweep_xwin<WCOLS>), dim3(grid), dim3(BLOCK), lds, 0, m.val, m.idx, m.cbase, x, m.cpb, b0, nunits,
+                           c.S, 0x1p40, nacc, out);
+    }, reps);
+}
+
+int main(int argc, char **argv)
+{
+    const int reps = argc > 1 ? std::atoi(argv[1]) : 5;
+    const char *which = argc > 2 ? argv[2] : "a";
+    double *x, *out;
+    CK(hipMalloc(&x, sizeof(double) * 11000000));
+    CK(hipMemset(x, 0, sizeof(double) * 11000000));
+    CK(hipMalloc(&out, 64));
+    const Cfg cfgs[] = {
+        {"config 4: 10M x 10M x 100, 512 blocks, S = 4", 10000000, 19532, 100.0, 512, 4},
+        {"rank block of config 4 at N = 8: 1.25M x 10M x 100, 64 blocks, S = 4", 10000000, 19532, 100.0, 64, 4},
+        {"config 5: 5M x 2M power law (21.3 per row), 256 blocks, S = 1", 2000000, 19532, 21.29, 256, 1},
+        {"config 3 at 100 per row: 4M x 1M, 256 blocks of 15625 rows, S = 1", 1000000, 15625, 100.0, 256, 1},
+    };
+    if (std::strchr(which, 'a')) {
+        std::printf("(a) scalar-cache prefetch of the stream beside the gathers; ms per product, two rounds of every variant\n");
+        std::printf("%-72s %8s %8s %8s %8s %8s %8s %8s %8s\n", "configuration", "base", "8v/1", "8v/2", "8v4i/1", "8v4i/2", "4v2i/1",
+                    "2v/1", "base");
+        for (const Cfg &c : cfgs) {
+            Mat m = build(c);
+            for (int round = 0; round < 2; ++round) {
+                const double t0 = run_spf<0, 0, 1>(c, m, x, out, reps);
+                const double t1 = run_spf<8, 0, 1>(c, m, x, out, reps);
+                const double t2 = run_spf<8, 0, 2>(c, m, x, out, reps);
+                const double t3 = run_spf<8, 4, 1>(c, m, x, out, reps);
+                const double t4 = run_spf<8, 4, 2>(c, m, x, out, reps);
+                const double t5 = run_spf<4, 2, 1>(c, m, x, out, reps);
+                const double t6 = run_spf<2, 0, 1>(c, m, x, out, reps);
+                const double t7 = run_spf<0, 0, 1>(c, m, x, out, reps);
+                std::printf("%-72s %8.3f %8.3f %8.3f %8.3f %8.3f %8.3f %8.3f %8.3f   (%.0f GB/s base)\n", c.name, t0, t1, t2, t3,
+                            t4, t5, t6, t7, m.bytes / t0 / 1e6);
+                std::fflush(stdout);
+            }
+            release(m);
+        }
+    }
+    if (std::strchr(which, 'b')) {
+        // the ring costs accumulators: the same matrix cut into blocks of R' = R - SL * 384 rows (same nonzeros per row:
+        // more blocks of fewer rows), S as the library would choose
+        std::printf("(b) producer waves + LDS-DMA ring; ms per product (the same 10^9 / 1.25 10^8 nonzeros in every column)\n");
+        std::printf("%-44s %8s | %8s %8s %8s %8s %8s %8s | %8s\n", "configuration", "base R", "xwin0 R'", "2p/8s/2d", "2p/8s/3d",
+                    "4p/8s/2d", "4p/12s/2d", "4p/16s/3d", "base R");
+        struct RC { const char *name; int n; double d; int64_t rows; int S; };
+        const RC rcs[] = {{"config 4: 10M x 10M x 100, S = 4", 10000000, 100.0, 10000000, 4},
+                          {"rank block: 1.25M x 10M x 100, S = 4", 10000000, 100.0, 1250000, 4},
+                          {"config 5: 5M x 2M x 21.3, S = 1", 2000000, 21.29, 5000000, 1}};
+        for (const RC &rc : rcs) {
+            auto cfg_for = [&](int R) { return blocking(rc.name, rc.n, rc.d, rc.rows, rc.S, R); };
+            const Cfg full = cfg_for(20352);
+            const Cfg r8 = cfg_for(20352 - 8 * 384 - 8), r12 = cfg_for(20352 - 12 * 384 - 16), r16 = cfg_for(20352 - 16 * 384 - 16);
+            Mat mf = build(full), m8 = build(r8), m12 = build(r12), m16 = build(r16);
+            for (int round = 0; round < 2; ++round) {
+                const double t0 = run_spf<0, 0, 1>(full, mf, x, out, reps);
+                const double t1 = run_xwin<0>(r8, m8, x, out, reps);
+                const double t2 = run_ring<2, 8, 2>(r8, m8, x, out, reps);
+                const double t3 = run_ring<2, 8, 3>(r8, m8, x, out, reps);
+                const double t4 = run_ring<4, 8, 2>(r8, m8, x, out, reps);
+                const double t5 = run_ring<4, 12, 2>(r12, m12, x, out, reps);
+                const double t6 = run_ring<4, 16, 3>(r16, m16, x, out, reps);
+                const double t7 = run_spf<0, 0, 1>(full, mf, x, out, reps);
+                std::printf("%-44s %8.3f | %8.3f %8.3f %8.3f %8.3f %8.3f %8.3f | %8.3f   R %d / %d / %d / %d blocks %d / %d / %d / %d S %d / %d / %d / %d\n",
+                            rc.name, t0, t1, t2, t3, t4, t5, t6, t7, full.R, r8.R, r12.R, r16.R, full.nblocks, r8.nblocks,
+                            r12.nblocks, r16.nblocks, full.S, r8.S, r12.S, r16.S);
+                std::fflush(stdout);
+            }
+            release(mf); release(m8); release(m12); release(m16);
+        }
+    }
+    if (std::strchr(which, 'c')) {
+        std::printf("(c) a wave's span of x staged in LDS (dense rows); ms per product\n");
+        std::printf("%-64s %8s %8s %8s %8s\n", "configuration", "base R", "base R'", "xwin R'", "base R");
+        struct DC { const char *name; int n; double d; int64_t rows; int S; int wcols; };
+        const DC dcs[] = {{"config 3 literal: 4M x 1M x 1000, S = 1 (window 128 columns)", 1000000, 1000.0, 4000000, 1, 128},
+                          {"rank block at 1000 per row: 1.25M x 10M x 1000, S = 4 (256)", 10000000, 1000.0, 1250000, 4, 256}};
+        for (const DC &dc : dcs) {
+            auto cfg_for = [&](int R) { return blocking(dc.name, dc.n, dc.d, dc.rows, dc.S, R); };
+            const Cfg full = cfg_for(20352), cut = cfg_for(20352 - WAVES * dc.wcols - 64);   // (a window column costs a row)
+            Mat mf = build(full), mc = build(cut);
+            for (int round = 0; round < 2; ++round) {
+                const double t0 = run_spf<0, 0, 1>(full, mf, x, out, reps);
+                const double t1 = run_xwin<0>(cut, mc, x, out, reps);
+                const double t2 = dc.wcols == 128 ? run_xwin<128>(cut, mc, x, out, reps) : run_xwin<256>(cut, mc, x, out, reps);
+                const double t3 = run_spf<0, 0, 1>(full, mf, x, out, reps);
+                std::printf("%-64s %8.3f %8.3f %8.3f %8.3f   R %d / %d blocks %d / %d S %d / %d (%.0f GB/s base)\n", dc.name, t0, t1, t2, t3,
+                            full.R, cut.R, full.nblocks, cut.nblocks, full.S, cut.S, mf.bytes / t0 / 1e6);
+                std::fflush(stdout);
+            }
+            release(mf); release(mc);
+        }
+    }
+    return 0;
+}
