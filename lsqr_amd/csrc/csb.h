@@ -714,7 +714,10 @@ __device__ __forceinline__ double csb_row_sum(const CsbMat &A, long long fine, i
     return sum;
 }
 
-template <typename VT = double, bool NARROW = false>
+// K: chunks a wave takes per LOCK-STEP step (round 5; header "lock step"), or 0: the free-running sweep of rounds 2-4
+// (every wave on its own, next chunk's stream requested behind this chunk's gathers) -- kept for the A/B
+// (LSQRHIP_CSB_LOCKSTEP=0 at create).  Same sums bit for bit: integer adds do not care when they happen.
+template <typename VT = double, bool NARROW = false, int K = 0>
 __global__ __launch_bounds__(CSB_BLOCK, 1) void k_spmv_csb(
     CsbMat A, const VT *__restrict__ x, VT *__restrict__ y, const SpmvCoef *__restrict__ coef,
     const int *__restrict__ stop, double *__restrict__ partials, const double *__restrict__ pin, int npin,
@@ -850,16 +853,75 @@ __global__ __launch_bounds__(CSB_BLOCK, 1) void k_spmv_csb(
                 }
             }
         };
-        if (c0 + w < c1) {
-            issue(c0 + w, av, iv);
-            for (long long c = c0 + w; c < c1; c += 2 * CSB_WAVES) {
-                gather(iv);
-                issue(c + CSB_WAVES, bv, jv);
-                accumulate(av);
-                if (c + CSB_WAVES < c1) {  // uniform
-                    gather(jv);
-                    issue(c + 2 * CSB_WAVES, av, iv);
-                    accumulate(bv);
+        if (K == 0) {
+            if (c0 + w < c1) {
+                issue(c0 + w, av, iv);
+                for (long long c = c0 + w; c < c1; c += 2 * CSB_WAVES) {
+                    gather(iv);
+                    issue(c + CSB_WAVES, bv, jv);
+                    accumulate(av);
+                    if (c + CSB_WAVES < c1) {  // uniform
+                        gather(jv);
+                        issue(c + 2 * CSB_WAVES, av, iv);
+                        accumulate(bv);
+                    }
+                }
+            }
+        } else {
+            // LOCK STEP (header): all 16 waves move together, KK chunks per wave and step --
+            //   barrier A | decode + gathers of this step's chunks | barrier B | stream of the next step's chunks |
+            //   products + LDS adds (behind the gathers, the stream in flight) | wait for the stream |
+            // Barrier A: every wave's stream has landed, the CU has no HBM request queued when the gathers go out.
+            // Barrier B: every wave's gathers are REQUESTED (not back): stream requests queued behind gathers hold
+            // nobody up, so they follow at once and the L1 never runs dry between the two phases.
+            // The step count is the same for every wave (barriers inside); a wave without a real chunk in a step
+            // loads the range's last chunk again (clamped) and adds nothing.
+            constexpr int KK = K > 0 ? K : 1;
+            const long long nch = c1 - c0;
+            const int nsteps = (int)((nch + (long long)KK * CSB_WAVES - 1) / ((long long)KK * CSB_WAVES));
+            double a0[KK][CSB_U], a1[KK][CSB_U];
+            CsbRaw<NARROW> q0[KK], q1[KK];
+            auto issue_set = [&](long long cfirst, double (&a)[KK][CSB_U], CsbRaw<NARROW> (&q)[KK]) {
+#pragma unroll
+                for (int k = 0; k < KK; ++k) issue(cfirst + (long long)k * CSB_WAVES, a[k], q[k]);
+            };
+            auto lockstep = [&](long long cfirst, double (&a)[KK][CSB_U], CsbRaw<NARROW> (&q)[KK], double (&an)[KK][CSB_U],
+                                CsbRaw<NARROW> (&qn)[KK]) {
+                int rr[KK][CSB_U];
+                double xx[KK][CSB_U];
+                __builtin_amdgcn_s_barrier();   // A
+#pragma unroll
+                for (int k = 0; k < KK; ++k) {
+                    int col[CSB_U];
+                    csb_decode<NARROW>(q[k], rr[k], col);
+#pragma unroll
+                    for (int j = 0; j < CSB_U; ++j) xx[k][j] = (double)x[col[j]];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();   // B
+                __builtin_amdgcn_sched_barrier(0);
+                issue_set(cfirst + (long long)KK * CSB_WAVES, an, qn);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k = 0; k < KK; ++k) {
+                    if (cfirst + (long long)k * CSB_WAVES < c1) {   // (uniform)
+#pragma unroll
+                        for (int j = 0; j < CSB_U; ++j) {
+                            r[j] = rr[k][j];
+                            xv[j] = xx[k][j];
+                        }
+                        accumulate(a[k]);
+                    }
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next step's stream has landed
+            };
+            if (nsteps > 0) {   // (uniform)
+                issue_set(c0 + w, a0, q0);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                for (int st = 0; st < nsteps; st += 2) {
+                    const long long cfirst = c0 + (long long)st * KK * CSB_WAVES + w;
+                    lockstep(cfirst, a0, q0, a1, q1);
+                    if (st + 1 < nsteps) lockstep(cfirst + (long long)KK * CSB_WAVES, a1, q1, a0, q0);
                 }
             }
         }

@@ -176,6 +176,7 @@ struct Csr {
     unsigned *cdel = nullptr;     // narrow form: [nchunks * 64] four u8 column deltas per lane
     int *ccb = nullptr;           // [nchunks] first column of each chunk; narrow form: [nchunks * 4] of each segment
     bool cnarrow = false;         // 11 bytes per nonzero (csb.h "NARROW form")
+    int clockstep = 2;            // chunks per wave and lock-step step of the sweep (csb.h "lock step"); 0: free-running waves
     // overlap plan of the sharded engine (csb.h "Column stripes / phases"); all off: NS = 1, border = null
     long long *gptr = nullptr;    // [nrb * NS + 1] first chunk of every (block, stripe) group
     int *border = nullptr;        // [nrb] launch order of the row blocks (phase-major), or null
@@ -1243,6 +1244,10 @@ static int build_csb(hipStream_t s, const int *rowk, const int *colk, const doub
     out.csb = 1;
     out.cval = s_val.release<double>();
     out.cnarrow = narrow;
+    {   // LSQRHIP_CSB_LOCKSTEP = 0 (the sweep of rounds 2-4: every wave on its own) | 1 | 2 (default) chunks per wave and step
+        const int ls = env_int("LSQRHIP_CSB_LOCKSTEP", 2);
+        out.clockstep = ls < 0 ? 0 : (ls > 2 ? 2 : ls);
+    }
     if (narrow) {
         out.cidx = reinterpret_cast<unsigned *>(s_row16.release<unsigned short>());
         out.cdel = reinterpret_cast<unsigned *>(s_del.release<unsigned char>());

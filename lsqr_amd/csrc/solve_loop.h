@@ -274,9 +274,9 @@ static void launch_xl(const SpmvArgs &a, double *z)
     else launch_xl_C<OffT, V8, false>(a, z);
 }
 
-// column-swept row blocks (csb.h)
-template <typename VT, bool NARROW>
-static void launch_csb_N(H *h, const SpmvArgs &a)
+// column-swept row blocks (csb.h); K: chunks per wave and lock-step step (0: the free-running sweep)
+template <typename VT, bool NARROW, int K>
+static void launch_csb_K(H *h, const SpmvArgs &a)
 {
     const Csr &c = *a.c;
     const VT *x = reinterpret_cast<const VT *>(a.x);
@@ -331,10 +331,10 @@ static void launch_csb_N(H *h, const SpmvArgs &a)
             const dim3 grid(std::max(1, std::min(c.grid, (b1 - b0) * nsp)) + (rider.kind != 0 ? 1 : 0));
             hipEvent_t e0 = first ? a.e0 : nullptr, e1 = (last && S == 1) ? a.e1 : nullptr;
             if (e0 == nullptr && e1 == nullptr)
-                hipLaunchKernelGGL((k_spmv_csb<VT, NARROW>), grid, dim3(CSB_BLOCK), 0, a.stream, A, x, y, a.coef, a.stop, a.pout,
+                hipLaunchKernelGGL((k_spmv_csb<VT, NARROW, K>), grid, dim3(CSB_BLOCK), 0, a.stream, A, x, y, a.coef, a.stop, a.pout,
                                    a.pin, a.npin, a.slot_in, a.slot_out, a.skip_if_zero, rider, xb, a.nsc);
             else
-                hipExtLaunchKernelGGL((k_spmv_csb<VT, NARROW>), grid, dim3(CSB_BLOCK), 0, a.stream, e0, e1, 0, A, x, y, a.coef,
+                hipExtLaunchKernelGGL((k_spmv_csb<VT, NARROW, K>), grid, dim3(CSB_BLOCK), 0, a.stream, e0, e1, 0, A, x, y, a.coef,
                                       a.stop, a.pout, a.pin, a.npin, a.slot_in, a.slot_out, a.skip_if_zero, rider, xb,
                                       a.nsc);
             first = false;
@@ -349,6 +349,16 @@ static void launch_csb_N(H *h, const SpmvArgs &a)
         else
             hipExtLaunchKernelGGL((k_csb_combine<VT, NARROW>), grid, dim3(CSB_BLOCK), 0, a.stream, nullptr, a.e1, 0, A, x, y,
                                   a.coef, a.stop, a.pout, a.pin, a.npin, a.slot_in, a.skip_if_zero, xb, a.nsc);
+    }
+}
+
+template <typename VT, bool NARROW>
+static void launch_csb_N(H *h, const SpmvArgs &a)
+{
+    switch (a.c->clockstep) {   // (fixed at create: LSQRHIP_CSB_LOCKSTEP)
+    case 0: launch_csb_K<VT, NARROW, 0>(h, a); break;
+    case 1: launch_csb_K<VT, NARROW, 1>(h, a); break;
+    default: launch_csb_K<VT, NARROW, 2>(h, a); break;
     }
 }
 

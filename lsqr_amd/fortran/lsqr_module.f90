@@ -50,6 +50,9 @@ module lsqr_module
       procedure, public :: initialize => initialize_ez
       procedure, public :: solve => solve_ez
       procedure, public :: aprod => aprod_ez
+      procedure, public :: lsqr => lsqr_ez       !< the inherited entry points, when called on THIS type, run on the
+      procedure, public :: acheck => acheck_ez   !< device too (round 5): no aprod round trip over PCIe per product
+      procedure, public :: xcheck => xcheck_ez
       procedure, public :: destroy => destroy_ez
       procedure, private :: copy_ez
       generic, public :: assignment(=) => copy_ez
@@ -155,6 +158,42 @@ module lsqr_module
          type(c_ptr), value :: h
          integer(c_int), value :: mode
          real(c_float), intent(inout) :: x(*), y(*)
+         integer(c_int) :: rc
+      end function
+      function lsqrhip_acheck(h, eps, inform, relerr) bind(C, name='lsqrhip_acheck') result(rc)
+         import :: c_int, c_double, c_ptr
+         type(c_ptr), value :: h
+         real(c_double), value :: eps
+         integer(c_int), intent(out) :: inform
+         real(c_double), intent(out) :: relerr
+         integer(c_int) :: rc
+      end function
+      function lsqrhip_acheck_f32(h, eps, inform, relerr) bind(C, name='lsqrhip_acheck_f32') result(rc)
+         import :: c_int, c_double, c_ptr
+         type(c_ptr), value :: h
+         real(c_double), value :: eps
+         integer(c_int), intent(out) :: inform
+         real(c_double), intent(out) :: relerr
+         integer(c_int) :: rc
+      end function
+      function lsqrhip_xcheck(h, anorm, damp, eps, b, x, u, v, w, inform, tests) bind(C, name='lsqrhip_xcheck') result(rc)
+         import :: c_int, c_double, c_ptr
+         type(c_ptr), value :: h
+         real(c_double), value :: anorm, damp, eps
+         real(c_double), intent(in) :: b(*), x(*)
+         real(c_double), intent(out) :: u(*), v(*), w(*)
+         integer(c_int), intent(out) :: inform
+         real(c_double), intent(out) :: tests(3)
+         integer(c_int) :: rc
+      end function
+      function lsqrhip_xcheck_f32(h, anorm, damp, eps, b, x, u, v, w, inform, tests) bind(C, name='lsqrhip_xcheck_f32') result(rc)
+         import :: c_int, c_double, c_float, c_ptr
+         type(c_ptr), value :: h
+         real(c_double), value :: anorm, damp, eps
+         real(c_float), intent(in) :: b(*), x(*)
+         real(c_float), intent(out) :: u(*), v(*), w(*)
+         integer(c_int), intent(out) :: inform
+         real(c_double), intent(out) :: tests(3)
          integer(c_int) :: rc
       end function
       function lsqrhip_log_count(h) bind(C, name='lsqrhip_log_count') result(k)
@@ -699,11 +738,9 @@ contains
       integer, intent(out) :: inform
       real(wp), intent(in) :: eps
       real(wp) :: v(n), w(m), x(n), y(m)
-      real(wp), parameter :: power = 0.5_wp
-      real(wp) :: ywdot, xvdot, gap, tol
+      real(wp) :: ywdot, xvdot, gap
       integer :: i
 
-      tol = eps**power
       if (nout /= 0) write (nout, '(//A)') 'Enter acheck. Test of aprod for LSQR and CRAIG'
       x = [(sqrt(real(i + 1, wp)), i=1, n)]
       y = [(one/sqrt(real(i + 1, wp)), i=1, m)]
@@ -716,14 +753,49 @@ contains
       ywdot = ddot(m, y, 1, w, 1)
       xvdot = ddot(n, x, 1, v, 1)
       gap = abs(ywdot - xvdot)/(one + abs(ywdot) + abs(xvdot))
-      if (gap <= tol) then
+      call acheck_verdict(nout, eps, gap, inform)
+   end subroutine acheck
+
+   !> the decision and the two report lines of `acheck` (src/lsqr.f90:984-992), shared by the host and the device form
+   subroutine acheck_verdict(nout, eps, gap, inform)
+      integer, intent(in) :: nout
+      real(wp), intent(in) :: eps, gap
+      integer, intent(out) :: inform
+      real(wp), parameter :: power = 0.5_wp
+      if (gap <= eps**power) then
          inform = 0
          if (nout /= 0) write (nout, '(1P,A,1X,E10.1)') 'aprod seems OK. Relative error =', gap
       else
          inform = 1
          if (nout /= 0) write (nout, '(1P,A,1X,E10.1)') 'aprod seems incorrect. Relative error =', gap
       end if
-   end subroutine acheck
+   end subroutine acheck_verdict
+
+   !> `acheck` of an `lsqr_solver_ez`: the whole test -- the two vectors, both products, both dot products -- on the
+   !! device operator (lsqrhip_acheck, include/lsqrhip.h), one call, no vector crosses PCIe.  v, w, x, y are the
+   !! reference's work arrays: not touched.  A handle sharded over several GPUs has no device form of the test and takes
+   !! the inherited host path over `aprod_ez`.
+   subroutine acheck_ez(me, m, n, nout, eps, v, w, x, y, inform)
+      class(lsqr_solver_ez), intent(inout) :: me
+      integer, intent(in) :: m, n, nout
+      integer, intent(out) :: inform
+      real(wp), intent(in) :: eps
+      real(wp) :: v(n), w(m), x(n), y(m)
+      integer(c_int) :: inf
+      real(c_double) :: err
+      if (m /= me%m .or. n /= me%n .or. .not. c_associated(me%handle)) call check(4_c_int)
+      if (me%sharded) then
+         call acheck(me, m, n, nout, eps, v, w, x, y, inform)
+         return
+      end if
+      if (nout /= 0) write (nout, '(//A)') 'Enter acheck. Test of aprod for LSQR and CRAIG'
+      if (me%io32) then
+         call check(lsqrhip_acheck_f32(me%handle, real(eps, c_double), inf, err))
+      else
+         call check(lsqrhip_acheck(me%handle, real(eps, c_double), inf, err))
+      end if
+      call acheck_verdict(nout, eps, real(err, wp), inform)
+   end subroutine acheck_ez
 
    !> Which of Ax=b, min|Ax-b|, damped least squares does x solve?  (replaces src/lsqr.f90:1015-1154)
    subroutine xcheck(me, m, n, nout, anorm, damp, eps, b, u, v, w, x, inform, test1, test2, test3)
@@ -735,12 +807,8 @@ contains
       real(wp), intent(in) :: b(m)
       real(wp), intent(out) :: u(m), v(n), w(n)
       real(wp), intent(in) :: x(n)
-      real(wp), parameter :: power = 0.5_wp
-      real(wp) :: bnorm, xnorm, rho1, rho2, sigma1, sigma2, tol, dampsq
       real(wp), dimension(n) :: xwork
 
-      dampsq = damp**2
-      tol = eps**power
       xwork = x
       u = -b                                  ! r = b - A x, formed as -(-b + A x)
       call me%aprod(1, m, n, xwork, u)
@@ -748,8 +816,23 @@ contains
       v = zero
       call me%aprod(2, m, n, v, u)            ! v = A'r
       w = v
-      if (damp /= zero) w = w - dampsq*x      ! w = A'r - damp^2 x
+      if (damp /= zero) w = w - damp**2*x     ! w = A'r - damp^2 x
+      call xcheck_report(m, n, nout, anorm, damp, eps, b, u, v, w, x, inform, test1, test2, test3)
+   end subroutine xcheck
 
+   !> the norms, the three tests and the report of `xcheck` (src/lsqr.f90:1098-1154) from r = b - A x, A'r and
+   !! A'r - damp^2 x -- shared by the host form (which gets them through `aprod`) and the device form
+   subroutine xcheck_report(m, n, nout, anorm, damp, eps, b, u, v, w, x, inform, test1, test2, test3)
+      integer, intent(in) :: m, n, nout
+      integer, intent(out) :: inform
+      real(wp), intent(in) :: anorm, damp, eps
+      real(wp), intent(out) :: test1, test2, test3
+      real(wp), intent(in) :: b(m), u(m), v(n), w(n), x(n)
+      real(wp), parameter :: power = 0.5_wp
+      real(wp) :: bnorm, xnorm, rho1, rho2, sigma1, sigma2, tol, dampsq
+
+      dampsq = damp**2
+      tol = eps**power
       bnorm = dnrm2(m, b, 1)
       xnorm = dnrm2(n, x, 1)
       rho1 = dnrm2(m, u, 1)
@@ -796,6 +879,99 @@ contains
          write (nout, '(1P,A,E10.3,A)') ' test2           =', test2, ' (least-squares)'
          write (nout, '(1P,A,E10.3,A)') ' test3           =', test3, ' (damped least-squares)'
       end if
-   end subroutine xcheck
+   end subroutine xcheck_report
+
+   !> `xcheck` of an `lsqr_solver_ez`: r = b - A x, A'r and A'r - damp^2 x by the device operator in ONE call
+   !! (lsqrhip_xcheck: b and x go up once, u, v, w come back once -- the inherited form ships both vectors up and down
+   !! for each of its two products); the norms and the report are the host form's, from the returned vectors.
+   subroutine xcheck_ez(me, m, n, nout, anorm, damp, eps, b, u, v, w, x, inform, test1, test2, test3)
+      class(lsqr_solver_ez), intent(inout) :: me
+      integer, intent(in) :: m, n, nout
+      integer, intent(out) :: inform
+      real(wp), intent(in) :: anorm, damp, eps
+      real(wp), intent(out) :: test1, test2, test3
+      real(wp), intent(in) :: b(m)
+      real(wp), intent(out) :: u(m), v(n), w(n)
+      real(wp), intent(in) :: x(n)
+      integer(c_int) :: inf
+      real(c_double) :: tests(3)
+      real(c_double), allocatable :: bl(:), xl(:), ul(:), vl(:), wl(:)
+      real(c_float), allocatable :: bf(:), xf(:), uf(:), vf(:), wf(:)
+      if (m /= me%m .or. n /= me%n .or. .not. c_associated(me%handle)) call check(4_c_int)
+      if (me%sharded) then
+         call xcheck(me, m, n, nout, anorm, damp, eps, b, u, v, w, x, inform, test1, test2, test3)
+         return
+      end if
+      if (me%io32) then
+         allocate (bf(max(m, 1)), xf(max(n, 1)), uf(max(m, 1)), vf(max(n, 1)), wf(max(n, 1)))
+         bf(1:m) = real(b, c_float)
+         xf(1:n) = real(x, c_float)
+         call check(lsqrhip_xcheck_f32(me%handle, real(anorm, c_double), real(damp, c_double), real(eps, c_double), &
+                                       bf, xf, uf, vf, wf, inf, tests))
+         u = real(uf(1:m), wp)
+         v = real(vf(1:n), wp)
+         w = real(wf(1:n), wp)
+      else
+         allocate (bl(max(m, 1)), xl(max(n, 1)), ul(max(m, 1)), vl(max(n, 1)), wl(max(n, 1)))
+         bl(1:m) = b
+         xl(1:n) = x
+         call check(lsqrhip_xcheck(me%handle, real(anorm, c_double), real(damp, c_double), real(eps, c_double), &
+                                   bl, xl, ul, vl, wl, inf, tests))
+         u = real(ul(1:m), wp)
+         v = real(vl(1:n), wp)
+         w = real(wl(1:n), wp)
+      end if
+      call xcheck_report(m, n, nout, anorm, damp, eps, b, u, v, w, x, inform, test1, test2, test3)
+   end subroutine xcheck_ez
+
+   !> `lsqr` of an `lsqr_solver_ez` (src/lsqr.f90:432-882 called on the EZ type): the device solve with the CALL's
+   !! tolerances, limits and log unit (not the object's), b = u on entry.  The inherited host loop would ship both
+   !! vectors over PCIe twice per iteration through `aprod_ez`.  u, v, w are the reference's work arrays: left as they
+   !! are (the reference leaves its last bidiagonalisation vectors there, which nothing can use).
+   subroutine lsqr_ez(me, m, n, damp, wantse, u, v, w, x, se, atol, btol, conlim, itnlim, nout, &
+                      istop, itn, anorm, acond, rnorm, arnorm, xnorm)
+      class(lsqr_solver_ez), intent(inout) :: me
+      integer, intent(in) :: m, n
+      real(wp), intent(in) :: damp
+      logical, intent(in) :: wantse
+      real(wp), intent(inout) :: u(m), v(n), w(n)
+      real(wp), intent(out) :: x(n)
+      real(wp), dimension(*), intent(out) :: se
+      real(wp), intent(in) :: atol, btol, conlim
+      integer, intent(in) :: itnlim, nout
+      integer, intent(out) :: istop, itn
+      real(wp), intent(out) :: anorm, acond, rnorm, arnorm, xnorm
+      real(c_double), allocatable :: xl(:), sel(:), bl(:)
+      real(c_float), allocatable :: xf(:), sef(:), bf(:)
+      integer(c_int) :: istop_, itn_, ws, wl
+      real(c_double) :: sc(5)
+      if (m /= me%m .or. n /= me%n .or. .not. c_associated(me%handle)) call check(4_c_int)
+      ws = merge(1_c_int, 0_c_int, wantse)
+      wl = merge(1_c_int, 0_c_int, nout /= 0)
+      if (me%io32) then
+         allocate (xf(max(n, 1)), sef(max(n, 1)), bf(max(m, 1)))
+         bf(1:m) = real(u, c_float)
+         call check(lsqrhip_solve_f32(me%handle, bf, real(damp, c_double), real(atol, c_double), real(btol, c_double), &
+                                      real(conlim, c_double), int(itnlim, c_int), ws, wl, xf, sef, istop_, itn_, &
+                                      sc(1), sc(2), sc(3), sc(4), sc(5)))
+         x = real(xf(1:n), wp)
+         if (wantse) se(1:n) = real(sef(1:n), wp)
+      else
+         allocate (xl(max(n, 1)), sel(max(n, 1)), bl(max(m, 1)))
+         bl(1:m) = u
+         call check(lsqrhip_solve(me%handle, bl, real(damp, c_double), real(atol, c_double), real(btol, c_double), &
+                                  real(conlim, c_double), int(itnlim, c_int), ws, wl, xl, sel, istop_, itn_, &
+                                  sc(1), sc(2), sc(3), sc(4), sc(5)))
+         x = real(xl(1:n), wp)
+         if (wantse) se(1:n) = real(sel(1:n), wp)
+      end if
+      istop = istop_
+      itn = itn_
+      anorm = real(sc(1), wp); acond = real(sc(2), wp); rnorm = real(sc(3), wp)
+      arnorm = real(sc(4), wp); xnorm = real(sc(5), wp)
+      if (nout /= 0) call lsqr_print_device_log(me%handle, nout, m, n, damp, wantse, atol, btol, conlim, itnlim, &
+                                                istop, itn, anorm, acond, rnorm, arnorm, xnorm)
+      if (.false.) v(1) = w(1)
+   end subroutine lsqr_ez
 
 end module lsqr_module

@@ -373,6 +373,101 @@ __global__ __launch_bounds__(BLOCK, 1) void k_sweep_xwin(const double *__restric
     if (t == 0x123456789ull) out[1] = 1.0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// (d) phased: the CU's vector L1 returns data in request order across ALL waves of the CU (csb_ceiling by grid,
+// profiles/r05: with half or a quarter of the CUs the mixed sweep takes MORE than the stream's and the gathers' times
+// together, while each alone scales) -- a gather line that hits L2 in ~250 cycles queued behind another wave's
+// stream line from HBM (~900) holds its slot until that one is back.  So: never have both kinds in the L1's queue.
+// All 16 waves move in lock step, K chunks per wave and step:
+//     barrier | gathers of the K chunks, wait | barrier | stream of the next K chunks, products + LDS adds, wait |
+// ---------------------------------------------------------------------------------------------------------------
+// `stagger`: every other workgroup of an XCD (workgroup i runs on XCD i % 8) starts `stagger` x 2048 cycles late, so that
+// half of the chip gathers (L2) while the other half streams (HBM) -- all CUs in the same phase would use the two in turn.
+// V2: the second barrier comes behind the ISSUE of the gathers, not their return -- stream requests queued behind gathers
+// hold nobody up (data returns in request order), so the next stream may be requested at once and the L1 never runs dry
+// between the two phases; a wave waits for its gathers with the stream already in flight behind them.
+template <int K, bool V2 = false>
+__global__ __launch_bounds__(BLOCK, 1) void k_sweep_phased(const double *__restrict__ val, const unsigned *__restrict__ idx,
+                                                           const int *__restrict__ cbase, const double *__restrict__ x,
+                                                           int64_t cpb, int b0, int nunits, int S, double ginv, int stagger,
+                                                           double *__restrict__ out)
+{
+    {   // stagger = groups << 8 | delay: group g = (workgroup / 8) % groups waits g * delay * 2048 cycles
+        const int groups = (stagger >> 8) > 0 ? (stagger >> 8) : 2, delay = stagger & 255;
+        const int g = (int)(blockIdx.x >> 3) % groups;
+        for (int i = 0; i < g * delay; ++i) __builtin_amdgcn_s_sleep(32);
+    }
+    __shared__ unsigned long long acc[NACC];
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1);
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int i = tid; i < NACC; i += BLOCK) acc[i] = 0ull;
+    __syncthreads();
+    for (int u = blockIdx.x; u < nunits; u += gridDim.x) {
+        const int b = b0 + u / S, sp = u % S;
+        const int64_t cb0 = (int64_t)b * cpb;
+        const int64_t c0 = cb0 + (cpb * sp) / S, c1 = cb0 + (cpb * (sp + 1)) / S;
+        const int64_t clast = c1 > c0 ? c1 - 1 : c0;
+        const int nsteps = (int)((c1 - c0 + K * WAVES - 1) / (K * WAVES));   // the same for every wave: barriers inside
+        struct Set {
+            double a[K][U];
+            unsigned ix[K][U];
+            int base[K];
+        };
+        Set s0, s1;   // two register sets, used alternately: the next chunks' stream lands in the one not being added
+        auto issue = [&](int64_t cfirst, Set &t) {
+#pragma unroll
+            for (int q = 0; q < K; ++q) {
+                const int64_t c = cfirst + q * WAVES;
+                const int64_t cc = c < clast ? c : clast;
+                t.base[q] = cbase[cc];
+                const int64_t k = cc * CHUNK + lane;
+#pragma unroll
+                for (int j = 0; j < U; ++j) {
+                    t.a[q][j] = __builtin_nontemporal_load(&val[k + j * WAVE]);
+                    t.ix[q][j] = __builtin_nontemporal_load(&idx[k + j * WAVE]);
+                }
+            }
+        };
+        auto step = [&](int64_t cfirst, Set &cur, Set &nxt) {
+            double xv[K][U];
+            __builtin_amdgcn_s_barrier();   // every wave's stream has landed: the L1's queue is empty
+#pragma unroll
+            for (int q = 0; q < K; ++q)
+#pragma unroll
+                for (int j = 0; j < U; ++j) xv[q][j] = x[cur.base[q] + (int)(cur.ix[q][j] & LMASK)];
+            if (!V2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();   // every wave's gathers are back (V2: are requested)
+            __builtin_amdgcn_sched_barrier(0);
+            issue(cfirst + K * WAVES, nxt);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < K; ++q) {
+                const bool live = cfirst + q * WAVES < c1;
+#pragma unroll
+                for (int j = 0; j < U; ++j) {
+                    const double p = live ? cur.a[q][j] * xv[q][j] : 0.0;
+                    atomicAdd(&acc[cur.ix[q][j] >> LBITS], (unsigned long long)__double2ll_rn(p * ginv));
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        };
+        issue(c0 + w, s0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        for (int st = 0; st < nsteps; st += 2) {
+            const int64_t cfirst = c0 + (int64_t)st * K * WAVES + w;
+            step(cfirst, s0, s1);
+            if (st + 1 < nsteps) step(cfirst + K * WAVES, s1, s0);   // (uniform)
+            else {   // (an odd count: the sweep of this unit is over; s0 is reloaded by the next unit)
+            }
+        }
+    }
+    __syncthreads();
+    unsigned long long t = 0;
+    for (int i = tid; i < NACC; i += BLOCK) t += acc[i];
+    if (t == 0x123456789ull) out[1] = 1.0;
+}
+
 struct Cfg {
     const char *name;
     int n;          // columns of x
@@ -410,6 +505,8 @@ static void release(Mat &m)
     CK(hipFree(m.cbase));
 }
 
+static int g_grid = 256;   // workgroups per launch (CSB_GRID: fewer CUs)
+
 template <typename L>
 static double time_product(const Cfg &c, L launch, int reps)
 {
@@ -420,7 +517,7 @@ static double time_product(const Cfg &c, L launch, int reps)
     auto product = [&]() {
         for (int b0 = 0; b0 < c.nblocks; b0 += per_launch) {
             const int nb = std::min(per_launch, c.nblocks - b0);
-            launch(b0, nb * c.S, std::min(256, nb * c.S));
+            launch(b0, nb * c.S, std::min(g_grid, nb * c.S));
         }
     };
     product();
@@ -448,17 +545,18 @@ static double run_spf(const Cfg &c, const Mat &m, const double *x, double *out, 
 
 // the blocking the library would choose for `rows` rows of at most Rcap each: whole rounds of 256 blocks without splits
 // (S = 1), whole sets of 256 / S blocks with S splits (many rows), or -- fewer rows than 256 full blocks -- the fewest
-// splits S for which 256 / S blocks of <= Rcap rows cover the matrix
+// splits' worth of CUs per block: the MOST splits S <= 8 for which 256 / S blocks of <= Rcap rows cover the matrix
 static Cfg blocking(const char *name, int n, double d, int64_t rows, int S, int Rcap)
 {
     int nb = (int)((rows + Rcap - 1) / Rcap);
     if (S == 1) nb = ((nb + 255) / 256) * 256;
     else if (nb >= 256) nb = ((nb + 256 / S - 1) / (256 / S)) * (256 / S);
     else {
-        for (S = 1; S <= 8; ++S) {
+        for (S = 8; S > 1; --S) {   // the tallest blocks that fit: the most splits
             nb = 256 / S;
             if ((rows + nb - 1) / nb <= Rcap) break;
         }
+        nb = 256 / S;
     }
     return Cfg{name, n, (int)((rows + nb - 1) / nb), d, nb, S};
 }
@@ -476,9 +574,9 @@ static double run_ring(const Cfg &c, const Mat &m, const double *x, double *out,
     }, reps);
 }
 template <int WCOLS>
-static double run_xwin(const Cfg &c, const Mat &m, const double *x, double *out, int reps)
+static double run_xwin(const Cfg &c, const Mat &m, const double *x, double *out, int reps, int nacc_forced = 0)
 {
-    const int nacc = c.R + 64;
+    const int nacc = nacc_forced > 0 ? nacc_forced : c.R + 64;
     const size_t lds = (size_t)nacc * 8 + (size_t)WAVES * WCOLS * 8;
     if (lds > 160 * 1024) return -1.0;
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sweep_xwin<WCOLS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -488,10 +586,20 @@ static double run_xwin(const Cfg &c, const Mat &m, const double *x, double *out,
     }, reps);
 }
 
+template <int K, bool V2 = false>
+static double run_phased(const Cfg &c, const Mat &m, const double *x, double *out, int reps, int stagger = 0)
+{
+    return time_product(c, [&](int b0, int nunits, int grid) {
+        hipLaunchKernelGGL((k_sweep_phased<K, V2>), dim3(grid), dim3(BLOCK), 0, 0, m.val, m.idx, m.cbase, x, m.cpb, b0, nunits, c.S,
+                           0x1p40, stagger, out);
+    }, reps);
+}
+
 int main(int argc, char **argv)
 {
     const int reps = argc > 1 ? std::atoi(argv[1]) : 5;
     const char *which = argc > 2 ? argv[2] : "a";
+    if (const char *e = std::getenv("CSB_GRID")) g_grid = std::max(1, std::min(256, std::atoi(e)));
     double *x, *out;
     CK(hipMalloc(&x, sizeof(double) * 11000000));
     CK(hipMemset(x, 0, sizeof(double) * 11000000));
@@ -519,6 +627,29 @@ int main(int argc, char **argv)
                 const double t7 = run_spf<0, 0, 1>(c, m, x, out, reps);
                 std::printf("%-72s %8.3f %8.3f %8.3f %8.3f %8.3f %8.3f %8.3f %8.3f   (%.0f GB/s base)\n", c.name, t0, t1, t2, t3,
                             t4, t5, t6, t7, m.bytes / t0 / 1e6);
+                std::fflush(stdout);
+            }
+            release(m);
+        }
+    }
+    if (std::strchr(which, 'd')) {
+        std::printf("(d) stream and gathers never in the L1's queue together (lock-step phases); ms per product, grid = %d\n", g_grid);
+        std::printf("%-72s %8s %8s %8s %8s %8s | %8s %8s %8s %8s %8s\n", "configuration", "base", "v2K1 s4", "v2K2 s4", "v2K3 s4", "base",
+                    "v2K2 s0", "v2K2 s2", "v2K2 s6", "v2K2 4g2", "v2K1 4g1");
+        for (const Cfg &c : cfgs) {
+            Mat m = build(c);
+            for (int round = 0; round < 2; ++round) {
+                const double t0 = run_spf<0, 0, 1>(c, m, x, out, reps);
+                const double t1 = run_phased<1, true>(c, m, x, out, reps, 4);
+                const double t2 = run_phased<2, true>(c, m, x, out, reps, 4);
+                const double t3 = run_phased<3, true>(c, m, x, out, reps, 4);
+                const double t4 = run_spf<0, 0, 1>(c, m, x, out, reps);
+                const double u1 = run_phased<2, true>(c, m, x, out, reps, 0), u2 = run_phased<2, true>(c, m, x, out, reps, 2);
+                const double u3 = run_phased<2, true>(c, m, x, out, reps, 6), u4 = run_phased<2, true>(c, m, x, out, reps, (4 << 8) | 2);
+                const double u5 = run_phased<1, true>(c, m, x, out, reps, (4 << 8) | 1);
+                const double best = std::min(std::min(std::min(t1, t2), std::min(u1, u2)), std::min(std::min(u3, u4), u5));
+                std::printf("%-72s %8.3f %8.3f %8.3f %8.3f %8.3f | %8.3f %8.3f %8.3f %8.3f %8.3f   (%.0f -> %.0f GB/s)\n", c.name, t0, t1,
+                            t2, t3, t4, u1, u2, u3, u4, u5, m.bytes / t0 / 1e6, m.bytes / best / 1e6);
                 std::fflush(stdout);
             }
             release(m);
@@ -558,7 +689,7 @@ int main(int argc, char **argv)
     }
     if (std::strchr(which, 'c')) {
         std::printf("(c) a wave's span of x staged in LDS (dense rows); ms per product\n");
-        std::printf("%-64s %8s %8s %8s %8s\n", "configuration", "base R", "base R'", "xwin R'", "base R");
+        std::printf("%-64s %8s %8s %8s %8s %8s\n", "configuration", "base R", "base R'", "xwin R'", "base R", "R'/160KB");
         struct DC { const char *name; int n; double d; int64_t rows; int S; int wcols; };
         const DC dcs[] = {{"config 3 literal: 4M x 1M x 1000, S = 1 (window 128 columns)", 1000000, 1000.0, 4000000, 1, 128},
                           {"rank block at 1000 per row: 1.25M x 10M x 1000, S = 4 (256)", 10000000, 1000.0, 1250000, 4, 256}};
@@ -571,7 +702,8 @@ int main(int argc, char **argv)
                 const double t1 = run_xwin<0>(cut, mc, x, out, reps);
                 const double t2 = dc.wcols == 128 ? run_xwin<128>(cut, mc, x, out, reps) : run_xwin<256>(cut, mc, x, out, reps);
                 const double t3 = run_spf<0, 0, 1>(full, mf, x, out, reps);
-                std::printf("%-64s %8.3f %8.3f %8.3f %8.3f   R %d / %d blocks %d / %d S %d / %d (%.0f GB/s base)\n", dc.name, t0, t1, t2, t3,
+                const double t4 = run_xwin<0>(cut, mc, x, out, reps, NACC);   // the R' form with all 160 KB of LDS allocated
+                std::printf("%-64s %8.3f %8.3f %8.3f %8.3f %8.3f   R %d / %d blocks %d / %d S %d / %d (%.0f GB/s base)\n", dc.name, t0, t1, t2, t3, t4,
                             full.R, cut.R, full.nblocks, cut.nblocks, full.S, cut.S, mf.bytes / t0 / 1e6);
                 std::fflush(stdout);
             }

@@ -170,6 +170,10 @@ struct Cfg {
     double measured_ms;   // the product of the library on this configuration (mode 1, profiles/r03, r04), for the table
 };
 
+// workgroups per launch (one per CU): 256, or fewer (CSB_GRID=128 / 64: round 5 -- is the ceiling a CU's or the chip's?
+// With half the CUs a bound inside the CU doubles the time, a bound in L2 / fabric / HBM does not)
+static int g_grid = 256;
+
 template <int MODE>
 static double run(const Cfg &c, const double *val, const unsigned *idx, const int *cbase, const double *x, int64_t cpb,
                   double *out, int reps)
@@ -182,7 +186,7 @@ static double run(const Cfg &c, const double *val, const unsigned *idx, const in
     auto product = [&]() {
         for (int b0 = 0; b0 < c.nblocks; b0 += per_launch) {
             const int nb = std::min(per_launch, c.nblocks - b0);
-            hipLaunchKernelGGL(k_sweep<MODE>, dim3(std::min(256, nb * c.S)), dim3(BLOCK), 0, 0, val, idx, cbase, x, cpb, b0,
+            hipLaunchKernelGGL(k_sweep<MODE>, dim3(std::min(g_grid, nb * c.S)), dim3(BLOCK), 0, 0, val, idx, cbase, x, cpb, b0,
                                nb * c.S, c.S, 0x1p40, gapi, out);
         }
     };
@@ -203,6 +207,8 @@ static double run(const Cfg &c, const double *val, const unsigned *idx, const in
 int main(int argc, char **argv)
 {
     const int reps = argc > 1 ? std::atoi(argv[1]) : 5;
+    if (const char *e = std::getenv("CSB_GRID")) g_grid = std::max(1, std::min(256, std::atoi(e)));
+    std::printf("workgroups per launch: %d\n", g_grid);
     const Cfg cfgs[] = {
         {"config 4: 10M x 10M x 100, 512 blocks, S = 4 (8 launches)", 10000000, 19532, 100.0, 512, 4, 3.45},
         {"config 4, S = 1 (2 launches)", 10000000, 19532, 100.0, 512, 1, 3.7},
