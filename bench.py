@@ -24,6 +24,7 @@ The ONE JSON line (rank 0) carries, for the dominant kernel (aprod mode 1):
                     and structure patterns.
   strong_scaling_n1 configs[3] (10M x 10M, 1e9 nonzeros) whole on this GPU, with its own roofline:
                     N = 1 of the series the --gpus N lines continue.
+  roofline_configs  the same object for configs[2] at its literal 1000 per row, configs[4] and the r = 1000 rank block.
   cpu_baseline      the reference's own CPU path (oracle/_ref), 1 core, bounded sample.
 `--workload SPEC --extras off` measures one workload alone (what profiles/r02/*.txt were made with).
 """
@@ -57,11 +58,17 @@ HBM_INSTANCES = [("poisson2d:4000:4000", {}, "row patterns (what the build choos
 PRODUCT_KERNELS = ("k_spmv_", "k_panel_combine", "k_csb_combine", "k_csb_xmax")
 # the N = 1 line measures configs[1]; the series the --gpus N lines continue is strong_scaling_n1 (configs[3])
 SCALING_N1 = "n/a (configs[1]; the strong-scaling series is strong_scaling_n1)"
-# What the memory system delivers for the ACCESS PATTERN of the column-swept product -- the real layout and sweep without
-# arithmetic, LDS sums and epilogue (scripts/csb_ceiling.hip "both"; profiles/r04/csb_ceiling.txt), GB/s of layout bytes.
-# Keyed by (columns of x, nonzeros per column and row block rounded to 0.01): the two things the pattern depends on.
-CSB_CEILING_GBS = {"random:10000000:10000000:100": 3945.0, "random:1250000:10000000:100": 3828.0,
-                   "powerlaw:5000000:2000000:10000": 3772.0, "random:4000000:1000000:100": 5751.0}
+# (Round 4 pasted builder-measured "ceilings of the access pattern" -- scripts/csb_ceiling.hip -- into this line as
+# constants.  Round 5's lock-step sweep runs PAST them: they were ceilings of one schedule, not of the memory system, and
+# are gone from the line.  What is left is measured by the run itself.)
+# The other BASELINE configurations one GPU holds, each with the roofline object of its mode-1 product measured by THIS
+# run (`roofline_configs`): configs[2] at its literal 1000 per row, configs[4], and the block one rank of eight holds of
+# configs[3] at SURVEY 8d's r = 1000.  (spec, solve iterations, note)
+ROOFLINE_CONFIGS = [
+    ("random:4000000:1000000:1000", 6, "BASELINE.json configs[2] at its literal size: 4M x 1M, 1000 per row (4e9 nonzeros, 96 GB of layouts)"),
+    ("powerlaw:5000000:2000000:10000", 40, "BASELINE.json configs[4]: power-law rows up to 10^4, 5M x 2M"),
+    ("random:1250000:10000000:1000", 10, "one rank's block (N = 8) of configs[3] at SURVEY 8d's r = 1000: 1.25M x 10M, 1.25e9 nonzeros"),
+]
 GENERAL_INSTANCE = 2      # HBM_INSTANCES[2]: sliced ELL with 8-byte values -- the best HBM-resident GENERAL short-row kernel
 
 
@@ -76,6 +83,8 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--extras", choices=["on", "off"], default="on",
                     help="off: only the one workload (no HBM-resident instances, no configs[3] point)")
+    ap.add_argument("--configs", choices=["on", "off"], default="on",
+                    help="off: skip roofline_configs (configs[2] literal, configs[4], the r = 1000 rank block: ~1 min of builds)")
     ap.add_argument("--no-scaling-ref", action="store_true",
                     help="skip the N = 1 point of the multi-GPU series (configs[3] whole on this GPU)")
     ap.add_argument("--traffic", choices=["live", "off"], default="live",
@@ -228,14 +237,8 @@ def product_roofline(s, facts, reps, traffic=None):
     # peak.  Above 1 the layout moves fewer bytes than that count and the product is not an HBM stream of it.
     roof["frac_survey8d"] = alg1 / (avg1 * 1e-3) / 1e9 / HBM_PEAK_GBS
     roof["bound_survey8d"] = "cache" if roof["frac_survey8d"] > 1.0 else "hbm"
-    ceil_gbs = CSB_CEILING_GBS.get(facts.get("spec", ""))
-    if info["xlds"] == 3 and ceil_gbs:
-        roof["ceiling_gbps"] = ceil_gbs
-        roof["ceiling_frac"] = ceil_gbs / HBM_PEAK_GBS
-        roof["of_ceiling"] = ach / ceil_gbs
-        roof["ceiling_is"] = ("what the memory system delivers for this product's access pattern -- the real chunk layout and "
-                              "sweep (12-byte stream from HBM + sorted gathers of x through L2) with the arithmetic, the LDS "
-                              "sums and the epilogue taken away: scripts/csb_ceiling.hip, profiles/r04/csb_ceiling.txt")
+    if info["xlds"] == 3:
+        roof["csb_lockstep"] = s.get_option("csb_lockstep_mode1")   # chunks per wave and lock-step step (0: free-running sweep)
     if traffic:
         roof["traffic"] = traffic.get("bytes_per_launch")
         roof["traffic_detail"] = traffic
@@ -294,7 +297,9 @@ def side_workload(spec, env, note, K, traffic):
     the product's roofline.  Never fails the headline measurement."""
     from lsqr_amd import capi
     try:
+        t_build = time.perf_counter()
         s, d_b, facts, _ = build_workload(spec, env, itnlim=K)
+        t_build = time.perf_counter() - t_build
         d_x = capi.DeviceBuffer(8 * max(facts["n"], 1))
         s.atol = s.btol = s.conlim = 0.0
         s.set_option("graph_iters", min(K + (K & 1), 50))
@@ -305,7 +310,7 @@ def side_workload(spec, env, note, K, traffic):
         roof, kernels, (alg1, alg2, lay1, lay2) = product_roofline(s, facts, reps, traffic)
         out = {"workload": f"{spec} m={facts['m']} n={facts['n']} nnz={facts['nnz']} damp={facts['damp']}",
                "variant": note, "env": env or {}, "n_gpus": 1, "steps": K, "value": K / dt, "unit": "it/s",
-               "ms_per_step": 1e3 * dt / K, "restarts": restarts,
+               "ms_per_step": 1e3 * dt / K, "restarts": restarts, "generate_and_build_s": t_build,
                "iter_bytes_layout": lay1 + lay2 + 40 * facts["n"],
                "iter_gbps_layout": (lay1 + lay2 + 40 * facts["n"]) * K / dt / 1e9,
                "roofline": roof, "kernels": kernels}
@@ -476,6 +481,10 @@ def run_single(args):
         n1 = side_workload(DEFAULT_SPEC, {}, "BASELINE.json configs[3], whole on one GPU", 40, tr(DEFAULT_SPEC, {}))
         n1["note"] = "the --gpus N > 1 lines shard this matrix by row blocks: compare their value with this one"
         out["strong_scaling_n1"] = n1
+    if extras and not args.no_roofline and args.configs == "on":
+        # every other BASELINE configuration a single GPU holds, measured by this run (no PMC pass: each would build
+        # the matrix twice more; `traffic` of the column-swept kernel is on strong_scaling_n1)
+        out["roofline_configs"] = [side_workload(sp, {}, note, k, None) for sp, k, note in ROOFLINE_CONFIGS]
     if args.cpu_iters > 0 and host is not None:
         out["cpu_baseline"] = cpu_baseline(host, args.cpu_iters)
     elif args.cpu_iters > 0:

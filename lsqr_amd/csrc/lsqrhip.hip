@@ -214,9 +214,15 @@ struct ShardCtx {
     int want_log = 0;             // option "shard_log": this rank keeps the iteration log of the next sharded solves
                                   // (rank 0's business: the scalars are replicated and x(1) lies on its slice)
     bool active = false;
+    bool engine_next = false;     // set by shard_engine.h right before ITS lsqrhip_shard_begin: the engine-only fields above
+                                  // (gath, msg, own_in_T, vmax_msg) are meant.  Any other caller of lsqrhip_shard_begin --
+                                  // the Python stage driver, also as the fall-back after an engine solve that FAILED half
+                                  // way and never reached lsqrhip_shard_end -- finds them cleared there (round-4 advisor).
 };
 
 struct ShardGroup;  // shard_engine.h: the ranks of a sharded solve driven from this process (RCCL)
+struct lsqrhip_handle_s;
+static int64_t shard_effective(const lsqrhip_handle_s *h, bool parts);   // shard_engine.h
 
 struct lsqrhip_handle_s {
     std::atomic<int> refs{1};  // lsqrhip_retain / lsqrhip_destroy
@@ -2216,6 +2222,17 @@ extern "C" int lsqrhip_get_option(lsqrhip_handle_t h, const char *name, int64_t 
     } else if (k == "csb_splits_mode1" || k == "csb_splits_mode2") {
         const Csr &c = k == "csb_splits_mode1" ? h->A : h->AT;
         *value = c.csb ? c.S : 0;
+    } else if (k == "csb_lockstep_mode1" || k == "csb_lockstep_mode2") {   // chunks per wave and lock-step step (0: free-running)
+        const Csr &c = k == "csb_lockstep_mode1" ? h->A : h->AT;
+        *value = c.csb ? c.clockstep : 0;
+    } else if (k == "shard_engine_flags") {
+        // what the C++ engine left in this rank's stage context (0 between solves -- also after an engine solve that failed):
+        // 1 own slice read in T | 2 `sums` is the long message | 4 norms gathered by the engine | 8 a sharded solve is open
+        const ShardCtx &c = h->shard;
+        *value = (c.own_in_T ? 1 : 0) | (c.vmax_msg ? 2 : 0) | (c.gath != nullptr ? 4 : 0) | (c.active ? 8 : 0);
+    } else if (k == "shard_overlap" || k == "shard_parts") {
+        // the schedule the engine of this handle REALLY runs (a requested overlap that could not be set up is off here)
+        *value = shard_effective(h, k == "shard_parts");
     } else return fail(LSQRHIP_ERR_ARG, "unknown option: " + k);
     return LSQRHIP_OK;
 }

@@ -262,6 +262,13 @@ extern "C" int lsqrhip_shard_begin(lsqrhip_handle_t h, const double *d_b_local, 
     HIPCHK(hipSetDevice(h->device));
     hipStream_t s = h->stream;
     ShardCtx &c = h->shard;
+    if (!c.engine_next) {   // not the engine's call: whatever an engine solve left behind (it may have failed before its
+        c.own_in_T = false;   // lsqrhip_shard_end) must not steer this caller's stages -- they reduce `sums` themselves,
+        c.gath = nullptr;     // copy their own slice of T to R and bring a 4-double `sums`
+        c.vmax_msg = false;
+        c.msg = 4;
+    }
+    c.engine_next = false;
     c.P = world;
     c.rank = rank;
     c.chunk = ((int64_t)h->n + world - 1) / world;
@@ -543,5 +550,6 @@ extern "C" int lsqrhip_shard_end(lsqrhip_handle_t h, double *d_x, double *d_se, 
     c.own_in_T = false;
     c.gath = nullptr;
     c.vmax_msg = false;   // (the next caller of lsqrhip_shard_begin may bring a 4-double `sums`: lsqr_amd/dist.py)
+    c.msg = 4;
     return LSQRHIP_OK;
 }

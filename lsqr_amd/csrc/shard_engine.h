@@ -164,6 +164,13 @@ struct ShardGroup {
 };
 
 static H *lsqrhip_group_rank0(H *h) { return h->group->r[0].h; }
+// option "shard_overlap" / "shard_parts": what the group this handle belongs to runs (0 / 1: no group)
+static int64_t shard_effective(const H *h, bool parts)
+{
+    const ShardGroup *g = h->group ? h->group : h->mp;
+    if (g == nullptr) return parts ? 1 : 0;
+    return parts ? (g->overlap ? g->parts : 1) : g->overlap;
+}
 static H *log_owner(H *h) { return h->group && !h->group->r.empty() && h->group->r[0].h ? h->group->r[0].h : h; }
 
 static void free_group(ShardGroup *g)
@@ -683,7 +690,7 @@ static int capture_group_batch(ShardGroup &g)
 }
 
 // The loop.  b: every local rank's block is in q.bloc.  Outputs: x (and se) replicated in q.xfull / q.sefull.
-static int run_group(ShardGroup &g, double damp, double atol, double btol, double conlim, int itnlim, int wantse,
+static int run_group_body(ShardGroup &g, double damp, double atol, double btol, double conlim, int itnlim, int wantse,
                      int *istop, int *itn, double *anorm, double *acond, double *rnorm, double *arnorm, double *xnorm)
 {
     if (g.P > 1 && !g.loopback && !rccl()) return fail(LSQRHIP_ERR_HIP, "librccl.so.1 could not be loaded");
@@ -707,6 +714,7 @@ static int run_group(ShardGroup &g, double damp, double atol, double btol, doubl
             q.h->shard.own_in_T = true;
             q.h->shard.gath = q.gath;
             q.h->shard.msg = g.msg;
+            q.h->shard.engine_next = true;   // (lsqrhip_shard_begin: these fields are meant)
         }
     }
     for (ShardRank &q : g.r)
@@ -745,7 +753,10 @@ static int run_group(ShardGroup &g, double damp, double atol, double btol, doubl
         }
     }
     int64_t launched = 0;
+    const int fail_at = env_int("LSQRHIP_SHARD_FAIL_AT", -1);   // test hook: an error exit after this many queued iterations
     while (!st3[0]) {
+        if (fail_at >= 0 && launched >= fail_at)
+            return fail(LSQRHIP_ERR_HIP, "LSQRHIP_SHARD_FAIL_AT: injected failure of the sharded engine (test hook)");
         if (launched > (int64_t)itnlim + g.poll_every)
             return fail(LSQRHIP_ERR_HIP, "sharded iteration loop did not terminate (device state not advancing)");
         if (graph) {
@@ -784,6 +795,35 @@ static int run_group(ShardGroup &g, double damp, double atol, double btol, doubl
         HIPCHK(hipStreamSynchronize(q.h->stream));
     }
     return LSQRHIP_OK;
+}
+
+// ... and whatever way it ends, the handles are left as a caller of the C stages expects them: an error exit above (an RCCL
+// call that failed, a poll error, the "did not terminate" guard, LSQRHIP_SHARD_FAIL_AT in the tests) never reached
+// lsqrhip_shard_end, and the engine-only fields of the ranks' handles would still say "the norms are gathered in gath, your
+// own slice stays in T, sums is a 64-double message" to the Python stage driver that lsqr_amd/dist_bench.py falls back to.
+static int run_group(ShardGroup &g, double damp, double atol, double btol, double conlim, int itnlim, int wantse,
+                     int *istop, int *itn, double *anorm, double *acond, double *rnorm, double *arnorm, double *xnorm)
+{
+    const int rc = run_group_body(g, damp, atol, btol, conlim, itnlim, wantse, istop, itn, anorm, acond, rnorm, arnorm, xnorm);
+    if (rc != LSQRHIP_OK) {
+        const std::string why = g_last_error;
+        for (ShardRank &q : g.r) {
+            if (q.h == nullptr) continue;
+            (void)hipSetDevice(q.h->device);
+            (void)hipStreamSynchronize(q.h->stream);   // (stages already queued read gath / T: let them finish first)
+            if (q.cstream) (void)hipStreamSynchronize(q.cstream);
+            ShardCtx &c = q.h->shard;
+            c.active = false;
+            c.own_in_T = false;
+            c.gath = nullptr;
+            c.vmax_msg = false;
+            c.msg = 4;
+            c.engine_next = false;
+        }
+        (void)hipGetLastError();
+        g_last_error = why;
+    }
+    return rc;
 }
 
 // Every rank of the world uses the largest norm_exp (scalar.h "range-safe norms").

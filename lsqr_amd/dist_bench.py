@@ -293,11 +293,6 @@ def run_distributed(args):
                          "bytes_per_launch": lay1, "avg_launch_us": avg1 * 1e3, "launches": reps,
                          "bytes_are": "the layout in use: matrix as stored + x once + y read and written (physical)",
                          "effective_gbps": b1 / (avg1 * 1e-3) / 1e9, "effective_bytes_per_launch": b1,
-                         **({"ceiling_gbps": 3828.0, "of_ceiling": ach / 3828.0,
-                             "ceiling_is": "the access pattern of this product without its arithmetic: scripts/csb_ceiling.hip, "
-                                           "profiles/r04/csb_ceiling.txt (one rank's block of configs[3] at N = 8)"}
-                            if info["xlds"] == 3 and spec == DEFAULT_SPEC and world == 8 or
-                            (info["xlds"] == 3 and spec == "random:1250000:10000000:100" and world == 1) else {}),
                          "frac_survey8d": b1 / (avg1 * 1e-3) / 1e9 / 8000.0,
                          "bound_survey8d": "cache" if b1 / (avg1 * 1e-3) / 1e9 > 8000.0 else "hbm"},
         }

@@ -82,8 +82,22 @@ def test_committed_single_gpu_lines():
                 check_survey8d(e["roofline"])
             n1 = d["strong_scaling_n1"]["roofline"]
             check_survey8d(n1)
-            # the column-swept product against the measured ceiling of its access pattern (scripts/csb_ceiling.hip)
-            assert n1["ceiling_gbps"] > 0 and abs(n1["of_ceiling"] - n1["achieved"] / n1["ceiling_gbps"]) < 1e-9
+            if round_of_lines() == 4:
+                # round 4 quoted a builder-measured "ceiling of the access pattern" as a constant; round 5's lock-step
+                # sweep runs past it and the keys are gone
+                assert n1["ceiling_gbps"] > 0 and abs(n1["of_ceiling"] - n1["achieved"] / n1["ceiling_gbps"]) < 1e-9
+            else:
+                assert "ceiling_gbps" not in n1 and n1["csb_lockstep"] in (0, 1, 2)
+                # every other BASELINE configuration one GPU holds, measured by the same run
+                rc = d["roofline_configs"]
+                assert [e["workload"].split()[0] for e in rc] == ["random:4000000:1000000:1000", "powerlaw:5000000:2000000:10000",
+                                                                  "random:1250000:10000000:1000"]
+                for e in rc:
+                    assert "error" not in e, e
+                    check_survey8d(e["roofline"])
+                    for k in dist_bench.ROOFLINE_KEYS:
+                        assert k in e["roofline"], k
+                    assert 0 < e["roofline"]["frac"] <= 1 and e["value"] > 0
             # the best HBM-resident GENERAL short-row kernel at top level, with the rocprofv3 summary that backs it
             g = d["roofline_general"]
             assert g["bound"] == "hbm" and 0 < g["frac"] <= 1 and "poisson2d:4000:4000" in g["workload"]

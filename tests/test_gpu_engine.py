@@ -631,3 +631,88 @@ def test_copy_mode_without_a_device_per_rank_fails_loudly():
             os.environ.pop(k, None)
             if v is not None:
                 os.environ[k] = v
+
+
+# ---- an engine solve that fails half way must not steer the next caller of the C stages (round-4 advisor) ----
+class _OneRankComm:
+    """lsqr_amd.dist.TorchComm's interface for a world of one, without a process group."""
+    world, rank, backend = 1, 0, "none"
+
+    def all_reduce_scalars(self, t):
+        return
+
+    def scatter_slices(self, T, R, chunk):
+        R[:chunk].copy_(T[:chunk])
+
+    def gather_slices(self, V, chunk):
+        return
+
+    def agree_max(self, value):
+        return int(value)
+
+    def barrier(self):
+        return
+
+
+def _flags(s):
+    v = C.c_int64()
+    check(lib().lsqrhip_get_option(s._h, b"shard_engine_flags", C.byref(v)))
+    return int(v.value)
+
+
+@pytest.mark.parametrize("csb", [None, "1"])
+def test_stage_driver_after_an_engine_solve_that_failed_half_way(monkeypatch, csb):
+    """The engine sets `own slice stays in T`, `norms are gathered by me`, `sums is the long message` on the rank's handle
+    and lowers them in lsqrhip_shard_end.  An error exit in between (here: LSQRHIP_SHARD_FAIL_AT, the test hook; in the
+    field: a failing RCCL call, the did-not-terminate guard) used to leave them up, and the Python stage driver that
+    lsqr_amd/dist_bench.py falls back to -- same handle, a 4-double `sums` -- then read stale gathered norms and had
+    512 bytes cleared in its 32-byte tensor."""
+    import torch
+    from lsqr_amd.dist import HipShardBackend, ShardedLSQR
+    p, o = CASES["random_over_se"]
+    if csb:
+        monkeypatch.setenv("LSQRHIP_CSB", csb)
+
+    def fresh():
+        return lsqr_solver_ez().initialize(p.m, p.n, p.a, p.irow, p.icol)
+
+    def stage_driver(s):
+        be = HipShardBackend(s, p.m, 1, 0)
+        try:
+            d_b = torch.tensor(p.b, dtype=torch.float64, device="cuda")
+            r = ShardedLSQR(be, _OneRankComm(), poll_every=3).solve(d_b.data_ptr(), **o)
+            torch.cuda.synchronize()
+            return r.istop, r.itn, r.anorm, r.rnorm, r.x.cpu().numpy().copy(), r.se.cpu().numpy().copy()
+        finally:
+            be.close()
+
+    clean = stage_driver(fresh())                      # a handle the engine never touched
+    s = fresh()
+    eng = EngineSolver(s, 0, p.m, 1, 0)
+    d_b = capi.DeviceBuffer.from_array(p.b)
+    monkeypatch.setenv("LSQRHIP_SHARD_FAIL_AT", "8")
+    with pytest.raises(capi.LsqrHipError, match="injected failure"):
+        eng.solve(d_b.ptr.value, **o)
+    monkeypatch.delenv("LSQRHIP_SHARD_FAIL_AT")
+    assert _flags(s) == 0                              # lowered by the engine's own error exit
+    after = stage_driver(s)
+    assert after[:4] == clean[:4]
+    assert np.array_equal(after[4], clean[4]) and np.array_equal(after[5], clean[5])
+    g = oracle.port().solve(p.m, p.n, p.irow, p.icol, p.a, p.b, **o)
+    assert after[0] == g.istop and after[1] == g.itn
+    assert np.linalg.norm(after[4] - g.x) <= 1e-10 * np.linalg.norm(g.x)
+    assert abs(after[2] - g.anorm) <= 1e-10 * g.anorm and abs(after[3] - g.rnorm) <= 1e-10 * g.rnorm
+    # ... and the engine still works on the handle afterwards, and leaves nothing behind when it succeeds
+    r = eng.solve(d_b.ptr.value, **o)
+    assert (r.istop, r.itn) == (g.istop, g.itn) and _flags(s) == 0
+    # belt and braces: flags left up by hand (as a crash between begin and end would) are cleared by the next begin
+    # of a caller that is not the engine
+    be = HipShardBackend(s, p.m, 1, 0)
+    try:
+        dbt = torch.tensor(p.b, dtype=torch.float64, device="cuda")
+        be.run(lambda: be.begin(dbt.data_ptr(), o["damp"], o["atol"], o["btol"], o["conlim"], o["itnlim"], o["wantse"]))
+        assert _flags(s) == 8                          # open, nothing of the engine's
+        be.run(lambda: be.end(_OneRankComm()))
+        assert _flags(s) == 0
+    finally:
+        be.close()
