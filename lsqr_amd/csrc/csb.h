@@ -126,6 +126,7 @@ struct CsbMat {
     int NS, G, J, Pst;      // stripes = Pst slices x G parts; split sp = k * J + j sweeps the stripes q * G + k, q = j, j + J, ...
     const int *border;      // the launch order of the row blocks (position -> block), or null: natural order
     int sp0, sp1;           // the column splits of THIS launch: [sp0, sp1)
+    int stagger;               // lock step: every other workgroup of an XCD starts this many x 2048 cycles late (0: together)
     unsigned long long *ymax;  // or null: the piece maxima of |y| (csb_pieces(rows): the words the k_csb_xmax pass over y would
                                // leave), raised by the epilogue with atomic max -- all zero on entry.  The NEXT product (the
                                // one that gathers from this y) takes its grids from them: no pass.
@@ -740,6 +741,10 @@ __global__ __launch_bounds__(CSB_BLOCK, 1) void k_spmv_csb(
         return;
     }
     if (*stop != 0) return;
+    // lock step: all CUs in the same phase would use HBM and the L2s in turn -- half of each XCD's workgroups
+    // (workgroup i runs on XCD i % 8) start half a step late, so that one half gathers while the other streams
+    if (K > 0 && A.stagger > 0 && ((wg >> 3) & 1))
+        for (int i = 0; i < A.stagger; ++i) __builtin_amdgcn_s_sleep(32);
     const VT *__restrict__ aval = static_cast<const VT *>(A.val);
     if (xb.clr != nullptr)
         for (int i = wg * CSB_BLOCK + tid; i < xb.nxmax; i += nwg * CSB_BLOCK) xb.clr[i] = 0ull;

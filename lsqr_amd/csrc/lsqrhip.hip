@@ -176,6 +176,7 @@ struct Csr {
     unsigned *cdel = nullptr;     // narrow form: [nchunks * 64] four u8 column deltas per lane
     int *ccb = nullptr;           // [nchunks] first column of each chunk; narrow form: [nchunks * 4] of each segment
     bool cnarrow = false;         // 11 bytes per nonzero (csb.h "NARROW form")
+    int cstagger = 0;             // lock step: late start of every other workgroup of an XCD, x 2048 cycles (LSQRHIP_CSB_STAGGER)
     int clockstep = 2;            // chunks per wave and lock-step step of the sweep (csb.h "lock step"); 0: free-running waves
     // overlap plan of the sharded engine (csb.h "Column stripes / phases"); all off: NS = 1, border = null
     long long *gptr = nullptr;    // [nrb * NS + 1] first chunk of every (block, stripe) group
@@ -1053,17 +1054,16 @@ static int build_csb(hipStream_t s, const int *rowk, const int *colk, const doub
         // few rows: as many splits as keep one round of blocks tall
         S = (int)std::min<int64_t>(8, std::max<int64_t>(1, (int64_t)rfill * CSB_GRID / std::max(rows, 1)));
         if ((int64_t)rows * S < (int64_t)CSB_GRID * 512) S = 1;   // small systems: not worth a second launch
-        // many rows (more than half a round of full blocks) over an x far beyond L2: 2 or 4 splits -- every XCD then
-        // sweeps a half / a quarter of x per launch (split = unit mod S), its workgroups drift that much less far apart
-        // and far fewer of their gathers miss L2.  Config 4 (profiles/r03/csb_column_splits.txt): 3.90 / 3.95 ms without -> 3.44 / 3.46 with 2,
-        // 3.53 / 3.53 with 4, 3.79 / 3.73 with 8; PMC fetch 25 GB -> 16.4 GB for 12.3 GB of layout.  Round 4
-        // (profiles/r04/csb_splits_by_shape.txt, one process per shape): config 4 3.32 / 3.30 ms with 2 and 3.33 / 3.33
-        // with 4; the row block of one rank of TWO (5M x 10M, just under a full round: no splits until then) 1.87 /
-        // 1.86 -> 1.69 / 1.73 ms with 2 where its transpose had 4.  Not for matrices whose x fits L2 (config 5: 0.39 ->
-        // 0.48 / 0.50 ms with 2 / 4 splits; the transposed blocks of 4 and 8 ranks).
-        // Two and four are equal in TIME on config 4, but four move less: PMC fetch 17.6 GB per product against 19.7 GB
-        // with two (12.36 GB of layout) -- so four where the matrix needs two rounds or more anyway and x is twice L2.
-        if (S == 1 && 2 * (int64_t)rows > (int64_t)CSB_GRID * rmax && (int64_t)cols * 8 > (32ll << 20))
+        // Many rows (a round of full blocks or more): NO splits since round 5.  Rounds 3 and 4 gave such matrices 2 or 4
+        // splits when x lay far beyond L2 -- every XCD then sweeps a half / a quarter of x per launch and fewer of its
+        // gathers miss L2 (config 4: PMC fetch 25 GB -> 16.4 GB, 3.9 -> 3.45 ms with the free-running sweep).  Under the
+        // lock-step sweep the misses cost less than the splits' partial sums and the combine launch do
+        // (profiles/r05/lockstep_splits_by_shape.txt, one process per shape, ms mode 1 / mode 2):
+        //   config 4 (10M x 10M)                 S = 1 2.82 / 2.82   2: 2.98 / 2.93   4: 3.09 / 3.13   8: 3.37 / 3.32
+        //   one rank of two's block (5M x 10M)   S = 1 1.41 / 1.48   2: 1.50 / 1.59   4: 1.58 / 1.69
+        // Blocks of fewer rows than a round (one rank of four, of eight) keep the splits that fill the chip, above.
+        if (env_int("LSQRHIP_CSB_SPLIT_RULE", 5) == 4 && S == 1 && 2 * (int64_t)rows > (int64_t)CSB_GRID * rmax &&
+            (int64_t)cols * 8 > (32ll << 20))   // (round 4's rule, for the A/B)
             S = ((int64_t)rows > (int64_t)CSB_GRID * rmax && (int64_t)cols * 8 >= (64ll << 20)) ? 4 : 2;
     }
     std::vector<int> border, phase_pos;   // segments: launch order of the blocks, where its phases begin
@@ -1253,6 +1253,8 @@ static int build_csb(hipStream_t s, const int *rowk, const int *colk, const doub
     {   // LSQRHIP_CSB_LOCKSTEP = 0 (the sweep of rounds 2-4: every wave on its own) | 1 | 2 (default) chunks per wave and step
         const int ls = env_int("LSQRHIP_CSB_LOCKSTEP", 2);
         out.clockstep = ls < 0 ? 0 : (ls > 2 ? 2 : ls);
+        const int sg = env_int("LSQRHIP_CSB_STAGGER", 0);
+        out.cstagger = sg < 0 ? 0 : (sg > 64 ? 64 : sg);
     }
     if (narrow) {
         out.cidx = reinterpret_cast<unsigned *>(s_row16.release<unsigned short>());

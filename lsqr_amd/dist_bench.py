@@ -85,6 +85,103 @@ def share_one_gpu(rank: int) -> bool:
     return True
 
 
+class _Env:
+    """LSQRHIP_* knobs for the duration of a build or a solve."""
+
+    def __init__(self, env):
+        self.env = env or {}
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.env}
+        os.environ.update(self.env)
+
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v
+
+
+def timed_sharded_solve(drv, d_b, K, kw, dist, torch, spec="", env=None):
+    """EXACTLY K iterations between barrier + synchronize on both sides; the slowest rank's time.
+    (dt, last result, restarts)"""
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    # exactly K iterations: configs[3] does not stop on its own in 5000 (scripts/converge_at.py); a
+    # --workload that reaches machine precision earlier is started again on the same b (every rank
+    # sees the same itn, so the ranks stay in step)
+    done, restarts = 0, 0
+    with _Env(env):
+        while done < K:
+            r = drv.solve(d_b, itnlim=K - done, **kw)
+            done += r.itn
+            if done < K:
+                restarts += 1
+                if r.itn == 0:
+                    raise SystemExit(f"bench.py: workload {spec} stops at iteration 0")
+    torch.cuda.synchronize()
+    dist.barrier()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    assert done == K and (restarts > 0 or r.istop == 5), (done, r.itn, r.istop)
+    return float(t.item()), r, restarts
+
+
+def all_ranks_ok(ok: bool, dist, torch) -> bool:
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda")
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    return int(flag.item()) == 1
+
+
+def inprocess_sharded_check(world: int):
+    """Rank 0 only, after the timed region: the ONE-process form of the sharded solve -- lsqrhip_create_sharded(ngpu = N),
+    what Fortran's `initialize(..., ngpu = N)` binds (lsqr_amd/fortran/lsqr_module.f90; ncclCommInitAll + peer copies or
+    RCCL between the devices of this process) -- on a small system, against one handle of the same system.  GPUTEST boxes
+    have one GPU: this is the only place that form meets several real devices."""
+    import ctypes as C
+
+    import numpy as np
+    import torch
+
+    from . import capi
+    from . import problems as P
+    from .solver import lsqr_solver_ez
+    have = torch.cuda.device_count()
+    ngpu = min(world, have)
+    if ngpu < 2:
+        return {"skipped": f"this process sees {have} device(s): the one-process sharded form needs two"}
+    p = P.random_rows(400000, 100000, 20, damp=1e-3)
+    K = 30
+    t0 = time.perf_counter()
+    one = lsqr_solver_ez().initialize(p.m, p.n, p.a, p.irow, p.icol, itnlim=K)
+    r1 = one.solve(p.b, p.damp)
+    h = C.c_void_p()
+    irow = np.ascontiguousarray(p.irow, np.int32)
+    icol = np.ascontiguousarray(p.icol, np.int32)
+    a = np.ascontiguousarray(p.a, np.float64)
+    capi.check(capi.lib().lsqrhip_create_sharded(p.m, p.n, a.size, irow.ctypes.data, icol.ctypes.data, a.ctypes.data, ngpu,
+                                                 C.byref(h)))
+    try:
+        x = np.zeros(p.n)
+        istop, itn = C.c_int(), C.c_int()
+        sc = [C.c_double() for _ in range(5)]
+        b = np.ascontiguousarray(p.b, np.float64)
+        capi.check(capi.lib().lsqrhip_solve(h, b.ctypes.data, p.damp, 0.0, 0.0, 0.0, K, 0, 0, x.ctypes.data, None,
+                                            C.addressof(istop), C.addressof(itn), *[C.addressof(v) for v in sc]))
+    finally:
+        capi.lib().lsqrhip_destroy(h)
+    relx = float(np.linalg.norm(x - r1.x) / np.linalg.norm(r1.x))
+    out = {"ngpu": ngpu, "workload": f"{p.name}: {K} iterations", "istop": [int(istop.value), int(r1.istop)],
+           "itn": [int(itn.value), int(r1.itn)], "rel_dx": relx,
+           "anorm_rel": abs(sc[0].value - r1.anorm) / r1.anorm, "rnorm_rel": abs(sc[2].value - r1.rnorm) / r1.rnorm,
+           "seconds": time.perf_counter() - t0}
+    out["ok"] = bool(out["istop"][0] == out["istop"][1] and out["itn"][0] == out["itn"][1] and relx <= 1e-10
+                     and out["anorm_rel"] <= 1e-10 and out["rnorm_rel"] <= 1e-10)
+    return out
+
+
 def run_distributed(args):
     import numpy as np
     import torch
@@ -182,27 +279,10 @@ def run_distributed(args):
 
     if W > 0:
         drv.solve(prob.d_b.ptr.value, itnlim=W, **kw)
-    dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    # exactly K iterations: configs[3] does not stop on its own in 5000 (scripts/converge_at.py); a
-    # --workload that reaches machine precision earlier is started again on the same b (every rank
-    # sees the same itn, so the ranks stay in step)
-    done, restarts = 0, 0
-    while done < K:
-        r = drv.solve(prob.d_b.ptr.value, itnlim=K - done, **kw)
-        done += r.itn
-        if done < K:
-            restarts += 1
-            if r.itn == 0:
-                raise SystemExit(f"bench.py: workload {spec} stops at iteration 0")
-    torch.cuda.synchronize()
-    dist.barrier()
-    dt = time.perf_counter() - t0
-    t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
-    assert done == K and (restarts > 0 or r.istop == 5), (done, r.itn, r.istop)
+    dt, r, restarts = timed_sharded_solve(drv, prob.d_b.ptr.value, K, kw, dist, torch, spec)
+    variants = {"plain": {"value": K / dt, "ms_per_step": 1e3 * dt / K, "validated": True,
+                          "is": "one stream: product, exchange, product, exchange (the 4-iteration probe against the Python "
+                                "stage driver above)"}}
 
     nnz_all = torch.tensor([prob.nnz], dtype=torch.int64, device="cuda")
     dist.all_reduce(nnz_all)
@@ -300,10 +380,114 @@ def run_distributed(args):
         # number of this line.  (bench.py's own N = 1 line measures configs[1], another workload: never divide by it.)
         out["value_1gpu_same_workload"] = ref["value"] if ref and "value" in ref else None
         out["speedup_vs_1gpu_same_workload"] = (K / dt) / ref["value"] if ref and "value" in ref else None
-        out["overlap"] = int(os.environ.get("LSQRHIP_SHARD_OVERLAP", "0") or 0)
+        # the schedule the engine of the line's `value` REALLY ran (a requested overlap that could not be set up is off)
+        out["overlap"] = (int(prob.solver.get_option("shard_overlap")) if engine == "c++" else 0)
         out["cpu_baseline"] = cpu
         if ref is not None:
             out["strong_scaling_ref"] = ref
+        out["variants"] = variants
+        out["config"]["schedule"] = "plain"
+    else:
+        out = None
+
+    # ---- the other schedules of the same solve, in the same invocation (round 5) -------------------------------------
+    # graph   : the plain schedule's batches captured in a hipGraph, RCCL's kernels with them (LSQRHIP_SHARD_GRAPH=1)
+    # overlap : the two n-vector exchanges in parts on a stream of their own beside the products (LSQRHIP_SHARD_OVERLAP=1:
+    #           the rank's layouts are rebuilt for it, a second communicator is split off)
+    # Each is probed first -- 4 iterations against the plain engine's, which was held to the Python driver above: they
+    # must agree to 1e-12 on every rank -- then timed like the plain one.  `value` = the best VALIDATED schedule.
+    # None of this has run over xGMI before the driver's multi-GPU run: a hang inside RCCL cannot be recovered from, so
+    # a watchdog prints the line as it stands (plain schedule, the failing variant named) and ends the job cleanly.
+    # (a run with LSQRHIP_SHARD_OVERLAP / LSQRHIP_SHARD_GRAPH set in its environment measures that one schedule)
+    pinned = [k for k in ("LSQRHIP_SHARD_OVERLAP", "LSQRHIP_SHARD_GRAPH") if os.environ.get(k, "0") not in ("", "0")]
+    if rank == 0 and pinned:
+        out["config"]["schedule"] = "as the environment says: " + ", ".join(f"{k}={os.environ[k]}" for k in pinned)
+    want_variants = engine == "c++" and not pinned and (world > 1 or os.environ.get("LSQR_BENCH_VARIANTS") == "1") and \
+        os.environ.get("LSQR_BENCH_VARIANTS", "1") != "0"
+    state = {"doing": None}
+
+    def bail():
+        if rank == 0 and out is not None:
+            out["variants"][state["doing"] or "?"] = {"error": "timed out (watchdog): RCCL hang?", "validated": False}
+            out["config"]["variants_note"] = f"stopped by the watchdog inside `{state['doing']}`"
+            print(json.dumps(out), flush=True)
+        os._exit(0)
+
+    if want_variants:
+        import threading
+        wd = threading.Timer(float(os.environ.get("LSQR_DIST_VARIANT_TIMEOUT", "420")), bail)
+        wd.daemon = True
+        wd.start()
+        r_ref = drv.solve(prob.d_b.ptr.value, itnlim=4, **kw)     # the plain engine's 4 iterations (same on every rank)
+
+        def agrees(rv):
+            return (rv.itn == r_ref.itn and abs(rv.rnorm - r_ref.rnorm) <= 1e-12 * abs(r_ref.rnorm)
+                    and abs(rv.anorm - r_ref.anorm) <= 1e-12 * abs(r_ref.anorm))
+
+        def measure(name, vdrv, vprob, env, what):
+            state["doing"] = name
+            ok, note = True, None
+            try:
+                with _Env(env):
+                    rv = vdrv.solve(vprob.d_b.ptr.value, itnlim=4, **kw)
+                ok = agrees(rv)
+                if not ok:
+                    note = f"disagrees with the plain schedule after 4 iterations (rnorm {rv.rnorm!r} vs {r_ref.rnorm!r})"
+            except Exception as e:  # noqa: BLE001
+                ok, note = False, repr(e)
+            if not all_ranks_ok(ok, dist, torch):
+                variants[name] = {"validated": False, "error": note or "failed or disagreed on another rank", "is": what}
+                return
+            with _Env(env):
+                if W > 0:
+                    vdrv.solve(vprob.d_b.ptr.value, itnlim=W, **kw)
+            dtv, rv, _ = timed_sharded_solve(vdrv, vprob.d_b.ptr.value, K, kw, dist, torch, spec, env)
+            variants[name] = {"value": K / dtv, "ms_per_step": 1e3 * dtv / K, "validated": True, "is": what,
+                              "result": {"istop": rv.istop, "itn": rv.itn, "anorm": rv.anorm, "rnorm": rv.rnorm}}
+
+        measure("graph", drv, prob, {"LSQRHIP_SHARD_GRAPH": "1"},
+                "the plain schedule, batches of iterations captured in a hipGraph (RCCL's kernels with them)")
+        prob_ov, drv_ov, ok = None, None, True
+        state["doing"] = "overlap (build + communicator)"
+        try:
+            with _Env({"LSQRHIP_SHARD_OVERLAP": "1", "LSQRHIP_SHARD_WORLD": str(world)}):
+                prob_ov = devgen.generate(spec, row0, nrows)
+                drv_ov = EngineSolver(prob_ov.solver, row0, cfg["m"], world, rank)
+            eff = int(prob_ov.solver.get_option("shard_overlap"))
+            if eff != 1 and world > 1:
+                raise RuntimeError("the engine could not set the overlapped schedule up (shard_overlap = 0)")
+        except Exception as e:  # noqa: BLE001
+            ok, err = False, repr(e)
+        if all_ranks_ok(ok, dist, torch):
+            measure("overlap", drv_ov, prob_ov, {"LSQRHIP_SHARD_OVERLAP": "1"},
+                    "the n-vector exchanges in parts on a stream of their own beside the products")
+            if "overlap" in variants and variants["overlap"].get("validated"):
+                variants["overlap"]["parts"] = int(prob_ov.solver.get_option("shard_parts"))
+        else:
+            variants["overlap"] = {"validated": False, "error": err if not ok else "set-up failed on another rank"}
+        del drv_ov, prob_ov
+        if rank == 0:
+            best = max((k for k, v in variants.items() if v.get("validated")), key=lambda k: variants[k]["value"])
+            out["value"] = variants[best]["value"]
+            out["ms_per_step"] = variants[best]["ms_per_step"]
+            out["config"]["schedule"] = best
+            out["overlap"] = 1 if best == "overlap" else 0
+            if "result" in variants[best]:
+                out["result"] = variants[best]["result"]
+            if out.get("value_1gpu_same_workload"):
+                out["speedup_vs_1gpu_same_workload"] = out["value"] / out["value_1gpu_same_workload"]
+            # the one-process form (Fortran `ngpu = N`) on this node's devices, small system, untimed
+            state["doing"] = "inprocess_sharded_check"
+            try:
+                out["inprocess_sharded_check"] = inprocess_sharded_check(world)
+            except Exception as e:  # noqa: BLE001
+                out["inprocess_sharded_check"] = {"ok": False, "error": repr(e)}
+        wd.cancel()
+    if rank == 0:
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
         print(json.dumps(out), flush=True)
     dist.barrier()
     dist.destroy_process_group()

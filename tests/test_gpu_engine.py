@@ -230,7 +230,7 @@ def test_rccl_two_ranks_through_bench_launcher(overlap):
 
 
 @pytest.mark.parametrize("world,overlap,graph", [(2, "0", ""), (2, "1", ""), (3, "0", ""), (4, "1", ""), (8, "0", ""),
-                                                 (8, "1", ""), (2, "0", "1"), (3, "0", "1")])
+                                                 (8, "1", ""), (2, "0", "1"), (3, "0", "1"), (2, "", ""), (5, "", "")])
 def test_rccl_ranks_sharing_one_gpu_through_bench_launcher(world, overlap, graph):
     """The RCCL branch at world > 1 on a ONE-GPU box: `bench.py --gpus N` with LSQR_RANKS_SHARE_GPU=1 starts N processes
     that all use device 0; each claims a host of its own (NCCL_HOSTID) so that RCCL takes them, over its socket
@@ -240,7 +240,10 @@ def test_rccl_ranks_sharing_one_gpu_through_bench_launcher(world, overlap, graph
     against the stage-by-stage Python driver (torch.distributed collectives) on four iterations: `engine` = "c++" with
     no `engine_note` says they agreed on every rank.  The result is then held against ONE handle solving the whole
     matrix.  graph = "1": LSQRHIP_SHARD_GRAPH=1, the batches of 16 iterations captured WITH their RCCL calls and replayed
-    (40 iterations: two replays and an eager tail)."""
+    (40 iterations: two replays and an eager tail).
+    overlap = "" (round 5): nothing pinned in the environment -- the launcher's own form.  The line then carries all three
+    schedules (plain, graph, overlap), each probed against the plain engine on four iterations and timed in the same
+    invocation, `value` = the best validated one, and `inprocess_sharded_check` (skipped here: one device)."""
     import json
     import os
     import subprocess
@@ -249,6 +252,8 @@ def test_rccl_ranks_sharing_one_gpu_through_bench_launcher(world, overlap, graph
     spec, K = "random:200000:100000:20", 40 if graph else 20
     env = {**os.environ, "LSQR_BENCH_STRONG_REF": "0", "LSQRHIP_SHARD_OVERLAP": overlap, "LSQR_RANKS_SHARE_GPU": "1",
            "LSQR_DIST_PROBE_TIMEOUT": "300"}
+    if overlap == "":
+        env.pop("LSQRHIP_SHARD_OVERLAP")
     if graph:
         env["LSQRHIP_SHARD_GRAPH"] = graph
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", str(K), "--warmup", "2",
@@ -259,7 +264,19 @@ def test_rccl_ranks_sharing_one_gpu_through_bench_launcher(world, overlap, graph
     assert line["n_gpus"] == world and line["config"]["world_size"] == world and line["steps"] == K
     assert line["config"]["ranks_share_one_gpu"] is True and "TEST" in line["config"]["backend"]
     assert line["config"]["engine"] == "c++" and line["config"]["engine_note"] is None, line["config"]
-    assert line["result"]["itn"] == K and line["value"] > 0 and line["overlap"] == int(overlap)
+    assert line["result"]["itn"] == K and line["value"] > 0
+    if overlap in ("", "0") and not graph:     # nothing pinned: every schedule in the one invocation
+        v = line["variants"]
+        assert set(v) == {"plain", "graph", "overlap"}, v
+        for name, e in v.items():
+            assert e["validated"] is True and e["value"] > 0, (name, e)
+        best = line["config"]["schedule"]
+        assert best in v and line["value"] == v[best]["value"] == max(e["value"] for e in v.values())
+        assert line["overlap"] == (1 if best == "overlap" else 0) and v["overlap"]["parts"] >= 2
+        assert "skipped" in line["inprocess_sharded_check"]        # (one device: the form needs two)
+    else:
+        assert line["overlap"] == int(overlap) and set(line["variants"]) == {"plain"}
+        assert line["config"]["schedule"].startswith("as the environment says")
     # the same 20 iterations on one handle that holds the whole matrix (same generator)
     from lsqr_amd import devgen
     from lsqr_amd.capi import DeviceBuffer
