@@ -574,6 +574,11 @@ static int enqueue_iteration_overlap(ShardGroup &g)
     for (ShardRank &q : g.r) {
         phA = phA && q.h->A.csb && q.h->A.phases == G;
         phT = phT && q.h->AT.csb && q.h->AT.phases == G;
+        // Without the piece maxima of v in the norms' message (LSQRHIP_SHARD_VMAX=0, or a world of 69..128 ranks whose
+        // message would not fit) phase 0 of mode 1 would take them with a pass over the WHOLE of V -- while the parts
+        // 1..G-1 of it are still arriving: maxima of a mix of old and new v, grids that differ from run to run
+        // (round-4 advisor).  Mode 1 then runs whole, behind all the parts: bit for bit the plain schedule again.
+        phA = phA && q.h->shard.vmax_msg;
     }
     auto wait_all = [&](ShardRank &q, auto getev) -> int {   // q's compute stream waits for an exchange-stream event
         HIPCHK(hipSetDevice(q.h->device));

@@ -386,7 +386,8 @@ __global__ __launch_bounds__(BLOCK, 1) void k_sweep_xwin(const double *__restric
 // V2: the second barrier comes behind the ISSUE of the gathers, not their return -- stream requests queued behind gathers
 // hold nobody up (data returns in request order), so the next stream may be requested at once and the L1 never runs dry
 // between the two phases; a wave waits for its gathers with the stream already in flight behind them.
-template <int K, bool V2 = false>
+// GM: how the gathers of x are loaded -- 0 plain | 1 non-temporal | 2 agent scope (sc1: past the L1, smaller requests?)
+template <int K, bool V2 = false, int GM = 0>
 __global__ __launch_bounds__(BLOCK, 1) void k_sweep_phased(const double *__restrict__ val, const unsigned *__restrict__ idx,
                                                            const int *__restrict__ cbase, const double *__restrict__ x,
                                                            int64_t cpb, int b0, int nunits, int S, double ginv, int stagger,
@@ -434,7 +435,12 @@ __global__ __launch_bounds__(BLOCK, 1) void k_sweep_phased(const double *__restr
 #pragma unroll
             for (int q = 0; q < K; ++q)
 #pragma unroll
-                for (int j = 0; j < U; ++j) xv[q][j] = x[cur.base[q] + (int)(cur.ix[q][j] & LMASK)];
+                for (int j = 0; j < U; ++j) {
+                    const double *px = &x[cur.base[q] + (int)(cur.ix[q][j] & LMASK)];
+                    if (GM == 1) xv[q][j] = __builtin_nontemporal_load(px);
+                    else if (GM == 2) xv[q][j] = __hip_atomic_load(px, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    else xv[q][j] = *px;
+                }
             if (!V2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();   // every wave's gathers are back (V2: are requested)
@@ -586,11 +592,11 @@ static double run_xwin(const Cfg &c, const Mat &m, const double *x, double *out,
     }, reps);
 }
 
-template <int K, bool V2 = false>
+template <int K, bool V2 = false, int GM = 0>
 static double run_phased(const Cfg &c, const Mat &m, const double *x, double *out, int reps, int stagger = 0)
 {
     return time_product(c, [&](int b0, int nunits, int grid) {
-        hipLaunchKernelGGL((k_sweep_phased<K, V2>), dim3(grid), dim3(BLOCK), 0, 0, m.val, m.idx, m.cbase, x, m.cpb, b0, nunits, c.S,
+        hipLaunchKernelGGL((k_sweep_phased<K, V2, GM>), dim3(grid), dim3(BLOCK), 0, 0, m.val, m.idx, m.cbase, x, m.cpb, b0, nunits, c.S,
                            0x1p40, stagger, out);
     }, reps);
 }
@@ -606,6 +612,7 @@ int main(int argc, char **argv)
     CK(hipMalloc(&out, 64));
     const Cfg cfgs[] = {
         {"config 4: 10M x 10M x 100, 512 blocks, S = 4", 10000000, 19532, 100.0, 512, 4},
+        {"config 4: 10M x 10M x 100, 512 blocks, S = 1 (2 launches)", 10000000, 19532, 100.0, 512, 1},
         {"rank block of config 4 at N = 8: 1.25M x 10M x 100, 64 blocks, S = 4", 10000000, 19532, 100.0, 64, 4},
         {"config 5: 5M x 2M power law (21.3 per row), 256 blocks, S = 1", 2000000, 19532, 21.29, 256, 1},
         {"config 3 at 100 per row: 4M x 1M, 256 blocks of 15625 rows, S = 1", 1000000, 15625, 100.0, 256, 1},
@@ -635,7 +642,7 @@ int main(int argc, char **argv)
     if (std::strchr(which, 'd')) {
         std::printf("(d) stream and gathers never in the L1's queue together (lock-step phases); ms per product, grid = %d\n", g_grid);
         std::printf("%-72s %8s %8s %8s %8s %8s | %8s %8s %8s %8s %8s\n", "configuration", "base", "v2K1 s4", "v2K2 s4", "v2K3 s4", "base",
-                    "v2K2 s0", "v2K2 s2", "v2K2 s6", "v2K2 4g2", "v2K1 4g1");
+                    "v2K2 s0", "v2K2 s2", "v2K2 s6", "v2K2 nt", "v2K2 sc1");
         for (const Cfg &c : cfgs) {
             Mat m = build(c);
             for (int round = 0; round < 2; ++round) {
@@ -645,8 +652,8 @@ int main(int argc, char **argv)
                 const double t3 = run_phased<3, true>(c, m, x, out, reps, 4);
                 const double t4 = run_spf<0, 0, 1>(c, m, x, out, reps);
                 const double u1 = run_phased<2, true>(c, m, x, out, reps, 0), u2 = run_phased<2, true>(c, m, x, out, reps, 2);
-                const double u3 = run_phased<2, true>(c, m, x, out, reps, 6), u4 = run_phased<2, true>(c, m, x, out, reps, (4 << 8) | 2);
-                const double u5 = run_phased<1, true>(c, m, x, out, reps, (4 << 8) | 1);
+                const double u3 = run_phased<2, true>(c, m, x, out, reps, 6), u4 = run_phased<2, true, 1>(c, m, x, out, reps, 0);
+                const double u5 = run_phased<2, true, 2>(c, m, x, out, reps, 0);
                 const double best = std::min(std::min(std::min(t1, t2), std::min(u1, u2)), std::min(std::min(u3, u4), u5));
                 std::printf("%-72s %8.3f %8.3f %8.3f %8.3f %8.3f | %8.3f %8.3f %8.3f %8.3f %8.3f   (%.0f -> %.0f GB/s)\n", c.name, t0, t1,
                             t2, t3, t4, u1, u2, u3, u4, u5, m.bytes / t0 / 1e6, m.bytes / best / 1e6);

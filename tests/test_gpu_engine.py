@@ -499,17 +499,20 @@ def _solve_with_log(h, p, o):
 
 
 @pytest.mark.parametrize("ngpu", [2, 3, 8])
-@pytest.mark.parametrize("csb,parts", [(None, 2), ("1", 2), ("1", 3)])
-def test_overlapped_exchanges_change_no_bit(loopback, ngpu, csb, parts):
+@pytest.mark.parametrize("csb,parts,vmax", [(None, 2, None), ("1", 2, None), ("1", 3, None), ("1", 2, "0"), ("1", 3, "0")])
+def test_overlapped_exchanges_change_no_bit(loopback, ngpu, csb, parts, vmax):
     """LSQRHIP_SHARD_OVERLAP=1: the reduce-scatter of T leaves in parts behind the phases of mode 2 and the all-gather
     of v arrives in parts ahead of the phases of mode 1, on an exchange stream of its own (shard_engine.h
     enqueue_iteration_overlap; here in the loopback harness -- the exchanges are device copies, the streams, events
     and parts are the production schedule).  The kernels, their data and the order of every sum are those of the plain
     schedule: x, se, every scalar and every line of the iteration log must be identical to the last bit -- with the
     ranks' blocks in column-swept row blocks built for the parts (stripes, part-major row blocks: the products run
-    phase by phase) and in whatever the build chooses at this size (the products run whole, the exchanges in parts)."""
+    phase by phase) and in whatever the build chooses at this size (the products run whole, the exchanges in parts).
+    vmax = "0" (LSQRHIP_SHARD_VMAX=0: the piece maxima of v do NOT ride with the norms -- also what a world of 69..128 ranks
+    gets): mode 1 must then run whole behind all the parts of v (its grids come from a pass over all of V, which phase 0
+    would have made while the other parts were still arriving -- round-4 advisor), and still change no bit."""
     import os
-    keys = ("LSQRHIP_CSB", "LSQRHIP_SHARD_OVERLAP", "LSQRHIP_SHARD_PARTS")
+    keys = ("LSQRHIP_CSB", "LSQRHIP_SHARD_OVERLAP", "LSQRHIP_SHARD_PARTS", "LSQRHIP_SHARD_VMAX")
     old = {k: os.environ.get(k) for k in keys}
     p = P.random_rows(60000, 12011, 10, seed=31, damp=1e-3)      # (12011: ragged slices and parts)
     o = dict(damp=p.damp, atol=1e-10, btol=1e-10, conlim=0.0, itnlim=25, wantse=True)
@@ -518,6 +521,8 @@ def test_overlapped_exchanges_change_no_bit(loopback, ngpu, csb, parts):
         if csb:
             os.environ["LSQRHIP_CSB"] = csb
         os.environ["LSQRHIP_SHARD_PARTS"] = str(parts)
+        if vmax is not None:
+            os.environ["LSQRHIP_SHARD_VMAX"] = vmax
         for overlap in ("0", "1"):
             os.environ["LSQRHIP_SHARD_OVERLAP"] = overlap
             h = sharded_handle(p, ngpu)
