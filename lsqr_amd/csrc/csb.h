@@ -104,6 +104,9 @@ constexpr int CSB_XHIST = 64;                    // product: piece maxima of x b
 #ifndef CSB_NT_STREAM
 #define CSB_NT_STREAM 1
 #endif
+#ifndef CSB_BARRIER_A
+#define CSB_BARRIER_A 0   // lock step: a second barrier in front of the gathers (round 5's first form; slower)
+#endif
 
 struct CsbMat {
     const void *val;        // VT values (double; float for a REAL32 handle), each row scaled by 2^-rexp[row]
@@ -874,11 +877,16 @@ __global__ __launch_bounds__(CSB_BLOCK, 1) void k_spmv_csb(
             }
         } else {
             // LOCK STEP (header): all 16 waves move together, KK chunks per wave and step --
-            //   barrier A | decode + gathers of this step's chunks | barrier B | stream of the next step's chunks |
+            //   decode + gathers of this step's chunks | BARRIER | stream of the next step's chunks |
             //   products + LDS adds (behind the gathers, the stream in flight) | wait for the stream |
-            // Barrier A: every wave's stream has landed, the CU has no HBM request queued when the gathers go out.
-            // Barrier B: every wave's gathers are REQUESTED (not back): stream requests queued behind gathers hold
-            // nobody up, so they follow at once and the L1 never runs dry between the two phases.
+            // The barrier: every wave's gathers are REQUESTED (not back) before any wave requests its next stream.
+            // Data returns in request order across the CU: a stream request queued behind gathers holds nobody up, a
+            // gather queued behind another wave's NEW stream request waits an HBM round trip for a line L2 had ready.
+            // (The first form also had a barrier in FRONT of the gathers -- "every wave's stream has landed" -- so that
+            // no gather ever stood behind a stream line.  Behind the LAST stream lines of slower waves a gather waits
+            // no longer than it would have at that barrier, and the L1 does not run dry in between: config 4's sweeps
+            // 2.89 -> 2.50 ms in scripts/csb_break.hip, profiles/r05/csb_break_d_single_barrier.txt.  CSB_BARRIER_A=1
+            // brings it back.)
             // The step count is the same for every wave (barriers inside); a wave without a real chunk in a step
             // loads the range's last chunk again (clamped) and adds nothing.
             constexpr int KK = K > 0 ? K : 1;
@@ -894,7 +902,7 @@ __global__ __launch_bounds__(CSB_BLOCK, 1) void k_spmv_csb(
                                 CsbRaw<NARROW> (&qn)[KK]) {
                 int rr[KK][CSB_U];
                 double xx[KK][CSB_U];
-                __builtin_amdgcn_s_barrier();   // A
+                if (CSB_BARRIER_A) __builtin_amdgcn_s_barrier();   // A (the first form; see above)
 #pragma unroll
                 for (int k = 0; k < KK; ++k) {
                     int col[CSB_U];
@@ -907,16 +915,21 @@ __global__ __launch_bounds__(CSB_BLOCK, 1) void k_spmv_csb(
                 __builtin_amdgcn_sched_barrier(0);
                 issue_set(cfirst + (long long)KK * CSB_WAVES, an, qn);
                 __builtin_amdgcn_sched_barrier(0);
+                // A wave without a real chunk in this step (clamped loads) adds zeros to rows of the range's last chunk:
+                // by SELECT, not by a branch around the adds -- with a branch the compiler sinks that chunk's gathers
+                // into it, behind the barrier and the stream requests (seen in the ISA of the first build: half of the
+                // gathers went out AFTER the wave's own stream), which is the very order this loop exists to avoid.
 #pragma unroll
                 for (int k = 0; k < KK; ++k) {
-                    if (cfirst + (long long)k * CSB_WAVES < c1) {   // (uniform)
+                    const bool live = cfirst + (long long)k * CSB_WAVES < c1;   // (uniform)
+                    double am[CSB_U];
 #pragma unroll
-                        for (int j = 0; j < CSB_U; ++j) {
-                            r[j] = rr[k][j];
-                            xv[j] = xx[k][j];
-                        }
-                        accumulate(a[k]);
+                    for (int j = 0; j < CSB_U; ++j) {
+                        r[j] = rr[k][j];
+                        xv[j] = live ? xx[k][j] : 0.0;
+                        am[j] = live ? a[k][j] : 0.0;
                     }
+                    accumulate(am);
                 }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next step's stream has landed
             };

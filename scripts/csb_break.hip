@@ -431,7 +431,10 @@ __global__ __launch_bounds__(BLOCK, 1) void k_sweep_phased(const double *__restr
         };
         auto step = [&](int64_t cfirst, Set &cur, Set &nxt) {
             double xv[K][U];
-            __builtin_amdgcn_s_barrier();   // every wave's stream has landed: the L1's queue is empty
+            if (GM != 4) __builtin_amdgcn_s_barrier();   // every wave's stream has landed: the L1's queue is empty
+            // (GM == 4, "V3": no such barrier -- a wave's gathers may queue behind the LAST stream lines of slower waves,
+            //  which they would have waited for at the barrier anyway; what must not happen is NEW stream requests in
+            //  front of gathers, and the second barrier sees to that)
 #pragma unroll
             for (int q = 0; q < K; ++q)
 #pragma unroll
@@ -642,7 +645,7 @@ int main(int argc, char **argv)
     if (std::strchr(which, 'd')) {
         std::printf("(d) stream and gathers never in the L1's queue together (lock-step phases); ms per product, grid = %d\n", g_grid);
         std::printf("%-72s %8s %8s %8s %8s %8s | %8s %8s %8s %8s %8s\n", "configuration", "base", "v2K1 s4", "v2K2 s4", "v2K3 s4", "base",
-                    "v2K2 s0", "v2K2 s2", "v2K2 s6", "v2K2 nt", "v2K2 sc1");
+                    "v2K2 s0", "v3K1 s0", "v3K2 s0", "v3K3 s0", "v3K2 s4");
         for (const Cfg &c : cfgs) {
             Mat m = build(c);
             for (int round = 0; round < 2; ++round) {
@@ -651,9 +654,9 @@ int main(int argc, char **argv)
                 const double t2 = run_phased<2, true>(c, m, x, out, reps, 4);
                 const double t3 = run_phased<3, true>(c, m, x, out, reps, 4);
                 const double t4 = run_spf<0, 0, 1>(c, m, x, out, reps);
-                const double u1 = run_phased<2, true>(c, m, x, out, reps, 0), u2 = run_phased<2, true>(c, m, x, out, reps, 2);
-                const double u3 = run_phased<2, true>(c, m, x, out, reps, 6), u4 = run_phased<2, true, 1>(c, m, x, out, reps, 0);
-                const double u5 = run_phased<2, true, 2>(c, m, x, out, reps, 0);
+                const double u1 = run_phased<2, true>(c, m, x, out, reps, 0), u2 = run_phased<1, true, 4>(c, m, x, out, reps, 0);
+                const double u3 = run_phased<2, true, 4>(c, m, x, out, reps, 0), u4 = run_phased<3, true, 4>(c, m, x, out, reps, 0);
+                const double u5 = run_phased<2, true, 4>(c, m, x, out, reps, 4);
                 const double best = std::min(std::min(std::min(t1, t2), std::min(u1, u2)), std::min(std::min(u3, u4), u5));
                 std::printf("%-72s %8.3f %8.3f %8.3f %8.3f %8.3f | %8.3f %8.3f %8.3f %8.3f %8.3f   (%.0f -> %.0f GB/s)\n", c.name, t0, t1,
                             t2, t3, t4, u1, u2, u3, u4, u5, m.bytes / t0 / 1e6, m.bytes / best / 1e6);
