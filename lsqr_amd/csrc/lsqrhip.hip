@@ -176,6 +176,7 @@ struct Csr {
     unsigned *cdel = nullptr;     // narrow form: [nchunks * 64] four u8 column deltas per lane
     int *ccb = nullptr;           // [nchunks] first column of each chunk; narrow form: [nchunks * 4] of each segment
     bool cnarrow = false;         // 11 bytes per nonzero (csb.h "NARROW form")
+    int crounds = 1;              // one launch per round of 256 units (1) or one launch over all of them (0): LSQRHIP_CSB_ROUNDS
     int cstagger = 0;             // lock step: late start of every other workgroup of an XCD, x 2048 cycles (LSQRHIP_CSB_STAGGER)
     int clockstep = 2;            // chunks per wave and lock-step step of the sweep (csb.h "lock step"); 0: free-running waves
     // overlap plan of the sharded engine (csb.h "Column stripes / phases"); all off: NS = 1, border = null
@@ -1253,6 +1254,7 @@ static int build_csb(hipStream_t s, const int *rowk, const int *colk, const doub
     {   // LSQRHIP_CSB_LOCKSTEP = 0 (the sweep of rounds 2-4: every wave on its own) | 1 | 2 (default) chunks per wave and step
         const int ls = env_int("LSQRHIP_CSB_LOCKSTEP", 2);
         out.clockstep = ls < 0 ? 0 : (ls > 2 ? 2 : ls);
+        out.crounds = env_int("LSQRHIP_CSB_ROUNDS", 1) != 0 ? 1 : 0;
         const int sg = env_int("LSQRHIP_CSB_STAGGER", 0);
         out.cstagger = sg < 0 ? 0 : (sg > 64 ? 64 : sg);
     }
@@ -2210,7 +2212,7 @@ extern "C" int lsqrhip_get_option(lsqrhip_handle_t h, const char *name, int64_t 
         // average is divided over; dispatches_*: every kernel one product enqueues (the max|x| pass of csb.h too)
         const Csr &c = (k == "launches_mode1" || k == "dispatches_mode1") ? h->A : h->AT;
         const bool all = k[0] == 'd';
-        static const int rounds = env_int("LSQRHIP_CSB_ROUNDS", 1);
+        const int rounds = c.crounds;
         // (the pass is not part of a product inside the loop when both matrices are column-swept: xmax_folded, and
         //  lsqrhip_bench_kernel times that form)
         if (c.csb) *value = (all && !xmax_folded(h) ? 1 : 0) + csb_sweep_launches(c, rounds != 0) + (c.S > 1 ? 1 : 0);

@@ -305,7 +305,7 @@ static void launch_csb_K(H *h, const SpmvArgs &a)
     // With the overlap plan of the sharded engine (csb.h "Column stripes / phases") the launches fall into phases:
     // stripes -- phase k = all blocks x the J splits of part k of the gathered vector; segments -- phase k = the blocks
     // of part k of the output vector; `a.phase` picks one (the engine waits for an exchange between them).
-    static const int rounds = env_int("LSQRHIP_CSB_ROUNDS", 1);
+    const int rounds = c.crounds;   // (LSQRHIP_CSB_ROUNDS at create)
     const int S = std::max(c.S, 1);
     CsbMat A{c.cval, c.cidx, c.cdel, c.ccb, c.cptr, c.crs, c.nrb, c.R, c.rows, c.cols, c.rexp, c.zcoarse, 0, 0, S, c.zsplit,
              c.cbad, std::max(c.Q, 1), c.gptr, c.NS, c.G, c.J, c.Pst, c.border, 0, S, c.cstagger,
