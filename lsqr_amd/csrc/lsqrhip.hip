@@ -1252,8 +1252,18 @@ static int build_csb(hipStream_t s, const int *rowk, const int *colk, const doub
     out.cval = s_val.release<double>();
     out.cnarrow = narrow;
     {   // LSQRHIP_CSB_LOCKSTEP = 0 (the sweep of rounds 2-4: every wave on its own) | 1 | 2 (default) chunks per wave and step
-        const int ls = env_int("LSQRHIP_CSB_LOCKSTEP", 2);
-        out.clockstep = ls < 0 ? 0 : (ls > 2 ? 2 : ls);
+        // Default by shape (profiles/r05/lockstep_ab.txt, lockstep_k_dense.txt: every shape in one process): ONE chunk per
+        // wave and step, except long sweeps over sparse columns -- a unit (block x split) of >= 256 chunks per wave with
+        // fewer than one nonzero per column and block (config 4 whole, the block of one rank of two: 2 chunks, -2 %).
+        // Dense columns (config 3, 1000 per row) and short sweeps (a rank of eight's block, config 5) lose 1-10 % with 2.
+        const int ls = env_int("LSQRHIP_CSB_LOCKSTEP", -1);
+        if (ls >= 0) out.clockstep = ls > 2 ? 2 : ls;
+        else {
+            const double per_unit = (double)nnz / std::max(1.0, (double)nrb * std::max(S, 1));
+            const double chunks_per_wave = per_unit / CSB_CHUNK / CSB_WAVES;
+            const double per_column = (double)nnz / std::max(1, nrb) / std::max(cols, 1);
+            out.clockstep = (chunks_per_wave >= 256.0 && per_column < 1.0) ? 2 : 1;
+        }
         out.crounds = env_int("LSQRHIP_CSB_ROUNDS", 1) != 0 ? 1 : 0;
         const int sg = env_int("LSQRHIP_CSB_STAGGER", 0);
         out.cstagger = sg < 0 ? 0 : (sg > 64 ? 64 : sg);

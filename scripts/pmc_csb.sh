@@ -22,8 +22,10 @@ lay = [l.split() for l in open(sys.argv[2]) if l.startswith("LAYOUT")][0]
 times = [l.split() for l in open(sys.argv[2]) if l.startswith("TIMES_MS")]
 L1, L2 = int(lay[3]), int(lay[4])
 S1, S2 = int(lay[9]), int(lay[10])
-L1 -= 2 if S1 > 1 else 1      # k_csb_xmax and k_csb_combine are kernels of their own
-L2 -= 2 if S2 > 1 else 1
+# dispatches = [k_csb_xmax, unless the products keep the piece maxima themselves] + sweeps + [k_csb_combine if splits]
+XM = 0 if lay[-1] == "xfold" else 1
+L1 -= XM + (1 if S1 > 1 else 0)
+L2 -= XM + (1 if S2 > 1 else 0)
 rows = [r for r in csv.DictReader(open(sys.argv[1])) if "k_spmv_csb" in r["Kernel_Name"]]
 for c in sorted(set(r["Counter_Name"] for r in rows)):
     rc = sorted((r for r in rows if r["Counter_Name"] == c), key=lambda r: int(r["Dispatch_Id"]))

@@ -10,7 +10,7 @@ s = dp.solver
 g = s.get_option
 print("LAYOUT", spec, "launches", g("dispatches_mode1"), g("dispatches_mode2"), "blocks", g("csb_blocks_mode1"),
       g("csb_blocks_mode2"), "splits", g("csb_splits_mode1"), g("csb_splits_mode2"), "bytes", s.info()["csr_bytes"],
-      s.info()["csrt_bytes"], flush=True)
+      s.info()["csrt_bytes"], "xfold" if g("launches_mode1") == g("dispatches_mode1") else "xpass", flush=True)
 t1 = s.bench_kernel(1, 10)
 t2 = s.bench_kernel(2, 10)
 print("TIMES_MS", round(t1, 4), round(t2, 4), flush=True)
