@@ -53,6 +53,17 @@
 //     reference's (tests/test_gpu_csb.py::test_non_finite_and_huge_x_as_the_reference).
 //   * the epilogue of a block forms y_i, the block's partial of sum (y ns)^2 (one per BLOCK, so the
 //     fixed-order reduction is independent of the launch shape) and clears the accumulators.
+//   * LOCK STEP (round 5).  A CU's vector L1 returns data in REQUEST ORDER across all its waves: a gathered line of x
+//     that L2 had ready in ~250 cycles, queued behind another wave's stream line from HBM (~900), waits for that one
+//     and holds its slot meanwhile.  Rounds 2-4 let every wave run on its own (next chunk's stream requested right
+//     behind this chunk's gathers -- in front of the gathers of fifteen other waves); the stream's and the gathers' times
+//     then ADD UP and worse (scripts/csb_ceiling.hip on 64 CUs: 11.2 ms against 3.9 + 4.4), which round 4 took for the
+//     ceiling of the access pattern.  Now the 16 waves of a workgroup move in lock step, K chunks per wave and step:
+//         gathers of this step's chunks | s_barrier | stream of the next step's chunks | products + LDS adds | wait
+//     -- every wave has REQUESTED its gathers before any wave requests new stream lines.  One barrier per step; no
+//     arithmetic changes (integer adds do not care when they happen): config 4 3.47 -> 2.42 ms per product, one
+//     rank's block 0.446 -> 0.342, config 5 0.370 -> 0.280 (profiles/r05/lockstep_ab.txt).  K and the free-running
+//     form (LSQRHIP_CSB_LOCKSTEP=0) are template parameters of the kernel.
 //
 // Layout (built once by build_csb from the COO triplets, stable LSD radix sorts of csr_build.h):
 //   block b = rows [rstart[b], rstart[b+1]): at most R rows, cut so that every block holds about the

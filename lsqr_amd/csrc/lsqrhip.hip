@@ -224,7 +224,7 @@ struct ShardCtx {
 
 struct ShardGroup;  // shard_engine.h: the ranks of a sharded solve driven from this process (RCCL)
 struct lsqrhip_handle_s;
-static int64_t shard_effective(const lsqrhip_handle_s *h, bool parts);   // shard_engine.h
+static int64_t shard_effective(const lsqrhip_handle_s *h, int what);   // shard_engine.h
 
 struct lsqrhip_handle_s {
     std::atomic<int> refs{1};  // lsqrhip_retain / lsqrhip_destroy
@@ -2244,9 +2244,10 @@ extern "C" int lsqrhip_get_option(lsqrhip_handle_t h, const char *name, int64_t 
         // 1 own slice read in T | 2 `sums` is the long message | 4 norms gathered by the engine | 8 a sharded solve is open
         const ShardCtx &c = h->shard;
         *value = (c.own_in_T ? 1 : 0) | (c.vmax_msg ? 2 : 0) | (c.gath != nullptr ? 4 : 0) | (c.active ? 8 : 0);
-    } else if (k == "shard_overlap" || k == "shard_parts") {
-        // the schedule the engine of this handle REALLY runs (a requested overlap that could not be set up is off here)
-        *value = shard_effective(h, k == "shard_parts");
+    } else if (k == "shard_overlap" || k == "shard_parts" || k == "shard_copy") {
+        // the schedule the engine of this handle REALLY runs (a requested overlap that could not be set up is off here;
+        // shard_copy: the n-vector exchanges are copies between mapped buffers, not RCCL send / receive kernels)
+        *value = shard_effective(h, k == "shard_overlap" ? 0 : (k == "shard_parts" ? 1 : 2));
     } else return fail(LSQRHIP_ERR_ARG, "unknown option: " + k);
     return LSQRHIP_OK;
 }

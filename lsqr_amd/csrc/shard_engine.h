@@ -157,6 +157,15 @@ struct ShardGroup {
     int parts = 1;
     int msg = 4;                   // doubles a rank contributes to the exchange of the norms: 4, or SHARD_MSG when its piece
                                    // maxima of |v_q| ride along (every matrix in column-swept row blocks: csb.h)
+    // One process per GPU with LSQRHIP_SHARD_COPY=1 ("ipc", round 5): the n-vector exchanges are PULLS by the copy engines
+    // from the peers' buffers, which hipIpcOpenMemHandle maps into this process -- no RCCL send / receive kernel takes CUs
+    // from sweeps that hold every CU and all of its LDS.  RCCL keeps the all-gather of the norms (<= 512 bytes per rank:
+    // a one-workgroup kernel that is also the fence in front of the pulls of v) and an 8-byte all-gather as the fence in
+    // front of the pulls of T.  peer*[p]: rank p's T, V, xfull, sefull as seen from here (own entry: the local buffer).
+    bool ipc = false;
+    std::vector<char *> peerT, peerV, peerX, peerSE;
+    std::vector<void *> ipc_opened;   // what hipIpcCloseMemHandle must see again
+    double *bar = nullptr;            // [1 + P] the fence's all-gather
     // one captured batch of `poll_every` iterations -- stages AND exchanges of every local rank (capture_group_batch)
     hipGraphExec_t gexec = nullptr;
     std::vector<int> gexec_epoch;  // the ranks' graph_epoch at capture
@@ -165,11 +174,12 @@ struct ShardGroup {
 
 static H *lsqrhip_group_rank0(H *h) { return h->group->r[0].h; }
 // option "shard_overlap" / "shard_parts": what the group this handle belongs to runs (0 / 1: no group)
-static int64_t shard_effective(const H *h, bool parts)
+static int64_t shard_effective(const H *h, int what)   // 0 overlap | 1 parts | 2 exchanges as copies
 {
     const ShardGroup *g = h->group ? h->group : h->mp;
-    if (g == nullptr) return parts ? 1 : 0;
-    return parts ? (g->overlap ? g->parts : 1) : g->overlap;
+    if (g == nullptr) return what == 1 ? 1 : 0;
+    if (what == 2) return (g->ipc || (g->loopback && g->P > 1)) ? 1 : 0;
+    return what == 1 ? (g->overlap ? g->parts : 1) : g->overlap;
 }
 static H *log_owner(H *h) { return h->group && !h->group->r.empty() && h->group->r[0].h ? h->group->r[0].h : h; }
 
@@ -177,6 +187,12 @@ static void free_group(ShardGroup *g)
 {
     if (!g) return;
     if (g->gexec) (void)hipGraphExecDestroy(g->gexec);
+    if (!g->r.empty() && (g->bar || !g->ipc_opened.empty())) {
+        (void)hipSetDevice(g->r[0].dev >= 0 ? g->r[0].dev : 0);
+        (void)hipDeviceSynchronize();   // (no copy of ours may still read a peer's buffer)
+        for (void *p : g->ipc_opened) (void)hipIpcCloseMemHandle(p);
+        if (g->bar) (void)hipFree(g->bar);
+    }
 
     for (size_t i = 0; i < g->ev.size(); ++i) {
         (void)hipSetDevice(g->r[i].dev >= 0 ? g->r[i].dev : 0);
@@ -316,6 +332,9 @@ static int pull_end(PullBatch &b)
         }
     return LSQRHIP_OK;
 }
+// (one process per GPU with copies over IPC-mapped buffers: defined behind the exchanges)
+static int ipc_fence(ShardGroup &g);
+static int ipc_pull(PullBatch &b, int p, void *d, const void *s, size_t bytes);
 // element i of a vector buffer (binary64 or REAL32 elements)
 static inline char *at(double *base, size_t i, size_t esz) { return reinterpret_cast<char *>(base) + i * esz; }
 
@@ -350,6 +369,23 @@ static int ex_scalars(ShardGroup &g, int k, bool with_v = false, bool fused = fa
         RET(fence_ranks(g));
         if (!fused)
             for (ShardRank &q : g.r) RET(sum_ranks(q, q.gath));
+        return LSQRHIP_OK;
+    }
+    if (g.P > 1 && g.ipc) {
+        // the norms by RCCL (one tiny kernel) -- which, complete on this rank, says every rank's v_q is final: the
+        // slices are then PULLED by the copy engines, every peer's at once.  (What follows reads v only after the pulls:
+        // pull_end makes the stream wait.  The peers' next write of v_q lies behind the next exchange of norms.)
+        ShardRank &q = g.r[0];
+        NCCLCHK(rc->AllGather(q.sums, q.gath, msg, ncclDouble, q.comm, q.h->stream));
+        if (with_v && c > 0) {
+            PullBatch pb;
+            RET(pull_begin(pb, g, q, q.h->stream));
+            for (int p = 0; p < g.P; ++p)
+                if (p != q.grank)
+                    RET(ipc_pull(pb, p, at(q.V, (size_t)p * c, g.esz), g.peerV[(size_t)p] + (size_t)p * c * g.esz, c * g.esz));
+            RET(pull_end(pb));
+        }
+        if (!fused) RET(sum_ranks(q, q.gath));
         return LSQRHIP_OK;
     }
     if (g.P > 1) {
@@ -387,6 +423,16 @@ static int ex_scatter(ShardGroup &g)  // slice q of every rank's T -> rank q's R
         }
         return fence_ranks(g);
     }
+    if (g.ipc) {   // every rank's T complete (the fence), then slice q of every peer's T pulled into R[peer]
+        ShardRank &q = g.r[0];
+        RET(ipc_fence(g));
+        PullBatch pb;
+        RET(pull_begin(pb, g, q, q.h->stream));
+        for (int p = 0; p < g.P; ++p)
+            if (p != q.grank)
+                RET(ipc_pull(pb, p, at(q.R, (size_t)p * c, e), g.peerT[(size_t)p] + (size_t)q.grank * c * e, c * e));
+        return pull_end(pb);   // (the peers overwrite T behind the next exchange of norms: every pull is done by then)
+    }
     // the rank's own slice never leaves the device (nor T: k_rs_combine reads it there); the others go to their
     // owners over all links at once
     NCCLCHK(rc->GroupStart());
@@ -422,6 +468,21 @@ static int ex_gather(ShardGroup &g, bool x_too, bool se_too)  // in-place all-ga
         }
         return fence_ranks(g);
     }
+    if (g.ipc) {   // fence, pulls, fence: what follows (the next solve's first stage) may overwrite the sources
+        ShardRank &q = g.r[0];
+        RET(ipc_fence(g));
+        PullBatch pb;
+        RET(pull_begin(pb, g, q, q.h->stream));
+        for (int p = 0; p < g.P; ++p) {
+            if (p == q.grank) continue;
+            const size_t o = (size_t)p * c;
+            if (!x_too) RET(ipc_pull(pb, p, at(q.V, o, e), g.peerV[(size_t)p] + o * e, c * e));
+            if (x_too) RET(ipc_pull(pb, p, at(q.xfull, o, e), g.peerX[(size_t)p] + o * e, c * e));
+            if (se_too) RET(ipc_pull(pb, p, at(q.sefull, o, e), g.peerSE[(size_t)p] + o * e, c * e));
+        }
+        RET(pull_end(pb));
+        return ipc_fence(g);
+    }
     NCCLCHK(rc->GroupStart());
     for (ShardRank &q : g.r) {
         const size_t o = (size_t)q.grank * c;
@@ -430,6 +491,101 @@ static int ex_gather(ShardGroup &g, bool x_too, bool se_too)  // in-place all-ga
         if (se_too) NCCLCHK(rc->AllGather(at(q.sefull, o, e), q.sefull, c, vtype, q.comm, q.h->stream));
     }
     NCCLCHK(rc->GroupEnd());
+    return LSQRHIP_OK;
+}
+
+// ---- one process per GPU, exchanges as copies over IPC-mapped buffers (ShardGroup::ipc) ---------------------------
+// `when every rank's stream has come this far, go on`: an 8-byte all-gather (one workgroup for a few microseconds)
+static int ipc_fence(ShardGroup &g)
+{
+    ShardRank &q = g.r[0];
+    NCCLCHK(rccl()->AllGather(g.bar, g.bar + 1, 1, ncclDouble, q.comm, q.h->stream));
+    return LSQRHIP_OK;
+}
+// this rank pulls `bytes` from peer `p`'s buffer on the copy stream of that peer (PullBatch: all peers at once)
+static int ipc_pull(PullBatch &b, int p, void *d, const void *s, size_t bytes)
+{
+    if (!bytes) return LSQRHIP_OK;
+    ShardRank &q = *b.q;
+    hipStream_t st = b.base;
+    if (b.streams) {
+        const int i = p % COPY_STREAMS;
+        st = q.ps[(size_t)i];
+        if (!(b.used & (1u << i))) HIPCHK(hipStreamWaitEvent(st, q.eb, 0));
+        b.used |= 1u << i;
+    }
+    HIPCHK(hipMemcpyAsync(d, s, bytes, hipMemcpyDeviceToDevice, st));
+    return LSQRHIP_OK;
+}
+// Maps every peer's T, V, xfull, sefull into this process.  Collective: every rank calls it; the handles travel by an
+// all-gather on the communicator, and so does the verdict -- the ranks switch to copies together or not at all.
+static int ipc_setup(ShardGroup &g)
+{
+    ShardRank &q = g.r[0];
+    Rccl *rc = rccl();
+    const int P = g.P, me = q.grank;
+    constexpr int NB = 4;
+    HIPCHK(hipSetDevice(q.h->device));
+    HIPCHK(hipMalloc((void **)&g.bar, sizeof(double) * (size_t)(1 + P)));
+    HIPCHK(hipMemset(g.bar, 0, sizeof(double) * (size_t)(1 + P)));
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handles travel as 64-byte records");
+    std::vector<hipIpcMemHandle_t> mine(NB), all((size_t)NB * P);
+    double *bufs[NB] = {q.T, q.V, q.xfull, q.sefull};
+    int ok = 1;
+    for (int i = 0; i < NB; ++i)
+        if (hipIpcGetMemHandle(&mine[(size_t)i], bufs[i]) != hipSuccess) {
+            ok = 0;
+            (void)hipGetLastError();
+        }
+    char *d_send = nullptr, *d_recv = nullptr;
+    HIPCHK(hipMalloc((void **)&d_send, 64 * NB + 64));
+    HIPCHK(hipMalloc((void **)&d_recv, (size_t)(64 * NB + 64) * P));
+    std::vector<char> rec(64 * NB + 64, 0), recs((size_t)(64 * NB + 64) * P);
+    std::memcpy(rec.data(), mine.data(), 64 * NB);
+    rec[64 * NB] = (char)ok;
+    auto exchange = [&]() -> int {
+        HIPCHK(hipMemcpy(d_send, rec.data(), rec.size(), hipMemcpyHostToDevice));
+        NCCLCHK(rc->AllGather(d_send, d_recv, rec.size(), ncclChar, q.comm, q.h->stream));
+        HIPCHK(hipStreamSynchronize(q.h->stream));
+        HIPCHK(hipMemcpy(recs.data(), d_recv, recs.size(), hipMemcpyDeviceToHost));
+        return LSQRHIP_OK;
+    };
+    int rcx = exchange();
+    if (rcx == LSQRHIP_OK) {
+        for (int p = 0; p < P; ++p) ok = ok && recs[(size_t)p * rec.size() + 64 * NB] != 0;
+        g.peerT.assign((size_t)P, nullptr);
+        g.peerV.assign((size_t)P, nullptr);
+        g.peerX.assign((size_t)P, nullptr);
+        g.peerSE.assign((size_t)P, nullptr);
+        std::vector<char *> *dst[NB] = {&g.peerT, &g.peerV, &g.peerX, &g.peerSE};
+        for (int p = 0; p < P && ok; ++p)
+            for (int i = 0; i < NB; ++i) {
+                if (p == me) {
+                    (*dst[i])[(size_t)p] = reinterpret_cast<char *>(bufs[i]);
+                    continue;
+                }
+                hipIpcMemHandle_t hd;
+                std::memcpy(&hd, recs.data() + (size_t)p * rec.size() + 64 * i, 64);
+                void *ptr = nullptr;
+                if (hipIpcOpenMemHandle(&ptr, hd, hipIpcMemLazyEnablePeerAccess) != hipSuccess || ptr == nullptr) {
+                    ok = 0;
+                    (void)hipGetLastError();
+                    break;
+                }
+                g.ipc_opened.push_back(ptr);
+                (*dst[i])[(size_t)p] = reinterpret_cast<char *>(ptr);
+            }
+        // the verdict: every rank must have every buffer of every peer
+        rec[64 * NB] = (char)ok;
+        rcx = exchange();
+        if (rcx == LSQRHIP_OK)
+            for (int p = 0; p < P; ++p) ok = ok && recs[(size_t)p * rec.size() + 64 * NB] != 0;
+    }
+    (void)hipFree(d_send);
+    (void)hipFree(d_recv);
+    RET(rcx);
+    g.ipc = ok != 0;
+    g.copy_streams = env_int("LSQRHIP_SHARD_COPY_STREAMS", 1) != 0;
     return LSQRHIP_OK;
 }
 
@@ -659,7 +815,7 @@ static int enqueue_iterations(ShardGroup &g, int count)
 static bool group_graph_wanted(const ShardGroup &g)
 {
     const int mode = env_int("LSQRHIP_SHARD_GRAPH", -1);   // (read at every solve: the tests switch it)
-    if (mode == 0 || g.graph_state < 0 || g.r.size() != 1 || g.overlap) return false;
+    if (mode == 0 || g.graph_state < 0 || g.r.size() != 1 || g.overlap || g.ipc) return false;   // (ipc: copy streams fork)
     return g.P == 1 || mode == 1;
 }
 
@@ -1155,6 +1311,9 @@ extern "C" int lsqrhip_shard_comm_init(lsqrhip_handle_t h, int world, int rank, 
             g->parts = std::min(std::max(env_int("LSQRHIP_SHARD_PARTS", 2), 2), 4);
         }
     }
+    // LSQRHIP_SHARD_COPY=1 (set on EVERY rank): the n-vector exchanges as copies over IPC-mapped buffers (ipc_setup).  With
+    // the plain schedule only: the overlapped one keeps RCCL on its second communicator.
+    if (rc == LSQRHIP_OK && world > 1 && !g->overlap && env_int("LSQRHIP_SHARD_COPY", 0) != 0) rc = ipc_setup(*g);
     if (rc == LSQRHIP_OK) rc = agree_norm_exp(*g);
     if (rc != LSQRHIP_OK) {
         q.h = nullptr;  // not ours to destroy

@@ -394,12 +394,14 @@ def run_distributed(args):
     # graph   : the plain schedule's batches captured in a hipGraph, RCCL's kernels with them (LSQRHIP_SHARD_GRAPH=1)
     # overlap : the two n-vector exchanges in parts on a stream of their own beside the products (LSQRHIP_SHARD_OVERLAP=1:
     #           the rank's layouts are rebuilt for it, a second communicator is split off)
+    # copy    : the plain schedule, exchanges as copy-engine pulls over IPC-mapped buffers (LSQRHIP_SHARD_COPY=1)
     # Each is probed first -- 4 iterations against the plain engine's, which was held to the Python driver above: they
     # must agree to 1e-12 on every rank -- then timed like the plain one.  `value` = the best VALIDATED schedule.
     # None of this has run over xGMI before the driver's multi-GPU run: a hang inside RCCL cannot be recovered from, so
     # a watchdog prints the line as it stands (plain schedule, the failing variant named) and ends the job cleanly.
     # (a run with LSQRHIP_SHARD_OVERLAP / LSQRHIP_SHARD_GRAPH set in its environment measures that one schedule)
-    pinned = [k for k in ("LSQRHIP_SHARD_OVERLAP", "LSQRHIP_SHARD_GRAPH") if os.environ.get(k, "0") not in ("", "0")]
+    pinned = [k for k in ("LSQRHIP_SHARD_OVERLAP", "LSQRHIP_SHARD_GRAPH", "LSQRHIP_SHARD_COPY")
+              if os.environ.get(k, "0") not in ("", "0")]
     if rank == 0 and pinned:
         out["config"]["schedule"] = "as the environment says: " + ", ".join(f"{k}={os.environ[k]}" for k in pinned)
     want_variants = engine == "c++" and not pinned and (world > 1 or os.environ.get("LSQR_BENCH_VARIANTS") == "1") and \
@@ -466,12 +468,31 @@ def run_distributed(args):
         else:
             variants["overlap"] = {"validated": False, "error": err if not ok else "set-up failed on another rank"}
         del drv_ov, prob_ov
+        # copy : the plain schedule with the n-vector exchanges as copy-engine pulls from IPC-mapped peer buffers
+        #        (LSQRHIP_SHARD_COPY=1 at comm_init: a handle of its own) -- no RCCL send / receive kernel on the CUs
+        prob_cp, drv_cp, ok = None, None, True
+        state["doing"] = "copy (build + IPC handles)"
+        try:
+            with _Env({"LSQRHIP_SHARD_COPY": "1"}):
+                prob_cp = devgen.generate(spec, row0, nrows)
+                drv_cp = EngineSolver(prob_cp.solver, row0, cfg["m"], world, rank)
+            if int(prob_cp.solver.get_option("shard_copy")) != 1 and world > 1:
+                raise RuntimeError("the ranks could not map each other's buffers (hipIpcOpenMemHandle): shard_copy = 0")
+        except Exception as e:  # noqa: BLE001
+            ok, err = False, repr(e)
+        if all_ranks_ok(ok, dist, torch):
+            measure("copy", drv_cp, prob_cp, {},
+                    "the plain schedule, n-vector exchanges as copy-engine pulls over IPC-mapped buffers (no RCCL send / receive kernels)")
+        else:
+            variants["copy"] = {"validated": False, "error": err if not ok else "set-up failed on another rank"}
+        del drv_cp, prob_cp
         if rank == 0:
             best = max((k for k, v in variants.items() if v.get("validated")), key=lambda k: variants[k]["value"])
             out["value"] = variants[best]["value"]
             out["ms_per_step"] = variants[best]["ms_per_step"]
             out["config"]["schedule"] = best
             out["overlap"] = 1 if best == "overlap" else 0
+            out["copy"] = 1 if best == "copy" else 0
             if "result" in variants[best]:
                 out["result"] = variants[best]["result"]
             if out.get("value_1gpu_same_workload"):

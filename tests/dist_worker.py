@@ -3,8 +3,8 @@
     python tests/dist_worker.py RANK WORLD PORT CASE BACKEND OUT.npz
 
 BACKEND = numpy (CPU, gloo, oracle-backed stage stand-in) | hip / hip32 (C-ABI stages on cuda:0, gloo; binary64 / REAL32)
-        | engine / engine32 / engine_ov / engine32_ov (the C++ engine over RCCL, binary64 / REAL32, exchanges plain /
-          overlapped: the ranks SHARE cuda:0, each with a NCCL_HOSTID of its own -- lsqr_amd.dist_bench.share_one_gpu)."""
+        | engine / engine32 / engine_ov / engine32_ov / engine_copy / engine32_copy (the C++ engine over RCCL, binary64 /
+          REAL32, exchanges plain / overlapped / as copy-engine pulls over IPC-mapped buffers: the ranks SHARE cuda:0, each with a NCCL_HOSTID of its own -- lsqr_amd.dist_bench.share_one_gpu)."""
 import os
 import sys
 
@@ -63,6 +63,8 @@ def engine_rank(rank, world, port, case, backend, out):
     if backend.endswith("_ov"):
         os.environ["LSQRHIP_SHARD_OVERLAP"] = "1"
         os.environ["LSQRHIP_SHARD_WORLD"] = str(world)
+    if backend.endswith("_copy"):      # the n-vector exchanges as copy-engine pulls from IPC-mapped peer buffers
+        os.environ["LSQRHIP_SHARD_COPY"] = "1"
     from lsqr_amd.dist_bench import share_one_gpu
     assert share_one_gpu(rank)
     import torch
@@ -82,6 +84,8 @@ def engine_rank(rank, world, port, case, backend, out):
     wp = np.float32 if real32 else np.float64
     d_b = capi.DeviceBuffer.from_array((b if nrows else np.zeros(1)).astype(wp))
     eng = EngineSolver(s, row0, p.m, world, rank)
+    if backend.endswith("_copy"):
+        assert s.get_option("shard_copy") == 1, "LSQRHIP_SHARD_COPY=1 did not take (IPC handles refused?)"
     r = eng.solve(d_b.ptr.value, damp=o["damp"], atol=o["atol"], btol=o["btol"], conlim=o["conlim"], itnlim=o["itnlim"],
                   wantse=o["wantse"])
     r2 = eng.solve(d_b.ptr.value, damp=o["damp"], atol=o["atol"], btol=o["btol"], conlim=o["conlim"], itnlim=o["itnlim"],

@@ -30,6 +30,7 @@ def free_port():
 
 def run_world(case, world, backend, tmp_path):
     port = free_port()
+    os.makedirs(str(tmp_path), exist_ok=True)
     outs = [str(tmp_path / f"r{r}.npz") for r in range(world)]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dist_worker.py"), str(r), str(world), str(port),
@@ -155,3 +156,32 @@ def test_cpp_engine_real32_over_rccl_ranks_sharing_one_gpu(case, world, backend,
         assert abs(float(r["rnorm"]) - ref.rnorm) <= 2e-3 * ref.rnorm
     for r in res[1:]:
         assert np.array_equal(r["x"], res[0]["x"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case,world", [("random_over_se", 2), ("random_over_damped", 3), ("poisson_20x20_it50", 5),
+                                        ("empty_rows_cols_it20", 4), ("poisson_48x37_it100", 8), ("one_by_one", 2)])
+def test_exchanges_as_ipc_copies_between_processes_change_no_bit(case, world, tmp_path):
+    """LSQRHIP_SHARD_COPY=1 with one process per rank (round 5): every rank maps its peers' T, V, x and se buffers
+    (hipIpcGetMemHandle / hipIpcOpenMemHandle, the handles handed round by an all-gather on the communicator) and the
+    n-vector exchanges become copy-engine PULLS on a stream per peer -- no RCCL send / receive kernel; RCCL keeps the
+    all-gather of the norms (which is also the fence in front of the pulls of v) and an 8-byte all-gather in front of the
+    pulls of T.  Same stages, same buffers, same order of every sum: every output must equal the RCCL engine's bit for
+    bit, on every rank.  (Here the processes share cuda:0; on a node each has its own GPU and the pulls go over xGMI.)"""
+    rccl = run_world(case, world, "engine", tmp_path / "rccl")
+    copy = run_world(case, world, "engine_copy", tmp_path / "copy")
+    for a, b in zip(rccl, copy):
+        assert int(b["again_same"]) == 1
+        for k in ("istop", "itn", "anorm", "acond", "rnorm", "arnorm", "xnorm"):
+            assert a[k] == b[k], (k, a[k], b[k])
+        assert np.array_equal(a["x"], b["x"]) and np.array_equal(a["se"], b["se"])
+    check_against_oracle(case, copy)
+
+
+@pytest.mark.gpu
+def test_ipc_copies_real32(tmp_path):
+    rccl = run_world("random_over_se", 3, "engine32", tmp_path / "rccl")
+    copy = run_world("random_over_se", 3, "engine32_copy", tmp_path / "copy")
+    for a, b in zip(rccl, copy):
+        assert int(b["again_same"]) == 1 and a["itn"] == b["itn"] and a["rnorm"] == b["rnorm"]
+        assert np.array_equal(a["x"], b["x"]) and np.array_equal(a["se"], b["se"])

@@ -242,7 +242,7 @@ def test_rccl_ranks_sharing_one_gpu_through_bench_launcher(world, overlap, graph
     matrix.  graph = "1": LSQRHIP_SHARD_GRAPH=1, the batches of 16 iterations captured WITH their RCCL calls and replayed
     (40 iterations: two replays and an eager tail).
     overlap = "" (round 5): nothing pinned in the environment -- the launcher's own form.  The line then carries all three
-    schedules (plain, graph, overlap), each probed against the plain engine on four iterations and timed in the same
+    schedules (plain, graph, overlap, copy), each probed against the plain engine on four iterations and timed in the same
     invocation, `value` = the best validated one, and `inprocess_sharded_check` (skipped here: one device)."""
     import json
     import os
@@ -267,7 +267,7 @@ def test_rccl_ranks_sharing_one_gpu_through_bench_launcher(world, overlap, graph
     assert line["result"]["itn"] == K and line["value"] > 0
     if overlap in ("", "0") and not graph:     # nothing pinned: every schedule in the one invocation
         v = line["variants"]
-        assert set(v) == {"plain", "graph", "overlap"}, v
+        assert set(v) == {"plain", "graph", "overlap", "copy"}, v
         for name, e in v.items():
             assert e["validated"] is True and e["value"] > 0, (name, e)
         best = line["config"]["schedule"]
