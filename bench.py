@@ -473,7 +473,7 @@ def run_single(args):
         if "roofline" in g_inst:
             gen = dict(g_inst["roofline"])
             gen["workload"] = g_inst["workload"]
-            gen["rocprof_summary"] = "profiles/r04/poisson4000_val8_roofline.txt"
+            gen["rocprof_summary"] = "profiles/r05/poisson4000_val8_roofline.txt"
             out["roofline_general"] = gen
         else:
             out["roofline_general"] = g_inst

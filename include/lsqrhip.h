@@ -266,7 +266,13 @@ int lsqrhip_set_option(lsqrhip_handle_t h, const char *name, int64_t value);
  * "log_truncated": 1 when the last solve had more printable iterations than the log buffer holds
  * (itnlim / 10 + 64 records for n > 40): the earliest overflowing records were dropped, the record of
  * the stopping iteration is always kept (last slot).  "launches_mode1" / "launches_mode2": kernel
- * launches one product takes in the layout in use (for reading profiler output). */
+ * launches one product takes in the layout in use (for reading profiler output).
+ * Round 5: "csb_lockstep_mode1" / "_mode2" -- chunks per wave and lock-step step of the column-swept product in use
+ * (0: the free-running sweep, or another layout); "shard_overlap", "shard_parts", "shard_copy" -- the
+ * schedule the sharded engine of this handle REALLY runs (a requested overlap or copy mode that could not be set up
+ * reads 0); "shard_engine_flags" -- what the C++ engine left in this rank's stage context (0 between solves, also
+ * after an engine solve that failed half way: 1 own slice read in T | 2 long norms message | 4 norms gathered by the
+ * engine | 8 a sharded solve is open). */
 int lsqrhip_get_option(lsqrhip_handle_t h, const char *name, int64_t *value);
 /* Run all work of this handle on an externally owned hipStream_t (e.g. the
  * caller's torch stream); NULL restores the handle's own stream. */
