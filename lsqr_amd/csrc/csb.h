@@ -714,9 +714,10 @@ __device__ __forceinline__ void csb_group_max_rows(unsigned long long *__restric
 // HBM sum of its big columns on the coarse grid (taken and cleared with agent-scope atomics: the adds of other
 // workgroups' sweeps -- column splits -- were performed at memory, not in this XCD's L2).  One rounding per
 // part and one for their sum; the row's power of two is exact.
-__device__ __forceinline__ double csb_row_sum(const CsbMat &A, long long fine, int row, CsbGrid gr, bool coarse)
+__device__ __forceinline__ double csb_row_sum(const CsbMat &A, long long fine, int row, CsbGrid gr, bool coarse,
+                                              int e_known = INT_MIN)   // (the row's exponent, when the caller has loaded it)
 {
-    const int e = (int)A.rexp[row];
+    const int e = e_known != INT_MIN ? e_known : (int)A.rexp[row];
     double sum = ldexp((double)fine, gr.ef - 61 + e);
     if (coarse) {
         const long long c = (long long)__hip_atomic_load((unsigned long long *)&A.zc[row], __ATOMIC_RELAXED,
@@ -985,19 +986,39 @@ __global__ __launch_bounds__(CSB_BLOCK, 1) void k_spmv_csb(
         const long long g_first = (long long)row0 >> pc.L;
         const int ng = nr > 0 ? (int)((((long long)row0 + nr - 1) >> pc.L) - g_first) + 1 : 0;
         const bool inlds = ng <= CSB_GMX;
-        for (int rb = 0; rb < nr; rb += CSB_BLOCK) {     // (every wave runs every step: csb_group_max is a wave operation)
-            const int r = rb + tid;
-            unsigned hv = 0u;
-            if (r < nr) {
-                const double sum = csb_row_sum(A, (long long)acc[r], row0 + r, gr, big);
-                acc[r] = 0ull;
-                const VT yn = (VT)(cy * ((double)y[row0 + r] * sy) + sum);
-                y[row0 + r] = yn;
-                const double ys = (double)yn * nsc.s;
-                sq += ys * ys;
-                hv = csb_hi_up(fabs((double)yn));
+        // y and the rows' exponents of FOUR steps at a time are requested before any of them is used: 5 round trips to
+        // memory for the epilogue of a full block instead of 20 dependent ones (10-15 % of a launch that lives 200 us:
+        // one rank's block of config 4, mode 2).  (All 20 at once -- fully unrolled -- bloated the kernel past the
+        // instruction cache and spilled: slower.)
+        constexpr int EPG = 4;
+        for (int rb0 = 0; rb0 < nr; rb0 += EPG * CSB_BLOCK) {     // (every wave runs every step: csb_group_max is a wave operation)
+            VT yold[EPG];
+            int eold[EPG];
+#pragma unroll
+            for (int i = 0; i < EPG; ++i) {
+                const int r = rb0 + i * CSB_BLOCK + tid;
+                const bool in = r < nr;
+                yold[i] = in ? y[row0 + r] : (VT)0;
+                eold[i] = in ? (int)A.rexp[row0 + r] : 0;
             }
-            if (pieces) csb_group_max(A.ymax, pc, gmx, inlds, g_first, (long long)row0 + rb + (tid & ~(WAVE - 1)), hv);
+#pragma unroll
+            for (int i = 0; i < EPG; ++i) {
+                const int rb = rb0 + i * CSB_BLOCK;
+                if (rb < nr) {                   // (uniform)
+                    const int r = rb + tid;
+                    unsigned hv = 0u;
+                    if (r < nr) {
+                        const double sum = csb_row_sum(A, (long long)acc[r], row0 + r, gr, big, eold[i]);
+                        acc[r] = 0ull;
+                        const VT yn = (VT)(cy * ((double)yold[i] * sy) + sum);
+                        y[row0 + r] = yn;
+                        const double ys = (double)yn * nsc.s;
+                        sq += ys * ys;
+                        hv = csb_hi_up(fabs((double)yn));
+                    }
+                    if (pieces) csb_group_max(A.ymax, pc, gmx, inlds, g_first, (long long)row0 + rb + (tid & ~(WAVE - 1)), hv);
+                }
+            }
         }
         if (tid == 0) {  // the padding's dummy accumulator
             acc[A.R] = 0ull;
