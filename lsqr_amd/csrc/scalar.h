@@ -401,7 +401,13 @@ __global__ __launch_bounds__(SC_BLOCK) void k_s3_snap(const double *partials, in
     for (int i = threadIdx.x; i < (int)(sizeof(LsqrState) / sizeof(int)); i += SC_BLOCK) dst[i] = src[i];
     __threadfence_system();
     __syncthreads();
-    if (threadIdx.x == 0) st->batch = k + 1;
+    if (threadIdx.x == 0) {
+        st->batch = k + 1;
+        // the seal, last: every word of the snapshot is performed system-wide (fence + barrier above) before this store
+        // is issued, so a host that SPINS on it (solve_loop.h: ~10 us sooner than hipEventSynchronize wakes up) and
+        // then reads the slot reads the settled state
+        __hip_atomic_store(&(snap + (k & 1))->seal, k + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 // ---- riders -----------------------------------------------------------------------------

@@ -43,6 +43,7 @@
 //      SpMV -- was measured first: 73 us/iteration device time against 60 sequential.
 //      Cross-queue dependencies inside a hipGraph cost more than the bubbles they hide.)
 #pragma once
+#include <atomic>
 
 // ---------------------------------------------------------------------------
 // kernel launch helpers
@@ -961,8 +962,18 @@ static int solve_core(H *h, const double *b, bool b_on_device, double damp, doub
         // overlap device work.  Never beyond itnlim; after a stop inside batch k the kernels of
         // batch k+1 return at their first instruction (stop flag) and change nothing.
         int64_t outputs_in = -1;   // the batch the outputs were enqueued behind (enqueue_outputs), if any
+        // spin on the snapshot's seal instead of sleeping on the batch's event: only where the batch's last kernel writes
+        // the snapshot itself (pipelined schedules), the outputs need no later command of this stream (x copied by the
+        // batch: dev_out) and nobody asked for the log (copied out behind the loop).  LSQRHIP_SPIN_POLL=0: never.
+        static const int spin_env = env_int("LSQRHIP_SPIN_POLL", 1);
+        const bool spin_poll = spin_env != 0 && h->pipeline != 0 && dev_out && !want_log && !loop_events;
         bool loop1 = false;
         auto enqueue = [&](int64_t k) -> int {
+            if (spin_poll) {   // (the slot's seal down before the batch that will raise it is launched)
+                std::atomic_thread_fence(std::memory_order_seq_cst);
+                reinterpret_cast<volatile int &>(h->h_state[1 + (k & 1)].seal) = 0;
+                std::atomic_thread_fence(std::memory_order_seq_cst);
+            }
             HIPCHK(hipGraphLaunch(k == 0 ? h->gexec_first : h->gexec, s));
             // the snapshot in h_state[1 + (k & 1)]: written by the batch's last kernel itself (k_s3_snap), or copied
             if (!h->pipeline)
@@ -984,7 +995,28 @@ static int solve_core(H *h, const double *b, bool b_on_device, double damp, doub
             if (batch > max_batches)
                 return fail(LSQRHIP_ERR_HIP, "iteration loop did not terminate (device state not advancing)");
             if ((batch + 1) * G < (int64_t)itnlim) RET(enqueue(batch + 1));
-            HIPCHK(hipEventSynchronize(h->ev_batch[batch & 1]));
+            // Wait for batch `batch`.  Its last kernel (k_s3_snap) writes the settled state into the pinned slot and
+            // seals it; the host spins on the seal for up to 2 ms -- a short solve is over by then, and the spin sees
+            // it ~10 us before hipEventSynchronize would have woken (profiles/r05/k20_timeline.txt: 13 us from the
+            // last kernel's end to the return of the wait) -- then sleeps on the batch's event as before.
+            bool sealed = false;
+            if (spin_poll) {
+                const volatile int *seal = &h->h_state[1 + (batch & 1)].seal;
+                const int want = (int)(batch + 1);
+                const auto t_spin = std::chrono::steady_clock::now();
+                for (int it = 0;; ++it) {
+                    if (*seal == want) {
+                        sealed = true;
+                        break;
+                    }
+                    __builtin_ia32_pause();
+                    if ((it & 1023) == 1023 &&
+                        std::chrono::steady_clock::now() - t_spin > std::chrono::microseconds(2000))
+                        break;
+                }
+                std::atomic_thread_fence(std::memory_order_acquire);
+            }
+            if (!sealed) HIPCHK(hipEventSynchronize(h->ev_batch[batch & 1]));
             stopped_in = batch;
             if (h->h_state[1 + (batch & 1)].stop != 0) break;
             if ((batch + 1) * G >= (int64_t)itnlim)  // S3 stops at itnlim at the latest

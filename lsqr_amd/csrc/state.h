@@ -69,6 +69,10 @@ struct LsqrState {
     double t1, t2, t3;            // coefficients of the x/w update kernel
     // log-only extras ----------------------------------------------------------
     double alpha0, beta0, test2_0;
+    // The seal of a host snapshot (scalar.h k_s3_snap): 0 in the device state; in a pinned host slot the kernel writes
+    // batch + 1 LAST, behind a system-scope fence -- a host that reads it holds every other word of the snapshot.
+    int seal;
+    int pad_seal;
 };
 
 constexpr int LOG_STRIDE = 14;  // == LSQRHIP_LOG_STRIDE

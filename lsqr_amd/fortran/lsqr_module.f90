@@ -302,6 +302,8 @@ contains
       real(c_float), allocatable :: af(:)
       integer(c_int64_t) :: nz
 
+      if (wp /= c_float .and. wp /= c_double) &
+         error stop 'lsqr_solver_ez: the REAL128 build has no device path (the GPU computes in binary64); use lsqr_solver with a host aprod'
       if (size(a) /= size(irow) .or. size(a) /= size(icol)) call check(1_c_int)
       ir = irow            ! contiguous copies for the C side
       ic = icol

@@ -127,3 +127,51 @@ def test_host_layer_under_address_sanitizer(tmp_path):
     assert p.returncode == 0 and "AddressSanitizer" not in p.stderr and "LeakSanitizer" not in p.stderr, p.stderr[-3000:]
     lis = open(os.path.join(tmp, "LSQR.LIS")).read()
     assert len(re.findall(r"LSQR\s+appears to be successful", lis)) == 16
+
+
+def test_real128_build_of_the_host_layer_is_the_reference_in_binary128(tmp_path):
+    """`-DREAL128` (src/lsqr_kinds.F90:20-21; round 5): the host path -- `lsqr_solver` with a user `aprod`, `lsqr`, `acheck`,
+    `xcheck`, `lsqpblas_module` -- compiled in binary128 (lsqr_amd/lib/fmod128 + liblsqr_amd_f128.a).  The reference's
+    18-problem program, compiled unchanged against it, must write the SAME LSQR.LIS, byte for byte, as the reference's own
+    -DREAL128 build (oracle/_ref/lsqrtest128, oracle/Makefile) -- and in binary128 all 18 problems "appear to be
+    successful" (the REAL64 build fails problems 5 and 6 by rounding)."""
+    tmp = str(tmp_path)
+    for f in ("liblsqr_amd_f128.a", "fmod128/lsqr_module.mod"):
+        assert os.path.exists(os.path.join(LIB, f)), f"{f} missing: run __graft_entry__.build()"
+    ref_exe = os.path.join(ROOT, "oracle", "_ref", "lsqrtest128")
+    assert os.path.exists(ref_exe), "oracle/_ref/lsqrtest128 missing: make -C oracle ref"
+    exe = os.path.join(tmp, "lsqrtest128")
+    cmd = [FC, "-O2", "-I" + os.path.join(LIB, "fmod128"), os.path.join(REF, "test", "lsqrtest_module.f90"),
+           os.path.join(REF, "test", "lsqrtest.f90"), os.path.join(LIB, "liblsqr_amd_f128.a"), "-L" + LIB, "-llsqrhip",
+           "-Wl,-rpath," + LIB, "-o", exe]
+    p = subprocess.run(cmd, cwd=tmp, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    p = subprocess.run([exe], cwd=tmp, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    lis = open(os.path.join(tmp, "LSQR.LIS")).read()
+    refdir = os.path.join(tmp, "ref")
+    os.makedirs(refdir)
+    q = subprocess.run([ref_exe], cwd=refdir, capture_output=True, text=True, timeout=600)
+    assert q.returncode == 0, q.stderr[-2000:]
+    ref_lis = open(os.path.join(refdir, "LSQR.LIS")).read()
+    assert lis == ref_lis
+    assert len(re.findall(r"LSQR\s+appears to be successful", lis)) == 18
+    assert [int(t) for t in re.findall(r"istop\s*=\s*(\d+)", lis)] == [3] * 18
+
+
+def test_real128_ez_type_stops_with_a_message(tmp_path):
+    """The REAL128 build has no device path: `lsqr_solver_ez%initialize` says so instead of computing in binary64."""
+    tmp = str(tmp_path)
+    src = os.path.join(tmp, "ez128.f90")
+    with open(src, "w") as f:
+        f.write("program ez128\n use lsqr_kinds\n use lsqr_module\n implicit none\n type(lsqr_solver_ez) :: s\n"
+                " real(wp) :: a(1) = [1.0_wp]\n integer :: ir(1) = [1], ic(1) = [1]\n"
+                " call s%initialize(1, 1, a, ir, ic)\n print *, 'not reached'\nend program\n")
+    exe = os.path.join(tmp, "ez128")
+    p = subprocess.run([FC, "-O2", "-I" + os.path.join(LIB, "fmod128"), src, os.path.join(LIB, "liblsqr_amd_f128.a"),
+                        "-L" + LIB, "-llsqrhip", "-Wl,-rpath," + LIB, "-o", exe], cwd=tmp, capture_output=True, text=True,
+                       timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    p = subprocess.run([exe], cwd=tmp, capture_output=True, text=True, timeout=600)
+    assert p.returncode != 0 and "REAL128 build has no device path" in (p.stdout + p.stderr)
+    assert "not reached" not in p.stdout
