@@ -427,3 +427,89 @@ def test_piece_maxima_of_the_writing_product_are_those_of_the_pass(csb_env, real
             r = s.solve(p.b, 1e-3)    # (the second solve of a handle starts from sets the first one left)
             assert np.array_equal(r.x, out[-1][0]) and r.anorm == out[-1][1]
         assert np.array_equal(out[0][0], out[1][0]) and out[0][1:] == out[1][1:]
+
+
+@pytest.mark.parametrize("shape", ["rows of 9", "powerlaw rows of 2500", "long sweeps", "overlap plan", "real32"])
+def test_lock_step_sweep_changes_no_bit(csb_env, shape):
+    """Round 5: the 16 waves of a workgroup move in lock step -- gathers of a step, ONE barrier, then the next step's
+    stream -- K = 1 or 2 chunks per wave and step (csb.h "LOCK STEP"; LSQRHIP_CSB_LOCKSTEP, by shape when unset), where
+    rounds 2-4 let every wave run on its own (LSQRHIP_CSB_LOCKSTEP=0).  A schedule, not arithmetic: row sums are exact
+    integer sums, so products and solves must be IDENTICAL to the last bit in all three forms -- over blockings with
+    fewer chunks than waves, odd and even step counts, column splits, the 11-byte stream, the stripes of the sharded
+    engine's overlap plan (several chunk ranges per unit), REAL32 storage, and with x that holds inf / NaN / huge entries
+    (the outlier pass reads the stream a second time)."""
+    extra = {}
+    real32 = False
+    if shape == "rows of 9":
+        p = P.random_rows(6000, 2500, 9, seed=7, damp=1e-3)
+        blockings = ((None, None, 0), (64, None, 0), (1000, 2, 0), (700, 3, 1), (4097, None, 1))
+    elif shape == "powerlaw rows of 2500":
+        p = P.powerlaw_rows(5000, 3000, seed=7, dmin=3, dmax=2500, damp=1e-3)
+        blockings = ((None, None, 0), (333, None, 0), (900, 4, 1))
+    elif shape == "long sweeps":       # hundreds of chunks per wave and unit: many steps, both parities of the step count
+        p = P.random_rows(40000, 3000, 60, seed=11, damp=1e-3)
+        blockings = ((None, None, 0), (20000, None, 0), (13000, None, 1), (None, 2, 0))
+    elif shape == "overlap plan":
+        p = P.random_rows(60000, 12000, 10, seed=29, damp=1e-3)
+        blockings = ((None, None, 0),)
+        extra = {"LSQRHIP_SHARD_OVERLAP": "1", "LSQRHIP_SHARD_WORLD": "3", "LSQRHIP_SHARD_PARTS": "3"}
+    else:
+        p = P.random_rows(6000, 2500, 9, seed=7, damp=1e-3)
+        blockings = ((None, None, 0), (1000, 2, 0))
+        real32 = True
+    wp = np.float32 if real32 else np.float64
+    xp, yp = vecs(p)
+    xbad = xp.copy()
+    xbad[[3, 77, 1500]] = [np.inf, np.nan, 1e300]
+    if real32:
+        xbad[1500] = 3e38
+    a = p.a.astype(wp)
+    keys = ("LSQRHIP_CSB_LOCKSTEP",) + tuple(extra)
+    old = {k: os.environ.get(k) for k in keys}
+    try:
+        os.environ.update(extra)
+        for R, S, narrow in blockings:
+            csb_env(R)
+            os.environ.pop("LSQRHIP_CSB_S", None)
+            if S:
+                os.environ["LSQRHIP_CSB_S"] = str(S)
+            os.environ["LSQRHIP_CSB_NARROW"] = str(narrow)
+            out = []
+            for ls in ("0", "1", "2"):
+                os.environ["LSQRHIP_CSB_LOCKSTEP"] = ls
+                s = lsqr_solver_ez().initialize(p.m, p.n, a, p.irow, p.icol, itnlim=12, real32=real32)
+                assert s.info()["xlds"] == 3 and s.info()["xlds_t"] == 3
+                assert s.get_option("csb_lockstep_mode1") == int(ls) and s.get_option("csb_lockstep_mode2") == int(ls)
+                res = []
+                for xin in (xp, xbad):
+                    x, y = xin.astype(wp), yp.astype(wp)
+                    s.aprod(1, p.m, p.n, x, y)
+                    res.append(y)
+                x, y = xp.astype(wp), yp.astype(wp)
+                s.aprod(2, p.m, p.n, x, y)
+                res.append(x)
+                r = s.solve(p.b.astype(wp), 1e-3)
+                res += [r.x, np.array([r.itn, r.istop]), np.array([r.anorm, r.rnorm, r.arnorm, r.xnorm])]
+                out.append(res)
+            for other in out[1:]:
+                for u, v in zip(out[0], other):
+                    assert np.array_equal(u, v, equal_nan=True), (shape, R, S, narrow)
+    finally:
+        for k, v in old.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v
+
+
+def test_lock_step_by_shape_default():
+    """Unset, the build chooses the chunks per step by shape: 1, or 2 for long sweeps over sparse columns."""
+    old = os.environ.pop("LSQRHIP_CSB_LOCKSTEP", None)
+    try:
+        os.environ["LSQRHIP_CSB"] = "1"
+        p = P.random_rows(6000, 2500, 9, seed=7, damp=1e-3)
+        s = lsqr_solver_ez().initialize(p.m, p.n, p.a, p.irow, p.icol)
+        assert s.get_option("csb_lockstep_mode1") == 1 and s.get_option("csb_lockstep_mode2") == 1
+    finally:
+        os.environ.pop("LSQRHIP_CSB", None)
+        if old is not None:
+            os.environ["LSQRHIP_CSB_LOCKSTEP"] = old
