@@ -618,6 +618,8 @@ int main(int argc, char **argv)
         {"config 4: 10M x 10M x 100, 512 blocks, S = 1 (2 launches)", 10000000, 19532, 100.0, 512, 1},
         {"rank block of config 4 at N = 8: 1.25M x 10M x 100, 64 blocks, S = 4", 10000000, 19532, 100.0, 64, 4},
         {"config 5: 5M x 2M power law (21.3 per row), 256 blocks, S = 1", 2000000, 19532, 21.29, 256, 1},
+        {"transpose of the rank block: 10M x 1.25M x 12.5, 512 blocks, S = 1 (2 launches)", 1250000, 19532, 12.5, 512, 1},
+        {"transpose of config 5: 2M x 5M x 53, 103 -> 128 blocks of 15625, S = 2", 5000000, 15625, 53.2, 128, 2},
         {"config 3 at 100 per row: 4M x 1M, 256 blocks of 15625 rows, S = 1", 1000000, 15625, 100.0, 256, 1},
     };
     if (std::strchr(which, 'a')) {
