@@ -140,6 +140,7 @@ struct CsbMat {
     int NS, G, J, Pst;      // stripes = Pst slices x G parts; split sp = k * J + j sweeps the stripes q * G + k, q = j, j + J, ...
     const int *border;      // the launch order of the row blocks (position -> block), or null: natural order
     int sp0, sp1;           // the column splits of THIS launch: [sp0, sp1)
+    int barrier_a;             // lock step: a second barrier in front of the gathers (the first form; LSQRHIP_CSB_BARRIER_A)
     int stagger;               // lock step: every other workgroup of an XCD starts this many x 2048 cycles late (0: together)
     unsigned long long *ymax;  // or null: the piece maxima of |y| (csb_pieces(rows): the words the k_csb_xmax pass over y would
                                // leave), raised by the epilogue with atomic max -- all zero on entry.  The NEXT product (the
@@ -897,8 +898,8 @@ __global__ __launch_bounds__(CSB_BLOCK, 1) void k_spmv_csb(
             // (The first form also had a barrier in FRONT of the gathers -- "every wave's stream has landed" -- so that
             // no gather ever stood behind a stream line.  Behind the LAST stream lines of slower waves a gather waits
             // no longer than it would have at that barrier, and the L1 does not run dry in between: config 4's sweeps
-            // 2.89 -> 2.50 ms in scripts/csb_break.hip, profiles/r05/csb_break_d_single_barrier.txt.  CSB_BARRIER_A=1
-            // brings it back.)
+            // 2.89 -> 2.50 ms in scripts/csb_break.hip, profiles/r05/csb_break_d_single_barrier.txt; in the library it is
+            // slower on every shape, profiles/r05/lockstep_barrier_a.txt.  LSQRHIP_CSB_BARRIER_A=1 brings it back.)
             // The step count is the same for every wave (barriers inside); a wave without a real chunk in a step
             // loads the range's last chunk again (clamped) and adds nothing.
             constexpr int KK = K > 0 ? K : 1;
@@ -914,7 +915,7 @@ __global__ __launch_bounds__(CSB_BLOCK, 1) void k_spmv_csb(
                                 CsbRaw<NARROW> (&qn)[KK]) {
                 int rr[KK][CSB_U];
                 double xx[KK][CSB_U];
-                if (CSB_BARRIER_A) __builtin_amdgcn_s_barrier();   // A (the first form; see above)
+                if (CSB_BARRIER_A || A.barrier_a) __builtin_amdgcn_s_barrier();   // A (uniform; the first form: see above)
 #pragma unroll
                 for (int k = 0; k < KK; ++k) {
                     int col[CSB_U];

@@ -177,6 +177,7 @@ struct Csr {
     int *ccb = nullptr;           // [nchunks] first column of each chunk; narrow form: [nchunks * 4] of each segment
     bool cnarrow = false;         // 11 bytes per nonzero (csb.h "NARROW form")
     int crounds = 1;              // one launch per round of 256 units (1) or one launch over all of them (0): LSQRHIP_CSB_ROUNDS
+    int cbarrier_a = 0;           // lock step: the second barrier, in front of the gathers (LSQRHIP_CSB_BARRIER_A; by shape)
     int cstagger = 0;             // lock step: late start of every other workgroup of an XCD, x 2048 cycles (LSQRHIP_CSB_STAGGER)
     int clockstep = 2;            // chunks per wave and lock-step step of the sweep (csb.h "lock step"); 0: free-running waves
     // overlap plan of the sharded engine (csb.h "Column stripes / phases"); all off: NS = 1, border = null
@@ -1264,6 +1265,9 @@ static int build_csb(hipStream_t s, const int *rowk, const int *colk, const doub
             const double per_column = (double)nnz / std::max(1, nrb) / std::max(cols, 1);
             out.clockstep = (chunks_per_wave >= 256.0 && per_column < 1.0) ? 2 : 1;
         }
+        // the first form's second barrier, in front of the gathers: slower on every shape in the library (0.78 -> 0.84 ms at
+        // config 3 per 100, 2.40 -> 2.62 at config 4: profiles/r05/lockstep_barrier_a.txt), kept as a knob for the A/B
+        out.cbarrier_a = env_int("LSQRHIP_CSB_BARRIER_A", 0) != 0 ? 1 : 0;
         out.crounds = env_int("LSQRHIP_CSB_ROUNDS", 1) != 0 ? 1 : 0;
         const int sg = env_int("LSQRHIP_CSB_STAGGER", 0);
         out.cstagger = sg < 0 ? 0 : (sg > 64 ? 64 : sg);

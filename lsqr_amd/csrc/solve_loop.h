@@ -309,7 +309,7 @@ static void launch_csb_K(H *h, const SpmvArgs &a)
     const int rounds = c.crounds;   // (LSQRHIP_CSB_ROUNDS at create)
     const int S = std::max(c.S, 1);
     CsbMat A{c.cval, c.cidx, c.cdel, c.ccb, c.cptr, c.crs, c.nrb, c.R, c.rows, c.cols, c.rexp, c.zcoarse, 0, 0, S, c.zsplit,
-             c.cbad, std::max(c.Q, 1), c.gptr, c.NS, c.G, c.J, c.Pst, c.border, 0, S, c.cstagger,
+             c.cbad, std::max(c.Q, 1), c.gptr, c.NS, c.G, c.J, c.Pst, c.border, 0, S, c.cbarrier_a, c.cstagger,
              reinterpret_cast<unsigned long long *>(a.ymax_out)};
     bool first = head;
     for (int ph = ph0; ph < ph1; ++ph) {
