@@ -166,6 +166,7 @@ struct ShardGroup {
     std::vector<char *> peerT, peerV, peerX, peerSE;
     std::vector<void *> ipc_opened;   // what hipIpcCloseMemHandle must see again
     double *bar = nullptr;            // [1 + P] the fence's all-gather
+    double *bar2 = nullptr;           // ... and the one of the exchange stream (overlapped schedule)
     // one captured batch of `poll_every` iterations -- stages AND exchanges of every local rank (capture_group_batch)
     hipGraphExec_t gexec = nullptr;
     std::vector<int> gexec_epoch;  // the ranks' graph_epoch at capture
@@ -192,6 +193,7 @@ static void free_group(ShardGroup *g)
         (void)hipDeviceSynchronize();   // (no copy of ours may still read a peer's buffer)
         for (void *p : g->ipc_opened) (void)hipIpcCloseMemHandle(p);
         if (g->bar) (void)hipFree(g->bar);
+        if (g->bar2) (void)hipFree(g->bar2);
     }
 
     for (size_t i = 0; i < g->ev.size(); ++i) {
@@ -334,6 +336,7 @@ static int pull_end(PullBatch &b)
 }
 // (one process per GPU with copies over IPC-mapped buffers: defined behind the exchanges)
 static int ipc_fence(ShardGroup &g);
+static int ipc_fence2(ShardGroup &g);   // ... on the exchange stream and its communicator (overlapped schedule)
 static int ipc_pull(PullBatch &b, int p, void *d, const void *s, size_t bytes);
 // element i of a vector buffer (binary64 or REAL32 elements)
 static inline char *at(double *base, size_t i, size_t esz) { return reinterpret_cast<char *>(base) + i * esz; }
@@ -502,6 +505,12 @@ static int ipc_fence(ShardGroup &g)
     NCCLCHK(rccl()->AllGather(g.bar, g.bar + 1, 1, ncclDouble, q.comm, q.h->stream));
     return LSQRHIP_OK;
 }
+static int ipc_fence2(ShardGroup &g)
+{
+    ShardRank &q = g.r[0];
+    NCCLCHK(rccl()->AllGather(g.bar2, g.bar2 + 1, 1, ncclDouble, q.comm2, q.cstream));
+    return LSQRHIP_OK;
+}
 // this rank pulls `bytes` from peer `p`'s buffer on the copy stream of that peer (PullBatch: all peers at once)
 static int ipc_pull(PullBatch &b, int p, void *d, const void *s, size_t bytes)
 {
@@ -528,6 +537,8 @@ static int ipc_setup(ShardGroup &g)
     HIPCHK(hipSetDevice(q.h->device));
     HIPCHK(hipMalloc((void **)&g.bar, sizeof(double) * (size_t)(1 + P)));
     HIPCHK(hipMemset(g.bar, 0, sizeof(double) * (size_t)(1 + P)));
+    HIPCHK(hipMalloc((void **)&g.bar2, sizeof(double) * (size_t)(1 + P)));
+    HIPCHK(hipMemset(g.bar2, 0, sizeof(double) * (size_t)(1 + P)));
     static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handles travel as 64-byte records");
     std::vector<hipIpcMemHandle_t> mine(NB), all((size_t)NB * P);
     double *bufs[NB] = {q.T, q.V, q.xfull, q.sefull};
@@ -664,6 +675,18 @@ static int ov_scatter_part(ShardGroup &g, int k)
         HIPCHK(hipSetDevice(q.h->device));
         HIPCHK(hipStreamWaitEvent(q.cstream, q.evT[(size_t)k], 0));
     }
+    if (g.ipc) {   // every rank's phase k of mode 2 done (the fence on the exchange stream), then part k of my slice pulled
+        ShardRank &q = g.r[0];
+        size_t off, len;
+        part_of(g, q.grank, k, &off, &len);
+        RET(ipc_fence2(g));
+        PullBatch pb;
+        RET(pull_begin(pb, g, q, q.cstream));
+        for (int p = 0; p < g.P; ++p)
+            if (p != q.grank && len)
+                RET(ipc_pull(pb, p, at(q.R, (size_t)p * c + off, e), g.peerT[(size_t)p] + ((size_t)q.grank * c + off) * e, len * e));
+        return pull_end(pb);
+    }
     NCCLCHK(rc->GroupStart());
     for (ShardRank &q : g.r) {
         size_t offq, lenq;
@@ -700,6 +723,21 @@ static int ov_gather_part(ShardGroup &g, int k)
             RET(pull_end(pb));
             HIPCHK(hipEventRecord(q.evAG[(size_t)k], q.cstream));
         }
+        return LSQRHIP_OK;
+    }
+    if (g.ipc) {   // (the exchange stream has waited for this rank's v_q: evV) every rank's v_q final -- one fence, in front
+        ShardRank &q = g.r[0];   // of part 0 -- then part k of every peer's slice pulled
+        if (k == 0) RET(ipc_fence2(g));
+        PullBatch pb;
+        RET(pull_begin(pb, g, q, q.cstream));
+        for (int p = 0; p < g.P; ++p) {
+            if (p == q.grank) continue;
+            size_t off, len;
+            part_of(g, p, k, &off, &len);
+            if (len) RET(ipc_pull(pb, p, at(q.V, (size_t)p * c + off, e), g.peerV[(size_t)p] + ((size_t)p * c + off) * e, len * e));
+        }
+        RET(pull_end(pb));
+        HIPCHK(hipEventRecord(q.evAG[(size_t)k], q.cstream));
         return LSQRHIP_OK;
     }
     NCCLCHK(rc->GroupStart());
@@ -1311,9 +1349,10 @@ extern "C" int lsqrhip_shard_comm_init(lsqrhip_handle_t h, int world, int rank, 
             g->parts = std::min(std::max(env_int("LSQRHIP_SHARD_PARTS", 2), 2), 4);
         }
     }
-    // LSQRHIP_SHARD_COPY=1 (set on EVERY rank): the n-vector exchanges as copies over IPC-mapped buffers (ipc_setup).  With
-    // the plain schedule only: the overlapped one keeps RCCL on its second communicator.
-    if (rc == LSQRHIP_OK && world > 1 && !g->overlap && env_int("LSQRHIP_SHARD_COPY", 0) != 0) rc = ipc_setup(*g);
+    // LSQRHIP_SHARD_COPY=1 (set on EVERY rank): the n-vector exchanges as copies over IPC-mapped buffers (ipc_setup) -- of
+    // the plain schedule and of the overlapped one (whose parts are then fenced by 8-byte all-gathers on the second
+    // communicator: the only RCCL kernels left beside the sweeps are one-workgroup ones)
+    if (rc == LSQRHIP_OK && world > 1 && env_int("LSQRHIP_SHARD_COPY", 0) != 0) rc = ipc_setup(*g);
     if (rc == LSQRHIP_OK) rc = agree_norm_exp(*g);
     if (rc != LSQRHIP_OK) {
         q.h = nullptr;  // not ours to destroy

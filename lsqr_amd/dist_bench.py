@@ -486,13 +486,32 @@ def run_distributed(args):
         else:
             variants["copy"] = {"validated": False, "error": err if not ok else "set-up failed on another rank"}
         del drv_cp, prob_cp
+        # overlap_copy : the overlapped schedule with its parts as copy-engine pulls (fences: 8-byte all-gathers on the
+        #        second communicator) -- the exchanges beside the products AND no send / receive kernel on the CUs
+        prob_oc, drv_oc, ok = None, None, True
+        state["doing"] = "overlap_copy (build + communicator + IPC handles)"
+        try:
+            with _Env({"LSQRHIP_SHARD_OVERLAP": "1", "LSQRHIP_SHARD_WORLD": str(world), "LSQRHIP_SHARD_COPY": "1"}):
+                prob_oc = devgen.generate(spec, row0, nrows)
+                drv_oc = EngineSolver(prob_oc.solver, row0, cfg["m"], world, rank)
+            if world > 1 and (int(prob_oc.solver.get_option("shard_copy")) != 1 or
+                              int(prob_oc.solver.get_option("shard_overlap")) != 1):
+                raise RuntimeError("overlap + copy could not be set up (shard_overlap / shard_copy = 0)")
+        except Exception as e:  # noqa: BLE001
+            ok, err = False, repr(e)
+        if all_ranks_ok(ok, dist, torch):
+            measure("overlap_copy", drv_oc, prob_oc, {"LSQRHIP_SHARD_OVERLAP": "1"},
+                    "exchanges in parts beside the products, as copy-engine pulls over IPC-mapped buffers")
+        else:
+            variants["overlap_copy"] = {"validated": False, "error": err if not ok else "set-up failed on another rank"}
+        del drv_oc, prob_oc
         if rank == 0:
             best = max((k for k, v in variants.items() if v.get("validated")), key=lambda k: variants[k]["value"])
             out["value"] = variants[best]["value"]
             out["ms_per_step"] = variants[best]["ms_per_step"]
             out["config"]["schedule"] = best
-            out["overlap"] = 1 if best == "overlap" else 0
-            out["copy"] = 1 if best == "copy" else 0
+            out["overlap"] = 1 if best in ("overlap", "overlap_copy") else 0
+            out["copy"] = 1 if best in ("copy", "overlap_copy") else 0
             if "result" in variants[best]:
                 out["result"] = variants[best]["result"]
             if out.get("value_1gpu_same_workload"):

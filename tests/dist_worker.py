@@ -59,10 +59,12 @@ def main():
 def engine_rank(rank, world, port, case, backend, out):
     """The C++ engine (csrc/shard_engine.h) on this rank's row block, RCCL between the ranks."""
     os.environ["LSQR_RANKS_SHARE_GPU"] = "1"
-    real32 = "32" in backend
-    if backend.endswith("_ov"):
+    real32 = "engine32" in backend
+    if backend.endswith("_ov") or backend.endswith("_ov_copy"):
         os.environ["LSQRHIP_SHARD_OVERLAP"] = "1"
         os.environ["LSQRHIP_SHARD_WORLD"] = str(world)
+    if "csb" in backend:                 # the blocks in column-swept layouts (with the overlap: built for the parts, the
+        os.environ["LSQRHIP_CSB"] = "1"  # products run phase by phase)
     if backend.endswith("_copy"):      # the n-vector exchanges as copy-engine pulls from IPC-mapped peer buffers
         os.environ["LSQRHIP_SHARD_COPY"] = "1"
     from lsqr_amd.dist_bench import share_one_gpu
@@ -86,6 +88,7 @@ def engine_rank(rank, world, port, case, backend, out):
     eng = EngineSolver(s, row0, p.m, world, rank)
     if backend.endswith("_copy"):
         assert s.get_option("shard_copy") == 1, "LSQRHIP_SHARD_COPY=1 did not take (IPC handles refused?)"
+        assert s.get_option("shard_overlap") == (1 if "_ov" in backend else 0)
     r = eng.solve(d_b.ptr.value, damp=o["damp"], atol=o["atol"], btol=o["btol"], conlim=o["conlim"], itnlim=o["itnlim"],
                   wantse=o["wantse"])
     r2 = eng.solve(d_b.ptr.value, damp=o["damp"], atol=o["atol"], btol=o["btol"], conlim=o["conlim"], itnlim=o["itnlim"],

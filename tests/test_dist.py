@@ -185,3 +185,20 @@ def test_ipc_copies_real32(tmp_path):
     for a, b in zip(rccl, copy):
         assert int(b["again_same"]) == 1 and a["itn"] == b["itn"] and a["rnorm"] == b["rnorm"]
         assert np.array_equal(a["x"], b["x"]) and np.array_equal(a["se"], b["se"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case,world,backend", [("poisson_20x20_it50", 5, "engine"), ("random_over_se", 2, "engine"),
+                                                ("poisson_48x37_it100", 3, "enginecsb"), ("empty_rows_cols_it20", 4, "engine")])
+def test_overlapped_exchanges_as_ipc_copies_change_no_bit(case, world, backend, tmp_path):
+    """LSQRHIP_SHARD_OVERLAP=1 + LSQRHIP_SHARD_COPY=1 between processes: the parts of T and of v travel as copy-engine pulls
+    on the exchange stream, fenced by 8-byte all-gathers on the second communicator -- the CU-free overlapped form.  Bit
+    for bit the plain RCCL engine ("csb": the ranks' blocks in column-swept layouts built for the parts, products phase
+    by phase)."""
+    rccl = run_world(case, world, backend, tmp_path / "rccl")
+    copy = run_world(case, world, backend + "_ov_copy", tmp_path / "copy")
+    for a, b in zip(rccl, copy):
+        assert int(b["again_same"]) == 1
+        for k in ("istop", "itn", "anorm", "acond", "rnorm", "arnorm", "xnorm"):
+            assert a[k] == b[k], (k, a[k], b[k])
+        assert np.array_equal(a["x"], b["x"]) and np.array_equal(a["se"], b["se"])

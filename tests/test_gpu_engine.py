@@ -267,12 +267,12 @@ def test_rccl_ranks_sharing_one_gpu_through_bench_launcher(world, overlap, graph
     assert line["result"]["itn"] == K and line["value"] > 0
     if overlap in ("", "0") and not graph:     # nothing pinned: every schedule in the one invocation
         v = line["variants"]
-        assert set(v) == {"plain", "graph", "overlap", "copy"}, v
+        assert set(v) == {"plain", "graph", "overlap", "copy", "overlap_copy"}, v
         for name, e in v.items():
             assert e["validated"] is True and e["value"] > 0, (name, e)
         best = line["config"]["schedule"]
         assert best in v and line["value"] == v[best]["value"] == max(e["value"] for e in v.values())
-        assert line["overlap"] == (1 if best == "overlap" else 0) and v["overlap"]["parts"] >= 2
+        assert line["overlap"] == (1 if best in ("overlap", "overlap_copy") else 0) and v["overlap"]["parts"] >= 2
         assert "skipped" in line["inprocess_sharded_check"]        # (one device: the form needs two)
     else:
         assert line["overlap"] == int(overlap) and set(line["variants"]) == {"plain"}
