@@ -222,6 +222,76 @@ __global__ __launch_bounds__(64) void k_shard_s2g(const double *__restrict__ src
     s2_step(st, sqrt(s0) * st->ns_inv, st->c2.skip != 0);
 }
 
+// k_shard_s2g + k_update_slice in ONE launch (round 5: an engine iteration has a launch fewer).  EVERY workgroup sums the
+// ranks' gathered norms in rank order and evaluates the rotation itself (scalar.h rot_step: a pure function) from inputs
+// that no workgroup of this launch writes -- alpha from the sums (or, product skipped, the alpha and sv step 2 then leaves
+// alone), beta, rhobar / phibar of the OTHER parity -- exactly as the one-handle loop's fused update does; workgroup 0 is
+// also the scalar machine (what k_shard_s2g was): sums[0..1], `live`, the state, the ranks' piece maxima side by side.
+// Same functions on the same inputs: t1, t2, t3, sv are the bits s2_step stores.
+template <typename VT>
+__global__ __launch_bounds__(VEC_BLOCK) void k_update_slice_g(VT *__restrict__ x, VT *__restrict__ w,
+                                                              const VT *__restrict__ Vq, VT *__restrict__ se, int64_t len,
+                                                              LsqrState *st, int *__restrict__ live,
+                                                              double *__restrict__ partials,
+                                                              const double *__restrict__ src, int P, int msg,
+                                                              double *__restrict__ sums, double *__restrict__ vmax)
+{
+    __shared__ double red[VEC_BLOCK / WAVE];
+    __shared__ double sh[8];
+    if (threadIdx.x == 0) {
+        double s0 = src[0], s1 = src[1];
+        for (int r = 1; r < P; ++r) {
+            s0 = s0 + src[msg * r];
+            s1 = s1 + src[msg * r + 1];
+        }
+        const bool stopped = st->stop != 0;
+        const bool skipped = st->c2.skip != 0;
+        const double alpha = skipped ? st->alpha : sqrt(s0) * st->ns_inv;
+        const double sv = skipped ? st->sv : (alpha > 0.0 ? 1.0 / alpha : 1.0);
+        const int k = st->itn & 1;
+        const Rot r = rot_step(st->rhobar2[k ^ 1], st->phibar2[k ^ 1], st->damp, st->damped, alpha, st->beta);
+        sh[0] = r.t1;
+        sh[1] = r.t2;
+        sh[2] = r.t3;
+        sh[3] = sv;
+        sh[4] = stopped ? 0.0 : 1.0;
+        sh[5] = s0;
+        sh[6] = s1;
+        sh[7] = st->wantse != 0 ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    const bool on = sh[4] != 0.0;
+    if (blockIdx.x == 0) {   // the scalar machine
+        if (vmax != nullptr && msg == SHARD_MSG)
+            for (int i = threadIdx.x; i < P * SHARD_NMAX; i += VEC_BLOCK)
+                vmax[i] = src[(i / SHARD_NMAX) * SHARD_MSG + 4 + i % SHARD_NMAX];
+        if (threadIdx.x == 0) {
+            sums[0] = sh[5];
+            sums[1] = sh[6];   // (step 3 reads it after the update)
+            *live = on ? 1 : 0;
+            if (on) s2_step(st, sqrt(sh[5]) * st->ns_inv, st->c2.skip != 0);
+        }
+    }
+    if (!on) return;
+    const double t1 = sh[0], t2 = sh[1], t3 = sh[2], sv = sh[3];
+    const bool wantse = sh[7] != 0.0;
+    double s = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * VEC_BLOCK;
+    for (int64_t i = (int64_t)blockIdx.x * VEC_BLOCK + threadIdx.x; i < len; i += stride) {
+        const double t = (double)w[i];
+        x[i] = (VT)(t1 * t + (double)x[i]);
+        const VT wn = (VT)(t2 * t + (double)Vq[i] * sv);
+        w[i] = wn;
+        if (wantse) {
+            const double d = (t3 * t) * (t3 * t);
+            se[i] = (VT)(d + (double)se[i]);
+        }
+        s += (double)wn * (double)wn;
+    }
+    const double tot = block_sum<VEC_BLOCK>(s, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = tot;
+}
+
 __global__ __launch_bounds__(VEC_BLOCK) void k_shard_s3w(const double *__restrict__ partials, int np,
                                                          double *__restrict__ wsq, const double *__restrict__ sums,
                                                          LsqrState *st, const int *__restrict__ live,
@@ -321,6 +391,18 @@ extern "C" int lsqrhip_shard_begin(lsqrhip_handle_t h, const double *d_b_local, 
     HIPCHK(hipMemsetAsync(c.live, 0, sizeof(int), s));
     c.active = true;
     return LSQRHIP_OK;
+}
+
+// this rank's slice of v and its x, w, se (element type: the handle's)
+struct VecPtrs {
+    void *X, *W, *SE;
+    const void *Vq;
+};
+static VecPtrs shard_vec_ptrs(H *h)
+{
+    ShardCtx &c = h->shard;
+    const size_t esz = h->f32 ? sizeof(float) : sizeof(double);
+    return VecPtrs{h->X, h->W, h->SE, reinterpret_cast<const char *>(c.V) + esz * (size_t)c.my0};
 }
 
 // the kernels of a stage that touch the vectors, for binary64 and REAL32 handles alike
@@ -455,12 +537,26 @@ static int shard_stage_phase(lsqrhip_handle_t h, int stage, int phase)
                            c.vmax_msg ? (const double *)(h->partials + SPMV_MAX_GRID) : (const double *)nullptr);
         break;
     case ST_UPDATE:
-        if (c.gath != nullptr)
-            hipLaunchKernelGGL(k_shard_s2g, dim3(1), dim3(64), 0, s, (const double *)(c.P > 1 ? c.gath : sums), c.P, c.msg,
-                               sums, st, c.live, c.vmax_msg ? h->xmax_part : (double *)nullptr);
-        else
-            hipLaunchKernelGGL(k_shard_s2, dim3(1), dim3(1), 0, s, (const double *)sums, st, c.live);
-        vec(stage);
+        if (c.gath != nullptr && env_int("LSQRHIP_SHARD_FUSE_S2", 1) != 0) {   // step 2 inside the update's launch
+            const double *src = c.P > 1 ? c.gath : sums;
+            double *vmx = c.vmax_msg ? h->xmax_part : (double *)nullptr;
+            const VecPtrs vp = shard_vec_ptrs(h);
+            if (h->f32)
+                hipLaunchKernelGGL(k_update_slice_g<float>, dim3(gq), dim3(VEC_BLOCK), 0, s, (float *)vp.X, (float *)vp.W,
+                                   (const float *)vp.Vq, (float *)vp.SE, c.mylen, st, c.live, h->partials, src, c.P, c.msg,
+                                   sums, vmx);
+            else
+                hipLaunchKernelGGL(k_update_slice_g<double>, dim3(gq), dim3(VEC_BLOCK), 0, s, (double *)vp.X, (double *)vp.W,
+                                   (const double *)vp.Vq, (double *)vp.SE, c.mylen, st, c.live, h->partials, src, c.P, c.msg,
+                                   sums, vmx);
+        } else {
+            if (c.gath != nullptr)
+                hipLaunchKernelGGL(k_shard_s2g, dim3(1), dim3(64), 0, s, (const double *)(c.P > 1 ? c.gath : sums), c.P,
+                                   c.msg, sums, st, c.live, c.vmax_msg ? h->xmax_part : (double *)nullptr);
+            else
+                hipLaunchKernelGGL(k_shard_s2, dim3(1), dim3(1), 0, s, (const double *)sums, st, c.live);
+            vec(stage);
+        }
         // step 3 AFTER the update, as in the reference (src/lsqr.f90:729-745, then :751-837): the x(1) of the
         // iteration log is the updated one; both are gated by `live`, which step 2 set for this iteration
         if (c.gath != nullptr) {

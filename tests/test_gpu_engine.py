@@ -738,3 +738,24 @@ def test_stage_driver_after_an_engine_solve_that_failed_half_way(monkeypatch, cs
         assert _flags(s) == 0
     finally:
         be.close()
+
+
+@pytest.mark.parametrize("ngpu", [1, 3])
+@pytest.mark.parametrize("name", ["random_over_se", "poisson_20x20_it50", "empty_rows_cols_it20", "t1_readme_damped"])
+def test_step_two_inside_the_update_launch_changes_no_bit(loopback, name, ngpu, monkeypatch):
+    """Round 5: the engine's scalar step 2 (alpha, the rotations, t1..t3) runs inside the slice update's launch -- every
+    workgroup evaluates the rotation itself from inputs the launch does not write, workgroup 0 is the scalar machine
+    (shard_api.h k_update_slice_g) -- instead of a one-workgroup kernel in front of it (LSQRHIP_SHARD_FUSE_S2=0).  Same
+    functions on the same inputs: x, se, every scalar and every record of the iteration log must be identical."""
+    p, o = CASES[name]
+    out = []
+    for fuse in ("0", "1"):
+        monkeypatch.setenv("LSQRHIP_SHARD_FUSE_S2", fuse)
+        h = sharded_handle(p, ngpu)
+        try:
+            out.append(_solve_with_log(h, p, o))
+        finally:
+            check(lib().lsqrhip_destroy(h))
+    a, b = out
+    assert a[2:5] == b[2:5]
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[5], b[5])
