@@ -314,7 +314,11 @@ int lsqrhip_create_sharded_f32(int m, int n, int64_t nnz, const int *irow, const
  *     ordinary handle from its own row block (rows renumbered from 1, all n columns), rank 0 obtains a
  *     128-byte RCCL id and the host program hands it to the others (any transport), every rank joins,
  *     and lsqrhip_shard_solve runs the whole loop -- kernels and RCCL calls -- from C++:
- *     d_b_local (m_p) in, d_x (n, and d_se if wantse) out on every rank, all device pointers. */
+ *     d_b_local (m_p) in, d_x (n, and d_se if wantse) out on every rank, all device pointers.
+ *     Environment of EVERY rank, read by lsqrhip_shard_comm_init: LSQRHIP_SHARD_OVERLAP=1 (with LSQRHIP_SHARD_WORLD at the
+ *     handle's create: exchanges in parts beside the products), LSQRHIP_SHARD_COPY=1 (round 5: the n-vector exchanges as
+ *     copy-engine pulls from the peers' buffers, mapped by hipIpcOpenMemHandle -- no RCCL send / receive kernel; both may
+ *     be set); lsqrhip_get_option "shard_overlap" / "shard_copy" report what took. */
 int lsqrhip_rccl_unique_id(char *out128);
 int lsqrhip_shard_comm_init(lsqrhip_handle_t h, int world, int rank, int64_t row0, int64_t m_global,
                             const char *id128);
