@@ -159,8 +159,8 @@ def test_cpp_engine_real32_over_rccl_ranks_sharing_one_gpu(case, world, backend,
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case,world", [("random_over_se", 2), ("random_over_damped", 3), ("poisson_20x20_it50", 5),
-                                        ("empty_rows_cols_it20", 4), ("poisson_48x37_it100", 8), ("one_by_one", 2)])
+@pytest.mark.parametrize("case,world", [("random_over_se", 2), ("random_over_damped", 3), ("empty_rows_cols_it20", 5),
+                                        ("poisson_20x20_it50", 4), ("shuffled_dups", 8), ("one_by_one", 2)])
 def test_exchanges_as_ipc_copies_between_processes_change_no_bit(case, world, tmp_path):
     """LSQRHIP_SHARD_COPY=1 with one process per rank (round 5): every rank maps its peers' T, V, x and se buffers
     (hipIpcGetMemHandle / hipIpcOpenMemHandle, the handles handed round by an all-gather on the communicator) and the
@@ -188,8 +188,8 @@ def test_ipc_copies_real32(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case,world,backend", [("poisson_20x20_it50", 5, "engine"), ("random_over_se", 2, "engine"),
-                                                ("poisson_48x37_it100", 3, "enginecsb"), ("empty_rows_cols_it20", 4, "engine")])
+@pytest.mark.parametrize("case,world,backend", [("random_over_damped", 5, "engine"), ("random_over_se", 2, "engine"),
+                                                ("empty_rows_cols_it20", 3, "enginecsb"), ("shuffled_dups", 4, "engine")])
 def test_overlapped_exchanges_as_ipc_copies_change_no_bit(case, world, backend, tmp_path):
     """LSQRHIP_SHARD_OVERLAP=1 + LSQRHIP_SHARD_COPY=1 between processes: the parts of T and of v travel as copy-engine pulls
     on the exchange stream, fenced by 8-byte all-gathers on the second communicator -- the CU-free overlapped form.  Bit
