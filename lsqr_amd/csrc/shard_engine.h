@@ -135,6 +135,12 @@ struct ShardRank {
     std::vector<hipStream_t> ps;
     std::vector<hipEvent_t> pe;
     hipEvent_t eb = nullptr;                           // "the base stream up to here" for the copy streams to wait on
+    // ... and a second set for batches that hang off the EXCHANGE stream (overlapped schedule): with one set the 512-byte
+    // pulls of the norms (compute stream) queued on the same copy streams behind that iteration's gather of v -- which
+    // the overlap is there to hide (round-4 advisor)
+    std::vector<hipStream_t> ps2;
+    std::vector<hipEvent_t> pe2;
+    hipEvent_t eb2 = nullptr;
     double *T = nullptr, *R = nullptr, *V = nullptr, *sums = nullptr, *gath = nullptr;  // exchange buffers (owned)
     double *xfull = nullptr, *sefull = nullptr, *bloc = nullptr;                         // P*chunk, P*chunk, m_p
 };
@@ -213,6 +219,9 @@ static void free_group(ShardGroup *g)
         for (hipEvent_t e : k.pe) if (e) (void)hipEventDestroy(e);
         for (hipStream_t st : k.ps) if (st) (void)hipStreamDestroy(st);
         if (k.eb) (void)hipEventDestroy(k.eb);
+        for (hipEvent_t e : k.pe2) if (e) (void)hipEventDestroy(e);
+        for (hipStream_t st : k.ps2) if (st) (void)hipStreamDestroy(st);
+        if (k.eb2) (void)hipEventDestroy(k.eb2);
         for (double *p : {k.T, k.R, k.V, k.sums, k.gath, k.xfull, k.sefull, k.bloc})
             if (p) (void)hipFree(p);
         if (g->owned && k.h) lsqrhip_destroy(k.h);
@@ -284,6 +293,9 @@ struct PullBatch {
     hipStream_t base = nullptr;
     bool streams = false;
     unsigned used = 0;   // copy streams this batch touched
+    std::vector<hipStream_t> *ps = nullptr;   // the set this batch uses (the rank's, or its exchange stream's)
+    std::vector<hipEvent_t> *pe = nullptr;
+    hipEvent_t *eb = nullptr;
 };
 static int pull_begin(PullBatch &b, const ShardGroup &g, ShardRank &dst, hipStream_t base)
 {
@@ -293,16 +305,20 @@ static int pull_begin(PullBatch &b, const ShardGroup &g, ShardRank &dst, hipStre
     b.used = 0;
     HIPCHK(hipSetDevice(dst.h->device));
     if (!b.streams) return LSQRHIP_OK;
-    if (dst.ps.empty()) {
-        dst.ps.assign(COPY_STREAMS, nullptr);
-        dst.pe.assign(COPY_STREAMS, nullptr);
+    const bool second = dst.cstream != nullptr && base == dst.cstream;
+    b.ps = second ? &dst.ps2 : &dst.ps;
+    b.pe = second ? &dst.pe2 : &dst.pe;
+    b.eb = second ? &dst.eb2 : &dst.eb;
+    if (b.ps->empty()) {
+        b.ps->assign(COPY_STREAMS, nullptr);
+        b.pe->assign(COPY_STREAMS, nullptr);
         for (int i = 0; i < COPY_STREAMS; ++i) {
-            HIPCHK(hipStreamCreateWithFlags(&dst.ps[(size_t)i], hipStreamNonBlocking));
-            HIPCHK(hipEventCreateWithFlags(&dst.pe[(size_t)i], hipEventDisableTiming));
+            HIPCHK(hipStreamCreateWithFlags(&(*b.ps)[(size_t)i], hipStreamNonBlocking));
+            HIPCHK(hipEventCreateWithFlags(&(*b.pe)[(size_t)i], hipEventDisableTiming));
         }
-        HIPCHK(hipEventCreateWithFlags(&dst.eb, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(b.eb, hipEventDisableTiming));
     }
-    HIPCHK(hipEventRecord(dst.eb, base));
+    HIPCHK(hipEventRecord(*b.eb, base));
     return LSQRHIP_OK;
 }
 static int pull(PullBatch &b, const ShardRank &src, void *d, const void *s, size_t bytes, hipEvent_t src_ready = nullptr)
@@ -312,8 +328,8 @@ static int pull(PullBatch &b, const ShardRank &src, void *d, const void *s, size
     hipStream_t st = b.base;
     if (b.streams) {
         const int i = src.grank % COPY_STREAMS;
-        st = q.ps[(size_t)i];
-        if (!(b.used & (1u << i))) HIPCHK(hipStreamWaitEvent(st, q.eb, 0));
+        st = (*b.ps)[(size_t)i];
+        if (!(b.used & (1u << i))) HIPCHK(hipStreamWaitEvent(st, *b.eb, 0));
         b.used |= 1u << i;
     }
     if (src_ready) HIPCHK(hipStreamWaitEvent(st, src_ready, 0));
@@ -327,10 +343,11 @@ static int pull_end(PullBatch &b)
 {
     if (!b.streams) return LSQRHIP_OK;
     ShardRank &q = *b.q;
+    (void)q;
     for (int i = 0; i < COPY_STREAMS; ++i)
         if (b.used & (1u << i)) {
-            HIPCHK(hipEventRecord(q.pe[(size_t)i], q.ps[(size_t)i]));
-            HIPCHK(hipStreamWaitEvent(b.base, q.pe[(size_t)i], 0));
+            HIPCHK(hipEventRecord((*b.pe)[(size_t)i], (*b.ps)[(size_t)i]));
+            HIPCHK(hipStreamWaitEvent(b.base, (*b.pe)[(size_t)i], 0));
         }
     return LSQRHIP_OK;
 }
@@ -517,10 +534,11 @@ static int ipc_pull(PullBatch &b, int p, void *d, const void *s, size_t bytes)
     if (!bytes) return LSQRHIP_OK;
     ShardRank &q = *b.q;
     hipStream_t st = b.base;
+    (void)q;
     if (b.streams) {
         const int i = p % COPY_STREAMS;
-        st = q.ps[(size_t)i];
-        if (!(b.used & (1u << i))) HIPCHK(hipStreamWaitEvent(st, q.eb, 0));
+        st = (*b.ps)[(size_t)i];
+        if (!(b.used & (1u << i))) HIPCHK(hipStreamWaitEvent(st, *b.eb, 0));
         b.used |= 1u << i;
     }
     HIPCHK(hipMemcpyAsync(d, s, bytes, hipMemcpyDeviceToDevice, st));
