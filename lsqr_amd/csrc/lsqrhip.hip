@@ -144,6 +144,10 @@ struct Csr {
     int *pdelta = nullptr;           // ... [PAT_MAX_E] column - row of each entry
     double *pval = nullptr;          // ... [PAT_MAX_E] value of each entry
     int npat = 0, npat_e = 0;        // patterns, entries in use
+    bool pat_wide = false;           // sell = 3, 257 ... 4096 patterns (pat.h "wide"): pid holds u16, the table is pent and stays in global memory
+    int pat_u = 2;                   // ... slices a wave takes through a trip together (LSQRHIP_PAT2_U)
+    void *pent = nullptr;            // ... [npat * pat_stride] PatEnt { value, column - row, length }: entry k of pattern p at p * pat_stride + k
+    int pat_stride = 1;              // ... the longest pattern
     bool nt = false;                 // short-row layouts: the matrix stream is loaded non-temporally (common.h ld_stream)
     unsigned *soff = nullptr;        // [nslices+1] first element (sell = 2: first record) of each 64-row slice
     uint4 *srec = nullptr;           // sell = 2: records (5 columns, 5 value codes, row length)
@@ -382,6 +386,7 @@ static void free_csr(Csr &c)
     if (c.pdesc) (void)hipFree(c.pdesc);
     if (c.pdelta) (void)hipFree(c.pdelta);
     if (c.pval) (void)hipFree(c.pval);
+    if (c.pent) (void)hipFree(c.pent);
     if (c.rb) (void)hipFree(c.rb);
     if (c.gpid) (void)hipFree(c.gpid);
     if (c.blk) (void)hipFree(c.blk);
@@ -482,7 +487,7 @@ static void launch_scan_small(hipStream_t s, unsigned *a, int64_t L)
 
 // Row patterns (pat.h): a matrix with <= 256 distinct rows keeps one byte per row.  On success out.sell = 3 and the
 // CSR arrays col / val are released; otherwise `out` is left as it was.
-static int try_pat(hipStream_t s, Csr &out, int64_t nnz, bool vals, unsigned long long *stats)
+static int try_pat(hipStream_t s, Csr &out, int64_t nnz, bool vals, unsigned long long *stats, bool *too_many = nullptr)
 {
     dbg_stage(s, vals ? "try_pat(vals) enter" : "try_pat(structure) enter");
     const int rows = out.rows;
@@ -509,7 +514,10 @@ static int try_pat(hipStream_t s, Csr &out, int64_t nnz, bool vals, unsigned lon
     int got[4];
     HIPCHK(hipMemcpyAsync(got, ctl, sizeof(got), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
-    if (got[1] != 0 || got[0] > PAT_MAX) return LSQRHIP_OK;
+    if (got[1] != 0 || got[0] > PAT_MAX) {
+        if (too_many) *too_many = got[0] > PAT_MAX;   // (the 257th distinct row stopped the pass: the wide table may hold them)
+        return LSQRHIP_OK;
+    }
     if (mode != 1 && (int64_t)got[0] * 16 > rows) return LSQRHIP_OK;  // too few rows per pattern to be a structure
     HIPCHK(s_desc.alloc(sizeof(unsigned) * PAT_MAX));
     HIPCHK(s_delta.alloc(sizeof(int) * PAT_MAX_E));
@@ -588,6 +596,93 @@ static int try_pat(hipStream_t s, Csr &out, int64_t nnz, bool vals, unsigned lon
     out.nstored = 0;
     // what one product reads of the matrix: a byte per row and the table
     out.bytes = (int64_t)rows + (int64_t)sizeof(unsigned) * PAT_MAX + 12ll * got[3];
+    return LSQRHIP_OK;
+}
+
+// Wide row patterns (pat.h): 257 ... 4096 distinct rows keep two bytes per row and their table in global memory.  Tried
+// when the one-byte table declined for the number of patterns alone.  On success out.sell = 3 with out.pat_wide set.
+static int try_pat2(hipStream_t s, Csr &out, int64_t nnz)
+{
+    dbg_stage(s, "try_pat2 enter");
+    const int rows = out.rows;
+    const int mode = env_int("LSQRHIP_PAT2", -1);
+    if (out.P > 1 || nnz <= 0 || rows <= 0 || mode == 0 || env_int("LSQRHIP_PAT", -1) == 0) return LSQRHIP_OK;
+    if (mode != 1 && rows < 16 * (PAT_MAX + 1)) return LSQRHIP_OK;   // (fewer than 16 rows per pattern whatever the count)
+    DevScratch s_keys, s_reps, s_slot, s_len, s_ctl, s_ent, s_pid;
+    HIPCHK(s_keys.alloc(sizeof(unsigned long long) * PAT2_TAB));
+    HIPCHK(s_reps.alloc(sizeof(int) * PAT2_TAB));
+    HIPCHK(s_len.alloc(sizeof(int) * PAT2_TAB));
+    HIPCHK(s_ctl.alloc(sizeof(int) * 4));
+    HIPCHK(hipMemsetAsync(s_keys.p, 0, sizeof(unsigned long long) * PAT2_TAB, s));
+    HIPCHK(hipMemsetAsync(s_reps.p, 0x7f, sizeof(int) * PAT2_TAB, s));
+    HIPCHK(hipMemsetAsync(s_ctl.p, 0, sizeof(int) * 4, s));
+    const int g = (int)std::min<int64_t>(((int64_t)rows + 255) / 256, 2048);
+    int *ctl = s_ctl.as<int>();
+    hipLaunchKernelGGL(k_pat_discover, dim3(g), dim3(256), 0, s, (const int *)out.rowptr, (const int *)out.col,
+                       (const double *)out.val, rows, 1, s_keys.as<unsigned long long>(), s_reps.as<int>(), ctl, PAT2_TAB,
+                       PAT2_MAX);
+    hipLaunchKernelGGL(k_pat2_lens, dim3(PAT2_TAB / 256), dim3(256), 0, s, (const int *)out.rowptr,
+                       (const unsigned long long *)s_keys.p, (const int *)s_reps.p, PAT2_TAB, s_len.as<int>());
+    HIPCHK(hipGetLastError());
+    int got[4];
+    HIPCHK(hipMemcpyAsync(got, ctl, sizeof(got), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    const int np = got[0];
+    if (got[1] != 0 || np > PAT2_MAX || np <= 0) return LSQRHIP_OK;
+    if (mode != 1 && (int64_t)np * 16 > rows) return LSQRHIP_OK;
+    // rank the keys: pattern p = the p-th smallest key, whatever order the rows arrived in
+    std::vector<unsigned long long> keys(PAT2_TAB);
+    std::vector<int> len(PAT2_TAB), slot_pat(PAT2_TAB, -1);
+    HIPCHK(hipMemcpyAsync(keys.data(), s_keys.p, sizeof(unsigned long long) * PAT2_TAB, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(len.data(), s_len.p, sizeof(int) * PAT2_TAB, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    std::vector<std::pair<unsigned long long, int>> order;
+    order.reserve((size_t)np);
+    for (int t = 0; t < PAT2_TAB; ++t)
+        if (keys[(size_t)t] != 0ull) order.emplace_back(keys[(size_t)t], t);
+    if ((int)order.size() != np) return LSQRHIP_OK;
+    std::sort(order.begin(), order.end());
+    int stride = 1;   // the longest pattern: entry k of pattern p at p * stride + k
+    for (int p = 0; p < np; ++p) {
+        const int t = order[(size_t)p].second, l = len[(size_t)t];
+        if (l < 0 || l > PAT_MAX_LEN) return LSQRHIP_OK;
+        slot_pat[(size_t)t] = p;
+        stride = std::max(stride, l);
+    }
+    const int64_t ne = (int64_t)np * stride;
+    if (ne > PAT2_MAX_E) return LSQRHIP_OK;
+    HIPCHK(s_slot.alloc(sizeof(int) * PAT2_TAB));
+    HIPCHK(s_ent.alloc(sizeof(PatEnt) * (size_t)ne));
+    HIPCHK(s_pid.alloc(sizeof(unsigned short) * (size_t)rows));
+    HIPCHK(hipMemcpyAsync(s_slot.p, slot_pat.data(), sizeof(int) * PAT2_TAB, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemsetAsync(s_ent.p, 0, sizeof(PatEnt) * (size_t)ne, s));
+    hipLaunchKernelGGL(k_pat2_fill, dim3(PAT2_TAB / 256), dim3(256), 0, s, (const int *)out.rowptr, (const int *)out.col,
+                       (const double *)out.val, (const int *)s_reps.p, (const int *)s_slot.p, PAT2_TAB, stride,
+                       s_ent.as<PatEnt>());
+    hipLaunchKernelGGL(k_pat2_assign, dim3(g), dim3(256), 0, s, (const int *)out.rowptr, (const int *)out.col,
+                       (const double *)out.val, rows, (const unsigned long long *)s_keys.p, (const int *)s_slot.p,
+                       (const PatEnt *)s_ent.p, PAT2_TAB, np, stride, s_pid.as<unsigned short>(), ctl);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(got, ctl, sizeof(got), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));   // (the host vectors above are read by the copies until here)
+    if (got[1] != 0) return LSQRHIP_OK;   // two different rows under one key
+    (void)hipFree(out.col);
+    (void)hipFree(out.val);
+    out.col = nullptr;
+    out.val = nullptr;
+    out.sell = 3;
+    out.pat_wide = true;
+    out.pat_u = std::min(std::max(env_int("LSQRHIP_PAT2_U", 2), 1), 2);
+    out.pat_stride = stride;
+    out.pid = s_pid.release<unsigned char>();
+    out.pent = s_ent.release<void>();
+    out.npat = np;
+    out.npat_e = (int)ne;
+    out.nslices = (rows + 63) / 64;
+    out.nblk = (out.nslices + SELL_SLICES - 1) / SELL_SLICES;
+    out.nstored = 0;
+    // what one product reads of the matrix: two bytes per row and the table
+    out.bytes = 2ll * rows + (int64_t)sizeof(PatEnt) * ne;
     return LSQRHIP_OK;
 }
 
@@ -775,7 +870,10 @@ static int build_csr_T(hipStream_t s, const int *d_keys, const int *d_other, con
     dbg_stage(s, "csr built");
     // short, even rows: sliced-ELL layout instead of row windows (sell.h)
     if (std::is_same<OffT, int>::value) {
-        int rcs = try_pat(s, out, nnz, true, (unsigned long long *)hist);   // rows that repeat: one byte per row (pat.h)
+        bool too_many = false;
+        int rcs = try_pat(s, out, nnz, true, (unsigned long long *)hist, &too_many);   // rows that repeat: one byte per row (pat.h)
+        // ... more than 256 of them: two bytes per row, the table through L2 (pat.h "wide")
+        if (rcs == LSQRHIP_OK && !out.sell && too_many) rcs = try_pat2(s, out, nnz);
         // ... rows whose column structure repeats, without a value dictionary: no column indices (pat.h)
         if (rcs == LSQRHIP_OK && !out.sell && ndict == 0) rcs = try_pat(s, out, nnz, false, (unsigned long long *)hist);
         if (rcs == LSQRHIP_OK && !out.sell) rcs = try_sell(s, out, nnz, dict, ndict, (unsigned long long *)hist);
@@ -2240,6 +2338,9 @@ extern "C" int lsqrhip_get_option(lsqrhip_handle_t h, const char *name, int64_t 
     } else if (k == "csb_splits_mode1" || k == "csb_splits_mode2") {
         const Csr &c = k == "csb_splits_mode1" ? h->A : h->AT;
         *value = c.csb ? c.S : 0;
+    } else if (k == "pat_wide_mode1" || k == "pat_wide_mode2") {   // patterns of the wide row-pattern table in use (0: another layout)
+        const Csr &c = k == "pat_wide_mode1" ? h->A : h->AT;
+        *value = c.pat_wide ? c.npat : 0;
     } else if (k == "csb_lockstep_mode1" || k == "csb_lockstep_mode2") {   // chunks per wave and lock-step step (0: free-running)
         const Csr &c = k == "csb_lockstep_mode1" ? h->A : h->AT;
         *value = c.csb ? c.clockstep : 0;

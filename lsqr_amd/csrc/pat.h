@@ -28,8 +28,9 @@
 // Chosen when the matrix has <= 256 distinct rows of <= 64 nonzeros, <= 1024 pattern entries, and at least 16 rows per
 // pattern.  LSQRHIP_PAT=0 never, =1 whenever the limits hold.
 //
-// Second half of the file: STRUCTURE patterns (sell = 4) -- the same table over (length, column offsets) alone, for rows
+// Second part of the file: STRUCTURE patterns (sell = 4) -- the same table over (length, column offsets) alone, for rows
 // whose values do not repeat (variable coefficients): 8-byte values column-major per slice and no column indices.
+// Third part: WIDE row patterns -- 257 ... 4096 distinct rows: two bytes per row, the table in global memory.
 #pragma once
 
 #include "common.h"
@@ -77,8 +78,10 @@ __device__ __forceinline__ unsigned long long pat_row_key(const int *__restrict_
 __global__ __launch_bounds__(256) void k_pat_discover(const int *__restrict__ rowptr, const int *__restrict__ col,
                                                       const double *__restrict__ val, int rows, int vals,
                                                       unsigned long long *__restrict__ keys, int *__restrict__ reps,
-                                                      int *__restrict__ ctl)
+                                                      int *__restrict__ ctl, int tab = PAT_TAB, int pmax = PAT_MAX)
 {
+    // (tab slots, a power of two; give up at the (pmax + 1)-th distinct key: PAT_TAB / PAT_MAX, or PAT2_TAB / PAT2_MAX for
+    // the wide table below)
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += stride) {
         if (*(volatile int *)&ctl[1] != 0) return;
@@ -88,15 +91,15 @@ __global__ __launch_bounds__(256) void k_pat_discover(const int *__restrict__ ro
             return;
         }
         const unsigned long long h = pat_row_key(col, val, q0, len, (int)r, vals);
-        unsigned slot = (unsigned)(h >> 11) & (PAT_TAB - 1);
+        unsigned slot = (unsigned)(h >> 11) & (unsigned)(tab - 1);
         int tries = 0;
-        for (; tries < PAT_TAB; ++tries) {
+        for (; tries < tab; ++tries) {
             // look before the exchange: a million interior rows of a stencil share ONE key, and a million compare-and-
             // swaps on one word take 11 ms; a device-scope load (the L2 of another XCD may hold the word as it was) does not
             unsigned long long old = __hip_atomic_load(&keys[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (old == 0ull) old = atomicCAS(&keys[slot], 0ull, h);
             if (old == 0ull) {
-                if (atomicAdd(&ctl[0], 1) >= PAT_MAX) ctl[1] = 1;
+                if (atomicAdd(&ctl[0], 1) >= pmax) ctl[1] = 1;
                 atomicMin(&reps[slot], (int)r);
                 break;
             }
@@ -106,9 +109,9 @@ __global__ __launch_bounds__(256) void k_pat_discover(const int *__restrict__ ro
                 break;
             }
             if (*(volatile int *)&ctl[1] != 0) return;
-            slot = (slot + 1) & (PAT_TAB - 1);
+            slot = (slot + 1) & (unsigned)(tab - 1);
         }
-        if (tries == PAT_TAB) {
+        if (tries == tab) {
             ctl[1] = 1;
             return;
         }
@@ -484,6 +487,287 @@ __global__ __launch_bounds__(SELL_BLOCK, 6) void k_spmv_spat(
             y[r] = yn;
             const double ys = (double)yn * nsc.s;
             sq += ys * ys;
+        }
+    }
+    const double tot = block_sum<SELL_BLOCK>(sq, red);
+    if (tid == 0) partials[wg] = tot;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// WIDE row patterns (sell = 3, Csr.pat_wide): 257 ... 4096 distinct rows -- a stencil whose coefficients are constant
+// on each of many regions (materials, refinement levels), every region with its own interior and interface rows.
+// The pattern number of a row takes two bytes and the table no longer fits the LDS of four workgroups per CU, so it
+// stays in global memory and is read through L1 / L2 (a megabyte at most, and the rows of one slice name the same few
+// patterns): a product moves 2 + 8 + 16 = 26 bytes per row, against the 65 of structure patterns.
+//
+//   pid[r]             = pattern of row r                                                      (u16)
+//   ent[p * stride + k] = { value, column - row, length of the pattern } of entry k of pattern p, 16 bytes: ONE request
+//                         per entry where the LDS table has two reads, and no descriptor to fetch first -- stride = the
+//                         longest pattern (>= 1), the length rides in every entry
+//
+// Same rows, same left-to-right sums from 0, the same contract: every bit of a product equals the other short-row
+// layouts'.
+//
+// What the kernel is short of is vector-memory INSTRUCTIONS, not bytes and not latency (16M-row mesh of 2304 patterns,
+// profiles/r05/wide_patterns.txt): with a descriptor and five entry requests per 64-row slice beside the eight of
+// k_spmv_pat a product took 124 us whatever the occupancy (4, 6, 8 workgroups per CU), however many slices went
+// through a trip together, with the entries requested a trip ahead (117 us), and with the entries requested by 8 of the
+// 64 lanes only (120 us: a gather costs the same whoever takes part); without the entry requests 90 us.  So:
+//   * no descriptor (the fixed stride above);
+//   * a slice whose rows all name ONE pattern -- the interior of a region, three slices in four on that mesh -- asks
+//     for its entries with ONE request, lane k for entry k, and hands them round with v_readlane; only a slice that
+//     crosses an interface requests entry k of every lane's own pattern, PAT_K requests (every slice that way: 127 us);
+//   * the trip is a software pipeline: pattern numbers of trip t + 2, entries of t + 1, gathered x of t.
+// Together 103-104 us on that mesh (0.50 of 8 TB/s on its 26 bytes per row; structure patterns, what the matrix had
+// before: 175 us; the one-byte kernel on a mesh of 9 patterns: 84 us), the same at 4 to 16 workgroups per CU.
+// Measured and dropped: the table of one-pattern slices through the scalar cache (s_load of the entries, once per
+// wave): 137 us -- the scalar waits stall the wave in front of its gathers.
+//
+// Build: k_pat_discover with the wide table; the keys are ranked on the HOST (4096 keys: one small copy each way --
+// pattern numbers do not depend on the order the rows arrived in there either); k_pat2_fill copies each pattern from its
+// first row and k_pat2_assign compares every row with its pattern entry by entry, bit by bit.
+// Chosen when the one-byte table declines for the number of patterns alone, with <= 4096 patterns of <= 64 nonzeros,
+// patterns x longest pattern <= 65536 and >= 16 rows per pattern.  LSQRHIP_PAT2=0 never, =1 whenever the limits hold.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int PAT2_MAX = 4096;      // patterns (two bytes per row)
+constexpr int PAT2_MAX_E = 65536;   // entries of the table: patterns x stride (1 MB)
+constexpr int PAT2_TAB = 16384;     // slots of the discovery table
+struct __align__(16) PatEnt {
+    double v;
+    int d;
+    int len;   // of the pattern the entry belongs to
+};
+static_assert(sizeof(PatEnt) == 16, "one 16-byte request per entry");
+
+// len[slot] = length of the first row under the key in that slot (-1: empty slot)
+__global__ __launch_bounds__(256) void k_pat2_lens(const int *__restrict__ rowptr,
+                                                   const unsigned long long *__restrict__ keys,
+                                                   const int *__restrict__ reps, int tab, int *__restrict__ len)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= tab) return;
+    const int rep = reps[t];
+    len[t] = keys[t] != 0ull ? rowptr[rep + 1] - rowptr[rep] : -1;
+}
+
+// the entries of every pattern from the first row under its key (slot_pat[slot] = pattern of the slot, -1: empty; the
+// table arrives zeroed: an empty pattern is one entry of length 0)
+__global__ __launch_bounds__(256) void k_pat2_fill(const int *__restrict__ rowptr, const int *__restrict__ col,
+                                                   const double *__restrict__ val, const int *__restrict__ reps,
+                                                   const int *__restrict__ slot_pat, int tab, int stride,
+                                                   PatEnt *__restrict__ ent)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= tab) return;
+    const int p = slot_pat[t];
+    if (p < 0) return;
+    const int rep = reps[t], q0 = rowptr[rep], len = rowptr[rep + 1] - q0;
+    for (int k = 0; k < len && k < stride; ++k) {
+        PatEnt e;
+        e.v = val[q0 + k];
+        e.d = col[q0 + k] - rep;
+        e.len = len;
+        ent[(size_t)p * stride + k] = e;
+    }
+}
+
+// pid[r] = pattern of row r, after comparing the row with it entry by entry (ctl[1] = 1 on any difference)
+__global__ __launch_bounds__(256) void k_pat2_assign(const int *__restrict__ rowptr, const int *__restrict__ col,
+                                                     const double *__restrict__ val, int rows,
+                                                     const unsigned long long *__restrict__ keys,
+                                                     const int *__restrict__ slot_pat, const PatEnt *__restrict__ ent,
+                                                     int tab, int npat, int stride, unsigned short *__restrict__ pid,
+                                                     int *__restrict__ ctl)
+{
+    const int64_t gstride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += gstride) {
+        if (*(volatile int *)&ctl[1] != 0) return;
+        const int q0 = rowptr[r], len = rowptr[r + 1] - q0;
+        const unsigned long long h = pat_row_key(col, val, q0, len, (int)r, 1);
+        unsigned slot = (unsigned)(h >> 11) & (unsigned)(tab - 1);
+        int p = -1;
+        for (int tries = 0; tries < tab; ++tries) {
+            const unsigned long long k = keys[slot];
+            if (k == h) {
+                p = slot_pat[slot];
+                break;
+            }
+            if (k == 0ull) break;
+            slot = (slot + 1) & (unsigned)(tab - 1);
+        }
+        bool same = p >= 0 && p < npat && len <= stride && ent[(size_t)p * stride].len == len;
+        for (int k = 0; same && k < len; ++k) {
+            const PatEnt e = ent[(size_t)p * stride + k];
+            same = e.len == len && e.d == col[q0 + k] - (int)r &&
+                   __double_as_longlong(e.v) == __double_as_longlong(val[q0 + k]);
+        }
+        if (!same) {
+            ctl[1] = 1;
+            return;
+        }
+        pid[r] = (unsigned short)p;
+    }
+}
+
+// One slice's entries on their way through the pipeline: q[0] alone when every row of the slice names one pattern
+// (`one`, wave-uniform; lane k holds entry k of it), else q[k] = entry k of the lane's own pattern p (-1: no row).
+__device__ __forceinline__ uint4 pat2_load(const PatEnt *__restrict__ ent, int e)
+{
+    return *reinterpret_cast<const uint4 *>(ent + e);
+}
+__device__ __forceinline__ void pat2_request(int p, bool &one, uint4 (&q)[PAT_K], const PatEnt *__restrict__ ent, int stride,
+                                             int lane)
+{
+    const int p0 = __builtin_amdgcn_readfirstlane(p);   // (rows fill a slice from lane 0: p0 < 0 means no row at all)
+    one = __all(p < 0 || p == p0) != 0;
+    if (one) {
+        q[0] = pat2_load(ent, (p0 >= 0 && lane < stride) ? p0 * stride + lane : 0);
+#pragma unroll
+        for (int k = 1; k < PAT_K; ++k) q[k] = make_uint4(0u, 0u, 0u, 0u);
+    } else {
+#pragma unroll
+        for (int k = 0; k < PAT_K; ++k) q[k] = pat2_load(ent, (p >= 0 && k < stride) ? p * stride + k : 0);
+    }
+}
+// value, column - row of entry k and the length of the lane's pattern (0: no row)
+__device__ __forceinline__ void pat2_unpack(int p, bool one, const uint4 (&q)[PAT_K], double (&v)[PAT_K], int (&d)[PAT_K],
+                                            int &len)
+{
+    if (one) {
+#pragma unroll
+        for (int k = 0; k < PAT_K; ++k) {   // (k >= stride: entry 0 of the table, never used: k >= len)
+            v[k] = __hiloint2double(__builtin_amdgcn_readlane((int)q[0].y, k), __builtin_amdgcn_readlane((int)q[0].x, k));
+            d[k] = __builtin_amdgcn_readlane((int)q[0].z, k);
+        }
+        len = p >= 0 ? __builtin_amdgcn_readlane((int)q[0].w, 0) : 0;
+    } else {
+#pragma unroll
+        for (int k = 0; k < PAT_K; ++k) {
+            v[k] = __hiloint2double((int)q[k].y, (int)q[k].x);
+            d[k] = (int)q[k].z;
+        }
+        len = p >= 0 ? (int)q[0].w : 0;
+    }
+}
+
+template <bool UPD, typename VT = double, bool NT = false, int U = PAT_U>
+__global__ __launch_bounds__(SELL_BLOCK, 4) void k_spmv_pat2(
+    const unsigned short *__restrict__ pid, const PatEnt *__restrict__ ent, int stride, int rows, int nslices,
+    int64_t nblk, const VT *__restrict__ x, VT *__restrict__ y, const SpmvCoef *__restrict__ coef,
+    const int *__restrict__ stop, double *__restrict__ partials, const double *__restrict__ pin, int npin,
+    const NormSlot *__restrict__ slot_in, NormSlot *__restrict__ slot_out, int skip_if_zero, Rider rider, UpdArgs upd,
+    NScale nsc)
+{
+    __shared__ double red[SELL_BLOCK / WAVE + 1];
+    const int shift = rider.kind != 0 ? 1 : 0;
+    const int nwg = (int)gridDim.x - shift;
+    const int wg = (int)blockIdx.x - shift;
+    if (wg < 0) {
+        run_rider(rider, red);
+        return;
+    }
+    const int tid = threadIdx.x;
+    const bool pre = pin != nullptr && npin <= PAT_SHARE_K * SELL_BLOCK;   // (uniform)
+    double pshare[PAT_SHARE_K];
+    if (pre) strided_share_load<SELL_BLOCK, PAT_SHARE_K>(pin, npin, pshare);
+    const int lane = tid & (WAVE - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const XcdRange xr = xcd_range(nblk, nwg, wg);
+    // row of slice u of the trip that starts at block b (-1: none)
+    auto row_of = [&](int64_t b, int u) -> int {
+        const int64_t bu = b + u * xr.stride;
+        const int64_t r64 = (bu * SELL_SLICES + wave) * WAVE + lane;
+        return (bu < xr.end && r64 < rows) ? (int)r64 : -1;
+    };
+    auto pid_of = [&](int64_t b, int (&p)[U]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int r = row_of(b, u);
+            p[u] = r >= 0 ? (int)ld_stream<NT>(&pid[r]) : -1;
+        }
+    };
+    const int64_t step = U * xr.stride;
+    int64_t b = xr.first;
+    int pid_2[U];   // pattern numbers, two trips ahead of the sums
+    pid_of(b, pid_2);
+
+    if (*stop != 0) return;
+    SellCoef kc;
+    const double share = pre ? strided_share_sum<SELL_BLOCK, PAT_SHARE_K>(pshare, npin) : 0.0;
+    if (!sell_prologue<UPD, VT, NT>(coef, pin, npin, slot_in, slot_out, skip_if_zero, upd, nwg, wg, red, kc, nsc, pre, share))
+        return;
+    const double sx = kc.sx, sy = kc.sy, cy = kc.cy;
+    __syncthreads();
+
+    int p_c[U];             // this trip: the lanes' patterns,
+    bool one_c[U];          // ... whether a slice names one only,
+    uint4 q_c[U][PAT_K];    // ... the entries as requested
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        p_c[u] = pid_2[u];
+        pat2_request(p_c[u], one_c[u], q_c[u], ent, stride, lane);
+    }
+    pid_of(b + step, pid_2);
+    double sq = 0.0;
+    for (; b < xr.end; b += step) {
+        int r[U], len[U], d[U][PAT_K];
+        double y0[U], v[U][PAT_K], xv[U][PAT_K];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            r[u] = row_of(b, u);
+            pat2_unpack(p_c[u], one_c[u], q_c[u], v[u], d[u], len[u]);
+            y0[u] = (double)ld_stream<NT>(&y[r[u] >= 0 ? r[u] : 0]);
+#pragma unroll
+            for (int k = 0; k < PAT_K; ++k) xv[u][k] = (double)x[k < len[u] ? r[u] + d[u][k] : 0];   // (no entry: x[0], never added)
+        }
+        // behind the gathers: the next trip's entries, the pattern numbers of the one after it
+        int p_n[U];
+        bool one_n[U];
+        uint4 q_n[U][PAT_K];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            p_n[u] = pid_2[u];
+            pat2_request(p_n[u], one_n[u], q_n[u], ent, stride, lane);
+        }
+        pid_of(b + 2 * step, pid_2);
+        double sum[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            sum[u] = 0.0;
+#pragma unroll
+            for (int k = 0; k < PAT_K; ++k) {
+                const double p = v[u][k] * (xv[u][k] * sx);
+                if (k < len[u]) sum[u] = sum[u] + p;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            for (int k0 = PAT_K; __any(k0 < len[u]); k0 += PAT_K) {   // rows of more than PAT_K nonzeros
+                uint4 q2[PAT_K];
+                double x2[PAT_K];
+#pragma unroll
+                for (int k = 0; k < PAT_K; ++k) q2[k] = pat2_load(ent, k0 + k < len[u] ? p_c[u] * stride + k0 + k : 0);
+#pragma unroll
+                for (int k = 0; k < PAT_K; ++k) x2[k] = (double)x[k0 + k < len[u] ? r[u] + (int)q2[k].z : 0];
+#pragma unroll
+                for (int k = 0; k < PAT_K; ++k) {
+                    const double p = __hiloint2double((int)q2[k].y, (int)q2[k].x) * (x2[k] * sx);
+                    if (k0 + k < len[u]) sum[u] = sum[u] + p;
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (r[u] >= 0) {
+                const VT yn = (VT)(cy * (y0[u] * sy) + sum[u]);
+                store_through(&y[r[u]], yn);
+                const double ys = (double)yn * nsc.s;
+                sq += ys * ys;
+            }
+            p_c[u] = p_n[u];
+            one_c[u] = one_n[u];
+#pragma unroll
+            for (int k = 0; k < PAT_K; ++k) q_c[u][k] = q_n[u][k];
         }
     }
     const double tot = block_sum<SELL_BLOCK>(sq, red);

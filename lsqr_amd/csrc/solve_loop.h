@@ -197,6 +197,24 @@ static void launch_sellp(const SpmvArgs &a)
     else launch_sellp_N<UPD, VT, false>(a);
 }
 
+template <bool UPD, typename VT, bool NT, int U>
+static void launch_pat2_U(const SpmvArgs &a, const dim3 grid)
+{
+    const Csr &c = *a.c;
+    const VT *x = reinterpret_cast<const VT *>(a.x);
+    VT *y = reinterpret_cast<VT *>(a.y);
+    if (a.e0 == nullptr && a.e1 == nullptr)
+        hipLaunchKernelGGL((k_spmv_pat2<UPD, VT, NT, U>), grid, dim3(SELL_BLOCK), 0, a.stream,
+                           (const unsigned short *)c.pid, (const PatEnt *)c.pent, c.pat_stride, c.rows,
+                           c.nslices, c.nblk, x, y, a.coef, a.stop, a.pout, a.pin, a.npin, a.slot_in, a.slot_out,
+                           a.skip_if_zero, a.rider, a.upd, a.nsc);
+    else
+        hipExtLaunchKernelGGL((k_spmv_pat2<UPD, VT, NT, U>), grid, dim3(SELL_BLOCK), 0, a.stream, a.e0, a.e1, 0,
+                              (const unsigned short *)c.pid, (const PatEnt *)c.pent, c.pat_stride, c.rows,
+                              c.nslices, c.nblk, x, y, a.coef, a.stop, a.pout, a.pin, a.npin, a.slot_in, a.slot_out,
+                              a.skip_if_zero, a.rider, a.upd, a.nsc);
+}
+
 template <bool UPD, typename VT, bool NT>
 static void launch_pat_N(const SpmvArgs &a)
 {
@@ -204,6 +222,13 @@ static void launch_pat_N(const SpmvArgs &a)
     const VT *x = reinterpret_cast<const VT *>(a.x);
     VT *y = reinterpret_cast<VT *>(a.y);
     const dim3 grid(c.grid + (a.rider.kind != 0 ? 1 : 0));
+    if (c.pat_wide) {   // two-byte pattern numbers, the table in global memory (pat.h "wide")
+        switch (c.pat_u) {
+        case 1: launch_pat2_U<UPD, VT, NT, 1>(a, grid); break;
+        default: launch_pat2_U<UPD, VT, NT, 2>(a, grid); break;
+        }
+        return;
+    }
     if (a.e0 == nullptr && a.e1 == nullptr)
         hipLaunchKernelGGL((k_spmv_pat<UPD, VT, NT>), grid, dim3(SELL_BLOCK), 0, a.stream, (const unsigned char *)c.pid,
                            (const unsigned *)c.pdesc, (const int *)c.pdelta, (const double *)c.pval, c.npat_e, c.rows,

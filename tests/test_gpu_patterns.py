@@ -14,7 +14,7 @@ from lsqr_amd.solver import lsqr_solver_ez
 
 pytestmark = pytest.mark.gpu
 CASES = build_cases()
-KNOBS = ("LSQRHIP_STREAM_NT", "LSQRHIP_PAT", "LSQRHIP_SPAT", "LSQRHIP_SELL", "LSQRHIP_SELLP", "LSQRHIP_VAL8", "LSQRHIP_COL16", "LSQRHIP_CSB")
+KNOBS = ("LSQRHIP_STREAM_NT", "LSQRHIP_PAT", "LSQRHIP_PAT2", "LSQRHIP_SPAT", "LSQRHIP_SELL", "LSQRHIP_SELLP", "LSQRHIP_VAL8", "LSQRHIP_COL16", "LSQRHIP_CSB")
 
 
 @pytest.fixture(autouse=True)
@@ -136,19 +136,29 @@ def test_matrices_without_repeating_rows_keep_their_layout():
     info = lsqr_solver_ez().initialize(p.m, p.n, p.a, p.irow, p.icol).info()
     assert info["sell"] != 3 and info["sell_t"] != 3
     # nd distinct diagonal values, each 100 times, over a constant superdiagonal that the last row lacks: nd + 1
-    # patterns -- 256 fit a byte, 257 do not
+    # patterns -- 256 fit a byte, 257 do not (they take two: the wide table below; without it the structure -- two
+    # patterns -- is what is left, one value too many for a dictionary as well)
     for nd, want in ((255, 3), (256, 1)):
-        m = n = 100 * nd
-        r = np.arange(m)
-        irow = np.concatenate([r, r[:-1]])
-        icol = np.concatenate([r, r[:-1] + 1])
-        a = np.concatenate([1.0 + (r % nd), np.full(m - 1, -1.0)])
-        order = np.argsort(irow, kind="stable")
-        irow, icol, a = (irow[order] + 1).astype(np.int32), (icol[order] + 1).astype(np.int32), a[order]
+        m, n, irow, icol, a = diagonal_steps(nd, 100)
         if want == 3:
-            check_against_oracle(m, n, irow, icol, a, _vec(7, m), itnlim=8)
-        else:     # (one value too many for a dictionary as well: the structure -- two patterns -- is what is left)
+            s, _ = check_against_oracle(m, n, irow, icol, a, _vec(7, m), itnlim=8)
+            assert s.info()["pat_wide"] == 0
+        else:
+            os.environ["LSQRHIP_PAT2"] = "0"
             assert lsqr_solver_ez().initialize(m, n, a, irow, icol).info()["sell"] in (want, 4)
+            os.environ.pop("LSQRHIP_PAT2")
+
+
+def diagonal_steps(nd, each):
+    """nd distinct diagonal values, each `each` times in turn, over a constant superdiagonal that the last row lacks:
+    nd + 1 distinct rows."""
+    m = n = each * nd
+    r = np.arange(m)
+    irow = np.concatenate([r, r[:-1]])
+    icol = np.concatenate([r, r[:-1] + 1])
+    a = np.concatenate([1.0 + (r % nd), np.full(m - 1, -1.0)])
+    order = np.argsort(irow, kind="stable")
+    return m, n, (irow[order] + 1).astype(np.int32), (icol[order] + 1).astype(np.int32), a[order]
 
 
 def grid3d(nx, ny, nz, radius_taps):
@@ -237,6 +247,114 @@ def test_the_golden_parity_cases_with_patterns_forced(name):
     kernel and must hold the same golden values; the others keep their layout."""
     import test_gpu_parity as tp
     os.environ["LSQRHIP_PAT"] = "1"
+    tp.test_solve_parity_vs_reference_golden(name)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# wide row patterns (sell = 3, two-byte pattern numbers, the table through L2): 257 ... 4096 distinct rows
+# ---------------------------------------------------------------------------------------------------------------------
+def piecewise_mesh(nx, ny, bx, by, seed=11):
+    """-div(k grad u) on an nx x ny grid, five points, k constant on each of bx x by blocks of cells (its own value on
+    every block) and the harmonic mean of the two sides on a face: one row for the interior of a block, others along
+    every interface, at every corner where four blocks meet, and along the boundary of the domain."""
+    ix, iy = np.meshgrid(np.arange(nx), np.arange(ny), indexing="xy")
+    ix, iy = ix.ravel(), iy.ravel()
+    region = (ix * bx // nx) + bx * (iy * by // ny)
+    kreg = 2.0 + _vec(seed, bx * by)              # in (1, 3)
+    k = kreg[region]
+    m = n = nx * ny
+    r = np.arange(m)
+
+    def face(dx, dy):
+        jx, jy = ix + dx, iy + dy
+        ok = (jx >= 0) & (jx < nx) & (jy >= 0) & (jy < ny)
+        j = np.where(ok, jx + nx * jy, 0)
+        kf = 2.0 * k * k[j] / (k + k[j])
+        return ok, j, np.where(ok, kf, k)       # (a face on the boundary of the domain: the cell's own k, Dirichlet)
+
+    faces = [face(0, -1), face(-1, 0), face(1, 0), face(0, 1)]
+    diag = faces[0][2] + faces[1][2] + faces[2][2] + faces[3][2]
+    # the order inside a row: south, west, centre, east, north
+    rows = [r, r, r, r, r]
+    cols = [faces[0][1], faces[1][1], r, faces[2][1], faces[3][1]]
+    vals = [-faces[0][2], -faces[1][2], diag, -faces[2][2], -faces[3][2]]
+    keep = [faces[0][0], faces[1][0], np.ones(m, bool), faces[2][0], faces[3][0]]
+    rows, cols, vals, keep = (np.stack(v, axis=1).ravel() for v in (rows, cols, vals, keep))
+    irow, icol, a = rows[keep], cols[keep], vals[keep]
+    return m, n, (irow + 1).astype(np.int32), (icol + 1).astype(np.int32), a.astype(np.float64), _vec(7, m)
+
+
+def test_a_piecewise_constant_coefficient_mesh_takes_two_bytes_per_row():
+    m, n, irow, icol, a, b = piecewise_mesh(500, 400, 12, 10)     # (<= 1024 blocks of 256 rows: one grid for every layout)
+    s, r = check_against_oracle(m, n, irow, icol, a, b, damp=1e-3)
+    info = s.info()
+    assert 256 < info["pat_wide"] <= 4096 and 256 < info["pat_wide_t"] <= 4096, info
+    # two bytes per row and the table (<= 5 entries of 16 bytes and a descriptor per pattern)
+    assert info["csr_bytes"] <= 2 * m + 84 * info["pat_wide"]
+    # ... and the same bits as the layouts underneath: without the wide table, then without any pattern layout
+    for knobs in ({"LSQRHIP_PAT2": "0"}, {"LSQRHIP_PAT": "0", "LSQRHIP_SPAT": "0"}):
+        os.environ.update(knobs)
+        s0 = lsqr_solver_ez().initialize(m, n, a, irow, icol, itnlim=25)
+        assert s0.info()["pat_wide"] == 0 and s0.info()["csr_bytes"] > 2 * info["csr_bytes"]
+        r0 = s0.solve(b, 1e-3)
+        assert np.array_equal(r0.x, r.x) and r0.anorm == r.anorm and r0.rnorm == r.rnorm and r0.itn == r.itn
+        for k in knobs:
+            os.environ.pop(k)
+
+
+@pytest.mark.parametrize("nd,wide", [(256, True), (4095, True), (4096, False)])
+def test_limits_of_the_wide_table(nd, wide):
+    """nd + 1 distinct rows: 257 are the first that take two bytes, 4096 the last that fit."""
+    m, n, irow, icol, a = diagonal_steps(nd, 100 if nd == 256 else 20)
+    if wide:
+        s, _ = check_against_oracle(m, n, irow, icol, a, _vec(7, m), itnlim=8)
+        assert s.info()["pat_wide"] == nd + 1 and s.info()["pat_wide_t"] == nd + 1
+    else:
+        info = lsqr_solver_ez().initialize(m, n, a, irow, icol).info()
+        assert info["pat_wide"] == 0 and info["sell"] != 3
+
+
+def test_wide_patterns_with_long_rows_and_few_rows_per_pattern():
+    """12 entries per row (more than one trip of 5 through the table), every entry scaled by the coefficient of the row's
+    region: a pattern per region and its boundary variants; then a matrix with fewer than 16 rows per pattern -- the
+    wide table only when forced."""
+    offs = tuple(range(-6, 6))
+    m, n, irow, icol, a, b = stencil(90000, 90000, offs, tuple(1.0 + 0.01 * k for k in range(12)))
+    a = a * (1.0 + ((irow - 1) // 300))          # 300 regions of 300 rows
+    s, _ = check_against_oracle(m, n, irow, icol, a, b, itnlim=10)
+    assert s.info()["pat_wide"] >= 300
+    m, n, irow, icol, a = diagonal_steps(600, 10)       # 601 patterns for 6000 rows
+    assert lsqr_solver_ez().initialize(m, n, a, irow, icol).info()["pat_wide"] == 0
+    os.environ["LSQRHIP_PAT2"] = "1"
+    s, _ = check_against_oracle(m, n, irow, icol, a, _vec(7, m), itnlim=8)
+    assert s.info()["pat_wide"] == 601
+
+
+def test_real32_wide_patterns():
+    m, n, irow, icol, a, b = piecewise_mesh(240, 200, 8, 6)
+    a32, b32 = a.astype(np.float32), b.astype(np.float32)
+    s = lsqr_solver_ez().initialize(m, n, a32, irow, icol, itnlim=30, real32=True)
+    assert s.info()["pat_wide"] > 256
+    xp, yp = _vec(9, n).astype(np.float32), _vec(10, m).astype(np.float32)
+    po = oracle.port()
+    _, y_ref = po.aprod(1, m, n, irow, icol, a32.astype(np.float64), xp.astype(np.float64), yp.astype(np.float64))
+    x, y = xp.copy(), yp.copy()
+    s.aprod(1, m, n, x, y)
+    assert np.array_equal(y, y_ref.astype(np.float32))      # binary64 sums, rounded once
+    os.environ["LSQRHIP_PAT"] = "0"
+    s0 = lsqr_solver_ez().initialize(m, n, a32, irow, icol, itnlim=30, real32=True)
+    assert s0.info()["sell"] != 3
+    r, r0 = s.solve(b32, 0.0), s0.solve(b32, 0.0)
+    assert np.array_equal(r.x, r0.x) and r.itn == r0.itn and r.anorm == r0.anorm
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_the_golden_parity_cases_with_wide_patterns_forced(name):
+    """... and with LSQRHIP_PAT2=1 beside LSQRHIP_PAT=1: systems of 257 ... 4096 rows, every row a pattern of its own, go
+    through the wide table."""
+    import test_gpu_parity as tp
+    os.environ["LSQRHIP_PAT"] = "1"
+    os.environ["LSQRHIP_PAT2"] = "1"
     tp.test_solve_parity_vs_reference_golden(name)
 
 
