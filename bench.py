@@ -21,7 +21,8 @@ The ONE JSON line (rank 0) carries, for the dominant kernel (aprod mode 1):
                     SURVEY 8d algorithmic bytes (12 B per nonzero ...) / the same time, labelled as such.
   roofline_hbm      the same kernel family on HBM-RESIDENT instances (configs[1] fits the 256 MB
                     Infinity Cache): poisson2d:4000:4000 as row patterns, packed records, sliced ELL with 8-byte values
-                    and structure patterns.
+                    and structure patterns; mesh2d:4000:4000:16:16 (the same operator with its coefficient constant on
+                    each of 256 regions: 2304 distinct rows) as wide row patterns.
   strong_scaling_n1 configs[3] (10M x 10M, 1e9 nonzeros) whole on this GPU, with its own roofline:
                     N = 1 of the series the --gpus N lines continue.
   roofline_configs  the same object for configs[2] at its literal 1000 per row, configs[4] and the r = 1000 rank block.
@@ -54,7 +55,10 @@ HBM_INSTANCES = [("poisson2d:4000:4000", {}, "row patterns (what the build choos
                  ("poisson2d:4000:4000", {"LSQRHIP_PAT": "0", "LSQRHIP_VAL8": "0", "LSQRHIP_SPAT": "0"},
                   "sliced ELL: 8-byte values, 16-bit columns (matrices without a repeating structure)"),
                  ("poisson2d:4000:4000", {"LSQRHIP_PAT": "0", "LSQRHIP_VAL8": "0"},
-                  "structure patterns: 8-byte values, no column indices (what a variable-coefficient stencil gets)")]
+                  "structure patterns: 8-byte values, no column indices (what a variable-coefficient stencil gets)"),
+                 ("mesh2d:4000:4000:16:16", {},
+                  "wide row patterns: the same five-point operator with its coefficient constant on each of 16 x 16 regions "
+                  "(2304 distinct rows): two bytes per row, the table through L1 / L2 (round 4: structure patterns)")]
 PRODUCT_KERNELS = ("k_spmv_", "k_panel_combine", "k_csb_combine", "k_csb_xmax")
 # the N = 1 line measures configs[1]; the series the --gpus N lines continue is strong_scaling_n1 (configs[3])
 SCALING_N1 = "n/a (configs[1]; the strong-scaling series is strong_scaling_n1)"
@@ -78,7 +82,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=None, help="timed LSQR iterations (default 2000; 400 for --gpus > 1)")
     ap.add_argument("--warmup", type=int, default=None, help="untimed iterations first (default steps / 10)")
     ap.add_argument("--workload", default="auto",
-                    help="auto | poisson2d:NX:NY | random:M:N:PER_ROW | powerlaw:M:N:DMAX")
+                    help="auto | poisson2d:NX:NY | mesh2d:NX:NY:BX:BY | random:M:N:PER_ROW | powerlaw:M:N:DMAX")
     ap.add_argument("--cpu-iters", type=int, default=1000, help="iterations of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--extras", choices=["on", "off"], default="on",
@@ -107,6 +111,8 @@ def make_problem(spec: str):
     kind, *a = spec.split(":")
     if kind == "poisson2d":
         return P.poisson2d(int(a[0]), int(a[1]))
+    if kind == "mesh2d":
+        return P.mesh2d(int(a[0]), int(a[1]), int(a[2]), int(a[3]))
     if kind == "random":
         return P.random_rows(int(a[0]), int(a[1]), int(a[2]), damp=1e-3)
     if kind == "powerlaw":
@@ -154,7 +160,7 @@ def build_workload(spec: str, env=None, itnlim=100, rows=None):
     from lsqr_amd import capi, devgen
     from lsqr_amd.solver import lsqr_solver_ez
     cfg = devgen.parse_spec(spec)
-    nnz_est = cfg["m"] * (5 if cfg["kind"] == "poisson2d" else cfg.get("per_row", 30))
+    nnz_est = cfg["m"] * (5 if cfg["kind"] in ("poisson2d", "mesh2d") else cfg.get("per_row", 30))
     host = None
     with _Env(env):
         if rows is not None:

@@ -364,7 +364,9 @@ int lsqrhip_shard_end(lsqrhip_handle_t h, double *d_x, double *d_se, int *istop,
  * kind 0: random rows (p0 = nnz per row); kind 1: 5-point Poisson (p0 = nx, p1 = ny; b is
  * not generated, d_b may be NULL); kind 2: rows with prescribed degrees (power law):
  * d_rowptr_local = exclusive prefix of the local row degrees, nrows+1 entries, built by the
- * host from the integer CDF table (problems.powerlaw_degrees).
+ * host from the integer CDF table (problems.powerlaw_degrees); kind 3: a five-point mesh whose
+ * coefficient is constant on each of bx x by regions (problems.mesh2d: p0 = nx, ny = m / nx,
+ * p1 = bx << 16 | by).
  * Generates rows [row0, row0+nrows) of the global m-by-n system as LOCAL 1-based COO
  * (irow in 1..nrows) plus b for those rows.  *nnz_out = triplets written. */
 int64_t lsqrhip_gen_count(int kind, int64_t m, int64_t n, int64_t p0, int64_t p1, int64_t row0, int64_t nrows);

@@ -104,6 +104,40 @@ __global__ __launch_bounds__(256) void k_gen_poisson(long long nx, long long ny,
     }
 }
 
+// kind 3: the five-point mesh of problems.mesh2d -- k of a cell = 2 + u(-1, 1) of its region, a face the harmonic
+// mean of its two cells (the cell's own k on the boundary of the grid, kept in the diagonal only); the structure is
+// Poisson's.  Every operation in the order the host generator has it (no contraction: -ffp-contract=off).
+__global__ __launch_bounds__(256) void k_gen_mesh(unsigned long long seed, long long nx, long long ny, long long bx,
+                                                  long long by, long long row0, long long nrows, int *__restrict__ irow,
+                                                  int *__restrict__ icol, double *__restrict__ a, double *__restrict__ b)
+{
+    const long long base = poisson_offset(row0, nx, ny);
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x; r < nrows; r += stride) {
+        const long long c = row0 + r, i = c % nx, j = c / nx;
+        auto kcell = [&](long long ii, long long jj) {
+            const unsigned long long region = (unsigned long long)((ii * bx) / nx + bx * ((jj * by) / ny));
+            return 2.0 + u64_to_unit(rng_u64(seed, S_VAL, region, 0ull));
+        };
+        const double k = kcell(i, j);
+        auto face = [&](bool ok, long long ii, long long jj) {
+            if (!ok) return k;
+            const double kn = kcell(ii, jj);
+            return 2.0 * k * kn / (k + kn);
+        };
+        const double fs = face(j > 0, i, j - 1), fw = face(i > 0, i - 1, j), fe = face(i < nx - 1, i + 1, j),
+                     fn = face(j < ny - 1, i, j + 1);
+        long long p = poisson_offset(c, nx, ny) - base;
+        const int lr = (int)(r + 1);
+        if (j > 0) { irow[p] = lr; icol[p] = (int)(c - nx + 1); a[p] = -fs; ++p; }
+        if (i > 0) { irow[p] = lr; icol[p] = (int)(c); a[p] = -fw; ++p; }
+        irow[p] = lr; icol[p] = (int)(c + 1); a[p] = ((fs + fw) + fe) + fn; ++p;
+        if (i < nx - 1) { irow[p] = lr; icol[p] = (int)(c + 2); a[p] = -fe; ++p; }
+        if (j < ny - 1) { irow[p] = lr; icol[p] = (int)(c + nx + 1); a[p] = -fn; ++p; }
+        if (b) b[r] = u64_to_unit(rng_u64(seed, S_B, (unsigned long long)c, 0ull));
+    }
+}
+
 }  // namespace lsqrhip
 
 extern "C" int64_t lsqrhip_gen_count(int kind, int64_t m, int64_t n, int64_t p0, int64_t p1, int64_t row0,
@@ -113,6 +147,7 @@ extern "C" int64_t lsqrhip_gen_count(int kind, int64_t m, int64_t n, int64_t p0,
     (void)n;
     if (kind == 0) return nrows * p0;
     if (kind == 1) return poisson_offset(row0 + nrows, p0, p1) - poisson_offset(row0, p0, p1);
+    if (kind == 3 && p0 > 0) return poisson_offset(row0 + nrows, p0, m / p0) - poisson_offset(row0, p0, m / p0);
     return -1;
 }
 
@@ -135,6 +170,13 @@ extern "C" int lsqrhip_gen_coo(int kind, uint64_t seed, int64_t m, int64_t n, in
         nnz = poisson_offset(row0 + nrows, p0, p1) - poisson_offset(row0, p0, p1);
         hipLaunchKernelGGL(k_gen_poisson, dim3(grid), dim3(256), 0, 0, (long long)p0, (long long)p1, (long long)row0,
                            (long long)nrows, d_irow, d_icol, d_a);
+    } else if (kind == 3) {   // p0 = nx (ny = m / nx), p1 = bx << 16 | by
+        const int64_t nx = p0, ny = nx > 0 ? m / nx : 0, bx = p1 >> 16, by = p1 & 0xffff;
+        if (nx <= 0 || nx * ny != m || n != m || bx <= 0 || by <= 0 || bx > nx || by > ny)
+            return fail(LSQRHIP_ERR_ARG, "mesh: m = n = nx*ny and 1 <= bx <= nx, 1 <= by <= ny required");
+        nnz = poisson_offset(row0 + nrows, nx, ny) - poisson_offset(row0, nx, ny);
+        hipLaunchKernelGGL(k_gen_mesh, dim3(grid), dim3(256), 0, 0, (unsigned long long)seed, (long long)nx, (long long)ny,
+                           (long long)bx, (long long)by, (long long)row0, (long long)nrows, d_irow, d_icol, d_a, d_b);
     } else if (kind == 2) {
         if (!d_rowptr_local) return fail(LSQRHIP_ERR_ARG, "power-law generator needs the local row pointer");
         long long last = 0;

@@ -17,7 +17,7 @@ from . import capi, problems as P
 from .capi import DeviceBuffer, check, lib
 from .solver import lsqr_solver_ez
 
-KIND_RANDOM, KIND_POISSON, KIND_BY_ROWPTR = 0, 1, 2
+KIND_RANDOM, KIND_POISSON, KIND_BY_ROWPTR, KIND_MESH = 0, 1, 2, 3
 
 
 @dataclass
@@ -34,11 +34,13 @@ class DeviceProblem:
 
 
 def parse_spec(spec: str):
-    """'poisson2d:NX:NY' | 'random:M:N:PER_ROW' | 'powerlaw:M:N:DMAX[:DMIN]' -> dict"""
+    """'poisson2d:NX:NY' | 'mesh2d:NX:NY:BX:BY' | 'random:M:N:PER_ROW' | 'powerlaw:M:N:DMAX[:DMIN]' -> dict"""
     kind, *a = spec.split(":")
     a = [int(t) for t in a]
     if kind == "poisson2d":
         return dict(kind="poisson2d", m=a[0] * a[1], n=a[0] * a[1], nx=a[0], ny=a[1], damp=0.0)
+    if kind == "mesh2d":
+        return dict(kind="mesh2d", m=a[0] * a[1], n=a[0] * a[1], nx=a[0], ny=a[1], bx=a[2], by=a[3], damp=0.0)
     if kind == "random":
         return dict(kind="random", m=a[0], n=a[1], per_row=a[2], damp=1e-3)
     if kind == "powerlaw":
@@ -64,6 +66,9 @@ def generate(spec: str, row0: int = 0, nrows: int | None = None, seed: int = 123
         nnz = nrows * cfg["per_row"]
     elif cfg["kind"] == "poisson2d":
         kind, p0, p1 = KIND_POISSON, cfg["nx"], cfg["ny"]
+        nnz = int(L.lsqrhip_gen_count(kind, m, n, p0, p1, row0, nrows))
+    elif cfg["kind"] == "mesh2d":
+        kind, p0, p1 = KIND_MESH, cfg["nx"], (cfg["bx"] << 16) | cfg["by"]
         nnz = int(L.lsqrhip_gen_count(kind, m, n, p0, p1, row0, nrows))
     else:
         kind, p0, p1 = KIND_BY_ROWPTR, cfg["dmin"], cfg["dmax"]
@@ -107,6 +112,9 @@ def download_coo(spec: str, row0: int = 0, nrows: int | None = None, seed: int =
         kind, p0, p1, nnz = KIND_RANDOM, cfg["per_row"], 0, nrows * cfg["per_row"]
     elif cfg["kind"] == "poisson2d":
         kind, p0, p1 = KIND_POISSON, cfg["nx"], cfg["ny"]
+        nnz = int(L.lsqrhip_gen_count(kind, m, n, p0, p1, row0, nrows))
+    elif cfg["kind"] == "mesh2d":
+        kind, p0, p1 = KIND_MESH, cfg["nx"], (cfg["bx"] << 16) | cfg["by"]
         nnz = int(L.lsqrhip_gen_count(kind, m, n, p0, p1, row0, nrows))
     else:
         kind, p0, p1 = KIND_BY_ROWPTR, cfg["dmin"], cfg["dmax"]

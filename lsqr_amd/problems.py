@@ -117,6 +117,40 @@ def poisson2d(nx: int, ny: int) -> Problem:
 
 
 # ---------------------------------------------------------------------------
+# a five-point mesh whose coefficient is constant on each of bx x by regions (no BASELINE configuration: the matrix
+# of a few thousand distinct rows that the wide row patterns of csrc/pat.h are for)
+# ---------------------------------------------------------------------------
+
+def mesh2d(nx: int, ny: int, bx: int, by: int, seed: int = 12345) -> Problem:
+    """-div(k grad u) on an nx x ny grid: row c = j*nx + i holds -kS, -kW, kS + kW + kE + kN, -kE, -kN (ascending
+    columns, a face outside the grid left out of the row but kept in the diagonal with the cell's own k: Dirichlet);
+    k of a cell = 2 + u(-1, 1) of its region ((i*bx)//nx, (j*by)//ny), k of a face = the harmonic mean 2 k1 k2 / (k1 + k2)
+    of its two cells; b = u(-1, 1).  Same hash and the same operation order as the device generator (csrc/gen_api.h)."""
+    N = nx * ny
+    c = np.arange(N, dtype=np.int64)
+    i, j = c % nx, c // nx
+    region = (i * bx) // nx + bx * ((j * by) // ny)
+    kreg = 2.0 + u64_to_unit(rng_u64(seed, S_VAL, np.arange(bx * by, dtype=np.uint64)))
+    k = kreg[region]
+
+    def face(ok, nb):
+        kn = k[np.where(ok, nb, 0)]
+        return np.where(ok, 2.0 * k * kn / (k + kn), k)
+
+    inside = [j > 0, i > 0, i < nx - 1, j < ny - 1]
+    nbr = [c - nx, c - 1, c + 1, c + nx]
+    f = [face(ok, nb) for ok, nb in zip(inside, nbr)]
+    diag = ((f[0] + f[1]) + f[2]) + f[3]
+    cols = np.stack([nbr[0], nbr[1], c, nbr[2], nbr[3]], axis=1)
+    vals = np.stack([-f[0], -f[1], diag, -f[2], -f[3]], axis=1)
+    keep = np.stack([inside[0], inside[1], np.ones(N, bool), inside[2], inside[3]], axis=1)
+    rows = np.repeat(c[:, None], 5, axis=1)
+    b = u64_to_unit(rng_u64(seed, S_B, c.astype(np.uint64)))
+    return Problem(f"mesh2d_{nx}x{ny}_{bx}x{by}", N, N, (rows[keep] + 1).astype(np.int32),
+                   (cols[keep] + 1).astype(np.int32), vals[keep], b)
+
+
+# ---------------------------------------------------------------------------
 # configs 3/4: random rectangular, fixed nnz per row (duplicates allowed)
 # ---------------------------------------------------------------------------
 

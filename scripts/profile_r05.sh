@@ -77,6 +77,8 @@ for t in $TAGS; do
                       roof poisson4000_val8 LSQRHIP_PAT=0,LSQRHIP_VAL8=0,LSQRHIP_SPAT=0 poisson2d:4000:4000 ;;
     poisson4000_spat) run poisson4000_structure_patterns LSQRHIP_PAT=0,LSQRHIP_VAL8=0 --workload poisson2d:4000:4000 --steps 200 --warmup 20
                       roof poisson4000_structure_patterns LSQRHIP_PAT=0,LSQRHIP_VAL8=0 poisson2d:4000:4000 ;;
+    mesh4000_wide)    run mesh4000_wide_patterns - --workload mesh2d:4000:4000:16:16 --steps 200 --warmup 20
+                      roof mesh4000_wide_patterns - mesh2d:4000:4000:16:16 ;;
     config4)          run config4_random_10Mx10Mx100 - --workload random:10000000:10000000:100 --steps 20 --warmup 2
                       roof config4_random_10Mx10Mx100 - random:10000000:10000000:100 ;;
     shard8)           run shard8_random_1250000x10Mx100 - --workload random:1250000:10000000:100 --steps 40 --warmup 4

@@ -13,6 +13,7 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.parametrize("spec,host", [
     ("random:3000:700:9", lambda: P.random_rows(3000, 700, 9)),
     ("poisson2d:37:23", lambda: P.poisson2d(37, 23)),
+    ("mesh2d:61:47:5:3", lambda: P.mesh2d(61, 47, 5, 3)),
     ("powerlaw:4000:900:1500:3", lambda: P.powerlaw_rows(4000, 900, dmin=3, dmax=1500)),
 ])
 def test_device_generators_match_host_bit_for_bit(spec, host):

@@ -256,32 +256,10 @@ def test_the_golden_parity_cases_with_patterns_forced(name):
 def piecewise_mesh(nx, ny, bx, by, seed=11):
     """-div(k grad u) on an nx x ny grid, five points, k constant on each of bx x by blocks of cells (its own value on
     every block) and the harmonic mean of the two sides on a face: one row for the interior of a block, others along
-    every interface, at every corner where four blocks meet, and along the boundary of the domain."""
-    ix, iy = np.meshgrid(np.arange(nx), np.arange(ny), indexing="xy")
-    ix, iy = ix.ravel(), iy.ravel()
-    region = (ix * bx // nx) + bx * (iy * by // ny)
-    kreg = 2.0 + _vec(seed, bx * by)              # in (1, 3)
-    k = kreg[region]
-    m = n = nx * ny
-    r = np.arange(m)
-
-    def face(dx, dy):
-        jx, jy = ix + dx, iy + dy
-        ok = (jx >= 0) & (jx < nx) & (jy >= 0) & (jy < ny)
-        j = np.where(ok, jx + nx * jy, 0)
-        kf = 2.0 * k * k[j] / (k + k[j])
-        return ok, j, np.where(ok, kf, k)       # (a face on the boundary of the domain: the cell's own k, Dirichlet)
-
-    faces = [face(0, -1), face(-1, 0), face(1, 0), face(0, 1)]
-    diag = faces[0][2] + faces[1][2] + faces[2][2] + faces[3][2]
-    # the order inside a row: south, west, centre, east, north
-    rows = [r, r, r, r, r]
-    cols = [faces[0][1], faces[1][1], r, faces[2][1], faces[3][1]]
-    vals = [-faces[0][2], -faces[1][2], diag, -faces[2][2], -faces[3][2]]
-    keep = [faces[0][0], faces[1][0], np.ones(m, bool), faces[2][0], faces[3][0]]
-    rows, cols, vals, keep = (np.stack(v, axis=1).ravel() for v in (rows, cols, vals, keep))
-    irow, icol, a = rows[keep], cols[keep], vals[keep]
-    return m, n, (irow + 1).astype(np.int32), (icol + 1).astype(np.int32), a.astype(np.float64), _vec(7, m)
+    every interface, at every corner where four blocks meet, and along the boundary of the domain
+    (lsqr_amd/problems.py mesh2d, the host twin of the generator bench.py uses)."""
+    p = P.mesh2d(nx, ny, bx, by, seed=seed)
+    return p.m, p.n, p.irow, p.icol, p.a, p.b
 
 
 def test_a_piecewise_constant_coefficient_mesh_takes_two_bytes_per_row():
