@@ -14,7 +14,7 @@ for ov in 0 1; do
   LSQR_BENCH_STRONG_REF=1 LSQRHIP_SHARD_OVERLAP=$ov LSQR_RANKS_SHARE_GPU=1 LSQR_DIST_PROBE_TIMEOUT=600 python bench.py --gpus 8 --steps 20 --warmup 2 --workload random:10000000:10000000:100 --traffic off --cpu-iters 0 2> $OUT/rccl_shared_gpu_configs3_w8_overlap$ov.err | grep '^{' | tail -1 > $OUT/rccl_shared_gpu_configs3_w8_overlap$ov.json
 done
 LSQR_BENCH_STRONG_REF=0 LSQR_RANKS_SHARE_GPU=1 LSQR_DIST_PROBE_TIMEOUT=600 python bench.py --gpus 4 --steps 20 --warmup 2 --workload random:2000000:1000000:50 --traffic off --cpu-iters 0 2> $OUT/rccl_shared_gpu_variants_w4.err | grep '^{' | tail -1 > $OUT/rccl_shared_gpu_variants_w4.json
-bash scripts/profile_r05.sh config2 config2_packed poisson4000_pat poisson4000_dict poisson4000_val8 poisson4000_spat config4 shard8 shard8_r1000 shard8_plan config3_100 config3_literal config5 > $OUT/profile_log.txt 2>&1
+bash scripts/profile_r05.sh config2 config2_packed poisson4000_pat poisson4000_dict poisson4000_val8 poisson4000_spat config4 shard8 shard8_r1000 shard8_plan config3_100 config3_literal config5 mesh4000_wide > $OUT/profile_log.txt 2>&1
 export PMC_SETS="TCC_HIT_sum,TCC_MISS_sum TCP_TCC_READ_REQ_sum,TCP_TOTAL_CACHE_ACCESSES_sum FETCH_SIZE WRITE_SIZE"
 bash scripts/pmc_csb.sh random:10000000:10000000:100 r05/pmc_c4 > $OUT/pmc_config4.txt 2>&1
 bash scripts/pmc_csb.sh powerlaw:5000000:2000000:10000 r05/pmc_c5 > $OUT/pmc_config5.txt 2>&1
