@@ -142,7 +142,7 @@ def run(ncases, seed, verbose=True, bands=False, only=None, engine=False, real32
         return run_real32(ncases, seed, verbose)
     rs = np.random.RandomState(seed)
     po = oracle.port()
-    bad = widened = total = se_wide = 0
+    bad = widened = total = se_wide = wide_hits = 0
     for case in range(ncases):
         m, n, irow, icol, a, b = make_case(rs)
         xp, yp = rs.uniform(-1, 1, size=n), rs.uniform(-1, 1, size=m)
@@ -257,6 +257,8 @@ def run(ncases, seed, verbose=True, bands=False, only=None, engine=False, real32
                                                                               (r.istop == o.istop or r.itn != o.itn)))
                 info = s.info()
                 total += 1
+                if info.get("pat_wide") or info.get("pat_wide_t"):
+                    wide_hits += 1
                 if ok and not e3 < TIGHT:
                     widened += 1
                 if ok and se_widened:
@@ -281,7 +283,8 @@ def run(ncases, seed, verbose=True, bands=False, only=None, engine=False, real32
         bad += 1
         print(f"FAIL: {se_wide} of {total} standard-error results needed a measured band (at most {MAX_WIDENED_SHARE:.0%} may)")
     if verbose:
-        print(f"({se_wide} of {total} standard-error vectors were accepted on the reference's own measured band)")
+        print(f"({se_wide} of {total} standard-error vectors were accepted on the reference's own measured band; "
+              f"{wide_hits} results went through the wide row-pattern table)")
         print(f"{ncases} cases x {len(ENGINES if engine else LAYOUTS)} {'engine variants' if engine else 'layouts'}: {bad} failures; {widened} of {total} results needed more than "
               f"{TIGHT:g} (at most {MAX_WIDENED_SHARE:.0%} may)")
     return bad, widened, total
