@@ -144,6 +144,7 @@ struct Csr {
     int *pdelta = nullptr;           // ... [PAT_MAX_E] column - row of each entry
     double *pval = nullptr;          // ... [PAT_MAX_E] value of each entry
     int npat = 0, npat_e = 0;        // patterns, entries in use
+    bool pat_pair = false;           // sell = 3, one-byte table: lane L owns rows 2L, 2L + 1 of a 128-row group (pat.h "paired rows"); nblk counts blocks of 4 groups
     bool pat_wide = false;           // sell = 3, 257 ... 4096 patterns (pat.h "wide"): pid holds u16, the table is pent and stays in global memory
     int pat_u = 2;                   // ... slices a wave takes through a trip together (LSQRHIP_PAT2_U)
     void *pent = nullptr;            // ... [npat * pat_stride] PatEnt { value, column - row, length }: entry k of pattern p at p * pat_stride + k
@@ -522,7 +523,8 @@ static int try_pat(hipStream_t s, Csr &out, int64_t nnz, bool vals, unsigned lon
     HIPCHK(s_desc.alloc(sizeof(unsigned) * PAT_MAX));
     HIPCHK(s_delta.alloc(sizeof(int) * PAT_MAX_E));
     HIPCHK(s_val.alloc(sizeof(double) * PAT_MAX_E));
-    HIPCHK(s_pid.alloc((size_t)rows));
+    HIPCHK(s_pid.alloc((size_t)rows + 2));   // (two bytes of padding: the paired-rows kernel reads two pattern numbers at once)
+    HIPCHK(hipMemsetAsync(s_pid.as<unsigned char>() + rows, 0, 2, s));
     HIPCHK(hipMemsetAsync(s_desc.p, 0, sizeof(unsigned) * PAT_MAX, s));
     HIPCHK(hipMemsetAsync(s_slot.p, 0xff, sizeof(int) * PAT_TAB, s));
     HIPCHK(hipMemsetAsync(s_delta.p, 0, sizeof(int) * PAT_MAX_E, s));
@@ -593,6 +595,12 @@ static int try_pat(hipStream_t s, Csr &out, int64_t nnz, bool vals, unsigned lon
     out.npat_e = got[3];
     out.nslices = (rows + 63) / 64;
     out.nblk = (out.nslices + SELL_SLICES - 1) / SELL_SLICES;
+    // paired rows (pat.h): half the vector-memory requests per row.  LSQRHIP_PAT_PAIR=0 / 1.
+    out.pat_pair = env_int("LSQRHIP_PAT_PAIR", 1) != 0 && out.cols >= 2;
+    if (out.pat_pair) {
+        out.nblk = (out.nslices + 2 * SELL_SLICES - 1) / (2 * SELL_SLICES);
+        out.pat_u = std::min(std::max(env_int("LSQRHIP_PAT_PAIR_U", 1), 1), 2);   // groups a wave takes through a trip together (2: 128 registers, slower)
+    }
     out.nstored = 0;
     // what one product reads of the matrix: a byte per row and the table
     out.bytes = (int64_t)rows + (int64_t)sizeof(unsigned) * PAT_MAX + 12ll * got[3];
@@ -2338,6 +2346,9 @@ extern "C" int lsqrhip_get_option(lsqrhip_handle_t h, const char *name, int64_t 
     } else if (k == "csb_splits_mode1" || k == "csb_splits_mode2") {
         const Csr &c = k == "csb_splits_mode1" ? h->A : h->AT;
         *value = c.csb ? c.S : 0;
+    } else if (k == "pat_pair_mode1" || k == "pat_pair_mode2") {   // row patterns in the paired-rows form (pat.h)
+        const Csr &c = k == "pat_pair_mode1" ? h->A : h->AT;
+        *value = c.pat_pair ? 1 : 0;
     } else if (k == "pat_wide_mode1" || k == "pat_wide_mode2") {   // patterns of the wide row-pattern table in use (0: another layout)
         const Csr &c = k == "pat_wide_mode1" ? h->A : h->AT;
         *value = c.pat_wide ? c.npat : 0;

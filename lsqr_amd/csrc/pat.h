@@ -385,6 +385,214 @@ __global__ __launch_bounds__(SELL_BLOCK, 4) void k_spmv_pat(
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// PAIRED ROWS (Csr.pat_pair): the same one-byte layout, the same table in LDS, the same row sums -- with lane L of a
+// wave owning rows 2L and 2L + 1 of a 128-row group instead of row L of a 64-row slice.  What the pattern kernels run
+// out of is vector-memory REQUESTS, not bytes (profiles/r05/pmc_short_rows.txt: k_spmv_pat issues 7.1 reads + 1 store per
+// 64 rows at ~26 cycles each per CU, the texture addressers 70 % busy, at 0.59 of the HBM peak).  Two neighbouring rows
+// per lane turn every stream into 16-byte requests -- two pattern numbers in one 2-byte load, y read and stored as a
+// pair -- and, where the two rows name the SAME pattern (every lane of a group: wave-uniform; a stencil's interior), the
+// two gathers of an entry into ONE 16-byte gather of x[r + delta], x[r + 1 + delta] (8-byte aligned): 8 requests per
+// 128 rows where the slice kernel has 16.  A group with a lane whose rows differ -- the ends of a grid row -- gathers
+// per row, as before.  Every row sum is the same left-to-right sum; the partial sums of the norms run over other
+// rows per thread, so a norm may differ from the slice kernels' in its last bit.
+// ---------------------------------------------------------------------------------------------------------------
+typedef double lsqrhip_d2u __attribute__((ext_vector_type(2), aligned(8)));
+typedef float lsqrhip_f2u __attribute__((ext_vector_type(2), aligned(4)));
+__device__ __forceinline__ void ld_pair(const double *p, double &a, double &b)
+{
+    const lsqrhip_d2u v = *reinterpret_cast<const lsqrhip_d2u *>(p);
+    a = v.x;
+    b = v.y;
+}
+__device__ __forceinline__ void ld_pair(const float *p, double &a, double &b)
+{
+    const lsqrhip_f2u v = *reinterpret_cast<const lsqrhip_f2u *>(p);
+    a = (double)v.x;
+    b = (double)v.y;
+}
+__device__ __forceinline__ void store_through2(double *p, double a, double b)
+{
+    lsqrhip_d2 v;
+    v.x = a;
+    v.y = b;
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void store_through2(float *p, float a, float b)
+{
+    lsqrhip_f2 v;
+    v.x = a;
+    v.y = b;
+    asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+}
+
+template <bool UPD, typename VT = double, bool NT = false, int U = 1>
+__global__ __launch_bounds__(SELL_BLOCK, 4) void k_spmv_patp(
+    const unsigned char *__restrict__ pid, const unsigned *__restrict__ desc, const int *__restrict__ delta,
+    const double *__restrict__ pval, int nent, int rows, int64_t nblk, const VT *__restrict__ x, VT *__restrict__ y,
+    const SpmvCoef *__restrict__ coef, const int *__restrict__ stop, double *__restrict__ partials,
+    const double *__restrict__ pin, int npin, const NormSlot *__restrict__ slot_in, NormSlot *__restrict__ slot_out,
+    int skip_if_zero, Rider rider, UpdArgs upd, NScale nsc)
+{
+    typedef typename Vec2<VT>::type V2T;
+    __shared__ double red[SELL_BLOCK / WAVE + 1];
+    __shared__ unsigned sdesc[PAT_MAX];
+    __shared__ int sdelta[PAT_MAX_E];
+    __shared__ double sval[PAT_MAX_E];
+    const int shift = rider.kind != 0 ? 1 : 0;
+    const int nwg = (int)gridDim.x - shift;
+    const int wg = (int)blockIdx.x - shift;
+    if (wg < 0) {
+        run_rider(rider, red);
+        return;
+    }
+    const int tid = threadIdx.x;
+    const unsigned desc_mine = desc[tid];
+    int d_mine[PAT_MAX_E / SELL_BLOCK];
+    double v_mine[PAT_MAX_E / SELL_BLOCK];
+#pragma unroll
+    for (int j = 0; j < PAT_MAX_E / SELL_BLOCK; ++j) {
+        const int e = tid + j * SELL_BLOCK;
+        d_mine[j] = e < nent ? delta[e] : 0;
+        v_mine[j] = e < nent ? pval[e] : 0.0;
+    }
+    const bool pre = pin != nullptr && npin <= PAT_SHARE_K * SELL_BLOCK;   // (uniform)
+    double pshare[PAT_SHARE_K];
+    if (pre) strided_share_load<SELL_BLOCK, PAT_SHARE_K>(pin, npin, pshare);
+    const int lane = tid & (WAVE - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const XcdRange xr = xcd_range(nblk, nwg, wg);   // blocks of SELL_SLICES groups of 2 * WAVE rows
+    // the two pattern numbers of the lane's rows in group (b, wave) (pid has two bytes of padding behind the last row)
+    auto pids_of = [&](int64_t b) -> int {
+        const int64_t r0 = (b * SELL_SLICES + wave) * (2 * WAVE) + 2 * lane;
+        return (b < xr.end && r0 < rows) ? (int)ld_stream<NT>(reinterpret_cast<const unsigned short *>(pid + r0)) : 0;
+    };
+    int64_t b = xr.first;
+    int pid_next[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) pid_next[u] = pids_of(b + u * xr.stride);
+
+    if (*stop != 0) return;
+    sdesc[tid] = desc_mine;
+#pragma unroll
+    for (int j = 0; j < PAT_MAX_E / SELL_BLOCK; ++j) {
+        const int e = tid + j * SELL_BLOCK;
+        if (e < nent) {
+            sdelta[e] = d_mine[j];
+            sval[e] = v_mine[j];
+        }
+    }
+    SellCoef kc;
+    const double share = pre ? strided_share_sum<SELL_BLOCK, PAT_SHARE_K>(pshare, npin) : 0.0;
+    if (!sell_prologue<UPD, VT, NT>(coef, pin, npin, slot_in, slot_out, skip_if_zero, upd, nwg, wg, red, kc, nsc, pre, share))
+        return;
+    const double sx = kc.sx, sy = kc.sy, cy = kc.cy;
+    __syncthreads();
+
+    double sq = 0.0;
+    for (; b < xr.end; b += U * xr.stride) {
+        int r0[U], e0[U], len0[U], e1[U], len1[U];
+        bool act0[U], act1[U], full[U];
+        double y0[U], y1[U], a0[U][PAT_K], a1[U][PAT_K], x0[U][PAT_K], x1[U][PAT_K];
+        int pp[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) pp[u] = pid_next[u];
+#pragma unroll
+        for (int u = 0; u < U; ++u) pid_next[u] = pids_of(b + (U + u) * xr.stride);
+        // everything the first PAT_K entries of the rows of the trip's groups need, requested before any of it is used
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t bu = b + u * xr.stride;
+            const int64_t R0 = (bu * SELL_SLICES + wave) * (2 * WAVE);
+            const int64_t r64 = R0 + 2 * lane;
+            const bool in = bu < xr.end;
+            act0[u] = in && r64 < rows;
+            act1[u] = in && r64 + 1 < rows;
+            r0[u] = act0[u] ? (int)r64 : 0;
+            const unsigned d0 = act0[u] ? sdesc[pp[u] & 255] : 0u, d1 = act1[u] ? sdesc[pp[u] >> 8] : 0u;
+            e0[u] = (int)(d0 & 0xffffu);
+            len0[u] = (int)(d0 >> 16);
+            e1[u] = (int)(d1 & 0xffffu);
+            len1[u] = (int)(d1 >> 16);
+            full[u] = in && R0 + 2 * WAVE <= rows;                                              // (uniform)
+            const bool pair = full[u] && __all((pp[u] & 255) == (pp[u] >> 8)) != 0;            // (uniform) every lane: one pattern for both rows
+            if (full[u]) {
+                const V2T yv = ld_stream2<NT>(reinterpret_cast<const V2T *>(&y[r0[u]]));
+                y0[u] = (double)yv.x;
+                y1[u] = (double)yv.y;
+            } else {
+                y0[u] = act0[u] ? (double)y[r0[u]] : 0.0;
+                y1[u] = act1[u] ? (double)y[r0[u] + 1] : 0.0;
+            }
+            if (pair) {
+#pragma unroll
+                for (int k = 0; k < PAT_K; ++k) {
+                    const bool live = k < len0[u];
+                    const int e = live ? e0[u] + k : 0;
+                    a0[u][k] = sval[e];
+                    a1[u][k] = a0[u][k];
+                    ld_pair(&x[live ? r0[u] + sdelta[e] : 0], x0[u][k], x1[u][k]);   // (no entry: x[0], x[1], never added; the layout needs two columns)
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < PAT_K; ++k) {
+                    const bool l0 = k < len0[u], l1 = k < len1[u];
+                    const int ea = l0 ? e0[u] + k : 0, eb = l1 ? e1[u] + k : 0;
+                    a0[u][k] = sval[ea];
+                    a1[u][k] = sval[eb];
+                    x0[u][k] = (double)x[l0 ? r0[u] + sdelta[ea] : 0];
+                    x1[u][k] = (double)x[l1 ? r0[u] + 1 + sdelta[eb] : 0];
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            double sum0 = 0.0, sum1 = 0.0;
+#pragma unroll
+            for (int k = 0; k < PAT_K; ++k) {
+                const double p0 = a0[u][k] * (x0[u][k] * sx), p1 = a1[u][k] * (x1[u][k] * sx);
+                if (k < len0[u]) sum0 = sum0 + p0;
+                if (k < len1[u]) sum1 = sum1 + p1;
+            }
+            for (int k0 = PAT_K; __any(k0 < len0[u] || k0 < len1[u]); k0 += PAT_K) {   // rows of more than PAT_K nonzeros
+                double b0[PAT_K], b1[PAT_K], z0[PAT_K], z1[PAT_K];
+#pragma unroll
+                for (int k = 0; k < PAT_K; ++k) {
+                    const bool l0 = k0 + k < len0[u], l1 = k0 + k < len1[u];
+                    const int ea = l0 ? e0[u] + k0 + k : 0, eb = l1 ? e1[u] + k0 + k : 0;
+                    b0[k] = sval[ea];
+                    b1[k] = sval[eb];
+                    z0[k] = (double)x[l0 ? r0[u] + sdelta[ea] : 0];
+                    z1[k] = (double)x[l1 ? r0[u] + 1 + sdelta[eb] : 0];
+                }
+#pragma unroll
+                for (int k = 0; k < PAT_K; ++k) {
+                    const double p0 = b0[k] * (z0[k] * sx), p1 = b1[k] * (z1[k] * sx);
+                    if (k0 + k < len0[u]) sum0 = sum0 + p0;
+                    if (k0 + k < len1[u]) sum1 = sum1 + p1;
+                }
+            }
+            const VT yn0 = (VT)(cy * (y0[u] * sy) + sum0), yn1 = (VT)(cy * (y1[u] * sy) + sum1);
+            if (full[u]) {
+                store_through2(&y[r0[u]], yn0, yn1);
+            } else {
+                if (act0[u]) store_through(&y[r0[u]], yn0);
+                if (act1[u]) store_through(&y[r0[u] + 1], yn1);
+            }
+            if (act0[u]) {
+                const double ys = (double)yn0 * nsc.s;
+                sq += ys * ys;
+            }
+            if (act1[u]) {
+                const double ys = (double)yn1 * nsc.s;
+                sq += ys * ys;
+            }
+        }
+    }
+    const double tot = block_sum<SELL_BLOCK>(sq, red);
+    if (tid == 0) partials[wg] = tot;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Structure patterns (sell = 4): rows whose column STRUCTURE repeats while their values do not -- a stencil with
 // variable coefficients.  The pattern table holds (length, column offsets) only; the values stay 8 bytes each,
 // column-major per 64-row slice as in sell.h (element (row i of slice s, k) at soff[s] + 64 k + i, padding 0.0, never

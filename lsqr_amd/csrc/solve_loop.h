@@ -215,6 +215,24 @@ static void launch_pat2_U(const SpmvArgs &a, const dim3 grid)
                               a.skip_if_zero, a.rider, a.upd, a.nsc);
 }
 
+template <bool UPD, typename VT, bool NT, int U>
+static void launch_patp_U(const SpmvArgs &a, const dim3 grid)
+{
+    const Csr &c = *a.c;
+    const VT *x = reinterpret_cast<const VT *>(a.x);
+    VT *y = reinterpret_cast<VT *>(a.y);
+    if (a.e0 == nullptr && a.e1 == nullptr)
+        hipLaunchKernelGGL((k_spmv_patp<UPD, VT, NT, U>), grid, dim3(SELL_BLOCK), 0, a.stream, (const unsigned char *)c.pid,
+                           (const unsigned *)c.pdesc, (const int *)c.pdelta, (const double *)c.pval, c.npat_e, c.rows,
+                           c.nblk, x, y, a.coef, a.stop, a.pout, a.pin, a.npin, a.slot_in, a.slot_out, a.skip_if_zero,
+                           a.rider, a.upd, a.nsc);
+    else
+        hipExtLaunchKernelGGL((k_spmv_patp<UPD, VT, NT, U>), grid, dim3(SELL_BLOCK), 0, a.stream, a.e0, a.e1, 0,
+                              (const unsigned char *)c.pid, (const unsigned *)c.pdesc, (const int *)c.pdelta,
+                              (const double *)c.pval, c.npat_e, c.rows, c.nblk, x, y, a.coef, a.stop, a.pout, a.pin,
+                              a.npin, a.slot_in, a.slot_out, a.skip_if_zero, a.rider, a.upd, a.nsc);
+}
+
 template <bool UPD, typename VT, bool NT>
 static void launch_pat_N(const SpmvArgs &a)
 {
@@ -227,6 +245,11 @@ static void launch_pat_N(const SpmvArgs &a)
         case 1: launch_pat2_U<UPD, VT, NT, 1>(a, grid); break;
         default: launch_pat2_U<UPD, VT, NT, 2>(a, grid); break;
         }
+        return;
+    }
+    if (c.pat_pair) {   // lane L owns rows 2L, 2L + 1 (pat.h "paired rows")
+        if (c.pat_u == 2) launch_patp_U<UPD, VT, NT, 2>(a, grid);
+        else launch_patp_U<UPD, VT, NT, 1>(a, grid);
         return;
     }
     if (a.e0 == nullptr && a.e1 == nullptr)

@@ -36,10 +36,11 @@ TIGHT = 1e-9
 MAX_WIDENED_SHARE = 0.10
 
 KNOBS = ["LSQRHIP_SELL", "LSQRHIP_SELLP", "LSQRHIP_VAL8", "LSQRHIP_COL16", "LSQRHIP_PANELS", "LSQRHIP_PANEL_KB",
-         "LSQRHIP_XLDS", "LSQRHIP_XLDS_COLS", "LSQRHIP_OFF64", "LSQRHIP_SKEW", "LSQRHIP_TUNE", "LSQRHIP_CSB", "LSQRHIP_CSB_R", "LSQRHIP_CSB_S", "LSQRHIP_CSB_NARROW", "LSQRHIP_PAT", "LSQRHIP_PAT2", "LSQRHIP_SPAT"]
+         "LSQRHIP_XLDS", "LSQRHIP_XLDS_COLS", "LSQRHIP_OFF64", "LSQRHIP_SKEW", "LSQRHIP_TUNE", "LSQRHIP_CSB", "LSQRHIP_CSB_R", "LSQRHIP_CSB_S", "LSQRHIP_CSB_NARROW", "LSQRHIP_PAT", "LSQRHIP_PAT2", "LSQRHIP_PAT_PAIR", "LSQRHIP_SPAT"]
 LAYOUTS = [
     {},                                                                        # whatever the build chooses
     {"LSQRHIP_PAT": "1"},                                                      # row patterns whenever the limits hold (pat.h)
+    {"LSQRHIP_PAT": "1", "LSQRHIP_PAT_PAIR": "0"},                             # ... in the slice form (lane L owns row L) instead of paired rows
     {"LSQRHIP_PAT": "1", "LSQRHIP_PAT2": "1"},                                 # ... up to 4096 of them (two-byte pattern numbers)
     {"LSQRHIP_PAT": "0", "LSQRHIP_SPAT": "1"},                                 # structure patterns whenever the limits hold
     {"LSQRHIP_PAT": "0", "LSQRHIP_SPAT": "0"},                                 # ... and neither kind

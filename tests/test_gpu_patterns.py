@@ -14,7 +14,7 @@ from lsqr_amd.solver import lsqr_solver_ez
 
 pytestmark = pytest.mark.gpu
 CASES = build_cases()
-KNOBS = ("LSQRHIP_STREAM_NT", "LSQRHIP_PAT", "LSQRHIP_PAT2", "LSQRHIP_SPAT", "LSQRHIP_SELL", "LSQRHIP_SELLP", "LSQRHIP_VAL8", "LSQRHIP_COL16", "LSQRHIP_CSB")
+KNOBS = ("LSQRHIP_STREAM_NT", "LSQRHIP_PAT", "LSQRHIP_PAT2", "LSQRHIP_PAT_PAIR", "LSQRHIP_SPAT", "LSQRHIP_SELL", "LSQRHIP_SELLP", "LSQRHIP_VAL8", "LSQRHIP_COL16", "LSQRHIP_CSB")
 
 
 @pytest.fixture(autouse=True)
@@ -89,13 +89,31 @@ def test_a_stencil_is_stored_as_row_patterns_and_gives_the_references_bits(shape
     info = s.info()
     # a byte per row and the table: far below the 16 bytes per row of the packed records
     assert info["csr_bytes"] <= p.m + 1024 + 12 * 1024
-    # ... and the same bits as the layouts underneath
+    # ... and the layouts underneath: the same bits from the slice form of the pattern kernel (lane L owns row L of a
+    # 64-row slice, as in sell.h: the same rows per thread, the same partial sums of the norms); the paired form -- the
+    # default: lane L owns rows 2L, 2L + 1 -- forms the same row sums and adds their squares in another order
+    os.environ["LSQRHIP_PAT_PAIR"] = "0"
+    s1 = lsqr_solver_ez().initialize(p.m, p.n, p.a, p.irow, p.icol, itnlim=25)
+    assert s1.info()["sell"] == 3 and s1.get_option("pat_pair_mode1") == 0 and s.get_option("pat_pair_mode1") == (1 if p.n >= 2 else 0)
+    r1 = s1.solve(p.b, 0.0)
     os.environ["LSQRHIP_PAT"] = "0"
     os.environ["LSQRHIP_SPAT"] = "0"
     s0 = lsqr_solver_ez().initialize(p.m, p.n, p.a, p.irow, p.icol, itnlim=25)
     assert s0.info()["sell"] in (1, 2)
     r0 = s0.solve(p.b, 0.0)
-    assert np.array_equal(r0.x, r.x) and r0.anorm == r.anorm and r0.rnorm == r.rnorm and r0.itn == r.itn
+    assert np.array_equal(r0.x, r1.x) and r0.anorm == r1.anorm and r0.rnorm == r1.rnorm and r0.itn == r1.itn
+    assert r0.itn == r.itn and np.linalg.norm(r0.x - r.x) <= 1e-12 * np.linalg.norm(r.x)
+    assert abs(r0.anorm - r.anorm) <= 1e-13 * r.anorm and abs(r0.rnorm - r.rnorm) <= 1e-12 * r.rnorm
+    # the products themselves: bit for bit, paired or not
+    xp, yp = _vec(9, p.n), _vec(10, p.m)
+    outs = []
+    for sv in (s, s1, s0):
+        x, y = xp.copy(), yp.copy()
+        sv.aprod(1, p.m, p.n, x, y)
+        x2, y2 = xp.copy(), yp.copy()
+        sv.aprod(2, p.m, p.n, x2, y2)
+        outs.append((y, x2))
+    assert all(np.array_equal(o[0], outs[0][0]) and np.array_equal(o[1], outs[0][1]) for o in outs[1:])
 
 
 def test_unsymmetric_patterns_duplicates_and_the_order_inside_a_row():
@@ -240,13 +258,16 @@ def test_real32_patterns():
     assert np.array_equal(r.x, r0.x) and r.itn == r0.itn and r.anorm == r0.anorm
 
 
+@pytest.mark.parametrize("pair", ["1", "0"])
 @pytest.mark.parametrize("name", sorted(CASES))
-def test_the_golden_parity_cases_with_patterns_forced(name):
+def test_the_golden_parity_cases_with_patterns_forced(name, pair):
     """Every case of tests/test_gpu_parity.py once more with LSQRHIP_PAT=1: whatever has <= 256 distinct rows of <= 64
     nonzeros and <= 1024 entries -- most of the small systems: every row its own pattern -- goes through the pattern
-    kernel and must hold the same golden values; the others keep their layout."""
+    kernel (paired rows, the default, and the slice form) and must hold the same golden values; the others keep
+    their layout."""
     import test_gpu_parity as tp
     os.environ["LSQRHIP_PAT"] = "1"
+    os.environ["LSQRHIP_PAT_PAIR"] = pair
     tp.test_solve_parity_vs_reference_golden(name)
 
 
