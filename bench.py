@@ -182,10 +182,11 @@ def build_workload(spec: str, env=None, itnlim=100, rows=None):
 def describe_layout(info):
     if info["sell"] == 4:
         return "structure patterns (one byte per row + 8-byte values, column offsets in LDS)", "k_spmv_spat"
+    pair = " -- paired rows" if info.get("pat_pair") else ""
     if info["sell"] == 3 and info.get("pat_wide"):
-        return "row patterns (two bytes per row, the table through L2)", "k_spmv_pat2"
+        return "row patterns (two bytes per row, the table through L2)" + pair, "k_spmv_pat2p" if pair else "k_spmv_pat2"
     if info["sell"] == 3:
-        return "row patterns (one byte per row, patterns in LDS)", "k_spmv_pat"
+        return "row patterns (one byte per row, patterns in LDS)" + pair, "k_spmv_patp" if pair else "k_spmv_pat"
     if info["sell"] == 2:
         return "sliced ELL, packed 16-byte records", "k_spmv_sellp"
     if info["sell"]:

@@ -597,10 +597,7 @@ static int try_pat(hipStream_t s, Csr &out, int64_t nnz, bool vals, unsigned lon
     out.nblk = (out.nslices + SELL_SLICES - 1) / SELL_SLICES;
     // paired rows (pat.h): half the vector-memory requests per row.  LSQRHIP_PAT_PAIR=0 / 1.
     out.pat_pair = env_int("LSQRHIP_PAT_PAIR", 1) != 0 && out.cols >= 2;
-    if (out.pat_pair) {
-        out.nblk = (out.nslices + 2 * SELL_SLICES - 1) / (2 * SELL_SLICES);
-        out.pat_u = std::min(std::max(env_int("LSQRHIP_PAT_PAIR_U", 1), 1), 2);   // groups a wave takes through a trip together (2: 128 registers, slower)
-    }
+    if (out.pat_pair) out.nblk = (out.nslices + 2 * SELL_SLICES - 1) / (2 * SELL_SLICES);
     out.nstored = 0;
     // what one product reads of the matrix: a byte per row and the table
     out.bytes = (int64_t)rows + (int64_t)sizeof(unsigned) * PAT_MAX + 12ll * got[3];
@@ -661,7 +658,8 @@ static int try_pat2(hipStream_t s, Csr &out, int64_t nnz)
     if (ne > PAT2_MAX_E) return LSQRHIP_OK;
     HIPCHK(s_slot.alloc(sizeof(int) * PAT2_TAB));
     HIPCHK(s_ent.alloc(sizeof(PatEnt) * (size_t)ne));
-    HIPCHK(s_pid.alloc(sizeof(unsigned short) * (size_t)rows));
+    HIPCHK(s_pid.alloc(sizeof(unsigned short) * ((size_t)rows + 2)));   // (two numbers of padding: the paired-rows kernel reads two at once)
+    HIPCHK(hipMemsetAsync(s_pid.as<unsigned short>() + rows, 0, 2 * sizeof(unsigned short), s));
     HIPCHK(hipMemcpyAsync(s_slot.p, slot_pat.data(), sizeof(int) * PAT2_TAB, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemsetAsync(s_ent.p, 0, sizeof(PatEnt) * (size_t)ne, s));
     hipLaunchKernelGGL(k_pat2_fill, dim3(PAT2_TAB / 256), dim3(256), 0, s, (const int *)out.rowptr, (const int *)out.col,
@@ -681,13 +679,14 @@ static int try_pat2(hipStream_t s, Csr &out, int64_t nnz)
     out.sell = 3;
     out.pat_wide = true;
     out.pat_u = std::min(std::max(env_int("LSQRHIP_PAT2_U", 2), 1), 2);
+    out.pat_pair = env_int("LSQRHIP_PAT_PAIR", 1) != 0 && out.cols >= 2;   // paired rows (pat.h)
     out.pat_stride = stride;
     out.pid = s_pid.release<unsigned char>();
     out.pent = s_ent.release<void>();
     out.npat = np;
     out.npat_e = (int)ne;
     out.nslices = (rows + 63) / 64;
-    out.nblk = (out.nslices + SELL_SLICES - 1) / SELL_SLICES;
+    out.nblk = out.pat_pair ? (out.nslices + 2 * SELL_SLICES - 1) / (2 * SELL_SLICES) : (out.nslices + SELL_SLICES - 1) / SELL_SLICES;
     out.nstored = 0;
     // what one product reads of the matrix: two bytes per row and the table
     out.bytes = 2ll * rows + (int64_t)sizeof(PatEnt) * ne;

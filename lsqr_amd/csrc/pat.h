@@ -28,6 +28,10 @@
 // Chosen when the matrix has <= 256 distinct rows of <= 64 nonzeros, <= 1024 pattern entries, and at least 16 rows per
 // pattern.  LSQRHIP_PAT=0 never, =1 whenever the limits hold.
 //
+// PAIRED ROWS (round 5, the default: k_spmv_patp below): the same layout with lane L owning rows 2L, 2L + 1 of a 128-row
+// group -- half the vector-memory requests per row, which is what these kernels run out of.  The slice form here
+// (LSQRHIP_PAT_PAIR=0) keeps the rows-per-thread of sell.h, and with them norms bit-equal to the other short-row layouts.
+//
 // Second part of the file: STRUCTURE patterns (sell = 4) -- the same table over (length, column offsets) alone, for rows
 // whose values do not repeat (variable coefficients): 8-byte values column-major per slice and no column indices.
 // Third part: WIDE row patterns -- 257 ... 4096 distinct rows: two bytes per row, the table in global memory.
@@ -395,6 +399,10 @@ __global__ __launch_bounds__(SELL_BLOCK, 4) void k_spmv_pat(
 // 128 rows where the slice kernel has 16.  A group with a lane whose rows differ -- the ends of a grid row -- gathers
 // per row, as before.  Every row sum is the same left-to-right sum; the partial sums of the norms run over other
 // rows per thread, so a norm may differ from the slice kernels' in its last bit.
+// Measured (profiles/r05/pair_ab.txt, one process per pair of lines): 16M-row Poisson 85-86 -> 71-72 us per product
+// (0.59 -> 0.70 of 8 TB/s on its 25 bytes per row); configs[1] 7.3 -> 6.7 us per product, 47.5-47.8k -> 49.2-49.4k
+// iterations/s at K = 2000 and 41.0-41.5k -> 42.4-43.1k at K = 20.  Two groups per trip (128 registers): 45.5-46.6k.
+// 1024 workgroups stay the best grid (768: 46.5-47.0k, 1536: 45.4k, 2048: 38.7k; profiles/r05/pair_grid.txt).
 // ---------------------------------------------------------------------------------------------------------------
 typedef double lsqrhip_d2u __attribute__((ext_vector_type(2), aligned(8)));
 typedef float lsqrhip_f2u __attribute__((ext_vector_type(2), aligned(4)));
@@ -976,6 +984,182 @@ __global__ __launch_bounds__(SELL_BLOCK, 4) void k_spmv_pat2(
             one_c[u] = one_n[u];
 #pragma unroll
             for (int k = 0; k < PAT_K; ++k) q_c[u][k] = q_n[u][k];
+        }
+    }
+    const double tot = block_sum<SELL_BLOCK>(sq, red);
+    if (tid == 0) partials[wg] = tot;
+}
+
+// The wide table in PAIRED ROWS (see "PAIRED ROWS" above: lane L owns rows 2L, 2L + 1 of a 128-row group): two pattern
+// numbers in one 4-byte load, y read and stored as a pair, and in a group whose 128 rows all name ONE pattern the
+// entries in one request and every entry's two gathers of x in one 16-byte gather -- 9 requests per 128 rows where
+// k_spmv_pat2 has 20.  A group that crosses an interface requests the entries of both rows of every lane and gathers
+// per row.  The same pipeline: pattern numbers of trip t + 2, entries of t + 1, gathered x of t.
+// What it buys depends on how many 128-row groups lie inside one region: the 16M-row mesh of 16 x 16 regions (250
+// columns each: every second group crosses an interface, every fourth 64-row slice did) 103 -> 101 us; regions of 1000
+// columns 86 -> 76 us (profiles/r05/wide_patterns_paired.txt).
+template <bool UPD, typename VT = double, bool NT = false>
+__global__ __launch_bounds__(SELL_BLOCK, 4) void k_spmv_pat2p(
+    const unsigned short *__restrict__ pid, const PatEnt *__restrict__ ent, int stride, int rows, int64_t nblk,
+    const VT *__restrict__ x, VT *__restrict__ y, const SpmvCoef *__restrict__ coef, const int *__restrict__ stop,
+    double *__restrict__ partials, const double *__restrict__ pin, int npin, const NormSlot *__restrict__ slot_in,
+    NormSlot *__restrict__ slot_out, int skip_if_zero, Rider rider, UpdArgs upd, NScale nsc)
+{
+    typedef typename Vec2<VT>::type V2T;
+    __shared__ double red[SELL_BLOCK / WAVE + 1];
+    const int shift = rider.kind != 0 ? 1 : 0;
+    const int nwg = (int)gridDim.x - shift;
+    const int wg = (int)blockIdx.x - shift;
+    if (wg < 0) {
+        run_rider(rider, red);
+        return;
+    }
+    const int tid = threadIdx.x;
+    const bool pre = pin != nullptr && npin <= PAT_SHARE_K * SELL_BLOCK;   // (uniform)
+    double pshare[PAT_SHARE_K];
+    if (pre) strided_share_load<SELL_BLOCK, PAT_SHARE_K>(pin, npin, pshare);
+    const int lane = tid & (WAVE - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const XcdRange xr = xcd_range(nblk, nwg, wg);   // blocks of SELL_SLICES groups of 2 * WAVE rows
+    auto row_of = [&](int64_t b) -> int64_t {       // the lane's first row in group (b, wave); >= rows: none
+        return b < xr.end ? (b * SELL_SLICES + wave) * (2 * WAVE) + 2 * lane : (int64_t)rows;
+    };
+    // the pattern numbers of the lane's two rows (pid has two numbers of padding behind the last row)
+    auto pids_of = [&](int64_t b) -> unsigned {
+        const int64_t r = row_of(b);
+        return r < rows ? ld_stream<NT>(reinterpret_cast<const unsigned *>(pid + r)) : 0u;
+    };
+    // the entries of a group on their way: q0[0] alone when its 128 rows name one pattern (`one`; lane k holds entry k),
+    // else q0[k] / q1[k] = entry k of the patterns of the lane's two rows
+    auto request = [&](int64_t b, unsigned pp, bool &one, uint4 (&q0)[PAT_K], uint4 (&q1)[PAT_K]) {
+        const int p0 = (int)(pp & 0xffffu), p1 = (int)(pp >> 16);
+        const int P = __builtin_amdgcn_readfirstlane(p0);
+        const bool full = b < xr.end && (b * SELL_SLICES + wave + 1) * (2 * WAVE) <= rows;   // (uniform)
+        one = full && __all(p0 == P && p1 == P) != 0;
+        if (one) {
+            q0[0] = pat2_load(ent, lane < stride ? P * stride + lane : 0);
+#pragma unroll
+            for (int k = 1; k < PAT_K; ++k) q0[k] = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+            for (int k = 0; k < PAT_K; ++k) q1[k] = make_uint4(0u, 0u, 0u, 0u);
+        } else {
+#pragma unroll
+            for (int k = 0; k < PAT_K; ++k) {
+                q0[k] = pat2_load(ent, k < stride ? p0 * stride + k : 0);
+                q1[k] = pat2_load(ent, k < stride ? p1 * stride + k : 0);
+            }
+        }
+    };
+    int64_t b = xr.first;
+    unsigned pid_2 = pids_of(b);   // pattern numbers, two trips ahead of the sums
+
+    if (*stop != 0) return;
+    SellCoef kc;
+    const double share = pre ? strided_share_sum<SELL_BLOCK, PAT_SHARE_K>(pshare, npin) : 0.0;
+    if (!sell_prologue<UPD, VT, NT>(coef, pin, npin, slot_in, slot_out, skip_if_zero, upd, nwg, wg, red, kc, nsc, pre, share))
+        return;
+    const double sx = kc.sx, sy = kc.sy, cy = kc.cy;
+    __syncthreads();
+
+    unsigned pp_c = pid_2;
+    bool one_c;
+    uint4 q0_c[PAT_K], q1_c[PAT_K];
+    request(b, pp_c, one_c, q0_c, q1_c);
+    pid_2 = pids_of(b + xr.stride);
+    double sq = 0.0;
+    for (; b < xr.end; b += xr.stride) {
+        const int64_t r64 = row_of(b);
+        const bool act0 = r64 < rows, act1 = r64 + 1 < rows;
+        const int r0 = act0 ? (int)r64 : 0;
+        const bool full = (b * SELL_SLICES + wave + 1) * (2 * WAVE) <= rows;   // (uniform)
+        double v0[PAT_K], v1[PAT_K], x0[PAT_K], x1[PAT_K], y0, y1;
+        int d0[PAT_K], d1[PAT_K], len0, len1;
+        if (full) {
+            const V2T yv = ld_stream2<NT>(reinterpret_cast<const V2T *>(&y[r0]));
+            y0 = (double)yv.x;
+            y1 = (double)yv.y;
+        } else {
+            y0 = act0 ? (double)y[r0] : 0.0;
+            y1 = act1 ? (double)y[r0 + 1] : 0.0;
+        }
+        if (one_c) {
+            len0 = len1 = __builtin_amdgcn_readlane((int)q0_c[0].w, 0);
+#pragma unroll
+            for (int k = 0; k < PAT_K; ++k) {   // (k >= stride: entry 0 of the table, never used: k >= len)
+                v0[k] = __hiloint2double(__builtin_amdgcn_readlane((int)q0_c[0].y, k), __builtin_amdgcn_readlane((int)q0_c[0].x, k));
+                v1[k] = v0[k];
+                d0[k] = d1[k] = __builtin_amdgcn_readlane((int)q0_c[0].z, k);
+                ld_pair(&x[k < len0 ? r0 + d0[k] : 0], x0[k], x1[k]);   // (no entry: x[0], x[1], never added; the layout needs two columns)
+            }
+        } else {
+            len0 = act0 ? (int)q0_c[0].w : 0;
+            len1 = act1 ? (int)q1_c[0].w : 0;
+#pragma unroll
+            for (int k = 0; k < PAT_K; ++k) {
+                v0[k] = __hiloint2double((int)q0_c[k].y, (int)q0_c[k].x);
+                v1[k] = __hiloint2double((int)q1_c[k].y, (int)q1_c[k].x);
+                d0[k] = (int)q0_c[k].z;
+                d1[k] = (int)q1_c[k].z;
+                x0[k] = (double)x[k < len0 ? r0 + d0[k] : 0];
+                x1[k] = (double)x[k < len1 ? r0 + 1 + d1[k] : 0];
+            }
+        }
+        // behind the gathers: the next trip's entries, the pattern numbers of the one after it
+        const unsigned pp_n = pid_2;
+        bool one_n;
+        uint4 q0_n[PAT_K], q1_n[PAT_K];
+        request(b + xr.stride, pp_n, one_n, q0_n, q1_n);
+        pid_2 = pids_of(b + 2 * xr.stride);
+        double sum0 = 0.0, sum1 = 0.0;
+#pragma unroll
+        for (int k = 0; k < PAT_K; ++k) {
+            const double t0 = v0[k] * (x0[k] * sx), t1 = v1[k] * (x1[k] * sx);
+            if (k < len0) sum0 = sum0 + t0;
+            if (k < len1) sum1 = sum1 + t1;
+        }
+        const int p0 = (int)(pp_c & 0xffffu), p1 = (int)(pp_c >> 16);
+        for (int k0 = PAT_K; __any(k0 < len0 || k0 < len1); k0 += PAT_K) {   // rows of more than PAT_K nonzeros
+            uint4 e0[PAT_K], e1[PAT_K];
+            double z0[PAT_K], z1[PAT_K];
+#pragma unroll
+            for (int k = 0; k < PAT_K; ++k) {
+                e0[k] = pat2_load(ent, k0 + k < len0 ? p0 * stride + k0 + k : 0);
+                e1[k] = pat2_load(ent, k0 + k < len1 ? p1 * stride + k0 + k : 0);
+            }
+#pragma unroll
+            for (int k = 0; k < PAT_K; ++k) {
+                z0[k] = (double)x[k0 + k < len0 ? r0 + (int)e0[k].z : 0];
+                z1[k] = (double)x[k0 + k < len1 ? r0 + 1 + (int)e1[k].z : 0];
+            }
+#pragma unroll
+            for (int k = 0; k < PAT_K; ++k) {
+                const double t0 = __hiloint2double((int)e0[k].y, (int)e0[k].x) * (z0[k] * sx);
+                const double t1 = __hiloint2double((int)e1[k].y, (int)e1[k].x) * (z1[k] * sx);
+                if (k0 + k < len0) sum0 = sum0 + t0;
+                if (k0 + k < len1) sum1 = sum1 + t1;
+            }
+        }
+        const VT yn0 = (VT)(cy * (y0 * sy) + sum0), yn1 = (VT)(cy * (y1 * sy) + sum1);
+        if (full) {
+            store_through2(&y[r0], yn0, yn1);
+        } else {
+            if (act0) store_through(&y[r0], yn0);
+            if (act1) store_through(&y[r0 + 1], yn1);
+        }
+        if (act0) {
+            const double ys = (double)yn0 * nsc.s;
+            sq += ys * ys;
+        }
+        if (act1) {
+            const double ys = (double)yn1 * nsc.s;
+            sq += ys * ys;
+        }
+        pp_c = pp_n;
+        one_c = one_n;
+#pragma unroll
+        for (int k = 0; k < PAT_K; ++k) {
+            q0_c[k] = q0_n[k];
+            q1_c[k] = q1_n[k];
         }
     }
     const double tot = block_sum<SELL_BLOCK>(sq, red);

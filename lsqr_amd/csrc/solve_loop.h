@@ -240,6 +240,19 @@ static void launch_pat_N(const SpmvArgs &a)
     const VT *x = reinterpret_cast<const VT *>(a.x);
     VT *y = reinterpret_cast<VT *>(a.y);
     const dim3 grid(c.grid + (a.rider.kind != 0 ? 1 : 0));
+    if (c.pat_wide && c.pat_pair) {   // ... in paired rows
+        if (a.e0 == nullptr && a.e1 == nullptr)
+            hipLaunchKernelGGL((k_spmv_pat2p<UPD, VT, NT>), grid, dim3(SELL_BLOCK), 0, a.stream,
+                               (const unsigned short *)c.pid, (const PatEnt *)c.pent, c.pat_stride, c.rows, c.nblk, x, y,
+                               a.coef, a.stop, a.pout, a.pin, a.npin, a.slot_in, a.slot_out, a.skip_if_zero, a.rider, a.upd,
+                               a.nsc);
+        else
+            hipExtLaunchKernelGGL((k_spmv_pat2p<UPD, VT, NT>), grid, dim3(SELL_BLOCK), 0, a.stream, a.e0, a.e1, 0,
+                                  (const unsigned short *)c.pid, (const PatEnt *)c.pent, c.pat_stride, c.rows, c.nblk, x, y,
+                                  a.coef, a.stop, a.pout, a.pin, a.npin, a.slot_in, a.slot_out, a.skip_if_zero, a.rider,
+                                  a.upd, a.nsc);
+        return;
+    }
     if (c.pat_wide) {   // two-byte pattern numbers, the table in global memory (pat.h "wide")
         switch (c.pat_u) {
         case 1: launch_pat2_U<UPD, VT, NT, 1>(a, grid); break;
@@ -248,8 +261,7 @@ static void launch_pat_N(const SpmvArgs &a)
         return;
     }
     if (c.pat_pair) {   // lane L owns rows 2L, 2L + 1 (pat.h "paired rows")
-        if (c.pat_u == 2) launch_patp_U<UPD, VT, NT, 2>(a, grid);
-        else launch_patp_U<UPD, VT, NT, 1>(a, grid);
+        launch_patp_U<UPD, VT, NT, 1>(a, grid);   // (two groups per trip: 128 registers, 46k against 49k it/s at config 2)
         return;
     }
     if (a.e0 == nullptr && a.e1 == nullptr)

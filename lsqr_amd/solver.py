@@ -233,7 +233,9 @@ class lsqr_solver_ez:  # noqa: N801  (name kept from the reference)
                     dict_entries=d[6], value_bytes=d[7], col_bytes=d[8], colt_bytes=d[9],
                     panels=d[10], panels_t=d[11], sell=d[12], sell_t=d[13], xlds=d[14], xlds_t=d[15],
                     # patterns of the wide row-pattern table (sell = 3 with two-byte pattern numbers; 0: not in use)
-                    pat_wide=self.get_option("pat_wide_mode1"), pat_wide_t=self.get_option("pat_wide_mode2"))
+                    pat_wide=self.get_option("pat_wide_mode1"), pat_wide_t=self.get_option("pat_wide_mode2"),
+                    # row patterns in the paired-rows form (lane L owns rows 2L, 2L + 1: csrc/pat.h)
+                    pat_pair=self.get_option("pat_pair_mode1"), pat_pair_t=self.get_option("pat_pair_mode2"))
 
     def log_records(self) -> np.ndarray:
         self._need()

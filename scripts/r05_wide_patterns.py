@@ -17,8 +17,8 @@ t0 = time.time()
 m, n, irow, icol, a, b = piecewise_mesh(nx, ny, bx, by)
 print(f"mesh {nx} x {ny}, {bx} x {by} regions: {m} rows, {a.size} nonzeros ({time.time() - t0:.1f} s on the host)", flush=True)
 LAYOUTS = [("wide row patterns", {}),
-           ("wide, 1 slice per trip", {"LSQRHIP_PAT2_U": "1"}),
-           ("wide, 8 workgroups per CU", {"LSQRHIP_PAT_GRID": "2048"}),
+           ("wide, slice form", {"LSQRHIP_PAT_PAIR": "0"}),
+           ("wide, 6 workgroups per CU", {"LSQRHIP_PAT_GRID": "1536"}),
            ("without the wide table", {"LSQRHIP_PAT2": "0"}),
            ("no pattern layout", {"LSQRHIP_PAT": "0", "LSQRHIP_SPAT": "0"}),
            ("sliced ELL, 8-byte values", {"LSQRHIP_PAT": "0", "LSQRHIP_SPAT": "0", "LSQRHIP_SELLP": "0", "LSQRHIP_VAL8": "0"})]

@@ -290,15 +290,28 @@ def test_a_piecewise_constant_coefficient_mesh_takes_two_bytes_per_row():
     assert 256 < info["pat_wide"] <= 4096 and 256 < info["pat_wide_t"] <= 4096, info
     # two bytes per row and the table (<= 5 entries of 16 bytes and a descriptor per pattern)
     assert info["csr_bytes"] <= 2 * m + 84 * info["pat_wide"]
-    # ... and the same bits as the layouts underneath: without the wide table, then without any pattern layout
+    # ... and the layouts underneath -- without the wide table, then without any pattern layout: the same bits from the
+    # slice form of the wide kernel (the same rows per thread as sell.h), the same solve to rounding from the paired form
+    os.environ["LSQRHIP_PAT_PAIR"] = "0"
+    s1 = lsqr_solver_ez().initialize(m, n, a, irow, icol, itnlim=25)
+    assert s1.info()["pat_wide"] == info["pat_wide"] and s1.get_option("pat_pair_mode1") == 0 and s.get_option("pat_pair_mode1") == 1
+    r1 = s1.solve(b, 1e-3)
     for knobs in ({"LSQRHIP_PAT2": "0"}, {"LSQRHIP_PAT": "0", "LSQRHIP_SPAT": "0"}):
         os.environ.update(knobs)
         s0 = lsqr_solver_ez().initialize(m, n, a, irow, icol, itnlim=25)
         assert s0.info()["pat_wide"] == 0 and s0.info()["csr_bytes"] > 2 * info["csr_bytes"]
         r0 = s0.solve(b, 1e-3)
-        assert np.array_equal(r0.x, r.x) and r0.anorm == r.anorm and r0.rnorm == r.rnorm and r0.itn == r.itn
+        assert np.array_equal(r0.x, r1.x) and r0.anorm == r1.anorm and r0.rnorm == r1.rnorm and r0.itn == r1.itn
+        assert r0.itn == r.itn and np.linalg.norm(r0.x - r.x) <= 1e-12 * np.linalg.norm(r.x)
+        assert abs(r0.anorm - r.anorm) <= 1e-13 * r.anorm and abs(r0.rnorm - r.rnorm) <= 1e-12 * r.rnorm
         for k in knobs:
             os.environ.pop(k)
+    # the products themselves: bit for bit, paired or not (check_against_oracle held s to the oracle's)
+    xp, yp = _vec(9, n), _vec(10, m)
+    ya, yb_ = yp.copy(), yp.copy()
+    s.aprod(1, m, n, xp.copy(), ya)
+    s1.aprod(1, m, n, xp.copy(), yb_)
+    assert np.array_equal(ya, yb_)
 
 
 @pytest.mark.parametrize("nd,wide", [(256, True), (4095, True), (4096, False)])
