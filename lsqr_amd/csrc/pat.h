@@ -403,6 +403,10 @@ __global__ __launch_bounds__(SELL_BLOCK, 4) void k_spmv_pat(
 // (0.59 -> 0.70 of 8 TB/s on its 25 bytes per row); configs[1] 7.3 -> 6.7 us per product, 47.5-47.8k -> 49.2-49.4k
 // iterations/s at K = 2000 and 41.0-41.5k -> 42.4-43.1k at K = 20.  Two groups per trip (128 registers): 45.5-46.6k.
 // 1024 workgroups stay the best grid (768: 46.5-47.0k, 1536: 45.4k, 2048: 38.7k; profiles/r05/pair_grid.txt).
+// Measured and dropped (profiles/r05/pair_mid_ab.txt): the middle entry of a run of columns d - 1, d, d + 1 -- the -1, 0,
+// +1 of a stencil -- formed in the lane from the pairs before and behind it instead of gathered (7 requests per 128
+// rows instead of 8): the wave-uniform test in front of every gather breaks the batch of requests up -- 70 -> 85 us
+// at 16M rows, 49.7k -> 43.4k it/s at configs[1].
 // ---------------------------------------------------------------------------------------------------------------
 typedef double lsqrhip_d2u __attribute__((ext_vector_type(2), aligned(8)));
 typedef float lsqrhip_f2u __attribute__((ext_vector_type(2), aligned(4)));

@@ -261,7 +261,8 @@ static void launch_pat_N(const SpmvArgs &a)
         return;
     }
     if (c.pat_pair) {   // lane L owns rows 2L, 2L + 1 (pat.h "paired rows")
-        launch_patp_U<UPD, VT, NT, 1>(a, grid);   // (two groups per trip: 128 registers, 46k against 49k it/s at config 2)
+        // (two groups per trip: 128 registers, 46k against 49k it/s at config 2)
+        launch_patp_U<UPD, VT, NT, 1>(a, grid);
         return;
     }
     if (a.e0 == nullptr && a.e1 == nullptr)
