@@ -272,7 +272,9 @@ int lsqrhip_set_option(lsqrhip_handle_t h, const char *name, int64_t value);
  * schedule the sharded engine of this handle REALLY runs (a requested overlap or copy mode that could not be set up
  * reads 0); "shard_engine_flags" -- what the C++ engine left in this rank's stage context (0 between solves, also
  * after an engine solve that failed half way: 1 own slice read in T | 2 long norms message | 4 norms gathered by the
- * engine | 8 a sharded solve is open). */
+ * engine | 8 a sharded solve is open); "pat_wide_mode1" / "_mode2" -- distinct rows of the wide row-pattern table
+ * in use (two-byte pattern numbers; 0: the one-byte table or another layout); "pat_pair_mode1" / "_mode2" -- 1 when the
+ * row-pattern product runs in paired rows (a lane owns two neighbouring rows: DESIGN.md 3.4b). */
 int lsqrhip_get_option(lsqrhip_handle_t h, const char *name, int64_t *value);
 /* Run all work of this handle on an externally owned hipStream_t (e.g. the
  * caller's torch stream); NULL restores the handle's own stream. */
