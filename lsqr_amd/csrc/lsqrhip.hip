@@ -222,6 +222,7 @@ struct ShardCtx {
     int want_log = 0;             // option "shard_log": this rank keeps the iteration log of the next sharded solves
                                   // (rank 0's business: the scalars are replicated and x(1) lies on its slice)
     bool active = false;
+    bool fuse_s2 = true;          // LSQRHIP_SHARD_FUSE_S2, read once per solve in lsqrhip_shard_begin: scalar step 2 inside the update's launch
     bool engine_next = false;     // set by shard_engine.h right before ITS lsqrhip_shard_begin: the engine-only fields above
                                   // (gath, msg, own_in_T, vmax_msg) are meant.  Any other caller of lsqrhip_shard_begin --
                                   // the Python stage driver, also as the fall-back after an engine solve that FAILED half

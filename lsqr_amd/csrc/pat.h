@@ -18,6 +18,11 @@
 //
 // Lane i of a wave owns row i of a 64-row slice as in sell.h; its sum is the plain left-to-right sum over the
 // pattern's entries starting from 0 -- bit-identical to the reference's and to the other short-row kernels.
+// CONTRACT across the short-row layouts: every PRODUCT y is bit-equal in all of them (slice form, paired rows, sliced
+// ELL, packed records).  The fused NORMS (sum of y_i^2) are bit-equal only between layouts with the same rows per
+// thread -- the slice form and sell.h; the paired rows (the default) add the squares in another order, so alpha and beta
+// may differ in the last bit and the iterates of a solve agree to rounding (<= 1e-12), not bit for bit
+// (tests/test_gpu_patterns.py::test_paired_rows_and_the_slice_form_agree).
 //
 // Build (k_pat_* below, from the CSR of csr_build.h, all on the device): every row is hashed over (length, column
 // offsets, value bits) into a 1024-slot table that gives up at the 257th distinct key; the keys are ranked (pattern

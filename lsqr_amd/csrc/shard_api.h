@@ -347,6 +347,7 @@ extern "C" int lsqrhip_shard_begin(lsqrhip_handle_t h, const double *d_b_local, 
     c.T = d_T; c.R = d_R; c.V = d_V; c.sums = d_sums;
     c.wantse = wantse;
     c.upar = 0;
+    c.fuse_s2 = env_int("LSQRHIP_SHARD_FUSE_S2", 1) != 0;   // (once per solve, on the caller's thread: never from a stage)
     if (h->MXU != nullptr) HIPCHK(hipMemsetAsync(h->MXU, 0, sizeof(double) * 2 * MX_SET, s));   // (xmax_folded: both sets zero)
     if (!c.wsq) HIPCHK(hipMalloc((void **)&c.wsq, sizeof(double)));
     if (!c.live) HIPCHK(hipMalloc((void **)&c.live, sizeof(int)));
@@ -537,7 +538,7 @@ static int shard_stage_phase(lsqrhip_handle_t h, int stage, int phase)
                            c.vmax_msg ? (const double *)(h->partials + SPMV_MAX_GRID) : (const double *)nullptr);
         break;
     case ST_UPDATE:
-        if (c.gath != nullptr && env_int("LSQRHIP_SHARD_FUSE_S2", 1) != 0) {   // step 2 inside the update's launch
+        if (c.gath != nullptr && c.fuse_s2) {   // step 2 inside the update's launch
             const double *src = c.P > 1 ? c.gath : sums;
             double *vmx = c.vmax_msg ? h->xmax_part : (double *)nullptr;
             const VecPtrs vp = shard_vec_ptrs(h);

@@ -58,6 +58,7 @@ struct Rccl {
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;   // (optional: ipc_setup, when a collective of its own failed on this rank)
     ncclResult_t (*CommSplit)(ncclComm_t, int, int, ncclComm_t *, void *) = nullptr;   // (optional: the overlap's second communicator)
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -95,6 +96,7 @@ static Rccl *rccl()
     r.GroupEnd = (decltype(r.GroupEnd))sym("ncclGroupEnd");
     r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
     r.CommSplit = (decltype(r.CommSplit))dlsym(r.lib, "ncclCommSplit");
+    r.CommAbort = (decltype(r.CommAbort))dlsym(r.lib, "ncclCommAbort");
     if (!ok) {
         r.lib = nullptr;
         return nullptr;
@@ -552,36 +554,53 @@ static int ipc_setup(ShardGroup &g)
     Rccl *rc = rccl();
     const int P = g.P, me = q.grank;
     constexpr int NB = 4;
-    HIPCHK(hipSetDevice(q.h->device));
-    HIPCHK(hipMalloc((void **)&g.bar, sizeof(double) * (size_t)(1 + P)));
-    HIPCHK(hipMemset(g.bar, 0, sizeof(double) * (size_t)(1 + P)));
-    HIPCHK(hipMalloc((void **)&g.bar2, sizeof(double) * (size_t)(1 + P)));
-    HIPCHK(hipMemset(g.bar2, 0, sizeof(double) * (size_t)(1 + P)));
     static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handles travel as 64-byte records");
-    std::vector<hipIpcMemHandle_t> mine(NB), all((size_t)NB * P);
-    double *bufs[NB] = {q.T, q.V, q.xfull, q.sefull};
+    // A COLLECTIVE: between its two all-gathers no rank may leave.  Every local failure (an allocation, a handle that
+    // cannot be made or opened) is folded into `ok`, which travels with the records: a rank that failed still runs both
+    // exchanges, with ok = 0, and all ranks decline together.  Only a failure of an exchange ITSELF (the all-gather or
+    // the copies around it) ends the set-up: the peers may be waiting inside a collective this rank never joined, so
+    // the communicator is aborted before the error is returned (ncclCommAbort, where the library has it).
     int ok = 1;
-    for (int i = 0; i < NB; ++i)
-        if (hipIpcGetMemHandle(&mine[(size_t)i], bufs[i]) != hipSuccess) {
+    std::string why;
+    auto soft = [&](hipError_t e, const char *what) {
+        if (e != hipSuccess) {
+            if (ok) why = std::string(what) + ": " + hipGetErrorString(e);
             ok = 0;
             (void)hipGetLastError();
         }
+    };
+    soft(hipSetDevice(q.h->device), "hipSetDevice");
+    soft(hipMalloc((void **)&g.bar, sizeof(double) * (size_t)(1 + P)), "hipMalloc(bar)");
+    if (g.bar) soft(hipMemset(g.bar, 0, sizeof(double) * (size_t)(1 + P)), "hipMemset(bar)");
+    soft(hipMalloc((void **)&g.bar2, sizeof(double) * (size_t)(1 + P)), "hipMalloc(bar2)");
+    if (g.bar2) soft(hipMemset(g.bar2, 0, sizeof(double) * (size_t)(1 + P)), "hipMemset(bar2)");
+    std::vector<hipIpcMemHandle_t> mine(NB);
+    double *bufs[NB] = {q.T, q.V, q.xfull, q.sefull};
+    for (int i = 0; i < NB; ++i) soft(hipIpcGetMemHandle(&mine[(size_t)i], bufs[i]), "hipIpcGetMemHandle");
+    const size_t recsz = 64 * NB + 64;
     char *d_send = nullptr, *d_recv = nullptr;
-    HIPCHK(hipMalloc((void **)&d_send, 64 * NB + 64));
-    HIPCHK(hipMalloc((void **)&d_recv, (size_t)(64 * NB + 64) * P));
-    std::vector<char> rec(64 * NB + 64, 0), recs((size_t)(64 * NB + 64) * P);
+    hipError_t e_alloc = hipMalloc((void **)&d_send, recsz);
+    if (e_alloc == hipSuccess) e_alloc = hipMalloc((void **)&d_recv, recsz * (size_t)P);
+    std::vector<char> rec(recsz, 0), recs(recsz * (size_t)P);
     std::memcpy(rec.data(), mine.data(), 64 * NB);
-    rec[64 * NB] = (char)ok;
+    // one exchange: every step is attempted in order, the first failure is kept (no early return: the scratch buffers
+    // are released in one place below)
     auto exchange = [&]() -> int {
-        HIPCHK(hipMemcpy(d_send, rec.data(), rec.size(), hipMemcpyHostToDevice));
-        NCCLCHK(rc->AllGather(d_send, d_recv, rec.size(), ncclChar, q.comm, q.h->stream));
-        HIPCHK(hipStreamSynchronize(q.h->stream));
-        HIPCHK(hipMemcpy(recs.data(), d_recv, recs.size(), hipMemcpyDeviceToHost));
+        if (e_alloc != hipSuccess) return fail(LSQRHIP_ERR_ALLOC, std::string("ipc_setup scratch: ") + hipGetErrorString(e_alloc));
+        rec[64 * NB] = (char)ok;
+        hipError_t e = hipMemcpy(d_send, rec.data(), rec.size(), hipMemcpyHostToDevice);
+        if (e != hipSuccess) return fail(LSQRHIP_ERR_HIP, std::string("ipc_setup upload: ") + hipGetErrorString(e));
+        ncclResult_t nr = rc->AllGather(d_send, d_recv, rec.size(), ncclChar, q.comm, q.h->stream);
+        if (nr != ncclSuccess)
+            return fail(LSQRHIP_ERR_HIP, std::string("ipc_setup ncclAllGather: ") + (rc->GetErrorString ? rc->GetErrorString(nr) : "?"));
+        e = hipStreamSynchronize(q.h->stream);
+        if (e == hipSuccess) e = hipMemcpy(recs.data(), d_recv, recs.size(), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) return fail(LSQRHIP_ERR_HIP, std::string("ipc_setup download: ") + hipGetErrorString(e));
+        for (int p = 0; p < P; ++p) ok = ok && recs[(size_t)p * rec.size() + 64 * NB] != 0;
         return LSQRHIP_OK;
     };
     int rcx = exchange();
     if (rcx == LSQRHIP_OK) {
-        for (int p = 0; p < P; ++p) ok = ok && recs[(size_t)p * rec.size() + 64 * NB] != 0;
         g.peerT.assign((size_t)P, nullptr);
         g.peerV.assign((size_t)P, nullptr);
         g.peerX.assign((size_t)P, nullptr);
@@ -605,14 +624,19 @@ static int ipc_setup(ShardGroup &g)
                 (*dst[i])[(size_t)p] = reinterpret_cast<char *>(ptr);
             }
         // the verdict: every rank must have every buffer of every peer
-        rec[64 * NB] = (char)ok;
         rcx = exchange();
-        if (rcx == LSQRHIP_OK)
-            for (int p = 0; p < P; ++p) ok = ok && recs[(size_t)p * rec.size() + 64 * NB] != 0;
     }
-    (void)hipFree(d_send);
-    (void)hipFree(d_recv);
-    RET(rcx);
+    if (d_send) (void)hipFree(d_send);
+    if (d_recv) (void)hipFree(d_recv);
+    if (rcx != LSQRHIP_OK) {   // an exchange failed on THIS rank: do not leave the peers waiting in it
+        const std::string keep = g_last_error;
+        if (rc->CommAbort && q.comm) {
+            (void)rc->CommAbort(q.comm);
+            q.comm = nullptr;
+        }
+        g_last_error = keep;
+        return rcx;
+    }
     g.ipc = ok != 0;
     g.copy_streams = env_int("LSQRHIP_SHARD_COPY_STREAMS", 1) != 0;
     return LSQRHIP_OK;

@@ -1023,11 +1023,13 @@ static int solve_core(H *h, const double *b, bool b_on_device, double damp, doub
         // overlap device work.  Never beyond itnlim; after a stop inside batch k the kernels of
         // batch k+1 return at their first instruction (stop flag) and change nothing.
         int64_t outputs_in = -1;   // the batch the outputs were enqueued behind (enqueue_outputs), if any
-        // spin on the snapshot's seal instead of sleeping on the batch's event: only where the batch's last kernel writes
-        // the snapshot itself (pipelined schedules), the outputs need no later command of this stream (x copied by the
-        // batch: dev_out) and nobody asked for the log (copied out behind the loop).  LSQRHIP_SPIN_POLL=0: never.
+        // spin on the snapshot's seal instead of sleeping on the batch's event: only where the snapshot kernel is the
+        // batch's LAST node -- the fused schedule, whose tail update has already left x at xout.  (In the other pipelined
+        // schedules k_out_copy follows the snapshot: a seal seen there says nothing about x, so those wait for the
+        // batch's event, which covers the copy.)  Also: the outputs need no later command of this stream (dev_out) and
+        // nobody asked for the log (copied out behind the loop).  LSQRHIP_SPIN_POLL=0: never.
         static const int spin_env = env_int("LSQRHIP_SPIN_POLL", 1);
-        const bool spin_poll = spin_env != 0 && h->pipeline != 0 && dev_out && !want_log && !loop_events;
+        const bool spin_poll = spin_env != 0 && h->pipeline != 0 && fused_update && dev_out && !want_log && !loop_events;
         bool loop1 = false;
         auto enqueue = [&](int64_t k) -> int {
             if (spin_poll) {   // (the slot's seal down before the batch that will raise it is launched)
@@ -1087,8 +1089,9 @@ static int solve_core(H *h, const double *b, bool b_on_device, double damp, doub
         // returns at its stop-flag tests and has not touched it)
         *h->h_state = h->h_state[1 + (stopped_in & 1)];
         if (!loop1 && loop_events) HIPCHK(hipEventRecord(h->ev_loop1, s));
-        if (dev_out)   // x was copied by the batch whose snapshot showed the stop, and that batch's event has been
-                       // waited for; a batch enqueued behind it (look-ahead) repeats the copy: wait for that one too
+        if (dev_out)   // x was copied by the batch whose snapshot showed the stop, and that batch has been waited for --
+                       // its event (which covers k_out_copy), or its seal where the snapshot is its last node (fused
+                       // schedule); a batch enqueued behind it (look-ahead) repeats the copy: wait for that one too
             return finish_solve(h, wantse, want_log, x, se, out_on_device, istop, itn, anorm, acond, rnorm, arnorm,
                                 xnorm, timed, t_host0, (stopped_in + 1) * G < (int64_t)itnlim ? 1 : 2);
         return finish_solve(h, wantse, want_log, x, se, out_on_device, istop, itn, anorm, acond, rnorm, arnorm, xnorm,

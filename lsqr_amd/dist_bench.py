@@ -413,7 +413,7 @@ def run_distributed(args):
             out["variants"][state["doing"] or "?"] = {"error": "timed out (watchdog): RCCL hang?", "validated": False}
             out["config"]["variants_note"] = f"stopped by the watchdog inside `{state['doing']}`"
             print(json.dumps(out), flush=True)
-        os._exit(0)
+        os._exit(3)     # a hung job is a FAILED job on every rank: the line above says what was measured before it
 
     if want_variants:
         import threading

@@ -252,3 +252,40 @@ def test_scale_properties_of_one_rank_of_config4_at_1000_per_row():
     inform, tests, u, v, w = s.xcheck(out[0][2], 1e-3, b, out[0][5])
     rn = np.sqrt(np.linalg.norm(u) ** 2 + (1e-3 * np.linalg.norm(out[0][5])) ** 2)
     assert np.isfinite(tests).all() and abs(rn - out[0][3]) <= 1e-8 * out[0][3]
+
+
+def test_x_of_a_device_resident_solve_is_complete_when_solve_returns():
+    """on a column-swept matrix (no fused schedule) k_out_copy follows the snapshot kernel, so a host
+    that returns on the snapshot's seal returns before x has reached the caller's buffer.  The solve must only return once
+    the copy is done: x read on ANOTHER stream (hipMemcpy on the null stream does not wait for the handle's non-blocking
+    stream) right after lsqrhip_solve_device -- the stop in the last possible batch, spin poll at its default -- is the
+    x a device-wide synchronise shows later.  n = 12M: the copy out is 96 MB each way."""
+    from lsqr_amd import capi
+    from lsqr_amd.capi import DeviceBuffer
+    assert os.environ.get("LSQRHIP_SPIN_POLL", "1") != "0"
+    old = os.environ.get("LSQRHIP_CSB")
+    os.environ["LSQRHIP_CSB"] = "1"
+    try:
+        dp = devgen.generate("random:300000:12000000:40", itnlim=4)
+    finally:
+        os.environ.pop("LSQRHIP_CSB", None)
+        if old is not None:
+            os.environ["LSQRHIP_CSB"] = old
+    s = dp.solver
+    assert s.info()["xlds"] == 3                      # column-swept row blocks: the schedule is not the fused one
+    s.atol = s.btol = s.conlim = 0.0
+    d_x = DeviceBuffer(8 * dp.n)
+    tail = 4096
+    nan_tail = np.full(tail, np.nan)
+    for k in range(6):
+        # poison the END of x (what the copy kernel's last workgroups write), not by a full upload: keep the gap short
+        capi.check(capi.lib().lsqrhip_dev_upload(d_x.ptr.value + 8 * (dp.n - tail), nan_tail.ctypes.data, 8 * tail))
+        r = s.solve_device(dp.d_b.ptr.value, d_x.ptr.value, 1e-3)
+        got = np.empty(tail)
+        capi.check(capi.lib().lsqrhip_dev_download(got.ctypes.data, d_x.ptr.value + 8 * (dp.n - tail), 8 * tail))
+        capi.check(capi.lib().lsqrhip_dev_sync())
+        later = np.empty(tail)
+        capi.check(capi.lib().lsqrhip_dev_download(later.ctypes.data, d_x.ptr.value + 8 * (dp.n - tail), 8 * tail))
+        assert (r.istop, r.itn) == (5, 4)
+        assert not np.isnan(later).any()
+        assert np.array_equal(got, later), k

@@ -116,6 +116,46 @@ def test_a_stencil_is_stored_as_row_patterns_and_gives_the_references_bits(shape
     assert all(np.array_equal(o[0], outs[0][0]) and np.array_equal(o[1], outs[0][1]) for o in outs[1:])
 
 
+@pytest.mark.parametrize("m,n,offs", [
+    (127, 130, (-1, 0, 1)),                          # fewer rows than one 128-row pair group, odd
+    (1, 2, (0, 1)),                                  # one row
+    (1001, 2, (0, -1, 1)),                           # two columns, odd rows: the last pair is half empty
+    (4097, 4100, (-9, -5, -2, -1, 0, 1, 2, 5, 9)),   # 9 entries per row: longer than PAT_K (5) entries in flight
+    (255, 255, (-3, -1, 0, 0, 1, 3, 7)),             # a duplicate entry, 7 long, odd
+])
+def test_paired_rows_and_the_slice_form_agree(m, n, offs):
+    """The contract of the paired-row kernels (k_spmv_patp / k_spmv_pat2p, the default): against the slice
+    form (LSQRHIP_PAT_PAIR=0) every PRODUCT is bit-equal -- the same left-to-right row sums -- while the fused norms add
+    the rows' squares in another order, so alpha / beta may differ in the last bit and a solve agrees to rounding, not
+    bit for bit."""
+    vals = tuple(0.37 * (k + 1) * (-1) ** k for k in range(len(offs)))
+    m, n, irow, icol, a, b = stencil(m, n, offs, vals)
+    os.environ["LSQRHIP_PAT"] = "1"
+    made = {}
+    for pair in ("1", "0"):
+        os.environ["LSQRHIP_PAT_PAIR"] = pair
+        s = lsqr_solver_ez().initialize(m, n, a, irow, icol, itnlim=12)
+        assert s.info()["sell"] == 3 and s.info()["sell_t"] == 3
+        made[pair] = s
+    assert made["0"].get_option("pat_pair_mode1") == 0
+    if n >= 2 and m >= 2:
+        assert made["1"].get_option("pat_pair_mode1") == 1
+    xp, yp = _vec(9, n), _vec(10, m)
+    outs = {}
+    for pair, s in made.items():
+        y = yp.copy(); s.aprod(1, m, n, xp.copy(), y)
+        x = xp.copy(); s.aprod(2, m, n, x, yp.copy())
+        outs[pair] = (y, x, s.solve(b, 1e-2))
+    assert np.array_equal(outs["0"][0], outs["1"][0]) and np.array_equal(outs["0"][1], outs["1"][1])
+    r0, r1 = outs["0"][2], outs["1"][2]
+    assert (r0.istop, r0.itn) == (r1.istop, r1.itn)
+    assert np.linalg.norm(r0.x - r1.x) <= 1e-12 * max(np.linalg.norm(r0.x), 1e-300)
+    assert abs(r0.anorm - r1.anorm) <= 1e-13 * r0.anorm and abs(r0.rnorm - r1.rnorm) <= 1e-12 * max(r0.rnorm, 1e-300)
+    po = oracle.port()
+    _, y_ref = po.aprod(1, m, n, irow, icol, a, xp, yp)
+    assert np.array_equal(outs["1"][0], y_ref)
+
+
 def test_unsymmetric_patterns_duplicates_and_the_order_inside_a_row():
     """An upwind-like stencil whose transpose has other values, one offset twice (a duplicate (i, j) entry), offsets
     out of order, rows delivered last-first: the stable sort by row keeps the order inside each row, and that order is
