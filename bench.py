@@ -5,29 +5,28 @@
     python bench.py --gpus N ...                     # starts its N ranks itself (torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" is ONE LSQR iteration (mode-1 SpMV + mode-2 SpMV + x/w update + the scalar
-recurrences) over the whole system.  The timed region is one `solve` of exactly K
-iterations (atol = btol = conlim = 0, itnlim = K -> istop = 5) with the matrix, b and x
-already resident in HBM; W warm-up iterations run first as a separate solve.
+A "step" is ONE LSQR iteration (mode-1 SpMV + mode-2 SpMV + x/w update + the scalar recurrences) over the whole
+system.  The timed region is one `solve` of exactly K iterations (atol = btol = conlim = 0, itnlim = K -> istop = 5) with
+the matrix, b and x already resident in HBM; W warm-up iterations run first as a separate solve.
 
-N = 1 workload: BASELINE.json configs[1] -- 1M x 1M 5-point Poisson (nnz 4 996 000),
-damp = 0.  N > 1: the row-block sharded solve of configs[3] (lsqr_amd/dist_bench.py).
+Workload, at EVERY N: BASELINE.json configs[3] made concrete per SURVEY.md 8d -- m = n = 10^7 random sparse least
+squares, 100 nonzeros per row (10^9 nonzeros), damp = 1e-3 -- whole on the one GPU at N = 1, row-block sharded at N > 1
+(lsqr_amd/dist_bench.py): total work fixed as N grows, "scaling": "strong", and the lines of a series divide directly.
 
-The ONE JSON line (rank 0) carries, for the dominant kernel (aprod mode 1):
-  roofline          PHYSICAL: bytes of the layout the build chose / average launch time (HIP events on
-                    the solver's stream), frac = that / 8 TB/s (always <= 1); `traffic` = HBM bytes per
-                    launch from rocprofv3 PMC passes of THIS build made by this run (FETCH_SIZE and
-                    WRITE_SIZE in passes of their own, FETCH_SIZE x2 on gfx950); `effective_gbps` = the
-                    SURVEY 8d algorithmic bytes (12 B per nonzero ...) / the same time, labelled as such.
-  roofline_hbm      the same kernel family on HBM-RESIDENT instances (configs[1] fits the 256 MB
-                    Infinity Cache): poisson2d:4000:4000 as row patterns, packed records, sliced ELL with 8-byte values
-                    and structure patterns; mesh2d:4000:4000:16:16 (the same operator with its coefficient constant on
-                    each of 256 regions: 2304 distinct rows) as wide row patterns.
-  strong_scaling_n1 configs[3] (10M x 10M, 1e9 nonzeros) whole on this GPU, with its own roofline:
-                    N = 1 of the series the --gpus N lines continue.
-  roofline_configs  the same object for configs[2] at its literal 1000 per row, configs[4] and the r = 1000 rank block.
-  cpu_baseline      the reference's own CPU path (oracle/_ref), 1 core, bounded sample.
-`--workload SPEC --extras off` measures one workload alone (what profiles/r02/*.txt were made with).
+The LAST line of stdout is the ONE JSON line (rank 0), at most 4 KB (tests/test_bench_line_keys.py):
+  contract keys, `result`;
+  roofline      the dominant kernel, k_spmv_csb of aprod mode 1: `achieved` = SURVEY 8d's algorithmic bytes B1 =
+                12 nnz + P (m + 1) + 8 n + 16 m  /  the average duration of a product (HIP events on the solver's stream
+                around back-to-back launches), `frac` = that / 8 TB/s; `traffic` = HBM bytes per product from rocprofv3 PMC
+                passes of THIS build made by this run (FETCH_SIZE and WRITE_SIZE in passes of their own, FETCH_SIZE x2
+                on gfx950); `frac_mode2` the same figure for the transposed product;
+  cpu_baseline  the reference's own CPU path (oracle/_ref), 1 core, on a scaled-down instance of the same generator;
+  configs[]     {workload, it_s, frac_mode1, frac_mode2} for the other BASELINE configurations one GPU holds and the
+                row blocks a rank of eight holds -- measured by a CHILD process after the headline (a failure or a
+                time-out there costs its entries, never the line);
+  detail        path of the side file with everything else (per-kernel times, layouts, physical bytes, PMC detail).
+`--workload SPEC --extras off` measures one workload alone; `--roofline-only` only its mode-1 product (what a
+`rocprofv3 --kernel-trace --stats` of the same command averages: profiles/rNN/*_roofline.txt).
 """
 from __future__ import annotations
 
@@ -49,58 +48,47 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s measured float4 copy)
 INFINITY_CACHE = 256 << 20
-HEADLINE = "poisson2d:1000:1000"
-HBM_INSTANCES = [("poisson2d:4000:4000", {}, "row patterns (what the build chooses for a constant-coefficient stencil)"),
-                 ("poisson2d:4000:4000", {"LSQRHIP_PAT": "0"}, "packed records: value dictionary (1-byte codes), 16-bit columns"),
-                 ("poisson2d:4000:4000", {"LSQRHIP_PAT": "0", "LSQRHIP_VAL8": "0", "LSQRHIP_SPAT": "0"},
-                  "sliced ELL: 8-byte values, 16-bit columns (matrices without a repeating structure)"),
-                 ("poisson2d:4000:4000", {"LSQRHIP_PAT": "0", "LSQRHIP_VAL8": "0"},
-                  "structure patterns: 8-byte values, no column indices (what a variable-coefficient stencil gets)"),
-                 ("mesh2d:4000:4000:16:16", {},
-                  "wide row patterns: the same five-point operator with its coefficient constant on each of 16 x 16 regions "
-                  "(2304 distinct rows): two bytes per row, the table through L1 / L2 (round 4: structure patterns)")]
+HEADLINE = "random:10000000:10000000:100"      # BASELINE.json configs[3] (100 per row), = dist_bench.DEFAULT_SPEC
+HEADLINE_NOTE = "BASELINE.json configs[3]: 10M x 10M random"
+LINE_MAX = 4096            # bytes of the one JSON line (the driver's reader gave up on round 5's 22 KB)
 PRODUCT_KERNELS = ("k_spmv_", "k_panel_combine", "k_csb_combine", "k_csb_xmax")
-# the N = 1 line measures configs[1]; the series the --gpus N lines continue is strong_scaling_n1 (configs[3])
-SCALING_N1 = "n/a (configs[1]; the strong-scaling series is strong_scaling_n1)"
-# (Round 4 pasted builder-measured "ceilings of the access pattern" -- scripts/csb_ceiling.hip -- into this line as
-# constants.  Round 5's lock-step sweep runs PAST them: they were ceilings of one schedule, not of the memory system, and
-# are gone from the line.  What is left is measured by the run itself.)
-# The other BASELINE configurations one GPU holds, each with the roofline object of its mode-1 product measured by THIS
-# run (`roofline_configs`): configs[2] at its literal 1000 per row, configs[4], and the block one rank of eight holds of
-# configs[3] at SURVEY 8d's r = 1000.  (spec, solve iterations, note)
-ROOFLINE_CONFIGS = [
-    ("random:4000000:1000000:1000", 6, "BASELINE.json configs[2] at its literal size: 4M x 1M, 1000 per row (4e9 nonzeros, 96 GB of layouts)"),
-    ("powerlaw:5000000:2000000:10000", 40, "BASELINE.json configs[4]: power-law rows up to 10^4, 5M x 2M"),
-    ("random:1250000:10000000:1000", 10, "one rank's block (N = 8) of configs[3] at SURVEY 8d's r = 1000: 1.25M x 10M, 1.25e9 nonzeros"),
+# The other BASELINE configurations one GPU holds and the shapes an 8-GPU run executes, each measured by the same run in
+# a child process: (spec, timed iterations, warm-up iterations, tag, engine) -- `engine`: also the sharded engine at world
+# 1 on that block (what one rank of eight does per iteration, exchanges apart).
+COMPACT_CONFIGS = [
+    ("poisson2d:1000:1000", 20, 5, "configs[1]", False),
+    ("random:4000000:1000000:1000", 6, 2, "configs[2] literal", False),
+    ("powerlaw:5000000:2000000:10000", 40, 4, "configs[4]", False),
+    ("random:1250000:10000000:100", 60, 6, "configs[3] rank block N=8", True),
+    ("random:1250000:10000000:1000", 10, 2, "configs[3] rank block N=8 at r=1000", False),
 ]
-GENERAL_INSTANCE = 2      # HBM_INSTANCES[2]: sliced ELL with 8-byte values -- the best HBM-resident GENERAL short-row kernel
+CHILD_TIMEOUT = 420        # seconds for the configs[] child
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=None, help="timed LSQR iterations (default 2000; 400 for --gpus > 1)")
+    ap.add_argument("--steps", type=int, default=None, help="timed LSQR iterations (default 200)")
     ap.add_argument("--warmup", type=int, default=None, help="untimed iterations first (default steps / 10)")
     ap.add_argument("--workload", default="auto",
                     help="auto | poisson2d:NX:NY | mesh2d:NX:NY:BX:BY | random:M:N:PER_ROW | powerlaw:M:N:DMAX")
-    ap.add_argument("--cpu-iters", type=int, default=1000, help="iterations of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-iters", type=int, default=20, help="iterations of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--extras", choices=["on", "off"], default="on",
-                    help="off: only the one workload (no HBM-resident instances, no configs[3] point)")
-    ap.add_argument("--configs", choices=["on", "off"], default="on",
-                    help="off: skip roofline_configs (configs[2] literal, configs[4], the r = 1000 rank block: ~1 min of builds)")
-    ap.add_argument("--no-scaling-ref", action="store_true",
-                    help="skip the N = 1 point of the multi-GPU series (configs[3] whole on this GPU)")
+                    help="off: only the one workload (no configs[] child)")
+    ap.add_argument("--configs", choices=["on", "off"], default="on", help="off: skip the configs[] child (~1.5 min)")
     ap.add_argument("--traffic", choices=["live", "off"], default="live",
                     help="live: HBM bytes per launch from rocprofv3 PMC passes run as child processes")
+    ap.add_argument("--detail", default=os.path.join(ROOT, "bench_detail.json"),
+                    help="where everything that does not fit the line goes")
     ap.add_argument("--roofline-only", action="store_true",
-                    help="build the workload and time ONLY its mode-1 product (what a `rocprofv3 --kernel-trace "
-                         "--stats` of this command then averages: profiles/r02/*_roofline.txt)")
+                    help="build the workload and time ONLY its products (what a `rocprofv3 --kernel-trace "
+                         "--stats` of this command then averages: profiles/rNN/*_roofline.txt)")
     ap.add_argument("--pmc-child", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--configs-child", action="store_true", help=argparse.SUPPRESS)
     a = ap.parse_args()
-    multi = a.gpus > 1 or int(os.environ.get("WORLD_SIZE", "1")) > 1
-    if a.steps is None:        # N = 1: ~26 us per iteration; N > 1 (10^9 nonzeros): milliseconds
-        a.steps = 400 if multi else 2000
+    if a.steps is None:        # ~5 ms per iteration on one GPU
+        a.steps = 200
     if a.warmup is None:
         a.warmup = max(1, a.steps // 10)
     return a
@@ -201,9 +189,12 @@ def describe_layout(info):
 
 
 def product_roofline(s, facts, reps, traffic=None):
-    """The `roofline` object of the mode-1 product of a built workload: average of `reps` back-to-back
-    launches inside ONE HIP event pair on the solver's stream (what rocprofv3's kernel trace reports as
-    the kernel's average duration), against the bytes of the layout in use."""
+    """(`roofline` object of the mode-1 product, detail): average of `reps` back-to-back launches inside ONE HIP event
+    pair on the solver's stream (what rocprofv3's kernel trace reports as the kernel's average duration x the launches
+    per product).  `achieved` / `frac` are on SURVEY 8d's ALGORITHMIC bytes (B1: 8-byte values, 4-byte columns, row
+    pointers, x once, y read and written); the bytes of the layout actually stored are beside it (`frac_layout`).  A
+    layout that compresses (row patterns, dictionaries) on a cache-resident system can exceed 1: `bound` then says
+    "cache" -- such a product is not an HBM stream of B1."""
     info = s.info()
     m, n, nnz = facts["m"], facts["n"], facts["nnz"]
     P = info["rowptr_bytes"]
@@ -213,51 +204,42 @@ def product_roofline(s, facts, reps, traffic=None):
     lay2 = info["csrt_bytes"] + 8 * m + 16 * n
     avg1, avg2, avg3 = (s.bench_kernel(w, reps) for w in (1, 2, 3))
     layout, kname = describe_layout(info)
-    ach = lay1 / (avg1 * 1e-3) / 1e9
+    ach = alg1 / (avg1 * 1e-3) / 1e9
     frac = ach / HBM_PEAK_GBS
+    ach2 = alg2 / (avg2 * 1e-3) / 1e9
     wset = info["csr_bytes"] + info["csrt_bytes"] + 8 * (m + 4 * n)
     lpp = s.get_option("launches_mode1")
-    roof = {"bound": "hbm", "kernel": f"{kname} (aprod mode 1)", "achieved": ach, "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": frac, "traffic": None, "bytes_per_launch": lay1,
+    roof = {"bound": "cache" if frac > 1.0 else "hbm", "kernel": f"{kname} (aprod mode 1)", "achieved": ach,
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": frac,
+            "traffic": traffic.get("bytes_per_launch") if traffic else None,
+            "bytes_per_launch": alg1, "bytes_are": "SURVEY 8d B1 = 12 nnz + P (m + 1) + 8 n + 16 m (algorithmic)",
             "avg_launch_us": avg1 * 1e3, "launches": reps,
-            "kernel_launches_per_product": lpp,      # > 1: a product is that many launches of the kernel (csb.h: one
+            "kernel_launches_per_product": lpp,        # > 1: a product is that many launches of the kernel (csb.h: one
             "avg_kernel_launch_us": avg1 * 1e3 / lpp,  # per round of row blocks); rocprofv3's per-kernel average is this
-            "bytes_are": "the layout in use: matrix as stored + x once + y read and written (physical)",
-            "effective_gbps": alg1 / (avg1 * 1e-3) / 1e9, "effective_bytes_per_launch": alg1,
-            "effective_is": "SURVEY 8d algorithmic bytes (8-byte values, 4-byte columns, row pointers) / the same time; "
-                            "exceeds the physical rate whenever the layout compresses -- not a roofline fraction",
-            "format": ({"layout": layout, "row_bytes": 1, "value_bytes": 0, "col_bytes": 0,
-                        "note": "one pattern number per row; the distinct rows (<= 256, <= 1024 entries) live in LDS"}
-                       if info["sell"] == 3 else
-                       {"layout": layout, "value_bytes": info["value_bytes"], "col_bytes": info["col_bytes"],
-                        "dict_entries": info["dict_entries"]}),
-            "resident": ("infinity cache (iteration working set %.0f MB < 256 MB: 'HBM' bytes are fabric requests "
-                         "that may be served on-die)" % (wset / 1e6)) if wset < INFINITY_CACHE else
-                        "hbm (iteration working set %.1f GB)" % (wset / 1e9)}
-    if info["sell"] == 3 and avg1 * 1e3 < 20.0:
-        roof["frac_is"] = ("a launch-latency figure: this launch lives %.1f us and moves %.0f MB -- a chain of dependent round "
-                           "trips (DESIGN.md 3.4b), not a stream; the same kernel on an HBM-resident instance is "
-                           "roofline_hbm[0], the layout it replaced at this size read 0.64 and was 17 %% slower per "
-                           "iteration" % (avg1 * 1e3, lay1 / 1e6))
-    if frac > 1.0:      # physical bytes faster than HBM can deliver them: the working set is served by a cache
-        roof["bound"] = "cache"
-        roof["frac_exceeds_hbm_peak"] = True
-    # SURVEY 8d's own figure: ALGORITHMIC bytes (12 B per nonzero, row pointers, x once, y twice) / the same time /
-    # peak.  Above 1 the layout moves fewer bytes than that count and the product is not an HBM stream of it.
-    roof["frac_survey8d"] = alg1 / (avg1 * 1e-3) / 1e9 / HBM_PEAK_GBS
-    roof["bound_survey8d"] = "cache" if roof["frac_survey8d"] > 1.0 else "hbm"
-    if info["xlds"] == 3:
-        roof["csb_lockstep"] = s.get_option("csb_lockstep_mode1")   # chunks per wave and lock-step step (0: free-running sweep)
-    if traffic:
-        roof["traffic"] = traffic.get("bytes_per_launch")
-        roof["traffic_detail"] = traffic
-    kernels = {
-        "spmv_mode2": {"avg_launch_us": avg2 * 1e3, "bytes_per_launch": lay2, "gbps": lay2 / (avg2 * 1e-3) / 1e9,
-                       "frac": lay2 / (avg2 * 1e-3) / 1e9 / HBM_PEAK_GBS, "effective_gbps": alg2 / (avg2 * 1e-3) / 1e9},
-        "update_xw": {"avg_launch_us": avg3 * 1e3, "bytes_per_launch": 40 * n,
-                      "gbps": 40 * n / (avg3 * 1e-3) / 1e9, "frac": 40 * n / (avg3 * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            "frac_layout": lay1 / (avg1 * 1e-3) / 1e9 / HBM_PEAK_GBS, "layout_bytes_per_launch": lay1,
+            "frac_mode2": ach2 / HBM_PEAK_GBS, "avg_launch_us_mode2": avg2 * 1e3}
+    detail = {
+        "layout": layout,
+        "format": ({"row_bytes": 2 if info.get("pat_wide") else 1, "value_bytes": 0, "col_bytes": 0}
+                   if info["sell"] == 3 else
+                   {"value_bytes": info["value_bytes"], "col_bytes": info["col_bytes"], "dict_entries": info["dict_entries"]}),
+        "resident": ("infinity cache (iteration working set %.0f MB < 256 MB)" % (wset / 1e6)) if wset < INFINITY_CACHE else
+                    "hbm (iteration working set %.1f GB)" % (wset / 1e9),
+        "traffic_detail": traffic,
+        "kernels": {
+            "spmv_mode1": {"avg_launch_us": avg1 * 1e3, "survey8d_bytes": alg1, "layout_bytes": lay1,
+                           "frac_survey8d": frac, "frac_layout": roof["frac_layout"]},
+            "spmv_mode2": {"avg_launch_us": avg2 * 1e3, "survey8d_bytes": alg2, "layout_bytes": lay2,
+                           "frac_survey8d": ach2 / HBM_PEAK_GBS, "frac_layout": lay2 / (avg2 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                           "kernel_launches_per_product": s.get_option("launches_mode2")},
+            "update_xw": {"avg_launch_us": avg3 * 1e3, "bytes_per_launch": 40 * n,
+                          "frac": 40 * n / (avg3 * 1e-3) / 1e9 / HBM_PEAK_GBS},
+        },
+        "iter_bytes_survey8d": alg1 + alg2 + 40 * n, "iter_bytes_layout": lay1 + lay2 + 40 * n,
     }
-    return roof, kernels, (alg1, alg2, lay1, lay2)
+    if info["xlds"] == 3:
+        detail["csb_lockstep"] = s.get_option("csb_lockstep_mode1")   # chunks per wave and lock-step step (0: free-running sweep)
+    return roof, detail
 
 
 def timed_solve(s, d_b, d_x, damp, K):
@@ -283,50 +265,144 @@ def timed_solve(s, d_b, d_x, damp, K):
 
 
 def roofline_only(args):
-    """Only the dominant kernel: 3 warm + `reps` back-to-back launches of the mode-1 product.  Under
-    `rocprofv3 --kernel-trace --stats` the kernel's average duration x kernel_launches_per_product is
-    roofline.avg_launch_us of the same line."""
+    """Only the products: 3 warm + `reps` back-to-back launches of mode 1, then of mode 2.  Under `rocprofv3
+    --kernel-trace --stats` the kernel's average duration x kernel_launches_per_product is avg_launch_us of the line."""
     spec = HEADLINE if args.workload == "auto" else args.workload
     s, d_b, facts, _ = build_workload(spec, None)
-    info = s.info()
     reps = 200 if facts["nnz"] < 50_000_000 else (50 if facts["nnz"] < 200_000_000 else 10)
-    avg1 = s.bench_kernel(1, reps)
-    lay1 = info["csr_bytes"] + 8 * facts["n"] + 16 * facts["m"]
-    lpp = s.get_option("launches_mode1")
-    ach = lay1 / (avg1 * 1e-3) / 1e9
+    roof, detail = product_roofline(s, facts, reps)
     print(json.dumps({"workload": spec, "env": {k: v for k, v in os.environ.items() if k.startswith("LSQRHIP_")},
-                      "roofline": {"kernel": describe_layout(info)[1] + " (aprod mode 1)", "bytes_per_launch": lay1,
-                                   "avg_launch_us": avg1 * 1e3, "kernel_launches_per_product": lpp,
-                                   "avg_kernel_launch_us": avg1 * 1e3 / lpp, "launches": reps, "achieved": ach,
-                                   "frac": ach / HBM_PEAK_GBS, "peak": HBM_PEAK_GBS, "unit": "GB/s"}}), flush=True)
+                      "roofline": roof, "kernels": detail["kernels"]}), flush=True)
 
 
-def side_workload(spec, env, note, K, traffic):
-    """An additional instance of the same path (HBM-resident Poisson, configs[3]): a short solve and
-    the product's roofline.  Never fails the headline measurement."""
+def graph_batch(K):
+    """a divisor of K when there is a good one (no predicated-off tail iterations in the timed solve), else up to 50
+    iterations (launches past the stop are ~us-scale no-ops)"""
+    return next((g for g in (100, 50, 40, 32, 26, 20, 16) if K % g == 0), min(50, K + (K & 1)))
+
+
+def measure_workload(spec, K, W, traffic=None, env=None, note="", engine=False):
+    """One workload on this GPU: build (generated in HBM), warm up, W + K timed iterations, the products' roofline;
+    `engine`: also the sharded engine at world 1 on it.  (full record for the detail file)"""
     from lsqr_amd import capi
+    t_build = time.perf_counter()
+    s, d_b, facts, _ = build_workload(spec, env, itnlim=K)
+    t_build = time.perf_counter() - t_build
+    d_x = capi.DeviceBuffer(8 * max(facts["n"], 1))
+    s.atol = s.btol = s.conlim = 0.0
+    gi = graph_batch(K)
+    s.set_option("graph_iters", gi)
+    # setup, untimed: the graphs of this batch size are captured and instantiated by the first solve, and the
+    # interpreter and the device clocks settle over a few more (a 20-iteration solve of configs[1] is 0.5 ms of device
+    # work: the first timed call after an idle start otherwise measures the ramp): at least 2 solves and 60 ms of them
+    t_warm, n_warm = time.perf_counter(), 0
+    while n_warm < 2 or (time.perf_counter() - t_warm < 0.06 and n_warm < 400):
+        timed_solve(s, d_b, d_x, facts["damp"], min(K, 100))
+        n_warm += 1
+    if W > 0:                                   # the W warm-up steps of the contract, through the timed path
+        timed_solve(s, d_b, d_x, facts["damp"], W)
+    dt, r, restarts = timed_solve(s, d_b, d_x, facts["damp"], K)
+    reps = 500 if facts["nnz"] < 50_000_000 else (100 if facts["nnz"] < 200_000_000 else 10)
+    roof, detail = product_roofline(s, facts, reps, traffic)
+    out = {"workload": f"{spec} m={facts['m']} n={facts['n']} nnz={facts['nnz']} damp={facts['damp']}", "spec": spec,
+           "note": note, "env": env or {}, "n_gpus": 1, "steps": K, "warmup": W, "value": K / dt, "unit": "it/s",
+           "ms_per_step": 1e3 * dt / K, "restarts": restarts, "graph_iters": gi, "generate_and_build_s": t_build,
+           "result": {"istop": r.istop, "itn": r.itn, "anorm": r.anorm, "rnorm": r.rnorm},
+           "iter_gbps_survey8d": detail["iter_bytes_survey8d"] * K / dt / 1e9,
+           "roofline": roof, "detail": detail}
+    if engine:      # what ONE rank of an N-GPU run does per iteration, exchanges apart (csrc/shard_engine.h at world 1)
+        try:
+            import torch
+
+            from lsqr_amd.dist import EngineSolver
+            drv = EngineSolver(s, 0, facts["m"], 1, 0)
+            kw = dict(damp=facts["damp"], atol=0.0, btol=0.0, conlim=0.0)
+            drv.solve(d_b.ptr.value, itnlim=max(W, 2), **kw)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            re = drv.solve(d_b.ptr.value, itnlim=K, **kw)
+            torch.cuda.synchronize()
+            out["engine_world1_ms_per_step"] = 1e3 * (time.perf_counter() - t0) / max(re.itn, 1)
+            out["engine_world1_itn"] = re.itn
+        except Exception as e:      # noqa: BLE001
+            out["engine_world1_error"] = repr(e)
+    del s, d_b, d_x
+    return out
+
+
+def compact_entry(full, tag):
+    """what the one line carries of a configs[] record"""
+    if "error" in full:
+        return {"workload": full.get("spec", "?"), "tag": tag, "error": full["error"][:80]}
+    r = full["roofline"]
+    e = {"workload": full["spec"], "tag": tag, "steps": full["steps"], "it_s": round(full["value"], 2),
+         "frac_mode1": round(r["frac"], 4), "frac_mode2": round(r["frac_mode2"], 4),
+         "us_mode1": round(r["avg_launch_us"], 2), "us_mode2": round(r["avg_launch_us_mode2"], 2)}
+    if r["bound"] != "hbm":
+        e["bound"] = r["bound"]
+    if "engine_world1_ms_per_step" in full:
+        e["engine_world1_ms_per_step"] = round(full["engine_world1_ms_per_step"], 4)
+    return e
+
+
+def configs_child():
+    """`bench.py --configs-child`: the COMPACT_CONFIGS one after the other, each guarded; prints ONE line
+    `CONFIGS_JSON [...]` of full records (the parent keeps the compact form in its line, the rest in the detail file)."""
+    import torch
+    from lsqr_amd import capi
+    if not torch.cuda.is_available() or capi.device_count() < 1:
+        raise SystemExit("bench.py: no MI355X visible; the HIP path has no CPU fallback")
+    t0 = time.perf_counter()
+    recs = []
+    for spec, K, W, tag, engine in COMPACT_CONFIGS:
+        if time.perf_counter() - t0 > CHILD_TIMEOUT - 90:
+            recs.append({"spec": spec, "tag": tag, "error": "skipped: the child's time budget was used up"})
+            continue
+        try:
+            rec = measure_workload(spec, K, W, note=tag, engine=engine)
+        except BaseException as e:      # noqa: BLE001
+            rec = {"spec": spec, "error": repr(e)}
+        rec["tag"] = tag
+        recs.append(rec)
+        print("CONFIGS_PARTIAL " + json.dumps(rec), flush=True)
+    print("CONFIGS_JSON " + json.dumps(recs), flush=True)
+
+
+def run_configs_child():
+    """(records, note): the configs[] child, its time bounded; whatever it finished is kept."""
+    env = dict(os.environ)
     try:
-        t_build = time.perf_counter()
-        s, d_b, facts, _ = build_workload(spec, env, itnlim=K)
-        t_build = time.perf_counter() - t_build
-        d_x = capi.DeviceBuffer(8 * max(facts["n"], 1))
-        s.atol = s.btol = s.conlim = 0.0
-        s.set_option("graph_iters", min(K + (K & 1), 50))
-        s.itnlim = min(4, K)
-        s.solve_device(d_b.ptr.value, d_x.ptr.value, facts["damp"])
-        dt, r, restarts = timed_solve(s, d_b, d_x, facts["damp"], K)
-        reps = 100 if facts["nnz"] < 200_000_000 else 10
-        roof, kernels, (alg1, alg2, lay1, lay2) = product_roofline(s, facts, reps, traffic)
-        out = {"workload": f"{spec} m={facts['m']} n={facts['n']} nnz={facts['nnz']} damp={facts['damp']}",
-               "variant": note, "env": env or {}, "n_gpus": 1, "steps": K, "value": K / dt, "unit": "it/s",
-               "ms_per_step": 1e3 * dt / K, "restarts": restarts, "generate_and_build_s": t_build,
-               "iter_bytes_layout": lay1 + lay2 + 40 * facts["n"],
-               "iter_gbps_layout": (lay1 + lay2 + 40 * facts["n"]) * K / dt / 1e9,
-               "roofline": roof, "kernels": kernels}
-        del s, d_b, d_x
-        return out
-    except Exception as e:      # noqa: BLE001
-        return {"workload": spec, "variant": note, "error": repr(e)}
+        cp = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--configs-child"], capture_output=True,
+                            text=True, timeout=CHILD_TIMEOUT, env=env, cwd=ROOT)
+        out, note = cp.stdout, (None if cp.returncode == 0 else f"configs child rc {cp.returncode}: {cp.stderr[-200:]}")
+    except subprocess.TimeoutExpired as e:
+        out = e.stdout.decode() if isinstance(e.stdout, bytes) else (e.stdout or "")
+        note = f"configs child timed out after {CHILD_TIMEOUT} s"
+    full = [ln for ln in out.splitlines() if ln.startswith("CONFIGS_JSON ")]
+    if full:
+        return json.loads(full[-1][len("CONFIGS_JSON "):]), note
+    return [json.loads(ln[len("CONFIGS_PARTIAL "):]) for ln in out.splitlines() if ln.startswith("CONFIGS_PARTIAL ")], note
+
+
+def emit(line: dict, detail: dict, path: str):
+    """The detail file first, then the ONE line -- at most LINE_MAX bytes: optional keys go, in this order, until it
+    fits (the contract keys, `roofline` and `cpu_baseline` always stay)."""
+    try:
+        with open(path, "w") as f:
+            json.dump(detail, f, indent=1)
+        line["detail"] = os.path.relpath(path, ROOT) if path.startswith(ROOT) else path
+    except OSError as e:
+        line["detail"] = f"not written: {e!r}"
+    text = json.dumps(line)
+    for victim in ("notes", "variants", "configs", "result"):
+        if len(text) <= LINE_MAX:
+            break
+        line.pop(victim, None)
+        line["dropped_for_length"] = line.get("dropped_for_length", []) + [victim]
+        text = json.dumps(line)
+    assert len(text) <= LINE_MAX, len(text)
+    sys.stdout.flush()
+    print(text, flush=True)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -409,96 +485,75 @@ def live_traffic(plan, timeout=600):
 def run_single(args):
     spec = HEADLINE if args.workload == "auto" else args.workload
     extras = args.extras == "on" and spec == HEADLINE
-    want_n1 = extras and not args.no_scaling_ref
-    from lsqr_amd.dist_bench import DEFAULT_SPEC
+    t_run = time.perf_counter()
+    notes = []
 
     # PMC passes first, as children, before this process touches the GPU
-    plan = [[spec, {}]]
-    if extras:
-        plan += [[sp, env] for sp, env, _ in HBM_INSTANCES]
-    if want_n1:
-        plan += [[DEFAULT_SPEC, {}]]
     traffic, traffic_note = ({}, "--traffic off")
     if args.traffic == "live" and not args.no_roofline:
-        traffic, traffic_note = live_traffic(plan)
-
-    def tr(sp, env):
-        return traffic.get((sp, json.dumps(env or {}, sort_keys=True), ()))
+        traffic, traffic_note = live_traffic([[spec, {}]])
+    tr = traffic.get((spec, "{}", ()))
 
     import torch
-    from lsqr_amd import capi
+    from lsqr_amd import capi, devgen
     if not torch.cuda.is_available() or capi.device_count() < 1:
         raise SystemExit("bench.py: no MI355X visible; the HIP path has no CPU fallback")
     K, W = args.steps, args.warmup
-    s, d_b, facts, host = build_workload(spec, None, itnlim=K)
-    d_x = capi.DeviceBuffer(8 * max(facts["n"], 1))
-    # graph batch: a divisor of K when there is a good one (no predicated-off tail iterations in
-    # the timed solve), else up to 50 iterations (launches past the stop are ~us-scale no-ops)
-    gi = next((g for g in (100, 50, 40, 32, 26, 20, 16) if K % g == 0), min(50, K + (K & 1)))
-    s.set_option("graph_iters", gi)
-    s.atol = s.btol = s.conlim = 0.0
-    # setup, untimed: the graphs of this batch size are captured and instantiated by the first solve, and the
-    # interpreter and the device clocks settle over a few more (a 20-iteration solve is 0.6 ms of device work:
-    # the first timed call after an idle start otherwise measures the ramp, +6 %)
-    # ... a 20-iteration solve still speeds up by 4 % over its first ~30 repeats, profiles/r03/perf_misc.txt): at
-    # least 3 solves and at least 60 ms of them
-    t_warm, n_warm = time.perf_counter(), 0
-    while n_warm < 3 or (time.perf_counter() - t_warm < 0.06 and n_warm < 400):
-        timed_solve(s, d_b, d_x, facts["damp"], min(K, 100))
-        n_warm += 1
-    if W > 0:                                   # the W warm-up steps of the contract, through the timed path
-        timed_solve(s, d_b, d_x, facts["damp"], W)
-    dt, r, restarts = timed_solve(s, d_b, d_x, facts["damp"], K)
-
-    cfgname = " (BASELINE.json configs[1])" if spec == HEADLINE else ""
-    out = {
-        "metric": "lsqr_iterations_per_sec", "value": K / dt, "unit": "it/s", "n_gpus": 1,
-        "steps": K, "warmup": W, "ms_per_step": 1e3 * dt / K, "higher_is_better": True,
-        "scaling": SCALING_N1 if spec == HEADLINE else "n/a (one GPU, one workload)",
+    full = measure_workload(spec, K, W, tr, note=HEADLINE_NOTE if spec == HEADLINE else "")
+    cfgname = f" ({HEADLINE_NOTE}, whole on one GPU)" if spec == HEADLINE else ""
+    roof = dict(full["roofline"])
+    if roof["traffic"] is None:
+        roof["traffic_note"] = (traffic_note or "no PMC rows for this workload")[:160]
+    if args.no_roofline:
+        roof = None
+    line = {
+        "metric": "lsqr_iterations_per_sec", "value": full["value"], "unit": "it/s", "n_gpus": 1,
+        "steps": K, "warmup": W, "ms_per_step": full["ms_per_step"], "higher_is_better": True,
+        # the same system at every N, total work fixed: the N > 1 lines (row-block sharded) divide by this one
+        "scaling": "strong" if spec == HEADLINE else "n/a (one GPU, one workload)",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"{facts['name']} m={facts['m']} n={facts['n']} nnz={facts['nnz']} "
-                               f"damp={facts['damp']}{cfgname}",
-                   "graph_iters": gi, "restarts": restarts},
-        "result": {"istop": r.istop, "itn": r.itn, "anorm": r.anorm, "rnorm": r.rnorm},
+        "config": {"workload": full["workload"] + cfgname, "graph_iters": full["graph_iters"], "restarts": full["restarts"]},
+        "result": full["result"],
+        "roofline": roof,
+        "spmv_gbps": {"mode1": full["roofline"]["achieved"], "mode2": full["roofline"]["frac_mode2"] * HBM_PEAK_GBS,
+                      "iteration": full["iter_gbps_survey8d"], "bytes": "SURVEY 8d algorithmic (B1, B2, BI)"},
     }
-    if not args.no_roofline:
-        reps = min(max(K, 500), 1000) if facts["nnz"] < 50_000_000 else (100 if facts["nnz"] < 200_000_000 else 10)
-        roof, kernels, (alg1, alg2, lay1, lay2) = product_roofline(s, facts, reps, tr(spec, {}))
-        if roof["traffic"] is None:
-            roof["traffic_note"] = traffic_note
-        out["roofline"] = roof
-        out["kernels"] = kernels
-        vec = 40 * facts["n"]
-        out["iter_bytes_layout"] = lay1 + lay2 + vec
-        out["iter_gbps_layout"] = (lay1 + lay2 + vec) * K / dt / 1e9
-        out["iter_bytes_survey8d"] = alg1 + alg2 + vec
-        out["iter_gbps_survey8d_effective"] = (alg1 + alg2 + vec) * K / dt / 1e9
-    del s, d_x
-    if extras and not args.no_roofline:
-        out["roofline_hbm"] = [side_workload(sp, env, note, 50, tr(sp, env)) for sp, env, note in HBM_INSTANCES]
-        # the general short-row kernel (no value dictionary, no repeating rows needed) on an HBM-resident instance,
-        # at top level: what a matrix without config 2's special structure gets from this library
-        g_inst = out["roofline_hbm"][GENERAL_INSTANCE]
-        if "roofline" in g_inst:
-            gen = dict(g_inst["roofline"])
-            gen["workload"] = g_inst["workload"]
-            gen["rocprof_summary"] = "profiles/r05/poisson4000_val8_roofline.txt"
-            out["roofline_general"] = gen
-        else:
-            out["roofline_general"] = g_inst
-    if want_n1:
-        n1 = side_workload(DEFAULT_SPEC, {}, "BASELINE.json configs[3], whole on one GPU", 40, tr(DEFAULT_SPEC, {}))
-        n1["note"] = "the --gpus N > 1 lines shard this matrix by row blocks: compare their value with this one"
-        out["strong_scaling_n1"] = n1
-    if extras and not args.no_roofline and args.configs == "on":
-        # every other BASELINE configuration a single GPU holds, measured by this run (no PMC pass: each would build
-        # the matrix twice more; `traffic` of the column-swept kernel is on strong_scaling_n1)
-        out["roofline_configs"] = [side_workload(sp, {}, note, k, None) for sp, k, note in ROOFLINE_CONFIGS]
-    if args.cpu_iters > 0 and host is not None:
-        out["cpu_baseline"] = cpu_baseline(host, args.cpu_iters)
-    elif args.cpu_iters > 0:
-        out["cpu_baseline"] = None   # workload generated in HBM only; the CPU sample is quoted on config 2
-    print(json.dumps(out), flush=True)
+    detail = {"headline": full, "traffic_note": traffic_note}
+
+    # cpu_baseline: the reference's CPU path, 1 core, on a bounded sample -- the workload itself where the host can hold it
+    cpu = None
+    if args.cpu_iters > 0:
+        try:
+            cfg = devgen.parse_spec(spec)
+            if cfg["kind"] == "random" and full_nnz(full) > 60_000_000:
+                from lsqr_amd.dist_bench import cpu_baseline_scaled
+                cpu = cpu_baseline_scaled(spec, full_nnz(full), iters=args.cpu_iters)
+            else:
+                host = make_problem(spec)
+                if host.nnz > 60_000_000:
+                    raise RuntimeError("no scaled-down generator for this workload")
+                cpu = cpu_baseline(host, max(args.cpu_iters, 200 if host.nnz < 10_000_000 else args.cpu_iters))
+                del host
+        except Exception as e:      # noqa: BLE001
+            cpu = {"error": repr(e)[:200]}
+    line["cpu_baseline"] = cpu
+
+    if extras and args.configs == "on" and not args.no_roofline:
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        recs, note = run_configs_child()
+        if note:
+            notes.append(note)
+        line["configs"] = [compact_entry(r, r.get("tag", "")) for r in recs]
+        detail["configs"] = recs
+    if notes:
+        line["notes"] = [n[:200] for n in notes]
+    detail["run_seconds"] = time.perf_counter() - t_run
+    emit(line, detail, args.detail)
+
+
+def full_nnz(full):
+    return int(full["workload"].split("nnz=")[1].split()[0])
 
 
 def spawn_ranks(args):
@@ -523,6 +578,8 @@ def main():
     args = parse()
     if args.pmc_child:
         return pmc_child(args.pmc_child)
+    if args.configs_child:
+        return configs_child()
     if args.roofline_only:
         return roofline_only(args)
     world = int(os.environ.get("WORLD_SIZE", "0"))

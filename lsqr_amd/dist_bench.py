@@ -4,7 +4,8 @@ Default workload: BASELINE.json configs[3] made concrete per SURVEY.md section 8
 m = n = 10^7 random sparse least squares with 100 nonzeros per row (10^9 nonzeros, density
 1e-5; the literal "~1 %" is 10^12 nonzeros = 12 TB and cannot exist on 8 x 288 GB), damp = 1e-3.
 Total work is fixed as N grows: "scaling": "strong".  The matrix is generated in HBM, each
-rank only its own row block.
+rank only its own row block.  `bench.py --gpus 1` measures the SAME system whole on one GPU: the lines of a series
+divide directly.  The one JSON line is at most 4 KB (bench.emit); everything else goes to the detail file it names.
 """
 from __future__ import annotations
 
@@ -280,9 +281,8 @@ def run_distributed(args):
     if W > 0:
         drv.solve(prob.d_b.ptr.value, itnlim=W, **kw)
     dt, r, restarts = timed_sharded_solve(drv, prob.d_b.ptr.value, K, kw, dist, torch, spec)
-    variants = {"plain": {"value": K / dt, "ms_per_step": 1e3 * dt / K, "validated": True,
-                          "is": "one stream: product, exchange, product, exchange (the 4-iteration probe against the Python "
-                                "stage driver above)"}}
+    # (what each schedule is: DESIGN.md section 5; the line carries value / ms_per_step / validated only)
+    variants = {"plain": {"value": K / dt, "ms_per_step": 1e3 * dt / K, "validated": True}}
 
     nnz_all = torch.tensor([prob.nnz], dtype=torch.int64, device="cuda")
     dist.all_reduce(nnz_all)
@@ -351,40 +351,56 @@ def run_distributed(args):
     sys.stdout.flush()
     dist.barrier()
 
+    detail = {}
     if rank == 0:
+        import bench as _bench
+        b2 = 12 * prob.nnz + info["rowptr_bytes"] * (cfg["n"] + 1) + 8 * nrows + 16 * cfg["n"]
+        try:
+            avg2 = s.bench_kernel(2, reps)
+        except Exception:  # noqa: BLE001
+            avg2 = None
+        ach_alg = b1 / (avg1 * 1e-3) / 1e9
         out = {
             "metric": "lsqr_iterations_per_sec", "value": K / dt, "unit": "it/s", "n_gpus": world, "steps": K,
             "warmup": W, "ms_per_step": 1e3 * dt / K, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{spec} m={cfg['m']} n={cfg['n']} nnz={nnz_total} damp={cfg['damp']} "
-                                   f"(BASELINE.json configs[3]: 10M x 10M random, row-block sharded)",
-                       "rows_per_rank": [b[1] for b in blocks], "exchanges_per_iteration":
-                           {"allreduce_scalars": "1 + 2 doubles (all-gather + rank-ordered sum)",
-                            "reduce_scatter_bytes_out_per_gpu": 8 * cfg["n"] * (world - 1) // world,
-                            "allgather_bytes_in_per_gpu": 8 * cfg["n"] * (world - 1) // world},
+                                   f"({_bench.HEADLINE_NOTE}, row-block sharded over {world} GPU{'s' if world > 1 else ''})",
+                       "rows_per_rank": ([b[1] for b in blocks] if world <= 8 else
+                                         {"min": min(b[1] for b in blocks), "max": max(b[1] for b in blocks)}),
                        "backend": ("nccl (RCCL; TEST: all ranks on ONE GPU, socket transport over lo -- not a measurement)" if shared
-                                   else "nccl (RCCL over xGMI)"), "ranks_share_one_gpu": shared, "engine": engine, "engine_note": engine_note, "world_size": dist.get_world_size(),
+                                   else "nccl (RCCL over xGMI)"), "ranks_share_one_gpu": shared, "engine": engine,
+                       "engine_note": engine_note[:200] if engine_note else None, "world_size": dist.get_world_size(),
                        "restarts": restarts},
             "result": {"istop": r.istop, "itn": r.itn, "anorm": r.anorm, "rnorm": r.rnorm},
-            "roofline": {"bound": "hbm", "kernel": f"{kname} (aprod mode 1, local row block, rank 0)",
-                         "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
+            # the dominant kernel on rank 0's row block, on SURVEY 8d's algorithmic bytes of that block (as at N = 1)
+            "roofline": {"bound": "cache" if ach_alg > 8000.0 else "hbm",
+                         "kernel": f"{kname} (aprod mode 1, local row block, rank 0)",
+                         "achieved": ach_alg, "peak": 8000.0, "unit": "GB/s", "frac": ach_alg / 8000.0,
                          "traffic": traffic.get("bytes_per_launch") if traffic else None,
-                         "traffic_detail": traffic, "traffic_note": traffic_note,
-                         "bytes_per_launch": lay1, "avg_launch_us": avg1 * 1e3, "launches": reps,
-                         "bytes_are": "the layout in use: matrix as stored + x once + y read and written (physical)",
-                         "effective_gbps": b1 / (avg1 * 1e-3) / 1e9, "effective_bytes_per_launch": b1,
-                         "frac_survey8d": b1 / (avg1 * 1e-3) / 1e9 / 8000.0,
-                         "bound_survey8d": "cache" if b1 / (avg1 * 1e-3) / 1e9 > 8000.0 else "hbm"},
+                         "bytes_per_launch": b1, "bytes_are": "SURVEY 8d B1 of the block (algorithmic)",
+                         "avg_launch_us": avg1 * 1e3, "launches": reps,
+                         "frac_layout": ach / 8000.0, "layout_bytes_per_launch": lay1,
+                         "frac_mode2": (b2 / (avg2 * 1e-3) / 1e9 / 8000.0) if avg2 else None,
+                         "avg_launch_us_mode2": avg2 * 1e3 if avg2 else None},
         }
-        # next to `value`: the same matrix whole on ONE GPU, measured by this run, and the ratio -- the strong-scaling
-        # number of this line.  (bench.py's own N = 1 line measures configs[1], another workload: never divide by it.)
+        if traffic is None:
+            out["roofline"]["traffic_note"] = (traffic_note or "")[:160]
+        detail["traffic_detail"] = traffic
+        detail["exchanges_per_iteration"] = {"allreduce_scalars": "1 + 2 doubles (all-gather + rank-ordered sum)",
+                                             "reduce_scatter_bytes_out_per_gpu": 8 * cfg["n"] * (world - 1) // world,
+                                             "allgather_bytes_in_per_gpu": 8 * cfg["n"] * (world - 1) // world}
+        # next to `value`: the same matrix whole on ONE GPU, measured by this run, and the ratio (bench.py --gpus 1
+        # measures the same system: its `value` is this figure from a run of its own)
         out["value_1gpu_same_workload"] = ref["value"] if ref and "value" in ref else None
         out["speedup_vs_1gpu_same_workload"] = (K / dt) / ref["value"] if ref and "value" in ref else None
         # the schedule the engine of the line's `value` REALLY ran (a requested overlap that could not be set up is off)
         out["overlap"] = (int(prob.solver.get_option("shard_overlap")) if engine == "c++" else 0)
         out["cpu_baseline"] = cpu
         if ref is not None:
-            out["strong_scaling_ref"] = ref
+            detail["strong_scaling_ref"] = ref
+            if "sharded_vs_1gpu" in ref:
+                out["sharded_vs_1gpu"] = ref["sharded_vs_1gpu"]
         out["variants"] = variants
         out["config"]["schedule"] = "plain"
     else:
@@ -412,7 +428,7 @@ def run_distributed(args):
         if rank == 0 and out is not None:
             out["variants"][state["doing"] or "?"] = {"error": "timed out (watchdog): RCCL hang?", "validated": False}
             out["config"]["variants_note"] = f"stopped by the watchdog inside `{state['doing']}`"
-            print(json.dumps(out), flush=True)
+            _bench.emit(out, detail, args.detail)
         os._exit(3)     # a hung job is a FAILED job on every rank: the line above says what was measured before it
 
     if want_variants:
@@ -421,6 +437,8 @@ def run_distributed(args):
         wd.daemon = True
         wd.start()
         r_ref = drv.solve(prob.d_b.ptr.value, itnlim=4, **kw)     # the plain engine's 4 iterations (same on every rank)
+
+        results = {}
 
         def agrees(rv):
             return (rv.itn == r_ref.itn and abs(rv.rnorm - r_ref.rnorm) <= 1e-12 * abs(r_ref.rnorm)
@@ -438,14 +456,14 @@ def run_distributed(args):
             except Exception as e:  # noqa: BLE001
                 ok, note = False, repr(e)
             if not all_ranks_ok(ok, dist, torch):
-                variants[name] = {"validated": False, "error": note or "failed or disagreed on another rank", "is": what}
+                variants[name] = {"validated": False, "error": (note or "failed or disagreed on another rank")[:120]}
                 return
             with _Env(env):
                 if W > 0:
                     vdrv.solve(vprob.d_b.ptr.value, itnlim=W, **kw)
             dtv, rv, _ = timed_sharded_solve(vdrv, vprob.d_b.ptr.value, K, kw, dist, torch, spec, env)
-            variants[name] = {"value": K / dtv, "ms_per_step": 1e3 * dtv / K, "validated": True, "is": what,
-                              "result": {"istop": rv.istop, "itn": rv.itn, "anorm": rv.anorm, "rnorm": rv.rnorm}}
+            variants[name] = {"value": K / dtv, "ms_per_step": 1e3 * dtv / K, "validated": True}
+            results[name] = {"istop": rv.istop, "itn": rv.itn, "anorm": rv.anorm, "rnorm": rv.rnorm}
 
         measure("graph", drv, prob, {"LSQRHIP_SHARD_GRAPH": "1"},
                 "the plain schedule, batches of iterations captured in a hipGraph (RCCL's kernels with them)")
@@ -466,7 +484,7 @@ def run_distributed(args):
             if "overlap" in variants and variants["overlap"].get("validated"):
                 variants["overlap"]["parts"] = int(prob_ov.solver.get_option("shard_parts"))
         else:
-            variants["overlap"] = {"validated": False, "error": err if not ok else "set-up failed on another rank"}
+            variants["overlap"] = {"validated": False, "error": (err if not ok else "set-up failed on another rank")[:120]}
         del drv_ov, prob_ov
         # copy : the plain schedule with the n-vector exchanges as copy-engine pulls from IPC-mapped peer buffers
         #        (LSQRHIP_SHARD_COPY=1 at comm_init: a handle of its own) -- no RCCL send / receive kernel on the CUs
@@ -484,7 +502,7 @@ def run_distributed(args):
             measure("copy", drv_cp, prob_cp, {},
                     "the plain schedule, n-vector exchanges as copy-engine pulls over IPC-mapped buffers (no RCCL send / receive kernels)")
         else:
-            variants["copy"] = {"validated": False, "error": err if not ok else "set-up failed on another rank"}
+            variants["copy"] = {"validated": False, "error": (err if not ok else "set-up failed on another rank")[:120]}
         del drv_cp, prob_cp
         # overlap_copy : the overlapped schedule with its parts as copy-engine pulls (fences: 8-byte all-gathers on the
         #        second communicator) -- the exchanges beside the products AND no send / receive kernel on the CUs
@@ -503,7 +521,7 @@ def run_distributed(args):
             measure("overlap_copy", drv_oc, prob_oc, {"LSQRHIP_SHARD_OVERLAP": "1"},
                     "exchanges in parts beside the products, as copy-engine pulls over IPC-mapped buffers")
         else:
-            variants["overlap_copy"] = {"validated": False, "error": err if not ok else "set-up failed on another rank"}
+            variants["overlap_copy"] = {"validated": False, "error": (err if not ok else "set-up failed on another rank")[:120]}
         del drv_oc, prob_oc
         if rank == 0:
             best = max((k for k, v in variants.items() if v.get("validated")), key=lambda k: variants[k]["value"])
@@ -512,22 +530,25 @@ def run_distributed(args):
             out["config"]["schedule"] = best
             out["overlap"] = 1 if best in ("overlap", "overlap_copy") else 0
             out["copy"] = 1 if best in ("copy", "overlap_copy") else 0
-            if "result" in variants[best]:
-                out["result"] = variants[best]["result"]
+            if best in results:
+                out["result"] = results[best]
             if out.get("value_1gpu_same_workload"):
                 out["speedup_vs_1gpu_same_workload"] = out["value"] / out["value_1gpu_same_workload"]
             # the one-process form (Fortran `ngpu = N`) on this node's devices, small system, untimed
             state["doing"] = "inprocess_sharded_check"
             try:
-                out["inprocess_sharded_check"] = inprocess_sharded_check(world)
+                chk = inprocess_sharded_check(world)
             except Exception as e:  # noqa: BLE001
-                out["inprocess_sharded_check"] = {"ok": False, "error": repr(e)}
+                chk = {"ok": False, "error": repr(e)}
+            detail["inprocess_sharded_check"] = chk
+            out["inprocess_sharded_check"] = {k: (v[:120] if isinstance(v, str) else v) for k, v in chk.items()
+                                              if k in ("ok", "ngpu", "rel_dx", "skipped", "error")}
         wd.cancel()
     if rank == 0:
         try:
             ctypes.CDLL(None).fflush(None)
         except Exception:
             pass
-        print(json.dumps(out), flush=True)
+        _bench.emit(out, detail, args.detail)
     dist.barrier()
     dist.destroy_process_group()

@@ -65,7 +65,101 @@ def check_survey8d(r):
     assert r["bound_survey8d"] == ("cache" if r["frac_survey8d"] > 1.0 else "hbm")
 
 
+LINE_MAX = 4096
+
+
+def raw_line(name):
+    with open(os.path.join(last_round_dir(), name)) as f:
+        return f.read().strip().splitlines()[-1]
+
+
+def system_of(workload: str):
+    """the tokens of config.workload that name the SYSTEM: spec, m, n, nnz, damp (what follows says how it is laid out)"""
+    return workload.split(" (")[0].split()
+
+
+def test_the_line_fits_the_drivers_reader():
+    """Round 5's line grew to 22 KB and the driver could not parse it (BENCH_r05.parsed = null).  From round 6 on every
+    committed driver-form line is at most 4 KB, and bench.emit drops optional keys rather than exceed it."""
+    import io
+    import sys
+
+    import bench
+    assert bench.LINE_MAX == LINE_MAX
+    if round_of_lines() >= 6:
+        for name in ("bench_default.json", "bench_default_k20.json", "engine_1rank_shard8.json"):
+            assert len(raw_line(name)) <= LINE_MAX, (name, len(raw_line(name)))
+    # emit(): a line made too long on purpose loses `notes`, then `variants`, `configs` ... -- never the contract keys
+    line = {k: 1 for k in CONTRACT}
+    line.update(roofline={k: 0 for k in dist_bench.ROOFLINE_KEYS}, cpu_baseline={k: 0 for k in dist_bench.CPU_BASELINE_KEYS},
+                notes=["x" * 3000], configs=[{"workload": "y" * 200} for _ in range(12)], variants={"plain": {"value": 1.0}})
+    old, sys.stdout = sys.stdout, io.StringIO()
+    try:
+        bench.emit(line, {"big": "z" * 10000}, os.path.join(os.environ.get("TMPDIR", "/tmp"), "bench_detail_test.json"))
+        text = sys.stdout.getvalue().strip()
+    finally:
+        sys.stdout = old
+    assert len(text) <= LINE_MAX and "\n" not in text
+    d = json.loads(text)
+    for k in CONTRACT + ("roofline", "cpu_baseline", "detail"):
+        assert k in d, k
+    assert "notes" in d["dropped_for_length"] and "variants" in d
+
+
+def check_round6_roofline(r):
+    """round 6 on: `achieved` / `frac` ARE SURVEY 8d's figure (algorithmic bytes / time / peak); the layout's own
+    bytes are beside it, and the transposed product's fraction"""
+    assert "SURVEY 8d" in r["bytes_are"] and r["bytes_per_launch"] > 0
+    assert abs(r["achieved"] - r["bytes_per_launch"] / (r["avg_launch_us"] * 1e-6) / 1e9) < 1e-6 * r["achieved"]
+    assert r["frac_layout"] > 0 and r["frac_mode2"] > 0 and r["avg_launch_us_mode2"] > 0
+
+
 def test_committed_single_gpu_lines():
+    if round_of_lines() >= 6:
+        for name in ("bench_default.json", "bench_default_k20.json"):
+            d = load(name)
+            check_line(d)
+            assert d["n_gpus"] == 1 and d["scaling"] == "strong"
+            # the headline IS the north star's workload: configs[3] whole on one GPU
+            assert system_of(d["config"]["workload"])[0] == dist_bench.DEFAULT_SPEC and "configs[3]" in d["config"]["workload"]
+            r = d["roofline"]
+            check_round6_roofline(r)
+            assert r["bound"] == "hbm" and 0.5 < r["frac"] <= 1.0 and "k_spmv_csb" in r["kernel"]
+            assert r["traffic"] is not None and 0.9 * r["bytes_per_launch"] < r["traffic"] < 2 * r["bytes_per_launch"]
+            assert r["kernel_launches_per_product"] >= 1
+            assert "scaled" in d["cpu_baseline"]["value_is"] or d["cpu_baseline"]["sample"]
+            # the other BASELINE configurations and the rank blocks, compact
+            cf = d["configs"]
+            assert [e["workload"] for e in cf] == ["poisson2d:1000:1000", "random:4000000:1000000:1000",
+                                                   "powerlaw:5000000:2000000:10000", "random:1250000:10000000:100",
+                                                   "random:1250000:10000000:1000"]
+            for e in cf:
+                assert "error" not in e, e
+                assert e["it_s"] > 0 and e["frac_mode1"] > 0 and e["frac_mode2"] > 0
+                if e.get("bound", "hbm") == "hbm":
+                    assert e["frac_mode1"] <= 1 and e["frac_mode2"] <= 1
+            assert cf[3]["engine_world1_ms_per_step"] > 0
+            assert os.path.basename(d["detail"]).endswith(".json")
+        assert load("bench_default_k20.json")["steps"] == 20 and load("bench_default_k20.json")["warmup"] == 5
+        return
+    _committed_single_gpu_lines_r05()
+
+
+def test_n1_and_n_gt_1_lines_name_the_same_system():
+    """`value` of the --gpus 1 line and of the --gpus N lines are points of ONE series: the same (m, n, nnz, damp)."""
+    import bench
+    assert bench.HEADLINE == dist_bench.DEFAULT_SPEC
+    if round_of_lines() < 6:
+        return
+    one = system_of(load("bench_default.json")["config"]["workload"])
+    for ov in (0, 1):
+        with open(os.path.join(last_round_dir(), f"rccl_shared_gpu_configs3_w8_overlap{ov}.json")) as f:
+            d = json.loads(f.read().strip().splitlines()[-1])
+        assert system_of(d["config"]["workload"]) == one, (one, d["config"]["workload"])
+        assert d["scaling"] == load("bench_default.json")["scaling"] == "strong"
+
+
+def _committed_single_gpu_lines_r05():
     for name in ("bench_default.json", "bench_default_k20.json"):
         d = load(name)
         check_line(d)
@@ -111,8 +205,12 @@ def test_committed_distributed_line():
     d = load("engine_1rank_shard8.json")        # the N > 1 line shape, forced at world = 1
     check_line(d)
     assert d["scaling"] == "strong" and d["config"]["engine"] in ("c++", "python") and "engine_note" in d["config"]
+    if round_of_lines() >= 6:
+        check_round6_roofline(d["roofline"])
+        assert len(raw_line("engine_1rank_shard8.json")) <= LINE_MAX
     if round_of_lines() >= 4:
-        check_survey8d(d["roofline"])
+        if round_of_lines() < 6:
+            check_survey8d(d["roofline"])
         # next to `value`: the same workload on one GPU and the ratio (None at world = 1: nothing to compare), and
         # whether the exchanges ran overlapped
         for k in ("value_1gpu_same_workload", "speedup_vs_1gpu_same_workload", "overlap"):
@@ -135,6 +233,10 @@ def test_committed_line_of_configs3_on_eight_rccl_ranks():
         c = d["config"]
         assert c["world_size"] == 8 and c["rows_per_rank"] == [1250000] * 8 and "random:10000000:10000000:100" in c["workload"]
         assert c["engine"] == "c++" and c["engine_note"] is None and c["ranks_share_one_gpu"] is True
+        if round_of_lines() >= 6:      # (the one-GPU reference solve itself is in the detail file; its distance is in the line)
+            assert len(json.dumps(d)) <= LINE_MAX and d["result"]["itn"] == d["steps"] and d["value_1gpu_same_workload"] > 0
+            assert d["sharded_vs_1gpu"]["rnorm_rel"] <= 1e-10 and d["sharded_vs_1gpu"]["anorm_rel"] <= 1e-10
+            continue
         ref = d["strong_scaling_ref"]
         assert ref["result"]["itn"] == d["result"]["itn"] == d["steps"]
         assert ref["sharded_vs_1gpu"]["rnorm_rel"] <= 1e-10 and ref["sharded_vs_1gpu"]["anorm_rel"] <= 1e-10

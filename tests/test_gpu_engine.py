@@ -318,7 +318,8 @@ def test_bench_distributed_leg_at_world_one_and_its_fallback(fail):
     from lsqr_amd import dist_bench
     assert set(dist_bench.LINE_KEYS) <= set(line)
     assert set(dist_bench.ROOFLINE_KEYS) <= set(line["roofline"]) and line["roofline"]["traffic"] is not None
-    assert line["roofline"]["traffic"] >= 0.9 * line["roofline"]["bytes_per_launch"]
+    assert line["roofline"]["traffic"] >= 0.9 * line["roofline"]["layout_bytes_per_launch"]   # (what the layout stores)
+    assert len(json.dumps(line)) <= 4096
     assert set(dist_bench.CPU_BASELINE_KEYS) <= set(line["cpu_baseline"]) and line["cpu_baseline"]["value"] > 0
     assert line["cpu_baseline"]["cores"] == 1 and line["cpu_baseline"]["kind"] in ("reference", "port")
 
@@ -563,16 +564,26 @@ def test_configs3_as_stated_eight_rccl_ranks_sharing_one_gpu(overlap):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {**os.environ, "LSQR_BENCH_STRONG_REF": "1", "LSQRHIP_SHARD_OVERLAP": overlap, "LSQR_RANKS_SHARE_GPU": "1",
            "LSQR_DIST_PROBE_TIMEOUT": "600", "LSQR_BENCH_VARIANTS": "0"}
-    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "20", "--warmup", "2",
-                        "--workload", "random:10000000:10000000:100", "--traffic", "off", "--cpu-iters", "0"],
+    # (6 iterations prove the path -- 8 ranks, every exchange, the one-handle comparison; the socket transport between
+    #  processes that share the GPU is what takes the time: round 5 ran 20)
+    K = 6
+    detail = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"bench_detail_w8_{overlap}.json")
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", str(K), "--warmup", "1",
+                        "--workload", "random:10000000:10000000:100", "--traffic", "off", "--cpu-iters", "0",
+                        "--detail", detail],
                        capture_output=True, text=True, timeout=1500, env=env)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
-    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    raw = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
+    assert len(raw) <= 4096
+    line = json.loads(raw)
     assert line["n_gpus"] == 8 and line["config"]["ranks_share_one_gpu"] is True and line["overlap"] == int(overlap)
     assert line["config"]["engine"] == "c++" and line["config"]["engine_note"] is None, line["config"]
-    assert line["config"]["rows_per_rank"] == [1250000] * 8 and line["result"]["itn"] == 20
-    ref = line["strong_scaling_ref"]
-    assert ref["result"]["itn"] == 20 and ref["result"]["istop"] == line["result"]["istop"]
+    assert line["config"]["rows_per_rank"] == [1250000] * 8 and line["result"]["itn"] == K
+    assert line["config"]["workload"].startswith("random:10000000:10000000:100 m=10000000 n=10000000 nnz=1000000000 damp=0.001")
+    with open(detail) as f:
+        ref = json.load(f)["strong_scaling_ref"]
+    assert ref["result"]["itn"] == K and ref["result"]["istop"] == line["result"]["istop"]
+    assert ref["sharded_vs_1gpu"] == line["sharded_vs_1gpu"] and line["value_1gpu_same_workload"] == ref["value"]
     assert ref["sharded_vs_1gpu"]["rnorm_rel"] <= 1e-10 and ref["sharded_vs_1gpu"]["anorm_rel"] <= 1e-10
 
 
@@ -594,7 +605,7 @@ def test_python_stage_driver_over_nccl_ranks_sharing_one_gpu():
     line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 3 and line["config"]["engine"] == "python" and "LSQR_DIST_TEST_ENGINE_FAILURE" in line["config"]["engine_note"]
     assert line["result"]["itn"] == 20
-    d = line["strong_scaling_ref"]["sharded_vs_1gpu"]
+    d = line["sharded_vs_1gpu"]
     assert d["rnorm_rel"] <= 1e-10 and d["anorm_rel"] <= 1e-10
 
 
