@@ -53,6 +53,15 @@
 //     reference's (tests/test_gpu_csb.py::test_non_finite_and_huge_x_as_the_reference).
 //   * the epilogue of a block forms y_i, the block's partial of sum (y ns)^2 (one per BLOCK, so the
 //     fixed-order reduction is independent of the launch shape) and clears the accumulators.
+//   * THE LAST SPLIT CLOSES THE BLOCK (round 6; column splits, S > 1).  Rounds 2-5 finished a split product with a second
+//     launch (k_csb_combine: 7-10 % of a product that lives 300 us -- its own prologue, a launch boundary, 62-128 row blocks
+//     on 256 CUs).  Now every split stores its exact sums to z -- write-through stores -- and draws a TICKET of the
+//     block (one returning atomic add); the split whose add returns S - 1 -- whichever it is -- acquires, and runs the
+//     block's epilogue from its own sums (still in LDS) + the other splits' z.  Integer adds: the sum is the same whoever
+//     closes the block, so y, the block's partial of sum y^2 (ONE per block, the unsplit kernel's thread -> row mapping)
+//     and the piece maxima are bit for bit those of S = 1.  No spinning: nobody waits for anybody.  A solve that stops
+//     while the product is under way (some splits saw the flag, some not) is told by the ticket's high half: the last
+//     arriver then only cleans up (zc, flags, ticket).  LSQRHIP_CSB_FUSE=0 at create: the combine launch.
 //   * LOCK STEP (round 5).  A CU's vector L1 returns data in REQUEST ORDER across all its waves: a gathered line of x
 //     that L2 had ready in ~250 cycles, queued behind another wave's stream line from HBM (~900), waits for that one
 //     and holds its slot meanwhile.  Rounds 2-4 let every wave run on its own (next chunk's stream requested right
@@ -108,6 +117,8 @@ constexpr int CSB_NORM_FRAC = 32;                // build: row 1-norms as intege
 constexpr int CSB_NO_EXP = INT_MIN;              // build: "this row has no nonzero value yet" in the rows' largest exponents
 constexpr int CSB_E1_LIMIT = 900;                // build: rows whose 1-norm lies beyond 2^+-900 decline the layout
 constexpr int CSB_QMAX = 4;                      // product: at most this many workgroups of k_csb_combine share a row block
+constexpr int CSB_PROBE_LAUNCHES = 8, CSB_PROBE_WGS = 512;   // LSQRHIP_CSB_PROBE=1: phase clocks of the first launches of a product
+constexpr int CSB_SMAX = 8;                      // column splits per row block at most (lsqrhip.hip build_csb)
 constexpr int CSB_XHIST = 64;                    // product: piece maxima of x binned by their distance (in exponents) from the largest
 // The (value, index) stream is read once: loaded non-temporal so that it does not push the part of x the
 // XCD's workgroups are gathering from out of L2 (PMC before: 15 % of the gathers missed L2, 2.6x the
@@ -145,6 +156,12 @@ struct CsbMat {
     unsigned long long *ymax;  // or null: the piece maxima of |y| (csb_pieces(rows): the words the k_csb_xmax pass over y would
                                // leave), raised by the epilogue with atomic max -- all zero on entry.  The NEXT product (the
                                // one that gathers from this y) takes its grids from them: no pass.
+    unsigned long long *probe; // or null (LSQRHIP_CSB_PROBE=1 at create, measurement only): [workgroup][8] wall-clock ticks (100 MHz)
+                               // of this launch's phases, written by thread 0 for the workgroup's first unit:
+                               // 0 entry | 1 coefficients | 2 grids + clear (sweep begins) | 3 sweep done | 4 sums published + ticket
+                               // | 5 epilogue done | 6 (last arriver: 1) | 7 unused
+    int fuse;                  // S > 1: the split of a block that arrives last at the block's ticket runs the block's epilogue
+                               // itself, from its own LDS sums + the other splits' z (no k_csb_combine launch)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -731,6 +748,84 @@ __device__ __forceinline__ double csb_row_sum(const CsbMat &A, long long fine, i
     return sum;
 }
 
+// ---- the last split closes the block (header) -----------------------------------------------------------------------
+// bad[b * CSB_QMAX + 0]: flags of the block (bit 0: a split left a product out, bit 1: a split added to zc);
+// bad[b * CSB_QMAX + 1]: the ticket -- low half: splits that have arrived, high half: how many of them had seen the stop flag.
+constexpr int CSB_TICKET_STOPPED = 1 << 16;
+// Write-through stores of the splits' sums (MI355X_MICROARCH.md "inter-workgroup visibility": every handed-off byte
+// stored sc1, every storing wave drained, then the counter; the consumer acquires and loads plainly).
+__device__ __forceinline__ void csb_store16_wt(long long *p, unsigned long long a, unsigned long long b)
+{
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    const v4u v = {(unsigned)a, (unsigned)(a >> 32), (unsigned)b, (unsigned)(b >> 32)};
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void csb_store8_wt(long long *p, unsigned long long a)
+{
+    typedef unsigned v2u __attribute__((ext_vector_type(2)));
+    const v2u v = {(unsigned)a, (unsigned)(a >> 32)};
+    asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+}
+// ONE lane, behind a workgroup barrier that follows every wave's `s_waitcnt vmcnt(0)` (its write-through z stores have
+// landed; the adds to zc and to the flags are atomics, performed at memory): draw the ticket; the last arriver acquires,
+// takes the block's flags and lowers flags and ticket for the next product.
+// Returns 0: not the last; else 1 | flags << 1 | (a split had stopped) << 3.
+__device__ __forceinline__ int csb_ticket(const CsbMat &A, int b, int myflags, bool stopped)
+{
+    int *fl = &A.bad[b * CSB_QMAX], *tk = &A.bad[b * CSB_QMAX + 1];
+    if (myflags != 0) {
+        (void)__hip_atomic_fetch_or(fl, myflags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    const int old = __hip_atomic_fetch_add(tk, 1 + (stopped ? CSB_TICKET_STOPPED : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((old & (CSB_TICKET_STOPPED - 1)) != A.S - 1) return 0;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int flags = __hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 3;
+    const bool anystopped = stopped || (old >> 16) != 0;
+    __hip_atomic_store(fl, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(tk, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return 1 | (flags << 1) | (anystopped ? 8 : 0);
+}
+// what the last arriver of a block does when a split of it never ran (the solve stopped under the product): y is no longer
+// wanted, but zc must be all zero again for the next product of this matrix
+__device__ __forceinline__ void csb_cleanup_block(const CsbMat &A, int row0, int nr, int verdict)
+{
+    if (verdict & 4)   // (flags bit 1: a split added to zc)
+        for (int r = threadIdx.x; r < nr; r += CSB_BLOCK)
+            __hip_atomic_store((unsigned long long *)&A.zc[row0 + r], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// the units of a workgroup that found the stop flag up: they still draw their tickets (as "stopped"), so that every
+// block's ticket comes back to zero whatever mix of splits ran
+__device__ void csb_fused_stopped(const CsbMat &A, int wg, int nwg, int *s_word)
+{
+    const int nsp = A.sp1 - A.sp0;
+    const int nunits = (A.b1 - A.b0) * nsp;
+    for (int u = wg; u < nunits; u += nwg) {
+        const int pos = A.b0 + u / nsp;
+        const int b = A.border != nullptr ? A.border[pos] : pos;
+        if (threadIdx.x == 0) *s_word = csb_ticket(A, b, 0, true);
+        __syncthreads();
+        const int verdict = *s_word;
+        if (verdict & 1) csb_cleanup_block(A, A.rstart[b], A.rstart[b + 1] - A.rstart[b], verdict);
+        __syncthreads();
+    }
+}
+// The closer's loads all go to lines other XCDs have just written through (the splits' sums) or nobody has touched in this
+// launch (y, the rows' exponents): five dependent round trips of ~5 us each for a full block (profiles/r06/
+// csb_phase_clocks_first.txt).  One request per 128-byte line of everything the epilogue will read, all in flight at once,
+// brings them into this XCD's L2 in ONE round trip; the epilogue's own loads then find them there.  (Results discarded;
+// loads return in order, so the epilogue's first real load waits for these by itself.)
+__device__ __forceinline__ void csb_touch_lines(const void *p, size_t bytes)
+{
+    const char *c = static_cast<const char *>(p);
+    const size_t first = (size_t)c & ~(size_t)127, last = ((size_t)c + bytes + 127) & ~(size_t)127;
+    for (size_t a = first + (size_t)threadIdx.x * 128; a < last; a += (size_t)CSB_BLOCK * 128) {
+        unsigned d;
+        asm volatile("global_load_dword %0, %1, off" : "=v"(d) : "v"(a) : "memory");
+    }
+}
+
 // K: chunks a wave takes per LOCK-STEP step (round 5; header "lock step"), or 0: the free-running sweep of rounds 2-4
 // (every wave on its own, next chunk's stream requested behind this chunk's gathers) -- kept for the A/B
 // (LSQRHIP_CSB_LOCKSTEP=0 at create).  Same sums bit for bit: integer adds do not care when they happen.
@@ -756,7 +851,13 @@ __global__ __launch_bounds__(CSB_BLOCK, 1) void k_spmv_csb(
         run_rider(rider, red);
         return;
     }
-    if (*stop != 0) return;
+    const bool fused = A.S > 1 && A.fuse != 0;
+    unsigned long long *pb = (A.probe != nullptr && tid == 0) ? A.probe + (size_t)wg * 8 : nullptr;
+    if (pb) pb[0] = wall_clock64();
+    if (*stop != 0) {
+        if (fused) csb_fused_stopped(A, wg, nwg, &s_bad);
+        return;
+    }
     // lock step: all CUs in the same phase would use HBM and the L2s in turn -- half of each XCD's workgroups
     // (workgroup i runs on XCD i % 8) start half a step late, so that one half gathers while the other streams
     if (K > 0 && A.stagger > 0 && ((wg >> 3) & 1))
@@ -772,6 +873,7 @@ __global__ __launch_bounds__(CSB_BLOCK, 1) void k_spmv_csb(
     }
     if (co.skip) return;
     const double sx = co.sx, sy = co.sy, cy = co.cy;
+    if (pb) pb[1] = wall_clock64();
 
     // the binary grids of this launch (the histogram of the piece maxima borrows the accumulators' space)
     const CsbGrid gr = csb_grids(xb, sx, red, reinterpret_cast<int *>(acc));
@@ -788,6 +890,7 @@ __global__ __launch_bounds__(CSB_BLOCK, 1) void k_spmv_csb(
     if (tid < CSB_GMX) gmx[tid] = 0u;
     const CsbPieces pc = csb_pieces(A.rows);
     __syncthreads();
+    if (pb) pb[2] = wall_clock64();
 
     // Column splits (few rows: fewer row blocks than CUs).  S workgroups share a block, each sweeping a
     // contiguous S-th of its column-sorted chunks into accumulators of its own; their integer sums go to
@@ -946,6 +1049,10 @@ __global__ __launch_bounds__(CSB_BLOCK, 1) void k_spmv_csb(
                 }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next step's stream has landed
             };
+            // (Round 6 tried the stream TWO steps ahead -- three register sets in rotation, no wait at a step's end, the
+            // lock step's order inside a step: 1-4 % SLOWER on every shape, profiles/r06/sweep_two_steps_ahead_ab.txt.  The
+            // CU's L1 returns data in request order: the gathers of step s + 1 stand behind the stream requested in step s
+            // whichever step consumes it, so a step still lasts that stream's round trip.)
             if (nsteps > 0) {   // (uniform)
                 issue_set(c0 + w, a0, q0);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -963,10 +1070,54 @@ __global__ __launch_bounds__(CSB_BLOCK, 1) void k_spmv_csb(
             __threadfence();   // this wave's adds to zc are performed before anyone reads them back
         }
         __syncthreads();
+        if (pb && u == wg) pb[3] = wall_clock64();
         // epilogue of the block: y, its partial of sum (y ns)^2, accumulators cleared
         const bool bad = s_bad != 0, big = s_big != 0;
         __syncthreads();   // (everyone has read the flags: they may be lowered)
-        if (A.S > 1) {  // a split: the exact sums as they are
+        int verdict = 0;   // fused splits: what the block's ticket said (csb_ticket); 0: this split is not the one that closes the block
+        if (fused) {
+            // the sums as they are to z, kept in LDS as well -- the last arriver uses its own.  WRITE-THROUGH stores (sc0 sc1,
+            // 16 bytes: pairs of rows from an even word on): the bytes leave this XCD's L2 as they are written and the
+            // ticket needs no release fence -- a `buffer_wbl2` per workgroup with 160 KB freshly dirtied each cost more than
+            // the combine launch it replaces (profiles/r06/fuse_ab_writethrough.txt against the first form, +10 us)
+            {
+                long long *zs = A.z + (size_t)sp * A.rows;
+                const int odd = (int)(((long long)sp * A.rows + row0) & 1);   // word parity of the block's first sum: pairs are 16-byte aligned
+                if (tid == 0 && odd && nr > 0) csb_store8_wt(&zs[row0], acc[0]);
+                const int npair = (nr - odd) >> 1;
+                for (int pi = tid; pi < npair; pi += CSB_BLOCK) {
+                    const int r = odd + 2 * pi;
+                    csb_store16_wt(&zs[row0 + r], acc[r], acc[r + 1]);
+                }
+                if (tid == 0 && nr > odd && ((nr - odd) & 1)) csb_store8_wt(&zs[row0 + nr - 1], acc[nr - 1]);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave, before the barrier the ticket lane waits at
+            __syncthreads();
+            if (tid == 0) {
+                s_big = csb_ticket(A, b, (bad ? 1 : 0) | (big ? 2 : 0), false);
+                s_bad = 0;
+            }
+            __syncthreads();
+            verdict = s_big;
+            __syncthreads();   // (everyone has read the word)
+            if (tid == 0) s_big = 0;
+            if (pb && u == wg) {
+                pb[4] = wall_clock64();
+                pb[6] = (unsigned long long)(verdict & 1);
+            }
+            if (!(verdict & 1) || (verdict & 8)) {   // not the last -- or the last of a product the solve stopped under: no epilogue
+                if (verdict & 1) csb_cleanup_block(A, row0, nr, verdict);
+                for (int r = tid; r < nr; r += CSB_BLOCK) acc[r] = 0ull;
+                if (tid == 0) acc[A.R] = 0ull;
+                __syncthreads();
+                continue;
+            }
+            // this split closes the block: everything its epilogue reads, requested at once (csb_touch_lines)
+            for (int k = 0; k < A.S; ++k)
+                if (k != sp) csb_touch_lines(&A.z[(size_t)k * A.rows + row0], sizeof(long long) * (size_t)nr);
+            csb_touch_lines(&y[row0], sizeof(VT) * (size_t)nr);
+            csb_touch_lines(&A.rexp[row0], sizeof(short) * (size_t)nr);
+        } else if (A.S > 1) {  // a split: the exact sums as they are
             long long *zs = A.z + (size_t)sp * A.rows + row0;
             for (int r = tid; r < nr; r += CSB_BLOCK) {
                 __builtin_nontemporal_store((long long)acc[r], &zs[r]);   // (written once, read once by k_csb_combine)
@@ -982,8 +1133,10 @@ __global__ __launch_bounds__(CSB_BLOCK, 1) void k_spmv_csb(
             __syncthreads();
             continue;
         }
+        // (a fused split that closes its block: the flags are the BLOCK's -- what any of its splits ran into)
+        const bool bad_b = fused ? (verdict & 2) != 0 : bad, big_b = fused ? (verdict & 4) != 0 : big;
         double sq = 0.0;
-        const bool pieces = A.ymax != nullptr && !bad;   // (uniform; with outliers: from y as patched, below)
+        const bool pieces = A.ymax != nullptr && !bad_b;   // (uniform; with outliers: from y as patched, below)
         const long long g_first = (long long)row0 >> pc.L;
         const int ng = nr > 0 ? (int)((((long long)row0 + nr - 1) >> pc.L) - g_first) + 1 : 0;
         const bool inlds = ng <= CSB_GMX;
@@ -995,12 +1148,35 @@ __global__ __launch_bounds__(CSB_BLOCK, 1) void k_spmv_csb(
         for (int rb0 = 0; rb0 < nr; rb0 += EPG * CSB_BLOCK) {     // (every wave runs every step: csb_group_max is a wave operation)
             VT yold[EPG];
             int eold[EPG];
+            long long zoth[EPG];   // fused: the other splits' sums of the row (all requested before any is used)
 #pragma unroll
             for (int i = 0; i < EPG; ++i) {
                 const int r = rb0 + i * CSB_BLOCK + tid;
                 const bool in = r < nr;
                 yold[i] = in ? y[row0 + r] : (VT)0;
                 eold[i] = in ? (int)A.rexp[row0 + r] : 0;
+                zoth[i] = 0;
+            }
+            if (fused) {
+                // three splits' sums at a time (S = 4, 2: one round trip; all seven of S = 8 at once cost the sweep its registers)
+                constexpr int ZB = 3;
+                for (int k0 = 0; k0 < A.S - 1; k0 += ZB) {   // (uniform)
+                    long long zv[ZB][EPG];
+#pragma unroll
+                    for (int kk = 0; kk < ZB; ++kk) {
+                        const int k = k0 + kk;
+                        const int so = k < sp ? k : k + 1;   // the k-th split that is not this one
+#pragma unroll
+                        for (int i = 0; i < EPG; ++i) {
+                            const int r = rb0 + i * CSB_BLOCK + tid;
+                            zv[kk][i] = (k < A.S - 1 && r < nr) ? A.z[(size_t)so * A.rows + row0 + r] : 0;
+                        }
+                    }
+#pragma unroll
+                    for (int kk = 0; kk < ZB; ++kk)
+#pragma unroll
+                        for (int i = 0; i < EPG; ++i) zoth[i] += zv[kk][i];
+                }
             }
 #pragma unroll
             for (int i = 0; i < EPG; ++i) {
@@ -1009,7 +1185,7 @@ __global__ __launch_bounds__(CSB_BLOCK, 1) void k_spmv_csb(
                     const int r = rb + tid;
                     unsigned hv = 0u;
                     if (r < nr) {
-                        const double sum = csb_row_sum(A, (long long)acc[r], row0 + r, gr, big, eold[i]);
+                        const double sum = csb_row_sum(A, (long long)acc[r] + zoth[i], row0 + r, gr, big_b, eold[i]);
                         acc[r] = 0ull;
                         const VT yn = (VT)(cy * ((double)yold[i] * sy) + sum);
                         y[row0 + r] = yn;
@@ -1026,13 +1202,17 @@ __global__ __launch_bounds__(CSB_BLOCK, 1) void k_spmv_csb(
             s_bad = 0;
             s_big = 0;
         }
-        if (bad) {  // uniform
+        if (bad_b) {  // uniform
             __syncthreads();
-            for (int ri = 0; ri < nranges; ++ri) {
-                long long c0, c1;
-                range(ri, c0, c1);
-                csb_add_outliers<VT, NARROW>(A, aval, c0, c1, x, sx, tau, pmax2, reinterpret_cast<double *>(acc), y, row0, nr);
-            }
+            if (fused)   // every chunk of the block, whichever split swept it
+                csb_add_outliers<VT, NARROW>(A, aval, A.cptr[b], A.cptr[b + 1], x, sx, tau, pmax2, reinterpret_cast<double *>(acc),
+                                             y, row0, nr);
+            else
+                for (int ri = 0; ri < nranges; ++ri) {
+                    long long c0, c1;
+                    range(ri, c0, c1);
+                    csb_add_outliers<VT, NARROW>(A, aval, c0, c1, x, sx, tau, pmax2, reinterpret_cast<double *>(acc), y, row0, nr);
+                }
             sq = csb_sumsq_rows<VT>(y, row0, nr, nsc);
             if (A.ymax != nullptr) csb_group_max_rows<VT>(A.ymax, pc, gmx, inlds, g_first, y, row0, nr);
         }
@@ -1047,6 +1227,7 @@ __global__ __launch_bounds__(CSB_BLOCK, 1) void k_spmv_csb(
         }
         if (A.ymax != nullptr) csb_group_flush(A.ymax, pc, gmx, inlds, g_first, ng);
         __syncthreads();
+        if (pb && u == wg) pb[5] = wall_clock64();
     }
 }
 

@@ -201,6 +201,9 @@ struct Csr {
     long long *zsplit = nullptr;  // S > 1: [S][rows] exact integer sums of the splits
     int *cbad = nullptr;          // S > 1: [nrb][CSB_QMAX] "a split left a product out / used the coarse sums" flags (csb.h)
     int Q = 1;                    // S > 1: workgroups of k_csb_combine per row block
+    unsigned long long *cprobe = nullptr;   // LSQRHIP_CSB_PROBE=1 (measurement only): [CSB_PROBE_LAUNCHES][CSB_PROBE_WGS][8] phase clocks (csb.h)
+    int cfuse = 0;                // S > 1: no k_csb_combine launch -- the split of a block that arrives LAST runs the block's epilogue
+                                  // itself (csb.h "the last split closes the block"; LSQRHIP_CSB_FUSE=0: the combine launch of rounds 2-5)
 };
 
 // One rank's view of a row-sharded solve (shard_api.h): its place in the world, the caller-owned
@@ -404,6 +407,7 @@ static void free_csr(Csr &c)
     if (c.rexp) (void)hipFree(c.rexp);
     if (c.zcoarse) (void)hipFree(c.zcoarse);
     if (c.cbad) (void)hipFree(c.cbad);
+    if (c.cprobe) (void)hipFree(c.cprobe);
     c = Csr();
 }
 
@@ -1420,6 +1424,14 @@ static int build_csb(hipStream_t s, const int *rowk, const int *colk, const doub
         // (splits that exist only for the overlap plan: one workgroup per block, whose partial of sum y^2 is bit for
         // bit the unsplit kernel's -- a solve with the plan repeats the solve without it)
         if (S_plain == 1) out.Q = 1;
+        // round 6: the split that arrives last at the block's ticket closes the block (csb.h) -- one partial per block,
+        // the unsplit kernel's thread -> row mapping: norms bit for bit those of S = 1, and no second launch
+        out.cfuse = env_int("LSQRHIP_CSB_FUSE", 1) != 0 ? 1 : 0;
+        if (out.cfuse) out.Q = 1;
+    }
+    if (env_int("LSQRHIP_CSB_PROBE", 0) != 0) {
+        HIPCHK(hipMalloc((void **)&out.cprobe, sizeof(unsigned long long) * CSB_PROBE_LAUNCHES * CSB_PROBE_WGS * 8));
+        HIPCHK(hipMemsetAsync(out.cprobe, 0, sizeof(unsigned long long) * CSB_PROBE_LAUNCHES * CSB_PROBE_WGS * 8, s));
     }
     out.grid = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)nrb * S, CSB_GRID));  // workgroups per launch
     out.out_grid = nrb * out.Q;   // partials of sum(y^2) one product leaves behind
@@ -2335,7 +2347,7 @@ extern "C" int lsqrhip_get_option(lsqrhip_handle_t h, const char *name, int64_t 
         const int rounds = c.crounds;
         // (the pass is not part of a product inside the loop when both matrices are column-swept: xmax_folded, and
         //  lsqrhip_bench_kernel times that form)
-        if (c.csb) *value = (all && !xmax_folded(h) ? 1 : 0) + csb_sweep_launches(c, rounds != 0) + (c.S > 1 ? 1 : 0);
+        if (c.csb) *value = (all && !xmax_folded(h) ? 1 : 0) + csb_sweep_launches(c, rounds != 0) + (c.S > 1 && !c.cfuse ? 1 : 0);
         else *value = c.P > 1 ? 2 : 1;
     } else if (k == "csb_blocks_mode1" || k == "csb_blocks_mode2") {  // row blocks of a column-swept layout (0: another layout)
         const Csr &c = k == "csb_blocks_mode1" ? h->A : h->AT;
@@ -2346,6 +2358,12 @@ extern "C" int lsqrhip_get_option(lsqrhip_handle_t h, const char *name, int64_t 
     } else if (k == "csb_splits_mode1" || k == "csb_splits_mode2") {
         const Csr &c = k == "csb_splits_mode1" ? h->A : h->AT;
         *value = c.csb ? c.S : 0;
+    } else if (k == "csb_probe_mode1" || k == "csb_probe_mode2") {   // device address of the phase clocks (0: LSQRHIP_CSB_PROBE was not set)
+        const Csr &c = k == "csb_probe_mode1" ? h->A : h->AT;
+        *value = (int64_t)(uintptr_t)c.cprobe;
+    } else if (k == "csb_fuse_mode1" || k == "csb_fuse_mode2") {   // column splits closed by their last arriver (no combine launch)
+        const Csr &c = k == "csb_fuse_mode1" ? h->A : h->AT;
+        *value = c.csb && c.S > 1 ? c.cfuse : 0;
     } else if (k == "pat_pair_mode1" || k == "pat_pair_mode2") {   // row patterns in the paired-rows form (pat.h)
         const Csr &c = k == "pat_pair_mode1" ? h->A : h->AT;
         *value = c.pat_pair ? 1 : 0;

@@ -371,7 +371,9 @@ static void launch_csb_K(H *h, const SpmvArgs &a)
     const int S = std::max(c.S, 1);
     CsbMat A{c.cval, c.cidx, c.cdel, c.ccb, c.cptr, c.crs, c.nrb, c.R, c.rows, c.cols, c.rexp, c.zcoarse, 0, 0, S, c.zsplit,
              c.cbad, std::max(c.Q, 1), c.gptr, c.NS, c.G, c.J, c.Pst, c.border, 0, S, c.cbarrier_a, c.cstagger,
-             reinterpret_cast<unsigned long long *>(a.ymax_out)};
+             reinterpret_cast<unsigned long long *>(a.ymax_out), nullptr, (S > 1 && c.cfuse) ? 1 : 0};
+    int probe_launch = 0;   // (LSQRHIP_CSB_PROBE=1: the phase clocks of this product's first launches)
+    const bool fused = A.fuse != 0;   // the last split of a block closes it inside the sweep launch: no k_csb_combine
     bool first = head;
     for (int ph = ph0; ph < ph1; ++ph) {
         int p0 = 0, p1 = c.nrb, nsp = S;   // positions of the launch order, splits per unit row
@@ -389,9 +391,11 @@ static void launch_csb_K(H *h, const SpmvArgs &a)
             const bool last = tail && ph == ph1 - 1 && b1 >= p1;
             A.b0 = b0;
             A.b1 = b1;
+            A.probe = (c.cprobe != nullptr && probe_launch < CSB_PROBE_LAUNCHES) ? c.cprobe + (size_t)probe_launch * CSB_PROBE_WGS * 8 : nullptr;
+            ++probe_launch;
             Rider rider = first ? a.rider : Rider{};
             const dim3 grid(std::max(1, std::min(c.grid, (b1 - b0) * nsp)) + (rider.kind != 0 ? 1 : 0));
-            hipEvent_t e0 = first ? a.e0 : nullptr, e1 = (last && S == 1) ? a.e1 : nullptr;
+            hipEvent_t e0 = first ? a.e0 : nullptr, e1 = (last && (S == 1 || fused)) ? a.e1 : nullptr;
             if (e0 == nullptr && e1 == nullptr)
                 hipLaunchKernelGGL((k_spmv_csb<VT, NARROW, K>), grid, dim3(CSB_BLOCK), 0, a.stream, A, x, y, a.coef, a.stop, a.pout,
                                    a.pin, a.npin, a.slot_in, a.slot_out, a.skip_if_zero, rider, xb, a.nsc);
@@ -403,7 +407,7 @@ static void launch_csb_K(H *h, const SpmvArgs &a)
             if (b1 >= p1) break;
         }
     }
-    if (S > 1 && tail) {  // the splits' sums -> y and the blocks' partials (csb.h k_csb_combine)
+    if (S > 1 && tail && !fused) {  // the splits' sums -> y and the blocks' partials (csb.h k_csb_combine)
         const dim3 grid(std::max(1, std::min(c.nrb * std::max(c.Q, 1), 2 * CSB_GRID)));
         if (a.e1 == nullptr)
             hipLaunchKernelGGL((k_csb_combine<VT, NARROW>), grid, dim3(CSB_BLOCK), 0, a.stream, A, x, y, a.coef, a.stop, a.pout,
