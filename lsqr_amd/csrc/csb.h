@@ -811,21 +811,6 @@ __device__ void csb_fused_stopped(const CsbMat &A, int wg, int nwg, int *s_word)
         __syncthreads();
     }
 }
-// The closer's loads all go to lines other XCDs have just written through (the splits' sums) or nobody has touched in this
-// launch (y, the rows' exponents): five dependent round trips of ~5 us each for a full block (profiles/r06/
-// csb_phase_clocks_first.txt).  One request per 128-byte line of everything the epilogue will read, all in flight at once,
-// brings them into this XCD's L2 in ONE round trip; the epilogue's own loads then find them there.  (Results discarded;
-// loads return in order, so the epilogue's first real load waits for these by itself.)
-__device__ __forceinline__ void csb_touch_lines(const void *p, size_t bytes)
-{
-    const char *c = static_cast<const char *>(p);
-    const size_t first = (size_t)c & ~(size_t)127, last = ((size_t)c + bytes + 127) & ~(size_t)127;
-    for (size_t a = first + (size_t)threadIdx.x * 128; a < last; a += (size_t)CSB_BLOCK * 128) {
-        unsigned d;
-        asm volatile("global_load_dword %0, %1, off" : "=v"(d) : "v"(a) : "memory");
-    }
-}
-
 // K: chunks a wave takes per LOCK-STEP step (round 5; header "lock step"), or 0: the free-running sweep of rounds 2-4
 // (every wave on its own, next chunk's stream requested behind this chunk's gathers) -- kept for the A/B
 // (LSQRHIP_CSB_LOCKSTEP=0 at create).  Same sums bit for bit: integer adds do not care when they happen.
@@ -1112,11 +1097,10 @@ __global__ __launch_bounds__(CSB_BLOCK, 1) void k_spmv_csb(
                 __syncthreads();
                 continue;
             }
-            // this split closes the block: everything its epilogue reads, requested at once (csb_touch_lines)
-            for (int k = 0; k < A.S; ++k)
-                if (k != sp) csb_touch_lines(&A.z[(size_t)k * A.rows + row0], sizeof(long long) * (size_t)nr);
-            csb_touch_lines(&y[row0], sizeof(VT) * (size_t)nr);
-            csb_touch_lines(&A.rexp[row0], sizeof(short) * (size_t)nr);
+            // This split closes the block.  (What bounds it is the ~64 lines one CU keeps in flight: 0.85 MB of sums, y and
+            // exponents through ONE CU take 28 us for a full block at S = 4 -- as long as the combine launch took on the whole
+            // chip.  Requesting every line it will read at once, ahead of the epilogue, made it 55 us: profiles/r06/
+            // fuse_touch_lines_negative.txt; two register sets in turn spilled the sweep.)
         } else if (A.S > 1) {  // a split: the exact sums as they are
             long long *zs = A.z + (size_t)sp * A.rows + row0;
             for (int r = tid; r < nr; r += CSB_BLOCK) {
@@ -1145,6 +1129,10 @@ __global__ __launch_bounds__(CSB_BLOCK, 1) void k_spmv_csb(
         // one rank's block of config 4, mode 2).  (All 20 at once -- fully unrolled -- bloated the kernel past the
         // instruction cache and spilled: slower.)
         constexpr int EPG = 4;
+        // cy == 0 (the sharded engine's mode 2: T <- 0 (T 1) + A_p'u, shard_api.h c2p): what y held does not enter the result
+        // and is not read -- 8 of the 18 bytes per row the epilogue loads.  (An old y that is not finite then no longer turns
+        // the row into NaN; the engine's T is its own buffer, written by this product alone.)
+        const bool ykeep = cy != 0.0;
         for (int rb0 = 0; rb0 < nr; rb0 += EPG * CSB_BLOCK) {     // (every wave runs every step: csb_group_max is a wave operation)
             VT yold[EPG];
             int eold[EPG];
@@ -1153,7 +1141,7 @@ __global__ __launch_bounds__(CSB_BLOCK, 1) void k_spmv_csb(
             for (int i = 0; i < EPG; ++i) {
                 const int r = rb0 + i * CSB_BLOCK + tid;
                 const bool in = r < nr;
-                yold[i] = in ? y[row0 + r] : (VT)0;
+                yold[i] = (in && ykeep) ? y[row0 + r] : (VT)0;
                 eold[i] = in ? (int)A.rexp[row0 + r] : 0;
                 zoth[i] = 0;
             }
