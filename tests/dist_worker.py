@@ -1,6 +1,6 @@
 """One rank of a sharded solve (launched by tests/test_dist.py as a subprocess).
 
-    python tests/dist_worker.py RANK WORLD PORT CASE BACKEND OUT.npz
+    python tests/dist_worker.py RANK WORLD PORT CASE BACKEND OUT.npz [ITNCAP]
 
 BACKEND = numpy (CPU, gloo, oracle-backed stage stand-in) | hip / hip32 (C-ABI stages on cuda:0, gloo; binary64 / REAL32)
         | engine / engine32 / engine_ov / engine32_ov / engine_copy / engine32_copy (the C++ engine over RCCL, binary64 /
@@ -79,6 +79,8 @@ def engine_rank(rank, world, port, case, backend, out):
     dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world,
                             device_id=torch.device("cuda:0"))
     p, o = build_cases()[case]
+    if len(sys.argv) > 7:     # ITNCAP: the case with its iteration limit lowered (what the socket transport between
+        o = dict(o, itnlim=min(o["itnlim"], int(sys.argv[7])))   # processes sharing the GPU costs per iteration adds up)
     w = np.bincount(p.irow - 1, minlength=p.m).astype(np.float64)
     row0, nrows = partition_rows(p.m, world, w)[rank]
     irow, icol, a, b = local_block(p.irow, p.icol, p.a, p.b, row0, nrows)

@@ -143,7 +143,7 @@ def run(ncases, seed, verbose=True, bands=False, only=None, engine=False, real32
         return run_real32(ncases, seed, verbose)
     rs = np.random.RandomState(seed)
     po = oracle.port()
-    bad = widened = total = se_wide = wide_hits = 0
+    bad = widened = total = se_wide = wide_hits = se_noise = 0
     for case in range(ncases):
         m, n, irow, icol, a, b = make_case(rs)
         xp, yp = rs.uniform(-1, 1, size=n), rs.uniform(-1, 1, size=m)
@@ -182,6 +182,21 @@ def run(ncases, seed, verbose=True, bands=False, only=None, engine=False, real32
                   f"-> tolerance {tol_long:.2e}", flush=True)
         worst = worst_ref = 0.0
         se_band = None
+        o_prev = None
+
+        def last_iteration_ran_on_noise():
+            """The reference's own normal-equations residual one iteration BEFORE its last was already at rounding level
+            (test2 = arnorm / (anorm rnorm) <= 1e-12, src/lsqr.f90:751-778): the Krylov space was exhausted, the last
+            iteration's v is normalised noise.  The rule tests/test_gpu_parity.py:101-109 applies to its goldens, here from
+            the oracle run one iteration shorter."""
+            nonlocal o_prev
+            if o.itn < 2:
+                return False
+            if o_prev is None:
+                o_prev = po.solve(m, n, irow, icol, a, b, damp=1e-2, itnlim=o.itn - 1, wantse=True)
+            den = o_prev.anorm * o_prev.rnorm
+            return o_prev.itn == o.itn - 1 and (den == 0.0 or o_prev.arnorm <= 1e-12 * den)
+
         for lay in (ENGINES if engine else LAYOUTS):
             se_widened, se_ok, e4 = False, True, 0.0
             for k in KNOBS + ENGINE_KNOBS:
@@ -246,6 +261,17 @@ def run(ncases, seed, verbose=True, bands=False, only=None, engine=False, real32
                                 po.set_norm_ulp(0, 0, 0)
                         if e4 < max(TIGHT, BAND_FACTOR * se_band):
                             se_widened = True      # accepted on the measured band: counted (se_wide) and bounded like x's
+                        elif last_iteration_ran_on_noise():
+                            # (round 6, seed 605: m = 2 / 5000, n = 65, TWO nonzeros -- solved exactly after two steps; the
+                            #  third, which both sides run, normalises rounding noise into a unit vector and se adds
+                            #  (w / rho)^2 of it, src/lsqr.f90:733-737.  The bands above are zero for two nonzeros.)  What is
+                            #  left to hold: every se_j is at least what the iterations BEFORE the noise had accumulated --
+                            #  the sums only grow -- and finite.
+                            lb = o_prev.se * (o.rnorm / o_prev.rnorm) if o_prev.rnorm > 0 else 0.0 * o_prev.se
+                            if np.all(np.isfinite(r.se)) and np.all(r.se >= lb * (1.0 - 1e-9) - 1e-300):
+                                se_noise += 1      # (counted apart: not a band, a quantity made of noise on both sides)
+                            else:
+                                se_ok = False
                         else:
                             se_ok = False
                 # 6 iterations at most; a system that converges to machine precision earlier may stop one
@@ -284,7 +310,8 @@ def run(ncases, seed, verbose=True, bands=False, only=None, engine=False, real32
         bad += 1
         print(f"FAIL: {se_wide} of {total} standard-error results needed a measured band (at most {MAX_WIDENED_SHARE:.0%} may)")
     if verbose:
-        print(f"({se_wide} of {total} standard-error vectors were accepted on the reference's own measured band; "
+        print(f"({se_wide} of {total} standard-error vectors were accepted on the reference's own measured band, {se_noise} more "
+              f"where the reference's last iteration ran on rounding noise; "
               f"{wide_hits} results went through the wide row-pattern table)")
         print(f"{ncases} cases x {len(ENGINES if engine else LAYOUTS)} {'engine variants' if engine else 'layouts'}: {bad} failures; {widened} of {total} results needed more than "
               f"{TIGHT:g} (at most {MAX_WIDENED_SHARE:.0%} may)")
