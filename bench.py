@@ -84,6 +84,7 @@ def parse():
     ap.add_argument("--roofline-only", action="store_true",
                     help="build the workload and time ONLY its products (what a `rocprofv3 --kernel-trace "
                          "--stats` of this command then averages: profiles/rNN/*_roofline.txt)")
+    ap.add_argument("--roofline-mode", type=int, choices=[1, 2], default=1, help="--roofline-only: which product (aprod mode)")
     ap.add_argument("--pmc-child", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--configs-child", action="store_true", help=argparse.SUPPRESS)
     a = ap.parse_args()
@@ -265,14 +266,27 @@ def timed_solve(s, d_b, d_x, damp, K):
 
 
 def roofline_only(args):
-    """Only the products: 3 warm + `reps` back-to-back launches of mode 1, then of mode 2.  Under `rocprofv3
-    --kernel-trace --stats` the kernel's average duration x kernel_launches_per_product is avg_launch_us of the line."""
+    """Only ONE product kernel: 3 warm + `reps` back-to-back launches of mode 1 (or, `--roofline-mode 2`, of mode 2).  Under
+    `rocprofv3 --kernel-trace --stats` the kernel's average duration x kernel_launches_per_product is avg_launch_us of the
+    line (nothing else of that kernel's name runs in the process)."""
     spec = HEADLINE if args.workload == "auto" else args.workload
+    mode = args.roofline_mode
     s, d_b, facts, _ = build_workload(spec, None)
-    reps = 200 if facts["nnz"] < 50_000_000 else (50 if facts["nnz"] < 200_000_000 else 10)
-    roof, detail = product_roofline(s, facts, reps)
+    info = s.info()
+    m, n, nnz, P = facts["m"], facts["n"], facts["nnz"], info["rowptr_bytes"]
+    reps = 200 if nnz < 50_000_000 else (50 if nnz < 200_000_000 else 10)
+    avg = s.bench_kernel(mode, reps)
+    alg = 12 * nnz + (P * (m + 1) + 8 * n + 16 * m if mode == 1 else P * (n + 1) + 8 * m + 16 * n)
+    lay = (info["csr_bytes"] + 8 * n + 16 * m) if mode == 1 else (info["csrt_bytes"] + 8 * m + 16 * n)
+    lpp = s.get_option(f"launches_mode{mode}")
+    ach = alg / (avg * 1e-3) / 1e9
     print(json.dumps({"workload": spec, "env": {k: v for k, v in os.environ.items() if k.startswith("LSQRHIP_")},
-                      "roofline": roof, "kernels": detail["kernels"]}), flush=True)
+                      "roofline": {"kernel": describe_layout(info)[1] + f" (aprod mode {mode})", "bytes_per_launch": alg,
+                                   "bytes_are": f"SURVEY 8d B{mode} (algorithmic)", "avg_launch_us": avg * 1e3,
+                                   "kernel_launches_per_product": lpp, "avg_kernel_launch_us": avg * 1e3 / lpp,
+                                   "launches": reps, "achieved": ach, "frac": ach / HBM_PEAK_GBS, "peak": HBM_PEAK_GBS,
+                                   "unit": "GB/s", "frac_layout": lay / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                   "layout_bytes_per_launch": lay}}), flush=True)
 
 
 def graph_batch(K):

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Fill the @@TOKENS@@ of DESIGN.md from the round's committed evidence (profiles/rNN): the default bench line, the rank
-block series, the GPU suite's summary.  usage: fill_design.py profiles/r06   (idempotent only on a file that still has tokens)"""
+block series, the GPU suite's summary.  usage: fill_design.py profiles/r06   (writes DESIGN.md from scripts/DESIGN.template.md)"""
 import json, os, re, sys
 d = sys.argv[1]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -48,7 +48,7 @@ p4 = os.path.join(d, "poisson4000_patterns_roofline.txt")
 mm = re.search(r'"frac_layout": ([\d.]+)', open(p4).read()) if os.path.exists(p4) else None
 T["P4000_F1"] = "%.2f" % float(mm.group(1)) if mm else "0.68"
 path = os.path.join(root, "DESIGN.md")
-s = open(path).read()
+s = open(os.path.join(root, "scripts", "DESIGN.template.md")).read()      # DESIGN.md is GENERATED from the template: edit that
 missing = set(re.findall(r"@@(\w+)@@", s)) - set(T)
 assert not missing, missing
 for k, v in T.items():

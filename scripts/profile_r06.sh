@@ -39,16 +39,17 @@ PY
   cat "$OUT/$tag.txt"
 }
 # the dominant kernel alone: its rocprofv3 average x launches per product = roofline.avg_launch_us
-roof() {   # tag, env assignment or "-", workload
-  local tag=$1 envs=$2 spec=$3
+roof() {   # tag, env assignment or "-", workload [, mode]
+  local tag=$1 envs=$2 spec=$3 mode=${4:-1}
+  [ "$mode" = 2 ] && tag=${tag}_mode2
   local d=$OUT/${tag}_roofline
   rm -rf "$d"; mkdir -p "$d"
   setenvs "$envs"
-  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$d/trace" -o t -- python3 "$R/bench.py" --workload $spec --roofline-only > "$d/bench.json" 2> "$d/err.txt"
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$d/trace" -o t -- python3 "$R/bench.py" --workload $spec --roofline-only --roofline-mode $mode > "$d/bench.json" 2> "$d/err.txt"
   unsetenvs "$envs"
   local f=$(find "$d/trace" -name "*kernel_stats.csv" | head -1)
   {
-    echo "# ${tag}_roofline: rocprofv3 --kernel-trace --stats -- python3 bench.py --workload $spec --roofline-only   ${envs}"
+    echo "# ${tag}_roofline: rocprofv3 --kernel-trace --stats -- python3 bench.py --workload $spec --roofline-only --roofline-mode $mode   ${envs}"
     echo "# bench.py line of the same run (HIP events on the solver's stream):"
     echo "#   $(tail -1 "$d/bench.json")"
     echo "# kernel stats of the product kernels (Name, Calls, TotalDurationNs, AverageNs):"
@@ -79,15 +80,18 @@ for t in $TAGS; do
     mesh4000_wide)    run mesh4000_wide_patterns - --workload mesh2d:4000:4000:16:16 --steps 200 --warmup 20
                       roof mesh4000_wide_patterns - mesh2d:4000:4000:16:16 ;;
     config4)          run config4_random_10Mx10Mx100 - --workload random:10000000:10000000:100 --steps 20 --warmup 2
-                      roof config4_random_10Mx10Mx100 - random:10000000:10000000:100 ;;
+                      roof config4_random_10Mx10Mx100 - random:10000000:10000000:100
+                      roof config4_random_10Mx10Mx100 - random:10000000:10000000:100 2 ;;
     shard8)           run shard8_random_1250000x10Mx100 - --workload random:1250000:10000000:100 --steps 40 --warmup 4
-                      roof shard8_random_1250000x10Mx100 - random:1250000:10000000:100 ;;
+                      roof shard8_random_1250000x10Mx100 - random:1250000:10000000:100
+                      roof shard8_random_1250000x10Mx100 - random:1250000:10000000:100 2 ;;
     config3_100)      run config3_random_4Mx1Mx100 - --workload random:4000000:1000000:100 --steps 40 --warmup 4
                       roof config3_random_4Mx1Mx100 - random:4000000:1000000:100 ;;
     config3_literal)  run config3_literal_4Mx1Mx1000 - --workload random:4000000:1000000:1000 --steps 10 --warmup 2
                       roof config3_literal_4Mx1Mx1000 - random:4000000:1000000:1000 ;;
     config5)          run config5_powerlaw_5Mx2M - --workload powerlaw:5000000:2000000:10000 --steps 40 --warmup 4
-                      roof config5_powerlaw_5Mx2M - powerlaw:5000000:2000000:10000 ;;
+                      roof config5_powerlaw_5Mx2M - powerlaw:5000000:2000000:10000
+                      roof config5_powerlaw_5Mx2M - powerlaw:5000000:2000000:10000 2 ;;
     shard8_r1000)     run shard8_random_1250000x10Mx1000 - --workload random:1250000:10000000:1000 --steps 10 --warmup 2
                       roof shard8_random_1250000x10Mx1000 - random:1250000:10000000:1000 ;;
     shard8_plan)      run shard8_overlap_plan LSQRHIP_SHARD_OVERLAP=1,LSQRHIP_SHARD_WORLD=8 --workload random:1250000:10000000:100 --steps 40 --warmup 4

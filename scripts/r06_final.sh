@@ -23,5 +23,5 @@ bash scripts/pmc_csb.sh powerlaw:5000000:2000000:10000 r06f/pmc_c5 > $OUT/pmc_co
 rm -rf $OUT/pmc_c4 $OUT/pmc_c5 $OUT/pmc_s8
 for spec in random:1250000:10000000:100 powerlaw:5000000:2000000:10000 random:10000000:10000000:100; do python3 scripts/csb_probe.py $spec 2>&1 | grep -v amdgpu.ids; done > $OUT/csb_phase_clocks.txt
 python -m lsqr_amd.operator > $OUT/LSQR_gpu_mi355x.LIS 2> $OUT/LSQR_gpu.err
-python -m pytest tests -m gpu -q --durations=15 2>&1 | tail -30 > $OUT/full_gpu.txt
+python -m pytest tests -m gpu -q -rf --durations=15 2>&1 | tail -60 > $OUT/full_gpu.txt
 tail -3 $OUT/full_gpu.txt

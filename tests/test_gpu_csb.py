@@ -135,6 +135,52 @@ def test_results_do_not_depend_on_the_blocking_bit_for_bit(csb_env, kind):
     assert np.array_equal(y1, 2.0 ** 40 * y0)
 
 
+def test_the_last_split_closes_the_block_bit_for_bit_and_every_time(csb_env):
+    """Round 6 (csb.h "the last split closes the block"): with column splits every split stores its exact sums write-through,
+    draws a ticket of its block, and whichever split arrives LAST acquires and runs the block's epilogue from its own sums +
+    the other splits' -- no k_csb_combine launch.  On the SAME row blocks (R fixed) the results are those of the unsplit
+    kernel bit for bit: y of every product, and -- one partial of sum y^2 per block, the same thread -> row mapping -- the
+    norms, hence every iterate of a solve.  The hand-off crosses XCDs (sums written through by one XCD's L2, read by
+    another's after an agent-scope acquire): 300 products in a row on fresh vectors, each compared, would show a single stale
+    line; the combine-launch form (LSQRHIP_CSB_FUSE=0) gives the same y."""
+    p = P.random_rows(60000, 200000, 16, seed=21, damp=1e-3)
+    os.environ.pop("LSQRHIP_CSB_FUSE", None)
+    made = {}
+    for S, fuse in ((1, None), (4, None), (8, None), (4, "0")):
+        csb_env(938)
+        os.environ["LSQRHIP_CSB_S"] = str(S)
+        if fuse is not None:
+            os.environ["LSQRHIP_CSB_FUSE"] = fuse
+        try:
+            s = lsqr_solver_ez().initialize(p.m, p.n, p.a, p.irow, p.icol, itnlim=40)
+        finally:
+            os.environ.pop("LSQRHIP_CSB_FUSE", None)
+            os.environ.pop("LSQRHIP_CSB_S", None)
+        assert s.info()["xlds"] == 3 and s.get_option("csb_splits_mode1") == S and s.get_option("csb_blocks_mode1") == 64
+        assert s.get_option("csb_fuse_mode1") == (1 if S > 1 and fuse is None else 0)
+        # rounds of 256 units (64 blocks x S splits), and no launch behind them where the splits close their blocks themselves
+        assert s.get_option("launches_mode1") == (64 * S + 255) // 256 + (1 if fuse == "0" else 0)
+        made[(S, fuse)] = s
+    rs = np.random.RandomState(5)
+    for k in range(300):
+        x = rs.uniform(-1, 1, size=p.n) * 10.0 ** rs.randint(-3, 4)
+        y0 = rs.uniform(-1, 1, size=p.m)
+        outs = []
+        for key, s in made.items():
+            y = y0.copy()
+            s.aprod(1, p.m, p.n, x.copy(), y)
+            outs.append(y)
+        for y in outs[1:]:
+            assert np.array_equal(y, outs[0]), k
+    ref = made[(1, None)].solve(p.b, p.damp)
+    for key in ((4, None), (8, None)):
+        r = made[key].solve(p.b, p.damp)
+        assert (r.istop, r.itn, r.anorm, r.rnorm, r.xnorm) == (ref.istop, ref.itn, ref.anorm, ref.rnorm, ref.xnorm), key
+        assert np.array_equal(r.x, ref.x), key
+    r = made[(4, "0")].solve(p.b, p.damp)       # (the combine launch leaves Q partials per block: the norms agree to rounding)
+    assert r.itn == ref.itn and np.linalg.norm(r.x - ref.x) <= 1e-12 * np.linalg.norm(ref.x)
+
+
 def test_a_block_too_empty_for_local_columns_falls_back(csb_env):
     """18-bit local columns need every chunk of 256 column-sorted nonzeros to span < 262144 columns.
     Three nonzeros per row over 600000 columns in blocks of 64 rows do not: the build must notice and
