@@ -249,9 +249,9 @@ def test_rccl_ranks_sharing_one_gpu_through_bench_launcher(world, overlap, graph
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    # (worlds of 4 and more: 8 iterations -- every exchange of every schedule still runs; over sockets between processes
+    # (worlds of 3 and more: 8 iterations -- every exchange of every schedule still runs; over sockets between processes
     #  that share the GPU an iteration costs tens of milliseconds)
-    spec, K = "random:200000:100000:20", 40 if graph else (8 if world >= 4 else 20)
+    spec, K = "random:200000:100000:20", 40 if graph else (8 if world >= 3 else 20)
     env = {**os.environ, "LSQR_BENCH_STRONG_REF": "0", "LSQRHIP_SHARD_OVERLAP": overlap, "LSQR_RANKS_SHARE_GPU": "1",
            "LSQR_DIST_PROBE_TIMEOUT": "300"}
     if overlap == "":

@@ -23,7 +23,7 @@ pytestmark = pytest.mark.gpu
 CASES = [
     # name, spec, (row0, nrows) or None, iterations, host GB needed
     ("config5_powerlaw_full", "powerlaw:5000000:2000000:10000", None, 10, 8),
-    ("config4_one_rank_of_8", "random:10000000:10000000:100", (0, 1250000), 8, 10),
+    ("config4_one_rank_of_8", "random:10000000:10000000:100", (0, 1250000), 6, 10),
     ("config3_100_per_row", "random:4000000:1000000:100", None, 6, 24),
 ]
 
