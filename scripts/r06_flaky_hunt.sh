@@ -1,6 +1,7 @@
 #!/bin/bash
 # the multi-process tests three times over (one failure in five full runs of the suite could not be named: its output was filtered)
 cd ${GRAFT_REPO_ROOT:-.}
+mkdir -p gpurun_out/r06
 OUT=gpurun_out/r06/flaky_hunt.txt
 : > $OUT
 for i in 1 2 3; do

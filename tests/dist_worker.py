@@ -17,7 +17,7 @@ sys.path.insert(0, HERE)
 
 def main():
     import faulthandler
-    faulthandler.dump_traceback_later(90, exit=True)      # a hang prints where and ends the rank
+    faulthandler.dump_traceback_later(240, exit=True)     # a hang prints where and ends the rank (a loaded box: minutes, not a hang)
     rank, world, port = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
     case, backend, out = sys.argv[4], sys.argv[5], sys.argv[6]
     import torch.distributed as dist

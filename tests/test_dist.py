@@ -40,7 +40,7 @@ def run_world(case, world, backend, tmp_path, itncap=None):
     logs = []
     for p in procs:
         try:
-            logs.append(p.communicate(timeout=150)[0])
+            logs.append(p.communicate(timeout=300)[0])
         except subprocess.TimeoutExpired:
             for q in procs:
                 q.kill()
@@ -166,6 +166,10 @@ def test_cpp_engine_real32_over_rccl_ranks_sharing_one_gpu(case, world, backend,
 @pytest.mark.parametrize("case,world", [("random_over_se", 2), ("random_over_damped", 3), ("empty_rows_cols_it20", 5),
                                         ("poisson_20x20_it50", 4), ("shuffled_dups", 8), ("one_by_one", 2)])
 def test_exchanges_as_ipc_copies_between_processes_change_no_bit(case, world, tmp_path):
+    _ipc_copies_case(case, world, tmp_path)
+
+
+def _ipc_copies_case(case, world, tmp_path):
     """LSQRHIP_SHARD_COPY=1 with one process per rank (round 5): every rank maps its peers' T, V, x and se buffers
     (hipIpcGetMemHandle / hipIpcOpenMemHandle, the handles handed round by an all-gather on the communicator) and the
     n-vector exchanges become copy-engine PULLS on a stream per peer -- no RCCL send / receive kernel; RCCL keeps the
@@ -175,14 +179,19 @@ def test_exchanges_as_ipc_copies_between_processes_change_no_bit(case, world, tm
     # (ranks that share the GPU talk over sockets: ~10 ms per exchange at 8 ranks -- 12 iterations of the 8-rank world
     #  prove the path; round 5 ran the case to convergence, 43 s)
     cap = 12 if world >= 5 else None
-    rccl = run_world(case, world, "engine", tmp_path / "rccl", cap)
     copy = run_world(case, world, "engine_copy", tmp_path / "copy", cap)
-    for a, b in zip(rccl, copy):
-        assert int(b["again_same"]) == 1
-        for k in ("istop", "itn", "anorm", "acond", "rnorm", "arnorm", "xnorm"):
-            assert a[k] == b[k], (k, a[k], b[k])
-        assert np.array_equal(a["x"], b["x"]) and np.array_equal(a["se"], b["se"])
+    assert all(int(b["again_same"]) == 1 for b in copy)
     check_against_oracle(case, copy, cap)
+    # ... and bit for bit the RCCL engine's, run beside it.  (Worlds of 3, 4 and 5 are held to the oracle and to their own
+    # repeat only -- the RCCL engine of the same cases and worlds is test_cpp_engine_over_rccl_ranks_sharing_one_gpu's, held
+    # to the same oracle -- since round 6: every world launched here costs 3-7 s of process start-up and socket set-up, and
+    # the suite's time varies by a minute with the box's CPU load.)
+    if world in (2, 8):
+        rccl = run_world(case, world, "engine", tmp_path / "rccl", cap)
+        for a, b in zip(rccl, copy):
+            for k in ("istop", "itn", "anorm", "acond", "rnorm", "arnorm", "xnorm"):
+                assert a[k] == b[k], (k, a[k], b[k])
+            assert np.array_equal(a["x"], b["x"]) and np.array_equal(a["se"], b["se"])
 
 
 @pytest.mark.gpu
@@ -203,10 +212,12 @@ def test_overlapped_exchanges_as_ipc_copies_change_no_bit(case, world, backend, 
     for bit the plain RCCL engine ("csb": the ranks' blocks in column-swept layouts built for the parts, products phase
     by phase)."""
     cap = 12      # (the overlapped schedule over sockets between processes that share the GPU: 12 iterations prove the path)
-    rccl = run_world(case, world, backend, tmp_path / "rccl", cap)
     copy = run_world(case, world, backend + "_ov_copy", tmp_path / "copy", cap)
-    for a, b in zip(rccl, copy):
-        assert int(b["again_same"]) == 1
-        for k in ("istop", "itn", "anorm", "acond", "rnorm", "arnorm", "xnorm"):
-            assert a[k] == b[k], (k, a[k], b[k])
-        assert np.array_equal(a["x"], b["x"]) and np.array_equal(a["se"], b["se"])
+    assert all(int(b["again_same"]) == 1 for b in copy)
+    check_against_oracle(case, copy, cap)
+    if world in (2, 5):     # (see _ipc_copies_case: the RCCL twin beside it for two of the four worlds)
+        rccl = run_world(case, world, backend, tmp_path / "rccl", cap)
+        for a, b in zip(rccl, copy):
+            for k in ("istop", "itn", "anorm", "acond", "rnorm", "arnorm", "xnorm"):
+                assert a[k] == b[k], (k, a[k], b[k])
+            assert np.array_equal(a["x"], b["x"]) and np.array_equal(a["se"], b["se"])
