@@ -62,7 +62,7 @@ COMPACT_CONFIGS = [
     ("random:1250000:10000000:100", 60, 6, "configs[3] rank block N=8", True),
     ("random:1250000:10000000:1000", 10, 2, "configs[3] rank block N=8 at r=1000", False),
 ]
-CHILD_TIMEOUT = 420        # seconds for the configs[] child
+CHILD_TIMEOUT = 240        # seconds for the configs[] child (it takes ~20)
 
 
 def parse():
@@ -438,7 +438,7 @@ def pmc_child(counter: str):
     print("PMC_MANIFEST " + json.dumps(manifest), flush=True)
 
 
-def live_traffic(plan, timeout=600):
+def live_traffic(plan, timeout=180):
     """{(spec, env-json): {bytes_per_launch, fetch_bytes, write_bytes}}.  FETCH_SIZE and WRITE_SIZE are
     collected in passes of their own (TCC slots); FETCH_SIZE is doubled (gfx950 tallies 128-byte
     requests at 64 bytes, MI355X_MICROARCH.md "HBM").  Returns ({}, reason) when rocprofv3 cannot run."""
