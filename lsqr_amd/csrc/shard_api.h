@@ -352,6 +352,7 @@ extern "C" int lsqrhip_shard_begin(lsqrhip_handle_t h, const double *d_b_local, 
     if (!c.wsq) HIPCHK(hipMalloc((void **)&c.wsq, sizeof(double)));
     if (!c.live) HIPCHK(hipMalloc((void **)&c.live, sizeof(int)));
     RET(prepare_log(h, itnlim, c.want_log));
+    RET(reset_csb_tickets(h));   // (solve_loop.h: a previous engine solve may have been abandoned between two phases of a product)
     LsqrState init;
     std::memset(&init, 0, sizeof(init));
     init.itnlim = itnlim;

@@ -827,6 +827,19 @@ static int ensure_graph(H *h, int G, int wantse)
 // ---------------------------------------------------------------------------
 // pieces of a solve shared by the matrix path (solve_core) and the operator path (op_api.h)
 // ---------------------------------------------------------------------------
+// Column splits closed by their last arriver (csb.h) keep a ticket and flags per row block, which every product returns
+// to zero -- unless a product was abandoned between its launches (an engine solve that failed between two phases of a
+// product: the remaining phases are never launched).  A solve must not inherit that: a few KB cleared on the handle's stream
+// in front of every solve (the accumulated coarse sums zc of such an abandoned product -- used only for outliers of x --
+// are NOT cleared: they cost 8 bytes per row).
+static int reset_csb_tickets(H *h)
+{
+    for (Csr *c : {&h->A, &h->AT})
+        if (c->csb && c->S > 1 && c->cfuse && c->cbad != nullptr)
+            HIPCHK(hipMemsetAsync(c->cbad, 0, sizeof(int) * (size_t)c->nrb * CSB_QMAX, h->stream));
+    return LSQRHIP_OK;
+}
+
 static int prepare_log(H *h, int itnlim, int want_log)
 {
     if (want_log) {
@@ -986,6 +999,7 @@ static int solve_core(H *h, const double *b, bool b_on_device, double damp, doub
     // x of a device-resident solve is copied out by the batch that raises the stop flag (vec.h k_out_copy)
     const bool dev_out = graph && h->poll_ahead && h->pipeline != 0 && out_on_device && !wantse && h->n > 0;
     RET(prepare_log(h, itnlim, want_log));
+    RET(reset_csb_tickets(h));
     RET(upload_initial_state(h, damp, atol, btol, conlim, itnlim, wantse, want_log, dev_out ? (void *)x : nullptr));
 
     if (graph) RET(ensure_graph(h, G, wantse));   // before anything of THIS solve is enqueued (capture)
