@@ -374,7 +374,7 @@ def configs_child():
             continue
         try:
             rec = measure_workload(spec, K, W, note=tag, engine=engine)
-        except BaseException as e:      # noqa: BLE001
+        except (Exception, SystemExit) as e:      # noqa: BLE001  (one entry's failure costs that entry)
             rec = {"spec": spec, "error": repr(e)}
         rec["tag"] = tag
         recs.append(rec)
