@@ -276,7 +276,7 @@ int lsqrhip_set_option(lsqrhip_handle_t h, const char *name, int64_t value);
  * in use (two-byte pattern numbers; 0: the one-byte table or another layout); "pat_pair_mode1" / "_mode2" -- 1 when the
  * row-pattern product runs in paired rows (a lane owns two neighbouring rows: DESIGN.md 3.4b).
  * Round 6: "csb_fuse_mode1" / "_mode2" -- 1 when a column-split product is closed by its last arriving split inside the
- * sweep launch (no k_csb_combine launch; LSQRHIP_CSB_FUSE=0 at create restores it); "csb_probe_mode1" /
+ * sweep launch (no k_csb_combine launch: the build's choice for two splits per block; LSQRHIP_CSB_FUSE=0 / 1 forces); "csb_probe_mode1" /
  * "_mode2" -- device address of the product's phase clocks when the handle was created with LSQRHIP_CSB_PROBE=1
  * (measurement only: scripts/csb_probe.py), else 0. */
 int lsqrhip_get_option(lsqrhip_handle_t h, const char *name, int64_t *value);

@@ -61,7 +61,9 @@
 //     closes the block, so y, the block's partial of sum y^2 (ONE per block, the unsplit kernel's thread -> row mapping)
 //     and the piece maxima are bit for bit those of S = 1.  No spinning: nobody waits for anybody.  A solve that stops
 //     while the product is under way (some splits saw the flag, some not) is told by the ticket's high half: the last
-//     arriver then only cleans up (zc, flags, ticket).  LSQRHIP_CSB_FUSE=0 at create: the combine launch.
+//     arriver then only cleans up (zc, flags, ticket).  Chosen for blocks of TWO splits; from three on one closer's CU is the
+//     bottleneck and k_csb_combine (below), which spreads the same bytes over the chip, stays 2-4 % ahead
+//     (profiles/r06/fuse_by_splits_and_harness_noise.txt).  LSQRHIP_CSB_FUSE=0 / 1 at create forces either.
 //   * LOCK STEP (round 5).  A CU's vector L1 returns data in REQUEST ORDER across all its waves: a gathered line of x
 //     that L2 had ready in ~250 cycles, queued behind another wave's stream line from HBM (~900), waits for that one
 //     and holds its slot meanwhile.  Rounds 2-4 let every wave run on its own (next chunk's stream requested right

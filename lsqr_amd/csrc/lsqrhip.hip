@@ -1426,7 +1426,13 @@ static int build_csb(hipStream_t s, const int *rowk, const int *colk, const doub
         if (S_plain == 1) out.Q = 1;
         // round 6: the split that arrives last at the block's ticket closes the block (csb.h) -- one partial per block,
         // the unsplit kernel's thread -> row mapping: norms bit for bit those of S = 1, and no second launch
-        out.cfuse = env_int("LSQRHIP_CSB_FUSE", 1) != 0 ? 1 : 0;
+        // ... where a block has TWO splits: the closer then pulls its own share and one other through its CU (config 5
+        // transposed 320 -> 313 us, the block of a rank of four 642 -> 627).  From three splits on ONE closer's CU is the
+        // bottleneck (0.85 MB through ~25 GB/s: 30 us for a full block at S = 4) and the combine launch, which spreads the same
+        // bytes over the chip, stays 2-4 % ahead (a rank of eight's block 344 against 352-361 us:
+        // profiles/r06/fuse_by_splits_and_harness_noise.txt).  LSQRHIP_CSB_FUSE=0 / 1 forces either.
+        const int fenv = env_int("LSQRHIP_CSB_FUSE", -1);
+        out.cfuse = fenv >= 0 ? (fenv != 0 ? 1 : 0) : (S == 2 ? 1 : 0);
         if (out.cfuse) out.Q = 1;
     }
     if (env_int("LSQRHIP_CSB_PROBE", 0) != 0) {

@@ -146,7 +146,7 @@ def test_the_last_split_closes_the_block_bit_for_bit_and_every_time(csb_env):
     p = P.random_rows(60000, 200000, 16, seed=21, damp=1e-3)
     os.environ.pop("LSQRHIP_CSB_FUSE", None)
     made = {}
-    for S, fuse in ((1, None), (4, None), (8, None), (4, "0")):
+    for S, fuse in ((1, None), (4, "1"), (8, "1"), (2, None), (4, "0")):     # (None: the build's own choice -- fused for S = 2)
         csb_env(938)
         os.environ["LSQRHIP_CSB_S"] = str(S)
         if fuse is not None:
@@ -157,7 +157,7 @@ def test_the_last_split_closes_the_block_bit_for_bit_and_every_time(csb_env):
             os.environ.pop("LSQRHIP_CSB_FUSE", None)
             os.environ.pop("LSQRHIP_CSB_S", None)
         assert s.info()["xlds"] == 3 and s.get_option("csb_splits_mode1") == S and s.get_option("csb_blocks_mode1") == 64
-        assert s.get_option("csb_fuse_mode1") == (1 if S > 1 and fuse is None else 0)
+        assert s.get_option("csb_fuse_mode1") == (0 if S == 1 else (1 if fuse == "1" or (fuse is None and S == 2) else 0))
         # rounds of 256 units (64 blocks x S splits), and no launch behind them where the splits close their blocks themselves
         assert s.get_option("launches_mode1") == (64 * S + 255) // 256 + (1 if fuse == "0" else 0)
         made[(S, fuse)] = s
@@ -173,7 +173,7 @@ def test_the_last_split_closes_the_block_bit_for_bit_and_every_time(csb_env):
         for y in outs[1:]:
             assert np.array_equal(y, outs[0]), k
     ref = made[(1, None)].solve(p.b, p.damp)
-    for key in ((4, None), (8, None)):
+    for key in ((4, "1"), (8, "1"), (2, None)):
         r = made[key].solve(p.b, p.damp)
         assert (r.istop, r.itn, r.anorm, r.rnorm, r.xnorm) == (ref.istop, ref.itn, ref.anorm, ref.rnorm, ref.xnorm), key
         assert np.array_equal(r.x, ref.x), key
