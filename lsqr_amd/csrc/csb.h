@@ -132,6 +132,15 @@ constexpr int CSB_XHIST = 64;                    // product: piece maxima of x b
 #define CSB_BARRIER_A 0   // lock step: a second barrier in front of the gathers (round 5's first form; slower)
 #endif
 
+// What the sweeps of a column-split product hand to its combine launch (round 6): the coefficients and the two grids every
+// workgroup of the product derives from the same partials -- written by the first workgroup of every sweep launch (all the
+// same values), read by k_csb_combine instead of deriving them once more (two reductions over up to 2048 partials and 4096
+// piece maxima and a histogram: 4-5 us of a launch that lives 20).
+struct CsbHand {
+    double sx, sy, cy;
+    int ef, ec, skip, pad;
+};
+
 struct CsbMat {
     const void *val;        // VT values (double; float for a REAL32 handle), each row scaled by 2^-rexp[row]
     const unsigned *idx;    // wide: [nchunks * 256] lrow << 17 | lcol; narrow: [nchunks * 64] pairs of words = a lane's 4 u16 rows
@@ -162,6 +171,7 @@ struct CsbMat {
                                // of this launch's phases, written by thread 0 for the workgroup's first unit:
                                // 0 entry | 1 coefficients | 2 grids + clear (sweep begins) | 3 sweep done | 4 sums published + ticket
                                // | 5 epilogue done | 6 (last arriver: 1) | 7 unused
+    CsbHand *hand;             // S > 1 with the combine launch: see CsbHand (or null)
     int fuse;                  // S > 1: the split of a block that arrives last at the block's ticket runs the block's epilogue
                                // itself, from its own LDS sums + the other splits' z (no k_csb_combine launch)
 };
@@ -858,7 +868,11 @@ __global__ __launch_bounds__(CSB_BLOCK, 1) void k_spmv_csb(
         slot_out->nrm = co.nrm;
         slot_out->scale = co.skip ? 1.0 : co.sx;
     }
-    if (co.skip) return;
+    const bool handoff = A.hand != nullptr && A.S > 1 && !fused && wg == 0 && tid == 0;
+    if (co.skip) {
+        if (handoff) A.hand->skip = 1;
+        return;
+    }
     const double sx = co.sx, sy = co.sy, cy = co.cy;
     if (pb) pb[1] = wall_clock64();
 
@@ -868,6 +882,7 @@ __global__ __launch_bounds__(CSB_BLOCK, 1) void k_spmv_csb(
     const double ginv = ldexp(1.0, 61 - gr.ef);    // 1 / g of the fine grid
     const double pmax2 = ldexp(1.0, gr.ec);        // a product of a big column is in range below this
     const double ginv2 = ldexp(1.0, 61 - gr.ec);   // 1 / g of the coarse grid
+    if (handoff) *A.hand = CsbHand{sx, sy, cy, gr.ef, gr.ec, 0, 0};
 
     for (int i = tid; i < CSB_NACC; i += CSB_BLOCK) acc[i] = 0ull;
     if (tid == 0) {
@@ -1258,10 +1273,21 @@ __global__ __launch_bounds__(CSB_BLOCK) void k_csb_combine(
         }
         return;
     }
-    const CsbCoef co = csb_coef(coef, pin, npin, slot_in, skip_if_zero, nsc, red);
-    if (co.skip) return;
-    const double sx = co.sx, sy = co.sy, cy = co.cy;
-    const CsbGrid gr = csb_grids(xb, sx, red, hist);   // the sweeps' grids: same partials, same function
+    // the coefficients and the grids: handed over by the sweeps (CsbHand), or derived like theirs -- same partials, same functions
+    double sx, sy, cy;
+    CsbGrid gr;
+    if (A.hand != nullptr) {
+        const CsbHand hd = *A.hand;
+        if (hd.skip) return;
+        sx = hd.sx; sy = hd.sy; cy = hd.cy;
+        gr.ef = hd.ef; gr.ec = hd.ec;
+        __syncthreads();   // (gmx is zero before its first use)
+    } else {
+        const CsbCoef co = csb_coef(coef, pin, npin, slot_in, skip_if_zero, nsc, red);
+        if (co.skip) return;
+        sx = co.sx; sy = co.sy; cy = co.cy;
+        gr = csb_grids(xb, sx, red, hist);
+    }
     const VT *__restrict__ aval = static_cast<const VT *>(A.val);
     bool cleared = false;
     for (int u = blockIdx.x; u < A.nrb * Q; u += gridDim.x) {
@@ -1276,20 +1302,55 @@ __global__ __launch_bounds__(CSB_BLOCK) void k_csb_combine(
         const long long g_first = ((long long)row0 + rlo) >> pc.L;
         const int ng = rhi > rlo ? (int)((((long long)row0 + rhi - 1) >> pc.L) - g_first) + 1 : 0;
         const bool inlds = ng <= CSB_GMX;
-        for (int rb = rlo; rb < rhi; rb += CSB_BLOCK) {
-            const int r = rb + tid;
-            unsigned hv = 0u;
-            if (r < rhi) {
-                long long s = __builtin_nontemporal_load(&A.z[row0 + r]);
-                for (int sp = 1; sp < A.S; ++sp) s += __builtin_nontemporal_load(&A.z[(size_t)sp * A.rows + row0 + r]);
-                const double sum = csb_row_sum(A, s, row0 + r, gr, (flags & 2) != 0);
-                const VT yn = (VT)(cy * ((double)y[row0 + r] * sy) + sum);
-                y[row0 + r] = yn;
-                const double ys = (double)yn * nsc.s;
-                sq += ys * ys;
-                hv = csb_hi_up(fabs((double)yn));
+        // THREE steps' worth of loads -- the splits' sums, y, the rows' exponents -- are requested before any of them is used
+        // (round 6; like the sweep's epilogue since round 5): a workgroup's share of a full block (5088 rows at Q = 4) is
+        // TWO round trips to memory instead of five dependent ones of a launch that lives 22 us.
+        constexpr int CG = 3, ZB4 = 4;   // (five steps at once spilled 24 registers: three, i.e. two round trips for a share of 5088 rows)
+        const bool ykeep = cy != 0.0;   // (cy == 0: what y held does not enter the result and is not read, csb.h k_spmv_csb)
+        for (int rb0 = rlo; rb0 < rhi; rb0 += CG * CSB_BLOCK) {     // (every wave runs every step: csb_group_max is a wave operation)
+            VT yo[CG];
+            int eo[CG];
+            long long zs[CG];
+#pragma unroll
+            for (int i = 0; i < CG; ++i) {
+                const int r = rb0 + i * CSB_BLOCK + tid;
+                const bool in = r < rhi;
+                yo[i] = (in && ykeep) ? y[row0 + r] : (VT)0;
+                eo[i] = in ? (int)A.rexp[row0 + r] : 0;
+                zs[i] = 0;
             }
-            if (pieces) csb_group_max(A.ymax, pc, gmx, inlds, g_first, (long long)row0 + rb + (tid & ~(WAVE - 1)), hv);
+            for (int k0 = 0; k0 < A.S; k0 += ZB4) {   // (uniform; S <= 4: once)
+                long long zv[ZB4][CG];
+#pragma unroll
+                for (int kk = 0; kk < ZB4; ++kk)
+#pragma unroll
+                    for (int i = 0; i < CG; ++i) {
+                        const int r = rb0 + i * CSB_BLOCK + tid;
+                        zv[kk][i] = (k0 + kk < A.S && r < rhi)
+                                        ? __builtin_nontemporal_load(&A.z[(size_t)(k0 + kk) * A.rows + row0 + r]) : 0;
+                    }
+#pragma unroll
+                for (int kk = 0; kk < ZB4; ++kk)
+#pragma unroll
+                    for (int i = 0; i < CG; ++i) zs[i] += zv[kk][i];
+            }
+#pragma unroll
+            for (int i = 0; i < CG; ++i) {
+                const int rb = rb0 + i * CSB_BLOCK;
+                if (rb < rhi) {   // (uniform)
+                    const int r = rb + tid;
+                    unsigned hv = 0u;
+                    if (r < rhi) {
+                        const double sum = csb_row_sum(A, zs[i], row0 + r, gr, (flags & 2) != 0, eo[i]);
+                        const VT yn = (VT)(cy * ((double)yo[i] * sy) + sum);
+                        y[row0 + r] = yn;
+                        const double ys = (double)yn * nsc.s;
+                        sq += ys * ys;
+                        hv = csb_hi_up(fabs((double)yn));
+                    }
+                    if (pieces) csb_group_max(A.ymax, pc, gmx, inlds, g_first, (long long)row0 + rb + (tid & ~(WAVE - 1)), hv);
+                }
+            }
         }
         if (flags & 1) {  // a split of this block left products out
             if (!cleared) {

@@ -201,6 +201,7 @@ struct Csr {
     long long *zsplit = nullptr;  // S > 1: [S][rows] exact integer sums of the splits
     int *cbad = nullptr;          // S > 1: [nrb][CSB_QMAX] "a split left a product out / used the coarse sums" flags (csb.h)
     int Q = 1;                    // S > 1: workgroups of k_csb_combine per row block
+    void *chand = nullptr;        // S > 1 with the combine launch: the sweeps' coefficients and grids for k_csb_combine (csb.h CsbHand)
     unsigned long long *cprobe = nullptr;   // LSQRHIP_CSB_PROBE=1 (measurement only): [CSB_PROBE_LAUNCHES][CSB_PROBE_WGS][8] phase clocks (csb.h)
     int cfuse = 0;                // S > 1: no k_csb_combine launch -- the split of a block that arrives LAST runs the block's epilogue
                                   // itself (csb.h "the last split closes the block"; LSQRHIP_CSB_FUSE=0: the combine launch of rounds 2-5)
@@ -408,6 +409,7 @@ static void free_csr(Csr &c)
     if (c.zcoarse) (void)hipFree(c.zcoarse);
     if (c.cbad) (void)hipFree(c.cbad);
     if (c.cprobe) (void)hipFree(c.cprobe);
+    if (c.chand) (void)hipFree(c.chand);
     c = Csr();
 }
 
@@ -1434,6 +1436,10 @@ static int build_csb(hipStream_t s, const int *rowk, const int *colk, const doub
         const int fenv = env_int("LSQRHIP_CSB_FUSE", -1);
         out.cfuse = fenv >= 0 ? (fenv != 0 ? 1 : 0) : (S == 2 ? 1 : 0);
         if (out.cfuse) out.Q = 1;
+        else if (env_int("LSQRHIP_CSB_HAND", 1) != 0) {   // (=0: the combine launch derives coefficients and grids itself, as in rounds 2-5)
+            HIPCHK(hipMalloc(&out.chand, 64));
+            HIPCHK(hipMemsetAsync(out.chand, 0, 64, s));
+        }
     }
     if (env_int("LSQRHIP_CSB_PROBE", 0) != 0) {
         HIPCHK(hipMalloc((void **)&out.cprobe, sizeof(unsigned long long) * CSB_PROBE_LAUNCHES * CSB_PROBE_WGS * 8));
