@@ -171,7 +171,8 @@ struct CsbMat {
                                // of this launch's phases, written by thread 0 for the workgroup's first unit:
                                // 0 entry | 1 coefficients | 2 grids + clear (sweep begins) | 3 sweep done | 4 sums published + ticket
                                // | 5 epilogue done | 6 (last arriver: 1) | 7 unused
-    CsbHand *hand;             // S > 1 with the combine launch: see CsbHand (or null)
+    CsbHand *hand;             // see CsbHand (or null): written by the first workgroup of a product's FIRST sweep launch ...
+    int hand_read;             // ... and read by its later launches (further rounds, phases) when this is set, and by k_csb_combine
     int fuse;                  // S > 1: the split of a block that arrives last at the block's ticket runs the block's epilogue
                                // itself, from its own LDS sums + the other splits' z (no k_csb_combine launch)
 };
@@ -863,26 +864,40 @@ __global__ __launch_bounds__(CSB_BLOCK, 1) void k_spmv_csb(
     if (xb.clr != nullptr)
         for (int i = wg * CSB_BLOCK + tid; i < xb.nxmax; i += nwg * CSB_BLOCK) xb.clr[i] = 0ull;
 
-    const CsbCoef co = csb_coef(coef, pin, npin, slot_in, skip_if_zero, nsc, red);
-    if (pin != nullptr && wg == 0 && tid == 0) {
-        slot_out->nrm = co.nrm;
-        slot_out->scale = co.skip ? 1.0 : co.sx;
+    // The coefficients and the two grids are the same in every workgroup of every launch of a product (same partials, same
+    // piece maxima, same functions).  The product's FIRST launch derives them and its first workgroup leaves them in
+    // A.hand; later launches of the product -- the second round of row blocks, the phases of the overlap plan -- and the
+    // combine launch READ them (a kernel boundary lies between): two reductions over up to 2048 partials and 4096 piece
+    // maxima and a histogram less, 4-5 us per launch.
+    double sx, sy, cy;
+    CsbGrid gr;
+    if (A.hand != nullptr && A.hand_read) {
+        const CsbHand hd = *A.hand;
+        if (hd.skip) return;
+        sx = hd.sx; sy = hd.sy; cy = hd.cy;
+        gr.ef = hd.ef; gr.ec = hd.ec;
+        if (pb) pb[1] = wall_clock64();
+    } else {
+        const CsbCoef co = csb_coef(coef, pin, npin, slot_in, skip_if_zero, nsc, red);
+        if (pin != nullptr && wg == 0 && tid == 0) {
+            slot_out->nrm = co.nrm;
+            slot_out->scale = co.skip ? 1.0 : co.sx;
+        }
+        const bool handoff = A.hand != nullptr && wg == 0 && tid == 0;
+        if (co.skip) {
+            if (handoff) A.hand->skip = 1;
+            return;
+        }
+        sx = co.sx; sy = co.sy; cy = co.cy;
+        if (pb) pb[1] = wall_clock64();
+        // the binary grids of this launch (the histogram of the piece maxima borrows the accumulators' space)
+        gr = csb_grids(xb, sx, red, reinterpret_cast<int *>(acc));
+        if (handoff) *A.hand = CsbHand{sx, sy, cy, gr.ef, gr.ec, 0, 0};
     }
-    const bool handoff = A.hand != nullptr && A.S > 1 && !fused && wg == 0 && tid == 0;
-    if (co.skip) {
-        if (handoff) A.hand->skip = 1;
-        return;
-    }
-    const double sx = co.sx, sy = co.sy, cy = co.cy;
-    if (pb) pb[1] = wall_clock64();
-
-    // the binary grids of this launch (the histogram of the piece maxima borrows the accumulators' space)
-    const CsbGrid gr = csb_grids(xb, sx, red, reinterpret_cast<int *>(acc));
     const double tau = ldexp(1.0, gr.ef);          // columns with |x sx| below this: the LDS sums
     const double ginv = ldexp(1.0, 61 - gr.ef);    // 1 / g of the fine grid
     const double pmax2 = ldexp(1.0, gr.ec);        // a product of a big column is in range below this
     const double ginv2 = ldexp(1.0, 61 - gr.ec);   // 1 / g of the coarse grid
-    if (handoff) *A.hand = CsbHand{sx, sy, cy, gr.ef, gr.ec, 0, 0};
 
     for (int i = tid; i < CSB_NACC; i += CSB_BLOCK) acc[i] = 0ull;
     if (tid == 0) {

@@ -1436,10 +1436,10 @@ static int build_csb(hipStream_t s, const int *rowk, const int *colk, const doub
         const int fenv = env_int("LSQRHIP_CSB_FUSE", -1);
         out.cfuse = fenv >= 0 ? (fenv != 0 ? 1 : 0) : (S == 2 ? 1 : 0);
         if (out.cfuse) out.Q = 1;
-        else if (env_int("LSQRHIP_CSB_HAND", 1) != 0) {   // (=0: the combine launch derives coefficients and grids itself, as in rounds 2-5)
-            HIPCHK(hipMalloc(&out.chand, 64));
-            HIPCHK(hipMemsetAsync(out.chand, 0, 64, s));
-        }
+    }
+    if (env_int("LSQRHIP_CSB_HAND", 1) != 0) {   // (=0: every launch of a product derives coefficients and grids itself, as in rounds 2-5)
+        HIPCHK(hipMalloc(&out.chand, 64));
+        HIPCHK(hipMemsetAsync(out.chand, 0, 64, s));
     }
     if (env_int("LSQRHIP_CSB_PROBE", 0) != 0) {
         HIPCHK(hipMalloc((void **)&out.cprobe, sizeof(unsigned long long) * CSB_PROBE_LAUNCHES * CSB_PROBE_WGS * 8));

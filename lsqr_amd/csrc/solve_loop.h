@@ -371,7 +371,7 @@ static void launch_csb_K(H *h, const SpmvArgs &a)
     const int S = std::max(c.S, 1);
     CsbMat A{c.cval, c.cidx, c.cdel, c.ccb, c.cptr, c.crs, c.nrb, c.R, c.rows, c.cols, c.rexp, c.zcoarse, 0, 0, S, c.zsplit,
              c.cbad, std::max(c.Q, 1), c.gptr, c.NS, c.G, c.J, c.Pst, c.border, 0, S, c.cbarrier_a, c.cstagger,
-             reinterpret_cast<unsigned long long *>(a.ymax_out), nullptr, reinterpret_cast<CsbHand *>(c.chand), (S > 1 && c.cfuse) ? 1 : 0};
+             reinterpret_cast<unsigned long long *>(a.ymax_out), nullptr, reinterpret_cast<CsbHand *>(c.chand), 0, (S > 1 && c.cfuse) ? 1 : 0};
     int probe_launch = 0;   // (LSQRHIP_CSB_PROBE=1: the phase clocks of this product's first launches)
     const bool fused = A.fuse != 0;   // the last split of a block closes it inside the sweep launch: no k_csb_combine
     bool first = head;
@@ -391,6 +391,7 @@ static void launch_csb_K(H *h, const SpmvArgs &a)
             const bool last = tail && ph == ph1 - 1 && b1 >= p1;
             A.b0 = b0;
             A.b1 = b1;
+            A.hand_read = first ? 0 : 1;   // (the product's first launch derives coefficients and grids, the others read them)
             A.probe = (c.cprobe != nullptr && probe_launch < CSB_PROBE_LAUNCHES) ? c.cprobe + (size_t)probe_launch * CSB_PROBE_WGS * 8 : nullptr;
             ++probe_launch;
             Rider rider = first ? a.rider : Rider{};
