@@ -181,6 +181,36 @@ def test_the_last_split_closes_the_block_bit_for_bit_and_every_time(csb_env):
     assert r.itn == ref.itn and np.linalg.norm(r.x - ref.x) <= 1e-12 * np.linalg.norm(ref.x)
 
 
+def test_coefficients_and_grids_handed_from_launch_to_launch_change_no_bit(csb_env):
+    """Round 6 (csb.h CsbHand): the first launch of a column-swept product derives the coefficients and the two grids and
+    leaves them for the product's later launches -- further rounds of row blocks -- and for its combine launch, which used
+    to derive them again from the same partials and piece maxima.  Same numbers, so every bit of every product and solve
+    is that of LSQRHIP_CSB_HAND=0 (every launch for itself, as in rounds 2-5): rounds of 256 units with one, two (closed by
+    the last arriver) and three (combine launch) splits per block."""
+    p = P.random_rows(90000, 40000, 14, seed=33, damp=1e-3)
+    for S in (1, 2, 3):
+        outs = []
+        for hand in ("1", "0"):
+            csb_env(300)                      # 300 row blocks (mode 2: 134): several rounds of 256 units at every S
+            os.environ["LSQRHIP_CSB_S"] = str(S)
+            os.environ["LSQRHIP_CSB_HAND"] = hand
+            try:
+                s = lsqr_solver_ez().initialize(p.m, p.n, p.a, p.irow, p.icol, itnlim=30)
+            finally:
+                os.environ.pop("LSQRHIP_CSB_HAND", None)
+                os.environ.pop("LSQRHIP_CSB_S", None)
+            assert s.info()["xlds"] == 3 and s.get_option("launches_mode1") >= 2
+            xp, yp = vecs(p)
+            y = yp.copy(); s.aprod(1, p.m, p.n, xp.copy(), y)
+            x = xp.copy(); s.aprod(2, p.m, p.n, x, yp.copy())
+            r = s.solve(p.b, p.damp)
+            outs.append((y, x, r))
+        (y1, x1, r1), (y0, x0, r0) = outs
+        assert np.array_equal(y1, y0) and np.array_equal(x1, x0), S
+        assert (r1.istop, r1.itn, r1.anorm, r1.rnorm, r1.xnorm) == (r0.istop, r0.itn, r0.anorm, r0.rnorm, r0.xnorm), S
+        assert np.array_equal(r1.x, r0.x), S
+
+
 def test_a_block_too_empty_for_local_columns_falls_back(csb_env):
     """18-bit local columns need every chunk of 256 column-sorted nonzeros to span < 262144 columns.
     Three nonzeros per row over 600000 columns in blocks of 64 rows do not: the build must notice and
